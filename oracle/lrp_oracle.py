@@ -1,0 +1,483 @@
+"""CPU oracle for the LRP hot path  —  TEST INFRASTRUCTURE ONLY.
+
+A plain PyTorch-CPU fp32 restatement of the reference's relevance-propagation algorithm
+(SunJiamei/LRP-imagecaptioning-pytorch), written from the reference's formulas with every
+function citing the reference file:line it follows.  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import this module; the product path
+(`lrp-imagecaptioning-pytorch_amd/`) never does and fails loudly without its HIP library.
+
+Pinning: the reference ships no tests or golden vectors, so this oracle is pinned
+against outputs of the reference itself, generated in the build container by
+`tests/golden/make_golden.py` (imports /root/reference read-only) and committed under
+`tests/golden/*.npz`; `tests/test_oracle_golden.py` checks every one of them.
+
+All tensors are torch CPU float32.  Shapes follow the reference (batch-1 explainers); the VGG
+part additionally accepts N relevance maps that share one image's activations.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPSILON = 0.01        # LRPtools/utils.py:10
+Z_EPSILON = 1e-7      # LRPtools/utils.py:11
+
+# models/vgg.py:81 cfgs['D'] minus the last pool (models/gridTDmodel.py:34)
+VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]
+
+
+def _t(x):
+    return x if isinstance(x, torch.Tensor) else torch.from_numpy(x)
+
+
+def state_to_torch(sd):
+    return {k: _t(v).float() for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# LRPtools numerics
+# ----------------------------------------------------------------------------------------------
+def safe_divide(num, den):
+    """LRPtools/utils.py:16-18 — only exact zeros are stabilised."""
+    return num / (den + Z_EPSILON * (den == 0).float())
+
+
+def eps_stabilise(z):
+    """models/gridTDmodel.py:757-759 — z + eps*sign(z); exact zeros -> eps."""
+    zt = EPSILON * z.sign() + z
+    return torch.where(zt == 0, torch.full_like(zt, EPSILON), zt)
+
+
+def eps_identity(r, x, z):
+    """`lrp_linear_eps` with weight=eye (models/gridTDmodel.py:744-765 as used at :1051-1069):
+    R_in = (x / z~) * r, elementwise; broadcasting allowed."""
+    return (x / eps_stabilise(z)) * r
+
+
+def eps_dense(r, x, z, w):
+    """`lrp_linear_eps` with a real weight (models/gridTDmodel.py:744-765):
+    R_in[i] = sum_o (W[o,i]*x[i] / z~[o]) * r[o]  ==  x * (W^T (r / z~)).
+    r,z: (..., out); x: (..., in); w: (out, in)."""
+    return x * ((r / eps_stabilise(z)) @ w)
+
+
+def conv_alpha1beta0(x, w, r_out):
+    """LRPtools/lrp_modules.py:124-150 + utils.lrp_backward :21-31 with alpha=1, beta=0,
+    ignore_bias=True (lrp_wrapper.py:7-12): Z = conv(x+,w+) + conv(x-,w-);
+    S = safe_divide(R, Z); R_in = x+ * convT(S, w+) + x- * convT(S, w-).
+    x: (1 or N, Cin, H, W) activations; r_out: (N, Cout, H, W)."""
+    wp, wn = w.clamp(min=0), w.clamp(max=0)
+    xp, xn = x.clamp(min=0), x.clamp(max=0)
+    z = F.conv2d(xp, wp, padding=1) + F.conv2d(xn, wn, padding=1)
+    s = safe_divide(r_out, z)
+    cp = F.conv_transpose2d(s, wp, padding=1)
+    cn = F.conv_transpose2d(s, wn, padding=1)
+    return xp * cp + xn * cn
+
+
+def maxpool_rule(x, r_out):
+    """LRPtools/lrp_modules.py:182-195 for MaxPool2d(2,2): Z = maxpool(x); S = safe_divide(R, Z);
+    R_in = x * dZ/dx(S)  (winner-take-all; first maximum in row-major window order wins)."""
+    z, idx = F.max_pool2d(x, 2, 2, return_indices=True)
+    s = safe_divide(r_out, z)
+    if idx.shape[0] != s.shape[0]:
+        idx = idx.expand(s.shape[0], -1, -1, -1)
+    g = F.max_unpool2d(s, idx, 2, 2, output_size=x.shape[-2:])
+    return x * g
+
+
+# ----------------------------------------------------------------------------------------------
+# VGG16 encoder: forward trace and LRP (lrp_wrapper.compute_lrp, LRPtools/lrp_wrapper.py:63-87)
+# ----------------------------------------------------------------------------------------------
+def vgg_layers():
+    layers, idx, cin = [], 0, 3
+    for v in VGG16_CFG:
+        if v == 'M':
+            layers.append(('pool', idx, cin, cin))
+            idx += 1
+        else:
+            layers.append(('conv', idx, cin, v))
+            idx += 2
+            cin = v
+    return layers
+
+
+def vgg_forward(sd, img, prefix="img_encoder.encoder."):
+    """models/gridTDmodel.py:40-43 `Encoder.forward` for vgg16 (`features[0:-1]`, :33-34).
+    Returns (features (B,512,h,w), avg (B,512), [input of every conv/pool layer])."""
+    x = img
+    saved = []
+    for kind, idx, cin, cout in vgg_layers():
+        saved.append(x)
+        if kind == 'conv':
+            x = F.relu(F.conv2d(x, sd[f"{prefix}{idx}.weight"], sd[f"{prefix}{idx}.bias"], padding=1))
+        else:
+            x = F.max_pool2d(x, 2, 2)
+    return x, x.mean(dim=(2, 3)), saved
+
+
+def vgg_lrp(sd, saved, r_feat, prefix="img_encoder.encoder."):
+    """Relevance from the encoder output back to the pixels: reverse walk over the leaf modules
+    (LRPtools/lrp_wrapper.py:37-59: Conv2d -> alpha_beta, ReLU -> identity, MaxPool2d ->
+    Pool2d rule).  `saved[l]` holds ONE image's activations (1,C,H,W); r_feat is (N,512,h,w)."""
+    r = r_feat
+    for (kind, idx, cin, cout), x in zip(reversed(vgg_layers()), reversed(saved)):
+        if kind == 'conv':
+            r = conv_alpha1beta0(x, sd[f"{prefix}{idx}.weight"], r)
+        else:
+            r = maxpool_rule(x, r)
+    return r
+
+
+def vgg_guided_backprop(sd, saved, g_feat, prefix="img_encoder.encoder."):
+    """models/gridTDmodel.py:1677-1723: gradient of the encoder output w.r.t. the image with the
+    guided ReLU rule g_in = clamp(g_out, min=0) * [relu_out > 0] at every ReLU."""
+    layers = vgg_layers()
+    g = g_feat
+    for li in range(len(layers) - 1, -1, -1):
+        kind, idx, cin, cout = layers[li]
+        x = saved[li]
+        if kind == 'conv':
+            w, b = sd[f"{prefix}{idx}.weight"], sd[f"{prefix}{idx}.bias"]
+            y = F.relu(F.conv2d(x, w, b, padding=1))
+            g = g.clamp(min=0) * (y > 0).float()
+            g = F.conv_transpose2d(g, w, padding=1)
+        else:
+            z, pidx = F.max_pool2d(x, 2, 2, return_indices=True)
+            if pidx.shape[0] != g.shape[0]:
+                pidx = pidx.expand(g.shape[0], -1, -1, -1)
+            g = F.max_unpool2d(g, pidx, 2, 2, output_size=x.shape[-2:])
+    return g
+
+
+# ----------------------------------------------------------------------------------------------
+# gridTD decoder (adaptive attention + two LSTMs)
+# ----------------------------------------------------------------------------------------------
+def _lstm_cell(x, h, c, w_ih, w_hh, bias):
+    """models/gridTDmodel.py:773-797: returns (h', c', z_g, sigmoid(z_i), sigmoid(z_f))."""
+    z = w_ih @ x + w_hh @ h + bias
+    zi, zf, zg, zo = z.chunk(4)
+    i, f = torch.sigmoid(zi), torch.sigmoid(zf)
+    c2 = f * c + i * torch.tanh(zg)
+    h2 = torch.sigmoid(zo) * torch.tanh(c2)
+    return h2, c2, zg, i, f
+
+
+def _adaptive_attention(sd, V, h, s):
+    """models/gridTDmodel.py:71-103 for one sample.  V: (P,H) projected pixels, h,s: (H,)."""
+    wv, bv = sd["AdaAttention.W_v_proj.weight"], sd["AdaAttention.W_v_proj.bias"]
+    ws, bs = sd["AdaAttention.W_s_proj.weight"], sd["AdaAttention.W_s_proj.bias"]
+    wg, wh = sd["AdaAttention.W_g_proj.weight"], sd["AdaAttention.w_h.weight"]
+    img_proj = V @ wv.t() + bv                         # (P,P)
+    h_proj = wg @ h                                    # (P,)
+    z = torch.tanh(img_proj + h_proj.unsqueeze(1)) @ wh.t()   # (P,1): ht_proj expanded over columns (:82)
+    alpha = torch.softmax(z, dim=0)                    # (P,1)
+    ctx = (V * alpha).sum(0)
+    att_s = wh @ torch.tanh(ws @ s + bs + h_proj)      # (1,)
+    alpha_hat = torch.softmax(torch.cat([z.squeeze(1), att_s]), dim=0)
+    beta = alpha_hat[-1]
+    ctx_hat = beta * s + (1 - beta) * ctx
+    return ctx_hat, ctx, alpha.squeeze(1), beta
+
+
+def gridtd_trace(sd, features, avg, caption, model_bias=False):
+    """models/gridTDmodel.py:933-1012 `get_hidden_parameters` for one image with a given caption
+    (`caption[0]` = <start>; T = len(caption)-1 words).  features (512,h,w), avg (512,).
+    Keeps the reference's quirks: LanguageLSTM adds bias_ih twice (:789); the sentinel gate uses
+    h_{t-1} (:982).  `model_bias=True` gives the MODEL's own forward instead
+    (`predict_next_word` :137-144 through nn.LSTMCell: bias_ih + bias_hh), used for decoding."""
+    Hd = sd["fc.weight"].shape[1]
+    C, hh, ww = features.shape
+    P = hh * ww
+    T = len(caption) - 1
+    F_pix = features.reshape(C, P).t().contiguous()                     # (P,C)
+    w_proj = sd["img_projector.weight"].reshape(Hd, C)
+    proj_pre = F_pix @ w_proj.t() + sd["img_projector.bias"]            # (P,H)
+    Vp = F.relu(proj_pre)
+    glob_pre = sd["global_img_feature_proj.weight"] @ avg + sd["global_img_feature_proj.bias"]
+    glob = F.relu(glob_pre)
+    a_wi, a_wh = sd["AdaLSTM.lstm_cell.weight_ih"], sd["AdaLSTM.lstm_cell.weight_hh"]
+    a_b = sd["AdaLSTM.lstm_cell.bias_hh"] + sd["AdaLSTM.lstm_cell.bias_ih"]
+    l_wi, l_wh = sd["LanguageLSTM.weight_ih"], sd["LanguageLSTM.weight_hh"]
+    l_b = sd["LanguageLSTM.bias_ih"] + sd["LanguageLSTM.bias_ih"]       # quirk (a)
+    if model_bias:
+        l_b = sd["LanguageLSTM.bias_ih"] + sd["LanguageLSTM.bias_hh"]
+    E = sd["embedding.weight"].shape[1]
+    tr = dict(T=T, P=P, F_pix=F_pix, avg=avg, proj_pre=proj_pre, Vp=Vp, glob_pre=glob_pre, glob=glob,
+              caption=list(int(c) for c in caption))
+    z = lambda *s: torch.zeros(*s)
+    for k in ("h1", "c1", "h2", "c2"):
+        tr[k] = z(T + 1, Hd)
+    for k in ("g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat"):
+        tr[k] = z(T, Hd)
+    tr["x1"], tr["x2"] = z(T, 2 * E + Hd), z(T, 2 * Hd)
+    tr["alpha"], tr["beta"] = z(T, P), z(T)
+    tr["pred"] = z(T, sd["fc.weight"].shape[0])
+    for t in range(T):
+        emb = sd["embedding.weight"][caption[t]]
+        x1 = torch.cat([tr["h2"][t], glob, emb])
+        h1, c1, g1, i1, f1 = _lstm_cell(x1, tr["h1"][t], tr["c1"][t], a_wi, a_wh, a_b)
+        gate = torch.sigmoid(sd["AdaLSTM.x_gate.weight"] @ x1 + sd["AdaLSTM.x_gate.bias"]
+                             + sd["AdaLSTM.h_gate.weight"] @ tr["h1"][t] + sd["AdaLSTM.h_gate.bias"])
+        s = gate * torch.tanh(c1)
+        ctx_hat, ctx, alpha, beta = _adaptive_attention(sd, Vp, h1, s)
+        x2 = torch.cat([ctx_hat, h1])
+        h2, c2, g2, i2, f2 = _lstm_cell(x2, tr["h2"][t], tr["c2"][t], l_wi, l_wh, l_b)
+        tr["pred"][t] = sd["fc.weight"] @ (ctx_hat + h2) + sd["fc.bias"]
+        tr["x1"][t], tr["x2"][t] = x1, x2
+        tr["h1"][t + 1], tr["c1"][t + 1], tr["g1"][t], tr["i1"][t], tr["f1"][t] = h1, c1, g1, i1, f1
+        tr["h2"][t + 1], tr["c2"][t + 1], tr["g2"][t], tr["i2"][t], tr["f2"][t] = h2, c2, g2, i2, f2
+        tr["s"][t], tr["ctx"][t], tr["ctx_hat"][t] = s, ctx, ctx_hat
+        tr["alpha"][t], tr["beta"][t] = alpha, beta
+    return tr
+
+
+def gridtd_greedy_caption(sd, features, avg, max_words, start_id, end_id):
+    """Greedy decoding with the explainer's forward (models/gridTDmodel.py:799-853
+    `forward_greedy`): argmax of the raw logits, stop at <end>.  Returns token ids incl. <start>."""
+    cap = [start_id]
+    for _ in range(max_words):
+        tr = gridtd_trace(sd, features, avg, cap + [0])
+        nxt = int(torch.argmax(tr["pred"][-1]))
+        if nxt == end_id:
+            break
+        cap.append(nxt)
+    return cap
+
+
+def gridtd_model_greedy(sd, img, max_cap_length, start_id, end_id):
+    """models/gridTDmodel.py:480-520 `greedy_search` for one image: argmax of log_softmax per step,
+    tokens after the first <end> are forced to 0 (:503-504); returns `seqs_temp[0]`
+    (max_cap_length ids incl. <start>)."""
+    feats, avg, _ = vgg_forward(sd, img)
+    seq, unfinished = [start_id], True
+    for step in range(max_cap_length - 1):
+        tr = gridtd_trace(sd, feats[0], avg[0], seq + [0], model_bias=True)
+        top = int(torch.argmax(torch.log_softmax(tr["pred"][-1], dim=-1)))
+        unfinished = unfinished and (top != end_id)
+        seq.append(top if unfinished else 0)
+    return seq
+
+
+def gridtd_explain_wordt(sd, tr, t):
+    """models/gridTDmodel.py:1014-1135 `explain_caption_wordt`.  Returns
+    (r_feat (P,C) relevance of the encoder features, r_words (t+1,))."""
+    Hd = tr["h1"].shape[1]
+    E = (tr["x1"].shape[1] - Hd) // 2
+    P = tr["P"]
+    k = tr["caption"][t + 1]
+    wg1 = torch.cat([sd["AdaLSTM.lstm_cell.weight_ih"].chunk(4, 0)[2],
+                     sd["AdaLSTM.lstm_cell.weight_hh"].chunk(4, 0)[2]], dim=1)      # (H, 2E+2H)
+    wg2 = torch.cat([sd["LanguageLSTM.weight_ih"].chunk(4, 0)[2],
+                     sd["LanguageLSTM.weight_hh"].chunk(4, 0)[2]], dim=1)           # (H, 3H)
+    xh1 = torch.cat([tr["x1"], tr["h1"][:-1]], dim=1)
+    xh2 = torch.cat([tr["x2"], tr["h2"][:-1]], dim=1)
+    n = t + 1
+    r_h1, r_c1 = torch.zeros(n + 1, Hd), torch.zeros(n + 1, Hd)
+    r_h2, r_c2 = torch.zeros(n + 1, Hd), torch.zeros(n + 1, Hd)
+    r_ctx_hat = torch.zeros(n, Hd)
+    r_glob = torch.zeros(E)
+    r_emb = torch.zeros(n, E)
+    r_proj = torch.zeros(P, Hd)
+    # fc: one-hot relevance = the target logit (:1033-1034, :1047-1050)
+    hc = tr["h2"][t + 1] + tr["ctx_hat"][t]
+    logit = tr["pred"][t][k]
+    r_hc = (sd["fc.weight"][k] * hc / eps_stabilise(logit)) * logit
+    r_h2[t + 1] = eps_identity(r_hc, tr["h2"][t + 1], hc)                 # :1051-1054
+    r_ctx_hat[t] = eps_identity(r_hc, tr["ctx_hat"][t], hc)               # :1056-1059
+    for i in range(t, -1, -1):
+        r_c2[i + 1] = r_c2[i + 1] + r_h2[i + 1]                           # :1061
+        r_g2 = eps_identity(r_c2[i + 1], tr["i2"][i] * torch.tanh(tr["g2"][i]), tr["c2"][i + 1])
+        r_c2[i] = eps_identity(r_c2[i + 1], tr["f2"][i] * tr["c2"][i], tr["c2"][i + 1])
+        r_xh2 = eps_dense(r_g2, xh2[i], tr["g2"][i], wg2)                 # :1070-1073
+        r_h2[i] = r_xh2[2 * Hd:]
+        r_h1[i + 1] = r_xh2[Hd:2 * Hd]
+        r_ctx_hat[i] = r_ctx_hat[i] + r_xh2[:Hd]
+        r_s = eps_identity(r_ctx_hat[i], tr["beta"][i] * tr["s"][i], tr["ctx_hat"][i])
+        r_ctx = eps_identity(r_ctx_hat[i], tr["ctx"][i] * (1 - tr["beta"][i]), tr["ctx_hat"][i])
+        # pixel spread (:1091-1095), all pixels at once
+        r_proj = r_proj + eps_identity(r_ctx.unsqueeze(0), tr["Vp"] * tr["alpha"][i].unsqueeze(1),
+                                       tr["ctx"][i].unsqueeze(0))
+        r_c1[i + 1] = r_c1[i + 1] + r_s
+        r_c1[i + 1] = r_c1[i + 1] + r_h1[i + 1]
+        r_g1 = eps_identity(r_c1[i + 1], tr["i1"][i] * torch.tanh(tr["g1"][i]), tr["c1"][i + 1])
+        r_c1[i] = eps_identity(r_c1[i + 1], tr["f1"][i] * tr["c1"][i], tr["c1"][i + 1])
+        r_xh1 = eps_dense(r_g1, xh1[i], tr["g1"][i], wg1)                 # :1106-1109
+        r_h1[i] = r_xh1[2 * E + Hd:]            # dead: overwritten by :1075 next iteration (quirk c)
+        r_h2[i] = r_h2[i] + r_xh1[:Hd]
+        r_glob = r_glob + r_xh1[Hd:Hd + E]
+        r_emb[i] = r_xh1[Hd + E:Hd + 2 * E]
+    r_avg = eps_dense(r_glob, tr["avg"], tr["glob_pre"], sd["global_img_feature_proj.weight"])
+    w_proj = sd["img_projector.weight"].reshape(Hd, -1)
+    r_feat = eps_identity(r_avg.unsqueeze(0), tr["F_pix"] / P, tr["avg"].unsqueeze(0)) \
+        + eps_dense(r_proj, tr["F_pix"], tr["proj_pre"], w_proj)          # :1120-1128
+    r_words = r_emb.sum(-1)
+    m = r_words.abs().max()
+    if m > 0:
+        r_words = r_words / m
+    return r_feat, r_words
+
+
+# ----------------------------------------------------------------------------------------------
+# gridTD guided-backprop decoder (models/gridTDmodel.py:1214-1422 trace, :1588-1675 backward)
+# ----------------------------------------------------------------------------------------------
+def gridtd_grad_trace(sd, features, avg, caption):
+    """models/gridTDmodel.py:1323-1422: the gradient explainers' trace.  Unlike the LRP trace the
+    LanguageLSTM bias is correct here (bias_ih + bias_hh, :1262-1274) and all four gate
+    activations are kept."""
+    raise NotImplementedError("filled in with the guided-backprop row (SURVEY §8(a) GB1-GB3)")
+
+
+# ----------------------------------------------------------------------------------------------
+# AoA decoder (multi-head attention on attention)
+# ----------------------------------------------------------------------------------------------
+def aoa_trace(sd, F_pix, caption, num_head=8):
+    """models/aoamodel.py:990-1062 `get_hidden_parameters` for one image.
+    F_pix: (P,C) encoder features, pixel-major.  Quirk: bias_ih added twice (:873)."""
+    Hd = sd["fc.weight"].shape[1]
+    P, C = F_pix.shape
+    T = len(caption) - 1
+    dk = Hd // num_head
+    w_proj = sd["img_projector.weight"].reshape(Hd, C)
+    proj_pre = F_pix @ w_proj.t() + sd["img_projector.bias"]
+    Vp = F.relu(proj_pre)
+    glob = Vp.mean(0)
+    key = Vp @ sd["decoder_k_proj.weight"].t() + sd["decoder_k_proj.bias"]
+    value = Vp @ sd["decoder_v_proj.weight"].t() + sd["decoder_v_proj.bias"]
+    l_wi, l_wh = sd["LanguageLSTM.weight_ih"], sd["LanguageLSTM.weight_hh"]
+    l_b = sd["LanguageLSTM.bias_ih"] + sd["LanguageLSTM.bias_ih"]
+    E = sd["embedding.weight"].shape[1]
+    z = lambda *s: torch.zeros(*s)
+    tr = dict(T=T, P=P, F_pix=F_pix, proj_pre=proj_pre, Vp=Vp, glob=glob, key=key, value=value,
+              caption=list(int(c) for c in caption), num_head=num_head)
+    tr["h"], tr["c"] = z(T + 1, Hd), z(T + 1, Hd)
+    for k in ("g", "i", "f", "ctx", "c_aoa", "c_aoa_lin", "c_aoa_gate"):
+        tr[k] = z(T, Hd)
+    tr["x"] = z(T, E + Hd)
+    tr["alpha"] = z(T, num_head, P)
+    tr["pred"] = z(T, sd["fc.weight"].shape[0])
+    kh = key.view(P, num_head, dk).transpose(0, 1)        # (heads,P,dk)
+    vh = value.view(P, num_head, dk).transpose(0, 1)
+    for t in range(T):
+        emb = sd["embedding.weight"][caption[t]]
+        x = torch.cat([emb, glob])
+        h, c, g, i, f = _lstm_cell(x, tr["h"][t], tr["c"][t], l_wi, l_wh, l_b)
+        q = sd["decoder_multihead_attention.q_proj.weight"] @ h + sd["decoder_multihead_attention.q_proj.bias"]
+        qh = q.view(num_head, 1, dk)
+        scores = (qh @ kh.transpose(1, 2)) / math.sqrt(dk)           # (heads,1,P)  aoamodel.py:77-85
+        alpha = torch.softmax(scores, dim=-1)
+        ctx = (alpha @ vh).reshape(Hd)
+        gate = sd["decoder_aoa_linear_gate.weight"] @ h + sd["decoder_aoa_linear_gate.bias"]
+        lin = sd["decoder_aoa_linear.weight"] @ ctx + sd["decoder_aoa_linear.bias"]
+        c_aoa = torch.sigmoid(gate) * lin
+        tr["pred"][t] = sd["fc.weight"] @ (c_aoa + h) + sd["fc.bias"]
+        tr["x"][t] = x
+        tr["h"][t + 1], tr["c"][t + 1], tr["g"][t], tr["i"][t], tr["f"][t] = h, c, g, i, f
+        tr["ctx"][t], tr["c_aoa"][t], tr["c_aoa_lin"][t], tr["c_aoa_gate"][t] = ctx, c_aoa, lin, gate
+        tr["alpha"][t] = alpha.squeeze(1)
+    return tr
+
+
+def aoa_explain_wordt(sd, tr, t, head_idx):
+    """models/aoamodel.py:1064-1156 `explain_caption_wordt` (+ `lrp_mha` :812-862).
+    Returns (r_feat (P,C), r_words (t+1,))."""
+    Hd = tr["h"].shape[1]
+    E = tr["x"].shape[1] - Hd
+    P, nh = tr["P"], tr["num_head"]
+    dk = Hd // nh
+    k = tr["caption"][t + 1]
+    wg = torch.cat([sd["LanguageLSTM.weight_ih"].chunk(4, 0)[2],
+                    sd["LanguageLSTM.weight_hh"].chunk(4, 0)[2]], dim=1)            # (H, E+2H)
+    xh = torch.cat([tr["x"], tr["h"][:-1]], dim=1)
+    n = t + 1
+    r_h = torch.zeros(n + 1, Hd)
+    r_emb = torch.zeros(n, E)
+    r_glob = torch.zeros(Hd)
+    hc = tr["h"][t + 1] + tr["c_aoa"][t]
+    logit = tr["pred"][t][k]
+    r_hc = (sd["fc.weight"][k] * hc / eps_stabilise(logit)) * logit                 # :1092-1095
+    r_h[t + 1] = eps_identity(r_hc, tr["h"][t + 1], hc)
+    r_caoa = eps_identity(r_hc, tr["c_aoa"][t], hc)
+    r_ctx = eps_dense(r_caoa, tr["ctx"][t], tr["c_aoa_lin"][t], sd["decoder_aoa_linear.weight"])  # :1107
+    # lrp_mha: only head `head_idx` receives relevance (:848-860)
+    r_value = torch.zeros(P, Hd)
+    sl = slice(head_idx * dk, (head_idx + 1) * dk)
+    r_value[:, sl] = eps_identity(r_ctx[sl].unsqueeze(0),
+                                  tr["value"][:, sl] * tr["alpha"][t][head_idx].unsqueeze(1),
+                                  tr["ctx"][t][sl].unsqueeze(0))
+    for i in range(t, -1, -1):
+        r_c = r_h[i + 1]                                                            # :1116 (assignment)
+        r_g = eps_identity(r_c, tr["i"][i] * torch.tanh(tr["g"][i]), tr["c"][i + 1])
+        r_xh = eps_dense(r_g, xh[i], tr["g"][i], wg)
+        r_h[i] = r_xh[Hd + E:]
+        r_emb[i] = r_xh[:E]
+        r_glob = r_glob + r_xh[E:E + Hd]
+    r_proj = eps_identity(r_glob.unsqueeze(0), tr["Vp"] / P, tr["glob"].unsqueeze(0)) \
+        + eps_dense(r_value, tr["Vp"], tr["value"], sd["decoder_v_proj.weight"])    # :1136-1144
+    w_proj = sd["img_projector.weight"].reshape(Hd, -1)
+    r_feat = eps_dense(r_proj, tr["F_pix"], tr["proj_pre"], w_proj)                 # :1145-1148
+    r_words = r_emb.sum(-1)
+    m = r_words.abs().max()
+    if m > 0:
+        r_words = r_words / m
+    return r_feat, r_words
+
+
+# ----------------------------------------------------------------------------------------------
+# whole-image drivers (models/gridTDmodel.py:1141-1156, models/aoamodel.py:1165-1181)
+# ----------------------------------------------------------------------------------------------
+def pix_to_nchw(r_feat, hw):
+    """(P,C) -> (1,C,h,w): the reference's `.unsqueeze(0).transpose(1,2).view(...)` (:1133)."""
+    P, C = r_feat.shape
+    return r_feat.t().reshape(1, C, hw[0], hw[1])
+
+
+def _accumulate(maps):
+    """Quirk (i), LRPtools/lrp_wrapper.py:64-82: `compute_lrp` reads `sample.grad` of the SAME leaf
+    tensor (`self.img`) on every word and never clears it (`model.zero_grad()` only touches
+    parameters), so the map the reference returns for word t is the running sum of the per-word
+    relevance maps of words 0..t.  Verified against the reference (tests/golden)."""
+    out, run = [], None
+    for m in maps:
+        run = m if run is None else run + m
+        out.append(run)
+    return out
+
+
+def gridtd_explain_caption(sd, img, caption, words=None, return_feat=False, accumulate=True):
+    """One image (1,3,H,W) + teacher-forced caption -> ([T] x (1,3,H,W), [T] x (t+1,)).
+    accumulate=True reproduces the reference's returned maps (running sums, see `_accumulate`);
+    False gives the per-word maps."""
+    feats, avg, saved = vgg_forward(sd, img)
+    tr = gridtd_trace(sd, feats[0], avg[0], caption)
+    maps, rws, rfs = [], [], []
+    for t in (range(tr["T"]) if words is None else words):
+        r_feat, r_words = gridtd_explain_wordt(sd, tr, t)
+        r_feat = pix_to_nchw(r_feat, feats.shape[-2:])
+        rfs.append(r_feat)
+        maps.append(vgg_lrp(sd, saved, r_feat))
+        rws.append(r_words)
+    if accumulate:
+        maps = _accumulate(maps)
+    if return_feat:
+        return maps, rws, rfs, tr
+    return maps, rws
+
+
+def aoa_explain_caption(sd, img, caption, head_idx, words=None, return_feat=False, accumulate=True):
+    feats, avg, saved = vgg_forward(sd, img)
+    C = feats.shape[1]
+    F_pix = feats[0].reshape(C, -1).t().contiguous()
+    tr = aoa_trace(sd, F_pix, caption)
+    maps, rws, rfs = [], [], []
+    for t in (range(tr["T"]) if words is None else words):
+        r_feat, r_words = aoa_explain_wordt(sd, tr, t, head_idx)
+        r_feat = pix_to_nchw(r_feat, feats.shape[-2:])
+        rfs.append(r_feat)
+        maps.append(vgg_lrp(sd, saved, r_feat))
+        rws.append(r_words)
+    if accumulate:
+        maps = _accumulate(maps)
+    if return_feat:
+        return maps, rws, rfs, tr
+    return maps, rws

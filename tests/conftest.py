@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b|  (the parity metric of SURVEY.md §8(d))"""
+    import torch
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
+
+
+def cosine(a, b):
+    import torch
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()

@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE implementation (read-only import from
+/root/reference) on seeded synthetic inputs.  Run in the build container only:
+
+    python tests/golden/make_golden.py [--only layers,gridtd,aoa,greedy,guided]
+
+The reference never travels to the GPU box; the .npz files written next to this script do.
+Harness-only shims (never shipped): inert stubs for modules the reference imports at module
+level but that are absent here (torchvision, skimage, nltk), `.cuda()` mapped to identity
+(the reference hard-codes it), and file/PIL/beam-search steps replaced by in-memory equivalents.
+`vgg16(pretrained=True)` would download weights; it is rebound to the random-init constructor and
+the weights are then overwritten by this repo's seeded generator (weights.py).
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Compose:
+        def __init__(self, *a, **k):
+            pass
+
+    tv = mod("torchvision")
+    tv.models = mod("torchvision.models")
+    tv.models.utils = mod("torchvision.models.utils", load_state_dict_from_url=lambda *a, **k: {})
+    tv.transforms = mod("torchvision.transforms", Compose=_Compose, Resize=_Compose, ToTensor=_Compose,
+                        Normalize=_Compose)
+    sk = mod("skimage")
+    sk.transform = mod("skimage.transform")
+    nl = mod("nltk")
+    nl.corpus = mod("nltk.corpus", stopwords=types.SimpleNamespace(words=lambda lang: []))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.empty_cache = lambda: None
+    sys.path.insert(0, REF)
+
+
+def load_pkg():
+    import lrp_amd  # noqa: F401  (the shim mounts the package)
+    from lrp_amd import weights
+    return weights
+
+
+def ref_vgg_patch():
+    import models.vgg as vgg
+    vgg.vgg16 = lambda pretrained=False, progress=True, **kw: vgg._vgg('vgg16', 'D', False, False, progress, **kw)
+
+
+def to_torch_sd(sd):
+    return {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+
+
+def make_args(tmp, **kw):
+    d = dict(embed_dim=512, hidden_dim=512, encoder='vgg16', weight='', save_path=tmp, dataset='synthetic',
+             height=224, width=224, num_head=8)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def sub4(x):
+    """strided subsample of a (1,3,H,W) map (every 4th pixel) for compact fixtures"""
+    return x[..., ::4, ::4].contiguous()
+
+
+def stats(x):
+    x = x.double()
+    return np.array([x.sum().item(), x.abs().max().item(), x.pow(2).sum().sqrt().item()], np.float64)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_layers(out):
+    """Layer-level rules through the reference's own hook machinery (LRPtools/)."""
+    from LRPtools import lrp_wrapper, lrp_modules
+    from LRPtools import utils as lutil
+    rs = np.random.RandomState(123)
+    g = {}
+    # --- Conv2d alpha1beta0 + ReLU identity + MaxPool2d through add_lrp/compute_lrp
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(inplace=True),
+                        nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(inplace=True),
+                        nn.MaxPool2d(2, 2),
+                        nn.Conv2d(8, 16, 3, padding=1), nn.ReLU(inplace=True))
+    for m in net:
+        if isinstance(m, nn.Conv2d):
+            m.weight.data = torch.from_numpy(rs.standard_normal(m.weight.shape).astype(np.float32) * 0.2)
+            m.bias.data = torch.from_numpy(rs.standard_normal(m.bias.shape).astype(np.float32) * 0.1)
+    net.eval()
+    lrp_wrapper.add_lrp(net)
+    x = torch.from_numpy(rs.standard_normal((1, 3, 16, 16)).astype(np.float32))
+    x[0, :, 3, 4] = 0.0           # exact-zero input pixels
+    target = torch.from_numpy(rs.standard_normal((1, 16, 8, 8)).astype(np.float32))
+    target[0, 2] = 0.0            # a channel with zero relevance
+    r = net.compute_lrp(x.clone(), target=target.clone())
+    g["mini_w0"], g["mini_b0"] = net[0].weight.data.numpy(), net[0].bias.data.numpy()
+    g["mini_w2"], g["mini_b2"] = net[2].weight.data.numpy(), net[2].bias.data.numpy()
+    g["mini_w5"], g["mini_b5"] = net[5].weight.data.numpy(), net[5].bias.data.numpy()
+    g["mini_x"], g["mini_target"], g["mini_r"] = x.numpy(), target.numpy(), r.numpy()
+    # --- single rules called directly on crafted inputs
+    conv = nn.Conv2d(4, 6, 3, padding=1)
+    conv.weight.data = torch.from_numpy(rs.standard_normal(conv.weight.shape).astype(np.float32) * 0.3)
+    xin = torch.from_numpy(rs.standard_normal((2, 4, 6, 6)).astype(np.float32))
+    xin[0, :, :2] = 0.0           # a zero region: Z == 0 there -> safe_divide path
+    conv.input = (xin,)
+    rout = torch.from_numpy(rs.standard_normal((2, 6, 6, 6)).astype(np.float32))
+    params = lrp_wrapper.SequentialPresetA().lrp_params
+    rin = lrp_modules.Conv2d().propagate_relevance(conv, (xin, conv.weight), (rout,), 'alpha_beta', params)[0]
+    g["conv_w"], g["conv_x"], g["conv_rout"], g["conv_rin"] = conv.weight.data.numpy(), xin.numpy(), rout.numpy(), rin.detach().numpy()
+    pool = nn.MaxPool2d(2, 2)
+    xp = torch.relu(torch.from_numpy(rs.standard_normal((2, 3, 8, 8)).astype(np.float32)))
+    xp[0, 0, 0:2, 0:2] = 0.7      # a tie: all four equal
+    xp[0, 1, 2:4, 2:4] = 0.0      # an all-zero window
+    pool.input = (xp,)
+    rp = torch.from_numpy(rs.standard_normal((2, 3, 4, 4)).astype(np.float32))
+    rpin = lrp_modules.Pool2d().propagate_relevance(pool, None, (rp,), 'alpha_beta', params)[0]
+    g["pool_x"], g["pool_rout"], g["pool_rin"] = xp.numpy(), rp.numpy(), rpin.detach().numpy()
+    lin = nn.Linear(10, 7)
+    xl = torch.from_numpy(rs.standard_normal((3, 10)).astype(np.float32))
+    xl[1, 4] = 0.0
+    lin.input = (xl.clone(),)
+    rl = torch.from_numpy(rs.standard_normal((3, 7)).astype(np.float32))
+    rlin = lrp_modules.Linear().propagate_relevance(lin, (torch.zeros(3, 10), torch.zeros(10, 7)), (rl,), 'epsilon', params)[0]
+    g["lin_w"], g["lin_x"], g["lin_rout"], g["lin_rin"] = lin.weight.data.numpy(), xl.numpy(), rl.numpy(), rlin.detach().numpy()
+    # --- lrp_linear_eps (explainer helper), dense and eye, with exact zeros in z
+    import models.gridTDmodel as gtd
+    ex = gtd.ExplainGridTDAttention.__new__(gtd.ExplainGridTDAttention)
+    w = torch.from_numpy(rs.standard_normal((12, 20)).astype(np.float32))
+    xi = torch.from_numpy(rs.standard_normal((20,)).astype(np.float32))
+    z = w @ xi
+    z[3] = 0.0
+    ro = torch.from_numpy(rs.standard_normal((12,)).astype(np.float32))
+    g["eps_w"], g["eps_x"], g["eps_z"], g["eps_r"] = w.numpy(), xi.numpy(), z.numpy(), ro.numpy()
+    g["eps_dense_out"] = ex.lrp_linear_eps(ro, xi, z, w).numpy()
+    xe = torch.from_numpy(rs.standard_normal((12,)).astype(np.float32))
+    g["eps_eye_x"] = xe.numpy()
+    g["eps_eye_out"] = ex.lrp_linear_eps(ro, xe, z, torch.eye(12)).numpy()
+    g["safe_div"] = lutil.safe_divide(ro, z).numpy()
+    np.savez(os.path.join(out, "layers.npz"), **g)
+    print("layers.npz:", {k: v.shape for k, v in g.items()})
+
+
+# ------------------------------------------------------------------------------------------------
+def _patch_explainer(ex, img, caption):
+    ex.preprocess_img = lambda path: torch.from_numpy(img.copy())
+    words = " ".join(f"w{c}" for c in caption[1:])
+    ex.model.beam_search = lambda *a, **k: ([words], list(int(c) for c in caption[1:]))
+    ex.visualize_explanations = lambda *a, **k: None
+    ex.save_linguistic_explanation = lambda *a, **k: None
+
+
+def gen_gridtd(out, weights, T=3, V=9586, seed=0):
+    import models.gridTDmodel as gtd
+    sd = weights.make_gridtd_state(seed=seed, vocab_size=V)
+    model = gtd.GridTDModel(512, 512, V, 'vgg16')
+    model.load_state_dict(to_torch_sd(sd))
+    wm = weights.make_word_map(V)
+    img = weights.make_images(seed, 1)
+    cap = weights.make_captions(seed + 1, 1, T, V)[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        ex = gtd.ExplainGridTDAttention(make_args(tmp), wm, model=model)
+        _patch_explainer(ex, img, cap)
+        feats = []
+        orig = ex.explain_caption_wordt
+
+        def wrapped(t):
+            rf, rw = orig(t)
+            feats.append(rf.clone())
+            return rf, rw
+        ex.explain_caption_wordt = wrapped
+        maps, rws = ex.explain_caption("synthetic.jpg")
+    g = dict(seed=np.int64(seed), V=np.int64(V), caption=cap)
+    g["features"] = ex.image_features.detach().numpy()
+    for k in ("predictions", "alphas", "betas", "h1t", "c1t", "h2t", "c2t", "g1t", "g2t", "i1t_act", "f1t_act",
+              "i2t_act", "f2t_act", "st", "context", "context_hat"):
+        v = getattr(ex, k).detach()
+        g["tr_" + k] = (v[:, ::97] if k == "predictions" else v).numpy()
+    for t in range(T):
+        g[f"r_feat_{t}"] = feats[t].detach().numpy()
+        g[f"r_words_{t}"] = rws[t].detach().numpy()
+        g[f"map_stats_{t}"] = stats(maps[t])
+        g[f"map_sub4_{t}"] = sub4(maps[t]).numpy()
+    g[f"map_full_{T - 1}"] = maps[T - 1].numpy()
+    np.savez(os.path.join(out, "gridtd_T3.npz"), **g)
+    print("gridtd_T3.npz written; map absmax:", [float(m.abs().max()) for m in maps])
+
+
+def gen_aoa(out, weights, T=3, V=11027, seed=0, heads=(0, 5)):
+    import models.aoamodel as aoa
+    sd = weights.make_aoa_state(seed=seed, vocab_size=V)
+    model = aoa.AOAModel(512, 512, 8, V, 'vgg16')
+    model.load_state_dict(to_torch_sd(sd))
+    wm = weights.make_word_map(V)
+    img = weights.make_images(seed, 1)
+    cap = weights.make_captions(seed + 1, 1, T, V)[0]
+    g = dict(seed=np.int64(seed), V=np.int64(V), caption=cap, heads=np.array(heads))
+    with tempfile.TemporaryDirectory() as tmp:
+        ex = aoa.ExplainAOAAttention(make_args(tmp), wm, model=model)
+        _patch_explainer(ex, img, cap)
+        for hd in heads:
+            feats = []
+            orig = aoa.ExplainAOAAttention.explain_caption_wordt
+
+            def wrapped(t, head_idx, _orig=orig, _feats=feats):
+                rf, rw = _orig(ex, t, head_idx)
+                _feats.append(rf.clone())
+                return rf, rw
+            ex.explain_caption_wordt = wrapped
+            maps, rws = ex.explain_caption("synthetic.jpg", hd)
+            for t in range(T):
+                g[f"h{hd}_r_feat_{t}"] = feats[t].detach().numpy()
+                g[f"h{hd}_r_words_{t}"] = rws[t].detach().numpy()
+                g[f"h{hd}_map_stats_{t}"] = stats(maps[t])
+                g[f"h{hd}_map_sub4_{t}"] = sub4(maps[t]).numpy()
+            if hd == heads[0]:
+                g[f"h{hd}_map_full_{T - 1}"] = maps[T - 1].numpy()
+        g["tr_predictions"] = ex.predictions.detach()[:, ::97].numpy()
+        g["tr_alphas"] = ex.alphas.detach().numpy()
+        g["tr_ht"] = ex.ht.detach().numpy()
+        g["tr_context"] = ex.context.detach().numpy()
+    np.savez(os.path.join(out, "aoa_T3.npz"), **g)
+    print("aoa_T3.npz written")
+
+
+def gen_aoa_bu(out, weights, T=3, V=11027, seed=0, head=0):
+    """Config 5 (SURVEY §8(a) row A-BU): no BU explainer exists in the reference, so the oracle
+    construction is ExplainAOAAttention on an AOAModel whose encoder is a stub returning the 36x2048
+    region features as (1,2048,6,6) and whose img_projector carries the Linear(2048,H) weights."""
+    import models.aoamodel as aoa
+    sd = weights.make_aoa_state(seed=seed, vocab_size=V, feat_dim=2048, with_encoder=False)
+    feats_np = weights.make_bu_features(seed, 1)[0]                       # (36,2048)
+
+    class StubEnc(nn.Module):
+        feat_dim = 2048
+
+        def forward(self, img):
+            f = torch.from_numpy(feats_np.T.copy()).reshape(1, 2048, 6, 6)
+            return f, f.mean(dim=(2, 3)).squeeze()
+    model = aoa.AOAModel(512, 512, 8, V, 'vgg16')
+    model.img_encoder = StubEnc()
+    model.encoder_raw_dim = 2048
+    model.img_projector = nn.Conv2d(2048, 512, 1)
+    model.load_state_dict(to_torch_sd(sd))
+    wm = weights.make_word_map(V)
+    cap = weights.make_captions(seed + 1, 1, T, V)[0]
+    g = dict(seed=np.int64(seed), V=np.int64(V), caption=cap, head=np.int64(head))
+    with tempfile.TemporaryDirectory() as tmp:
+        ex = aoa.ExplainAOAAttention(make_args(tmp), wm, model=model)
+        _patch_explainer(ex, np.zeros((1, 3, 8, 8), np.float32), cap)
+        ex.get_hidden_parameters("synthetic")
+        for t in range(T):
+            with torch.no_grad():
+                rf, rw = ex.explain_caption_wordt(t, head)
+            g[f"r_feat_{t}"] = rf.detach().reshape(2048, 36).t().contiguous().numpy()   # (36,2048)
+            g[f"r_words_{t}"] = rw.detach().numpy()
+    np.savez(os.path.join(out, "aoa_bu_T3.npz"), **g)
+    print("aoa_bu_T3.npz written")
+
+
+def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
+    """Config 1: greedy token ids from the reference model's own `greedy_search`
+    (models/gridTDmodel.py:480-520), int64, bit-exact target."""
+    import models.gridTDmodel as gtd
+    sd = weights.make_gridtd_state(seed=seed, vocab_size=V)
+    model = gtd.GridTDModel(512, 512, V, 'vgg16')
+    model.load_state_dict(to_torch_sd(sd))
+    model.eval()
+    wm = weights.make_word_map(V)
+    img = torch.from_numpy(weights.make_images(seed, 1))
+    _, seqs = model.greedy_search(img, wm, max_cap_length=max_len)
+    np.savez(os.path.join(out, "greedy_cfg1.npz"), seed=np.int64(seed), V=np.int64(V),
+             tokens=np.array(seqs[0], np.int64))
+    print("greedy tokens:", seqs[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy")
+    ap.add_argument("--threads", type=int, default=1)
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    install_stubs()
+    weights = load_pkg()
+    ref_vgg_patch()
+    todo = set(a.only.split(","))
+    if "layers" in todo:
+        gen_layers(HERE)
+    if "gridtd" in todo:
+        gen_gridtd(HERE, weights)
+    if "aoa" in todo:
+        gen_aoa(HERE, weights)
+    if "aoa_bu" in todo:
+        gen_aoa_bu(HERE, weights)
+    if "greedy" in todo:
+        gen_greedy(HERE, weights)
+
+
+if __name__ == "__main__":
+    main()

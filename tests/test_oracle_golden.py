@@ -1,0 +1,98 @@
+"""Pin the CPU oracle against END-TO-END outputs of the reference explainers
+(tests/golden/{gridtd_T3,aoa_T3,aoa_bu_T3,greedy_cfg1}.npz, made by make_golden.py from
+models/gridTDmodel.py:1141 `explain_caption`, models/aoamodel.py:1165, and
+models/gridTDmodel.py:480 `greedy_search`).  Weights/inputs are regenerated from the seeded
+generator (lrp_amd.weights) — only inputs' seeds and the reference's outputs are stored."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lrp_amd  # noqa: F401
+from lrp_amd import weights
+from conftest import GOLDEN, rel_err, cosine
+from oracle import lrp_oracle as O
+
+TOL_REL = 1e-4      # BASELINE.json: max|dR|/max|R_ref| <= 1e-4
+TOL_WORDS = 1e-5    # r_words max abs diff
+
+
+@pytest.fixture(scope="module")
+def gridtd():
+    g = np.load(os.path.join(GOLDEN, "gridtd_T3.npz"))
+    sd = O.state_to_torch(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=int(g["V"])))
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    torch.set_num_threads(8)
+    maps, rws, rfs, tr = O.gridtd_explain_caption(sd, img, g["caption"], return_feat=True)
+    return g, maps, rws, rfs, tr
+
+
+def test_gridtd_trace(gridtd):
+    g, maps, rws, rfs, tr = gridtd
+    pairs = dict(h1t="h1", c1t="c1", h2t="h2", c2t="c2", g1t="g1", g2t="g2", i1t_act="i1", f1t_act="f1",
+                 i2t_act="i2", f2t_act="f2", st="s", context="ctx", context_hat="ctx_hat", alphas="alpha",
+                 betas="beta")
+    for ref_name, mine in pairs.items():
+        assert rel_err(tr[mine], g["tr_" + ref_name]) < 2e-5, ref_name
+    assert rel_err(tr["pred"][:, ::97], g["tr_predictions"]) < 2e-5
+
+
+def test_gridtd_feature_relevance_and_words(gridtd):
+    g, maps, rws, rfs, tr = gridtd
+    for t in range(3):
+        assert rel_err(rfs[t], g[f"r_feat_{t}"]) < TOL_REL
+        assert cosine(rfs[t], g[f"r_feat_{t}"]) > 0.99999
+        assert np.abs(rws[t].numpy() - g[f"r_words_{t}"]).max() < TOL_WORDS
+
+
+def test_gridtd_pixel_maps(gridtd):
+    g, maps, rws, rfs, tr = gridtd
+    for t in range(3):
+        sub = maps[t][..., ::4, ::4]
+        scale = g[f"map_stats_{t}"][1]
+        assert np.abs(sub.numpy() - g[f"map_sub4_{t}"]).max() / scale < TOL_REL
+        assert abs(maps[t].double().sum().item() - g[f"map_stats_{t}"][0]) < 1e-3 * abs(g[f"map_stats_{t}"][0]) + 1e-9
+    assert rel_err(maps[2], g["map_full_2"]) < TOL_REL
+    assert cosine(maps[2], g["map_full_2"]) > 0.99999
+    assert (maps[2] - torch.from_numpy(g["map_full_2"])).abs().max() < 1e-4      # BASELINE absolute bound
+
+
+def test_aoa_heads():
+    g = np.load(os.path.join(GOLDEN, "aoa_T3.npz"))
+    sd = O.state_to_torch(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=int(g["V"])))
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    for hd in g["heads"]:
+        maps, rws, rfs, tr = O.aoa_explain_caption(sd, img, g["caption"], int(hd), return_feat=True)
+        for t in range(3):
+            assert rel_err(rfs[t], g[f"h{hd}_r_feat_{t}"]) < TOL_REL
+            assert np.abs(rws[t].numpy() - g[f"h{hd}_r_words_{t}"]).max() < TOL_WORDS
+            scale = g[f"h{hd}_map_stats_{t}"][1]
+            assert np.abs(maps[t][..., ::4, ::4].numpy() - g[f"h{hd}_map_sub4_{t}"]).max() / scale < TOL_REL
+        if f"h{hd}_map_full_2" in g:
+            assert rel_err(maps[2], g[f"h{hd}_map_full_2"]) < TOL_REL
+    assert rel_err(tr["alpha"], g["tr_alphas"]) < 2e-5
+    assert rel_err(tr["h"], g["tr_ht"]) < 2e-5
+
+
+def test_aoa_bottom_up_regions():
+    # config 5: 36x2048 region features, no CNN stage (SURVEY §8(a) row A-BU)
+    g = np.load(os.path.join(GOLDEN, "aoa_bu_T3.npz"))
+    sd = O.state_to_torch(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=int(g["V"]), feat_dim=2048,
+                                                 with_encoder=False))
+    feats = torch.from_numpy(weights.make_bu_features(int(g["seed"]), 1)[0])
+    tr = O.aoa_trace(sd, feats, g["caption"])
+    for t in range(3):
+        rf, rw = O.aoa_explain_wordt(sd, tr, t, int(g["head"]))
+        assert rel_err(rf, g[f"r_feat_{t}"]) < TOL_REL
+        assert np.abs(rw.numpy() - g[f"r_words_{t}"]).max() < TOL_WORDS
+
+
+def test_greedy_tokens_bit_exact():
+    # config 1: token ids are integers -> bit-exact
+    g = np.load(os.path.join(GOLDEN, "greedy_cfg1.npz"))
+    V = int(g["V"])
+    sd = O.state_to_torch(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=V))
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    toks = O.gridtd_model_greedy(sd, img, max_cap_length=len(g["tokens"]), start_id=V - 2, end_id=V - 1)
+    assert toks == [int(x) for x in g["tokens"]]
