@@ -1,0 +1,132 @@
+/* lrpx — C ABI of the MI355X-native LRP relevance-propagation hot path.
+ *
+ * Drop-in boundary for SunJiamei/LRP-imagecaptioning-pytorch.  The reference is pure Python; these
+ * are the entry points its Python would bind (ctypes) in place of the ATen op
+ * clusters of its LRP path.  Each function cites the reference interface it replaces
+ * (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (or int32 where stated), owned by the caller
+ *     (PyTorch's allocator); the library never frees or retains a caller pointer beyond the call
+ *     and never allocates device memory (one 4-byte flag word of lrpx_check excepted): workspaces
+ *     are caller-provided, sizes come from *_bytes().
+ *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous w.r.t. the host.
+ *   - internal activation layout is pixel-major NHWC: a [map*H*W][C] row-major matrix.
+ *   - return value: 0 = ok, otherwise an LRPX_E* code; lrpx_last_error_string() describes it.
+ */
+#ifndef LRPX_H
+#define LRPX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    LRPX_OK = 0,
+    LRPX_EINVAL = 1,      /* bad shape / null pointer / unsupported configuration */
+    LRPX_EARCH = 2,       /* device is not gfx950 */
+    LRPX_ELAUNCH = 3,     /* hip launch / runtime failure */
+    LRPX_ENONFINITE = 4,  /* NaN/Inf found by lrpx_check_finite (the reference's inline asserts) */
+    LRPX_EZERO = 5        /* all-zero relevance (reference: `assert sample.grad.sum()!=0`, lrp_wrapper.py:81) */
+};
+
+int lrpx_version(void);
+const char* lrpx_last_error_string(void);
+
+/* ---- weight packing ------------------------------------------------------------------------- */
+enum {
+    LRPX_PACK_FWD_DUAL = 0,  /* conv fwd: channels [0,cout) = W, [cout,2cout) = clamp(W,min=0)  (PosNetConv weights, LRPtools/lrp_modules.py:66-67) */
+    LRPX_PACK_BWD_POS = 1,   /* relevance pass: transposed conv with clamp(W,min=0)            (lrp_modules.py:136-138 through autograd) */
+    LRPX_PACK_BWD_FIRST = 2, /* first layer: out 0..cin-1 = W+ , cin..2cin-1 = W-  (signed inputs, lrp_modules.py:78-84) */
+    LRPX_PACK_BWD_PLAIN = 3, /* transposed conv with W (guided backprop, models/gridTDmodel.py:1702-1723) */
+    LRPX_PACK_DENSE_T = 4,   /* dense: out = in @ W      W is (k, n)   (epsilon rule W^T contraction, gridTDmodel.py:744-765) */
+    LRPX_PACK_DENSE = 5,     /* dense: out = in @ W^T    W is (n, k)   (nn.Linear forward) */
+    LRPX_PACK_FWD = 6,       /* conv fwd, plain W only */
+    LRPX_PACK_FWD_DUAL_FIRST = 7 /* first conv: the signed input is stored split, channels [0,cin) = x+, [cin,2cin) = x-;
+                                  plain part = W on both, Z part = W+ on x+ and W- on x-  (Z = conv(x+,W+)+conv(x-,W-),
+                                  lrp_modules.py:81-84) */
+};
+/* number of floats of the packed image: n_oc/k padded to multiples of 32 / kc */
+size_t lrpx_packed_floats(int n_oc, int k, int taps, int kc);
+/* w: conv (cout,cin,3,3) or dense matrix; kc = K-chunk the consuming kernel will use (lrpx_conv_kc) */
+int lrpx_pack_weights(const float* w, int cout, int cin, int taps, int mode, int kc, float* packed, void* stream);
+/* K-chunk used by lrpx_conv_mfma for a given image width / taps / input channels */
+int lrpx_conv_kc(int hw, int taps, int cin);
+
+/* ---- the contraction engine ------------------------------------------------------------------ */
+enum { LRPX_EPI_FWD_DUAL = 0, LRPX_EPI_REL = 1, LRPX_EPI_FIRST = 2, LRPX_EPI_PLAIN = 3, LRPX_EPI_GUIDED = 4 };
+enum { LRPX_STAB_NONE = 0, LRPX_STAB_SAFE = 1, LRPX_STAB_EPS = 2 };
+
+typedef struct lrpx_conv_desc {
+    const float* in;      /* [n_maps*pix_per_map][cin] */
+    const float* wpacked; /* from lrpx_pack_weights with kc = lrpx_conv_kc(hw,taps,cin) */
+    int n_maps, hw, cin, n_oc, taps, pix_per_map;
+    int epi, stab, oc_split, relu;
+    const float* bias;
+    const float* x;
+    const float* u;
+    const float* zdiv;
+    const int32_t* map2img;
+    float* out0;
+    float* out1;
+} lrpx_conv_desc;
+/* 3x3/pad-1 convolution (taps=9, square hw x hw maps) or dense GEMM (taps=1) on the fp32 MFMA with
+ * the fused epilogues of the relevance rules.  Replaces F.conv2d / conv backward inside
+ * LRPtools/utils.py:21-31 `lrp_backward` and torch.matmul/sum inside `lrp_linear_eps`. */
+int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream);
+
+/* ---- elementwise / layout kernels -------------------------------------------------------------- */
+/* (n,c,h,w) -> [n*h*w][c_pad] with zero padding channels; and back (first c of c_src channels) */
+int lrpx_nchw_to_nhwc(const float* src, float* dst, int n, int c, int hw_pix, int c_pad, void* stream);
+int lrpx_nhwc_to_nchw(const float* src, float* dst, int n, int c, int hw_pix, int c_src, void* stream);
+/* signed image -> [n*h*w][c_pad]: channels [0,c) = max(x,0), [c,2c) = min(x,0), rest 0 */
+int lrpx_nchw_to_nhwc_posneg(const float* src, float* dst, int n, int c, int hw_pix, int c_pad, void* stream);
+/* MaxPool2d(2,2) forward on NHWC (models/vgg.py:67) */
+int lrpx_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);
+/* Pool2d.propagate_relevance (LRPtools/lrp_modules.py:182-195) fused with the division by the
+ * conv layer below:  r_in = x * [argmax] * (r_out / safe(max));  s_out = r_in / safe(zdiv).
+ * x, zdiv: per IMAGE (n_img,2h,2w,c); r_out: per MAP (n_maps,h,w,c); outputs per map at 2h x 2w.
+ * r_in / s_out may be null (skip).  zdiv may be null (then s_out = r_in). */
+int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* zdiv, const int32_t* map2img,
+                              float* r_in, float* s_out, int n_maps, int h_out, int w_out, int c, void* stream);
+/* s[n,p,c] = r[n,p,c] / stab(z[img(n),p,c])   (LRPtools/utils.py:16-18 safe_divide with broadcast) */
+int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c,
+                     int stab, void* stream);
+/* running sum over the maps of one image: out[b,t] = sum_{t'<=t} in[b,t']  (the reference's
+ * `sample.grad` accumulation, LRPtools/lrp_wrapper.py:64-82); per = floats per map */
+int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long per, void* stream);
+/* NaN/Inf + all-zero check of a buffer (the asserts of lrp_modules.py:154-155, lrp_wrapper.py:81);
+ * synchronises the stream.  flags: bit0 = fail on non-finite, bit1 = fail on all-zero */
+int lrpx_check(const float* buf, long n, int flags, void* stream);
+
+/* ---- VGG16 encoder: trace + relevance chain ------------------------------------------------------ */
+/* bytes of the packed-weight blob / per-batch trace / relevance workspace */
+size_t lrpx_vgg16_packed_bytes(void);
+size_t lrpx_vgg16_trace_bytes(int n_img);
+size_t lrpx_vgg16_workspace_bytes(int n_maps);
+/* w[13], b[13]: device pointers to the conv weights (cout,cin,3,3) / biases in layer order */
+int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, void* stream);
+/* Encoder.forward (models/gridTDmodel.py:40-43) + the per-layer inputs `save_input_hook` keeps
+ * (LRPtools/lrp_wrapper.py:24-25) + Z+ of every conv.  img: (n_img,3,224,224) NCHW.
+ * feat_nhwc: (n_img,196,512) encoder output (may be null: it also lives in the trace). */
+int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, void* trace, float* feat_nhwc,
+                       void* stream);
+/* compute_lrp (LRPtools/lrp_wrapper.py:63-87) for N maps sharing n_img traces: r_feat (N,196,512) NHWC
+ * relevance at the encoder output -> out (N,3,224,224) NCHW.  map2img[N] int32 (null: identity, then
+ * n_maps == n_img).  `trace` must come from lrpx_vgg16_forward with the same n_img. */
+int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const float* r_feat_nhwc,
+                         const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream);
+/* offsets (in floats) of the per-layer tensors inside a trace made for n_img images: act_off[18]
+ * (act[l] = NHWC input of leaf l in forward order conv,conv,pool,...; act[0] is the image stored split
+ * [x+|x-|0 0] with 8 channels; act[17] = encoder output) and zpos_off[17] (Z+ of conv l, 0 for pools).
+ * This is what `module.input` is to the reference's hooks (lrp_wrapper.py:24-25). */
+int lrpx_vgg16_trace_layout(int n_img, size_t* act_off, size_t* zpos_off);
+/* pointer to the encoder output features (n_img,196,512) inside a trace */
+const float* lrpx_vgg16_trace_features(const void* trace, int n_img);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

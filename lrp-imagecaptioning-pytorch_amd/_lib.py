@@ -1,0 +1,102 @@
+"""ctypes binding of csrc/liblrpx.so (the C ABI declared in include/lrpx.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  Error codes map to the exceptions the reference raises at the same places
+(AssertionError for NaN/Inf/zero relevance, ValueError for unsupported layers/shapes)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblrpx.so")
+
+OK, EINVAL, EARCH, ELAUNCH, ENONFINITE, EZERO = range(6)
+PACK_FWD_DUAL, PACK_BWD_POS, PACK_BWD_FIRST, PACK_BWD_PLAIN, PACK_DENSE_T, PACK_DENSE, PACK_FWD, PACK_FWD_DUAL_FIRST = range(8)
+EPI_FWD_DUAL, EPI_REL, EPI_FIRST, EPI_PLAIN, EPI_GUIDED = range(5)
+STAB_NONE, STAB_SAFE, STAB_EPS = range(3)
+
+_f = C.c_void_p      # device pointers travel as void*
+_i = C.c_int
+_l = C.c_long
+_sz = C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("in_", _f), ("wpacked", _f),
+                ("n_maps", _i), ("hw", _i), ("cin", _i), ("n_oc", _i), ("taps", _i), ("pix_per_map", _i),
+                ("epi", _i), ("stab", _i), ("oc_split", _i), ("relu", _i),
+                ("bias", _f), ("x", _f), ("u", _f), ("zdiv", _f), ("map2img", _f),
+                ("out0", _f), ("out1", _f)]
+
+
+# name -> (restype, argtypes); must list every symbol of include/lrpx.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "lrpx_version": (_i, []),
+    "lrpx_last_error_string": (C.c_char_p, []),
+    "lrpx_packed_floats": (_sz, [_i, _i, _i, _i]),
+    "lrpx_pack_weights": (_i, [_f, _i, _i, _i, _i, _i, _f, _f]),
+    "lrpx_conv_kc": (_i, [_i, _i, _i]),
+    "lrpx_conv_mfma": (_i, [C.POINTER(ConvDesc), _f]),
+    "lrpx_nchw_to_nhwc": (_i, [_f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_nhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_nchw_to_nhwc_posneg": (_i, [_f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_maxpool2x2_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_maxpool2x2_relevance": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_divide_stab": (_i, [_f, _f, _f, _f, _i, _l, _i, _f]),
+    "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),
+    "lrpx_check": (_i, [_f, _l, _i, _f]),
+    "lrpx_vgg16_packed_bytes": (_sz, []),
+    "lrpx_vgg16_trace_bytes": (_sz, [_i]),
+    "lrpx_vgg16_workspace_bytes": (_sz, [_i]),
+    "lrpx_vgg16_pack": (_i, [C.POINTER(_f), C.POINTER(_f), _f, _f]),
+    "lrpx_vgg16_forward": (_i, [_f, _f, _i, _f, _f, _f]),
+    "lrpx_vgg16_relevance": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, _f]),
+    "lrpx_vgg16_trace_layout": (_i, [_i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "lrpx_vgg16_trace_features": (_f, [_f, _i]),
+}
+
+_lib = None
+
+
+class LrpxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liblrpx.so once.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LrpxError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+                        "(or __graft_entry__.build()); there is no CPU fallback for the LRP hot path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Translate a status code into the exception the reference raises at the same place."""
+    if rc == OK:
+        return
+    msg = load().lrpx_last_error_string().decode()
+    if rc in (ENONFINITE, EZERO):
+        raise AssertionError(msg)          # lrp_modules.py:154-155 / lrp_wrapper.py:81
+    if rc == EINVAL:
+        raise ValueError(msg)              # lrp_modules.py:338 style
+    raise LrpxError(f"lrpx error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "lrpx needs contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,54 @@
+// Launch helpers for the conv_mfma kernel family (instantiated in conv_inst_*.hip).
+#pragma once
+#include "common.h"
+#include "conv_mfma.h"
+
+namespace lrpx {
+
+template <int HW, int KC, int MT, int NWN, int TAPS, int EPI>
+int launch_conv_cfg(const ConvArgs& a, hipStream_t stream) {
+    using C = ConvCfg<HW, KC, MT, NWN, TAPS>;
+    long m_tiles;
+    if (TAPS == 9) m_tiles = ceil_div((long)a.n_maps * HW, C::R);
+    else m_tiles = ceil_div((long)a.n_maps * a.pix_per_map, C::PIX);
+    const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
+    const long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
+    if (grid <= 0 || grid > 0x7fffffffL) {
+        set_error("conv_mfma: grid %ld out of range", grid);
+        return LRPX_EINVAL;
+    }
+    auto kern = conv_mfma_kernel<HW, KC, MT, NWN, TAPS, EPI>;
+    static bool attr_done = false;   // benign race: the attribute call is idempotent
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess) {
+            set_error("conv_mfma: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+            return LRPX_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a, (int)m_tiles, n_blocks);
+    return check_launch("conv_mfma");
+}
+
+// one function per instantiation, defined in conv_inst_*.hip
+int launch_conv_224_16_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
+int launch_conv_224_8_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
+int launch_conv_224_16_2_2_9_rel(const ConvArgs& a, hipStream_t s);
+int launch_conv_224_16_2_1_9_first(const ConvArgs& a, hipStream_t s);
+int launch_conv_112_16_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
+int launch_conv_112_16_1_4_9_rel(const ConvArgs& a, hipStream_t s);
+int launch_conv_112_16_2_2_9_rel(const ConvArgs& a, hipStream_t s);
+int launch_conv_56_32_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
+int launch_conv_56_32_1_4_9_rel(const ConvArgs& a, hipStream_t s);
+int launch_conv_28_32_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
+int launch_conv_28_32_1_4_9_rel(const ConvArgs& a, hipStream_t s);
+int launch_conv_14_32_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
+int launch_conv_14_32_1_4_9_rel(const ConvArgs& a, hipStream_t s);
+int launch_conv_14_32_1_4_1_rel(const ConvArgs& a, hipStream_t s);
+int launch_conv_14_32_1_4_1_plain(const ConvArgs& a, hipStream_t s);
+
+// host-side entry used by the C ABI and by the VGG16 / decoder chains
+int conv_dispatch(const lrpx_conv_desc* d, hipStream_t stream);
+
+}  // namespace lrpx

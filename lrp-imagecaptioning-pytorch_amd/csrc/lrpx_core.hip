@@ -1,0 +1,352 @@
+// liblrpx core: error state, weight packing, layout / pooling / elementwise kernels of the LRP path.
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+#include "conv_mfma.h"
+
+namespace lrpx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fragment-major [ocb][chunk][tap][ks][lane][4]; lane l of a k-step holds
+// B[k = 8*ks + 4*(l>>5) + e][oc = 32*ocb + (l&31)], e = 0..3  (operand map of v_mfma_f32_32x32x2_f32
+// with the k index permuted identically on the A side, see conv_mfma.h)
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
+                                    int taps, int mode, int kc, int n_oc_pad, int k_pad, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    long rest = idx >> 8;
+    const int ksteps = kc / 8;
+    const int ks = rest % ksteps; rest /= ksteps;
+    const int tap = rest % taps; rest /= taps;
+    const int nchunk = k_pad / kc;
+    const int chunk = rest % nchunk; rest /= nchunk;
+    const int ocb = (int)rest;
+    const int oc = ocb * 32 + (lane & 31);
+    const int k = chunk * kc + ks * 8 + 4 * (lane >> 5) + e;
+    float v = 0.f;
+    // conv weights are (cout, cin, 3, 3): w[((co*cin + ci)*9) + tap]
+    switch (mode) {
+        case LRPX_PACK_FWD_DUAL:   // GEMM k = ci, oc in [0,2cout)
+            if (k < cin && oc < 2 * cout) {
+                int co = oc < cout ? oc : oc - cout;
+                float x = w[((long)co * cin + k) * taps + tap];
+                v = oc < cout ? x : fmaxf(x, 0.f);
+            }
+            break;
+        case LRPX_PACK_FWD:
+            if (k < cin && oc < cout) v = w[((long)oc * cin + k) * taps + tap];
+            break;
+        case LRPX_PACK_FWD_DUAL_FIRST:   // input channels [0,cin) = x+, [cin,2cin) = x-
+            if (k < 2 * cin && oc < 2 * cout) {
+                int co = oc < cout ? oc : oc - cout;
+                int ci = k < cin ? k : k - cin;
+                float x = w[((long)co * cin + ci) * taps + tap];
+                v = oc < cout ? x : (k < cin ? fmaxf(x, 0.f) : fminf(x, 0.f));
+            }
+            break;
+        case LRPX_PACK_BWD_POS:    // GEMM k = co, oc = ci, kernel flipped
+            if (k < cout && oc < cin) v = fmaxf(w[((long)k * cin + oc) * taps + (taps - 1 - tap)], 0.f);
+            break;
+        case LRPX_PACK_BWD_PLAIN:
+            if (k < cout && oc < cin) v = w[((long)k * cin + oc) * taps + (taps - 1 - tap)];
+            break;
+        case LRPX_PACK_BWD_FIRST:  // oc in [0,cin): W+, [cin,2cin): W-
+            if (k < cout && oc < 2 * cin) {
+                int ci = oc < cin ? oc : oc - cin;
+                float x = w[((long)k * cin + ci) * taps + (taps - 1 - tap)];
+                v = oc < cin ? fmaxf(x, 0.f) : fminf(x, 0.f);
+            }
+            break;
+        case LRPX_PACK_DENSE_T:    // W is (k = cout rows, n = cin cols): B[k][oc] = W[k][oc]
+            if (k < cout && oc < cin) v = w[(long)k * cin + oc];
+            break;
+        case LRPX_PACK_DENSE:      // W is (n = cout rows, k = cin cols): B[k][oc] = W[oc][k]
+            if (k < cin && oc < cout) v = w[(long)oc * cin + k];
+            break;
+    }
+    out[idx] = v;
+}
+
+static void pack_dims(int cout, int cin, int mode, int kc, int* n_oc_pad, int* k_pad) {
+    int n_oc, k;
+    switch (mode) {
+        case LRPX_PACK_FWD_DUAL: n_oc = 2 * cout; k = cin; break;
+        case LRPX_PACK_FWD: n_oc = cout; k = cin; break;
+        case LRPX_PACK_FWD_DUAL_FIRST: n_oc = 2 * cout; k = 2 * cin; break;
+        case LRPX_PACK_BWD_POS: case LRPX_PACK_BWD_PLAIN: n_oc = cin; k = cout; break;
+        case LRPX_PACK_BWD_FIRST: n_oc = 2 * cin; k = cout; break;
+        case LRPX_PACK_DENSE_T: n_oc = cin; k = cout; break;
+        default: n_oc = cout; k = cin; break;  // DENSE
+    }
+    *n_oc_pad = round_up(n_oc, 32);
+    *k_pad = round_up(k, kc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int c, int P, int c_pad,
+                                    long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*P*c_pad
+    if (idx >= total) return;
+    int ch = idx % c_pad;
+    long np = idx / c_pad;
+    long n = np / P, p = np - n * P;
+    dst[idx] = ch < c ? src[(n * c + ch) * P + p] : 0.f;
+}
+
+// signed first-layer input split into its positive and negative parts: channels [0,c) = max(x,0),
+// [c,2c) = min(x,0), rest zero (PosNetConv.forward clamps, LRPtools/lrp_modules.py:81-84)
+__global__ void nchw_to_nhwc_posneg_kernel(const float* __restrict__ src, float* __restrict__ dst, int c, int P,
+                                           int c_pad, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*P*c_pad
+    if (idx >= total) return;
+    int ch = idx % c_pad;
+    long np = idx / c_pad;
+    long n = np / P, p = np - n * P;
+    float v = 0.f;
+    if (ch < c) v = fmaxf(src[(n * c + ch) * P + p], 0.f);
+    else if (ch < 2 * c) v = fminf(src[(n * c + ch - c) * P + p], 0.f);
+    dst[idx] = v;
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int c, int P, int c_src,
+                                    long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*c*P
+    if (idx >= total) return;
+    long p = idx % P;
+    long nc = idx / P;
+    long n = nc / c;
+    int ch = nc - n * c;
+    dst[idx] = src[(n * P + p) * c_src + ch];
+}
+
+// MaxPool2d(2,2) forward, NHWC, 4 channels per thread
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int ho, int wo, int c4,
+                                   long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*ho*wo*c4
+    if (idx >= total) return;
+    int cc = idx % c4;
+    long r = idx / c4;
+    int xo = r % wo; r /= wo;
+    int yo = r % ho;
+    long n = r / ho;
+    const int wi = 2 * wo;
+    const f32x4* base = reinterpret_cast<const f32x4*>(x) + ((n * 2 * ho + 2 * yo) * wi + 2 * xo) * c4 + cc;
+    f32x4 a = base[0], b = base[c4], c_ = base[(long)wi * c4], d = base[(long)wi * c4 + c4];
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c_[e], d[e]));
+    reinterpret_cast<f32x4*>(y)[idx] = m;
+}
+
+// Pool2d rule + division by the Z+ of the conv below.  One thread = one hi-res pixel x 4 channels.
+__global__ void maxpool_relevance_kernel(const float* __restrict__ x, const float* __restrict__ r_out,
+                                         const float* __restrict__ zdiv, const int* __restrict__ map2img,
+                                         float* __restrict__ r_in, float* __restrict__ s_out, int ho, int wo, int c4,
+                                         long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n_maps*(2ho)*(2wo)*c4
+    if (idx >= total) return;
+    int cc = idx % c4;
+    long r = idx / c4;
+    const int wi = 2 * wo, hi = 2 * ho;
+    int xi = r % wi; r /= wi;
+    int yi = r % hi;
+    long n = r / hi;
+    long img = map2img ? map2img[n] : n;
+    const int yo = yi >> 1, xo = xi >> 1;
+    const int pos = (yi & 1) * 2 + (xi & 1);   // position of this pixel inside its window, row-major
+    const f32x4* xb = reinterpret_cast<const f32x4*>(x) + ((img * hi + 2 * yo) * wi + 2 * xo) * c4 + cc;
+    f32x4 w4[4] = {xb[0], xb[c4], xb[(long)wi * c4], xb[(long)wi * c4 + c4]};
+    f32x4 ro = reinterpret_cast<const f32x4*>(r_out)[((n * ho + yo) * wo + xo) * c4 + cc];
+    f32x4 z = {1.f, 1.f, 1.f, 1.f};
+    if (zdiv) z = reinterpret_cast<const f32x4*>(zdiv)[((img * hi + yi) * wi + xi) * c4 + cc];
+    f32x4 ri, so;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // first maximum in row-major window order wins (strict >), as max_pool2d's backward does
+        float m = w4[0][e];
+        int am = 0;
+        if (w4[1][e] > m) { m = w4[1][e]; am = 1; }
+        if (w4[2][e] > m) { m = w4[2][e]; am = 2; }
+        if (w4[3][e] > m) { m = w4[3][e]; am = 3; }
+        float v = 0.f;
+        if (am == pos) v = m * (ro[e] / stab_safe(m));
+        ri[e] = v;
+        so[e] = zdiv ? v / stab_safe(z[e]) : v;
+    }
+    if (r_in) reinterpret_cast<f32x4*>(r_in)[idx] = ri;
+    if (s_out) reinterpret_cast<f32x4*>(s_out)[idx] = so;
+}
+
+__global__ void divide_stab_kernel(const float* __restrict__ r, const float* __restrict__ z,
+                                   const int* __restrict__ map2img, float* __restrict__ s, long per4, int stab,
+                                   long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 units over n_maps*per4
+    if (idx >= total) return;
+    long n = idx / per4, i = idx - n * per4;
+    long img = map2img ? map2img[n] : n;
+    f32x4 rv = reinterpret_cast<const f32x4*>(r)[idx];
+    f32x4 zv = reinterpret_cast<const f32x4*>(z)[img * per4 + i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float zz = zv[e];
+        zz = stab == STAB_SAFE ? stab_safe(zz) : (stab == STAB_EPS ? stab_eps(zz) : zz);
+        o[e] = rv[e] / zz;
+    }
+    reinterpret_cast<f32x4*>(s)[idx] = o;
+}
+
+__global__ void cumsum_maps_kernel(const float* __restrict__ in, float* __restrict__ out, int t_per_img, long per4,
+                                   long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 units over n_img*per4
+    if (idx >= total) return;
+    long b = idx / per4, i = idx - b * per4;
+    f32x4 run = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < t_per_img; ++t) {
+        long o = (b * t_per_img + t) * per4 + i;
+        f32x4 v = reinterpret_cast<const f32x4*>(in)[o];
+        run = (t == 0) ? v : run + v;
+        reinterpret_cast<f32x4*>(out)[o] = run;
+    }
+}
+
+__global__ void check_kernel(const float* __restrict__ buf, long n, unsigned* flags) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    unsigned f = 0;
+    for (long i = idx; i < n; i += stride) {
+        float v = buf[i];
+        if (!isfinite(v)) f |= 1u;
+        if (v != 0.f) f |= 2u;
+    }
+    if (f) atomicOr(flags, f);
+}
+
+static inline unsigned grid_for(long total, int block = 256) { return (unsigned)ceil_div(total, block); }
+
+}  // namespace lrpx
+
+using namespace lrpx;
+
+extern "C" {
+
+int lrpx_version(void) { return 100; }
+
+const char* lrpx_last_error_string(void) { return g_err; }
+
+size_t lrpx_packed_floats(int n_oc, int k, int taps, int kc) {
+    return (size_t)round_up(n_oc, 32) * (size_t)round_up(k, kc) * (size_t)taps;
+}
+
+int lrpx_pack_weights(const float* w, int cout, int cin, int taps, int mode, int kc, float* packed, void* stream) {
+    LRPX_REQUIRE(w && packed, "pack_weights: null pointer");
+    LRPX_REQUIRE(taps == 9 || taps == 1, "pack_weights: taps must be 1 or 9");
+    LRPX_REQUIRE(kc == 8 || kc == 16 || kc == 32, "pack_weights: kc must be 8, 16 or 32");
+    LRPX_REQUIRE(mode >= 0 && mode <= LRPX_PACK_FWD_DUAL_FIRST, "pack_weights: unknown mode %d", mode);
+    int n_oc_pad, k_pad;
+    pack_dims(cout, cin, mode, kc, &n_oc_pad, &k_pad);
+    long total = (long)n_oc_pad * k_pad * taps;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, packed, cout,
+                       cin, taps, mode, kc, n_oc_pad, k_pad, total);
+    return check_launch("pack_weights");
+}
+
+int lrpx_nchw_to_nhwc(const float* src, float* dst, int n, int c, int hw_pix, int c_pad, void* stream) {
+    LRPX_REQUIRE(src && dst && c <= c_pad, "nchw_to_nhwc: bad arguments");
+    long total = (long)n * hw_pix * c_pad;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, c,
+                       hw_pix, c_pad, total);
+    return check_launch("nchw_to_nhwc");
+}
+
+int lrpx_nchw_to_nhwc_posneg(const float* src, float* dst, int n, int c, int hw_pix, int c_pad, void* stream) {
+    LRPX_REQUIRE(src && dst && 2 * c <= c_pad, "nchw_to_nhwc_posneg: bad arguments");
+    long total = (long)n * hw_pix * c_pad;
+    hipLaunchKernelGGL(nchw_to_nhwc_posneg_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       c, hw_pix, c_pad, total);
+    return check_launch("nchw_to_nhwc_posneg");
+}
+
+int lrpx_nhwc_to_nchw(const float* src, float* dst, int n, int c, int hw_pix, int c_src, void* stream) {
+    LRPX_REQUIRE(src && dst && c <= c_src, "nhwc_to_nchw: bad arguments");
+    long total = (long)n * hw_pix * c;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, c,
+                       hw_pix, c_src, total);
+    return check_launch("nhwc_to_nchw");
+}
+
+int lrpx_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream) {
+    LRPX_REQUIRE(x && y && (h % 2 == 0) && (w % 2 == 0) && (c % 4 == 0), "maxpool2x2_fwd: need even h,w and c%%4==0");
+    long total = (long)n * (h / 2) * (w / 2) * (c / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, h / 2,
+                       w / 2, c / 4, total);
+    return check_launch("maxpool2x2_fwd");
+}
+
+int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* zdiv, const int32_t* map2img,
+                              float* r_in, float* s_out, int n_maps, int h_out, int w_out, int c, void* stream) {
+    LRPX_REQUIRE(x && r_out && (r_in || s_out) && (c % 4 == 0), "maxpool2x2_relevance: bad arguments");
+    long total = (long)n_maps * (2 * h_out) * (2 * w_out) * (c / 4);
+    hipLaunchKernelGGL(maxpool_relevance_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, r_out,
+                       zdiv, map2img, r_in, s_out, h_out, w_out, c / 4, total);
+    return check_launch("maxpool2x2_relevance");
+}
+
+int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c,
+                     int stab, void* stream) {
+    LRPX_REQUIRE(r && z && s && (pix_c % 4 == 0), "divide_stab: bad arguments");
+    long total = (long)n_maps * (pix_c / 4);
+    hipLaunchKernelGGL(divide_stab_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, r, z, map2img, s,
+                       pix_c / 4, stab, total);
+    return check_launch("divide_stab");
+}
+
+int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long per, void* stream) {
+    LRPX_REQUIRE(in && out && (per % 4 == 0) && t_per_img > 0, "cumsum_maps: bad arguments");
+    long total = (long)n_img * (per / 4);
+    hipLaunchKernelGGL(cumsum_maps_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       t_per_img, per / 4, total);
+    return check_launch("cumsum_maps");
+}
+
+int lrpx_check(const float* buf, long n, int flags, void* stream) {
+    LRPX_REQUIRE(buf && n > 0, "check: bad arguments");
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    static unsigned* dflags = nullptr;   // init-once 4-byte scratch word owned by the library
+    if (!dflags && hipMalloc(&dflags, sizeof(unsigned)) != hipSuccess) {
+        set_error("check: cannot allocate flag word");
+        return LRPX_ELAUNCH;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(dflags, 0, sizeof(unsigned), st);
+    hipLaunchKernelGGL(check_kernel, dim3(1024), dim3(256), 0, st, buf, n, dflags);
+    unsigned h = 0;
+    (void)hipMemcpyAsync(&h, dflags, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) {
+        set_error("check: stream failure: %s", hipGetErrorString(hipGetLastError()));
+        return LRPX_ELAUNCH;
+    }
+    if ((flags & 1) && (h & 1u)) { set_error("check: NaN/Inf in relevance"); return LRPX_ENONFINITE; }
+    if ((flags & 2) && !(h & 2u)) { set_error("check: relevance is all zero"); return LRPX_EZERO; }
+    return LRPX_OK;
+}
+
+}  // extern "C"

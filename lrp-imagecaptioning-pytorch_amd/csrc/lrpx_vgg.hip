@@ -1,0 +1,252 @@
+// Conv dispatch + the VGG16 encoder chains (forward trace, LRP relevance) of liblrpx.
+//
+// Reference behaviour reproduced (paths relative to the reference repo):
+//   forward  : models/gridTDmodel.py:40-43 Encoder.forward over vgg16.features[0:-1] (models/vgg.py:62-81)
+//              + LRPtools/lrp_wrapper.py:24-25 save_input_hook (every leaf keeps its input)
+//   relevance: LRPtools/lrp_wrapper.py:63-87 compute_lrp -> per leaf, in reverse order,
+//              Conv2d alpha1beta0 (lrp_modules.py:124-150), ReLU identity (:42-46), MaxPool2d (:182-195)
+#include "conv_launch.h"
+
+namespace lrpx {
+
+int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
+    LRPX_REQUIRE(d && d->in && d->wpacked && (d->out0 || d->out1), "conv_mfma: null pointer");
+    LRPX_REQUIRE(d->taps == 9 || d->taps == 1, "conv_mfma: taps must be 9 or 1");
+    LRPX_REQUIRE(d->n_maps > 0 && d->cin > 0 && d->n_oc > 0 && d->n_oc % 32 == 0, "conv_mfma: bad sizes (n_oc %% 32)");
+    const int kc = lrpx_conv_kc(d->hw, d->taps, d->cin);
+    LRPX_REQUIRE(kc > 0 && d->cin % kc == 0, "conv_mfma: cin=%d is not a multiple of the K-chunk %d", d->cin, kc);
+    ConvArgs a;
+    a.in = d->in; a.wp = d->wpacked; a.n_maps = d->n_maps; a.cin = d->cin; a.n_oc = d->n_oc;
+    a.pix_per_map = d->taps == 9 ? d->hw * d->hw : d->pix_per_map;
+    a.epi = d->epi; a.stab = d->stab; a.oc_split = d->oc_split; a.relu = d->relu;
+    a.bias = d->bias; a.X = d->x; a.U = d->u; a.Zdiv = d->zdiv; a.map2img = d->map2img;
+    a.out0 = d->out0; a.out1 = d->out1;
+    LRPX_REQUIRE(a.pix_per_map > 0, "conv_mfma: pix_per_map must be positive");
+    LRPX_REQUIRE((long)a.n_maps * a.pix_per_map < 0x7fffffffL, "conv_mfma: too many pixels for 32-bit indexing");
+    switch (d->epi) {
+        case EPI_FWD_DUAL: LRPX_REQUIRE(d->out0 && d->out1 && 2 * d->oc_split <= d->n_oc, "conv_mfma: FWD_DUAL needs out0,out1"); break;
+        case EPI_REL: LRPX_REQUIRE(d->x && (d->out0 || d->out1) && (!d->out1 || d->zdiv || d->stab == STAB_NONE), "conv_mfma: REL needs x and (out0|out1,zdiv)"); break;
+        case EPI_FIRST: LRPX_REQUIRE(d->x && d->out0, "conv_mfma: FIRST needs x,out0"); break;
+        case EPI_PLAIN: LRPX_REQUIRE(d->out0, "conv_mfma: PLAIN needs out0"); break;
+        default: LRPX_REQUIRE(false, "conv_mfma: epilogue %d not built", d->epi);
+    }
+    if (d->taps == 1) {
+        if (d->epi == EPI_REL) return launch_conv_14_32_1_4_1_rel(a, s);
+        if (d->epi == EPI_PLAIN) return launch_conv_14_32_1_4_1_plain(a, s);
+        LRPX_REQUIRE(false, "conv_mfma: dense supports REL / PLAIN epilogues only");
+    }
+    const int e = d->epi;
+    switch (d->hw) {
+        case 224:
+            if (e == EPI_FWD_DUAL) return kc == 8 ? launch_conv_224_8_1_4_9_fwd_dual(a, s) : launch_conv_224_16_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return launch_conv_224_16_2_2_9_rel(a, s);
+            if (e == EPI_FIRST) { LRPX_REQUIRE(d->n_oc == 32, "conv_mfma: FIRST expects n_oc=32"); return launch_conv_224_16_2_1_9_first(a, s); }
+            break;
+        case 112:
+            if (e == EPI_FWD_DUAL) return launch_conv_112_16_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return d->n_oc <= 64 ? launch_conv_112_16_2_2_9_rel(a, s) : launch_conv_112_16_1_4_9_rel(a, s);
+            break;
+        case 56:
+            if (e == EPI_FWD_DUAL) return launch_conv_56_32_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return launch_conv_56_32_1_4_9_rel(a, s);
+            break;
+        case 28:
+            if (e == EPI_FWD_DUAL) return launch_conv_28_32_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return launch_conv_28_32_1_4_9_rel(a, s);
+            break;
+        case 14:
+            if (e == EPI_FWD_DUAL) return launch_conv_14_32_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return launch_conv_14_32_1_4_9_rel(a, s);
+            break;
+    }
+    set_error("conv_mfma: no kernel built for hw=%d epi=%d", d->hw, d->epi);
+    return LRPX_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------
+// VGG16 geometry (cfg 'D' without the last pool)
+// ------------------------------------------------------------------------------------------------
+struct VggLayer { int conv; int hw; int cin; int cout; };   // conv: 1 conv3x3, 0 maxpool; hw = input size
+static const VggLayer kVgg[17] = {
+    {1, 224, 3, 64},   {1, 224, 64, 64},   {0, 224, 64, 64},
+    {1, 112, 64, 128}, {1, 112, 128, 128}, {0, 112, 128, 128},
+    {1, 56, 128, 256}, {1, 56, 256, 256},  {1, 56, 256, 256}, {0, 56, 256, 256},
+    {1, 28, 256, 512}, {1, 28, 512, 512},  {1, 28, 512, 512}, {0, 28, 512, 512},
+    {1, 14, 512, 512}, {1, 14, 512, 512},  {1, 14, 512, 512}};
+static const int kNL = 17;
+static inline int cin_pad(int l) { return l == 0 ? 8 : kVgg[l].cin; }   // image is kept NHWC with 8 channels
+
+struct VggPacked {   // offsets in floats into the packed blob
+    size_t fwd[17], bwd[17], bias[17], total;
+};
+static VggPacked vgg_packed_layout() {
+    VggPacked p;
+    size_t off = 0;
+    for (int l = 0; l < kNL; ++l) {
+        p.fwd[l] = p.bwd[l] = p.bias[l] = 0;
+        if (!kVgg[l].conv) continue;
+        const VggLayer& L = kVgg[l];
+        p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
+        p.bwd[l] = off; off += lrpx_packed_floats(l == 0 ? 32 : L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout));
+        p.bias[l] = off; off += (size_t)L.cout;
+    }
+    p.total = off;
+    return p;
+}
+
+struct VggTrace {   // offsets in floats; act[l] = input of layer l, act[17] = encoder output
+    size_t act[18], zpos[17], total;
+};
+static VggTrace vgg_trace_layout(int n_img) {
+    VggTrace t;
+    size_t off = 0;
+    for (int l = 0; l <= kNL; ++l) {
+        int hw, c;
+        if (l < kNL) { hw = kVgg[l].hw; c = cin_pad(l); }
+        else { hw = 14; c = 512; }
+        t.act[l] = off;
+        off += (size_t)n_img * hw * hw * c;
+    }
+    for (int l = 0; l < kNL; ++l) {
+        t.zpos[l] = off;
+        if (kVgg[l].conv) off += (size_t)n_img * kVgg[l].hw * kVgg[l].hw * kVgg[l].cout;
+    }
+    t.total = off;
+    return t;
+}
+
+}  // namespace lrpx
+
+using namespace lrpx;
+
+extern "C" {
+
+int lrpx_conv_kc(int hw, int taps, int cin) {
+    if (taps == 1) return 32;
+    if (hw >= 112) return cin <= 8 ? 8 : 16;
+    return 32;
+}
+
+int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream) { return conv_dispatch(d, (hipStream_t)stream); }
+
+size_t lrpx_vgg16_packed_bytes(void) { return vgg_packed_layout().total * sizeof(float); }
+size_t lrpx_vgg16_trace_bytes(int n_img) { return vgg_trace_layout(n_img).total * sizeof(float); }
+size_t lrpx_vgg16_workspace_bytes(int n_maps) {
+    // two ping-pong S buffers (largest: 224*224*64 per map) + one R buffer in front of a pool (112*112*64)
+    return ((size_t)2 * 224 * 224 * 64 + (size_t)112 * 112 * 64) * (size_t)n_maps * sizeof(float);
+}
+
+int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, void* stream) {
+    LRPX_REQUIRE(w && b && packed, "vgg16_pack: null pointer");
+    VggPacked p = vgg_packed_layout();
+    float* base = (float*)packed;
+    int ci = 0;
+    for (int l = 0; l < kNL; ++l) {
+        if (!kVgg[l].conv) continue;
+        const VggLayer& L = kVgg[l];
+        LRPX_REQUIRE(w[ci] && b[ci], "vgg16_pack: null weight %d", ci);
+        LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, l == 0 ? LRPX_PACK_FWD_DUAL_FIRST : LRPX_PACK_FWD_DUAL,
+                                   lrpx_conv_kc(L.hw, 9, cin_pad(l)),
+                                   base + p.fwd[l], stream));
+        LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, l == 0 ? LRPX_PACK_BWD_FIRST : LRPX_PACK_BWD_POS,
+                                   lrpx_conv_kc(L.hw, 9, L.cout), base + p.bwd[l], stream));
+        if (hipMemcpyAsync(base + p.bias[l], b[ci], L.cout * sizeof(float), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream) != hipSuccess) {
+            set_error("vgg16_pack: bias copy failed");
+            return LRPX_ELAUNCH;
+        }
+        ++ci;
+    }
+    return LRPX_OK;
+}
+
+int lrpx_vgg16_trace_layout(int n_img, size_t* act_off, size_t* zpos_off) {
+    LRPX_REQUIRE(n_img > 0 && act_off && zpos_off, "vgg16_trace_layout: bad arguments");
+    const VggTrace t = vgg_trace_layout(n_img);
+    for (int l = 0; l <= kNL; ++l) act_off[l] = t.act[l];
+    for (int l = 0; l < kNL; ++l) zpos_off[l] = kVgg[l].conv ? t.zpos[l] : 0;
+    return LRPX_OK;
+}
+
+const float* lrpx_vgg16_trace_features(const void* trace, int n_img) {
+    return (const float*)trace + vgg_trace_layout(n_img).act[kNL];
+}
+
+int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, void* trace, float* feat_nhwc,
+                       void* stream) {
+    LRPX_REQUIRE(packed && img_nchw && trace && n_img > 0, "vgg16_forward: bad arguments");
+    const VggPacked p = vgg_packed_layout();
+    const VggTrace t = vgg_trace_layout(n_img);
+    const float* pk = (const float*)packed;
+    float* tr = (float*)trace;
+    // the signed image is kept split into x+ / x- (channels 0-2 / 3-5 of 8): Z of the first conv needs both
+    LRPX_TRY(lrpx_nchw_to_nhwc_posneg(img_nchw, tr + t.act[0], n_img, 3, 224 * 224, 8, stream));
+    for (int l = 0; l < kNL; ++l) {
+        const VggLayer& L = kVgg[l];
+        if (L.conv) {
+            lrpx_conv_desc d = {};
+            d.in = tr + t.act[l]; d.wpacked = pk + p.fwd[l];
+            d.n_maps = n_img; d.hw = L.hw; d.cin = cin_pad(l); d.n_oc = 2 * L.cout; d.taps = 9;
+            d.epi = EPI_FWD_DUAL; d.oc_split = L.cout; d.bias = pk + p.bias[l];
+            d.out0 = tr + t.act[l + 1]; d.out1 = tr + t.zpos[l];
+            LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
+        } else {
+            LRPX_TRY(lrpx_maxpool2x2_fwd(tr + t.act[l], tr + t.act[l + 1], n_img, L.hw, L.hw, L.cin, stream));
+        }
+    }
+    if (feat_nhwc) {
+        if (hipMemcpyAsync(feat_nhwc, tr + t.act[kNL], (size_t)n_img * 196 * 512 * sizeof(float),
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+            set_error("vgg16_forward: feature copy failed");
+            return LRPX_ELAUNCH;
+        }
+    }
+    return LRPX_OK;
+}
+
+int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const float* r_feat_nhwc,
+                         const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream) {
+    LRPX_REQUIRE(packed && trace && r_feat_nhwc && workspace && out_nchw && n_maps > 0 && n_img > 0,
+                 "vgg16_relevance: bad arguments");
+    LRPX_REQUIRE(map2img || n_maps == n_img, "vgg16_relevance: map2img is required when n_maps != n_img");
+    const VggPacked p = vgg_packed_layout();
+    const VggTrace t = vgg_trace_layout(n_img);
+    const float* pk = (const float*)packed;
+    const float* tr = (const float*)trace;
+    float* ws = (float*)workspace;
+    const size_t sbuf = (size_t)224 * 224 * 64 * n_maps;
+    float* S[2] = {ws, ws + sbuf};
+    float* R = ws + 2 * sbuf;
+    int cur = 0;
+    // S_16 = R_feat / safe(Z+_16)
+    LRPX_TRY(lrpx_divide_stab(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, STAB_SAFE, stream));
+    for (int l = kNL - 1; l >= 0; --l) {
+        const VggLayer& L = kVgg[l];
+        if (!L.conv) continue;   // pools are handled together with the conv above them
+        lrpx_conv_desc d = {};
+        d.in = S[cur]; d.wpacked = pk + p.bwd[l];
+        d.n_maps = n_maps; d.hw = L.hw; d.cin = L.cout; d.taps = 9; d.map2img = map2img;
+        d.x = tr + t.act[l];
+        if (l == 0) {
+            d.n_oc = 32; d.epi = EPI_FIRST; d.oc_split = 8; d.out0 = out_nchw;
+            LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
+            break;
+        }
+        d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
+        if (kVgg[l - 1].conv) {
+            // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
+            d.out1 = S[cur ^ 1]; d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE;
+            LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
+        } else {
+            // a pool lies below: R at the pool output, then the Pool2d rule + division by Z+ of the conv under it
+            d.out0 = R;
+            LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
+            LRPX_TRY(lrpx_maxpool2x2_relevance(tr + t.act[l - 1], R, tr + t.zpos[l - 2], map2img, nullptr, S[cur ^ 1],
+                                               n_maps, L.hw, L.hw, L.cin, stream));
+        }
+        cur ^= 1;
+    }
+    return LRPX_OK;
+}
+
+}  // extern "C"

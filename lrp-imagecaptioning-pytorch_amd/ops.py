@@ -1,0 +1,172 @@
+"""Thin torch-tensor wrappers over the lrpx C ABI (include/lrpx.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every computation is a
+hand-written HIP kernel inside csrc/liblrpx.so.  All tensors are CUDA(=HIP) float32 contiguous;
+activations are NHWC ([maps, H*W, C])."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ConvDesc, EPI_FIRST, EPI_FWD_DUAL, EPI_PLAIN, EPI_REL, PACK_BWD_FIRST, PACK_BWD_POS,
+                   PACK_DENSE, PACK_DENSE_T, PACK_FWD_DUAL, STAB_EPS, STAB_NONE, STAB_SAFE, check, ptr, stream_ptr)
+
+
+def _dev(t):
+    if t is not None and not t.is_cuda:
+        raise ValueError("lrpx ops need device tensors (there is no CPU path)")
+    return t
+
+
+def conv_kc(hw, taps, cin):
+    return _lib.load().lrpx_conv_kc(hw, taps, cin)
+
+
+def pack_weights(w, cout, cin, taps, mode, kc):
+    """w: conv (cout,cin,3,3) or dense 2-D matrix on device -> packed fragment-major tensor."""
+    lib = _lib.load()
+    _dev(w)
+    if mode in (PACK_FWD_DUAL,):
+        n_oc, k = 2 * cout, cin
+    elif mode in (PACK_BWD_POS, _lib.PACK_BWD_PLAIN, PACK_DENSE_T):
+        n_oc, k = cin, cout
+    elif mode == PACK_BWD_FIRST:
+        n_oc, k = 2 * cin, cout
+    else:
+        n_oc, k = cout, cin
+    n = lib.lrpx_packed_floats(n_oc, k, taps, kc)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.lrpx_pack_weights(ptr(w.contiguous()), cout, cin, taps, mode, kc, ptr(out), stream_ptr()))
+    return out
+
+
+def conv_mfma(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, *, pix_per_map=0, stab=STAB_NONE, oc_split=0,
+              relu=0, bias=None, x=None, u=None, zdiv=None, map2img=None, out0=None, out1=None):
+    d = ConvDesc()
+    d.in_, d.wpacked = ptr(_dev(inp)), ptr(_dev(wpacked))
+    d.n_maps, d.hw, d.cin, d.n_oc, d.taps, d.pix_per_map = n_maps, hw, cin, n_oc, taps, pix_per_map
+    d.epi, d.stab, d.oc_split, d.relu = epi, stab, oc_split, relu
+    d.bias, d.x, d.u, d.zdiv, d.map2img = ptr(bias), ptr(x), ptr(u), ptr(zdiv), ptr(map2img)
+    d.out0, d.out1 = ptr(out0), ptr(out1)
+    check(_lib.load().lrpx_conv_mfma(C.byref(d), stream_ptr()))
+
+
+def nchw_to_nhwc(src, c_pad=None):
+    n, c, h, w = src.shape
+    c_pad = c_pad or c
+    dst = torch.empty(n, h * w, c_pad, dtype=torch.float32, device=src.device)
+    check(_lib.load().lrpx_nchw_to_nhwc(ptr(src.contiguous()), ptr(dst), n, c, h * w, c_pad, stream_ptr()))
+    return dst
+
+
+def nhwc_to_nchw(src, c, h, w):
+    n, p, c_src = src.shape
+    dst = torch.empty(n, c, h, w, dtype=torch.float32, device=src.device)
+    check(_lib.load().lrpx_nhwc_to_nchw(ptr(src), ptr(dst), n, c, p, c_src, stream_ptr()))
+    return dst
+
+
+def maxpool2x2_fwd(x, n, h, w, c):
+    y = torch.empty(n, (h // 2) * (w // 2), c, dtype=torch.float32, device=x.device)
+    check(_lib.load().lrpx_maxpool2x2_fwd(ptr(x), ptr(y), n, h, w, c, stream_ptr()))
+    return y
+
+
+def maxpool2x2_relevance(x, r_out, zdiv, map2img, n_maps, h_out, w_out, c, want_r=True, want_s=False):
+    r_in = torch.empty(n_maps, 4 * h_out * w_out, c, dtype=torch.float32, device=x.device) if want_r else None
+    s_out = torch.empty(n_maps, 4 * h_out * w_out, c, dtype=torch.float32, device=x.device) if want_s else None
+    check(_lib.load().lrpx_maxpool2x2_relevance(ptr(x), ptr(r_out), ptr(zdiv), ptr(map2img), ptr(r_in), ptr(s_out),
+                                                n_maps, h_out, w_out, c, stream_ptr()))
+    return r_in, s_out
+
+
+def divide_stab(r, z, map2img, stab):
+    n = r.shape[0]
+    s = torch.empty_like(r)
+    check(_lib.load().lrpx_divide_stab(ptr(r), ptr(z), ptr(map2img), ptr(s), n, r[0].numel(), stab, stream_ptr()))
+    return s
+
+
+def cumsum_maps(maps, n_img, t_per_img):
+    out = torch.empty_like(maps)
+    check(_lib.load().lrpx_cumsum_maps(ptr(maps), ptr(out), n_img, t_per_img, maps[0].numel(), stream_ptr()))
+    return out
+
+
+def check_relevance(buf, finite=True, nonzero=False):
+    """The reference's inline asserts (lrp_modules.py:154-155, lrp_wrapper.py:81); syncs the stream."""
+    check(_lib.load().lrpx_check(ptr(buf), buf.numel(), (1 if finite else 0) | (2 if nonzero else 0), stream_ptr()))
+
+
+class Vgg16:
+    """VGG16 encoder context: packed weights + per-batch trace (device memory owned by torch)."""
+
+    def __init__(self, weights, biases):
+        lib = _lib.load()
+        dev = weights[0].device
+        self.device = dev
+        self.packed = torch.empty(lib.lrpx_vgg16_packed_bytes() // 4, dtype=torch.float32, device=dev)
+        ws = [w.contiguous() for w in weights]
+        bs = [b.contiguous() for b in biases]
+        wp = (C.c_void_p * 13)(*[w.data_ptr() for w in ws])
+        bp = (C.c_void_p * 13)(*[b.data_ptr() for b in bs])
+        check(lib.lrpx_vgg16_pack(wp, bp, ptr(self.packed), stream_ptr()))
+        torch.cuda.current_stream().synchronize()   # ws/bs may be temporaries
+        self.trace = None
+        self.n_img = 0
+        self._ws = None
+
+    def forward(self, img_nchw):
+        """Encoder.forward + trace (models/gridTDmodel.py:40-43).  Returns features (B,196,512) NHWC (a view
+        into the trace)."""
+        lib = _lib.load()
+        n = img_nchw.shape[0]
+        assert tuple(img_nchw.shape[1:]) == (3, 224, 224)
+        need = lib.lrpx_vgg16_trace_bytes(n) // 4
+        if self.trace is None or self.trace.numel() < need or self.n_img != n:
+            self.trace = torch.empty(need, dtype=torch.float32, device=self.device)
+        self.n_img = n
+        check(lib.lrpx_vgg16_forward(ptr(self.packed), ptr(img_nchw.contiguous()), n, ptr(self.trace), None,
+                                     stream_ptr()))
+        off = lib.lrpx_vgg16_trace_features(ptr(self.trace), n) - self.trace.data_ptr()
+        return self.trace[off // 4: off // 4 + n * 196 * 512].view(n, 196, 512)
+
+    # (hw, channels) of act[l] for l = 0..17 and of zpos[l]
+    ACT_DIMS = [(224, 8), (224, 64), (224, 64), (112, 64), (112, 128), (112, 128), (56, 128), (56, 256), (56, 256),
+                (56, 256), (28, 256), (28, 512), (28, 512), (28, 512), (14, 512), (14, 512), (14, 512), (14, 512)]
+    IS_CONV = [1, 1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1]
+
+    def trace_views(self):
+        """Views of the saved per-layer tensors (what `module.input` is to the reference's hooks):
+        ([act[0..17]] as (n_img, hw*hw, C), [zpos[l] or None])."""
+        lib = _lib.load()
+        n = self.n_img
+        a_off = (C.c_size_t * 18)()
+        z_off = (C.c_size_t * 17)()
+        check(lib.lrpx_vgg16_trace_layout(n, a_off, z_off))
+        acts, zs = [], []
+        for l in range(18):
+            hw, c = self.ACT_DIMS[l]
+            acts.append(self.trace[a_off[l]: a_off[l] + n * hw * hw * c].view(n, hw * hw, c))
+        for l in range(17):
+            if self.IS_CONV[l]:
+                c = self.ACT_DIMS[l + 1][1]
+                hw = self.ACT_DIMS[l][0]
+                zs.append(self.trace[z_off[l]: z_off[l] + n * hw * hw * c].view(n, hw * hw, c))
+            else:
+                zs.append(None)
+        return acts, zs
+
+    def relevance(self, r_feat_nhwc, map2img=None, out=None):
+        """compute_lrp (LRPtools/lrp_wrapper.py:63-87) for N maps: (N,196,512) -> (N,3,224,224)."""
+        lib = _lib.load()
+        n_maps = r_feat_nhwc.shape[0]
+        need = lib.lrpx_vgg16_workspace_bytes(n_maps) // 4
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(n_maps, 3, 224, 224, dtype=torch.float32, device=self.device)
+        check(lib.lrpx_vgg16_relevance(ptr(self.packed), ptr(self.trace), self.n_img, ptr(r_feat_nhwc.contiguous()),
+                                       ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
+        return out

@@ -1,0 +1,258 @@
+"""GPU parity of the VGG16 half of the hot path, through the C ABI (liblrpx.so), against
+  (a) the reference's own outputs (tests/golden/*.npz) and
+  (b) the CPU oracle on seeded inputs.
+Tolerances: max|dR|/max|R_ref| <= 1e-4 (BASELINE.json north_star) — fp32 MFMA is a k-ordered fmaf
+chain, so the observed error is ~1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import lrp_amd  # noqa: F401
+from conftest import GOLDEN, rel_err, cosine
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import ops as o
+    return o
+
+
+def to_nhwc(x, c_pad=None):
+    n, c, h, w = x.shape
+    c_pad = c_pad or c
+    out = torch.zeros(n, h * w, c_pad)
+    out[:, :, :c] = x.permute(0, 2, 3, 1).reshape(n, h * w, c)
+    return out
+
+
+def from_nhwc(x, c, h, w):
+    return x[:, :, :c].reshape(x.shape[0], h, w, c).permute(0, 3, 1, 2).contiguous()
+
+
+def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None):
+    """alpha1beta0 rule for one conv layer with non-negative input x (n_img,cin,hw,hw); r_out per map."""
+    from lrp_amd import _lib
+    n_img, cin, hw, _ = x.shape
+    cout = w.shape[0]
+    n_maps = r_out.shape[0]
+    cin_p = max(-(-cin // 32) * 32, 32) if hw < 112 else max(-(-cin // 16) * 16, 16)
+    cout_p = max(-(-cout // 32) * 32, 32)
+    dev = "cuda"
+    wpad = torch.zeros(cout_p, cin_p, 3, 3)
+    wpad[:cout, :cin] = w
+    xg = to_nhwc(x, cin_p).to(dev)
+    wg = wpad.to(dev)
+    kc_f = ops.conv_kc(hw, 9, cin_p)
+    wf = ops.pack_weights(wg, cout_p, cin_p, 9, _lib.PACK_FWD_DUAL, kc_f)
+    act = torch.empty(n_img, hw * hw, cout_p, device=dev)
+    zpos = torch.empty(n_img, hw * hw, cout_p, device=dev)
+    bpad = torch.zeros(cout_p)
+    if bias is not None:
+        bpad[:cout] = bias
+    ops.conv_mfma(xg, wf, n_img, hw, cin_p, 2 * cout_p, 9, _lib.EPI_FWD_DUAL, oc_split=cout_p, bias=bpad.to(dev),
+                  out0=act, out1=zpos)
+    m2i = None if map2img is None else torch.tensor(map2img, dtype=torch.int32, device=dev)
+    s = ops.divide_stab(to_nhwc(r_out, cout_p).to(dev), zpos, m2i, _lib.STAB_SAFE)
+    kc_b = ops.conv_kc(hw, 9, cout_p)
+    wb = ops.pack_weights(wg, cout_p, cin_p, 9, _lib.PACK_BWD_POS, kc_b)
+    r_in = torch.empty(n_maps, hw * hw, cin_p, device=dev)
+    ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL, oc_split=cin_p, x=xg, map2img=m2i, out0=r_in)
+    torch.cuda.synchronize()
+    return (from_nhwc(r_in.cpu(), cin, hw, hw), from_nhwc(act.cpu(), cout, hw, hw),
+            from_nhwc(zpos.cpu(), cout, hw, hw))
+
+
+@pytest.mark.parametrize("hw,cin,cout,n_img,n_maps", [
+    (14, 64, 96, 3, 5), (28, 32, 64, 2, 3), (56, 64, 128, 1, 2), (112, 32, 64, 1, 2), (112, 128, 128, 1, 1),
+    (224, 64, 64, 1, 1)])
+def test_conv_rule_vs_oracle(ops, hw, cin, cout, n_img, n_maps):
+    from oracle import lrp_oracle as O
+    g = torch.Generator().manual_seed(hw * 1000 + cin)
+    x = torch.relu(torch.randn(n_img, cin, hw, hw, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) * 0.1
+    r = torch.randn(n_maps, cout, hw, hw, generator=g)
+    m2i = [i % n_img for i in range(n_maps)]
+    got, act, zpos = gpu_conv_rule(ops, x, w, r, m2i, bias=b)
+    want = torch.cat([O.conv_alpha1beta0(x[m2i[i]:m2i[i] + 1], w, r[i:i + 1]) for i in range(n_maps)])
+    assert rel_err(act, F.relu(F.conv2d(x, w, b, padding=1))) < 1e-5
+    assert rel_err(zpos, F.conv2d(x, w.clamp(min=0), padding=1)) < 1e-5
+    assert rel_err(got, want) < TOL
+    assert cosine(got, want) > 0.99999
+
+
+def test_reference_conv_fixture_embedded(ops):
+    """The reference's own Conv2d.propagate_relevance output (layers.npz, 6x6 maps incl. an exact-zero
+    region) through the MFMA kernel, embedded in a zero 14x14 canvas (zero surroundings == zero padding).
+    The fixture input is signed, which only the first-layer path handles; use its non-negative part."""
+    from oracle import lrp_oracle as O
+    G = np.load(os.path.join(GOLDEN, "layers.npz"))
+    x = torch.from_numpy(G["conv_x"]).clamp(min=0)
+    w, r = torch.from_numpy(G["conv_w"]), torch.from_numpy(G["conv_rout"])
+    want = O.conv_alpha1beta0(x, w, r)          # oracle is pinned on the signed fixture in test_oracle_layers
+    X = torch.zeros(2, 4, 14, 14); X[:, :, :6, :6] = x
+    R = torch.zeros(2, 6, 14, 14); R[:, :, :6, :6] = r
+    got, _, _ = gpu_conv_rule(ops, X, w, R)
+    assert rel_err(got[:, :, :6, :6], want) < TOL
+    assert got[:, :, 6:, :].abs().max() == 0 and got[:, :, :, 7:].abs().max() == 0
+
+
+def test_maxpool_rule_reference_fixture(ops):
+    from lrp_amd import _lib
+    G = np.load(os.path.join(GOLDEN, "layers.npz"))
+    x, r, want = (torch.from_numpy(G[k]) for k in ("pool_x", "pool_rout", "pool_rin"))
+    xp = torch.zeros(2, 4, 8, 8); xp[:, :3] = x
+    rp = torch.zeros(2, 4, 4, 4); rp[:, :3] = r
+    r_in, _ = ops.maxpool2x2_relevance(to_nhwc(xp).cuda(), to_nhwc(rp).cuda(), None, None, 2, 4, 4, 4)
+    got = from_nhwc(r_in.cpu(), 3, 8, 8)
+    assert torch.equal(got, want)        # routing + x*(r/x) is elementwise: bit-exact, incl. tie and zero window
+
+
+def _vgg(ops, sd):
+    names = [k for k in sd if k.startswith("img_encoder.encoder.") and k.endswith(".weight")]
+    ws = [torch.from_numpy(sd[k]).cuda() for k in names]
+    bs = [torch.from_numpy(sd[k.replace(".weight", ".bias")]).cuda() for k in names]
+    return ops.Vgg16(ws, bs)
+
+
+@pytest.fixture(scope="module")
+def gridtd_case(ops):
+    from lrp_amd import weights
+    g = np.load(os.path.join(GOLDEN, "gridtd_T3.npz"))
+    sd = weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=int(g["V"]))
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    return g, sd, img
+
+
+def test_vgg_forward_vs_reference_features(ops, gridtd_case):
+    g, sd, img = gridtd_case
+    vgg = _vgg(ops, sd)
+    feats = vgg.forward(img.cuda())
+    torch.cuda.synchronize()
+    got = from_nhwc(feats.cpu(), 512, 14, 14)
+    assert rel_err(got, g["features"]) < 1e-4
+    assert cosine(got, g["features"]) > 0.99999
+
+
+def _inject_oracle_trace(vgg, sd, img):
+    """Overwrite the GPU trace with the CPU (oneDNN) forward of the same image, so that the max-pool winners
+    are the reference's own (see DESIGN.md 'parity and pool ties')."""
+    from oracle import lrp_oracle as O
+    sdt = O.state_to_torch(sd)
+    feats, _, saved = O.vgg_forward(sdt, img)
+    acts, zs = vgg.trace_views()
+    layers = O.vgg_layers()
+    for l, x in enumerate(saved + [feats]):
+        if l == 0:
+            split = torch.cat([x.clamp(min=0), x.clamp(max=0)], dim=1)
+            acts[0].copy_(to_nhwc(split, 8))
+        else:
+            acts[l].copy_(to_nhwc(x))
+    for l, (kind, idx, cin, cout) in enumerate(layers):
+        if kind == "conv":
+            w = sdt[f"img_encoder.encoder.{idx}.weight"]
+            x = saved[l]
+            z = F.conv2d(x.clamp(min=0), w.clamp(min=0), padding=1) + F.conv2d(x.clamp(max=0), w.clamp(max=0), padding=1)
+            zs[l].copy_(to_nhwc(z))
+
+
+def test_vgg_relevance_vs_reference_maps_same_trace(ops, gridtd_case):
+    """STRICT parity of the relevance kernels (1e-4): r_feat produced by the reference's decoder (golden) ->
+    pixel maps, on the reference's own forward activations; the reference returns running sums
+    (lrp_wrapper.py:64-82 quirk), reproduced with lrpx_cumsum_maps."""
+    g, sd, img = gridtd_case
+    vgg = _vgg(ops, sd)
+    vgg.forward(img.cuda())
+    _inject_oracle_trace(vgg, sd, img)
+    r_feat = torch.cat([torch.from_numpy(g[f"r_feat_{t}"]) for t in range(3)])           # (3,512,14,14)
+    m2i = torch.zeros(3, dtype=torch.int32, device="cuda")
+    maps = vgg.relevance(to_nhwc(r_feat).cuda(), m2i)
+    ops.check_relevance(maps, finite=True, nonzero=True)
+    cum = ops.cumsum_maps(maps, 1, 3).cpu()
+    for t in range(3):
+        scale = g[f"map_stats_{t}"][1]
+        assert np.abs(cum[t:t + 1, :, ::4, ::4].numpy() - g[f"map_sub4_{t}"]).max() / scale < TOL
+        assert abs(cum[t].double().sum().item() - g[f"map_stats_{t}"][0]) <= 1e-3 * abs(g[f"map_stats_{t}"][0])
+    assert rel_err(cum[2:3], g["map_full_2"]) < TOL
+    assert cosine(cum[2:3], g["map_full_2"]) > 0.99999
+    assert (cum[2:3] - torch.from_numpy(g["map_full_2"])).abs().max() < 1e-4
+
+
+def test_vgg_relevance_vs_reference_maps_end_to_end(ops, gridtd_case):
+    """GPU forward + GPU relevance vs the reference's maps.  Rounding-level differences of the forward
+    (fp32 MFMA fmaf chain vs oneDNN) flip the winner of a handful of near-tied 2x2 pool windows out of 1.5M,
+    each moving one channel's relevance by one pixel.  The reference moves by 1.6e-4 between its OWN oneDNN
+    and native CPU conv back-ends on this image (2 flips; measured in DESIGN.md), so the end-to-end bound
+    is 1e-3 with cosine >= 0.99999; the strict 1e-4 bound is checked on identical activations above."""
+    g, sd, img = gridtd_case
+    vgg = _vgg(ops, sd)
+    vgg.forward(img.cuda())
+    r_feat = torch.cat([torch.from_numpy(g[f"r_feat_{t}"]) for t in range(3)])
+    maps = vgg.relevance(to_nhwc(r_feat).cuda(), torch.zeros(3, dtype=torch.int32, device="cuda"))
+    cum = ops.cumsum_maps(maps, 1, 3).cpu()
+    for t in range(3):
+        scale = g[f"map_stats_{t}"][1]
+        assert np.abs(cum[t:t + 1, :, ::4, ::4].numpy() - g[f"map_sub4_{t}"]).max() / scale < 1e-3
+    assert rel_err(cum[2:3], g["map_full_2"]) < 1e-3
+    assert cosine(cum[2:3], g["map_full_2"]) > 0.99999
+    assert (cum[2:3] - torch.from_numpy(g["map_full_2"])).abs().max() < 1e-4      # BASELINE absolute bound
+
+
+def test_vgg_chain_multi_image_vs_oracle(ops):
+    """B=2 images, 3 maps with a non-trivial map->image table, nonzero conv biases."""
+    from lrp_amd import weights
+    from oracle import lrp_oracle as O
+    sd = weights.make_gridtd_state(seed=3, vocab_size=64, vgg_bias_std=0.05)
+    sdt = O.state_to_torch(sd)
+    img = torch.from_numpy(weights.make_images(5, 2))
+    torch.manual_seed(0)
+    r_feat = torch.randn(3, 512, 14, 14) * torch.rand(3, 512, 14, 14)
+    m2i = [1, 0, 1]
+    vgg = _vgg(ops, sd)
+    vgg.forward(img.cuda())
+    maps = vgg.relevance(to_nhwc(r_feat).cuda(), torch.tensor(m2i, dtype=torch.int32, device="cuda")).cpu()
+    for i, b in enumerate(m2i):
+        _, _, saved = O.vgg_forward(sdt, img[b:b + 1])
+        want = O.vgg_lrp(sdt, saved, r_feat[i:i + 1])
+        assert rel_err(maps[i:i + 1], want) < 1e-3, i           # end-to-end: pool-tie flips allowed (see above)
+        assert cosine(maps[i:i + 1], want) > 0.99999
+    _inject_oracle_trace(vgg, sd, img)                           # strict: identical activations
+    maps = vgg.relevance(to_nhwc(r_feat).cuda(), torch.tensor(m2i, dtype=torch.int32, device="cuda")).cpu()
+    for i, b in enumerate(m2i):
+        _, _, saved = O.vgg_forward(sdt, img[b:b + 1])
+        want = O.vgg_lrp(sdt, saved, r_feat[i:i + 1])
+        assert rel_err(maps[i:i + 1], want) < TOL, i
+
+
+def test_vgg_relevance_conservation(ops, gridtd_case):
+    """Size-independent property: with a strictly positive target the alpha1beta0 stack
+    conserves relevance: sum(R_img) == sum(target) up to fp32 rounding."""
+    g, sd, img = gridtd_case
+    vgg = _vgg(ops, sd)
+    vgg.forward(img.cuda())
+    torch.manual_seed(1)
+    r_feat = torch.rand(2, 196, 512, device="cuda") + 0.1
+    feats = vgg.forward(img.cuda())
+    r_feat = r_feat * (feats > 0)      # relevance only where the encoder output is active (Z+ > 0 there)
+    maps = vgg.relevance(r_feat, torch.zeros(2, dtype=torch.int32, device="cuda"))
+    for i in range(2):
+        assert abs(maps[i].double().sum().item() / r_feat[i].double().sum().item() - 1) < 2e-3
+
+
+def test_errors_raise_like_the_reference(ops):
+    z = torch.zeros(1, 8, device="cuda")
+    with pytest.raises(AssertionError):          # lrp_wrapper.py:81 `assert sample.grad.sum()!=0`
+        ops.check_relevance(z, nonzero=True)
+    z[0, 0] = float("nan")
+    with pytest.raises(AssertionError):          # lrp_modules.py:154
+        ops.check_relevance(z)
+    with pytest.raises(ValueError):              # unsupported shape -> ValueError (lrp_modules.py:338 style)
+        ops.conv_mfma(z, z, 1, 17, 32, 32, 9, 1, x=z, out0=z, oc_split=32)
