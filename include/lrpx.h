@@ -126,6 +126,60 @@ int lrpx_vgg16_trace_layout(int n_img, size_t* act_off, size_t* zpos_off);
 /* pointer to the encoder output features (n_img,196,512) inside a trace */
 const float* lrpx_vgg16_trace_features(const void* trace, int n_img);
 
+
+/* ---- small dense / utility kernels of the decoders ----------------------------------------------- */
+/* out[b][n] = act(sum_k x[b][k] w[n][k] + bias[n]); w in nn.Linear layout (N,K); a few rows b (weight-read bound).
+ * act: 0 none, 1 relu.  ldx/ldo = row strides in floats.  (nn.Linear / LSTMCell matmuls of
+ * models/gridTDmodel.py:773-797, :980-990 at batch size B) */
+int lrpx_linear_small(const float* x, long ldx, const float* w, const float* bias, float* out, long ldo, int B, int K,
+                      int N, int act, void* stream);
+/* avg[b][c] = mean_p f[b][p][c]   (nn.AdaptiveAvgPool2d(1), models/gridTDmodel.py:38,42) */
+int lrpx_mean_pixels(const float* f, float* avg, int B, int P, int C, void* stream);
+int lrpx_relu(const float* x, float* y, long n, void* stream);
+/* first maximum per row -> int64 (torch.argmax / topk(1), models/gridTDmodel.py:499, :849) */
+int lrpx_argmax_rows(const float* x, long ld, int rows, int n, long long* out, void* stream);
+/* logit[b*T+t] = fc.weight[tok[b][t+1]] . hc[b][t] + fc.bias[...]  (the one entry of `predictions`
+ * that explain_caption_wordt reads, models/gridTDmodel.py:1027,1034) */
+int lrpx_target_logit(const float* hc, const float* fcw, const float* fcb, const long long* tok, int tok_ld,
+                      float* logit, int B, int T, int H, void* stream);
+
+/* ---- gridTD decoder: trace (get_hidden_parameters, models/gridTDmodel.py:933-1012) ------------------ */
+typedef struct lrpx_gridtd_trace {
+    int B, T, H, E, P;
+    float *xh1, *xh2;                   /* [B][T][2E+2H] = x1t ++ h1t ; [B][T][3H] = x2t ++ h2t  (:1025-1026) */
+    float *h1, *c1, *h2, *c2;           /* [B][T+1][H] */
+    float *g1, *i1, *f1, *g2, *i2, *f2; /* [B][T][H]  g = pre-activation, i/f = activations (:1002-1009) */
+    float *s, *ctx, *ctx_hat, *hc;      /* [B][T][H]  hc = h2[t+1] + ctx_hat[t] (fc input) */
+    float *alpha, *beta;                /* [B][T][P], [B][T] */
+} lrpx_gridtd_trace;
+/* per step t: build xh1 ; LSTM point-wise (which = 1 AdaLSTM incl. sentinel, 2 LanguageLSTM) ; adaptive attention */
+int lrpx_gridtd_fwd_pre(const lrpx_gridtd_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
+                        int tok_ld, void* stream);
+int lrpx_gridtd_fwd_lstm(const lrpx_gridtd_trace* tr, int t, const float* zz, int ldz, int which, void* stream);
+int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img,
+                              const float* Wg, const float* Ws, const float* bs, const float* wh, void* stream);
+
+/* ---- gridTD decoder: relevance (explain_caption_wordt, models/gridTDmodel.py:1014-1135) -------------- */
+typedef struct lrpx_gridtd_relstate {
+    const int32_t* lens;                /* [B] words per image (null: T) */
+    float *r_h2n, *r_c2, *r_c1, *r_ch0, *r_h2p; /* [B*T][H] */
+    float* r_glob;                      /* [B*T][E] */
+    float *A, *rx;                      /* dense-rule input [B*T][H] / output [B*T][2E+2H] */
+    float* wacc;                        /* [B*T][T][H] */
+    float* r_words;                     /* [B*T][T] */
+} lrpx_gridtd_relstate;
+int lrpx_gridtd_rel_init(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* fcw,
+                         const float* logit, const long long* tok, int tok_ld, void* stream);
+/* lock-step s, phase 0: LanguageLSTM cell split (:1061-1069) -> A ; 1: after its dense rule (:1074-1105) -> A ;
+ * 2: after the AdaLSTM dense rule (:1110-1115) */
+int lrpx_gridtd_rel_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, int s, int phase, void* stream);
+int lrpx_gridtd_rel_glob(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* glob_pre,
+                         float* a_glob, void* stream);
+int lrpx_rel_avg_u(const float* r_avg, const float* avg, float* u, int rows, int T, int C, int P, void* stream);
+int lrpx_gridtd_rel_pix(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* Vp,
+                        const float* proj_pre, float* a_proj, void* stream);
+int lrpx_rel_words_norm(float* r_words, int rows, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,17 @@ _l = C.c_long
 _sz = C.c_size_t
 
 
+class GridTrace(C.Structure):
+    _fields_ = [("B", _i), ("T", _i), ("H", _i), ("E", _i), ("P", _i)] + [(k, _f) for k in (
+        "xh1", "xh2", "h1", "c1", "h2", "c2", "g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat", "hc",
+        "alpha", "beta")]
+
+
+class GridRelState(C.Structure):
+    _fields_ = [(k, _f) for k in ("lens", "r_h2n", "r_c2", "r_c1", "r_ch0", "r_h2p", "r_glob", "A", "rx", "wacc",
+                                  "r_words")]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("in_", _f), ("wpacked", _f),
                 ("n_maps", _i), ("hw", _i), ("cin", _i), ("n_oc", _i), ("taps", _i), ("pix_per_map", _i),
@@ -44,6 +55,20 @@ SIGNATURES = {
     "lrpx_divide_stab": (_i, [_f, _f, _f, _f, _i, _l, _i, _f]),
     "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),
     "lrpx_check": (_i, [_f, _l, _i, _f]),
+    "lrpx_linear_small": (_i, [_f, _l, _f, _f, _f, _l, _i, _i, _i, _i, _f]),
+    "lrpx_mean_pixels": (_i, [_f, _f, _i, _i, _i, _f]),
+    "lrpx_relu": (_i, [_f, _f, _l, _f]),
+    "lrpx_argmax_rows": (_i, [_f, _l, _i, _i, _f, _f]),
+    "lrpx_target_logit": (_i, [_f, _f, _f, _f, _i, _f, _i, _i, _i, _f]),
+    "lrpx_gridtd_fwd_pre": (_i, [C.POINTER(GridTrace), _i, _f, _f, _f, _i, _f]),
+    "lrpx_gridtd_fwd_lstm": (_i, [C.POINTER(GridTrace), _i, _f, _i, _i, _f]),
+    "lrpx_gridtd_fwd_attention": (_i, [C.POINTER(GridTrace), _i, _f, _f, _f, _f, _f, _f, _f]),
+    "lrpx_gridtd_rel_init": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f, _i, _f]),
+    "lrpx_gridtd_rel_step": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _i, _i, _f]),
+    "lrpx_gridtd_rel_glob": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f]),
+    "lrpx_rel_avg_u": (_i, [_f, _f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_gridtd_rel_pix": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f, _f]),
+    "lrpx_rel_words_norm": (_i, [_f, _i, _i, _f]),
     "lrpx_vgg16_packed_bytes": (_sz, []),
     "lrpx_vgg16_trace_bytes": (_sz, [_i]),
     "lrpx_vgg16_workspace_bytes": (_sz, [_i]),
@@ -95,6 +120,11 @@ def ptr(t):
         return None
     assert t.is_contiguous(), "lrpx needs contiguous tensors"
     return C.c_void_p(t.data_ptr())
+
+
+def ptr_at(t, offset_elems=0):
+    """Device pointer of t's storage start + offset (for strided row views)."""
+    return C.c_void_p(t.data_ptr() + 4 * offset_elems)
 
 
 def stream_ptr():

@@ -1,1 +1,589 @@
-// decoder kernels (filled in next)
+// Decoder-side kernels of the LRP hot path (gridTD adaptive-attention decoder, AoA decoder).
+//
+// Everything here is small next to the VGG16 relevance pass (<1 % of the FLOPs), HBM / latency bound,
+// and written as fused per-time-step kernels batched over all (image, word) rows so that the
+// reference's ~50 k tiny `lrp_linear_eps` calls per image (models/gridTDmodel.py:1060-1128) become
+// ~5 launches per lock-step.  Row r = b*T + t is the explanation of word t of image b; at lock-step s
+// every row with t >= s works on time index i = t - s (models/gridTDmodel.py:1060 `for i in range(t+1)[::-1]`).
+//
+// Trace tensors are [B][T(+1)][...] fp32; token ids int64 (torch.long).
+#include <math.h>
+
+#include "common.h"
+#include "conv_mfma.h"
+
+namespace lrpx {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float eps_id(float r, float x, float z) { return (x / stab_eps(z)) * r; }   // weight=eye rule
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide reductions for 256-thread blocks (4 waves); `red` has >= 4 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinny linear: out[b][n] = act(sum_k x[b][k] * w[n][k] + bias[n]) for a handful of rows b.
+// One wave per NPW output features; lanes split K in float4; rows live in register accumulators.
+// Weight-read bound (each weight byte is read once per 16-row chunk, from L2).
+// ------------------------------------------------------------------------------------------------
+template <int NPW, int BCH>
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, long ldx,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ out, long ldo, int B, int K, int N,
+                                                           int act) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n0 = wave * NPW;
+    if (n0 >= N) return;
+    const int K4 = K >> 2;
+    for (int b0 = 0; b0 < B; b0 += BCH) {
+        float acc[NPW][BCH];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j)
+#pragma unroll
+            for (int bb = 0; bb < BCH; ++bb) acc[j][bb] = 0.f;
+        for (int k4 = lane; k4 < K4; k4 += 64) {
+            f32x4 wv[NPW];
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                const int n = min(n0 + j, N - 1);
+                wv[j] = reinterpret_cast<const f32x4*>(w + (long)n * K)[k4];
+            }
+#pragma unroll
+            for (int bb = 0; bb < BCH; ++bb) {
+                const int b = min(b0 + bb, B - 1);
+                const f32x4 xv = reinterpret_cast<const f32x4*>(x + (long)b * ldx)[k4];
+#pragma unroll
+                for (int j = 0; j < NPW; ++j)
+                    acc[j][bb] += wv[j][0] * xv[0] + wv[j][1] * xv[1] + wv[j][2] * xv[2] + wv[j][3] * xv[3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPW; ++j)
+#pragma unroll
+            for (int bb = 0; bb < BCH; ++bb) {
+                float v = wave_sum(acc[j][bb]);
+                const int n = n0 + j, b = b0 + bb;
+                if (lane == 0 && n < N && b < B) {
+                    if (bias) v += bias[n];
+                    if (act == 1) v = v > 0.f ? v : 0.f;
+                    out[(long)b * ldo + n] = v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// image-side constants: avg over pixels, relu
+// ------------------------------------------------------------------------------------------------
+__global__ void mean_pixels_kernel(const float* __restrict__ f, float* __restrict__ avg, int P, int C, float scale) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += f[((long)b * P + p) * C + c];
+    avg[(long)b * C + c] = s * scale;
+}
+
+__global__ void relu_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fmaxf(x[i], 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gridTD forward (trace) — models/gridTDmodel.py:933-1012
+// ------------------------------------------------------------------------------------------------
+struct GridFwd {
+    int B, T, H, E, P;
+    // trace ([B][T..] tensors)
+    float *xh1, *xh2;                     // [B][T][2E+2H], [B][T][3H]
+    float *h1, *c1, *h2, *c2;             // [B][T+1][H]
+    float *g1, *i1, *f1, *g2, *i2, *f2;   // [B][T][H]
+    float *s, *ctx, *ctx_hat, *hc;        // [B][T][H]
+    float *alpha, *beta;                  // [B][T][P], [B][T]
+};
+
+// xh1[b,t] = [h2[b,t] | glob[b] | emb[tok[b,t]] | h1[b,t]]
+__global__ void gridtd_fwd_pre_kernel(GridFwd g, int t, const float* __restrict__ glob, const float* __restrict__ emb,
+                                      const long long* __restrict__ tok, int tok_ld) {
+    const int b = blockIdx.x;
+    const int W = 2 * g.E + 2 * g.H;
+    float* dst = g.xh1 + ((long)b * g.T + t) * W;
+    const long st = ((long)b * (g.T + 1) + t) * g.H;
+    const long long k = tok[(long)b * tok_ld + t];
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        float v;
+        if (c < g.H) v = g.h2[st + c];
+        else if (c < g.H + g.E) v = glob[(long)b * g.E + (c - g.H)];
+        else if (c < g.H + 2 * g.E) v = emb[k * g.E + (c - g.H - g.E)];
+        else v = g.h1[st + (c - g.H - 2 * g.E)];
+        dst[c] = v;
+    }
+}
+
+// LSTM point-wise part (models/gridTDmodel.py:777-784) + sentinel s = sigmoid(gate) * tanh(c) (:982-983)
+// zz: [B][4H (+H gate)] pre-activations incl. bias
+__global__ void gridtd_fwd_lstm_kernel(GridFwd g, int t, const float* __restrict__ zz, int ldz, int which) {
+    const int b = blockIdx.x;
+    const int H = g.H;
+    const long st0 = ((long)b * (g.T + 1) + t) * H, st1 = st0 + H, tr = ((long)b * g.T + t) * H;
+    float *hh = which == 1 ? g.h1 : g.h2, *cc = which == 1 ? g.c1 : g.c2;
+    float *gg = which == 1 ? g.g1 : g.g2, *ii = which == 1 ? g.i1 : g.i2, *ff = which == 1 ? g.f1 : g.f2;
+    const float* z = zz + (long)b * ldz;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float i = sigmoidf_(z[c]), f = sigmoidf_(z[H + c]), zg = z[2 * H + c], o = sigmoidf_(z[3 * H + c]);
+        const float cn = f * cc[st0 + c] + i * tanhf(zg);
+        const float hn = o * tanhf(cn);
+        cc[st1 + c] = cn; hh[st1 + c] = hn;
+        gg[tr + c] = zg; ii[tr + c] = i; ff[tr + c] = f;
+        if (which == 1) g.s[tr + c] = sigmoidf_(z[4 * H + c]) * tanhf(cn);
+        else g.hc[tr + c] = hn + g.ctx_hat[tr + c];           // fc input (:990)
+    }
+}
+
+// AdaptiveAttention.forward (models/gridTDmodel.py:71-103) for one image per block (256 threads) and
+// xh2[b,t] = [ctx_hat | h1_new | h2_old].  att_img = W_v_proj(V)+b_v is time-invariant and precomputed.
+__global__ __launch_bounds__(256) void gridtd_fwd_attention_kernel(
+    GridFwd g, int t, const float* __restrict__ Vp, const float* __restrict__ att_img,
+    const float* __restrict__ Wg, const float* __restrict__ Ws, const float* __restrict__ bs,
+    const float* __restrict__ wh) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, H = g.H, P = g.P, tid = threadIdx.x;
+    float* h1n = sm;            // H
+    float* sv = h1n + H;        // H
+    float* hproj = sv + H;      // P
+    float* zsc = hproj + P;     // P+1 scores
+    float* alpha = zsc + P + 1; // P
+    float* red = alpha + P;     // 8
+    const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = ((long)b * g.T + t) * H;
+    for (int c = tid; c < H; c += 256) { h1n[c] = g.h1[st1 + c]; sv[c] = g.s[tr + c]; }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    // h_proj = W_g h1 ; sproj = W_s s + b_s   (one wave per output row)
+    float* sproj = alpha;   // reuse alpha storage for sproj until softmax
+    for (int k = wv; k < P; k += 4) {
+        float a = 0.f, c2 = 0.f;
+        for (int c = lane; c < H; c += 64) { a += Wg[(long)k * H + c] * h1n[c]; c2 += Ws[(long)k * H + c] * sv[c]; }
+        a = wave_sum(a); c2 = wave_sum(c2);
+        if (lane == 0) { hproj[k] = a; sproj[k] = c2 + bs[k]; }
+    }
+    __syncthreads();
+    // z[k] = w_h . tanh(att_img[k,:] + hproj[k])  (ht_proj is broadcast along the row, :82)
+    for (int k = wv; k < P; k += 4) {
+        float a = 0.f;
+        const float hp = hproj[k];
+        for (int j = lane; j < P; j += 64) a += wh[j] * tanhf(att_img[((long)b * P + k) * P + j] + hp);
+        a = wave_sum(a);
+        if (lane == 0) zsc[k] = a;
+    }
+    // sentinel score = w_h . tanh(sproj + hproj)
+    {
+        float a = 0.f;
+        for (int j = tid; j < P; j += 256) a += wh[j] * tanhf(sproj[j] + hproj[j]);
+        a = block_sum(a, red);
+        if (tid == 0) zsc[P] = a;
+    }
+    __syncthreads();
+    // softmax over P (alpha) and over P+1 (beta = last)
+    float m = -INFINITY;
+    for (int k = tid; k < P; k += 256) m = fmaxf(m, zsc[k]);
+    m = block_max(m, red);
+    float e = 0.f;
+    for (int k = tid; k < P; k += 256) e += expf(zsc[k] - m);
+    const float denom = block_sum(e, red);
+    const float m2 = fmaxf(m, zsc[P]);
+    float e2 = 0.f;
+    for (int k = tid; k <= P; k += 256) e2 += expf(zsc[k] - m2);
+    const float denom2 = block_sum(e2, red);
+    const float beta = expf(zsc[P] - m2) / denom2;
+    __syncthreads();
+    for (int k = tid; k < P; k += 256) {
+        const float a = expf(zsc[k] - m) / denom;
+        alpha[k] = a;
+        g.alpha[((long)b * g.T + t) * P + k] = a;
+    }
+    if (tid == 0) g.beta[(long)b * g.T + t] = beta;
+    __syncthreads();
+    float* x2 = g.xh2 + ((long)b * g.T + t) * 3 * H;
+    const long st0 = ((long)b * (g.T + 1) + t) * H;
+    for (int c = tid; c < H; c += 256) {
+        float a = 0.f;
+        for (int k = 0; k < P; ++k) a += Vp[((long)b * P + k) * H + c] * alpha[k];
+        const float ch = beta * sv[c] + (1.f - beta) * a;
+        g.ctx[tr + c] = a; g.ctx_hat[tr + c] = ch;
+        x2[c] = ch; x2[H + c] = h1n[c]; x2[2 * H + c] = g.h2[st0 + c];
+    }
+}
+
+// logit of the target word: dot(fc.weight[k], hc[b,t]) + fc.bias[k]   (one wave per row)
+__global__ void target_logit_kernel(const float* __restrict__ hc, const float* __restrict__ fcw,
+                                    const float* __restrict__ fcb, const long long* __restrict__ tok, int tok_ld,
+                                    float* __restrict__ logit, int B, int T, int H) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * T) return;
+    const int b = row / T, t = row - b * T, lane = threadIdx.x & 63;
+    const long long k = tok[(long)b * tok_ld + t + 1];
+    float a = 0.f;
+    for (int c = lane; c < H; c += 64) a += fcw[k * H + c] * hc[(long)row * H + c];
+    a = wave_sum(a);
+    if (lane == 0) logit[row] = a + fcb[k];
+}
+
+// argmax over the vocabulary (first maximum wins, like torch.argmax / topk(1)) — one block per row
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long ld, int n,
+                                                          long long* __restrict__ out) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const float* r = x + (long)blockIdx.x * ld;
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) { const float v = r[i]; if (v > best) { best = v; idx = i; } }
+    bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float v = bv[threadIdx.x + s]; const int i2 = bi[threadIdx.x + s];
+            if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && i2 < bi[threadIdx.x])) { bv[threadIdx.x] = v; bi[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = bi[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// gridTD relevance — models/gridTDmodel.py:1014-1135.  One block (256 threads) per row, H = 512.
+// ------------------------------------------------------------------------------------------------
+struct GridRel {
+    int B, T, H, E, P;
+    const int* lens;                      // [B] caption length per image (null: T)
+    // trace (const)
+    const float *xh1, *xh2, *h2, *c1, *c2, *g1, *i1, *f1, *g2, *i2, *f2, *s, *ctx, *ctx_hat, *hc, *beta;
+    // state per row
+    float *r_h2n, *r_c2, *r_c1, *r_ch0, *r_h2p, *r_glob;   // [rows][H]   (r_glob: [rows][E])
+    float *A, *rx;                                          // GEMM in [rows][H], GEMM out [rows][<=2E+2H]
+    float *wacc;                                            // [rows][T][H]  r_ctx / z~(ctx)
+    float *r_words;                                         // [rows][T]
+};
+
+__device__ __forceinline__ bool row_active(const GridRel& g, int b, int t, int s) {
+    const int len = g.lens ? g.lens[b] : g.T;
+    return t < len && t >= s;
+}
+
+// :1033-1059 — one-hot relevance at the target logit through fc, split between h2 and ctx_hat
+__global__ void gridtd_rel_init_kernel(GridRel g, const float* __restrict__ fcw, const float* __restrict__ logit,
+                                       const long long* __restrict__ tok, int tok_ld) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    const long long k = tok[(long)b * tok_ld + t + 1];
+    const float lg = logit[row];
+    const float zt = stab_eps(lg);
+    const long tr = (long)row * H, st1 = ((long)b * (g.T + 1) + t + 1) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float hc = g.hc[tr + c];
+        const float r_hc = (fcw[k * H + c] * hc / zt) * lg;
+        g.r_h2n[tr + c] = eps_id(r_hc, g.h2[st1 + c], hc);
+        g.r_ch0[tr + c] = eps_id(r_hc, g.ctx_hat[tr + c], hc);
+        g.r_c2[tr + c] = 0.f; g.r_c1[tr + c] = 0.f;
+    }
+    for (int c = threadIdx.x; c < g.E; c += blockDim.x) g.r_glob[(long)row * g.E + c] = 0.f;
+    for (int c = threadIdx.x; c < g.T; c += blockDim.x) g.r_words[(long)row * g.T + c] = 0.f;
+}
+
+// :1061-1069 LanguageLSTM cell: r_c2 += r_h2; split into the g-gate path and the c-path; A = r_g2 / z~(g2)
+__global__ void gridtd_rel_a_kernel(GridRel g, int s) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    const long tr = (long)row * H;
+    if (!row_active(g, b, t, s)) {
+        for (int c = threadIdx.x; c < H; c += blockDim.x) g.A[tr + c] = 0.f;
+        return;
+    }
+    const int i = t - s;
+    const long ti = ((long)b * g.T + i) * H, sc1 = ((long)b * (g.T + 1) + i + 1) * H, sc0 = sc1 - H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float rc = g.r_c2[tr + c] + g.r_h2n[tr + c];
+        const float cn = g.c2[sc1 + c];
+        const float rg = eps_id(rc, g.i2[ti + c] * tanhf(g.g2[ti + c]), cn);
+        g.r_c2[tr + c] = eps_id(rc, g.f2[ti + c] * g.c2[sc0 + c], cn);
+        g.A[tr + c] = rg / stab_eps(g.g2[ti + c]);
+    }
+}
+
+// :1074-1105 after the LanguageLSTM dense rule: split r_xh2, sentinel/context split, AdaLSTM cell
+__global__ void gridtd_rel_b_kernel(GridRel g, int s) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    const long tr = (long)row * H;
+    if (!row_active(g, b, t, s)) {
+        for (int c = threadIdx.x; c < H; c += blockDim.x) g.A[tr + c] = 0.f;
+        return;
+    }
+    const int i = t - s;
+    const long ti = ((long)b * g.T + i) * H, sc1 = ((long)b * (g.T + 1) + i + 1) * H, sc0 = sc1 - H;
+    const float* rx = g.rx + (long)row * (3 * H);                 // r_xh2 = [ctx_hat | h1 | h2], row stride 3H
+    const float beta = g.beta[(long)b * g.T + i];
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        g.r_h2p[tr + c] = rx[2 * H + c];                           // :1074
+        const float r_h1 = rx[H + c];                              // :1075
+        const float r_ch = (s == 0 ? g.r_ch0[tr + c] : 0.f) + rx[c];   // :1076
+        const float ch = g.ctx_hat[ti + c], cx = g.ctx[ti + c];
+        const float r_s = eps_id(r_ch, beta * g.s[ti + c], ch);    // :1077-1080
+        const float r_cx = eps_id(r_ch, cx * (1.f - beta), ch);    // :1081-1084
+        g.wacc[((long)row * g.T + i) * H + c] = r_cx / stab_eps(cx);   // pixel spread (:1091-1095) is finished in rel_pix
+        float rc = g.r_c1[tr + c] + r_s;                           // :1096
+        rc = rc + r_h1;                                            // :1097
+        const float cn = g.c1[sc1 + c];
+        const float rg = eps_id(rc, g.i1[ti + c] * tanhf(g.g1[ti + c]), cn);
+        g.r_c1[tr + c] = eps_id(rc, g.f1[ti + c] * g.c1[sc0 + c], cn);
+        g.A[tr + c] = rg / stab_eps(g.g1[ti + c]);
+    }
+}
+
+// :1110-1115 after the AdaLSTM dense rule: r_xh1 = [h2 | glob | emb | h1]
+__global__ __launch_bounds__(256) void gridtd_rel_c_kernel(GridRel g, int s) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, E = g.E;
+    if (!row_active(g, b, t, s)) return;
+    const int i = t - s;
+    const long tr = (long)row * H;
+    const float* rx = g.rx + (long)row * (2 * E + 2 * H);
+    for (int c = threadIdx.x; c < H; c += 256) g.r_h2n[tr + c] = g.r_h2p[tr + c] + rx[c];           // :1111
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < E; c += 256) {
+        g.r_glob[(long)row * E + c] += rx[H + c];                                                    // :1114
+        acc += rx[H + E + c];                                                                        // :1115, :1129
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) g.r_words[(long)row * g.T + i] = acc;
+}
+
+// :1116-1119 prologue: A = r_glob / z~(glob_pre)
+__global__ void gridtd_rel_glob_kernel(GridRel g, const float* __restrict__ glob_pre, float* __restrict__ Aglob) {
+    const int row = blockIdx.x, b = row / g.T;
+    for (int c = threadIdx.x; c < g.E; c += blockDim.x)
+        Aglob[(long)row * g.E + c] = g.r_glob[(long)row * g.E + c] / stab_eps(glob_pre[(long)b * g.E + c]);
+}
+
+// U[row][c] = r_avg / (P * z~(avg))  — the eye rule of :1121-1124 folded into the projector GEMM's bracket
+__global__ void gridtd_rel_u_kernel(const float* __restrict__ r_avg, const float* __restrict__ avg,
+                                    float* __restrict__ U, int T, int C, int P) {
+    const int row = blockIdx.x, b = row / T;
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        U[(long)row * C + c] = r_avg[(long)row * C + c] / ((float)P * stab_eps(avg[(long)b * C + c]));
+}
+
+// pixel spread :1091-1095 summed over i, and the prologue of the projector rule (:1125-1128):
+// Aproj[row][k][c] = Vp[b][k][c] * sum_{i<=t} alpha[b][i][k] * wacc[row][i][c] / z~(proj_pre[b][k][c])
+__global__ __launch_bounds__(256) void gridtd_rel_pix_kernel(GridRel g, const float* __restrict__ Vp,
+                                                             const float* __restrict__ proj_pre,
+                                                             const float* __restrict__ alpha,
+                                                             float* __restrict__ Aproj, int kchunk) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, P = g.P;
+    const int len = g.lens ? g.lens[b] : g.T;
+    const int k0 = blockIdx.y * kchunk, k1 = min(k0 + kchunk, P);
+    extern __shared__ float al[];    // [t+1][kchunk]
+    const bool act = t < len;
+    const int n = act ? t + 1 : 0;
+    for (int j = threadIdx.x; j < n * kchunk; j += 256) {
+        const int i = j / kchunk, kk = j - i * kchunk;
+        al[j] = (k0 + kk < P) ? alpha[((long)b * g.T + i) * P + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        for (int k = k0; k < k1; ++k) {
+            float a = 0.f;
+            for (int i = n - 1; i >= 0; --i) a += al[i * kchunk + (k - k0)] * g.wacc[((long)row * g.T + i) * H + c];
+            const long pi = ((long)b * P + k) * H + c;
+            Aproj[((long)row * P + k) * H + c] = act ? Vp[pi] * a / stab_eps(proj_pre[pi]) : 0.f;
+        }
+    }
+}
+
+// :1129-1132  r_words / max|r_words|
+__global__ void rel_words_norm_kernel(float* __restrict__ r_words, int rows, int T) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int t = row % T;
+    float m = 0.f;
+    for (int i = 0; i <= t; ++i) m = fmaxf(m, fabsf(r_words[(long)row * T + i]));
+    if (m > 0.f)
+        for (int i = 0; i <= t; ++i) r_words[(long)row * T + i] /= m;
+}
+
+}  // namespace lrpx
+
+using namespace lrpx;
+
+extern "C" {
+
+int lrpx_linear_small(const float* x, long ldx, const float* w, const float* bias, float* out, long ldo, int B, int K,
+                      int N, int act, void* stream) {
+    LRPX_REQUIRE(x && w && out && B > 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0, "linear_small: bad arguments");
+    const int waves = (N + 3) / 4;
+    hipLaunchKernelGGL((linear_small_kernel<4, 16>), dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
+                       bias, out, ldo, B, K, N, act);
+    return check_launch("linear_small");
+}
+
+int lrpx_mean_pixels(const float* f, float* avg, int B, int P, int C, void* stream) {
+    LRPX_REQUIRE(f && avg && B > 0, "mean_pixels: bad arguments");
+    hipLaunchKernelGGL(mean_pixels_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, f, avg, P, C,
+                       1.0f / (float)P);
+    return check_launch("mean_pixels");
+}
+
+int lrpx_relu(const float* x, float* y, long n, void* stream) {
+    LRPX_REQUIRE(x && y && n > 0, "relu: bad arguments");
+    hipLaunchKernelGGL(relu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return check_launch("relu");
+}
+
+int lrpx_argmax_rows(const float* x, long ld, int rows, int n, long long* out, void* stream) {
+    LRPX_REQUIRE(x && out && rows > 0 && n > 0, "argmax_rows: bad arguments");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, out);
+    return check_launch("argmax_rows");
+}
+
+static GridFwd to_fwd(const lrpx_gridtd_trace* t) {
+    GridFwd g;
+    g.B = t->B; g.T = t->T; g.H = t->H; g.E = t->E; g.P = t->P;
+    g.xh1 = t->xh1; g.xh2 = t->xh2; g.h1 = t->h1; g.c1 = t->c1; g.h2 = t->h2; g.c2 = t->c2;
+    g.g1 = t->g1; g.i1 = t->i1; g.f1 = t->f1; g.g2 = t->g2; g.i2 = t->i2; g.f2 = t->f2;
+    g.s = t->s; g.ctx = t->ctx; g.ctx_hat = t->ctx_hat; g.hc = t->hc; g.alpha = t->alpha; g.beta = t->beta;
+    return g;
+}
+
+static int check_trace(const lrpx_gridtd_trace* t) {
+    LRPX_REQUIRE(t && t->B > 0 && t->T > 0 && t->H == 512 && t->E % 4 == 0 && t->P > 0 && t->P <= 256,
+                 "gridtd: unsupported trace dims (H must be 512, P <= 256)");
+    LRPX_REQUIRE(t->xh1 && t->xh2 && t->h1 && t->c1 && t->h2 && t->c2 && t->g1 && t->i1 && t->f1 && t->g2 && t->i2 &&
+                     t->f2 && t->s && t->ctx && t->ctx_hat && t->hc && t->alpha && t->beta,
+                 "gridtd: null trace tensor");
+    return LRPX_OK;
+}
+
+int lrpx_gridtd_fwd_pre(const lrpx_gridtd_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
+                        int tok_ld, void* stream) {
+    LRPX_TRY(check_trace(tr));
+    LRPX_REQUIRE(glob && emb && tok && t >= 0 && t < tr->T, "gridtd_fwd_pre: bad arguments");
+    hipLaunchKernelGGL(gridtd_fwd_pre_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, glob, emb,
+                       tok, tok_ld);
+    return check_launch("gridtd_fwd_pre");
+}
+
+int lrpx_gridtd_fwd_lstm(const lrpx_gridtd_trace* tr, int t, const float* zz, int ldz, int which, void* stream) {
+    LRPX_TRY(check_trace(tr));
+    LRPX_REQUIRE(zz && (which == 1 || which == 2) && t >= 0 && t < tr->T, "gridtd_fwd_lstm: bad arguments");
+    hipLaunchKernelGGL(gridtd_fwd_lstm_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, zz, ldz,
+                       which);
+    return check_launch("gridtd_fwd_lstm");
+}
+
+int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img,
+                              const float* Wg, const float* Ws, const float* bs, const float* wh, void* stream) {
+    LRPX_TRY(check_trace(tr));
+    LRPX_REQUIRE(Vp && att_img && Wg && Ws && bs && wh && t >= 0 && t < tr->T, "gridtd_fwd_attention: bad arguments");
+    const size_t lds = (size_t)(2 * tr->H + 3 * tr->P + 1 + 8) * sizeof(float);
+    hipLaunchKernelGGL(gridtd_fwd_attention_kernel, dim3(tr->B), dim3(256), lds, (hipStream_t)stream, to_fwd(tr), t, Vp,
+                       att_img, Wg, Ws, bs, wh);
+    return check_launch("gridtd_fwd_attention");
+}
+
+int lrpx_target_logit(const float* hc, const float* fcw, const float* fcb, const long long* tok, int tok_ld,
+                      float* logit, int B, int T, int H, void* stream) {
+    LRPX_REQUIRE(hc && fcw && fcb && tok && logit, "target_logit: null pointer");
+    hipLaunchKernelGGL(target_logit_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, hc, fcw, fcb, tok,
+                       tok_ld, logit, B, T, H);
+    return check_launch("target_logit");
+}
+
+static GridRel to_rel(const lrpx_gridtd_trace* t, const lrpx_gridtd_relstate* r) {
+    GridRel g;
+    g.B = t->B; g.T = t->T; g.H = t->H; g.E = t->E; g.P = t->P; g.lens = r->lens;
+    g.xh1 = t->xh1; g.xh2 = t->xh2; g.h2 = t->h2; g.c1 = t->c1; g.c2 = t->c2;
+    g.g1 = t->g1; g.i1 = t->i1; g.f1 = t->f1; g.g2 = t->g2; g.i2 = t->i2; g.f2 = t->f2;
+    g.s = t->s; g.ctx = t->ctx; g.ctx_hat = t->ctx_hat; g.hc = t->hc; g.beta = t->beta;
+    g.r_h2n = r->r_h2n; g.r_c2 = r->r_c2; g.r_c1 = r->r_c1; g.r_ch0 = r->r_ch0; g.r_h2p = r->r_h2p; g.r_glob = r->r_glob;
+    g.A = r->A; g.rx = r->rx; g.wacc = r->wacc; g.r_words = r->r_words;
+    return g;
+}
+
+static int check_rel(const lrpx_gridtd_trace* t, const lrpx_gridtd_relstate* r) {
+    LRPX_TRY(check_trace(t));
+    LRPX_REQUIRE(r && r->r_h2n && r->r_c2 && r->r_c1 && r->r_ch0 && r->r_h2p && r->r_glob && r->A && r->rx && r->wacc &&
+                     r->r_words, "gridtd: null relevance-state tensor");
+    return LRPX_OK;
+}
+
+int lrpx_gridtd_rel_init(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* fcw,
+                         const float* logit, const long long* tok, int tok_ld, void* stream) {
+    LRPX_TRY(check_rel(tr, rs));
+    LRPX_REQUIRE(fcw && logit && tok, "gridtd_rel_init: null pointer");
+    hipLaunchKernelGGL(gridtd_rel_init_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_rel(tr, rs),
+                       fcw, logit, tok, tok_ld);
+    return check_launch("gridtd_rel_init");
+}
+
+int lrpx_gridtd_rel_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, int s, int phase, void* stream) {
+    LRPX_TRY(check_rel(tr, rs));
+    LRPX_REQUIRE(s >= 0 && s < tr->T && phase >= 0 && phase <= 2, "gridtd_rel_step: bad step/phase");
+    const GridRel g = to_rel(tr, rs);
+    const dim3 grid(tr->B * tr->T), blk(256);
+    if (phase == 0) hipLaunchKernelGGL(gridtd_rel_a_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
+    else if (phase == 1) hipLaunchKernelGGL(gridtd_rel_b_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
+    else hipLaunchKernelGGL(gridtd_rel_c_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
+    return check_launch("gridtd_rel_step");
+}
+
+int lrpx_gridtd_rel_glob(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* glob_pre,
+                         float* a_glob, void* stream) {
+    LRPX_TRY(check_rel(tr, rs));
+    LRPX_REQUIRE(glob_pre && a_glob, "gridtd_rel_glob: null pointer");
+    hipLaunchKernelGGL(gridtd_rel_glob_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_rel(tr, rs),
+                       glob_pre, a_glob);
+    return check_launch("gridtd_rel_glob");
+}
+
+int lrpx_rel_avg_u(const float* r_avg, const float* avg, float* u, int rows, int T, int C, int P, void* stream) {
+    LRPX_REQUIRE(r_avg && avg && u && rows > 0, "rel_avg_u: bad arguments");
+    hipLaunchKernelGGL(gridtd_rel_u_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, r_avg, avg, u, T, C, P);
+    return check_launch("rel_avg_u");
+}
+
+int lrpx_gridtd_rel_pix(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* Vp,
+                        const float* proj_pre, float* a_proj, void* stream) {
+    LRPX_TRY(check_rel(tr, rs));
+    LRPX_REQUIRE(Vp && proj_pre && a_proj, "gridtd_rel_pix: null pointer");
+    const int kchunk = 28;
+    const size_t lds = (size_t)tr->T * kchunk * sizeof(float);
+    hipLaunchKernelGGL(gridtd_rel_pix_kernel, dim3(tr->B * tr->T, (tr->P + kchunk - 1) / kchunk), dim3(256), lds,
+                       (hipStream_t)stream, to_rel(tr, rs), Vp, proj_pre, tr->alpha, a_proj, kchunk);
+    return check_launch("gridtd_rel_pix");
+}
+
+int lrpx_rel_words_norm(float* r_words, int rows, int T, void* stream) {
+    LRPX_REQUIRE(r_words && rows > 0 && T > 0, "rel_words_norm: bad arguments");
+    hipLaunchKernelGGL(rel_words_norm_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, r_words, rows, T);
+    return check_launch("rel_words_norm");
+}
+
+}  // extern "C"

@@ -1,0 +1,255 @@
+"""Batched gridTD LRP engine + the drop-in `ExplainGridTDAttention` explainer.
+
+Reference: models/gridTDmodel.py:705-1211 (`ExplainGridTDAttention`).  The reference explains one
+image at a time with ~50k tiny tensor ops per image; here a batch of B images x T words is traced
+and explained in lock-step by HIP kernels behind the lrpx C ABI (see csrc/lrpx_decoder.hip).
+The host logic below only sequences kernel launches; torch is used for device memory."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .._lib import (EPI_PLAIN, EPI_REL, GridRelState, GridTrace, PACK_DENSE, PACK_DENSE_T, check, ptr, ptr_at,
+                    stream_ptr)
+
+VGG_PREFIX = "img_encoder.encoder."
+
+
+def _t(v, dev):
+    if isinstance(v, np.ndarray):
+        v = torch.from_numpy(v)
+    return v.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+class GridTDEngine:
+    """Device-resident gridTD model + trace/relevance pipelines.  `state` is the reference model's
+    `state_dict` (torch tensors or numpy arrays, names of models/gridTDmodel.py:111-130)."""
+
+    def __init__(self, state, device="cuda"):
+        _lib.load()   # fail loudly without the HIP library
+        if not torch.cuda.is_available():
+            raise _lib.LrpxError("the LRP hot path needs an MI355X; there is no CPU fallback")
+        dev = torch.device(device)
+        self.device = dev
+        sd = {k: _t(v, dev) for k, v in state.items() if not k.startswith(VGG_PREFIX)}
+        names = [k for k in state if k.startswith(VGG_PREFIX) and k.endswith(".weight")]
+        self.vgg = ops.Vgg16([_t(state[k], dev) for k in names],
+                             [_t(state[k.replace(".weight", ".bias")], dev) for k in names])
+        self.sd = sd
+        self.V, self.E = sd["embedding.weight"].shape
+        self.H = sd["fc.weight"].shape[1]
+        self.C = sd["img_projector.weight"].shape[1]
+        self.P = sd["AdaAttention.W_v_proj.weight"].shape[0]
+        H, E, Cc = self.H, self.E, self.C
+        assert H == 512 and E == 512, "kernels are built for hidden=embed=512 (config.py:123-124)"
+        # --- forward weights
+        a, l = "AdaLSTM.lstm_cell.", "LanguageLSTM."
+        self.Wcat1 = torch.cat([torch.cat([sd[a + "weight_ih"], sd[a + "weight_hh"]], 1),
+                                torch.cat([sd["AdaLSTM.x_gate.weight"], sd["AdaLSTM.h_gate.weight"]], 1)], 0).contiguous()
+        self.bcat1 = torch.cat([sd[a + "bias_ih"] + sd[a + "bias_hh"],
+                                sd["AdaLSTM.x_gate.bias"] + sd["AdaLSTM.h_gate.bias"]]).contiguous()
+        self.Wcat2 = torch.cat([sd[l + "weight_ih"], sd[l + "weight_hh"]], 1).contiguous()
+        self.bcat2_explainer = (sd[l + "bias_ih"] + sd[l + "bias_ih"]).contiguous()   # quirk: gridTDmodel.py:789
+        self.bcat2_model = (sd[l + "bias_ih"] + sd[l + "bias_hh"]).contiguous()       # nn.LSTMCell
+        self.w_proj2d = sd["img_projector.weight"].reshape(H, Cc).contiguous()
+        kc = ops.conv_kc(0, 1, Cc)
+        self.p_proj_fwd = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE, kc)
+        self.p_attv_fwd = ops.pack_weights(sd["AdaAttention.W_v_proj.weight"], self.P, H, 1, PACK_DENSE, kc)
+        self.p_fc_fwd = ops.pack_weights(sd["fc.weight"], self.V, H, 1, PACK_DENSE, kc)
+        # --- relevance weights: g-gate rows of the LSTMs, [W_ih^g | W_hh^g]  (gridTDmodel.py:1019-1024)
+        wg1 = torch.cat([sd[a + "weight_ih"][2 * H:3 * H], sd[a + "weight_hh"][2 * H:3 * H]], 1).contiguous()
+        wg2 = torch.cat([sd[l + "weight_ih"][2 * H:3 * H], sd[l + "weight_hh"][2 * H:3 * H]], 1).contiguous()
+        self.p_wg1 = ops.pack_weights(wg1, H, 2 * E + 2 * H, 1, PACK_DENSE_T, kc)
+        self.p_wg2 = ops.pack_weights(wg2, H, 3 * H, 1, PACK_DENSE_T, kc)
+        self.p_gp_rel = ops.pack_weights(sd["global_img_feature_proj.weight"], E, Cc, 1, PACK_DENSE_T, kc)
+        self.p_proj_rel = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE_T, kc)
+        torch.cuda.synchronize()
+        self._idx_cache = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _alloc_trace(self, B, T):
+        dev, H, E, P = self.device, self.H, self.E, self.P
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        tr = dict(B=B, T=T)
+        tr["xh1"], tr["xh2"] = z(B, T, 2 * E + 2 * H), z(B, T, 3 * H)
+        for k in ("h1", "c1", "h2", "c2"):
+            tr[k] = z(B, T + 1, H)
+        for k in ("g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat", "hc"):
+            tr[k] = z(B, T, H)
+        tr["alpha"], tr["beta"] = z(B, T, P), z(B, T)
+        c = GridTrace()
+        c.B, c.T, c.H, c.E, c.P = B, T, H, E, P
+        for k in ("xh1", "xh2", "h1", "c1", "h2", "c2", "g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat",
+                  "hc", "alpha", "beta"):
+            setattr(c, k, ptr(tr[k]))
+        tr["_c"] = c
+        return tr
+
+    def encode(self, images):
+        """VGG16 forward + the image-side constants of get_hidden_parameters (gridTDmodel.py:941-950)."""
+        lib = _lib.load()
+        st = stream_ptr()
+        B = images.shape[0]
+        H, E, Cc, P = self.H, self.E, self.C, self.P
+        feats = self.vgg.forward(images)                                   # (B,P,C) NHWC view into the trace
+        enc = dict(B=B, feats=feats)
+        enc["avg"] = torch.empty(B, Cc, device=self.device)
+        check(lib.lrpx_mean_pixels(ptr(feats), ptr(enc["avg"]), B, P, Cc, st))
+        enc["proj_pre"] = torch.empty(B, P, H, device=self.device)
+        ops.conv_mfma(feats, self.p_proj_fwd, B, 0, Cc, H, 1, EPI_PLAIN, pix_per_map=P, oc_split=H,
+                      bias=self.sd["img_projector.bias"], out0=enc["proj_pre"])
+        enc["Vp"] = torch.empty_like(enc["proj_pre"])
+        check(lib.lrpx_relu(ptr(enc["proj_pre"]), ptr(enc["Vp"]), enc["Vp"].numel(), st))
+        enc["glob_pre"] = torch.empty(B, E, device=self.device)
+        check(lib.lrpx_linear_small(ptr(enc["avg"]), Cc, ptr(self.sd["global_img_feature_proj.weight"]),
+                                    ptr(self.sd["global_img_feature_proj.bias"]), ptr(enc["glob_pre"]), E, B, Cc, E, 0, st))
+        enc["glob"] = torch.empty_like(enc["glob_pre"])
+        check(lib.lrpx_relu(ptr(enc["glob_pre"]), ptr(enc["glob"]), enc["glob"].numel(), st))
+        # time-invariant part of the attention scores: W_v_proj(V) + b  (gridTDmodel.py:79)
+        enc["att_img"] = torch.empty(B, P, P, device=self.device)
+        ops.conv_mfma(enc["Vp"], self.p_attv_fwd, B, 0, H, -(-P // 32) * 32, 1, EPI_PLAIN, pix_per_map=P, oc_split=P,
+                      bias=self.sd["AdaAttention.W_v_proj.bias"], out0=enc["att_img"])
+        return enc
+
+    def _step(self, tr, enc, t, tokens, model_bias):
+        lib = _lib.load()
+        st = stream_ptr()
+        B, T, H, E = tr["B"], tr["T"], self.H, self.E
+        c = C.byref(tr["_c"])
+        sd = self.sd
+        check(lib.lrpx_gridtd_fwd_pre(c, t, ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(tokens),
+                                      tokens.shape[1], st))
+        W1 = 2 * E + 2 * H
+        zz1 = tr.setdefault("_zz1", torch.empty(B, 5 * H, device=self.device))
+        check(lib.lrpx_linear_small(ptr_at(tr["xh1"], t * W1), T * W1, ptr(self.Wcat1), ptr(self.bcat1), ptr(zz1),
+                                    5 * H, B, W1, 5 * H, 0, st))
+        check(lib.lrpx_gridtd_fwd_lstm(c, t, ptr(zz1), 5 * H, 1, st))
+        aa = "AdaAttention."
+        check(lib.lrpx_gridtd_fwd_attention(c, t, ptr(enc["Vp"]), ptr(enc["att_img"]), ptr(sd[aa + "W_g_proj.weight"]),
+                                            ptr(sd[aa + "W_s_proj.weight"]), ptr(sd[aa + "W_s_proj.bias"]),
+                                            ptr(sd[aa + "w_h.weight"]), st))
+        zz2 = tr.setdefault("_zz2", torch.empty(B, 4 * H, device=self.device))
+        b2 = self.bcat2_model if model_bias else self.bcat2_explainer
+        check(lib.lrpx_linear_small(ptr_at(tr["xh2"], t * 3 * H), T * 3 * H, ptr(self.Wcat2), ptr(b2), ptr(zz2), 4 * H,
+                                    B, 3 * H, 4 * H, 0, st))
+        check(lib.lrpx_gridtd_fwd_lstm(c, t, ptr(zz2), 4 * H, 2, st))
+
+    def trace(self, enc, captions, model_bias=False, predictions=True):
+        """get_hidden_parameters (gridTDmodel.py:952-1012) for B images under teacher forcing.
+        captions: (B,T+1) int64 on device, column 0 = <start>."""
+        lib = _lib.load()
+        B, T = captions.shape[0], captions.shape[1] - 1
+        captions = captions.contiguous()
+        tr = self._alloc_trace(B, T)
+        for t in range(T):
+            self._step(tr, enc, t, captions, model_bias)
+        tr["captions"] = captions
+        tr["logit"] = torch.empty(B * T, device=self.device)
+        check(lib.lrpx_target_logit(ptr(tr["hc"]), ptr(self.sd["fc.weight"]), ptr(self.sd["fc.bias"]), ptr(captions),
+                                    T + 1, ptr(tr["logit"]), B, T, self.H, stream_ptr()))
+        if predictions:
+            tr["pred"] = self.logits(tr["hc"].view(B * T, self.H)).view(B, T, self.V)
+        return tr
+
+    def logits(self, hc_rows):
+        """fc(context_hat + h2) (gridTDmodel.py:990) for R rows -> (R,V)."""
+        R = hc_rows.shape[0]
+        out = torch.empty(R, self.V, device=self.device)
+        ops.conv_mfma(hc_rows, self.p_fc_fwd, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1,
+                      oc_split=self.V, bias=self.sd["fc.bias"], out0=out)
+        return out
+
+    def greedy(self, enc, max_cap_length, start_id, end_id, model_bias=True):
+        """GridTDModel.greedy_search (gridTDmodel.py:480-520): argmax per step; after the first <end> the
+        sequence is padded with 0.  Returns int64 (B, max_cap_length) incl. <start>."""
+        lib = _lib.load()
+        B = enc["B"]
+        T = max_cap_length - 1
+        toks = torch.zeros(B, T + 1, dtype=torch.int64, device=self.device)
+        toks[:, 0] = start_id
+        tr = self._alloc_trace(B, T)
+        nxt = torch.empty(B, dtype=torch.int64, device=self.device)
+        unfinished = torch.ones(B, dtype=torch.bool, device=self.device)
+        for t in range(T):
+            self._step(tr, enc, t, toks, model_bias)
+            lg = self.logits(tr["hc"][:, t].contiguous())
+            check(lib.lrpx_argmax_rows(ptr(lg), self.V, B, self.V, ptr(nxt), stream_ptr()))
+            unfinished = unfinished & (nxt != end_id)          # token bookkeeping (integers), :500-505
+            toks[:, t + 1] = nxt * unfinished
+        return toks
+
+    # ------------------------------------------------------------------------------------------
+    def _row_index(self, B, T):
+        key = (B, T)
+        if key not in self._idx_cache:
+            b = torch.arange(B, device=self.device).view(B, 1)
+            t = torch.arange(T, device=self.device).view(1, T)
+            s = torch.arange(T, device=self.device).view(T, 1, 1)
+            idx = (b * T + (t - s).clamp(min=0)).to(torch.int32).reshape(T, B * T).contiguous()
+            row2img = (b + 0 * t).to(torch.int32).reshape(B * T).contiguous()
+            self._idx_cache[key] = (idx, row2img)
+        return self._idx_cache[key]
+
+    def relevance(self, enc, tr, lens=None, want_r_feat=True):
+        """explain_caption_wordt (gridTDmodel.py:1014-1135) for every (image, word) row at once.
+        Returns r_feat (B*T, P, C) relevance of the encoder output (NHWC) and r_words (B*T, T)."""
+        lib = _lib.load()
+        st = stream_ptr()
+        B, T, H, E, P, Cc = tr["B"], tr["T"], self.H, self.E, self.P, self.C
+        rows = B * T
+        dev = self.device
+        e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        rs = dict(r_h2n=e(rows, H), r_c2=e(rows, H), r_c1=e(rows, H), r_ch0=e(rows, H), r_h2p=e(rows, H),
+                  r_glob=e(rows, E), A=e(rows, H), rx=e(rows, 2 * E + 2 * H), wacc=torch.zeros(rows, T, H, device=dev),
+                  r_words=e(rows, T))
+        c = GridRelState()
+        c.lens = ptr(lens)
+        for k, v in rs.items():
+            setattr(c, k, ptr(v))
+        ctr, crs = C.byref(tr["_c"]), C.byref(c)
+        idx, row2img = self._row_index(B, T)
+        check(lib.lrpx_gridtd_rel_init(ctr, crs, ptr(self.sd["fc.weight"]), ptr(tr["logit"]), ptr(tr["captions"]),
+                                       T + 1, st))
+        W1 = 2 * E + 2 * H
+        for s in range(T):
+            check(lib.lrpx_gridtd_rel_step(ctr, crs, s, 0, st))
+            ops.conv_mfma(rs["A"], self.p_wg2, rows, 0, H, 3 * H, 1, EPI_REL, pix_per_map=1, oc_split=3 * H,
+                          x=tr["xh2"], map2img=idx[s], out0=rs["rx"])
+            check(lib.lrpx_gridtd_rel_step(ctr, crs, s, 1, st))
+            ops.conv_mfma(rs["A"], self.p_wg1, rows, 0, H, W1, 1, EPI_REL, pix_per_map=1, oc_split=W1,
+                          x=tr["xh1"], map2img=idx[s], out0=rs["rx"])
+            check(lib.lrpx_gridtd_rel_step(ctr, crs, s, 2, st))
+        # global feature path (:1116-1124) and projector (:1125-1128)
+        a_glob = e(rows, E)
+        check(lib.lrpx_gridtd_rel_glob(ctr, crs, ptr(enc["glob_pre"]), ptr(a_glob), st))
+        r_avg = e(rows, Cc)
+        ops.conv_mfma(a_glob, self.p_gp_rel, rows, 0, E, Cc, 1, EPI_REL, pix_per_map=1, oc_split=Cc, x=enc["avg"],
+                      map2img=row2img, out0=r_avg)
+        U = e(rows, Cc)
+        check(lib.lrpx_rel_avg_u(ptr(r_avg), ptr(enc["avg"]), ptr(U), rows, T, Cc, P, st))
+        a_proj = e(rows, P, H)
+        check(lib.lrpx_gridtd_rel_pix(ctr, crs, ptr(enc["Vp"]), ptr(enc["proj_pre"]), ptr(a_proj), st))
+        r_feat = e(rows, P, Cc)
+        ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
+                      x=enc["feats"], u=U, map2img=row2img, out0=r_feat)
+        check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
+        return r_feat, rs["r_words"], row2img
+
+    def explain_batch(self, images, captions, lens=None, accumulate=False, return_features=False):
+        """Batched `explain_caption` (gridTDmodel.py:1141-1156): images (B,3,224,224), captions (B,T+1) int64.
+        Returns maps (B,T,3,224,224) and r_words (B,T,T) (row t holds t+1 valid entries).
+        accumulate=True reproduces the running sums the reference returns (lrp_wrapper.py:64-82 quirk)."""
+        images = images.to(self.device, torch.float32).contiguous()
+        captions = captions.to(self.device, torch.int64).contiguous()
+        B, T = captions.shape[0], captions.shape[1] - 1
+        enc = self.encode(images)
+        tr = self.trace(enc, captions, predictions=False)
+        r_feat, r_words, row2img = self.relevance(enc, tr, lens)
+        maps = self.vgg.relevance(r_feat, row2img)
+        if accumulate:
+            maps = ops.cumsum_maps(maps, B, T)
+        out = (maps.view(B, T, 3, 224, 224), r_words.view(B, T, T))
+        if return_features:
+            out = out + (r_feat.view(B, T, self.P, self.C), tr, enc)
+        return out

@@ -1,0 +1,94 @@
+"""GPU parity of the gridTD decoder half (trace + relevance) and of the whole explain_batch pipeline,
+against the reference's golden vectors and the CPU oracle.  Tolerances as in SURVEY §8(d)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lrp_amd  # noqa: F401
+from conftest import GOLDEN, rel_err, cosine
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def case():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine
+    g = np.load(os.path.join(GOLDEN, "gridtd_T3.npz"))
+    sd = weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=int(g["V"]))
+    eng = GridTDEngine(sd)
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    cap = torch.from_numpy(g["caption"]).view(1, -1)
+    maps, r_words, r_feat, tr, enc = eng.explain_batch(img, cap, accumulate=True, return_features=True)
+    torch.cuda.synchronize()
+    return g, sd, eng, img, cap, maps.cpu(), r_words.cpu(), r_feat.cpu(), tr, enc
+
+
+def test_trace_vs_reference(case):
+    g, sd, eng, img, cap, maps, r_words, r_feat, tr, enc = case
+    pairs = dict(h1t="h1", c1t="c1", h2t="h2", c2t="c2", g1t="g1", g2t="g2", i1t_act="i1", f1t_act="f1",
+                 i2t_act="i2", f2t_act="f2", st="s", context="ctx", context_hat="ctx_hat", alphas="alpha", betas="beta")
+    for ref_name, mine in pairs.items():
+        assert rel_err(tr[mine][0].cpu(), g["tr_" + ref_name]) < 1e-4, ref_name
+    pred = eng.logits(tr["hc"].view(-1, 512)).cpu()
+    assert rel_err(pred[:, ::97], g["tr_predictions"]) < 1e-4
+
+
+def test_feature_relevance_and_word_relevance_vs_reference(case):
+    g, sd, eng, img, cap, maps, r_words, r_feat, tr, enc = case
+    for t in range(3):
+        want = torch.from_numpy(g[f"r_feat_{t}"])[0].reshape(512, 196).t()      # (P,C)
+        assert rel_err(r_feat[0, t], want) < TOL, t
+        assert cosine(r_feat[0, t], want) > 0.99999
+        assert np.abs(r_words[0, t, :t + 1].numpy() - g[f"r_words_{t}"]).max() < 1e-5
+
+
+def test_maps_end_to_end_vs_reference(case):
+    """whole pipeline on the GPU; bound 1e-3 because of max-pool tie flips (see test_gpu_vgg.py)"""
+    g, sd, eng, img, cap, maps, r_words, r_feat, tr, enc = case
+    for t in range(3):
+        scale = g[f"map_stats_{t}"][1]
+        assert np.abs(maps[0, t][None, :, ::4, ::4].numpy() - g[f"map_sub4_{t}"]).max() / scale < 1e-3
+    assert cosine(maps[0, 2], g["map_full_2"][0]) > 0.99999
+    assert (maps[0, 2] - torch.from_numpy(g["map_full_2"][0])).abs().max() < 1e-4
+
+
+def test_batch_of_images_vs_oracle():
+    """B=2 images with different captions, T=4: every (image, word) row against the per-image oracle;
+    decoder relevance strict (1e-4), pixel maps end-to-end (1e-3)."""
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine
+    from oracle import lrp_oracle as O
+    V = 503
+    sd = weights.make_gridtd_state(seed=7, vocab_size=V, vgg_bias_std=0.02)
+    sdt = O.state_to_torch(sd)
+    eng = GridTDEngine(sd)
+    img = torch.from_numpy(weights.make_images(11, 2))
+    cap = torch.from_numpy(weights.make_captions(12, 2, 4, V))
+    maps, r_words, r_feat, tr, enc = eng.explain_batch(img, cap, return_features=True)
+    maps, r_words, r_feat = maps.cpu(), r_words.cpu(), r_feat.cpu()
+    for b in range(2):
+        w_maps, w_rw, w_rf, _ = O.gridtd_explain_caption(sdt, img[b:b + 1], cap[b].numpy(), return_feat=True,
+                                                         accumulate=False)
+        for t in range(4):
+            want_rf = w_rf[t][0].reshape(512, 196).t()
+            assert rel_err(r_feat[b, t], want_rf) < 2e-4, (b, t)   # forward differences (GPU vs CPU conv) included
+            assert np.abs(r_words[b, t, :t + 1].numpy() - w_rw[t].numpy()).max() < 1e-4
+            assert rel_err(maps[b, t], w_maps[t][0]) < 1e-3, (b, t)
+            assert cosine(maps[b, t], w_maps[t][0]) > 0.99999
+
+
+def test_greedy_tokens_bit_exact(case):
+    """config 1: greedy decoding with the model's own forward; integer token ids must match the
+    reference's `greedy_search` exactly (tests/golden/greedy_cfg1.npz)."""
+    g, sd, eng, img, cap, *_ = case
+    gg = np.load(os.path.join(GOLDEN, "greedy_cfg1.npz"))
+    V = int(gg["V"])
+    enc = eng.encode(img.cuda())
+    toks = eng.greedy(enc, len(gg["tokens"]), V - 2, V - 1)
+    assert toks[0].cpu().tolist() == [int(x) for x in gg["tokens"]]
