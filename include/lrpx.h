@@ -97,6 +97,11 @@ int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, flo
 /* running sum over the maps of one image: out[b,t] = sum_{t'<=t} in[b,t']  (the reference's
  * `sample.grad` accumulation, LRPtools/lrp_wrapper.py:64-82); per = floats per map */
 int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long per, void* stream);
+/* dst += src  (the `.grad` accumulation of autograd that compute_lrp relies on, lrp_wrapper.py:80-82) */
+int lrpx_accumulate(float* dst, const float* src, long n, void* stream);
+/* out[row][c] = in[row][c] + in[row][half + c]: joins the x+ / x- halves of a split relevance tensor
+ * (R = x+ * convT(S,W+) + x- * convT(S,W-), lrp_modules.py:56-84, for signed layer inputs) */
+int lrpx_fold_halves(const float* in, float* out, long rows, int half, void* stream);
 /* NaN/Inf + all-zero check of a buffer (the asserts of lrp_modules.py:154-155, lrp_wrapper.py:81);
  * synchronises the stream.  flags: bit0 = fail on non-finite, bit1 = fail on all-zero */
 int lrpx_check(const float* buf, long n, int flags, void* stream);

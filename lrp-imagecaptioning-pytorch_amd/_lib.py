@@ -54,6 +54,8 @@ SIGNATURES = {
     "lrpx_maxpool2x2_relevance": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f]),
     "lrpx_divide_stab": (_i, [_f, _f, _f, _f, _i, _l, _i, _f]),
     "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),
+    "lrpx_accumulate": (_i, [_f, _f, _l, _f]),
+    "lrpx_fold_halves": (_i, [_f, _f, _l, _i, _f]),
     "lrpx_check": (_i, [_f, _l, _i, _f]),
     "lrpx_linear_small": (_i, [_f, _l, _f, _f, _f, _l, _i, _i, _i, _i, _f]),
     "lrpx_mean_pixels": (_i, [_f, _f, _i, _i, _i, _f]),

@@ -227,6 +227,21 @@ __global__ void cumsum_maps_kernel(const float* __restrict__ in, float* __restri
     }
 }
 
+__global__ void accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, long n4) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    reinterpret_cast<f32x4*>(dst)[idx] += reinterpret_cast<const f32x4*>(src)[idx];
+}
+
+// out[row][c] = in[row][c] + in[row][c + half]   (x+ and x- halves of a split relevance tensor)
+__global__ void fold_halves_kernel(const float* __restrict__ in, float* __restrict__ out, int half, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over rows*half
+    if (idx >= total) return;
+    long row = idx / half;
+    int c = idx - row * half;
+    out[idx] = in[row * 2 * half + c] + in[row * 2 * half + half + c];
+}
+
 __global__ void check_kernel(const float* __restrict__ buf, long n, unsigned* flags) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long stride = (long)gridDim.x * blockDim.x;
@@ -324,6 +339,19 @@ int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long
     hipLaunchKernelGGL(cumsum_maps_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out,
                        t_per_img, per / 4, total);
     return check_launch("cumsum_maps");
+}
+
+int lrpx_accumulate(float* dst, const float* src, long n, void* stream) {
+    LRPX_REQUIRE(dst && src && n > 0 && n % 4 == 0, "accumulate: bad arguments");
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dst, src, n / 4);
+    return check_launch("accumulate");
+}
+
+int lrpx_fold_halves(const float* in, float* out, long rows, int half, void* stream) {
+    LRPX_REQUIRE(in && out && rows > 0 && half > 0, "fold_halves: bad arguments");
+    hipLaunchKernelGGL(fold_halves_kernel, dim3(grid_for(rows * half)), dim3(256), 0, (hipStream_t)stream, in, out, half,
+                       rows * half);
+    return check_launch("fold_halves");
 }
 
 int lrpx_check(const float* buf, long n, int flags, void* stream) {

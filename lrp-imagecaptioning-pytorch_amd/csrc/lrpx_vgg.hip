@@ -123,7 +123,8 @@ extern "C" {
 
 int lrpx_conv_kc(int hw, int taps, int cin) {
     if (taps == 1) return 32;
-    if (hw >= 112) return cin <= 8 ? 8 : 16;
+    if (hw == 224 && cin <= 8) return 8;   // the first VGG layer (image stored as 8 channels)
+    if (hw >= 112) return 16;
     return 32;
 }
 

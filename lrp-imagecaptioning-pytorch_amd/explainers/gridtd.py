@@ -253,3 +253,114 @@ class GridTDEngine:
         if return_features:
             out = out + (r_feat.view(B, T, self.P, self.C), tr, enc)
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# drop-in explainer (models/gridTDmodel.py:705-1211)
+# ------------------------------------------------------------------------------------------------
+class ExplainGridTDAttention(object):
+    """Same constructor, attributes and methods as the reference's `ExplainGridTDAttention`
+    (models/gridTDmodel.py:705-1156): `explain_caption(img_filepath) -> (relevance_imgs, relevance_preceeding_words)`,
+    `explain_caption_wordt(t)`, `explain_cnn(R)`, `teacherforce_forward(img, ids)`; attributes `.model .word_map .img
+    .beam_caption .beam_caption_encode .predictions .alphas .betas .args`.
+
+    `model` may be the reference's `GridTDModel` (any nn.Module with that `state_dict`), a `state_dict`, or None
+    (then `args.weight` is loaded like :717-718).  Differences, all outside the relevance math: the caption is
+    decoded greedily (beam_size=1) unless `caption_encode=` is given (the reference's beam search is not part of
+    the hot path), and nothing is written to disk (visualisation is out of scope)."""
+    EPS = 0.01
+    EX_TYPE = 'lrp'
+
+    def __init__(self, args, word_map, model=None):
+        self.args = args
+        self.word_map = word_map
+        self.vocab_size = len(word_map)
+        if model is None:
+            state = torch.load(args.weight, map_location="cpu")['state_dict']
+        elif hasattr(model, "state_dict"):
+            state = model.state_dict()
+        else:
+            state = model
+        self.model = model
+        self.engine = GridTDEngine(state)
+        self.mean = [0.485, 0.456, 0.406]
+        self.std = [0.229, 0.224, 0.225]
+        self.rev_word_map = {v: k for k, v in word_map.items()}
+
+    def preprocess_img(self, img_filepath):
+        """Resize -> ToTensor -> Normalize (models/gridTDmodel.py:767-771), host side."""
+        from PIL import Image
+        h, w = getattr(self.args, "height", 224), getattr(self.args, "width", 224)
+        im = Image.open(img_filepath).convert('RGB').resize((w, h), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1)
+        x = (x - torch.tensor(self.mean).view(3, 1, 1)) / torch.tensor(self.std).view(3, 1, 1)
+        return x.unsqueeze(0).to(self.engine.device)
+
+    def get_hidden_parameters(self, img, caption_encode=None, max_cap_length=50):
+        """Forward trace (:933-1012).  `img`: file path or a (1,3,224,224) tensor."""
+        self.img = self.preprocess_img(img) if isinstance(img, str) else img.to(self.engine.device, torch.float32)
+        eng = self.engine
+        self._enc = eng.encode(self.img)
+        if caption_encode is None:
+            toks = eng.greedy(self._enc, max_cap_length, self.word_map['<start>'], self.word_map['<end>'])[0].tolist()
+            words = [t for t in toks[1:] if t != 0]
+            caption_encode = [toks[0]] + words
+        self.beam_caption_encode = [int(c) for c in caption_encode]
+        special = {self.word_map[k] for k in ('<start>', '<end>', '<unk>', '<pad>') if k in self.word_map}
+        self.beam_caption = [' '.join(self.rev_word_map.get(c, str(c)) for c in self.beam_caption_encode[1:]
+                                      if c not in special)]
+        self.caption_length = len(self.beam_caption_encode) - 1
+        cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=eng.device)
+        self._tr = eng.trace(self._enc, cap, predictions=True)
+        self.image_features = ops.nhwc_to_nchw(self._enc["feats"].contiguous(), eng.C, 14, 14)
+        self.num_pixels = eng.P
+        self.predictions = self._tr["pred"][0]
+        self.alphas = self._tr["alpha"][0]
+        self.betas = self._tr["beta"][0]
+        self._rel = None
+
+    def _relevance(self):
+        if self._rel is None:
+            self._rel = self.engine.relevance(self._enc, self._tr)
+        return self._rel
+
+    def explain_caption_wordt(self, t):
+        """(:1014-1135) -> (r_img_feature (1,C,h,w), r_words (t+1,))"""
+        assert t < self.caption_length
+        r_feat, r_words, _ = self._relevance()
+        r = ops.nhwc_to_nchw(r_feat[t:t + 1].contiguous(), self.engine.C, 14, 14)
+        return r, r_words[t, :t + 1].clone()
+
+    def explain_cnn(self, r_img_feature):
+        """(:1137-1139) — `compute_lrp` on `self.img`; like the reference the result accumulates over calls on
+        the same image (`sample.grad`, lrp_wrapper.py:64-82)."""
+        t_nhwc = ops.nchw_to_nhwc(r_img_feature.to(torch.float32))
+        r = self.engine.vgg.relevance(t_nhwc, torch.zeros(r_img_feature.shape[0], dtype=torch.int32,
+                                                          device=self.engine.device))
+        if getattr(self, "_img_grad", None) is None:
+            self._img_grad = r
+        else:
+            check(_lib.load().lrpx_accumulate(ptr(self._img_grad), ptr(r), r.numel(), stream_ptr()))
+        ops.check_relevance(self._img_grad, finite=True, nonzero=True)
+        return self._img_grad.clone()
+
+    def explain_caption(self, img_filepath, t_list=None, caption_encode=None):
+        """(:1141-1156) -> ([T] x (1,3,H,W), [T] x (t+1,)); maps are the reference's running sums."""
+        self.img_filepath = img_filepath
+        self.get_hidden_parameters(img_filepath, caption_encode)
+        self._img_grad = None
+        r_feat, r_words, row2img = self._relevance()
+        maps = self.engine.vgg.relevance(r_feat, row2img)
+        maps = ops.cumsum_maps(maps, 1, self.caption_length)
+        ops.check_relevance(maps, finite=True, nonzero=True)
+        relevance_imgs = [maps[t:t + 1] for t in range(self.caption_length)]
+        relevance_preceeding_words = [r_words[t, :t + 1] for t in range(self.caption_length)]
+        assert len(relevance_imgs) == self.caption_length
+        return relevance_imgs, relevance_preceeding_words
+
+    def teacherforce_forward(self, img, beam_caption_encode):
+        """(:892-931) -> predictions (len, V) under teacher forcing (explainer forward incl. the bias quirk)."""
+        eng = self.engine
+        enc = eng.encode(img.to(eng.device, torch.float32))
+        cap = torch.tensor([list(beam_caption_encode) + [0]], dtype=torch.int64, device=eng.device)
+        return eng.trace(enc, cap, predictions=True)["pred"][0]

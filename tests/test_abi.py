@@ -1,0 +1,58 @@
+"""CPU-side checks of the boundary: liblrpx.so loads, exports every symbol include/lrpx.h declares, and the
+ctypes table (lrp_amd._lib.SIGNATURES) covers exactly those symbols.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import lrp_amd  # noqa: F401
+from lrp_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "lrpx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lrpx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("liblrpx.so not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/lrpx.h but not exported"
+
+
+def test_ctypes_table_matches_header():
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+
+
+def test_version_and_pure_host_entry_points():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("liblrpx.so not built")
+    lib = _lib.load()
+    assert lib.lrpx_version() >= 100
+    assert lib.lrpx_conv_kc(224, 9, 8) == 8 and lib.lrpx_conv_kc(224, 9, 64) == 16 and lib.lrpx_conv_kc(112, 9, 8) == 16
+    assert lib.lrpx_conv_kc(56, 9, 256) == 32 and lib.lrpx_conv_kc(0, 1, 512) == 32
+    assert lib.lrpx_packed_floats(64, 64, 9, 16) == 64 * 64 * 9
+    assert lib.lrpx_packed_floats(6, 64, 9, 16) == 32 * 64 * 9          # output channels pad to 32
+    assert lib.lrpx_vgg16_trace_bytes(2) == 2 * lib.lrpx_vgg16_trace_bytes(1)
+    # argument validation happens on the host, before any launch
+    assert lib.lrpx_pack_weights(None, 1, 1, 9, 0, 16, None, None) == _lib.EINVAL
+    assert b"null" in lib.lrpx_last_error_string()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.EINVAL)
+    with pytest.raises(AssertionError):
+        _lib.check(_lib.EZERO)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liblrpx.so")
+    with pytest.raises(_lib.LrpxError):
+        _lib.load()

@@ -1,0 +1,72 @@
+"""Host-side logic that needs no GPU: seeded generator, hook-API validation, no-CPU-fallback guarantees."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import lrp_amd  # noqa: F401
+from lrp_amd import weights
+from lrp_amd.LRPtools import lrp_modules, lrp_wrapper, utils
+
+
+def test_generator_is_deterministic_and_matches_reference_names():
+    a = weights.make_gridtd_state(seed=5, vocab_size=40)
+    b = weights.make_gridtd_state(seed=5, vocab_size=40)
+    assert list(a) == list(b) and all(np.array_equal(a[k], b[k]) for k in a)
+    assert a["img_encoder.encoder.28.weight"].shape == (512, 512, 3, 3)      # last conv of features[0:-1]
+    assert a["AdaLSTM.lstm_cell.weight_ih"].shape == (2048, 1536) and a["fc.weight"].shape == (40, 512)
+    assert a["embedding.weight"].dtype == np.float32
+    cap = weights.make_captions(1, 3, 5, 40)
+    assert cap.shape == (3, 6) and (cap[:, 0] == 38).all() and cap[:, 1:].min() >= 1 and cap[:, 1:].max() <= 36
+    wm = weights.make_word_map(40)
+    assert wm["<pad>"] == 0 and wm["<unk>"] == 37 and wm["<start>"] == 38 and wm["<end>"] == 39
+
+
+def test_constants_match_reference():
+    assert (utils.EPSILON, utils.Z_EPSILON, utils.RELEVANCE_RECT) == (0.01, 1e-7, -1e-6)
+    assert lrp_wrapper.SequentialPresetA().lrp_params == {"alpha": 1., "beta": 0., "ignore_bias": True}
+
+
+def test_unknown_leaf_raises_value_error_like_reference():
+    with pytest.raises(ValueError, match="not known"):
+        lrp_modules.get_lrp_module(nn.Linear(4, 4))
+    with pytest.raises(ValueError):
+        lrp_wrapper.add_lrp(nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.Sigmoid()))
+    with pytest.raises(NotImplementedError):           # lrp_modules.py:152
+        lrp_modules.Conv2d().propagate_relevance(nn.Conv2d(3, 8, 3, padding=1), None, (torch.zeros(1),), "epsilon", {})
+
+
+def test_vgg16_structure_matching():
+    def vgg(cfg):
+        mods, cin = [], 3
+        for v in cfg:
+            if v == 'M':
+                mods.append(nn.MaxPool2d(2, 2))
+            else:
+                mods += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        return nn.Sequential(*mods)
+    leaves = lambda m: [x for x in m.modules() if len(list(x.children())) == 0]
+    assert lrp_wrapper._match_vgg16(leaves(vgg(lrp_wrapper.VGG16_FEATURES)))
+    assert not lrp_wrapper._match_vgg16(leaves(vgg(lrp_wrapper.VGG16_FEATURES + ['M'])))
+    assert not lrp_wrapper._match_vgg16(leaves(vgg([64, 'M', 128])))
+
+
+def test_no_cpu_fallback():
+    from lrp_amd import _lib, ops
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    with pytest.raises(_lib.LrpxError):
+        from lrp_amd.explainers.gridtd import GridTDEngine
+        GridTDEngine(weights.make_gridtd_state(seed=0, vocab_size=16))
+    with pytest.raises(ValueError):
+        ops.conv_mfma(torch.zeros(4), torch.zeros(4), 1, 14, 32, 32, 9, 1)
+    cpu_vgg = nn.Sequential(*[m for v in [64] for m in (nn.Conv2d(3, 64, 3, padding=1), nn.ReLU())])
+    with pytest.raises((ValueError, _lib.LrpxError)):
+        lrp_wrapper.add_lrp(cpu_vgg)
+
+
+def test_bench_host_cores_respects_cgroup():
+    import bench
+    n = bench.host_cores()
+    assert 1 <= n <= 16
