@@ -1,7 +1,7 @@
 // generated instantiation list of conv_mfma_kernel (see conv_launch.h)
 #include "conv_launch.h"
 namespace lrpx {
-int launch_conv_224_16_2_1_9_first(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<224, 16, 2, 1, 9, EPI_FIRST>(a, s); }
-int launch_conv_112_16_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<112, 16, 1, 4, 9, EPI_FWD_DUAL>(a, s); }
-int launch_conv_112_16_1_4_9_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<112, 16, 1, 4, 9, EPI_REL>(a, s); }
+int launch_conv_112_8_1_4_9_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<112, 8, 1, 4, 9, EPI_REL>(a, s); }
+int launch_conv_112_8_2_2_9_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<112, 8, 2, 2, 9, EPI_REL>(a, s); }
+int launch_conv_56_16_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<56, 16, 1, 4, 9, EPI_FWD_DUAL>(a, s); }
 }

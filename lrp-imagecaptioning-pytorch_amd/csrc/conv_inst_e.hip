@@ -1,7 +1,6 @@
 // generated instantiation list of conv_mfma_kernel (see conv_launch.h)
 #include "conv_launch.h"
 namespace lrpx {
-int launch_conv_14_32_1_4_9_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<14, 32, 1, 4, 9, EPI_REL>(a, s); }
 int launch_conv_14_32_1_4_1_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<14, 32, 1, 4, 1, EPI_REL>(a, s); }
 int launch_conv_14_32_1_4_1_plain(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<14, 32, 1, 4, 1, EPI_PLAIN>(a, s); }
 }

@@ -67,10 +67,12 @@ struct ConvCfg {
     static constexpr int PIX = 224 * MT;                 // pixels per workgroup tile
     static constexpr int R = (TAPS == 9) ? PIX / W : 0;  // whole image rows per tile
     static constexpr int WP = W + 2;                     // LDS row width incl. zero columns
-    static constexpr int NSLOT = (TAPS == 9) ? R + 2 + (R - 1 + H - 1) / H : 0;
+    // rows of the tile + a halo row above/below + one zero row per map boundary that can fall inside the tile
+    // (none when tiles are aligned to maps, H % R == 0)
+    static constexpr int NSLOT = (TAPS == 9) ? R + 2 + ((H % (R ? R : 1) == 0) ? 0 : (R - 1 + H - 1) / H) : 0;
     static constexpr int STRIDE = KC + 4;                // floats per LDS pixel (pad: conflict-free b128)
     static constexpr int LDS_PIX = (TAPS == 9) ? NSLOT * WP : PIX;
-    static constexpr int LDS_BYTES = LDS_PIX * STRIDE * 4;
+    static constexpr int LDS_BYTES = 2 * LDS_PIX * STRIDE * 4;   // double-buffered A tile
     static constexpr int NT = 64 * MT * NWN;
     static constexpr int KSTEPS = KC / 8;
     static_assert(TAPS == 1 || PIX % W == 0, "tile must be whole rows");
@@ -166,11 +168,11 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
     const int wm = wave / NWN, wn = wave % NWN;
 
     // XCD-aware block mapping: blocks b and b+8 share an XCD (round-robin dispatch), so the n-blocks of one
-    // pixel tile get consecutive slots on ONE XCD and re-use the tile's A rows from that XCD's L2.
+    // pixel tile get consecutive slots on ONE XCD and re-use the tile's A rows from that XCD's L2 (speed only).
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int mtile = (idx / n_blocks) * 8 + xcd;
-    const int nblk = idx % n_blocks;
+    const int mtile = (idx / n_blocks) * 8 + xcd;   // neighbouring pixel tiles run at the same time on the 8 XCDs
+    const int nblk = idx % n_blocks;                // (measured: giving each XCD a contiguous tile range is 25 % slower on conv1_2)
     if (mtile >= m_tiles) return;   // whole workgroup exits together
 
     const int ocb = nblk * NWN + wn;                         // 32-channel block of this wave
@@ -198,8 +200,58 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
         for (int j = 0; j < 7; ++j) abase[j] = (wm * 224 + 32 * j + li) * STRIDE + lh * 4;
     }
 
-    // ---- zero the LDS once: halo columns and inter-map zero rows are never written afterwards ----
-    for (int i = tid; i < C::LDS_PIX * STRIDE / 4; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0, 0, 0, 0};
+    // ---- staging descriptors: every thread moves the same U 16-byte items of every K-chunk ----
+    constexpr int SEG = KC / 4;
+    constexpr int ROWPIX = (TAPS == 9) ? W : C::PIX;
+    constexpr int NROW = (TAPS == 9) ? C::NSLOT : 1;
+    constexpr int NITEM = NROW * ROWPIX * SEG;
+    constexpr int U = (NITEM + NT - 1) / NT;
+    constexpr int BUF = C::LDS_PIX * STRIDE;          // floats per LDS buffer (two buffers)
+    constexpr int STEPS = TAPS * C::KSTEPS;           // k-steps (of 8 channels) per chunk
+    constexpr int NB = (STEPS % 3 == 0) ? 3 : 2;      // B-fragment register ring: prefetch depth NB-1
+    static_assert(STEPS % NB == 0, "ring must realign at chunk boundaries");
+    int sdst[U], sgp[U];   // LDS float offset (-1: never written, stays zero) / global pixel (-1: store zeros)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int it = tid + u * NT;
+        sdst[u] = -1; sgp[u] = -1;
+        if (it < NITEM) {
+            const int s = it / (ROWPIX * SEG);
+            const int rem = it - s * (ROWPIX * SEG);
+            const int px = rem / SEG, seg = rem - px * SEG;
+            if constexpr (TAPS == 9) {
+                const long v_ = v0 - 1 + s;
+                const long n = v_ / (H + 1);
+                const int y = (int)(v_ - n * (H + 1));
+                if ((v_ >= 0) && (y < H) && (n < a.n_maps)) {
+                    sdst[u] = (s * WP + px + 1) * STRIDE + seg * 4;
+                    sgp[u] = (int)((n * H + y) * W + px);
+                }
+            } else {
+                const long gp = (long)mtile * C::PIX + px;
+                sdst[u] = px * STRIDE + seg * 4;        // rows past the end are (re)written as zeros
+                if (gp < total_pix) sgp[u] = (int)gp;
+            }
+            if (sdst[u] >= 0) sdst[u] |= (seg << 28);   // keep the 16-B segment index in the top bits
+        }
+    }
+    f32x4 sv[U];
+    // global -> registers for one chunk (issued a whole compute phase before the data is needed)
+#define LRPX_STAGE_ISSUE(CHUNK)                                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
+        sv[u] = f32x4{0, 0, 0, 0};                                                                           \
+        if (sgp[u] >= 0)                                                                                     \
+            sv[u] = *reinterpret_cast<const f32x4*>(a.in + (long)sgp[u] * a.cin + (CHUNK) * KC + ((sdst[u] >> 28) & 7) * 4); \
+    }
+#define LRPX_STAGE_COMMIT(BUFIDX)                                                                            \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                            \
+        if (sdst[u] >= 0) *reinterpret_cast<f32x4*>(lds + (BUFIDX) * BUF + (sdst[u] & 0x0fffffff)) = sv[u];
+
+    LRPX_STAGE_ISSUE(0)
+    // zero both LDS buffers once: halo columns and inter-map zero rows are never written afterwards
+    for (int i = tid; i < 2 * BUF / 4; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0, 0, 0, 0};
+    __syncthreads();
+    LRPX_STAGE_COMMIT(0)
 
     f32x16 acc[7];
 #pragma unroll
@@ -207,78 +259,50 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-    const f32x4* wbase = reinterpret_cast<const f32x4*>(a.wp) + (long)ocb * nchunk * (TAPS * C::KSTEPS * 64) + lane;
+    // B fragments: one contiguous stream of (nchunk * STEPS) 1-KiB wave-loads per channel block
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wp) + (long)ocb * nchunk * (STEPS * 64) + lane;
+    const int last_step = nchunk * STEPS - 1;
+    f32x4 bq[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bq[i] = f32x4{0, 0, 0, 0};
+    if (wave_active) {
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) bq[i] = wp[(long)min(i, last_step) * 64];
+    }
+    __syncthreads();
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-        __syncthreads();   // previous chunk's LDS reads are done (also orders the initial zero fill)
-        // ---- stage A: global (NHWC, 16-B segments) -> registers -> LDS ----
-        {
-            constexpr int SEG = KC / 4;
-            constexpr int ROWPIX = (TAPS == 9) ? W : C::PIX;
-            constexpr int NROW = (TAPS == 9) ? C::NSLOT : 1;
-            constexpr int NITEM = NROW * ROWPIX * SEG;
-            constexpr int BATCH = 8;
-            const float* src0 = a.in + (long)chunk * KC;
-            for (int it0 = tid; it0 < NITEM; it0 += NT * BATCH) {
-                f32x4 v[BATCH];
-                int dst[BATCH];
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    int it = it0 + u * NT;
-                    dst[u] = -1;
-                    if (it < NITEM) {
-                        int s = it / (ROWPIX * SEG);
-                        int rem = it - s * (ROWPIX * SEG);
-                        int px = rem / SEG, seg = rem - px * SEG;
-                        long gp;   // global pixel index
-                        bool ok;
-                        if constexpr (TAPS == 9) {
-                            long v_ = v0 - 1 + s;
-                            long n = v_ / (H + 1);
-                            int y = (int)(v_ - n * (H + 1));
-                            ok = (v_ >= 0) && (y < H) && (n < a.n_maps);
-                            gp = (n * H + y) * W + px;
-                            if (ok) dst[u] = (s * WP + px + 1) * STRIDE + seg * 4;
-                        } else {
-                            gp = (long)mtile * C::PIX + px;
-                            ok = gp < total_pix;
-                            dst[u] = px * STRIDE + seg * 4;   // rows past the end are written as zeros
-                        }
-                        v[u] = ok ? *reinterpret_cast<const f32x4*>(src0 + gp * a.cin + seg * 4) : f32x4{0, 0, 0, 0};
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u)
-                    if (dst[u] >= 0) *reinterpret_cast<f32x4*>(lds + dst[u]) = v[u];
-            }
-        }
-        __syncthreads();
+        const bool more = chunk + 1 < nchunk;
+        if (more) { LRPX_STAGE_ISSUE(chunk + 1) }
         if (wave_active) {
-            const f32x4* wp = wbase + (long)chunk * (TAPS * C::KSTEPS * 64);
-            f32x4 bcur = wp[0];
+            const float* abuf = lds + (chunk & 1) * BUF;
+            const int g0step = chunk * STEPS;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int tapoff = (TAPS == 9) ? ((tap / 3) * WP + (tap % 3)) * STRIDE : 0;
 #pragma unroll
                 for (int ks = 0; ks < C::KSTEPS; ++ks) {
-                    constexpr int LAST = TAPS * C::KSTEPS - 1;
                     const int step = tap * C::KSTEPS + ks;
-                    f32x4 bnext = bcur;
-                    if (step < LAST) bnext = wp[(step + 1) * 64];
+                    // refill the ring slot that was consumed one step ago with the fragment NB-1 steps ahead
+                    bq[(step + NB - 1) % NB] = wp[(long)min(g0step + step + NB - 1, last_step) * 64];
                     f32x4 av[7];
 #pragma unroll
                     for (int j = 0; j < 7; ++j)
-                        av[j] = *reinterpret_cast<const f32x4*>(lds + abase[j] + tapoff + ks * 8);
+                        av[j] = *reinterpret_cast<const f32x4*>(abuf + abase[j] + tapoff + ks * 8);
 #pragma unroll
                     for (int j = 0; j < 7; ++j)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][e], bcur[e], acc[j], 0, 0, 0);
-                    bcur = bnext;
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][e], bq[step % NB][e], acc[j], 0, 0, 0);
                 }
             }
         }
+        // the other buffer was last read one iteration ago and every wave has passed a barrier since
+        if (more) { LRPX_STAGE_COMMIT((chunk + 1) & 1) }
+        __syncthreads();
     }
+#undef LRPX_STAGE_ISSUE
+#undef LRPX_STAGE_COMMIT
     if (!wave_active) return;
 
     // ---- epilogue: lane holds channel oc for 16 pixels of each of its 7 row-tiles ----

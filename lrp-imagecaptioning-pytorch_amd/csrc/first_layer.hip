@@ -1,0 +1,91 @@
+// Relevance rule of the FIRST VGG16 conv (3 signed input channels <- 64 channels at 224x224):
+//   R[n][c][y][x] = x+[c] * convT(S, W+)[c] + x-[c] * convT(S, W-)[c]        (LRPtools/lrp_modules.py:124-150)
+// Only 6 output values per pixel (K = 64*9 = 576 each): a 32-wide MFMA tile would waste 26/32 of its work, so
+// this layer is a direct VALU convolution: one thread per output pixel, the S halo tile staged through LDS per
+// 16-channel chunk, the 3456 weights read through the scalar cache (wave-uniform addresses).
+// HBM: reads S once (12.8 MB per map) — this kernel sits at the HBM/VALU balance point.
+#include "common.h"
+#include "conv_mfma.h"
+
+namespace lrpx {
+
+constexpr int FL_TH = 8, FL_TW = 32, FL_KC = 16, FL_STRIDE = FL_KC + 4;
+constexpr int FL_HP = FL_TH + 2, FL_WP = FL_TW + 2;
+
+// w6: [chunk 4][tap 9][ch 16][6] = {W+ for c=0..2, W- for c=0..2} with the kernel flipped (transposed conv)
+__global__ void pack_first_layer_kernel(const float* __restrict__ w, float* __restrict__ w6, int cout) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over cout*9*6
+    if (idx >= cout * 9 * 6) return;
+    const int o = idx % 6;
+    int r = idx / 6;
+    const int ch = r % FL_KC; r /= FL_KC;
+    const int tap = r % 9;
+    const int chunk = r / 9;
+    const int co = chunk * FL_KC + ch, c = o % 3;
+    const float x = w[((long)co * 3 + c) * 9 + (8 - tap)];
+    w6[idx] = o < 3 ? fmaxf(x, 0.f) : fminf(x, 0.f);
+}
+
+__global__ __launch_bounds__(256) void first_layer_rel_kernel(const float* __restrict__ S, const float* __restrict__ w6,
+                                                              const float* __restrict__ X8,
+                                                              const int* __restrict__ map2img, float* __restrict__ out,
+                                                              int cin) {
+    constexpr int HW = 224;
+    __shared__ __attribute__((aligned(16))) float lds[FL_HP * FL_WP * FL_STRIDE];
+    const int n = blockIdx.z, ty0 = blockIdx.y * FL_TH, tx0 = blockIdx.x * FL_TW;
+    const int tid = threadIdx.x, ly = tid >> 5, lx = tid & 31;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* Sn = S + (long)n * HW * HW * cin;
+    const int nchunk = cin / FL_KC;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        __syncthreads();
+        // stage (TH+2) x (TW+2) pixels x 16 channels, zero outside the image
+        for (int it = tid; it < FL_HP * FL_WP * (FL_KC / 4); it += 256) {
+            const int seg = it & 3, p = it >> 2;
+            const int py = p / FL_WP, px = p - py * FL_WP;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < HW && gx >= 0 && gx < HW)
+                v = *reinterpret_cast<const f32x4*>(Sn + ((long)gy * HW + gx) * cin + chunk * FL_KC + seg * 4);
+            *reinterpret_cast<f32x4*>(lds + p * FL_STRIDE + seg * 4) = v;
+        }
+        __syncthreads();
+        const float* wc = w6 + chunk * 9 * FL_KC * 6;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* sp = lds + ((ly + tap / 3) * FL_WP + lx + tap % 3) * FL_STRIDE;
+#pragma unroll
+            for (int c4 = 0; c4 < FL_KC / 4; ++c4) {
+                const f32x4 s = *reinterpret_cast<const f32x4*>(sp + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* wk = wc + (tap * FL_KC + c4 * 4 + e) * 6;   // wave-uniform -> scalar loads
+#pragma unroll
+                    for (int o = 0; o < 6; ++o) acc[o] += s[e] * wk[o];
+                }
+            }
+        }
+    }
+    const int y = ty0 + ly, x = tx0 + lx;
+    const long img = map2img ? map2img[n] : n;
+    const long p = (long)y * HW + x;
+    const float* xp = X8 + (img * HW * HW + p) * 8;          // [x+ (3) | x- (3) | 0 0]
+    const f32x4 xa = *reinterpret_cast<const f32x4*>(xp), xb = *reinterpret_cast<const f32x4*>(xp + 4);
+    const float xpos[3] = {xa[0], xa[1], xa[2]}, xneg[3] = {xa[3], xb[0], xb[1]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[((long)n * 3 + c) * HW * HW + p] = xpos[c] * acc[c] + xneg[c] * acc[3 + c];
+}
+
+int first_layer_pack(const float* w, float* w6, int cout, hipStream_t s) {
+    hipLaunchKernelGGL(pack_first_layer_kernel, dim3((cout * 54 + 255) / 256), dim3(256), 0, s, w, w6, cout);
+    return check_launch("pack_first_layer");
+}
+
+int first_layer_relevance(const float* S, const float* w6, const float* X8, const int* map2img, float* out, int n_maps,
+                          int cin, hipStream_t s) {
+    hipLaunchKernelGGL(first_layer_rel_kernel, dim3(224 / FL_TW, 224 / FL_TH, n_maps), dim3(256), 0, s, S, w6, X8,
+                       map2img, out, cin);
+    return check_launch("first_layer_relevance");
+}
+
+}  // namespace lrpx

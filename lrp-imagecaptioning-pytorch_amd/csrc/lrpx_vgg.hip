@@ -38,25 +38,24 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     const int e = d->epi;
     switch (d->hw) {
         case 224:
-            if (e == EPI_FWD_DUAL) return kc == 8 ? launch_conv_224_8_1_4_9_fwd_dual(a, s) : launch_conv_224_16_1_4_9_fwd_dual(a, s);
-            if (e == EPI_REL) return launch_conv_224_16_2_2_9_rel(a, s);
-            if (e == EPI_FIRST) { LRPX_REQUIRE(d->n_oc == 32, "conv_mfma: FIRST expects n_oc=32"); return launch_conv_224_16_2_1_9_first(a, s); }
+            if (e == EPI_FWD_DUAL) return launch_conv_224_8_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return launch_conv_224_8_4_2_9_rel(a, s);
             break;
         case 112:
-            if (e == EPI_FWD_DUAL) return launch_conv_112_16_1_4_9_fwd_dual(a, s);
-            if (e == EPI_REL) return d->n_oc <= 64 ? launch_conv_112_16_2_2_9_rel(a, s) : launch_conv_112_16_1_4_9_rel(a, s);
+            if (e == EPI_FWD_DUAL) return launch_conv_112_8_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return d->n_oc <= 64 ? launch_conv_112_8_2_2_9_rel(a, s) : launch_conv_112_8_1_4_9_rel(a, s);
             break;
         case 56:
-            if (e == EPI_FWD_DUAL) return launch_conv_56_32_1_4_9_fwd_dual(a, s);
-            if (e == EPI_REL) return launch_conv_56_32_1_4_9_rel(a, s);
+            if (e == EPI_FWD_DUAL) return launch_conv_56_16_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return launch_conv_56_16_1_4_9_rel(a, s);
             break;
         case 28:
-            if (e == EPI_FWD_DUAL) return launch_conv_28_32_1_4_9_fwd_dual(a, s);
-            if (e == EPI_REL) return launch_conv_28_32_1_4_9_rel(a, s);
+            if (e == EPI_FWD_DUAL) return launch_conv_28_16_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return launch_conv_28_16_1_4_9_rel(a, s);
             break;
         case 14:
-            if (e == EPI_FWD_DUAL) return launch_conv_14_32_1_4_9_fwd_dual(a, s);
-            if (e == EPI_REL) return launch_conv_14_32_1_4_9_rel(a, s);
+            if (e == EPI_FWD_DUAL) return launch_conv_14_16_1_4_9_fwd_dual(a, s);
+            if (e == EPI_REL) return launch_conv_14_16_1_4_9_rel(a, s);
             break;
     }
     set_error("conv_mfma: no kernel built for hw=%d epi=%d", d->hw, d->epi);
@@ -76,8 +75,12 @@ static const VggLayer kVgg[17] = {
 static const int kNL = 17;
 static inline int cin_pad(int l) { return l == 0 ? 8 : kVgg[l].cin; }   // image is kept NHWC with 8 channels
 
+int first_layer_pack(const float* w, float* w6, int cout, hipStream_t s);
+int first_layer_relevance(const float* S, const float* w6, const float* X8, const int* map2img, float* out, int n_maps,
+                          int cin, hipStream_t s);
+
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bias[17], total;
+    size_t fwd[17], bwd[17], bias[17], first6, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
@@ -90,6 +93,7 @@ static VggPacked vgg_packed_layout() {
         p.bwd[l] = off; off += lrpx_packed_floats(l == 0 ? 32 : L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout));
         p.bias[l] = off; off += (size_t)L.cout;
     }
+    p.first6 = off; off += (size_t)64 * 9 * 6;   // direct-conv weights of the first layer's rule
     p.total = off;
     return p;
 }
@@ -123,9 +127,9 @@ extern "C" {
 
 int lrpx_conv_kc(int hw, int taps, int cin) {
     if (taps == 1) return 32;
-    if (hw == 224 && cin <= 8) return 8;   // the first VGG layer (image stored as 8 channels)
-    if (hw >= 112) return 16;
-    return 32;
+    (void)cin;
+    if (hw >= 112) return 8;    // two LDS buffers of (rows+halo) x (W+2) pixels must fit: narrower chunks on wide maps
+    return 16;
 }
 
 int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream) { return conv_dispatch(d, (hipStream_t)stream); }
@@ -156,6 +160,7 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
             set_error("vgg16_pack: bias copy failed");
             return LRPX_ELAUNCH;
         }
+        if (l == 0) LRPX_TRY(first_layer_pack(w[ci], base + p.first6, L.cout, (hipStream_t)stream));
         ++ci;
     }
     return LRPX_OK;
@@ -229,8 +234,9 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
         d.n_maps = n_maps; d.hw = L.hw; d.cin = L.cout; d.taps = 9; d.map2img = map2img;
         d.x = tr + t.act[l];
         if (l == 0) {
-            d.n_oc = 32; d.epi = EPI_FIRST; d.oc_split = 8; d.out0 = out_nchw;
-            LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
+            // 3 output channels: direct VALU conv (first_layer.hip) instead of a 32-wide MFMA tile
+            LRPX_TRY(first_layer_relevance(S[cur], pk + p.first6, tr + t.act[0], map2img, out_nchw, n_maps, L.cout,
+                                           (hipStream_t)stream));
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;

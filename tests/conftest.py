@@ -30,3 +30,23 @@ def cosine(a, b):
     import torch
     a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
     return (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
+
+
+def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=5e-2, l2=2e-3, what=""):
+    """End-to-end comparison of pixel relevance maps whose FORWARD passes were computed by different conv
+    implementations.  Relevance through MaxPool2d goes to the arg-max of each 2x2 window
+    (LRPtools/lrp_modules.py:182-195); rounding-level differences of the forward flip the winner of a few
+    near-tied windows out of 1.5 M, each moving one channel's relevance by one pixel — the reference itself moves
+    by 1.6e-4 of max|R| between PyTorch's oneDNN and native CPU convs (2 flips); GPU vs oneDNN on the golden image:
+    4 flips, relative L2 error 2.1e-4, 99th percentile 2.4e-5, 0.17 % of the pixels above 1e-4, max 1.8e-3
+    (tools/e2e_stats.py).  So: cosine >= 0.99999, relative L2 error < `l2`, at most `frac` of the
+    pixels off by more than 1e-4 of max|R|, none by more than `hard`.  The strict 1e-4 bound is asserted
+    separately on identical activations."""
+    import torch
+    got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
+    scale = want.abs().max().clamp_min(1e-300)
+    d = (got - want).abs() / scale
+    assert cosine(got, want) > 0.99999, (what, cosine(got, want))
+    assert ((got - want).norm() / want.norm().clamp_min(1e-300)).item() < l2, (what, "rel L2")
+    assert (d > 1e-4).double().mean().item() < frac, (what, (d > 1e-4).double().mean().item())
+    assert d.max().item() < hard, (what, d.max().item())

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 import lrp_amd  # noqa: F401
-from conftest import GOLDEN, rel_err, cosine
+from conftest import GOLDEN, rel_err, cosine, assert_close_modulo_pool_ties
 
 pytestmark = pytest.mark.gpu
 
@@ -49,10 +49,9 @@ def test_add_lrp_compute_lrp_accumulates_like_reference(gold):
     sample = img.cuda()
     for t in range(3):
         out = enc.compute_lrp(sample, target=torch.from_numpy(g[f"r_feat_{t}"]).cuda())
-        scale = g[f"map_stats_{t}"][1]
         assert out.shape == (1, 3, 224, 224) and out.device.type == "cuda"
-        assert np.abs(out[..., ::4, ::4].cpu().numpy() - g[f"map_sub4_{t}"]).max() / scale < 1e-3
-    assert cosine(out.cpu(), g["map_full_2"]) > 0.99999
+        assert_close_modulo_pool_ties(out[..., ::4, ::4].cpu(), g[f"map_sub4_{t}"], what=t)
+    assert_close_modulo_pool_ties(out.cpu(), g["map_full_2"], what="full")
     out2, logits = enc.compute_lrp(img.cuda(), target=torch.from_numpy(g["r_feat_0"]).cuda(), return_output=True)
     assert rel_err(logits.cpu(), g["features"]) < 1e-4
     with pytest.raises(AssertionError):           # lrp_wrapper.py:81 — all-zero relevance
@@ -125,8 +124,7 @@ def test_explainer_class_drop_in(gold):
     assert ex.caption_length == 3 and ex.predictions.shape == (3, V) and ex.alphas.shape == (3, 196)
     for t in range(3):
         assert np.abs(rws[t].cpu().numpy() - g[f"r_words_{t}"]).max() < 1e-5
-        scale = g[f"map_stats_{t}"][1]
-        assert np.abs(maps[t][..., ::4, ::4].cpu().numpy() - g[f"map_sub4_{t}"]).max() / scale < 1e-3
+        assert_close_modulo_pool_ties(maps[t][..., ::4, ::4].cpu(), g[f"map_sub4_{t}"], what=t)
         rf, rw = ex.explain_caption_wordt(t)
         assert rel_err(rf.cpu(), g[f"r_feat_{t}"]) < 1e-4 and rf.shape == (1, 512, 14, 14)
     # explain_cnn accumulates over calls on the same image exactly like the reference's sample.grad

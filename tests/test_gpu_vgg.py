@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 import lrp_amd  # noqa: F401
-from conftest import GOLDEN, rel_err, cosine
+from conftest import GOLDEN, rel_err, cosine, assert_close_modulo_pool_ties
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -190,8 +190,8 @@ def test_vgg_relevance_vs_reference_maps_end_to_end(ops, gridtd_case):
     """GPU forward + GPU relevance vs the reference's maps.  Rounding-level differences of the forward
     (fp32 MFMA fmaf chain vs oneDNN) flip the winner of a handful of near-tied 2x2 pool windows out of 1.5M,
     each moving one channel's relevance by one pixel.  The reference moves by 1.6e-4 between its OWN oneDNN
-    and native CPU conv back-ends on this image (2 flips; measured in DESIGN.md), so the end-to-end bound
-    is 1e-3 with cosine >= 0.99999; the strict 1e-4 bound is checked on identical activations above."""
+    and native CPU conv back-ends on this image (2 flips; measured in DESIGN.md), so the end-to-end check is
+    `assert_close_modulo_pool_ties`; the strict 1e-4 bound is checked on identical activations above."""
     g, sd, img = gridtd_case
     vgg = _vgg(ops, sd)
     vgg.forward(img.cuda())
@@ -199,10 +199,8 @@ def test_vgg_relevance_vs_reference_maps_end_to_end(ops, gridtd_case):
     maps = vgg.relevance(to_nhwc(r_feat).cuda(), torch.zeros(3, dtype=torch.int32, device="cuda"))
     cum = ops.cumsum_maps(maps, 1, 3).cpu()
     for t in range(3):
-        scale = g[f"map_stats_{t}"][1]
-        assert np.abs(cum[t:t + 1, :, ::4, ::4].numpy() - g[f"map_sub4_{t}"]).max() / scale < 1e-3
-    assert rel_err(cum[2:3], g["map_full_2"]) < 1e-3
-    assert cosine(cum[2:3], g["map_full_2"]) > 0.99999
+        assert_close_modulo_pool_ties(cum[t:t + 1, :, ::4, ::4], g[f"map_sub4_{t}"], what=t)
+    assert_close_modulo_pool_ties(cum[2:3], g["map_full_2"], what="full")
     assert (cum[2:3] - torch.from_numpy(g["map_full_2"])).abs().max() < 1e-4      # BASELINE absolute bound
 
 
@@ -222,8 +220,7 @@ def test_vgg_chain_multi_image_vs_oracle(ops):
     for i, b in enumerate(m2i):
         _, _, saved = O.vgg_forward(sdt, img[b:b + 1])
         want = O.vgg_lrp(sdt, saved, r_feat[i:i + 1])
-        assert rel_err(maps[i:i + 1], want) < 1e-3, i           # end-to-end: pool-tie flips allowed (see above)
-        assert cosine(maps[i:i + 1], want) > 0.99999
+        assert_close_modulo_pool_ties(maps[i:i + 1], want, what=i)   # end-to-end: pool-tie flips allowed
     _inject_oracle_trace(vgg, sd, img)                           # strict: identical activations
     maps = vgg.relevance(to_nhwc(r_feat).cuda(), torch.tensor(m2i, dtype=torch.int32, device="cuda")).cpu()
     for i, b in enumerate(m2i):
