@@ -185,6 +185,37 @@ int lrpx_gridtd_rel_pix(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate*
                         const float* proj_pre, float* a_proj, void* stream);
 int lrpx_rel_words_norm(float* r_words, int rows, int T, void* stream);
 
+/* ---- AoA decoder: trace (get_hidden_parameters, models/aoamodel.py:990-1062) -------------------------- */
+typedef struct lrpx_aoa_trace {
+    int B, T, H, E, P, NH;
+    float* xh;                     /* [B][T][E+2H] = xt ++ ht[:T]  (:1075) */
+    float *h, *c;                  /* [B][T+1][H] */
+    float *g, *i, *f;              /* [B][T][H] */
+    float *ctx, *lin, *c_aoa, *hc; /* [B][T][H]: context, decoder_aoa_linear(context), gated, fc input */
+    float* alpha;                  /* [B][T][NH][P] */
+} lrpx_aoa_trace;
+int lrpx_aoa_fwd_pre(const lrpx_aoa_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
+                     int tok_ld, void* stream);
+int lrpx_aoa_fwd_lstm(const lrpx_aoa_trace* tr, int t, const float* zz, int ldz, void* stream);
+/* qg: [B][2H] = [q_proj(h_t) | decoder_aoa_linear_gate(h_t)]; key/value: [B][P][H]  (MultiHeadedDotAttention, :77-108) */
+int lrpx_aoa_fwd_attention(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* key,
+                           const float* value, void* stream);
+int lrpx_aoa_fwd_post(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* lin, void* stream);
+
+/* ---- AoA decoder: relevance (explain_caption_wordt :1064-1156, lrp_mha :812-862) ----------------------- */
+typedef struct lrpx_aoa_relstate {
+    const int32_t* lens;
+    float *r_hn, *r_glob;          /* [B*T][H] */
+    float *A, *rx;                 /* dense-rule input [B*T][H] / output [B*T][E+2H] */
+    float* r_words;                /* [B*T][T] */
+} lrpx_aoa_relstate;
+int lrpx_aoa_rel_init(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* fcw, const float* logit,
+                      const long long* tok, int tok_ld, void* stream);
+int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
+                       int head, float* a_val, void* stream);
+/* lock-step s: phase 0 g-gate split (:1116-1120) -> A ; phase 1 after the LSTM dense rule (:1129-1133) */
+int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int s, int phase, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,15 @@ class GridRelState(C.Structure):
                                   "r_words")]
 
 
+class AoaTrace(C.Structure):
+    _fields_ = [("B", _i), ("T", _i), ("H", _i), ("E", _i), ("P", _i), ("NH", _i)] + [(k, _f) for k in (
+        "xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha")]
+
+
+class AoaRelState(C.Structure):
+    _fields_ = [(k, _f) for k in ("lens", "r_hn", "r_glob", "A", "rx", "r_words")]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("in_", _f), ("wpacked", _f),
                 ("n_maps", _i), ("hw", _i), ("cin", _i), ("n_oc", _i), ("taps", _i), ("pix_per_map", _i),
@@ -71,6 +80,13 @@ SIGNATURES = {
     "lrpx_rel_avg_u": (_i, [_f, _f, _f, _i, _i, _i, _i, _f]),
     "lrpx_gridtd_rel_pix": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f, _f]),
     "lrpx_rel_words_norm": (_i, [_f, _i, _i, _f]),
+    "lrpx_aoa_fwd_pre": (_i, [C.POINTER(AoaTrace), _i, _f, _f, _f, _i, _f]),
+    "lrpx_aoa_fwd_lstm": (_i, [C.POINTER(AoaTrace), _i, _f, _i, _f]),
+    "lrpx_aoa_fwd_attention": (_i, [C.POINTER(AoaTrace), _i, _f, _i, _f, _f, _f]),
+    "lrpx_aoa_fwd_post": (_i, [C.POINTER(AoaTrace), _i, _f, _i, _f, _f]),
+    "lrpx_aoa_rel_init": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _f, _i, _f]),
+    "lrpx_aoa_rel_value": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _i, _f, _f]),
+    "lrpx_aoa_rel_step": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _i, _i, _f]),
     "lrpx_vgg16_packed_bytes": (_sz, []),
     "lrpx_vgg16_trace_bytes": (_sz, [_i]),
     "lrpx_vgg16_workspace_bytes": (_sz, [_i]),

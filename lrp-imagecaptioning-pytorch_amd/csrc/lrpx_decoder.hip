@@ -429,6 +429,181 @@ __global__ void rel_words_norm_kernel(float* __restrict__ r_words, int rows, int
         for (int i = 0; i <= t; ++i) r_words[(long)row * T + i] /= m;
 }
 
+
+// ================================================================================================
+// AoA decoder (models/aoamodel.py): trace :990-1062, relevance :1064-1156
+// ================================================================================================
+struct AoaFwd {
+    int B, T, H, E, P, NH;
+    float *xh;                   // [B][T][E+2H] = [emb | glob | h_t]          (xt ++ ht[:T], :1075)
+    float *h, *c;                // [B][T+1][H]
+    float *g, *i, *f;            // [B][T][H]
+    float *ctx, *lin, *c_aoa, *hc;   // [B][T][H]  context, decoder_aoa_linear(context), gated, fc input
+    float *alpha;                // [B][T][NH][P]
+};
+
+// xh[b,t] = [emb[tok[b,t]] | glob[b] | h[b,t]]   (:1030, :1075)
+__global__ void aoa_fwd_pre_kernel(AoaFwd g, int t, const float* __restrict__ glob, const float* __restrict__ emb,
+                                   const long long* __restrict__ tok, int tok_ld) {
+    const int b = blockIdx.x, W = g.E + 2 * g.H;
+    float* dst = g.xh + ((long)b * g.T + t) * W;
+    const long st = ((long)b * (g.T + 1) + t) * g.H;
+    const long long k = tok[(long)b * tok_ld + t];
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        float v;
+        if (c < g.E) v = emb[k * g.E + c];
+        else if (c < g.E + g.H) v = glob[(long)b * g.H + (c - g.E)];
+        else v = g.h[st + (c - g.E - g.H)];
+        dst[c] = v;
+    }
+}
+
+__global__ void aoa_fwd_lstm_kernel(AoaFwd g, int t, const float* __restrict__ zz, int ldz) {
+    const int b = blockIdx.x, H = g.H;
+    const long st0 = ((long)b * (g.T + 1) + t) * H, st1 = st0 + H, tr = ((long)b * g.T + t) * H;
+    const float* z = zz + (long)b * ldz;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float i = sigmoidf_(z[c]), f = sigmoidf_(z[H + c]), zg = z[2 * H + c], o = sigmoidf_(z[3 * H + c]);
+        const float cn = f * g.c[st0 + c] + i * tanhf(zg);
+        g.c[st1 + c] = cn; g.h[st1 + c] = o * tanhf(cn);
+        g.g[tr + c] = zg; g.i[tr + c] = i; g.f[tr + c] = f;
+    }
+}
+
+// MultiHeadedDotAttention.forward (models/aoamodel.py:77-108) for a single query per image; one block per
+// (image, head).  qg: [B][2H] = [q_proj(h) | aoa_linear_gate(h)]
+__global__ __launch_bounds__(256) void aoa_fwd_attention_kernel(AoaFwd g, int t, const float* __restrict__ qg, int ldq,
+                                                                const float* __restrict__ key,
+                                                                const float* __restrict__ value) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, hd = blockIdx.y, H = g.H, P = g.P, dk = H / g.NH, tid = threadIdx.x;
+    float* q = sm;          // dk
+    float* sc = q + dk;     // P
+    float* red = sc + P;    // 8
+    for (int c = tid; c < dk; c += 256) q[c] = qg[(long)b * ldq + hd * dk + c];
+    __syncthreads();
+    const float inv = 1.f / sqrtf((float)dk);
+    for (int k = tid; k < P; k += 256) {
+        const float* kp = key + ((long)b * P + k) * H + hd * dk;
+        float a = 0.f;
+        for (int c = 0; c < dk; ++c) a += q[c] * kp[c];
+        sc[k] = a * inv;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int k = tid; k < P; k += 256) m = fmaxf(m, sc[k]);
+    m = block_max(m, red);
+    float e = 0.f;
+    for (int k = tid; k < P; k += 256) e += expf(sc[k] - m);
+    const float denom = block_sum(e, red);
+    __syncthreads();
+    float* al = g.alpha + (((long)b * g.T + t) * g.NH + hd) * P;
+    for (int k = tid; k < P; k += 256) { const float a = expf(sc[k] - m) / denom; sc[k] = a; al[k] = a; }
+    __syncthreads();
+    const long tr = ((long)b * g.T + t) * H;
+    for (int c = tid; c < dk; c += 256) {
+        float a = 0.f;
+        for (int k = 0; k < P; ++k) a += sc[k] * value[((long)b * P + k) * H + hd * dk + c];
+        g.ctx[tr + hd * dk + c] = a;
+    }
+}
+
+// c_aoa = sigmoid(gate) * lin ; hc = c_aoa + h   (:1034-1038)
+__global__ void aoa_fwd_post_kernel(AoaFwd g, int t, const float* __restrict__ qg, int ldq, const float* __restrict__ lin) {
+    const int b = blockIdx.x, H = g.H;
+    const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = ((long)b * g.T + t) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float l = lin[(long)b * H + c];
+        const float ca = sigmoidf_(qg[(long)b * ldq + H + c]) * l;
+        g.lin[tr + c] = l; g.c_aoa[tr + c] = ca; g.hc[tr + c] = ca + g.h[st1 + c];
+    }
+}
+
+struct AoaRel {
+    int B, T, H, E, P, NH;
+    const int* lens;
+    const float *xh, *h, *c, *g, *i, *ctx, *lin, *c_aoa, *hc, *alpha;
+    float *r_hn, *r_glob, *A, *rx, *r_words;     // [rows][H], [rows][H], [rows][H], [rows][E+2H], [rows][T]
+};
+
+__device__ __forceinline__ bool aoa_row_active(const AoaRel& g, int b, int t, int s) {
+    const int len = g.lens ? g.lens[b] : g.T;
+    return t < len && t >= s;
+}
+
+// :1081-1110 fc one-hot rule, split into h and context_aoa; A = r_caoa / z~(aoa_linear output) for the dense rule
+__global__ void aoa_rel_init_kernel(AoaRel g, const float* __restrict__ fcw, const float* __restrict__ logit,
+                                    const long long* __restrict__ tok, int tok_ld) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    const long long k = tok[(long)b * tok_ld + t + 1];
+    const float lg = logit[row], zt = stab_eps(lg);
+    const long tr = (long)row * H, st1 = ((long)b * (g.T + 1) + t + 1) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float hc = g.hc[tr + c];
+        const float r_hc = (fcw[k * H + c] * hc / zt) * lg;
+        g.r_hn[tr + c] = eps_id(r_hc, g.h[st1 + c], hc);
+        const float r_ca = eps_id(r_hc, g.c_aoa[tr + c], hc);
+        g.A[tr + c] = r_ca / stab_eps(g.lin[tr + c]);
+        g.r_glob[tr + c] = 0.f;
+    }
+    for (int c = threadIdx.x; c < g.T; c += blockDim.x) g.r_words[(long)row * g.T + c] = 0.f;
+}
+
+// lrp_mha (:812-862), single head: Aval[row][k][c] = (value*alpha / z~(ctx)) * r_ctx / z~(value)  inside head
+// `head`, 0 elsewhere — the prologue of the v_proj dense rule (:1141-1144).  r_ctx: [rows][H]
+__global__ __launch_bounds__(256) void aoa_rel_value_kernel(AoaRel g, const float* __restrict__ r_ctx,
+                                                            const float* __restrict__ value, int head,
+                                                            float* __restrict__ Aval) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, P = g.P, dk = H / g.NH;
+    const int len = g.lens ? g.lens[b] : g.T;
+    const bool act = t < len;
+    const float* al = g.alpha + (((long)b * g.T + t) * g.NH + head) * P;
+    for (int j = threadIdx.x; j < P * H; j += 256) {
+        const int k = j / H, c = j - k * H;
+        float v = 0.f;
+        if (act && c >= head * dk && c < (head + 1) * dk) {
+            const float val = value[((long)b * P + k) * H + c];
+            const float rv = eps_id(r_ctx[(long)row * H + c], val * al[k], g.ctx[(long)row * H + c]);
+            v = rv / stab_eps(val);
+        }
+        Aval[((long)row * P + k) * H + c] = v;
+    }
+}
+
+// :1116-1120  r_c = r_h (assignment); g-gate path; A = r_g / z~(g)
+__global__ void aoa_rel_a_kernel(AoaRel g, int s) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    const long tr = (long)row * H;
+    if (!aoa_row_active(g, b, t, s)) {
+        for (int c = threadIdx.x; c < H; c += blockDim.x) g.A[tr + c] = 0.f;
+        return;
+    }
+    const int i = t - s;
+    const long ti = ((long)b * g.T + i) * H, sc1 = ((long)b * (g.T + 1) + i + 1) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float rg = eps_id(g.r_hn[tr + c], g.i[ti + c] * tanhf(g.g[ti + c]), g.c[sc1 + c]);
+        g.A[tr + c] = rg / stab_eps(g.g[ti + c]);
+    }
+}
+
+// :1129-1133  r_xh = [emb | glob | h]
+__global__ __launch_bounds__(256) void aoa_rel_c_kernel(AoaRel g, int s) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, E = g.E;
+    if (!aoa_row_active(g, b, t, s)) return;
+    const int i = t - s;
+    const long tr = (long)row * H;
+    const float* rx = g.rx + (long)row * (E + 2 * H);
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < E; c += 256) acc += rx[c];
+    for (int c = threadIdx.x; c < H; c += 256) {
+        g.r_glob[tr + c] += rx[E + c];
+        g.r_hn[tr + c] = rx[E + H + c];
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) g.r_words[(long)row * g.T + i] = acc;
+}
+
 }  // namespace lrpx
 
 using namespace lrpx;
@@ -584,6 +759,98 @@ int lrpx_rel_words_norm(float* r_words, int rows, int T, void* stream) {
     LRPX_REQUIRE(r_words && rows > 0 && T > 0, "rel_words_norm: bad arguments");
     hipLaunchKernelGGL(rel_words_norm_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, r_words, rows, T);
     return check_launch("rel_words_norm");
+}
+
+
+static AoaFwd to_afwd(const lrpx_aoa_trace* t) {
+    AoaFwd g;
+    g.B = t->B; g.T = t->T; g.H = t->H; g.E = t->E; g.P = t->P; g.NH = t->NH;
+    g.xh = t->xh; g.h = t->h; g.c = t->c; g.g = t->g; g.i = t->i; g.f = t->f;
+    g.ctx = t->ctx; g.lin = t->lin; g.c_aoa = t->c_aoa; g.hc = t->hc; g.alpha = t->alpha;
+    return g;
+}
+
+static int check_atrace(const lrpx_aoa_trace* t) {
+    LRPX_REQUIRE(t && t->B > 0 && t->T > 0 && t->H == 512 && t->E % 4 == 0 && t->P > 0 && t->NH > 0 && t->H % t->NH == 0,
+                 "aoa: unsupported trace dims (H must be 512)");
+    LRPX_REQUIRE(t->xh && t->h && t->c && t->g && t->i && t->f && t->ctx && t->lin && t->c_aoa && t->hc && t->alpha,
+                 "aoa: null trace tensor");
+    return LRPX_OK;
+}
+
+int lrpx_aoa_fwd_pre(const lrpx_aoa_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
+                     int tok_ld, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(glob && emb && tok && t >= 0 && t < tr->T, "aoa_fwd_pre: bad arguments");
+    hipLaunchKernelGGL(aoa_fwd_pre_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), t, glob, emb, tok,
+                       tok_ld);
+    return check_launch("aoa_fwd_pre");
+}
+
+int lrpx_aoa_fwd_lstm(const lrpx_aoa_trace* tr, int t, const float* zz, int ldz, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(zz && t >= 0 && t < tr->T, "aoa_fwd_lstm: bad arguments");
+    hipLaunchKernelGGL(aoa_fwd_lstm_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), t, zz, ldz);
+    return check_launch("aoa_fwd_lstm");
+}
+
+int lrpx_aoa_fwd_attention(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* key,
+                           const float* value, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(qg && key && value && t >= 0 && t < tr->T, "aoa_fwd_attention: bad arguments");
+    const size_t lds = (size_t)(tr->H / tr->NH + tr->P + 8) * sizeof(float);
+    hipLaunchKernelGGL(aoa_fwd_attention_kernel, dim3(tr->B, tr->NH), dim3(256), lds, (hipStream_t)stream, to_afwd(tr), t,
+                       qg, ldq, key, value);
+    return check_launch("aoa_fwd_attention");
+}
+
+int lrpx_aoa_fwd_post(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* lin, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(qg && lin && t >= 0 && t < tr->T, "aoa_fwd_post: bad arguments");
+    hipLaunchKernelGGL(aoa_fwd_post_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), t, qg, ldq, lin);
+    return check_launch("aoa_fwd_post");
+}
+
+static AoaRel to_arel(const lrpx_aoa_trace* t, const lrpx_aoa_relstate* r) {
+    AoaRel g;
+    g.B = t->B; g.T = t->T; g.H = t->H; g.E = t->E; g.P = t->P; g.NH = t->NH; g.lens = r->lens;
+    g.xh = t->xh; g.h = t->h; g.c = t->c; g.g = t->g; g.i = t->i; g.ctx = t->ctx; g.lin = t->lin; g.c_aoa = t->c_aoa;
+    g.hc = t->hc; g.alpha = t->alpha;
+    g.r_hn = r->r_hn; g.r_glob = r->r_glob; g.A = r->A; g.rx = r->rx; g.r_words = r->r_words;
+    return g;
+}
+
+static int check_arel(const lrpx_aoa_trace* t, const lrpx_aoa_relstate* r) {
+    LRPX_TRY(check_atrace(t));
+    LRPX_REQUIRE(r && r->r_hn && r->r_glob && r->A && r->rx && r->r_words, "aoa: null relevance-state tensor");
+    return LRPX_OK;
+}
+
+int lrpx_aoa_rel_init(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* fcw, const float* logit,
+                      const long long* tok, int tok_ld, void* stream) {
+    LRPX_TRY(check_arel(tr, rs));
+    LRPX_REQUIRE(fcw && logit && tok, "aoa_rel_init: null pointer");
+    hipLaunchKernelGGL(aoa_rel_init_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_arel(tr, rs), fcw,
+                       logit, tok, tok_ld);
+    return check_launch("aoa_rel_init");
+}
+
+int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
+                       int head, float* a_val, void* stream) {
+    LRPX_TRY(check_arel(tr, rs));
+    LRPX_REQUIRE(r_ctx && value && a_val && head >= 0 && head < tr->NH, "aoa_rel_value: bad arguments");
+    hipLaunchKernelGGL(aoa_rel_value_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_arel(tr, rs),
+                       r_ctx, value, head, a_val);
+    return check_launch("aoa_rel_value");
+}
+
+int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int s, int phase, void* stream) {
+    LRPX_TRY(check_arel(tr, rs));
+    LRPX_REQUIRE(s >= 0 && s < tr->T && (phase == 0 || phase == 1), "aoa_rel_step: bad step/phase");
+    const AoaRel g = to_arel(tr, rs);
+    if (phase == 0) hipLaunchKernelGGL(aoa_rel_a_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, g, s);
+    else hipLaunchKernelGGL(aoa_rel_c_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, g, s);
+    return check_launch("aoa_rel_step");
 }
 
 }  // extern "C"

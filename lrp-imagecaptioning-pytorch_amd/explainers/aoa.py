@@ -1,0 +1,293 @@
+"""Batched AoA (attention-on-attention, 8-head) LRP engine + the drop-in `ExplainAOAAttention` explainer.
+
+Reference: models/aoamodel.py:748-1254.  Also serves the bottom-up variant (36 x 2048 region features, no CNN
+stage; SURVEY §8(a) row A-BU): pass `features=` instead of images.  Host logic only sequences HIP kernels."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .._lib import (AoaRelState, AoaTrace, EPI_PLAIN, EPI_REL, PACK_DENSE, PACK_DENSE_T, STAB_EPS, check, ptr, ptr_at,
+                    stream_ptr)
+from .gridtd import VGG_PREFIX, _t
+
+
+class AOAEngine:
+    """`state`: the reference `AOAModel` state_dict (models/aoamodel.py:116-142).  Without encoder weights
+    (bottom-up model, :1795-1797) only `features=` inputs are accepted."""
+
+    def __init__(self, state, num_head=8, device="cuda"):
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.LrpxError("the LRP hot path needs an MI355X; there is no CPU fallback")
+        dev = torch.device(device)
+        self.device = dev
+        sd = {k: _t(v, dev) for k, v in state.items() if not k.startswith(VGG_PREFIX)}
+        names = [k for k in state if k.startswith(VGG_PREFIX) and k.endswith(".weight")]
+        self.vgg = None
+        if names:
+            self.vgg = ops.Vgg16([_t(state[k], dev) for k in names],
+                                 [_t(state[k.replace(".weight", ".bias")], dev) for k in names])
+        self.sd = sd
+        self.NH = num_head
+        self.V, self.E = sd["embedding.weight"].shape
+        self.H = sd["fc.weight"].shape[1]
+        w_proj = sd["img_projector.weight"]
+        self.C = w_proj.shape[1]
+        H, E, Cc = self.H, self.E, self.C
+        assert H == 512, "kernels are built for hidden=512 (config.py:188)"
+        l = "LanguageLSTM."
+        self.Wcat = torch.cat([sd[l + "weight_ih"], sd[l + "weight_hh"]], 1).contiguous()          # (4H, E+2H)
+        self.bcat_explainer = (sd[l + "bias_ih"] + sd[l + "bias_ih"]).contiguous()                  # quirk :873
+        self.bcat_model = (sd[l + "bias_ih"] + sd[l + "bias_hh"]).contiguous()
+        self.Wqg = torch.cat([sd["decoder_multihead_attention.q_proj.weight"], sd["decoder_aoa_linear_gate.weight"]], 0).contiguous()
+        self.bqg = torch.cat([sd["decoder_multihead_attention.q_proj.bias"], sd["decoder_aoa_linear_gate.bias"]]).contiguous()
+        self.w_proj2d = w_proj.reshape(H, Cc).contiguous()
+        kc = ops.conv_kc(0, 1, Cc)
+        self.p_proj_fwd = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE, kc)
+        self.p_k_fwd = ops.pack_weights(sd["decoder_k_proj.weight"], H, H, 1, PACK_DENSE, kc)
+        self.p_v_fwd = ops.pack_weights(sd["decoder_v_proj.weight"], H, H, 1, PACK_DENSE, kc)
+        self.p_fc_fwd = ops.pack_weights(sd["fc.weight"], self.V, H, 1, PACK_DENSE, kc)
+        wg = torch.cat([sd[l + "weight_ih"][2 * H:3 * H], sd[l + "weight_hh"][2 * H:3 * H]], 1).contiguous()
+        self.p_wg = ops.pack_weights(wg, H, E + 2 * H, 1, PACK_DENSE_T, kc)
+        self.p_lin_rel = ops.pack_weights(sd["decoder_aoa_linear.weight"], H, H, 1, PACK_DENSE_T, kc)
+        self.p_v_rel = ops.pack_weights(sd["decoder_v_proj.weight"], H, H, 1, PACK_DENSE_T, kc)
+        self.p_proj_rel = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE_T, kc)
+        torch.cuda.synchronize()
+        self._idx_cache = {}
+
+    # ------------------------------------------------------------------------------------------
+    def encode(self, images=None, features=None):
+        """(:999-1009) image-side constants; `features`: (B,P,C) region/pixel features instead of images."""
+        lib = _lib.load()
+        st = stream_ptr()
+        H, Cc = self.H, self.C
+        if features is None:
+            if self.vgg is None:
+                raise ValueError("this AoA model has no encoder: pass features=(B,P,C)")
+            feats = self.vgg.forward(images.to(self.device, torch.float32).contiguous())
+        else:
+            feats = features.to(self.device, torch.float32).contiguous()
+        B, P, _ = feats.shape
+        e = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        enc = dict(B=B, P=P, feats=feats)
+        enc["proj_pre"] = e(B, P, H)
+        ops.conv_mfma(feats, self.p_proj_fwd, B, 0, Cc, H, 1, EPI_PLAIN, pix_per_map=P, oc_split=H,
+                      bias=self.sd["img_projector.bias"], out0=enc["proj_pre"])
+        enc["Vp"] = e(B, P, H)
+        check(lib.lrpx_relu(ptr(enc["proj_pre"]), ptr(enc["Vp"]), enc["Vp"].numel(), st))
+        enc["glob"] = e(B, H)
+        check(lib.lrpx_mean_pixels(ptr(enc["Vp"]), ptr(enc["glob"]), B, P, H, st))
+        enc["key"], enc["value"] = e(B, P, H), e(B, P, H)
+        ops.conv_mfma(enc["Vp"], self.p_k_fwd, B, 0, H, H, 1, EPI_PLAIN, pix_per_map=P, oc_split=H,
+                      bias=self.sd["decoder_k_proj.bias"], out0=enc["key"])
+        ops.conv_mfma(enc["Vp"], self.p_v_fwd, B, 0, H, H, 1, EPI_PLAIN, pix_per_map=P, oc_split=H,
+                      bias=self.sd["decoder_v_proj.bias"], out0=enc["value"])
+        return enc
+
+    def _alloc_trace(self, B, T, P):
+        dev, H, E, NH = self.device, self.H, self.E, self.NH
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        tr = dict(B=B, T=T, P=P)
+        tr["xh"] = z(B, T, E + 2 * H)
+        tr["h"], tr["c"] = z(B, T + 1, H), z(B, T + 1, H)
+        for k in ("g", "i", "f", "ctx", "lin", "c_aoa", "hc"):
+            tr[k] = z(B, T, H)
+        tr["alpha"] = z(B, T, NH, P)
+        c = AoaTrace()
+        c.B, c.T, c.H, c.E, c.P, c.NH = B, T, H, E, P, NH
+        for k in ("xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha"):
+            setattr(c, k, ptr(tr[k]))
+        tr["_c"] = c
+        return tr
+
+    def trace(self, enc, captions, model_bias=False, predictions=True):
+        lib = _lib.load()
+        st = stream_ptr()
+        B, T = captions.shape[0], captions.shape[1] - 1
+        H, E = self.H, self.E
+        captions = captions.to(self.device, torch.int64).contiguous()
+        tr = self._alloc_trace(B, T, enc["P"])
+        c = C.byref(tr["_c"])
+        W = E + 2 * H
+        zz = torch.empty(B, 4 * H, device=self.device)
+        qg = torch.empty(B, 2 * H, device=self.device)
+        lin = torch.empty(B, H, device=self.device)
+        bias = self.bcat_model if model_bias else self.bcat_explainer
+        sd = self.sd
+        for t in range(T):
+            check(lib.lrpx_aoa_fwd_pre(c, t, ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), T + 1, st))
+            check(lib.lrpx_linear_small(ptr_at(tr["xh"], t * W), T * W, ptr(self.Wcat), ptr(bias), ptr(zz), 4 * H, B, W,
+                                        4 * H, 0, st))
+            check(lib.lrpx_aoa_fwd_lstm(c, t, ptr(zz), 4 * H, st))
+            check(lib.lrpx_linear_small(ptr_at(tr["h"], (t + 1) * H), (T + 1) * H, ptr(self.Wqg), ptr(self.bqg), ptr(qg),
+                                        2 * H, B, H, 2 * H, 0, st))
+            check(lib.lrpx_aoa_fwd_attention(c, t, ptr(qg), 2 * H, ptr(enc["key"]), ptr(enc["value"]), st))
+            check(lib.lrpx_linear_small(ptr_at(tr["ctx"], t * H), T * H, ptr(sd["decoder_aoa_linear.weight"]),
+                                        ptr(sd["decoder_aoa_linear.bias"]), ptr(lin), H, B, H, H, 0, st))
+            check(lib.lrpx_aoa_fwd_post(c, t, ptr(qg), 2 * H, ptr(lin), st))
+        tr["captions"] = captions
+        tr["logit"] = torch.empty(B * T, device=self.device)
+        check(lib.lrpx_target_logit(ptr(tr["hc"]), ptr(sd["fc.weight"]), ptr(sd["fc.bias"]), ptr(captions), T + 1,
+                                    ptr(tr["logit"]), B, T, H, st))
+        if predictions:
+            tr["pred"] = self.logits(tr["hc"].view(B * T, H)).view(B, T, self.V)
+        return tr
+
+    def logits(self, hc_rows):
+        R = hc_rows.shape[0]
+        out = torch.empty(R, self.V, device=self.device)
+        ops.conv_mfma(hc_rows, self.p_fc_fwd, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1,
+                      oc_split=self.V, bias=self.sd["fc.bias"], out0=out)
+        return out
+
+    def _row_index(self, B, T):
+        key = (B, T)
+        if key not in self._idx_cache:
+            b = torch.arange(B, device=self.device).view(B, 1)
+            t = torch.arange(T, device=self.device).view(1, T)
+            s = torch.arange(T, device=self.device).view(T, 1, 1)
+            idx = (b * T + (t - s).clamp(min=0)).to(torch.int32).reshape(T, B * T).contiguous()
+            row2img = (b + 0 * t).to(torch.int32).reshape(B * T).contiguous()
+            rowid = torch.arange(B * T, device=self.device, dtype=torch.int32)
+            self._idx_cache[key] = (idx, row2img, rowid)
+        return self._idx_cache[key]
+
+    def relevance(self, enc, tr, head_idx, lens=None):
+        """explain_caption_wordt (:1064-1156) for every (image, word) row -> r_feat (B*T,P,C), r_words (B*T,T)."""
+        lib = _lib.load()
+        st = stream_ptr()
+        B, T, P, H, E, Cc = tr["B"], tr["T"], tr["P"], self.H, self.E, self.C
+        rows = B * T
+        e = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        rs = dict(r_hn=e(rows, H), r_glob=e(rows, H), A=e(rows, H), rx=e(rows, E + 2 * H), r_words=e(rows, T))
+        c = AoaRelState()
+        c.lens = ptr(lens)
+        for k, v in rs.items():
+            setattr(c, k, ptr(v))
+        ctr, crs = C.byref(tr["_c"]), C.byref(c)
+        idx, row2img, rowid = self._row_index(B, T)
+        check(lib.lrpx_aoa_rel_init(ctr, crs, ptr(self.sd["fc.weight"]), ptr(tr["logit"]), ptr(tr["captions"]), T + 1, st))
+        # decoder_aoa_linear dense rule (:1107-1110): r_ctx = ctx * (W^T (r_caoa / z~(lin)))
+        r_ctx = e(rows, H)
+        ops.conv_mfma(rs["A"], self.p_lin_rel, rows, 0, H, H, 1, EPI_REL, pix_per_map=1, oc_split=H, x=tr["ctx"],
+                      map2img=rowid, out0=r_ctx)
+        a_val = e(rows, P, H)
+        check(lib.lrpx_aoa_rel_value(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), st))
+        W = E + 2 * H
+        for s in range(T):
+            check(lib.lrpx_aoa_rel_step(ctr, crs, s, 0, st))
+            ops.conv_mfma(rs["A"], self.p_wg, rows, 0, H, W, 1, EPI_REL, pix_per_map=1, oc_split=W, x=tr["xh"],
+                          map2img=idx[s], out0=rs["rx"])
+            check(lib.lrpx_aoa_rel_step(ctr, crs, s, 1, st))
+        # :1136-1144  r_proj = eye rule on the mean (U) + v_proj dense rule; fused division for the projector rule
+        U = e(rows, H)
+        check(lib.lrpx_rel_avg_u(ptr(rs["r_glob"]), ptr(enc["glob"]), ptr(U), rows, T, H, P, st))
+        a_proj = e(rows, P, H)
+        ops.conv_mfma(a_val, self.p_v_rel, rows, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
+                      zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img, out1=a_proj)
+        r_feat = e(rows, P, Cc)
+        ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=enc["feats"],
+                      map2img=row2img, out0=r_feat)                                   # :1145-1148
+        check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
+        return r_feat, rs["r_words"], row2img
+
+    def explain_batch(self, captions, head_idx, images=None, features=None, lens=None, accumulate=False,
+                      return_features=False):
+        """Batched `explain_caption(img, head_idx)` (:1165-1181).  With images: maps (B,T,3,224,224); with
+        `features` (bottom-up): the region-feature relevance (B,T,P,C) is the result (no CNN stage)."""
+        enc = self.encode(images, features)
+        captions = captions.to(self.device, torch.int64).contiguous()
+        B, T = captions.shape[0], captions.shape[1] - 1
+        tr = self.trace(enc, captions, predictions=False)
+        r_feat, r_words, row2img = self.relevance(enc, tr, head_idx, lens)
+        if features is not None:
+            return r_feat.view(B, T, enc["P"], self.C), r_words.view(B, T, T)
+        maps = self.vgg.relevance(r_feat, row2img)
+        if accumulate:
+            maps = ops.cumsum_maps(maps, B, T)
+        out = (maps.view(B, T, 3, 224, 224), r_words.view(B, T, T))
+        if return_features:
+            out = out + (r_feat.view(B, T, enc["P"], self.C), tr, enc)
+        return out
+
+
+class ExplainAOAAttention(object):
+    """Drop-in for the reference's `ExplainAOAAttention` (models/aoamodel.py:748-1194): `explain_caption(img, head_idx)`,
+    `explain_caption_wordt(t, head_idx)`, `explain_cnn(R)`, `explain_caption_words(img)`; see
+    explainers/gridtd.py:ExplainGridTDAttention for the conventions (greedy instead of beam search unless
+    `caption_encode=` is given; nothing written to disk)."""
+    EPS = 0.01
+    EX_TYPE = 'lrp'
+
+    def __init__(self, args, word_map, model=None):
+        self.args = args
+        self.word_map = word_map
+        self.vocab_size = len(word_map)
+        self.num_head = getattr(args, "num_head", 8)
+        if model is None:
+            state = torch.load(args.weight, map_location="cpu")['state_dict']
+        elif hasattr(model, "state_dict"):
+            state = model.state_dict()
+        else:
+            state = model
+        self.model = model
+        self.engine = AOAEngine(state, self.num_head)
+        self.rev_word_map = {v: k for k, v in word_map.items()}
+
+    def get_hidden_parameters(self, img, caption_encode):
+        eng = self.engine
+        self.img = img.to(eng.device, torch.float32)
+        self._enc = eng.encode(self.img)
+        self.beam_caption_encode = [int(c) for c in caption_encode]
+        self.caption_length = len(self.beam_caption_encode) - 1
+        special = {self.word_map[k] for k in ('<start>', '<end>', '<unk>', '<pad>') if k in self.word_map}
+        self.beam_caption = [' '.join(self.rev_word_map.get(c, str(c)) for c in self.beam_caption_encode[1:]
+                                      if c not in special)]
+        cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=eng.device)
+        self._tr = eng.trace(self._enc, cap, predictions=True)
+        self.image_features = ops.nhwc_to_nchw(self._enc["feats"].contiguous(), eng.C, 14, 14)
+        self.num_pixels = self._enc["P"]
+        self.predictions = self._tr["pred"][0]
+        self.alphas = self._tr["alpha"][0]
+        self._rel = {}
+
+    def _relevance(self, head_idx):
+        if head_idx not in self._rel:
+            self._rel[head_idx] = self.engine.relevance(self._enc, self._tr, head_idx)
+        return self._rel[head_idx]
+
+    def explain_caption_wordt(self, t, head_idx):
+        assert t < self.caption_length
+        r_feat, r_words, _ = self._relevance(head_idx)
+        return ops.nhwc_to_nchw(r_feat[t:t + 1].contiguous(), self.engine.C, 14, 14), r_words[t, :t + 1].clone()
+
+    def explain_cnn(self, r_img_feature):
+        t_nhwc = ops.nchw_to_nhwc(r_img_feature.to(torch.float32))
+        r = self.engine.vgg.relevance(t_nhwc, torch.zeros(r_img_feature.shape[0], dtype=torch.int32,
+                                                          device=self.engine.device))
+        if getattr(self, "_img_grad", None) is None:
+            self._img_grad = r
+        else:
+            check(_lib.load().lrpx_accumulate(ptr(self._img_grad), ptr(r), r.numel(), stream_ptr()))
+        ops.check_relevance(self._img_grad, finite=True, nonzero=True)
+        return self._img_grad.clone()
+
+    def explain_caption(self, img, head_idx, t_list=None, caption_encode=None):
+        """(:1165-1181); the returned maps are the reference's running sums (lrp_wrapper.py:64-82)."""
+        if caption_encode is None:
+            raise ValueError("caption_encode is required (the reference's beam search is outside the hot path)")
+        self.get_hidden_parameters(img, caption_encode)
+        self._img_grad = None
+        r_feat, r_words, row2img = self._relevance(head_idx)
+        maps = ops.cumsum_maps(self.engine.vgg.relevance(r_feat, row2img), 1, self.caption_length)
+        ops.check_relevance(maps, finite=True, nonzero=True)
+        return ([maps[t:t + 1] for t in range(self.caption_length)],
+                [r_words[t, :t + 1] for t in range(self.caption_length)])
+
+    def explain_caption_words(self, img, caption_encode):
+        """(:1183-1194) linguistic relevance only, head 0."""
+        self.get_hidden_parameters(img, caption_encode)
+        _, r_words, _ = self._relevance(0)
+        return [r_words[t, :t + 1] for t in range(self.caption_length)]

@@ -37,8 +37,8 @@ def test_version_and_pure_host_entry_points():
         pytest.skip("liblrpx.so not built")
     lib = _lib.load()
     assert lib.lrpx_version() >= 100
-    assert lib.lrpx_conv_kc(224, 9, 8) == 8 and lib.lrpx_conv_kc(224, 9, 64) == 16 and lib.lrpx_conv_kc(112, 9, 8) == 16
-    assert lib.lrpx_conv_kc(56, 9, 256) == 32 and lib.lrpx_conv_kc(0, 1, 512) == 32
+    assert lib.lrpx_conv_kc(224, 9, 8) == 8 and lib.lrpx_conv_kc(224, 9, 64) == 8 and lib.lrpx_conv_kc(112, 9, 128) == 8
+    assert lib.lrpx_conv_kc(56, 9, 256) == 16 and lib.lrpx_conv_kc(0, 1, 512) == 32
     assert lib.lrpx_packed_floats(64, 64, 9, 16) == 64 * 64 * 9
     assert lib.lrpx_packed_floats(6, 64, 9, 16) == 32 * 64 * 9          # output channels pad to 32
     assert lib.lrpx_vgg16_trace_bytes(2) == 2 * lib.lrpx_vgg16_trace_bytes(1)

@@ -1,0 +1,85 @@
+"""GPU parity of the AoA decoder (trace + relevance, heads 0 and 5), the whole AoA pipeline, and the bottom-up
+(36x2048 region features) variant, against the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lrp_amd  # noqa: F401
+from conftest import GOLDEN, rel_err, cosine, assert_close_modulo_pool_ties
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def case():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    g = np.load(os.path.join(GOLDEN, "aoa_T3.npz"))
+    sd = weights.make_aoa_state(seed=int(g["seed"]), vocab_size=int(g["V"]))
+    eng = AOAEngine(sd)
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    cap = torch.from_numpy(g["caption"]).view(1, -1)
+    return g, sd, eng, img, cap
+
+
+@pytest.mark.parametrize("head", [0, 5])
+def test_aoa_vs_reference(case, head):
+    g, sd, eng, img, cap = case
+    maps, r_words, r_feat, tr, enc = eng.explain_batch(cap, head, images=img, accumulate=True, return_features=True)
+    maps, r_words, r_feat = maps.cpu(), r_words.cpu(), r_feat.cpu()
+    assert rel_err(tr["alpha"][0].cpu(), g["tr_alphas"]) < 1e-4
+    assert rel_err(tr["h"][0].cpu(), g["tr_ht"]) < 1e-4
+    assert rel_err(tr["ctx"][0].cpu(), g["tr_context"]) < 1e-4
+    for t in range(3):
+        want = torch.from_numpy(g[f"h{head}_r_feat_{t}"])[0].reshape(512, 196).t()
+        assert rel_err(r_feat[0, t], want) < TOL, t
+        assert cosine(r_feat[0, t], want) > 0.99999
+        assert np.abs(r_words[0, t, :t + 1].numpy() - g[f"h{head}_r_words_{t}"]).max() < 1e-5
+        assert_close_modulo_pool_ties(maps[0, t][None, :, ::4, ::4], g[f"h{head}_map_sub4_{t}"], what=(head, t))
+    if f"h{head}_map_full_2" in g:
+        assert_close_modulo_pool_ties(maps[0, 2], g[f"h{head}_map_full_2"][0], what="full")
+
+
+def test_aoa_bottom_up_regions_vs_reference():
+    """config 5: (36,2048) bottom-up features, relevance back to the region features (no CNN stage)."""
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    g = np.load(os.path.join(GOLDEN, "aoa_bu_T3.npz"))
+    sd = weights.make_aoa_state(seed=int(g["seed"]), vocab_size=int(g["V"]), feat_dim=2048, with_encoder=False)
+    eng = AOAEngine(sd)
+    feats = torch.from_numpy(weights.make_bu_features(int(g["seed"]), 1))
+    cap = torch.from_numpy(g["caption"]).view(1, -1)
+    r_feat, r_words = eng.explain_batch(cap, int(g["head"]), features=feats)
+    for t in range(3):
+        assert rel_err(r_feat[0, t].cpu(), g[f"r_feat_{t}"]) < TOL
+        # r_words = sum of 512 signed embedding relevances / max (cancellation ~1e2): device expf/tanhf vs glibc
+        # rounding shows up at 1.4e-5 here, so the GPU bound is 5e-5 (CPU oracle vs reference stays < 1e-5)
+        assert np.abs(r_words[0, t, :t + 1].cpu().numpy() - g[f"r_words_{t}"]).max() < 5e-5
+    with pytest.raises(ValueError):
+        eng.encode(images=torch.zeros(1, 3, 224, 224))
+
+
+def test_aoa_batch_vs_oracle():
+    """B=3 images, T=4, head 2: decoder relevance of every row against the per-image oracle."""
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    from oracle import lrp_oracle as O
+    V = 401
+    sd = weights.make_aoa_state(seed=9, vocab_size=V)
+    sdt = O.state_to_torch(sd)
+    eng = AOAEngine(sd)
+    img = torch.from_numpy(weights.make_images(13, 3))
+    cap = torch.from_numpy(weights.make_captions(14, 3, 4, V))
+    maps, r_words, r_feat, tr, enc = eng.explain_batch(cap, 2, images=img, return_features=True)
+    for b in range(3):
+        w_maps, w_rw, w_rf, _ = O.aoa_explain_caption(sdt, img[b:b + 1], cap[b].numpy(), 2, return_feat=True, accumulate=False)
+        for t in range(4):
+            want = w_rf[t][0].reshape(512, 196).t()
+            assert rel_err(r_feat[b, t].cpu(), want) < 2e-4, (b, t)
+            assert np.abs(r_words[b, t, :t + 1].cpu().numpy() - w_rw[t].numpy()).max() < 1e-4
+            assert_close_modulo_pool_ties(maps[b, t].cpu(), w_maps[t][0], what=(b, t))
