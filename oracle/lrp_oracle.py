@@ -321,11 +321,134 @@ def gridtd_explain_wordt(sd, tr, t):
 # ----------------------------------------------------------------------------------------------
 # gridTD guided-backprop decoder (models/gridTDmodel.py:1214-1422 trace, :1588-1675 backward)
 # ----------------------------------------------------------------------------------------------
+def _lstm_cell_full(x, h, c, w_ih, w_hh, bias):
+    """models/gridTDmodel.py:1248-1274: LSTM cell returning all four gate activations."""
+    z = w_ih @ x + w_hh @ h + bias
+    zi, zf, zg, zo = z.chunk(4)
+    i, f, g, o = torch.sigmoid(zi), torch.sigmoid(zf), torch.tanh(zg), torch.sigmoid(zo)
+    c2 = f * c + i * g
+    return o * torch.tanh(c2), c2, i, f, g, o
+
+
 def gridtd_grad_trace(sd, features, avg, caption):
     """models/gridTDmodel.py:1323-1422: the gradient explainers' trace.  Unlike the LRP trace the
     LanguageLSTM bias is correct here (bias_ih + bias_hh, :1262-1274) and all four gate
-    activations are kept."""
-    raise NotImplementedError("filled in with the guided-backprop row (SURVEY §8(a) GB1-GB3)")
+    activations plus the sentinel gate are kept."""
+    Hd = sd["fc.weight"].shape[1]
+    C, hh, ww = features.shape
+    P = hh * ww
+    T = len(caption) - 1
+    F_pix = features.reshape(C, P).t().contiguous()
+    w_proj = sd["img_projector.weight"].reshape(Hd, C)
+    Vp = F.relu(F_pix @ w_proj.t() + sd["img_projector.bias"])
+    glob = F.relu(sd["global_img_feature_proj.weight"] @ avg + sd["global_img_feature_proj.bias"])
+    a_wi, a_wh = sd["AdaLSTM.lstm_cell.weight_ih"], sd["AdaLSTM.lstm_cell.weight_hh"]
+    a_b = sd["AdaLSTM.lstm_cell.bias_hh"] + sd["AdaLSTM.lstm_cell.bias_ih"]
+    l_wi, l_wh = sd["LanguageLSTM.weight_ih"], sd["LanguageLSTM.weight_hh"]
+    l_b = sd["LanguageLSTM.bias_hh"] + sd["LanguageLSTM.bias_ih"]
+    tr = dict(T=T, P=P, F_pix=F_pix, Vp=Vp, glob=glob, caption=list(int(c) for c in caption))
+    z = lambda *s: torch.zeros(*s)
+    for k in ("h1", "c1", "h2", "c2"):
+        tr[k] = z(T + 1, Hd)
+    for k in ("i1", "f1", "g1", "o1", "i2", "f2", "g2", "o2", "s", "sen_gate", "ctx", "ctx_hat"):
+        tr[k] = z(T, Hd)
+    tr["alpha"], tr["beta"] = z(T, P), z(T)
+    tr["pred"] = z(T, sd["fc.weight"].shape[0])
+    for t in range(T):
+        emb = sd["embedding.weight"][caption[t]]
+        x1 = torch.cat([tr["h2"][t], glob, emb])
+        h1, c1, i1, f1, g1, o1 = _lstm_cell_full(x1, tr["h1"][t], tr["c1"][t], a_wi, a_wh, a_b)
+        gate = torch.sigmoid(sd["AdaLSTM.x_gate.weight"] @ x1 + sd["AdaLSTM.x_gate.bias"]
+                             + sd["AdaLSTM.h_gate.weight"] @ tr["h1"][t] + sd["AdaLSTM.h_gate.bias"])
+        s = gate * torch.tanh(c1)
+        ctx_hat, ctx, alpha, beta = _adaptive_attention(sd, Vp, h1, s)
+        x2 = torch.cat([ctx_hat, h1])
+        h2, c2, i2, f2, g2, o2 = _lstm_cell_full(x2, tr["h2"][t], tr["c2"][t], l_wi, l_wh, l_b)
+        tr["pred"][t] = sd["fc.weight"] @ (ctx_hat + h2) + sd["fc.bias"]
+        tr["h1"][t + 1], tr["c1"][t + 1], tr["h2"][t + 1], tr["c2"][t + 1] = h1, c1, h2, c2
+        for k, v in dict(i1=i1, f1=f1, g1=g1, o1=o1, i2=i2, f2=f2, g2=g2, o2=o2, s=s, sen_gate=gate, ctx=ctx,
+                         ctx_hat=ctx_hat, alpha=alpha).items():
+            tr[k][t] = v
+        tr["beta"][t] = beta
+    return tr
+
+
+def gridtd_guided_wordt(sd, tr, t):
+    """models/gridTDmodel.py:1588-1675 `ExplainiGridTDGuidedGradient.explain_caption_wordt`: hand-written BPTT with
+    alpha / beta treated as constants.  Quirks kept: `d_h1[i]` from the AdaLSTM recurrence is overwritten by
+    :1646 (no h1 recurrence), the sentinel gate's own inputs get no gradient, and the two projector 'ReLU gates'
+    test `< 0` on post-ReLU tensors (:1663, :1665), i.e. never fire; only `features <= 0` (:1674) does.
+    Returns (d_feat (P,C), r_words (t+1,))."""
+    Hd = tr["h1"].shape[1]
+    P = tr["P"]
+    k = tr["caption"][t + 1]
+    E = sd["embedding.weight"].shape[1]
+    a_wi, a_wh = sd["AdaLSTM.lstm_cell.weight_ih"], sd["AdaLSTM.lstm_cell.weight_hh"]
+    l_wi, l_wh = sd["LanguageLSTM.weight_ih"], sd["LanguageLSTM.weight_hh"]
+    n = t + 1
+    d_h1, d_c1 = torch.zeros(n + 1, Hd), torch.zeros(n + 1, Hd)
+    d_h2, d_c2 = torch.zeros(n + 1, Hd), torch.zeros(n + 1, Hd)
+    d_ch = torch.zeros(n, Hd)
+    d_glob, d_emb, d_proj = torch.zeros(E), torch.zeros(n, E), torch.zeros(P, Hd)
+    d_hc = sd["fc.weight"][k].clone()
+    d_ch[t] = d_hc
+    d_h2[t + 1] = d_hc
+    for i in range(t, -1, -1):
+        tc2 = torch.tanh(tr["c2"][i + 1])
+        d_o2a = d_h2[i + 1] * tc2
+        d_c2[i + 1] = d_c2[i + 1] + d_h2[i + 1] * tr["o2"][i] * (1 - tc2 ** 2)
+        d_f2a = d_c2[i + 1] * tr["c2"][i]
+        d_c2[i] = d_c2[i + 1] * tr["f2"][i]
+        d_i2a, d_g2a = d_c2[i + 1] * tr["g2"][i], d_c2[i + 1] * tr["i2"][i]
+        gates2 = torch.cat([d_i2a * tr["i2"][i] * (1 - tr["i2"][i]), d_f2a * tr["f2"][i] * (1 - tr["f2"][i]),
+                            d_g2a * (1 - tr["g2"][i] ** 2), d_o2a * tr["o2"][i] * (1 - tr["o2"][i])])
+        d_h2[i] = gates2 @ l_wh
+        d_x2 = gates2 @ l_wi
+        d_ch[i] = d_ch[i] + d_x2[:Hd]
+        d_ctx = d_ch[i] * (1 - tr["beta"][i])
+        d_proj = d_proj + d_ctx.unsqueeze(0) * tr["alpha"][i].unsqueeze(1)
+        d_s = d_ch[i] * tr["beta"][i]
+        tc1 = torch.tanh(tr["c1"][i + 1])
+        d_c1[i + 1] = d_c1[i + 1] + d_s * tr["sen_gate"][i] * (1 - tc1 ** 2)
+        d_h1[i + 1] = d_x2[Hd:]
+        d_o1a = d_h1[i + 1] * tc1
+        d_c1[i + 1] = d_c1[i + 1] + d_h1[i + 1] * tr["o1"][i] * (1 - tc1 ** 2)
+        d_f1a = d_c1[i + 1] * tr["c1"][i]
+        d_c1[i] = d_c1[i + 1] * tr["f1"][i]
+        d_i1a, d_g1a = d_c1[i + 1] * tr["g1"][i], d_c1[i + 1] * tr["i1"][i]
+        gates1 = torch.cat([d_i1a * tr["i1"][i] * (1 - tr["i1"][i]), d_f1a * tr["f1"][i] * (1 - tr["f1"][i]),
+                            d_g1a * (1 - tr["g1"][i] ** 2), d_o1a * tr["o1"][i] * (1 - tr["o1"][i])])
+        d_h1[i] = gates1 @ a_wh                 # dead: overwritten by :1646 in the next iteration
+        d_x1 = gates1 @ a_wi
+        d_glob = d_glob + d_x1[Hd:Hd + E]
+        d_emb[i] = d_x1[Hd + E:]
+        d_h2[i] = d_h2[i] + d_x1[:Hd]
+    d_avg = d_glob @ sd["global_img_feature_proj.weight"]
+    w_proj = sd["img_projector.weight"].reshape(Hd, -1)
+    d_feat = d_avg.unsqueeze(0) / P + d_proj @ w_proj
+    d_feat = d_feat * (tr["F_pix"] > 0).float()          # :1674
+    r_words = d_emb.sum(-1)
+    m = r_words.abs().max()
+    if m > 0:
+        r_words = r_words / m
+    return d_feat, r_words
+
+
+def gridtd_guided_explain_caption(sd, img, caption, words=None, return_feat=False):
+    """`ExplainiGridTDGuidedGradient.explain_caption` (:1525-1539 inherited + explain_cnn :1702-1723); the image
+    gradient is zeroed after every word (:1717), so these maps are NOT running sums."""
+    feats, avg, saved = vgg_forward(sd, img)
+    tr = gridtd_grad_trace(sd, feats[0], avg[0], caption)
+    maps, rws, dfs = [], [], []
+    for t in (range(tr["T"]) if words is None else words):
+        d_feat, r_words = gridtd_guided_wordt(sd, tr, t)
+        d_feat = pix_to_nchw(d_feat, feats.shape[-2:])
+        dfs.append(d_feat)
+        maps.append(vgg_guided_backprop(sd, saved, d_feat))
+        rws.append(r_words)
+    if return_feat:
+        return maps, rws, dfs, tr
+    return maps, rws
 
 
 # ----------------------------------------------------------------------------------------------

@@ -274,6 +274,46 @@ def gen_aoa_bu(out, weights, T=3, V=11027, seed=0, head=0):
     print("aoa_bu_T3.npz written")
 
 
+def gen_guided(out, weights, T=3, V=9586, seed=0):
+    """ExplainiGridTDGuidedGradient (models/gridTDmodel.py:1585-1723): guided backprop maps + word scores."""
+    import models.gridTDmodel as gtd
+    sd = weights.make_gridtd_state(seed=seed, vocab_size=V)
+    wm = weights.make_word_map(V)
+    img = weights.make_images(seed, 1)
+    cap = weights.make_captions(seed + 1, 1, T, V)[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        args = make_args(tmp)
+        # the class builds its own model and loads args.weight: feed it through a patched torch.load
+        real_load = torch.load
+        torch.load = lambda *a, **k: {"state_dict": to_torch_sd(sd)}
+        try:
+            ex = gtd.ExplainiGridTDGuidedGradient(args, wm)
+        finally:
+            torch.load = real_load
+        _patch_explainer(ex, img, cap)
+        feats = []
+        orig = ex.explain_caption_wordt
+
+        def wrapped(t):
+            rf, rw = orig(t)
+            feats.append(rf.clone())
+            return rf, rw
+        ex.explain_caption_wordt = wrapped
+        maps, rws = ex.explain_caption("synthetic.jpg")
+    g = dict(seed=np.int64(seed), V=np.int64(V), caption=cap)
+    for t in range(T):
+        g[f"d_feat_{t}"] = feats[t].detach().numpy()
+        g[f"r_words_{t}"] = rws[t].detach().numpy()
+        g[f"map_stats_{t}"] = stats(maps[t])
+        g[f"map_sub4_{t}"] = sub4(maps[t]).numpy()
+    g[f"map_full_{T - 1}"] = maps[T - 1].numpy()
+    g["tr_sen_gate"] = ex.sen_gate.detach().numpy()
+    g["tr_o2t_act"] = ex.o2t_act.detach().numpy()
+    g["tr_h2t"] = ex.h2t.detach().numpy()
+    np.savez(os.path.join(out, "guided_T3.npz"), **g)
+    print("guided_T3.npz written; map absmax:", [float(m.abs().max()) for m in maps])
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -292,7 +332,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -310,6 +350,8 @@ def main():
         gen_aoa_bu(HERE, weights)
     if "greedy" in todo:
         gen_greedy(HERE, weights)
+    if "guided" in todo:
+        gen_guided(HERE, weights)
 
 
 if __name__ == "__main__":

@@ -96,3 +96,19 @@ def test_greedy_tokens_bit_exact():
     img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
     toks = O.gridtd_model_greedy(sd, img, max_cap_length=len(g["tokens"]), start_id=V - 2, end_id=V - 1)
     assert toks == [int(x) for x in g["tokens"]]
+
+
+def test_guided_backprop_vs_reference():
+    # ExplainiGridTDGuidedGradient (models/gridTDmodel.py:1585-1723): decoder BPTT + guided backprop through VGG16
+    g = np.load(os.path.join(GOLDEN, "guided_T3.npz"))
+    sd = O.state_to_torch(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=int(g["V"])))
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    maps, rws, dfs, tr = O.gridtd_guided_explain_caption(sd, img, g["caption"], return_feat=True)
+    assert rel_err(tr["sen_gate"], g["tr_sen_gate"]) < 2e-5 and rel_err(tr["o2"], g["tr_o2t_act"]) < 2e-5
+    assert rel_err(tr["h2"], g["tr_h2t"]) < 2e-5
+    for t in range(3):
+        assert rel_err(dfs[t], g[f"d_feat_{t}"]) < TOL_REL
+        assert np.abs(rws[t].numpy() - g[f"r_words_{t}"]).max() < TOL_WORDS
+        scale = g[f"map_stats_{t}"][1]
+        assert np.abs(maps[t][..., ::4, ::4].numpy() - g[f"map_sub4_{t}"]).max() / scale < TOL_REL
+    assert rel_err(maps[2], g["map_full_2"]) < TOL_REL
