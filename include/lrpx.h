@@ -156,6 +156,8 @@ typedef struct lrpx_gridtd_trace {
     float *g1, *i1, *f1, *g2, *i2, *f2; /* [B][T][H]  g = pre-activation, i/f = activations (:1002-1009) */
     float *s, *ctx, *ctx_hat, *hc;      /* [B][T][H]  hc = h2[t+1] + ctx_hat[t] (fc input) */
     float *alpha, *beta;                /* [B][T][P], [B][T] */
+    float *o1, *o2, *sgate;             /* [B][T][H] output gates + sentinel gate: only the gradient explainers'
+                                           trace keeps them (models/gridTDmodel.py:1323-1422); may be null */
 } lrpx_gridtd_trace;
 /* per step t: build xh1 ; LSTM point-wise (which = 1 AdaLSTM incl. sentinel, 2 LanguageLSTM) ; adaptive attention */
 int lrpx_gridtd_fwd_pre(const lrpx_gridtd_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
@@ -215,6 +217,33 @@ int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, co
                        int head, float* a_val, void* stream);
 /* lock-step s: phase 0 g-gate split (:1116-1120) -> A ; phase 1 after the LSTM dense rule (:1129-1133) */
 int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int s, int phase, void* stream);
+
+/* ---- gridTD guided backprop, decoder side (ExplainiGridTDGuidedGradient.explain_caption_wordt,
+ *      models/gridTDmodel.py:1588-1675): BPTT with alpha/beta constant ------------------------------------ */
+typedef struct lrpx_gridtd_gradstate {
+    const int32_t* lens;
+    float *d_h2n, *d_c2, *d_c1, *d_ch0, *d_h2p; /* [B*T][H] */
+    float* d_glob;                      /* [B*T][E] */
+    float *gates, *dx;                  /* gate-gradient rows [B*T][4H] (GEMM input) / GEMM output [B*T][3H] */
+    float* wacc;                        /* [B*T][T][H]  d_context per time step */
+    float* r_words;                     /* [B*T][T] */
+} lrpx_gridtd_gradstate;
+int lrpx_gridtd_grad_init(const lrpx_gridtd_trace* tr, const lrpx_gridtd_gradstate* gs, const float* fcw,
+                          const long long* tok, int tok_ld, void* stream);
+/* phase 0: LanguageLSTM cell backward -> gates ; 1: after gates @ [W_ih|W_hh] -> AdaLSTM cell backward -> gates ;
+ * 2: after gates @ W_ih of the AdaLSTM */
+int lrpx_gridtd_grad_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_gradstate* gs, int s, int phase, void* stream);
+/* a_proj[row][k][:] = sum_{i<=t} alpha[b][i][k] * wacc[row][i][:]   (:1642-1643) */
+int lrpx_spread_pixels(const float* wacc, const float* alpha, const int32_t* lens, float* a_proj, int B, int T, int H,
+                       int P, void* stream);
+int lrpx_scale(const float* x, float* y, long n, float alpha, void* stream);
+int lrpx_positive_mask(const float* x, float* y, long n, void* stream);   /* y = [x > 0]  (:1674) */
+
+/* ---- VGG16 guided backprop (explain_cnn, models/gridTDmodel.py:1677-1723) ------------------------------ */
+/* d_feat (N,196,512) NHWC gradient at the encoder output -> (N,3,224,224) NCHW image gradient with the guided
+ * ReLU rule clamp(g,min=0)*[relu_out>0] at every ReLU.  Same trace / workspace as lrpx_vgg16_relevance. */
+int lrpx_vgg16_guided_backprop(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                               const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,12 @@ _sz = C.c_size_t
 class GridTrace(C.Structure):
     _fields_ = [("B", _i), ("T", _i), ("H", _i), ("E", _i), ("P", _i)] + [(k, _f) for k in (
         "xh1", "xh2", "h1", "c1", "h2", "c2", "g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat", "hc",
-        "alpha", "beta")]
+        "alpha", "beta", "o1", "o2", "sgate")]
+
+
+class GridGradState(C.Structure):
+    _fields_ = [(k, _f) for k in ("lens", "d_h2n", "d_c2", "d_c1", "d_ch0", "d_h2p", "d_glob", "gates", "dx", "wacc",
+                                  "r_words")]
 
 
 class GridRelState(C.Structure):
@@ -87,6 +92,12 @@ SIGNATURES = {
     "lrpx_aoa_rel_init": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _f, _i, _f]),
     "lrpx_aoa_rel_value": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _i, _f, _f]),
     "lrpx_aoa_rel_step": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _i, _i, _f]),
+    "lrpx_gridtd_grad_init": (_i, [C.POINTER(GridTrace), C.POINTER(GridGradState), _f, _f, _i, _f]),
+    "lrpx_gridtd_grad_step": (_i, [C.POINTER(GridTrace), C.POINTER(GridGradState), _i, _i, _f]),
+    "lrpx_spread_pixels": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_scale": (_i, [_f, _f, _l, C.c_float, _f]),
+    "lrpx_positive_mask": (_i, [_f, _f, _l, _f]),
+    "lrpx_vgg16_guided_backprop": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, _f]),
     "lrpx_vgg16_packed_bytes": (_sz, []),
     "lrpx_vgg16_trace_bytes": (_sz, [_i]),
     "lrpx_vgg16_workspace_bytes": (_sz, [_i]),

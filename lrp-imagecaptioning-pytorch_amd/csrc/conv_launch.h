@@ -43,8 +43,17 @@ int launch_conv_28_16_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
 int launch_conv_28_16_1_4_9_rel(const ConvArgs& a, hipStream_t s);
 int launch_conv_14_16_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
 int launch_conv_14_16_1_4_9_rel(const ConvArgs& a, hipStream_t s);
+int launch_conv_224_8_4_2_9_guided(const ConvArgs& a, hipStream_t s);
 int launch_conv_14_32_1_4_1_rel(const ConvArgs& a, hipStream_t s);
 int launch_conv_14_32_1_4_1_plain(const ConvArgs& a, hipStream_t s);
+int launch_conv_112_8_1_4_9_guided(const ConvArgs& a, hipStream_t s);
+int launch_conv_112_8_2_2_9_plain(const ConvArgs& a, hipStream_t s);
+int launch_conv_56_16_1_4_9_guided(const ConvArgs& a, hipStream_t s);
+int launch_conv_56_16_1_4_9_plain(const ConvArgs& a, hipStream_t s);
+int launch_conv_28_16_1_4_9_guided(const ConvArgs& a, hipStream_t s);
+int launch_conv_28_16_1_4_9_plain(const ConvArgs& a, hipStream_t s);
+int launch_conv_14_16_1_4_9_guided(const ConvArgs& a, hipStream_t s);
+int launch_conv_14_16_1_4_9_plain(const ConvArgs& a, hipStream_t s);
 
 // host-side entry used by the C ABI and by the VGG16 / decoder chains
 int conv_dispatch(const lrpx_conv_desc* d, hipStream_t stream);

@@ -13,7 +13,7 @@ constexpr int FL_TH = 8, FL_TW = 32, FL_KC = 16, FL_STRIDE = FL_KC + 4;
 constexpr int FL_HP = FL_TH + 2, FL_WP = FL_TW + 2;
 
 // w6: [chunk 4][tap 9][ch 16][6] = {W+ for c=0..2, W- for c=0..2} with the kernel flipped (transposed conv)
-__global__ void pack_first_layer_kernel(const float* __restrict__ w, float* __restrict__ w6, int cout) {
+__global__ void pack_first_layer_kernel(const float* __restrict__ w, float* __restrict__ w6, int cout, int plain) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over cout*9*6
     if (idx >= cout * 9 * 6) return;
     const int o = idx % 6;
@@ -23,13 +23,14 @@ __global__ void pack_first_layer_kernel(const float* __restrict__ w, float* __re
     const int chunk = r / 9;
     const int co = chunk * FL_KC + ch, c = o % 3;
     const float x = w[((long)co * 3 + c) * 9 + (8 - tap)];
-    w6[idx] = o < 3 ? fmaxf(x, 0.f) : fminf(x, 0.f);
+    if (plain) w6[idx] = o < 3 ? x : 0.f;      // plain transposed conv (guided backprop): second triple unused
+    else w6[idx] = o < 3 ? fmaxf(x, 0.f) : fminf(x, 0.f);
 }
 
 __global__ __launch_bounds__(256) void first_layer_rel_kernel(const float* __restrict__ S, const float* __restrict__ w6,
                                                               const float* __restrict__ X8,
                                                               const int* __restrict__ map2img, float* __restrict__ out,
-                                                              int cin) {
+                                                              int cin, int plain) {
     constexpr int HW = 224;
     __shared__ __attribute__((aligned(16))) float lds[FL_HP * FL_WP * FL_STRIDE];
     const int n = blockIdx.z, ty0 = blockIdx.y * FL_TH, tx0 = blockIdx.x * FL_TW;
@@ -69,6 +70,11 @@ __global__ __launch_bounds__(256) void first_layer_rel_kernel(const float* __res
     const int y = ty0 + ly, x = tx0 + lx;
     const long img = map2img ? map2img[n] : n;
     const long p = (long)y * HW + x;
+    if (plain) {     // image gradient: no input multiplication
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((long)n * 3 + c) * HW * HW + p] = acc[c];
+        return;
+    }
     const float* xp = X8 + (img * HW * HW + p) * 8;          // [x+ (3) | x- (3) | 0 0]
     const f32x4 xa = *reinterpret_cast<const f32x4*>(xp), xb = *reinterpret_cast<const f32x4*>(xp + 4);
     const float xpos[3] = {xa[0], xa[1], xa[2]}, xneg[3] = {xa[3], xb[0], xb[1]};
@@ -76,15 +82,15 @@ __global__ __launch_bounds__(256) void first_layer_rel_kernel(const float* __res
     for (int c = 0; c < 3; ++c) out[((long)n * 3 + c) * HW * HW + p] = xpos[c] * acc[c] + xneg[c] * acc[3 + c];
 }
 
-int first_layer_pack(const float* w, float* w6, int cout, hipStream_t s) {
-    hipLaunchKernelGGL(pack_first_layer_kernel, dim3((cout * 54 + 255) / 256), dim3(256), 0, s, w, w6, cout);
+int first_layer_pack(const float* w, float* w6, int cout, int plain, hipStream_t s) {
+    hipLaunchKernelGGL(pack_first_layer_kernel, dim3((cout * 54 + 255) / 256), dim3(256), 0, s, w, w6, cout, plain);
     return check_launch("pack_first_layer");
 }
 
 int first_layer_relevance(const float* S, const float* w6, const float* X8, const int* map2img, float* out, int n_maps,
-                          int cin, hipStream_t s) {
+                          int cin, int plain, hipStream_t s) {
     hipLaunchKernelGGL(first_layer_rel_kernel, dim3(224 / FL_TW, 224 / FL_TH, n_maps), dim3(256), 0, s, S, w6, X8,
-                       map2img, out, cin);
+                       map2img, out, cin, plain);
     return check_launch("first_layer_relevance");
 }
 

@@ -227,6 +227,53 @@ __global__ void cumsum_maps_kernel(const float* __restrict__ in, float* __restri
     }
 }
 
+// top ReLU hook of the guided pass: out = max(g,0) * [y > 0]   (models/gridTDmodel.py:1680-1686)
+__global__ void guided_gate_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                   const int* __restrict__ map2img, float* __restrict__ out, long per4, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 units over n_maps*per4
+    if (idx >= total) return;
+    long n = idx / per4, i = idx - n * per4;
+    long img = map2img ? map2img[n] : n;
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[idx];
+    f32x4 yv = reinterpret_cast<const f32x4*>(y)[img * per4 + i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (yv[e] > 0.f && gv[e] > 0.f) ? gv[e] : 0.f;
+    reinterpret_cast<f32x4*>(out)[idx] = o;
+}
+
+// max_pool2d backward (gradient to the arg-max, first maximum wins) followed by the guided ReLU hook of the conv
+// below: out = [this pixel is the window's arg-max and a > 0] * max(g, 0)
+__global__ void maxpool_guided_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g_out,
+                                          const int* __restrict__ map2img, float* __restrict__ g_in, int ho, int wo,
+                                          int c4, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n_maps*(2ho)*(2wo)*c4
+    if (idx >= total) return;
+    int cc = idx % c4;
+    long r = idx / c4;
+    const int wi = 2 * wo, hi = 2 * ho;
+    int xi = r % wi; r /= wi;
+    int yi = r % hi;
+    long n = r / hi;
+    long img = map2img ? map2img[n] : n;
+    const int yo = yi >> 1, xo = xi >> 1;
+    const int pos = (yi & 1) * 2 + (xi & 1);
+    const f32x4* xb = reinterpret_cast<const f32x4*>(x) + ((img * hi + 2 * yo) * wi + 2 * xo) * c4 + cc;
+    f32x4 w4[4] = {xb[0], xb[c4], xb[(long)wi * c4], xb[(long)wi * c4 + c4]};
+    f32x4 go = reinterpret_cast<const f32x4*>(g_out)[((n * ho + yo) * wo + xo) * c4 + cc];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float m = w4[0][e];
+        int am = 0;
+        if (w4[1][e] > m) { m = w4[1][e]; am = 1; }
+        if (w4[2][e] > m) { m = w4[2][e]; am = 2; }
+        if (w4[3][e] > m) { m = w4[3][e]; am = 3; }
+        o[e] = (am == pos && m > 0.f && go[e] > 0.f) ? go[e] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(g_in)[idx] = o;
+}
+
 __global__ void accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, long n4) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n4) return;
@@ -340,6 +387,23 @@ int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long
                        t_per_img, per / 4, total);
     return check_launch("cumsum_maps");
 }
+
+extern "C++" {
+namespace lrpx {
+int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, hipStream_t s) {
+    long total = (long)n_maps * (per / 4);
+    hipLaunchKernelGGL(guided_gate_kernel, dim3(grid_for(total)), dim3(256), 0, s, g, y, map2img, out, per / 4, total);
+    return check_launch("guided_gate");
+}
+int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
+                       int c, hipStream_t s) {
+    long total = (long)n_maps * (2 * ho) * (2 * wo) * (c / 4);
+    hipLaunchKernelGGL(maxpool_guided_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, g_out, map2img, g_in, ho,
+                       wo, c / 4, total);
+    return check_launch("maxpool_guided_bwd");
+}
+}  // namespace lrpx
+}  // extern "C++"
 
 int lrpx_accumulate(float* dst, const float* src, long n, void* stream) {
     LRPX_REQUIRE(dst && src && n > 0 && n % 4 == 0, "accumulate: bad arguments");

@@ -123,6 +123,7 @@ struct GridFwd {
     float *g1, *i1, *f1, *g2, *i2, *f2;   // [B][T][H]
     float *s, *ctx, *ctx_hat, *hc;        // [B][T][H]
     float *alpha, *beta;                  // [B][T][P], [B][T]
+    float *o1, *o2, *sgate;               // [B][T][H] output gates / sentinel gate (gradient explainers only; may be null)
 };
 
 // xh1[b,t] = [h2[b,t] | glob[b] | emb[tok[b,t]] | h1[b,t]]
@@ -158,8 +159,15 @@ __global__ void gridtd_fwd_lstm_kernel(GridFwd g, int t, const float* __restrict
         const float hn = o * tanhf(cn);
         cc[st1 + c] = cn; hh[st1 + c] = hn;
         gg[tr + c] = zg; ii[tr + c] = i; ff[tr + c] = f;
-        if (which == 1) g.s[tr + c] = sigmoidf_(z[4 * H + c]) * tanhf(cn);
-        else g.hc[tr + c] = hn + g.ctx_hat[tr + c];           // fc input (:990)
+        float* oo = which == 1 ? g.o1 : g.o2;
+        if (oo) oo[tr + c] = o;
+        if (which == 1) {
+            const float sg = sigmoidf_(z[4 * H + c]);
+            g.s[tr + c] = sg * tanhf(cn);
+            if (g.sgate) g.sgate[tr + c] = sg;
+        } else {
+            g.hc[tr + c] = hn + g.ctx_hat[tr + c];           // fc input (:990)
+        }
     }
 }
 
@@ -431,6 +439,143 @@ __global__ void rel_words_norm_kernel(float* __restrict__ r_words, int rows, int
 
 
 // ================================================================================================
+// gridTD guided-backprop decoder: hand-written BPTT with alpha/beta constant (models/gridTDmodel.py:1588-1675)
+// ================================================================================================
+struct GridGrad {
+    int B, T, H, E, P;
+    const int* lens;
+    const float *c1, *c2, *g1, *i1, *f1, *o1, *g2, *i2, *f2, *o2, *sgate, *beta;   // g* are pre-activations
+    float *d_h2n, *d_c2, *d_c1, *d_ch0, *d_h2p, *d_glob;    // [rows][H] (d_glob: [rows][E])
+    float *gates, *dx;                                       // GEMM in [rows][4H], out [rows][3H]
+    float *wacc, *r_words;                                   // [rows][T][H], [rows][T]
+};
+
+__device__ __forceinline__ bool grad_row_active(const GridGrad& g, int b, int t, int s) {
+    const int len = g.lens ? g.lens[b] : g.T;
+    return t < len && t >= s;
+}
+
+// :1592-1625  d_word_pred one-hot = 1  ->  d(h2+ctx_hat) = fc.weight[k]
+__global__ void gridtd_grad_init_kernel(GridGrad g, const float* __restrict__ fcw, const long long* __restrict__ tok,
+                                        int tok_ld) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    const long long k = tok[(long)b * tok_ld + t + 1];
+    const long tr = (long)row * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float d = fcw[k * H + c];
+        g.d_h2n[tr + c] = d; g.d_ch0[tr + c] = d; g.d_c2[tr + c] = 0.f; g.d_c1[tr + c] = 0.f;
+    }
+    for (int c = threadIdx.x; c < g.E; c += blockDim.x) g.d_glob[(long)row * g.E + c] = 0.f;
+    for (int c = threadIdx.x; c < g.T; c += blockDim.x) g.r_words[(long)row * g.T + c] = 0.f;
+}
+
+// LSTM cell backward (:1627-1637 / :1647-1657): dh, running dc -> gate pre-activation gradients [i|f|g|o]
+__device__ __forceinline__ void lstm_cell_bwd(float dh, float& dc, float c_new, float c_old, float i, float f, float gpre,
+                                              float o, float* gates, int H, int c) {
+    const float tc = tanhf(c_new), ga = tanhf(gpre);
+    const float d_oa = dh * tc;
+    dc = dc + dh * o * (1.f - tc * tc);
+    const float d_fa = dc * c_old, d_ia = dc * ga, d_ga = dc * i;
+    gates[c] = d_ia * i * (1.f - i);
+    gates[H + c] = d_fa * f * (1.f - f);
+    gates[2 * H + c] = d_ga * (1.f - ga * ga);
+    gates[3 * H + c] = d_oa * o * (1.f - o);
+    dc = dc * f;      // d_c[i] = d_c[i+1] * f   (:1630 / :1650)
+}
+
+__global__ void gridtd_grad_a_kernel(GridGrad g, int s) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    float* gates = g.gates + (long)row * 4 * H;
+    if (!grad_row_active(g, b, t, s)) {
+        for (int c = threadIdx.x; c < 4 * H; c += blockDim.x) gates[c] = 0.f;
+        return;
+    }
+    const int i = t - s;
+    const long tr = (long)row * H, ti = ((long)b * g.T + i) * H, sc1 = ((long)b * (g.T + 1) + i + 1) * H, sc0 = sc1 - H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float dc = g.d_c2[tr + c];
+        lstm_cell_bwd(g.d_h2n[tr + c], dc, g.c2[sc1 + c], g.c2[sc0 + c], g.i2[ti + c], g.f2[ti + c], g.g2[ti + c],
+                      g.o2[ti + c], gates, H, c);
+        g.d_c2[tr + c] = dc;
+    }
+}
+
+// dx = gates2 @ [W_ih | W_hh] = [d_ctx_hat | d_h1 | d_h2]   (:1638-1646), then the AdaLSTM cell backward
+__global__ void gridtd_grad_b_kernel(GridGrad g, int s) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    float* gates = g.gates + (long)row * 4 * H;
+    if (!grad_row_active(g, b, t, s)) {
+        for (int c = threadIdx.x; c < 4 * H; c += blockDim.x) gates[c] = 0.f;
+        return;
+    }
+    const int i = t - s;
+    const long tr = (long)row * H, ti = ((long)b * g.T + i) * H, sc1 = ((long)b * (g.T + 1) + i + 1) * H, sc0 = sc1 - H;
+    const float* dx = g.dx + (long)row * 3 * H;
+    const float beta = g.beta[(long)b * g.T + i];
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        g.d_h2p[tr + c] = dx[2 * H + c];                                    // :1638
+        const float d_ch = (s == 0 ? g.d_ch0[tr + c] : 0.f) + dx[c];        // :1640
+        g.wacc[((long)row * g.T + i) * H + c] = d_ch * (1.f - beta);        // d_context (:1641), spread in rel_pix
+        const float d_s = d_ch * beta;                                      // :1644
+        const float tc1 = tanhf(g.c1[sc1 + c]);
+        float dc = g.d_c1[tr + c] + d_s * g.sgate[ti + c] * (1.f - tc1 * tc1);   // :1645
+        lstm_cell_bwd(dx[H + c], dc, g.c1[sc1 + c], g.c1[sc0 + c], g.i1[ti + c], g.f1[ti + c], g.g1[ti + c],
+                      g.o1[ti + c], gates, H, c);                           // :1646-1657
+        g.d_c1[tr + c] = dc;
+    }
+}
+
+// dx = gates1 @ W_ih = [d_h2 | d_glob | d_emb]  (:1659-1662)
+__global__ __launch_bounds__(256) void gridtd_grad_c_kernel(GridGrad g, int s) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, E = g.E;
+    if (!grad_row_active(g, b, t, s)) return;
+    const int i = t - s;
+    const long tr = (long)row * H;
+    const float* dx = g.dx + (long)row * 3 * H;      // row stride of the GEMM output buffer (H + 2E == 3H)
+    for (int c = threadIdx.x; c < H; c += 256) g.d_h2n[tr + c] = g.d_h2p[tr + c] + dx[c];
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < E; c += 256) {
+        g.d_glob[(long)row * E + c] += dx[H + c];
+        acc += dx[H + E + c];
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) g.r_words[(long)row * g.T + i] = acc;
+}
+
+// Aproj[row][k][c] = sum_{i<=t} alpha[b][i][k] * wacc[row][i][c]   (:1642-1643 summed over i)
+__global__ __launch_bounds__(256) void spread_pixels_kernel(const float* __restrict__ wacc, const float* __restrict__ alpha,
+                                                            const int* __restrict__ lens, float* __restrict__ Aproj,
+                                                            int T, int H, int P, int kchunk) {
+    const int row = blockIdx.x, b = row / T, t = row - b * T;
+    const int len = lens ? lens[b] : T;
+    const int k0 = blockIdx.y * kchunk, k1 = min(k0 + kchunk, P);
+    extern __shared__ float al[];
+    const int n = t < len ? t + 1 : 0;
+    for (int j = threadIdx.x; j < n * kchunk; j += 256) {
+        const int i = j / kchunk, kk = j - i * kchunk;
+        al[j] = (k0 + kk < P) ? alpha[((long)b * T + i) * P + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256)
+        for (int k = k0; k < k1; ++k) {
+            float a = 0.f;
+            for (int i = n - 1; i >= 0; --i) a += al[i * kchunk + (k - k0)] * wacc[((long)row * T + i) * H + c];
+            Aproj[((long)row * P + k) * H + c] = a;
+        }
+}
+
+__global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float alpha) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * alpha;
+}
+
+__global__ void positive_mask_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] > 0.f ? 1.f : 0.f;
+}
+
+// ================================================================================================
 // AoA decoder (models/aoamodel.py): trace :990-1062, relevance :1064-1156
 // ================================================================================================
 struct AoaFwd {
@@ -644,6 +789,7 @@ static GridFwd to_fwd(const lrpx_gridtd_trace* t) {
     g.xh1 = t->xh1; g.xh2 = t->xh2; g.h1 = t->h1; g.c1 = t->c1; g.h2 = t->h2; g.c2 = t->c2;
     g.g1 = t->g1; g.i1 = t->i1; g.f1 = t->f1; g.g2 = t->g2; g.i2 = t->i2; g.f2 = t->f2;
     g.s = t->s; g.ctx = t->ctx; g.ctx_hat = t->ctx_hat; g.hc = t->hc; g.alpha = t->alpha; g.beta = t->beta;
+    g.o1 = t->o1; g.o2 = t->o2; g.sgate = t->sgate;
     return g;
 }
 
@@ -761,6 +907,66 @@ int lrpx_rel_words_norm(float* r_words, int rows, int T, void* stream) {
     return check_launch("rel_words_norm");
 }
 
+
+static GridGrad to_grad(const lrpx_gridtd_trace* t, const lrpx_gridtd_gradstate* r) {
+    GridGrad g;
+    g.B = t->B; g.T = t->T; g.H = t->H; g.E = t->E; g.P = t->P; g.lens = r->lens;
+    g.c1 = t->c1; g.c2 = t->c2; g.g1 = t->g1; g.i1 = t->i1; g.f1 = t->f1; g.o1 = t->o1;
+    g.g2 = t->g2; g.i2 = t->i2; g.f2 = t->f2; g.o2 = t->o2; g.sgate = t->sgate; g.beta = t->beta;
+    g.d_h2n = r->d_h2n; g.d_c2 = r->d_c2; g.d_c1 = r->d_c1; g.d_ch0 = r->d_ch0; g.d_h2p = r->d_h2p; g.d_glob = r->d_glob;
+    g.gates = r->gates; g.dx = r->dx; g.wacc = r->wacc; g.r_words = r->r_words;
+    return g;
+}
+
+static int check_grad(const lrpx_gridtd_trace* t, const lrpx_gridtd_gradstate* r) {
+    LRPX_TRY(check_trace(t));
+    LRPX_REQUIRE(t->o1 && t->o2 && t->sgate, "gridtd_grad: the trace must carry o1/o2/sgate (gradient-explainer trace)");
+    LRPX_REQUIRE(t->E == t->H, "gridtd_grad: embed_dim must equal hidden_dim");
+    LRPX_REQUIRE(r && r->d_h2n && r->d_c2 && r->d_c1 && r->d_ch0 && r->d_h2p && r->d_glob && r->gates && r->dx && r->wacc &&
+                     r->r_words, "gridtd_grad: null state tensor");
+    return LRPX_OK;
+}
+
+int lrpx_gridtd_grad_init(const lrpx_gridtd_trace* tr, const lrpx_gridtd_gradstate* gs, const float* fcw,
+                          const long long* tok, int tok_ld, void* stream) {
+    LRPX_TRY(check_grad(tr, gs));
+    LRPX_REQUIRE(fcw && tok, "gridtd_grad_init: null pointer");
+    hipLaunchKernelGGL(gridtd_grad_init_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_grad(tr, gs),
+                       fcw, tok, tok_ld);
+    return check_launch("gridtd_grad_init");
+}
+
+int lrpx_gridtd_grad_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_gradstate* gs, int s, int phase, void* stream) {
+    LRPX_TRY(check_grad(tr, gs));
+    LRPX_REQUIRE(s >= 0 && s < tr->T && phase >= 0 && phase <= 2, "gridtd_grad_step: bad step/phase");
+    const GridGrad g = to_grad(tr, gs);
+    const dim3 grid(tr->B * tr->T), blk(256);
+    if (phase == 0) hipLaunchKernelGGL(gridtd_grad_a_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
+    else if (phase == 1) hipLaunchKernelGGL(gridtd_grad_b_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
+    else hipLaunchKernelGGL(gridtd_grad_c_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
+    return check_launch("gridtd_grad_step");
+}
+
+int lrpx_spread_pixels(const float* wacc, const float* alpha, const int32_t* lens, float* a_proj, int B, int T, int H,
+                       int P, void* stream) {
+    LRPX_REQUIRE(wacc && alpha && a_proj && B > 0 && T > 0, "spread_pixels: bad arguments");
+    const int kchunk = 28;
+    hipLaunchKernelGGL(spread_pixels_kernel, dim3(B * T, (P + kchunk - 1) / kchunk), dim3(256),
+                       (size_t)T * kchunk * sizeof(float), (hipStream_t)stream, wacc, alpha, lens, a_proj, T, H, P, kchunk);
+    return check_launch("spread_pixels");
+}
+
+int lrpx_scale(const float* x, float* y, long n, float alpha, void* stream) {
+    LRPX_REQUIRE(x && y && n > 0, "scale: bad arguments");
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, alpha);
+    return check_launch("scale");
+}
+
+int lrpx_positive_mask(const float* x, float* y, long n, void* stream) {
+    LRPX_REQUIRE(x && y && n > 0, "positive_mask: bad arguments");
+    hipLaunchKernelGGL(positive_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return check_launch("positive_mask");
+}
 
 static AoaFwd to_afwd(const lrpx_aoa_trace* t) {
     AoaFwd g;

@@ -28,6 +28,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
         case EPI_REL: LRPX_REQUIRE(d->x && (d->out0 || d->out1) && (!d->out1 || d->zdiv || d->stab == STAB_NONE), "conv_mfma: REL needs x and (out0|out1,zdiv)"); break;
         case EPI_FIRST: LRPX_REQUIRE(d->x && d->out0, "conv_mfma: FIRST needs x,out0"); break;
         case EPI_PLAIN: LRPX_REQUIRE(d->out0, "conv_mfma: PLAIN needs out0"); break;
+        case EPI_GUIDED: LRPX_REQUIRE(d->out0 && d->x, "conv_mfma: GUIDED needs x,out0"); break;
         default: LRPX_REQUIRE(false, "conv_mfma: epilogue %d not built", d->epi);
     }
     if (d->taps == 1) {
@@ -40,22 +41,31 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
         case 224:
             if (e == EPI_FWD_DUAL) return launch_conv_224_8_1_4_9_fwd_dual(a, s);
             if (e == EPI_REL) return launch_conv_224_8_4_2_9_rel(a, s);
+            if (e == EPI_GUIDED) return launch_conv_224_8_4_2_9_guided(a, s);
             break;
         case 112:
             if (e == EPI_FWD_DUAL) return launch_conv_112_8_1_4_9_fwd_dual(a, s);
             if (e == EPI_REL) return d->n_oc <= 64 ? launch_conv_112_8_2_2_9_rel(a, s) : launch_conv_112_8_1_4_9_rel(a, s);
+            if (e == EPI_GUIDED) return launch_conv_112_8_1_4_9_guided(a, s);
+            if (e == EPI_PLAIN) return launch_conv_112_8_2_2_9_plain(a, s);
             break;
         case 56:
             if (e == EPI_FWD_DUAL) return launch_conv_56_16_1_4_9_fwd_dual(a, s);
             if (e == EPI_REL) return launch_conv_56_16_1_4_9_rel(a, s);
+            if (e == EPI_GUIDED) return launch_conv_56_16_1_4_9_guided(a, s);
+            if (e == EPI_PLAIN) return launch_conv_56_16_1_4_9_plain(a, s);
             break;
         case 28:
             if (e == EPI_FWD_DUAL) return launch_conv_28_16_1_4_9_fwd_dual(a, s);
             if (e == EPI_REL) return launch_conv_28_16_1_4_9_rel(a, s);
+            if (e == EPI_GUIDED) return launch_conv_28_16_1_4_9_guided(a, s);
+            if (e == EPI_PLAIN) return launch_conv_28_16_1_4_9_plain(a, s);
             break;
         case 14:
             if (e == EPI_FWD_DUAL) return launch_conv_14_16_1_4_9_fwd_dual(a, s);
             if (e == EPI_REL) return launch_conv_14_16_1_4_9_rel(a, s);
+            if (e == EPI_GUIDED) return launch_conv_14_16_1_4_9_guided(a, s);
+            if (e == EPI_PLAIN) return launch_conv_14_16_1_4_9_plain(a, s);
             break;
     }
     set_error("conv_mfma: no kernel built for hw=%d epi=%d", d->hw, d->epi);
@@ -75,25 +85,30 @@ static const VggLayer kVgg[17] = {
 static const int kNL = 17;
 static inline int cin_pad(int l) { return l == 0 ? 8 : kVgg[l].cin; }   // image is kept NHWC with 8 channels
 
-int first_layer_pack(const float* w, float* w6, int cout, hipStream_t s);
+int first_layer_pack(const float* w, float* w6, int cout, int plain, hipStream_t s);
 int first_layer_relevance(const float* S, const float* w6, const float* X8, const int* map2img, float* out, int n_maps,
-                          int cin, hipStream_t s);
+                          int cin, int plain, hipStream_t s);
+int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, hipStream_t s);
+int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
+                       int c, hipStream_t s);
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bias[17], first6, total;
+    size_t fwd[17], bwd[17], bwdp[17], bias[17], first6, first6p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
     size_t off = 0;
     for (int l = 0; l < kNL; ++l) {
-        p.fwd[l] = p.bwd[l] = p.bias[l] = 0;
+        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bias[l] = 0;
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
         p.bwd[l] = off; off += lrpx_packed_floats(l == 0 ? 32 : L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout));
         p.bias[l] = off; off += (size_t)L.cout;
+        if (l > 0) { p.bwdp[l] = off; off += lrpx_packed_floats(L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout)); }
     }
     p.first6 = off; off += (size_t)64 * 9 * 6;   // direct-conv weights of the first layer's rule
+    p.first6p = off; off += (size_t)64 * 9 * 6;  // ... and of its plain transposed conv (guided backprop)
     p.total = off;
     return p;
 }
@@ -160,7 +175,13 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
             set_error("vgg16_pack: bias copy failed");
             return LRPX_ELAUNCH;
         }
-        if (l == 0) LRPX_TRY(first_layer_pack(w[ci], base + p.first6, L.cout, (hipStream_t)stream));
+        if (l == 0) {
+            LRPX_TRY(first_layer_pack(w[ci], base + p.first6, L.cout, 0, (hipStream_t)stream));
+            LRPX_TRY(first_layer_pack(w[ci], base + p.first6p, L.cout, 1, (hipStream_t)stream));
+        } else {
+            LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, lrpx_conv_kc(L.hw, 9, L.cout),
+                                       base + p.bwdp[l], stream));
+        }
         ++ci;
     }
     return LRPX_OK;
@@ -235,7 +256,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
         d.x = tr + t.act[l];
         if (l == 0) {
             // 3 output channels: direct VALU conv (first_layer.hip) instead of a 32-wide MFMA tile
-            LRPX_TRY(first_layer_relevance(S[cur], pk + p.first6, tr + t.act[0], map2img, out_nchw, n_maps, L.cout,
+            LRPX_TRY(first_layer_relevance(S[cur], pk + p.first6, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 0,
                                            (hipStream_t)stream));
             break;
         }
@@ -250,6 +271,47 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
             LRPX_TRY(lrpx_maxpool2x2_relevance(tr + t.act[l - 1], R, tr + t.zpos[l - 2], map2img, nullptr, S[cur ^ 1],
                                                n_maps, L.hw, L.hw, L.cin, stream));
+        }
+        cur ^= 1;
+    }
+    return LRPX_OK;
+}
+
+int lrpx_vgg16_guided_backprop(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                               const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream) {
+    LRPX_REQUIRE(packed && trace && d_feat_nhwc && workspace && out_nchw && n_maps > 0 && n_img > 0,
+                 "vgg16_guided_backprop: bad arguments");
+    LRPX_REQUIRE(map2img || n_maps == n_img, "vgg16_guided_backprop: map2img is required when n_maps != n_img");
+    const VggPacked p = vgg_packed_layout();
+    const VggTrace t = vgg_trace_layout(n_img);
+    const float* pk = (const float*)packed;
+    const float* tr = (const float*)trace;
+    float* ws = (float*)workspace;
+    const size_t sbuf = (size_t)224 * 224 * 64 * n_maps;
+    float* G[2] = {ws, ws + sbuf};
+    float* R = ws + 2 * sbuf;
+    hipStream_t st = (hipStream_t)stream;
+    int cur = 0;
+    // hook of the last ReLU (the encoder ends with one): clamp(d,0) * [features > 0]
+    LRPX_TRY(guided_gate(d_feat_nhwc, tr + t.act[kNL], map2img, G[cur], n_maps, (long)196 * 512, st));
+    for (int l = kNL - 1; l >= 0; --l) {
+        const VggLayer& L = kVgg[l];
+        if (!L.conv) continue;
+        if (l == 0) {
+            LRPX_TRY(first_layer_relevance(G[cur], pk + p.first6p, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 1, st));
+            break;
+        }
+        lrpx_conv_desc d = {};
+        d.in = G[cur]; d.wpacked = pk + p.bwdp[l];
+        d.n_maps = n_maps; d.hw = L.hw; d.cin = L.cout; d.taps = 9; d.map2img = map2img;
+        d.n_oc = L.cin; d.oc_split = L.cin;
+        if (kVgg[l - 1].conv) {
+            d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];      // ReLU hook of conv l-1 fused
+            LRPX_TRY(conv_dispatch(&d, st));
+        } else {
+            d.epi = EPI_PLAIN; d.out0 = R;
+            LRPX_TRY(conv_dispatch(&d, st));
+            LRPX_TRY(maxpool_guided_bwd(tr + t.act[l - 1], R, map2img, G[cur ^ 1], n_maps, L.hw, L.hw, L.cin, st));
         }
         cur ^= 1;
     }

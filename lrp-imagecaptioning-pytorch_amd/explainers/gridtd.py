@@ -10,8 +10,8 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
-from .._lib import (EPI_PLAIN, EPI_REL, GridRelState, GridTrace, PACK_DENSE, PACK_DENSE_T, check, ptr, ptr_at,
-                    stream_ptr)
+from .._lib import (EPI_PLAIN, EPI_REL, GridGradState, GridRelState, GridTrace, PACK_DENSE, PACK_DENSE_T, check, ptr,
+                    ptr_at, stream_ptr)
 
 VGG_PREFIX = "img_encoder.encoder."
 
@@ -57,6 +57,10 @@ class GridTDEngine:
         self.p_proj_fwd = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE, kc)
         self.p_attv_fwd = ops.pack_weights(sd["AdaAttention.W_v_proj.weight"], self.P, H, 1, PACK_DENSE, kc)
         self.p_fc_fwd = ops.pack_weights(sd["fc.weight"], self.V, H, 1, PACK_DENSE, kc)
+        # --- guided-backprop weights: full gate matrices, contraction over the 4H gate rows (gridTDmodel.py:1637-1659)
+        self.p_g2 = ops.pack_weights(self.Wcat2, 4 * H, 3 * H, 1, PACK_DENSE_T, kc)
+        self.p_g1 = ops.pack_weights(sd[a + "weight_ih"].contiguous(), 4 * H, 2 * E + H, 1, PACK_DENSE_T, kc)
+        self.p_gp_grad = self.p_gp_rel = ops.pack_weights(sd["global_img_feature_proj.weight"], E, Cc, 1, PACK_DENSE_T, kc)
         # --- relevance weights: g-gate rows of the LSTMs, [W_ih^g | W_hh^g]  (gridTDmodel.py:1019-1024)
         wg1 = torch.cat([sd[a + "weight_ih"][2 * H:3 * H], sd[a + "weight_hh"][2 * H:3 * H]], 1).contiguous()
         wg2 = torch.cat([sd[l + "weight_ih"][2 * H:3 * H], sd[l + "weight_hh"][2 * H:3 * H]], 1).contiguous()
@@ -68,7 +72,7 @@ class GridTDEngine:
         self._idx_cache = {}
 
     # ------------------------------------------------------------------------------------------
-    def _alloc_trace(self, B, T):
+    def _alloc_trace(self, B, T, grad=False):
         dev, H, E, P = self.device, self.H, self.E, self.P
         z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
         tr = dict(B=B, T=T)
@@ -78,10 +82,15 @@ class GridTDEngine:
         for k in ("g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat", "hc"):
             tr[k] = z(B, T, H)
         tr["alpha"], tr["beta"] = z(B, T, P), z(B, T)
+        names = ["xh1", "xh2", "h1", "c1", "h2", "c2", "g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat", "hc",
+                 "alpha", "beta"]
+        if grad:     # the gradient explainers also keep the output gates and the sentinel gate (:1323-1422)
+            for k in ("o1", "o2", "sgate"):
+                tr[k] = z(B, T, H)
+            names += ["o1", "o2", "sgate"]
         c = GridTrace()
         c.B, c.T, c.H, c.E, c.P = B, T, H, E, P
-        for k in ("xh1", "xh2", "h1", "c1", "h2", "c2", "g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat",
-                  "hc", "alpha", "beta"):
+        for k in names:
             setattr(c, k, ptr(tr[k]))
         tr["_c"] = c
         return tr
@@ -135,13 +144,15 @@ class GridTDEngine:
                                     B, 3 * H, 4 * H, 0, st))
         check(lib.lrpx_gridtd_fwd_lstm(c, t, ptr(zz2), 4 * H, 2, st))
 
-    def trace(self, enc, captions, model_bias=False, predictions=True):
+    def trace(self, enc, captions, model_bias=False, predictions=True, grad=False):
         """get_hidden_parameters (gridTDmodel.py:952-1012) for B images under teacher forcing.
-        captions: (B,T+1) int64 on device, column 0 = <start>."""
+        captions: (B,T+1) int64 on device, column 0 = <start>.  grad=True: the gradient explainers' trace
+        (:1323-1422: correct LSTM bias, output + sentinel gates kept)."""
         lib = _lib.load()
         B, T = captions.shape[0], captions.shape[1] - 1
         captions = captions.contiguous()
-        tr = self._alloc_trace(B, T)
+        tr = self._alloc_trace(B, T, grad)
+        model_bias = model_bias or grad
         for t in range(T):
             self._step(tr, enc, t, captions, model_bias)
         tr["captions"] = captions
@@ -235,6 +246,62 @@ class GridTDEngine:
                       x=enc["feats"], u=U, map2img=row2img, out0=r_feat)
         check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
         return r_feat, rs["r_words"], row2img
+
+    def guided_gradient(self, enc, tr, lens=None):
+        """ExplainiGridTDGuidedGradient.explain_caption_wordt (gridTDmodel.py:1588-1675) for every (image, word)
+        row: decoder BPTT with alpha/beta constant.  `tr` must be a grad=True trace.
+        Returns d_feat (B*T, P, C), r_words (B*T, T), row2img."""
+        lib = _lib.load()
+        st = stream_ptr()
+        B, T, H, E, P, Cc = tr["B"], tr["T"], self.H, self.E, self.P, self.C
+        rows = B * T
+        e = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        gs = dict(d_h2n=e(rows, H), d_c2=e(rows, H), d_c1=e(rows, H), d_ch0=e(rows, H), d_h2p=e(rows, H),
+                  d_glob=e(rows, E), gates=e(rows, 4 * H), dx=e(rows, 3 * H), wacc=torch.zeros(rows, T, H, device=self.device),
+                  r_words=e(rows, T))
+        c = GridGradState()
+        c.lens = ptr(lens)
+        for k, v in gs.items():
+            setattr(c, k, ptr(v))
+        ctr, cgs = C.byref(tr["_c"]), C.byref(c)
+        _, row2img = self._row_index(B, T)
+        check(lib.lrpx_gridtd_grad_init(ctr, cgs, ptr(self.sd["fc.weight"]), ptr(tr["captions"]), T + 1, st))
+        for s in range(T):
+            check(lib.lrpx_gridtd_grad_step(ctr, cgs, s, 0, st))
+            ops.conv_mfma(gs["gates"], self.p_g2, rows, 0, 4 * H, 3 * H, 1, EPI_PLAIN, pix_per_map=1, oc_split=3 * H,
+                          out0=gs["dx"])
+            check(lib.lrpx_gridtd_grad_step(ctr, cgs, s, 1, st))
+            ops.conv_mfma(gs["gates"], self.p_g1, rows, 0, 4 * H, 2 * E + H, 1, EPI_PLAIN, pix_per_map=1,
+                          oc_split=2 * E + H, out0=gs["dx"])
+            check(lib.lrpx_gridtd_grad_step(ctr, cgs, s, 2, st))
+        d_avg = e(rows, Cc)
+        ops.conv_mfma(gs["d_glob"], self.p_gp_grad, rows, 0, E, Cc, 1, EPI_PLAIN, pix_per_map=1, oc_split=Cc, out0=d_avg)
+        U = e(rows, Cc)
+        check(lib.lrpx_scale(ptr(d_avg), ptr(U), d_avg.numel(), 1.0 / P, st))                    # :1667
+        a_proj = e(rows, P, H)
+        check(lib.lrpx_spread_pixels(ptr(gs["wacc"]), ptr(tr["alpha"]), ptr(lens), ptr(a_proj), B, T, H, P, st))
+        mask = e(B, P, Cc)
+        check(lib.lrpx_positive_mask(ptr(enc["feats"]), ptr(mask), mask.numel(), st))             # :1674
+        d_feat = e(rows, P, Cc)
+        ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=mask, u=U,
+                      map2img=row2img, out0=d_feat)                                              # :1668, :1674
+        check(lib.lrpx_rel_words_norm(ptr(gs["r_words"]), rows, T, st))
+        return d_feat, gs["r_words"], row2img
+
+    def explain_batch_guided(self, images, captions, lens=None, return_features=False):
+        """Batched `ExplainiGridTDGuidedGradient.explain_caption`: guided-backprop maps (B,T,3,224,224) and word
+        scores (B,T,T).  (No running sums here: the reference zeroes the image gradient per word, :1717.)"""
+        images = images.to(self.device, torch.float32).contiguous()
+        captions = captions.to(self.device, torch.int64).contiguous()
+        B, T = captions.shape[0], captions.shape[1] - 1
+        enc = self.encode(images)
+        tr = self.trace(enc, captions, predictions=False, grad=True)
+        d_feat, r_words, row2img = self.guided_gradient(enc, tr, lens)
+        maps = self.vgg.guided_backprop(d_feat, row2img)
+        out = (maps.view(B, T, 3, 224, 224), r_words.view(B, T, T))
+        if return_features:
+            out = out + (d_feat.view(B, T, self.P, self.C), tr, enc)
+        return out
 
     def explain_batch(self, images, captions, lens=None, accumulate=False, return_features=False):
         """Batched `explain_caption` (gridTDmodel.py:1141-1156): images (B,3,224,224), captions (B,T+1) int64.
@@ -364,3 +431,34 @@ class ExplainGridTDAttention(object):
         enc = eng.encode(img.to(eng.device, torch.float32))
         cap = torch.tensor([list(beam_caption_encode) + [0]], dtype=torch.int64, device=eng.device)
         return eng.trace(enc, cap, predictions=True)["pred"][0]
+
+
+class ExplainiGridTDGuidedGradient(ExplainGridTDAttention):
+    """Drop-in for the reference's `ExplainiGridTDGuidedGradient` (models/gridTDmodel.py:1585-1723; the spelling is
+    the reference's): guided backprop instead of LRP, same `explain_caption` surface."""
+    EX_TYPE = 'GuidedBackpropagate'
+
+    def get_hidden_parameters(self, img, caption_encode=None, max_cap_length=50):
+        super().get_hidden_parameters(img, caption_encode, max_cap_length)
+        cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=self.engine.device)
+        self._tr = self.engine.trace(self._enc, cap, predictions=True, grad=True)     # :1323-1422 (correct LSTM bias)
+        self.predictions = self._tr["pred"][0]
+        self.alphas, self.betas = self._tr["alpha"][0], self._tr["beta"][0]
+
+    def _relevance(self):
+        if self._rel is None:
+            self._rel = self.engine.guided_gradient(self._enc, self._tr)
+        return self._rel
+
+    def explain_cnn(self, d_img_feature):
+        t_nhwc = ops.nchw_to_nhwc(d_img_feature.to(torch.float32))
+        return self.engine.vgg.guided_backprop(t_nhwc, torch.zeros(d_img_feature.shape[0], dtype=torch.int32,
+                                                                   device=self.engine.device))
+
+    def explain_caption(self, img_filepath, t_list=None, caption_encode=None):
+        self.img_filepath = img_filepath
+        self.get_hidden_parameters(img_filepath, caption_encode)
+        d_feat, r_words, row2img = self._relevance()
+        maps = self.engine.vgg.guided_backprop(d_feat, row2img)
+        return ([maps[t:t + 1] for t in range(self.caption_length)],
+                [r_words[t, :t + 1] for t in range(self.caption_length)])

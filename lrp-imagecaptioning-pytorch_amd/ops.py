@@ -157,6 +157,21 @@ class Vgg16:
                 zs.append(None)
         return acts, zs
 
+    def guided_backprop(self, d_feat_nhwc, map2img=None, out=None):
+        """explain_cnn of the guided-backprop explainer (models/gridTDmodel.py:1702-1723): (N,196,512) gradient at
+        the encoder output -> (N,3,224,224) image gradient with the guided ReLU rule."""
+        lib = _lib.load()
+        n_maps = d_feat_nhwc.shape[0]
+        need = lib.lrpx_vgg16_workspace_bytes(n_maps) // 4
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(n_maps, 3, 224, 224, dtype=torch.float32, device=self.device)
+        check(lib.lrpx_vgg16_guided_backprop(ptr(self.packed), ptr(self.trace), self.n_img, ptr(d_feat_nhwc.contiguous()),
+                                             ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
+        return out
+
     def relevance(self, r_feat_nhwc, map2img=None, out=None):
         """compute_lrp (LRPtools/lrp_wrapper.py:63-87) for N maps: (N,196,512) -> (N,3,224,224)."""
         lib = _lib.load()

@@ -1,0 +1,101 @@
+"""GPU parity of the guided-backprop path (BASELINE config 4 runs it side by side with LRP): decoder BPTT kernels
+and the VGG16 guided backward chain against the reference's golden (tests/golden/guided_T3.npz) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lrp_amd  # noqa: F401
+from conftest import GOLDEN, rel_err, cosine, assert_close_modulo_pool_ties
+
+pytestmark = pytest.mark.gpu
+# End-to-end guided-backprop maps: besides the max-pool winners, every ReLU gate [a > 0] / clamp(g, min=0) is a
+# discrete decision on values that are often within rounding of zero, so more pixels move by > 1e-4 of the maximum
+# than for LRP when the forward comes from a different conv implementation (5 % on the golden image); cosine and
+# the relative L2 error (< 2e-3) are unaffected.  The strict 1e-4 check runs on identical activations below.
+E2E = dict(frac=0.25)
+
+
+@pytest.fixture(scope="module")
+def case():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine
+    g = np.load(os.path.join(GOLDEN, "guided_T3.npz"))
+    sd = weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=int(g["V"]))
+    eng = GridTDEngine(sd)
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    cap = torch.from_numpy(g["caption"]).view(1, -1)
+    return g, sd, eng, img, cap
+
+
+def test_guided_decoder_and_maps_vs_reference(case):
+    g, sd, eng, img, cap = case
+    maps, r_words, d_feat, tr, enc = eng.explain_batch_guided(img, cap, return_features=True)
+    assert rel_err(tr["sgate"][0].cpu(), g["tr_sen_gate"]) < 1e-4 and rel_err(tr["o2"][0].cpu(), g["tr_o2t_act"]) < 1e-4
+    assert rel_err(tr["h2"][0].cpu(), g["tr_h2t"]) < 1e-4
+    for t in range(3):
+        want = torch.from_numpy(g[f"d_feat_{t}"])[0].reshape(512, 196).t()
+        assert rel_err(d_feat[0, t].cpu(), want) < 1e-4, t
+        assert np.abs(r_words[0, t, :t + 1].cpu().numpy() - g[f"r_words_{t}"]).max() < 5e-5
+        assert_close_modulo_pool_ties(maps[0, t][None, :, ::4, ::4].cpu(), g[f"map_sub4_{t}"], what=t, **E2E)
+    assert_close_modulo_pool_ties(maps[0, 2].cpu(), g["map_full_2"][0], what="full", **E2E)
+
+
+def test_guided_cnn_chain_strict_on_identical_activations(case):
+    """the guided VGG16 backward on the oracle's own activations (same pool winners, same ReLU masks): 1e-4"""
+    from test_gpu_vgg import _inject_oracle_trace, to_nhwc
+    from oracle import lrp_oracle as O
+    g, sd, eng, img, cap = case
+    eng.vgg.forward(img.cuda())
+    _inject_oracle_trace(eng.vgg, sd, img)
+    d = torch.cat([torch.from_numpy(g[f"d_feat_{t}"]) for t in range(3)])
+    maps = eng.vgg.guided_backprop(to_nhwc(d).cuda(), torch.zeros(3, dtype=torch.int32, device="cuda")).cpu()
+    sdt = O.state_to_torch(sd)
+    _, _, saved = O.vgg_forward(sdt, img)
+    want = O.vgg_guided_backprop(sdt, saved, d)
+    assert rel_err(maps, want) < 1e-4
+    assert rel_err(maps[2:3], g["map_full_2"]) < 1e-4
+
+
+def test_lrp_and_guided_side_by_side_batch(case):
+    """config 4 shape: LRP and guided backprop on the same batch (B=2, T=3), guided vs the oracle"""
+    from lrp_amd import weights
+    from oracle import lrp_oracle as O
+    g, sd, eng, img, cap = case
+    V = int(g["V"])
+    imgs = torch.from_numpy(weights.make_images(21, 2))
+    caps = torch.from_numpy(weights.make_captions(22, 2, 3, V))
+    lrp_maps, _ = eng.explain_batch(imgs, caps)
+    gb_maps, gb_words, d_feat, _, enc = eng.explain_batch_guided(imgs, caps, return_features=True)
+    assert lrp_maps.shape == gb_maps.shape == (2, 3, 3, 224, 224)
+    sdt = O.state_to_torch(sd)
+    for b in range(2):
+        w_maps, w_rw, w_df, w_tr = O.gridtd_guided_explain_caption(sdt, imgs[b:b + 1], caps[b].numpy(), return_feat=True)
+        # d_feat carries the gate [features > 0] (:1674): encoder outputs within rounding of zero may be gated
+        # differently by the GPU and the CPU forward, so compare where both gates agree (and they must almost always)
+        same = (enc["feats"][b].cpu() > 0) == (w_tr["F_pix"] > 0)
+        assert (~same).float().mean().item() < 1e-4
+        for t in range(3):
+            want = w_df[t][0].reshape(512, 196).t()
+            assert rel_err(d_feat[b, t].cpu() * same, want * same) < 2e-4, (b, t)
+            assert np.abs(gb_words[b, t, :t + 1].cpu().numpy() - w_rw[t].numpy()).max() < 1e-4
+            assert_close_modulo_pool_ties(gb_maps[b, t].cpu(), w_maps[t][0], what=(b, t), **E2E)
+
+
+def test_guided_explainer_class(case):
+    import types
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import ExplainiGridTDGuidedGradient
+    g, sd, eng, img, cap = case
+    V = int(g["V"])
+    args = types.SimpleNamespace(embed_dim=512, hidden_dim=512, encoder='vgg16', weight='', save_path='/tmp',
+                                 dataset='synthetic', height=224, width=224)
+    ex = ExplainiGridTDGuidedGradient(args, weights.make_word_map(V), model={k: torch.from_numpy(v) for k, v in sd.items()})
+    maps, rws = ex.explain_caption(img, caption_encode=[int(c) for c in g["caption"]])
+    assert len(maps) == 3 and maps[1].shape == (1, 3, 224, 224)
+    for t in range(3):
+        assert np.abs(rws[t].cpu().numpy() - g[f"r_words_{t}"]).max() < 5e-5
+        assert_close_modulo_pool_ties(maps[t][..., ::4, ::4].cpu(), g[f"map_sub4_{t}"], what=t, **E2E)
