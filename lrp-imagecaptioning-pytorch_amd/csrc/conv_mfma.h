@@ -83,75 +83,91 @@ struct EpiCtx {
     long pix0, total_pix;
 };
 
-// Per-element epilogue.  acc[j][e] is pixel q = q0 + 32*j + (e&3) + 8*(e>>2) of the tile, channel cx.oc.
+// Per-tile epilogue.  accj[e] is pixel q = q0 + 32*j + (e&3) + 8*(e>>2) of the tile, channel cx.oc.
+// Two phases: (1) index math + ALL global loads of the 16 elements, (2) arithmetic + stores — with the pointers
+// marked __restrict__, otherwise every load has to wait for the previous element's store (possible aliasing) and
+// the epilogue degenerates into 16 dependent L2 round trips per tile.
 template <int EPI, int HW, int TAPS>
 __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const EpiCtx& cx, const int j, const f32x16 accj) {
+    const float* __restrict__ X = a.X;
+    const float* __restrict__ Zd = a.Zdiv;
+    const float* __restrict__ Uu = a.U;
+    const int* __restrict__ m2i = a.map2img;
+    float* __restrict__ o0 = a.out0;
+    float* __restrict__ o1 = a.out1;
     const int oc = cx.oc;
     const int ncol = a.oc_split;   // real channels of X / Zdiv / out (REL...), plain channels (FWD_DUAL)
     const unsigned P = (unsigned)a.pix_per_map;
     float bias = 0.f;
     if (EPI == EPI_FWD_DUAL || EPI == EPI_PLAIN) bias = (a.bias && oc < ncol) ? a.bias[oc] : 0.f;
-    {
+    constexpr bool NEEDS_X = (EPI == EPI_REL || EPI == EPI_GUIDED || EPI == EPI_FIRST);
+    bool ok[16];
+    unsigned nn[16], pp[16];
+    float xv[16], zv[16], uv[16], x3[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int q = cx.q0 + 32 * j + (e & 3) + 8 * (e >> 2);
-            const long gp = cx.pix0 + q;
-            if (gp >= cx.total_pix) continue;
-            float v = accj[e];
-            // map index n and pixel-in-map p (32-bit; constant divisors for the conv case)
-            unsigned n, p;
-            if (TAPS == 9) {
-                const unsigned r = (unsigned)q / (unsigned)HW, c = (unsigned)q - r * HW;
-                const unsigned g = (unsigned)cx.g0 + r;
-                n = g / (unsigned)HW;
-                p = (g - n * HW) * HW + c;
-            } else {
-                n = (unsigned)gp / P;
-                p = (unsigned)gp - n * P;
+    for (int e = 0; e < 16; ++e) {
+        const int q = cx.q0 + 32 * j + (e & 3) + 8 * (e >> 2);
+        const long gp = cx.pix0 + q;
+        ok[e] = gp < cx.total_pix;
+        unsigned n, p;   // map index and pixel-in-map (32-bit; constant divisors for the conv case)
+        if (TAPS == 9) {
+            const unsigned r = (unsigned)q / (unsigned)HW, c = (unsigned)q - r * HW;
+            const unsigned g = (unsigned)cx.g0 + r;
+            n = g / (unsigned)HW;
+            p = (g - n * HW) * HW + c;
+        } else {
+            n = (unsigned)gp / P;
+            p = (unsigned)gp - n * P;
+        }
+        nn[e] = n; pp[e] = p;
+        xv[e] = 0.f; zv[e] = 1.f; uv[e] = 0.f; x3[e] = 0.f;
+        if (NEEDS_X && ok[e] && oc < ncol) {
+            const long img = m2i ? m2i[n] : n;
+            const long xi = (img * P + p) * ncol + oc;
+            xv[e] = X[xi];
+            if (EPI == EPI_REL && Zd && o1) zv[e] = Zd[xi];
+            if (EPI == EPI_REL && Uu) uv[e] = Uu[(long)n * ncol + oc];
+            if (EPI == EPI_FIRST && oc < 3) x3[e] = X[xi + 3];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int q = cx.q0 + 32 * j + (e & 3) + 8 * (e >> 2);
+        const long gp = cx.pix0 + q;
+        float v = accj[e];
+        if (EPI == EPI_FIRST) {
+            // channels 0..2 carry convT(S, W+), 3..5 convT(S, W-); combine across lanes of the same half
+            const int li = cx.lane & 31;
+            const float other = __shfl(v, (cx.lane & 32) + ((li + 3) & 31), 64);
+            if (ok[e] && oc < 3) o0[((long)nn[e] * 3 + oc) * P + pp[e]] = xv[e] * v + x3[e] * other;   // NCHW
+            continue;
+        }
+        if (!ok[e]) continue;
+        if (EPI == EPI_FWD_DUAL) {
+            if (oc < ncol) {
+                v += bias;
+                o0[gp * ncol + oc] = v > 0.f ? v : 0.f;
+            } else if (oc < 2 * ncol) {
+                o1[gp * ncol + (oc - ncol)] = v;
             }
-            if (EPI == EPI_FWD_DUAL) {
-                if (oc < ncol) {
-                    v += bias;
-                    a.out0[gp * ncol + oc] = v > 0.f ? v : 0.f;
-                } else if (oc < 2 * ncol) {
-                    a.out1[gp * ncol + (oc - ncol)] = v;
-                }
-            } else if (EPI == EPI_REL) {
-                if (oc < ncol) {
-                    const long img = a.map2img ? a.map2img[n] : n;
-                    const long xi = (img * P + p) * ncol + oc;
-                    if (a.U) v += a.U[(long)n * ncol + oc];
-                    const float r = a.X[xi] * v;
-                    if (a.out0) a.out0[gp * ncol + oc] = r;
-                    if (a.out1) {
-                        float z = a.Zdiv[xi];
-                        z = (a.stab == STAB_SAFE) ? stab_safe(z) : ((a.stab == STAB_EPS) ? stab_eps(z) : z);
-                        a.out1[gp * ncol + oc] = r / z;
-                    }
-                }
-            } else if (EPI == EPI_FIRST) {
-                // channels 0..2 carry convT(S, W+), 3..5 convT(S, W-); combine across lanes of the same half
-                const int li = cx.lane & 31;
-                const float other = __shfl(v, (cx.lane & 32) + ((li + 3) & 31), 64);
-                if (oc < 3) {
-                    const long img = a.map2img ? a.map2img[n] : n;
-                    const float* xp = a.X + (img * P + p) * ncol + oc;   // image kept NHWC split: [x+ (3) | x- (3) | 0 0]
-                    const float r = xp[0] * v + xp[3] * other;
-                    a.out0[((long)n * 3 + oc) * P + p] = r;           // NCHW
-                }
-            } else if (EPI == EPI_PLAIN) {
-                if (oc < ncol) {
-                    v += bias;
-                    if (a.relu) v = v > 0.f ? v : 0.f;
-                    a.out0[gp * ncol + oc] = v;
-                }
-            } else {   // EPI_GUIDED
-                if (oc < ncol) {
-                    const long img = a.map2img ? a.map2img[n] : n;
-                    const float y = a.X[(img * P + p) * ncol + oc];
-                    a.out0[gp * ncol + oc] = (y > 0.f && v > 0.f) ? v : 0.f;
+        } else if (EPI == EPI_REL) {
+            if (oc < ncol) {
+                const float r = xv[e] * (v + uv[e]);
+                if (o0) o0[gp * ncol + oc] = r;
+                if (o1) {
+                    float z = zv[e];
+                    z = (a.stab == STAB_SAFE) ? stab_safe(z) : ((a.stab == STAB_EPS) ? stab_eps(z) : z);
+                    o1[gp * ncol + oc] = r / z;
                 }
             }
+        } else if (EPI == EPI_PLAIN) {
+            if (oc < ncol) {
+                v += bias;
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                o0[gp * ncol + oc] = v;
+            }
+        } else {   // EPI_GUIDED: ReLU hook of the layer below, out = max(g,0) * [y > 0]
+            if (oc < ncol) o0[gp * ncol + oc] = (xv[e] > 0.f && v > 0.f) ? v : 0.f;
         }
     }
 }
@@ -208,8 +224,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
     constexpr int U = (NITEM + NT - 1) / NT;
     constexpr int BUF = C::LDS_PIX * STRIDE;          // floats per LDS buffer (two buffers)
     constexpr int STEPS = TAPS * C::KSTEPS;           // k-steps (of 8 channels) per chunk
-    constexpr int NB = (STEPS % 3 == 0) ? 3 : 2;      // B-fragment register ring: prefetch depth NB-1
-    static_assert(STEPS % NB == 0, "ring must realign at chunk boundaries");
+    constexpr int NB = 6;                             // B-fragment register queue: prefetch depth NB-1 k-steps
     int sdst[U], sgp[U];   // LDS float offset (-1: never written, stays zero) / global pixel (-1: store zeros)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -262,7 +277,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
     // B fragments: one contiguous stream of (nchunk * STEPS) 1-KiB wave-loads per channel block
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.wp) + (long)ocb * nchunk * (STEPS * 64) + lane;
     const int last_step = nchunk * STEPS - 1;
-    f32x4 bq[NB];
+    f32x4 bq[NB];     // bq[0] = fragment of the current k-step, bq[i] = i steps ahead (L2 latency under load ~2 us)
 #pragma unroll
     for (int i = 0; i < NB; ++i) bq[i] = f32x4{0, 0, 0, 0};
     if (wave_active) {
@@ -283,8 +298,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
 #pragma unroll
                 for (int ks = 0; ks < C::KSTEPS; ++ks) {
                     const int step = tap * C::KSTEPS + ks;
-                    // refill the ring slot that was consumed one step ago with the fragment NB-1 steps ahead
-                    bq[(step + NB - 1) % NB] = wp[(long)min(g0step + step + NB - 1, last_step) * 64];
+                    bq[NB - 1] = wp[(long)min(g0step + step + NB - 1, last_step) * 64];   // NB-1 steps ahead
                     f32x4 av[7];
 #pragma unroll
                     for (int j = 0; j < 7; ++j)
@@ -293,7 +307,9 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
                     for (int j = 0; j < 7; ++j)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][e], bq[step % NB][e], acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][e], bq[0][e], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NB - 1; ++i) bq[i] = bq[i + 1];   // renamed away inside the unrolled chunk
                 }
             }
         }
