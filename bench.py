@@ -29,6 +29,10 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_MAP = 30.69          # one transposed conv per VGG16 layer = 15.35 GMAC
 PEAK_FP32_MFMA_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# HBM traffic of one relevance pass over 320 maps, from rocprofv3 --pmc (separate passes, tools/pmc_passes.sh;
+# profiles/r01_pmc_traffic.txt): FETCH_SIZE 42.9 GB raw (x2 for wide coalesced streams on gfx950, per
+# MI355X_MICROARCH.md §HBM) + WRITE_SIZE 22.2 GB.  Scaled linearly with the map count below.
+TRAFFIC_BYTES_PER_MAP = (2 * 42.9e9 + 22.2e9) / 320
 
 
 def host_cores():
@@ -75,6 +79,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=9586)
     ap.add_argument("--gather", action="store_true", help="gather the maps to rank 0 over RCCL inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,18 +113,19 @@ def main():
     if a.gather and world > 1 and rank == 0:
         gathered = [torch.empty(B * T, 3, 224, 224, device="cuda") for _ in range(world)]
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    chain_ms = []
+    state = {}
 
     def step(timed):
+        if a.graph:
+            maps, r_words = eng.explain_batch_graph(images, caps)
+            if a.gather and world > 1:
+                dist.gather(maps.view(B * T, 3, 224, 224), gathered, dst=0)
+            return maps, r_words
         enc = eng.encode(images)
         tr = eng.trace(enc, caps, predictions=False)
         r_feat, r_words, row2img = eng.relevance(enc, tr)
-        if timed:
-            ev[0].record()
         maps = eng.vgg.relevance(r_feat, row2img)
-        if timed:
-            ev[1].record()
+        state["chain_in"] = (r_feat, row2img)
         if a.gather and world > 1:
             dist.gather(maps, gathered, dst=0)
         return maps, r_words
@@ -137,8 +143,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         maps, _ = step(True)
-        chain_ms.append((ev[0], ev[1]))
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -160,12 +164,26 @@ def main():
                           "images_per_gpu": B, "words": T, "vocab": V, "maps_per_step": world * B * T,
                           "sharding": f"images x{world}, no data-path collective" + (" + gather" if a.gather else "")}}
         if world == 1:
-            ms = sorted(e0.elapsed_time(e1) for e0, e1 in chain_ms)
+            # roofline of the dominant kernel family: the 13 conv_mfma launches (+ pool / first-layer kernels between
+            # them) of one relevance pass, timed live with HIP events on the launch stream, outside the headline timing
+            if "chain_in" not in state:
+                enc = eng.encode(images)
+                state["chain_in"] = eng.relevance(enc, eng.trace(enc, caps, predictions=False))[::2]
+            r_feat, row2img = state["chain_in"]
+            ms = []
+            for _ in range(max(3, a.steps)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                eng.vgg.relevance(r_feat, row2img, out=maps.view(B * T, 3, 224, 224))
+                e1.record()
+                e1.synchronize()
+                ms.append(e0.elapsed_time(e1))
             avg = sum(ms) / len(ms)
             tf = GFLOP_PER_MAP * B * T / avg          # GFLOP / ms = TFLOP/s
             out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel relevance pass (13 launches/step)",
                                "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_FP32_MFMA_TF, 4), "traffic": None,
+                               "frac": round(tf / PEAK_FP32_MFMA_TF, 4),
+                               "traffic": round(TRAFFIC_BYTES_PER_MAP * B * T),
                                "ms_per_step": round(avg, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * B * T}
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(V, T, [0, 5, 10, 15, 19])

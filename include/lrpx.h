@@ -163,8 +163,10 @@ typedef struct lrpx_gridtd_trace {
 int lrpx_gridtd_fwd_pre(const lrpx_gridtd_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
                         int tok_ld, void* stream);
 int lrpx_gridtd_fwd_lstm(const lrpx_gridtd_trace* tr, int t, const float* zz, int ldz, int which, void* stream);
+/* scratch: [B][3*P] floats (scores, W_g h, W_s s) */
 int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img,
-                              const float* Wg, const float* Ws, const float* bs, const float* wh, void* stream);
+                              const float* Wg, const float* Ws, const float* bs, const float* wh, float* scratch,
+                              void* stream);
 
 /* ---- gridTD decoder: relevance (explain_caption_wordt, models/gridTDmodel.py:1014-1135) -------------- */
 typedef struct lrpx_gridtd_relstate {

@@ -83,66 +83,76 @@ struct EpiCtx {
     long pix0, total_pix;
 };
 
-// Per-tile epilogue.  accj[e] is pixel q = q0 + 32*j + (e&3) + 8*(e>>2) of the tile, channel cx.oc.
-// Two phases: (1) index math + ALL global loads of the 16 elements, (2) arithmetic + stores — with the pointers
-// marked __restrict__, otherwise every load has to wait for the previous element's store (possible aliasing) and
-// the epilogue degenerates into 16 dependent L2 round trips per tile.
+// Epilogue, per 32x32 accumulator tile j: accj[e] is pixel q = q0 + 32*j + (e&3) + 8*(e>>2), channel cx.oc.
+// Split in two so the kernel can software-pipeline it: `epi_gather` does the index math and ALL global loads of the
+// 16 elements of a tile (issued one tile ahead), `epi_finish` the arithmetic and the stores.  Pointers are
+// __restrict__: without that every load waits for the previous element's store (possible aliasing) and the
+// epilogue degenerates into dependent L2 round trips.
+struct EpiRegs {
+    float xv[16], zv[16], x3[16];      // x3 / nn / pp are only live in the FIRST epilogue (dead otherwise)
+    unsigned nn[16], pp[16];
+};
+
 template <int EPI, int HW, int TAPS>
-__device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const EpiCtx& cx, const int j, const f32x16 accj) {
+__device__ __forceinline__ void epi_gather(const ConvArgs& a, const EpiCtx& cx, const int j, EpiRegs& r) {
     const float* __restrict__ X = a.X;
     const float* __restrict__ Zd = a.Zdiv;
-    const float* __restrict__ Uu = a.U;
     const int* __restrict__ m2i = a.map2img;
-    float* __restrict__ o0 = a.out0;
-    float* __restrict__ o1 = a.out1;
     const int oc = cx.oc;
-    const int ncol = a.oc_split;   // real channels of X / Zdiv / out (REL...), plain channels (FWD_DUAL)
+    const int ncol = a.oc_split;
     const unsigned P = (unsigned)a.pix_per_map;
-    float bias = 0.f;
-    if (EPI == EPI_FWD_DUAL || EPI == EPI_PLAIN) bias = (a.bias && oc < ncol) ? a.bias[oc] : 0.f;
     constexpr bool NEEDS_X = (EPI == EPI_REL || EPI == EPI_GUIDED || EPI == EPI_FIRST);
-    bool ok[16];
-    unsigned nn[16], pp[16];
-    float xv[16], zv[16], uv[16], x3[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int q = cx.q0 + 32 * j + (e & 3) + 8 * (e >> 2);
         const long gp = cx.pix0 + q;
-        ok[e] = gp < cx.total_pix;
         unsigned n, p;   // map index and pixel-in-map (32-bit; constant divisors for the conv case)
         if (TAPS == 9) {
-            const unsigned r = (unsigned)q / (unsigned)HW, c = (unsigned)q - r * HW;
-            const unsigned g = (unsigned)cx.g0 + r;
+            const unsigned rr = (unsigned)q / (unsigned)HW, c = (unsigned)q - rr * HW;
+            const unsigned g = (unsigned)cx.g0 + rr;
             n = g / (unsigned)HW;
             p = (g - n * HW) * HW + c;
         } else {
             n = (unsigned)gp / P;
             p = (unsigned)gp - n * P;
         }
-        nn[e] = n; pp[e] = p;
-        xv[e] = 0.f; zv[e] = 1.f; uv[e] = 0.f; x3[e] = 0.f;
-        if (NEEDS_X && ok[e] && oc < ncol) {
+        r.nn[e] = n; r.pp[e] = p;
+        r.xv[e] = 0.f; r.zv[e] = 1.f; r.x3[e] = 0.f;
+        if (NEEDS_X && gp < cx.total_pix && oc < ncol) {
             const long img = m2i ? m2i[n] : n;
             const long xi = (img * P + p) * ncol + oc;
-            xv[e] = X[xi];
-            if (EPI == EPI_REL && Zd && o1) zv[e] = Zd[xi];
-            if (EPI == EPI_REL && Uu) uv[e] = Uu[(long)n * ncol + oc];
-            if (EPI == EPI_FIRST && oc < 3) x3[e] = X[xi + 3];
+            r.xv[e] = X[xi];
+            if (EPI == EPI_REL && Zd && a.out1) r.zv[e] = Zd[xi];
+            if (EPI == EPI_FIRST && oc < 3) r.x3[e] = X[xi + 3];
         }
     }
+}
+
+template <int EPI, int HW, int TAPS>
+__device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, const int j, const f32x16 accj,
+                                           const EpiRegs& r) {
+    float* __restrict__ o0 = a.out0;
+    float* __restrict__ o1 = a.out1;
+    const float* __restrict__ Uu = a.U;     // per-(map, channel) addend: only the small decoder GEMMs use it
+    const int oc = cx.oc;
+    const int ncol = a.oc_split;   // real channels of X / Zdiv / out (REL...), plain channels (FWD_DUAL)
+    const unsigned P = (unsigned)a.pix_per_map;
+    float bias = 0.f;
+    if (EPI == EPI_FWD_DUAL || EPI == EPI_PLAIN) bias = (a.bias && oc < ncol) ? a.bias[oc] : 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int q = cx.q0 + 32 * j + (e & 3) + 8 * (e >> 2);
         const long gp = cx.pix0 + q;
+        const bool ok = gp < cx.total_pix;
         float v = accj[e];
         if (EPI == EPI_FIRST) {
             // channels 0..2 carry convT(S, W+), 3..5 convT(S, W-); combine across lanes of the same half
             const int li = cx.lane & 31;
             const float other = __shfl(v, (cx.lane & 32) + ((li + 3) & 31), 64);
-            if (ok[e] && oc < 3) o0[((long)nn[e] * 3 + oc) * P + pp[e]] = xv[e] * v + x3[e] * other;   // NCHW
+            if (ok && oc < 3) o0[((long)r.nn[e] * 3 + oc) * P + r.pp[e]] = r.xv[e] * v + r.x3[e] * other;   // NCHW
             continue;
         }
-        if (!ok[e]) continue;
+        if (!ok) continue;
         if (EPI == EPI_FWD_DUAL) {
             if (oc < ncol) {
                 v += bias;
@@ -152,12 +162,14 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const EpiCtx& c
             }
         } else if (EPI == EPI_REL) {
             if (oc < ncol) {
-                const float r = xv[e] * (v + uv[e]);
-                if (o0) o0[gp * ncol + oc] = r;
+                if (Uu) v += Uu[(TAPS == 9 ? (long)(((unsigned)cx.g0 + (unsigned)q / (unsigned)HW) / (unsigned)HW)
+                                           : (long)((unsigned)gp / P)) * ncol + oc];
+                const float rel = r.xv[e] * v;
+                if (o0) o0[gp * ncol + oc] = rel;
                 if (o1) {
-                    float z = zv[e];
+                    float z = r.zv[e];
                     z = (a.stab == STAB_SAFE) ? stab_safe(z) : ((a.stab == STAB_EPS) ? stab_eps(z) : z);
-                    o1[gp * ncol + oc] = r / z;
+                    o1[gp * ncol + oc] = rel / z;
                 }
             }
         } else if (EPI == EPI_PLAIN) {
@@ -167,7 +179,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const EpiCtx& c
                 o0[gp * ncol + oc] = v;
             }
         } else {   // EPI_GUIDED: ReLU hook of the layer below, out = max(g,0) * [y > 0]
-            if (oc < ncol) o0[gp * ncol + oc] = (xv[e] > 0.f && v > 0.f) ? v : 0.f;
+            if (oc < ncol) o0[gp * ncol + oc] = (r.xv[e] > 0.f && v > 0.f) ? v : 0.f;
         }
     }
 }
@@ -329,15 +341,23 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
     cx.g0 = (int)g0;
     cx.pix0 = (TAPS == 9) ? g0 * W : (long)mtile * C::PIX;
     cx.total_pix = total_pix;
-    // written out: the pragma-unroll budget refuses a 7 x 16-element body, and a rolled loop would
-    // index acc[] dynamically (accumulators in scratch)
-    epilogue_tile<EPI, HW, TAPS>(a, cx, 0, acc[0]);
-    epilogue_tile<EPI, HW, TAPS>(a, cx, 1, acc[1]);
-    epilogue_tile<EPI, HW, TAPS>(a, cx, 2, acc[2]);
-    epilogue_tile<EPI, HW, TAPS>(a, cx, 3, acc[3]);
-    epilogue_tile<EPI, HW, TAPS>(a, cx, 4, acc[4]);
-    epilogue_tile<EPI, HW, TAPS>(a, cx, 5, acc[5]);
-    epilogue_tile<EPI, HW, TAPS>(a, cx, 6, acc[6]);
+    // written out (a rolled loop would index acc[] dynamically -> accumulators in scratch) and software-pipelined:
+    // the loads of tile j+1 are in flight while tile j is finished
+    EpiRegs ra, rb;
+    epi_gather<EPI, HW, TAPS>(a, cx, 0, ra);
+    epi_gather<EPI, HW, TAPS>(a, cx, 1, rb);
+    epi_finish<EPI, HW, TAPS>(a, cx, 0, acc[0], ra);
+    epi_gather<EPI, HW, TAPS>(a, cx, 2, ra);
+    epi_finish<EPI, HW, TAPS>(a, cx, 1, acc[1], rb);
+    epi_gather<EPI, HW, TAPS>(a, cx, 3, rb);
+    epi_finish<EPI, HW, TAPS>(a, cx, 2, acc[2], ra);
+    epi_gather<EPI, HW, TAPS>(a, cx, 4, ra);
+    epi_finish<EPI, HW, TAPS>(a, cx, 3, acc[3], rb);
+    epi_gather<EPI, HW, TAPS>(a, cx, 5, rb);
+    epi_finish<EPI, HW, TAPS>(a, cx, 4, acc[4], ra);
+    epi_gather<EPI, HW, TAPS>(a, cx, 6, ra);
+    epi_finish<EPI, HW, TAPS>(a, cx, 5, acc[5], rb);
+    epi_finish<EPI, HW, TAPS>(a, cx, 6, acc[6], ra);
 }
 
 }  // namespace lrpx

@@ -171,50 +171,55 @@ __global__ void gridtd_fwd_lstm_kernel(GridFwd g, int t, const float* __restrict
     }
 }
 
-// AdaptiveAttention.forward (models/gridTDmodel.py:71-103) for one image per block (256 threads) and
-// xh2[b,t] = [ctx_hat | h1_new | h2_old].  att_img = W_v_proj(V)+b_v is time-invariant and precomputed.
-__global__ __launch_bounds__(256) void gridtd_fwd_attention_kernel(
-    GridFwd g, int t, const float* __restrict__ Vp, const float* __restrict__ att_img,
-    const float* __restrict__ Wg, const float* __restrict__ Ws, const float* __restrict__ bs,
-    const float* __restrict__ wh) {
+// AdaptiveAttention.forward (models/gridTDmodel.py:71-103), two kernels so that B images fill the chip:
+//  (1) scores: grid (B, pixel blocks): h_proj[k] = W_g[k].h1, s_proj[k] = W_s[k].s + b_s[k],
+//      z[k] = w_h . tanh(att_img[k,:] + h_proj[k])   (ht_proj is broadcast along the row, :82);
+//      att_img = W_v_proj(V)+b_v is time-invariant and precomputed.
+//  (2) context: grid (B, channel blocks): sentinel score, both softmaxes, context, c_hat and
+//      xh2[b,t] = [ctx_hat | h1_new | h2_old].
+constexpr int ATT_PB = 28;    // pixels per block in (1)
+constexpr int ATT_CB = 128;   // channels per block in (2)
+
+__global__ __launch_bounds__(256) void gridtd_fwd_att_scores_kernel(
+    GridFwd g, int t, const float* __restrict__ att_img, const float* __restrict__ Wg, const float* __restrict__ Ws,
+    const float* __restrict__ bs, const float* __restrict__ wh, float* __restrict__ scr) {
     extern __shared__ float sm[];
-    const int b = blockIdx.x, H = g.H, P = g.P, tid = threadIdx.x;
-    float* h1n = sm;            // H
-    float* sv = h1n + H;        // H
-    float* hproj = sv + H;      // P
-    float* zsc = hproj + P;     // P+1 scores
-    float* alpha = zsc + P + 1; // P
-    float* red = alpha + P;     // 8
+    const int b = blockIdx.x, H = g.H, P = g.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* h1n = sm;          // H
+    float* sv = h1n + H;      // H
     const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = ((long)b * g.T + t) * H;
     for (int c = tid; c < H; c += 256) { h1n[c] = g.h1[st1 + c]; sv[c] = g.s[tr + c]; }
     __syncthreads();
-    const int lane = tid & 63, wv = tid >> 6;
-    // h_proj = W_g h1 ; sproj = W_s s + b_s   (one wave per output row)
-    float* sproj = alpha;   // reuse alpha storage for sproj until softmax
-    for (int k = wv; k < P; k += 4) {
+    float* zsc = scr + (long)b * 3 * P;       // [z | h_proj | s_proj]
+    const int k0 = blockIdx.y * ATT_PB, k1 = min(k0 + ATT_PB, P);
+    for (int k = k0 + wv; k < k1; k += 4) {
         float a = 0.f, c2 = 0.f;
         for (int c = lane; c < H; c += 64) { a += Wg[(long)k * H + c] * h1n[c]; c2 += Ws[(long)k * H + c] * sv[c]; }
         a = wave_sum(a); c2 = wave_sum(c2);
-        if (lane == 0) { hproj[k] = a; sproj[k] = c2 + bs[k]; }
+        float z = 0.f;
+        for (int j = lane; j < P; j += 64) z += wh[j] * tanhf(att_img[((long)b * P + k) * P + j] + a);
+        z = wave_sum(z);
+        if (lane == 0) { zsc[k] = z; zsc[P + k] = a; zsc[2 * P + k] = c2 + bs[k]; }
     }
-    __syncthreads();
-    // z[k] = w_h . tanh(att_img[k,:] + hproj[k])  (ht_proj is broadcast along the row, :82)
-    for (int k = wv; k < P; k += 4) {
+}
+
+__global__ __launch_bounds__(256) void gridtd_fwd_att_context_kernel(GridFwd g, int t, const float* __restrict__ Vp,
+                                                                     const float* __restrict__ wh,
+                                                                     const float* __restrict__ scr) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, H = g.H, P = g.P, tid = threadIdx.x;
+    float* zsc = sm;            // P+1
+    float* alpha = zsc + P + 1; // P
+    float* red = alpha + P;     // 8
+    const float* sc = scr + (long)b * 3 * P;
+    for (int k = tid; k < P; k += 256) zsc[k] = sc[k];
+    {   // sentinel score = w_h . tanh(s_proj + h_proj)   (:94)
         float a = 0.f;
-        const float hp = hproj[k];
-        for (int j = lane; j < P; j += 64) a += wh[j] * tanhf(att_img[((long)b * P + k) * P + j] + hp);
-        a = wave_sum(a);
-        if (lane == 0) zsc[k] = a;
-    }
-    // sentinel score = w_h . tanh(sproj + hproj)
-    {
-        float a = 0.f;
-        for (int j = tid; j < P; j += 256) a += wh[j] * tanhf(sproj[j] + hproj[j]);
+        for (int j = tid; j < P; j += 256) a += wh[j] * tanhf(sc[2 * P + j] + sc[P + j]);
         a = block_sum(a, red);
         if (tid == 0) zsc[P] = a;
     }
     __syncthreads();
-    // softmax over P (alpha) and over P+1 (beta = last)
     float m = -INFINITY;
     for (int k = tid; k < P; k += 256) m = fmaxf(m, zsc[k]);
     m = block_max(m, red);
@@ -230,18 +235,23 @@ __global__ __launch_bounds__(256) void gridtd_fwd_attention_kernel(
     for (int k = tid; k < P; k += 256) {
         const float a = expf(zsc[k] - m) / denom;
         alpha[k] = a;
-        g.alpha[((long)b * g.T + t) * P + k] = a;
+        if (blockIdx.y == 0) g.alpha[((long)b * g.T + t) * P + k] = a;
     }
-    if (tid == 0) g.beta[(long)b * g.T + t] = beta;
+    if (tid == 0 && blockIdx.y == 0) g.beta[(long)b * g.T + t] = beta;
     __syncthreads();
-    float* x2 = g.xh2 + ((long)b * g.T + t) * 3 * H;
-    const long st0 = ((long)b * (g.T + 1) + t) * H;
-    for (int c = tid; c < H; c += 256) {
-        float a = 0.f;
-        for (int k = 0; k < P; ++k) a += Vp[((long)b * P + k) * H + c] * alpha[k];
-        const float ch = beta * sv[c] + (1.f - beta) * a;
+    // context for this block's channels: 2 threads per channel split the pixels
+    const int c = blockIdx.y * ATT_CB + (tid >> 1), half = tid & 1;
+    float a = 0.f;
+    if (c < H)
+        for (int k = half; k < P; k += 2) a += Vp[((long)b * P + k) * H + c] * alpha[k];
+    a += __shfl_xor(a, 1, 64);
+    if (c < H && half == 0) {
+        const long tr = ((long)b * g.T + t) * H, st0 = ((long)b * (g.T + 1) + t) * H;
+        const float sv = g.s[tr + c], h1n = g.h1[st0 + H + c];
+        const float ch = beta * sv + (1.f - beta) * a;
+        float* x2 = g.xh2 + ((long)b * g.T + t) * 3 * H;
         g.ctx[tr + c] = a; g.ctx_hat[tr + c] = ch;
-        x2[c] = ch; x2[H + c] = h1n[c]; x2[2 * H + c] = g.h2[st0 + c];
+        x2[c] = ch; x2[H + c] = h1n; x2[2 * H + c] = g.h2[st0 + c];
     }
 }
 
@@ -820,13 +830,17 @@ int lrpx_gridtd_fwd_lstm(const lrpx_gridtd_trace* tr, int t, const float* zz, in
 }
 
 int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img,
-                              const float* Wg, const float* Ws, const float* bs, const float* wh, void* stream) {
+                              const float* Wg, const float* Ws, const float* bs, const float* wh, float* scratch,
+                              void* stream) {
     LRPX_TRY(check_trace(tr));
-    LRPX_REQUIRE(Vp && att_img && Wg && Ws && bs && wh && t >= 0 && t < tr->T, "gridtd_fwd_attention: bad arguments");
-    const size_t lds = (size_t)(2 * tr->H + 3 * tr->P + 1 + 8) * sizeof(float);
-    hipLaunchKernelGGL(gridtd_fwd_attention_kernel, dim3(tr->B), dim3(256), lds, (hipStream_t)stream, to_fwd(tr), t, Vp,
-                       att_img, Wg, Ws, bs, wh);
-    return check_launch("gridtd_fwd_attention");
+    LRPX_REQUIRE(Vp && att_img && Wg && Ws && bs && wh && scratch && t >= 0 && t < tr->T, "gridtd_fwd_attention: bad arguments");
+    const GridFwd g = to_fwd(tr);
+    hipLaunchKernelGGL(gridtd_fwd_att_scores_kernel, dim3(tr->B, (tr->P + ATT_PB - 1) / ATT_PB), dim3(256),
+                       (size_t)2 * tr->H * sizeof(float), (hipStream_t)stream, g, t, att_img, Wg, Ws, bs, wh, scratch);
+    LRPX_TRY(check_launch("gridtd_fwd_att_scores"));
+    hipLaunchKernelGGL(gridtd_fwd_att_context_kernel, dim3(tr->B, (tr->H + ATT_CB - 1) / ATT_CB), dim3(256),
+                       (size_t)(2 * tr->P + 1 + 8) * sizeof(float), (hipStream_t)stream, g, t, Vp, wh, scratch);
+    return check_launch("gridtd_fwd_att_context");
 }
 
 int lrpx_target_logit(const float* hc, const float* fcw, const float* fcb, const long long* tok, int tok_ld,

@@ -130,15 +130,20 @@ class GridTDEngine:
         check(lib.lrpx_gridtd_fwd_pre(c, t, ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(tokens),
                                       tokens.shape[1], st))
         W1 = 2 * E + 2 * H
-        zz1 = tr.setdefault("_zz1", torch.empty(B, 5 * H, device=self.device))
+        if "_zz1" not in tr:
+            tr["_zz1"] = torch.empty(B, 5 * H, device=self.device)
+            tr["_zz2"] = torch.empty(B, 4 * H, device=self.device)
+            tr["_att_scr"] = torch.empty(B, 3 * self.P, device=self.device)
+        zz1 = tr["_zz1"]
         check(lib.lrpx_linear_small(ptr_at(tr["xh1"], t * W1), T * W1, ptr(self.Wcat1), ptr(self.bcat1), ptr(zz1),
                                     5 * H, B, W1, 5 * H, 0, st))
         check(lib.lrpx_gridtd_fwd_lstm(c, t, ptr(zz1), 5 * H, 1, st))
         aa = "AdaAttention."
+        scr = tr["_att_scr"]
         check(lib.lrpx_gridtd_fwd_attention(c, t, ptr(enc["Vp"]), ptr(enc["att_img"]), ptr(sd[aa + "W_g_proj.weight"]),
                                             ptr(sd[aa + "W_s_proj.weight"]), ptr(sd[aa + "W_s_proj.bias"]),
-                                            ptr(sd[aa + "w_h.weight"]), st))
-        zz2 = tr.setdefault("_zz2", torch.empty(B, 4 * H, device=self.device))
+                                            ptr(sd[aa + "w_h.weight"]), ptr(scr), st))
+        zz2 = tr["_zz2"]
         b2 = self.bcat2_model if model_bias else self.bcat2_explainer
         check(lib.lrpx_linear_small(ptr_at(tr["xh2"], t * 3 * H), T * 3 * H, ptr(self.Wcat2), ptr(b2), ptr(zz2), 4 * H,
                                     B, 3 * H, 4 * H, 0, st))
@@ -246,6 +251,35 @@ class GridTDEngine:
                       x=enc["feats"], u=U, map2img=row2img, out0=r_feat)
         check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
         return r_feat, rs["r_words"], row2img
+
+    def explain_batch_graph(self, images, captions, accumulate=False):
+        """`explain_batch` replayed from a captured HIP graph (one graph per (B,T) shape): the ~450 kernel launches
+        of a step (decoder trace and lock-step relevance are launch-bound) are issued by one hipGraphLaunch instead
+        of the Python loop.  Inputs are copied into the graph's static buffers; the returned tensors are the graph's
+        static outputs (overwritten by the next call with the same shape)."""
+        images = images.to(self.device, torch.float32)
+        captions = captions.to(self.device, torch.int64)
+        key = (tuple(images.shape), tuple(captions.shape), bool(accumulate))
+        g = self._graphs.get(key) if hasattr(self, "_graphs") else None
+        if g is None:
+            if not hasattr(self, "_graphs"):
+                self._graphs = {}
+            st_img, st_cap = images.clone(), captions.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                       # warm-up outside capture (kernel attributes, caches)
+                self.explain_batch(st_img, st_cap, accumulate=accumulate)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.explain_batch(st_img, st_cap, accumulate=accumulate)
+            g = self._graphs[key] = (graph, st_img, st_cap, out)
+        graph, st_img, st_cap, out = g
+        st_img.copy_(images)
+        st_cap.copy_(captions)
+        graph.replay()
+        return out
 
     def guided_gradient(self, enc, tr, lens=None):
         """ExplainiGridTDGuidedGradient.explain_caption_wordt (gridTDmodel.py:1588-1675) for every (image, word)
