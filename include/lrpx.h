@@ -60,10 +60,11 @@ enum { LRPX_EPI_FWD_DUAL = 0, LRPX_EPI_REL = 1, LRPX_EPI_FIRST = 2, LRPX_EPI_PLA
 enum { LRPX_STAB_NONE = 0, LRPX_STAB_SAFE = 1, LRPX_STAB_EPS = 2 };
 
 typedef struct lrpx_conv_desc {
-    const float* in;      /* [n_maps*pix_per_map][cin] */
+    const float* in;      /* [n_maps*pix_per_map][cin], or channel-chunked [cin/kc][n_maps*pix_per_map][kc] if in_chunked */
     const float* wpacked; /* from lrpx_pack_weights with kc = lrpx_conv_kc(hw,taps,cin) */
     int n_maps, hw, cin, n_oc, taps, pix_per_map;
     int epi, stab, oc_split, relu;
+    int in_chunked;       /* input stored in K-chunks of lrpx_conv_kc(hw,taps,cin) channels (see lrpx_maxpool2x2_relevance) */
     const float* bias;
     const float* x;
     const float* u;
@@ -88,9 +89,12 @@ int lrpx_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, vo
 /* Pool2d.propagate_relevance (LRPtools/lrp_modules.py:182-195) fused with the division by the
  * conv layer below:  r_in = x * [argmax] * (r_out / safe(max));  s_out = r_in / safe(zdiv).
  * x, zdiv: per IMAGE (n_img,2h,2w,c); r_out: per MAP (n_maps,h,w,c); outputs per map at 2h x 2w.
- * r_in / s_out may be null (skip).  zdiv may be null (then s_out = r_in). */
+ * r_in / s_out may be null (skip).  zdiv may be null (then s_out = r_in).
+ * s_chunk > 0: s_out is written channel-chunked [c/s_chunk][n_maps*2h*2w][s_chunk] (s_chunk = 8), the layout
+ * lrpx_conv_mfma reads with in_chunked=1: whole 128-byte lines per chunk instead of 32-byte slices of every pixel. */
 int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* zdiv, const int32_t* map2img,
-                              float* r_in, float* s_out, int n_maps, int h_out, int w_out, int c, void* stream);
+                              float* r_in, float* s_out, int n_maps, int h_out, int w_out, int c, int s_chunk,
+                              void* stream);
 /* s[n,p,c] = r[n,p,c] / stab(z[img(n),p,c])   (LRPtools/utils.py:16-18 safe_divide with broadcast) */
 int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c,
                      int stab, void* stream);

@@ -48,7 +48,7 @@ class AoaRelState(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("in_", _f), ("wpacked", _f),
                 ("n_maps", _i), ("hw", _i), ("cin", _i), ("n_oc", _i), ("taps", _i), ("pix_per_map", _i),
-                ("epi", _i), ("stab", _i), ("oc_split", _i), ("relu", _i),
+                ("epi", _i), ("stab", _i), ("oc_split", _i), ("relu", _i), ("in_chunked", _i),
                 ("bias", _f), ("x", _f), ("u", _f), ("zdiv", _f), ("map2img", _f),
                 ("out0", _f), ("out1", _f)]
 
@@ -65,7 +65,7 @@ SIGNATURES = {
     "lrpx_nhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "lrpx_nchw_to_nhwc_posneg": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "lrpx_maxpool2x2_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f]),
-    "lrpx_maxpool2x2_relevance": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_maxpool2x2_relevance": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "lrpx_divide_stab": (_i, [_f, _f, _f, _f, _i, _l, _i, _f]),
     "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),
     "lrpx_accumulate": (_i, [_f, _f, _l, _f]),

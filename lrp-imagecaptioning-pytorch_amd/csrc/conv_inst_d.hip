@@ -3,5 +3,5 @@
 namespace lrpx {
 int launch_conv_14_16_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<14, 16, 1, 4, 9, EPI_FWD_DUAL>(a, s); }
 int launch_conv_14_16_1_4_9_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<14, 16, 1, 4, 9, EPI_REL>(a, s); }
-int launch_conv_224_8_4_2_9_guided(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<224, 8, 4, 2, 9, EPI_GUIDED>(a, s); }
+int launch_conv_224_8_2_2_9_guided(const ConvArgs& a, hipStream_t s) { return launch_conv_cfg<224, 8, 2, 2, 9, EPI_GUIDED>(a, s); }
 }

@@ -33,7 +33,7 @@ int launch_conv_cfg(const ConvArgs& a, hipStream_t stream) {
 
 // one function per instantiation, defined in conv_inst_*.hip
 int launch_conv_224_8_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
-int launch_conv_224_8_4_2_9_rel(const ConvArgs& a, hipStream_t s);
+int launch_conv_224_8_2_2_9_rel(const ConvArgs& a, hipStream_t s);
 int launch_conv_112_8_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
 int launch_conv_112_8_1_4_9_rel(const ConvArgs& a, hipStream_t s);
 int launch_conv_112_8_2_2_9_rel(const ConvArgs& a, hipStream_t s);
@@ -43,7 +43,7 @@ int launch_conv_28_16_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
 int launch_conv_28_16_1_4_9_rel(const ConvArgs& a, hipStream_t s);
 int launch_conv_14_16_1_4_9_fwd_dual(const ConvArgs& a, hipStream_t s);
 int launch_conv_14_16_1_4_9_rel(const ConvArgs& a, hipStream_t s);
-int launch_conv_224_8_4_2_9_guided(const ConvArgs& a, hipStream_t s);
+int launch_conv_224_8_2_2_9_guided(const ConvArgs& a, hipStream_t s);
 int launch_conv_14_32_1_4_1_rel(const ConvArgs& a, hipStream_t s);
 int launch_conv_14_32_1_4_1_plain(const ConvArgs& a, hipStream_t s);
 int launch_conv_112_8_1_4_9_guided(const ConvArgs& a, hipStream_t s);

@@ -36,6 +36,8 @@ enum Stab : int { STAB_NONE = 0, STAB_SAFE = 1, STAB_EPS = 2 };
 
 struct ConvArgs {
     const float* in;        // [n_maps*P][cin]  A operand (already S = R/Z for relevance passes)
+    long in_chunk_stride;   // 0: pixel-major NHWC.  >0: channel-chunked [cin/KC][n_maps*P][KC], stride between chunks
+                            // in floats (every staged chunk row is then one contiguous stream: no partial lines)
     const float* wp;        // packed weights  [n_ocb][nchunk][taps][KC/8][64][4]
     int n_maps;             // maps (images) in `in`
     int cin;                // input channels (multiple of KC)
@@ -70,7 +72,11 @@ struct ConvCfg {
     // rows of the tile + a halo row above/below + one zero row per map boundary that can fall inside the tile
     // (none when tiles are aligned to maps, H % R == 0)
     static constexpr int NSLOT = (TAPS == 9) ? R + 2 + ((H % (R ? R : 1) == 0) ? 0 : (R - 1 + H - 1) / H) : 0;
-    static constexpr int STRIDE = KC + 4;                // floats per LDS pixel (pad: conflict-free b128)
+    // floats per LDS pixel.  KC >= 16: padded by 4 (conflict-free ds_read_b128).  KC == 8: un-padded 32-byte pixels,
+    // the two 16-byte halves XOR-swizzled with bit 3 of the pixel index (equally conflict-free, 1/3 less LDS, so the
+    // double-buffered tiles of the 224^2 / 112^2 layers leave room for two workgroups per CU)
+    static constexpr bool SWZ = (KC == 8);
+    static constexpr int STRIDE = SWZ ? 8 : KC + 4;
     static constexpr int LDS_PIX = (TAPS == 9) ? NSLOT * WP : PIX;
     static constexpr int LDS_BYTES = 2 * LDS_PIX * STRIDE * 4;   // double-buffered A tile
     static constexpr int NT = 64 * MT * NWN;
@@ -81,7 +87,14 @@ struct ConvCfg {
 struct EpiCtx {
     int oc, lane, q0, g0;
     long pix0, total_pix;
+    long xi_base;   // aligned tiles: index into X / Zdiv of (pixel q0, channel oc); later pixels are + dq * ncol
 };
+
+// r / z with one v_rcp_f32 + multiply (~1.5 ulp) instead of the ~10-instruction IEEE sequence; falls back to the exact
+// division where 1/z would overflow (z in the denormal range)
+__device__ __forceinline__ float fast_div(float r, float z) {
+    return fabsf(z) > 1e-30f ? r * __builtin_amdgcn_rcpf(z) : r / z;
+}
 
 // Epilogue, per 32x32 accumulator tile j: accj[e] is pixel q = q0 + 32*j + (e&3) + 8*(e>>2), channel cx.oc.
 // Split in two so the kernel can software-pipeline it: `epi_gather` does the index math and ALL global loads of the
@@ -93,7 +106,10 @@ struct EpiRegs {
     unsigned nn[16], pp[16];
 };
 
-template <int EPI, int HW, int TAPS>
+// ALIGNED (conv tiles that never straddle two maps, H % R == 0): every pixel of the workgroup tile belongs to one map,
+// so X / Zdiv / out indices are linear in the tile pixel index — one multiply-add per element instead of the
+// divide/modulo chain (the epilogue's VALU count rivals the MFMA count on the K = 576 layer otherwise).
+template <int EPI, int HW, int TAPS, bool ALIGNED>
 __device__ __forceinline__ void epi_gather(const ConvArgs& a, const EpiCtx& cx, const int j, EpiRegs& r) {
     const float* __restrict__ X = a.X;
     const float* __restrict__ Zd = a.Zdiv;
@@ -102,6 +118,43 @@ __device__ __forceinline__ void epi_gather(const ConvArgs& a, const EpiCtx& cx, 
     const int ncol = a.oc_split;
     const unsigned P = (unsigned)a.pix_per_map;
     constexpr bool NEEDS_X = (EPI == EPI_REL || EPI == EPI_GUIDED || EPI == EPI_FIRST);
+    if constexpr (ALIGNED && EPI != EPI_FIRST) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            r.xv[e] = 0.f; r.zv[e] = 1.f;
+            if (NEEDS_X && oc < ncol) {
+                const long xi = cx.xi_base + (32 * j + (e & 3) + 8 * (e >> 2)) * ncol;
+                r.xv[e] = X[xi];
+                if (EPI == EPI_REL && Zd && a.out1) r.zv[e] = Zd[xi];
+            }
+        }
+        return;
+    }
+    if constexpr (TAPS == 9 && EPI != EPI_FIRST) {
+        // conv tiles that may straddle a map boundary (28x28, 14x14): a 32-pixel accumulator tile is shorter than a
+        // map (P >= 196), so it holds at most ONE boundary: one divide/modulo per tile, then linear indices on
+        // either side of it
+        const unsigned q0t = (unsigned)(cx.q0 + 32 * j);
+        const unsigned rr = q0t / (unsigned)HW, c0 = q0t - rr * HW;
+        const unsigned g = (unsigned)cx.g0 + rr;
+        const unsigned n0 = g / (unsigned)HW;
+        const int p0 = (int)((g - n0 * HW) * HW + c0);
+        const int nmax = a.n_maps - 1;
+        const long img0 = m2i ? m2i[min((int)n0, nmax)] : n0;
+        const long img1 = m2i ? m2i[min((int)n0 + 1, nmax)] : n0 + 1;
+        const long b0 = (img0 * P + p0) * ncol + oc, b1 = (img1 * P + p0 - (long)P) * ncol + oc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int dq = (e & 3) + 8 * (e >> 2);
+            r.xv[e] = 0.f; r.zv[e] = 1.f;
+            if (NEEDS_X && oc < ncol && cx.pix0 + q0t + dq < cx.total_pix) {
+                const long xi = (p0 + dq < (int)P ? b0 : b1) + dq * ncol;
+                r.xv[e] = X[xi];
+                if (EPI == EPI_REL && Zd && a.out1) r.zv[e] = Zd[xi];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int q = cx.q0 + 32 * j + (e & 3) + 8 * (e >> 2);
@@ -128,7 +181,7 @@ __device__ __forceinline__ void epi_gather(const ConvArgs& a, const EpiCtx& cx, 
     }
 }
 
-template <int EPI, int HW, int TAPS>
+template <int EPI, int HW, int TAPS, bool ALIGNED>
 __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, const int j, const f32x16 accj,
                                            const EpiRegs& r) {
     float* __restrict__ o0 = a.out0;
@@ -143,7 +196,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
     for (int e = 0; e < 16; ++e) {
         const int q = cx.q0 + 32 * j + (e & 3) + 8 * (e >> 2);
         const long gp = cx.pix0 + q;
-        const bool ok = gp < cx.total_pix;
+        const bool ok = ALIGNED || gp < cx.total_pix;      // aligned tiles are never partial
         float v = accj[e];
         if (EPI == EPI_FIRST) {
             // channels 0..2 carry convT(S, W+), 3..5 convT(S, W-); combine across lanes of the same half
@@ -169,7 +222,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
                 if (o1) {
                     float z = r.zv[e];
                     z = (a.stab == STAB_SAFE) ? stab_safe(z) : ((a.stab == STAB_EPS) ? stab_eps(z) : z);
-                    o1[gp * ncol + oc] = rel / z;
+                    o1[gp * ncol + oc] = fast_div(rel, z);
                 }
             }
         } else if (EPI == EPI_PLAIN) {
@@ -221,7 +274,8 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
             int r = q / W, c = q % W;
             long g = g0 + r;
             int slot = (int)(g + g / H - v0) + 1;           // LDS row holding this pixel's own image row
-            abase[j] = ((slot - 1) * WP + c) * STRIDE + lh * 4;   // top-left corner of its 3x3 window
+            abase[j] = C::SWZ ? ((slot - 1) * WP + c)                       // pixel index of the window corner
+                              : ((slot - 1) * WP + c) * STRIDE + lh * 4;    // float offset of the window corner
         }
     } else {
 #pragma unroll
@@ -251,7 +305,8 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
                 const long n = v_ / (H + 1);
                 const int y = (int)(v_ - n * (H + 1));
                 if ((v_ >= 0) && (y < H) && (n < a.n_maps)) {
-                    sdst[u] = (s * WP + px + 1) * STRIDE + seg * 4;
+                    const int lp = s * WP + px + 1;
+                    sdst[u] = C::SWZ ? lp * 8 + ((seg ^ ((lp >> 3) & 1)) << 2) : lp * STRIDE + seg * 4;
                     sgp[u] = (int)((n * H + y) * W + px);
                 }
             } else {
@@ -268,7 +323,9 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
         sv[u] = f32x4{0, 0, 0, 0};                                                                           \
         if (sgp[u] >= 0)                                                                                     \
-            sv[u] = *reinterpret_cast<const f32x4*>(a.in + (long)sgp[u] * a.cin + (CHUNK) * KC + ((sdst[u] >> 28) & 7) * 4); \
+            sv[u] = *reinterpret_cast<const f32x4*>(                                                         \
+                a.in_chunk_stride ? a.in + (CHUNK) * a.in_chunk_stride + (long)sgp[u] * KC + ((sdst[u] >> 28) & 7) * 4 \
+                                  : a.in + (long)sgp[u] * a.cin + (CHUNK) * KC + ((sdst[u] >> 28) & 7) * 4);  \
     }
 #define LRPX_STAGE_COMMIT(BUFIDX)                                                                            \
     _Pragma("unroll") for (int u = 0; u < U; ++u)                                                            \
@@ -306,15 +363,24 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
             const int g0step = chunk * STEPS;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
-                const int tapoff = (TAPS == 9) ? ((tap / 3) * WP + (tap % 3)) * STRIDE : 0;
+                const int tappix = (TAPS == 9) ? (tap / 3) * WP + (tap % 3) : 0;   // tap shift in pixels
+                const int tapoff = tappix * STRIDE;
 #pragma unroll
                 for (int ks = 0; ks < C::KSTEPS; ++ks) {
                     const int step = tap * C::KSTEPS + ks;
                     bq[NB - 1] = wp[(long)min(g0step + step + NB - 1, last_step) * 64];   // NB-1 steps ahead
                     f32x4 av[7];
 #pragma unroll
-                    for (int j = 0; j < 7; ++j)
-                        av[j] = *reinterpret_cast<const f32x4*>(abuf + abase[j] + tapoff + ks * 8);
+                    for (int j = 0; j < 7; ++j) {
+                        if constexpr (C::SWZ) {
+                            int corner = abase[j];
+                            asm volatile("" : "+v"(corner));   // keep the 63 (tile, tap) addresses out of registers:
+                            const int lp = corner + tappix;    // they are loop-invariant and would be hoisted + spilled
+                            av[j] = *reinterpret_cast<const f32x4*>(abuf + lp * 8 + ((((lp >> 3) & 1) ^ lh) << 2));
+                        } else {
+                            av[j] = *reinterpret_cast<const f32x4*>(abuf + abase[j] + tapoff + ks * 8);
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < 7; ++j)
 #pragma unroll
@@ -341,23 +407,32 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
     cx.g0 = (int)g0;
     cx.pix0 = (TAPS == 9) ? g0 * W : (long)mtile * C::PIX;
     cx.total_pix = total_pix;
+    cx.xi_base = 0;
     // written out (a rolled loop would index acc[] dynamically -> accumulators in scratch) and software-pipelined:
     // the loads of tile j+1 are in flight while tile j is finished
+    constexpr bool AL = (TAPS == 9) && (H % (C::R ? C::R : 1) == 0);
+    if constexpr (AL) {
+        const unsigned rr = (unsigned)cx.q0 / (unsigned)HW, cc = (unsigned)cx.q0 - rr * HW;
+        const unsigned g = (unsigned)cx.g0 + rr;
+        const unsigned n = g / (unsigned)HW;
+        const long img = a.map2img ? a.map2img[n] : n;
+        cx.xi_base = (img * a.pix_per_map + (long)((g - n * HW) * HW + cc)) * a.oc_split + cx.oc;
+    }
     EpiRegs ra, rb;
-    epi_gather<EPI, HW, TAPS>(a, cx, 0, ra);
-    epi_gather<EPI, HW, TAPS>(a, cx, 1, rb);
-    epi_finish<EPI, HW, TAPS>(a, cx, 0, acc[0], ra);
-    epi_gather<EPI, HW, TAPS>(a, cx, 2, ra);
-    epi_finish<EPI, HW, TAPS>(a, cx, 1, acc[1], rb);
-    epi_gather<EPI, HW, TAPS>(a, cx, 3, rb);
-    epi_finish<EPI, HW, TAPS>(a, cx, 2, acc[2], ra);
-    epi_gather<EPI, HW, TAPS>(a, cx, 4, ra);
-    epi_finish<EPI, HW, TAPS>(a, cx, 3, acc[3], rb);
-    epi_gather<EPI, HW, TAPS>(a, cx, 5, rb);
-    epi_finish<EPI, HW, TAPS>(a, cx, 4, acc[4], ra);
-    epi_gather<EPI, HW, TAPS>(a, cx, 6, ra);
-    epi_finish<EPI, HW, TAPS>(a, cx, 5, acc[5], rb);
-    epi_finish<EPI, HW, TAPS>(a, cx, 6, acc[6], ra);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 0, ra);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 1, rb);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 0, acc[0], ra);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 2, ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 1, acc[1], rb);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 3, rb);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 2, acc[2], ra);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 4, ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 3, acc[3], rb);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 5, rb);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 4, acc[4], ra);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 6, ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 5, acc[5], rb);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 6, acc[6], ra);
 }
 
 }  // namespace lrpx

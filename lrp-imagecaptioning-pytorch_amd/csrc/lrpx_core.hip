@@ -159,7 +159,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 __global__ void maxpool_relevance_kernel(const float* __restrict__ x, const float* __restrict__ r_out,
                                          const float* __restrict__ zdiv, const int* __restrict__ map2img,
                                          float* __restrict__ r_in, float* __restrict__ s_out, int ho, int wo, int c4,
-                                         long total) {
+                                         long total, int s_chunk4, long total_pix) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n_maps*(2ho)*(2wo)*c4
     if (idx >= total) return;
     int cc = idx % c4;
@@ -191,7 +191,14 @@ __global__ void maxpool_relevance_kernel(const float* __restrict__ x, const floa
         so[e] = zdiv ? v / stab_safe(z[e]) : v;
     }
     if (r_in) reinterpret_cast<f32x4*>(r_in)[idx] = ri;
-    if (s_out) reinterpret_cast<f32x4*>(s_out)[idx] = so;
+    if (s_out) {
+        long o = idx;
+        if (s_chunk4) {   // channel-chunked: [c4 / s_chunk4][pixel][s_chunk4] in float4 units
+            const long pix = idx / c4;
+            o = ((long)(cc / s_chunk4) * total_pix + pix) * s_chunk4 + (cc % s_chunk4);
+        }
+        reinterpret_cast<f32x4*>(s_out)[o] = so;
+    }
 }
 
 __global__ void divide_stab_kernel(const float* __restrict__ r, const float* __restrict__ z,
@@ -363,11 +370,14 @@ int lrpx_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, vo
 }
 
 int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* zdiv, const int32_t* map2img,
-                              float* r_in, float* s_out, int n_maps, int h_out, int w_out, int c, void* stream) {
+                              float* r_in, float* s_out, int n_maps, int h_out, int w_out, int c, int s_chunk,
+                              void* stream) {
     LRPX_REQUIRE(x && r_out && (r_in || s_out) && (c % 4 == 0), "maxpool2x2_relevance: bad arguments");
+    LRPX_REQUIRE(s_chunk == 0 || (s_chunk % 4 == 0 && c % s_chunk == 0), "maxpool2x2_relevance: bad s_chunk");
     long total = (long)n_maps * (2 * h_out) * (2 * w_out) * (c / 4);
     hipLaunchKernelGGL(maxpool_relevance_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, r_out,
-                       zdiv, map2img, r_in, s_out, h_out, w_out, c / 4, total);
+                       zdiv, map2img, r_in, s_out, h_out, w_out, c / 4, total, s_chunk / 4,
+                       (long)n_maps * (2 * h_out) * (2 * w_out));
     return check_launch("maxpool2x2_relevance");
 }
 

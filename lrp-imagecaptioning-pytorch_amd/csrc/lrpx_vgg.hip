@@ -18,6 +18,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     ConvArgs a;
     a.in = d->in; a.wp = d->wpacked; a.n_maps = d->n_maps; a.cin = d->cin; a.n_oc = d->n_oc;
     a.pix_per_map = d->taps == 9 ? d->hw * d->hw : d->pix_per_map;
+    a.in_chunk_stride = d->in_chunked ? (long)d->n_maps * a.pix_per_map * kc : 0;
     a.epi = d->epi; a.stab = d->stab; a.oc_split = d->oc_split; a.relu = d->relu;
     a.bias = d->bias; a.X = d->x; a.U = d->u; a.Zdiv = d->zdiv; a.map2img = d->map2img;
     a.out0 = d->out0; a.out1 = d->out1;
@@ -40,8 +41,8 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     switch (d->hw) {
         case 224:
             if (e == EPI_FWD_DUAL) return launch_conv_224_8_1_4_9_fwd_dual(a, s);
-            if (e == EPI_REL) return launch_conv_224_8_4_2_9_rel(a, s);
-            if (e == EPI_GUIDED) return launch_conv_224_8_4_2_9_guided(a, s);
+            if (e == EPI_REL) return launch_conv_224_8_2_2_9_rel(a, s);
+            if (e == EPI_GUIDED) return launch_conv_224_8_2_2_9_guided(a, s);
             break;
         case 112:
             if (e == EPI_FWD_DUAL) return launch_conv_112_8_1_4_9_fwd_dual(a, s);
@@ -245,6 +246,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
     float* S[2] = {ws, ws + sbuf};
     float* R = ws + 2 * sbuf;
     int cur = 0;
+    int cur_chunked = 0;   // S[cur] is stored in K-chunks (written so by the pool kernel for the 224^2 / 112^2 layers)
     // S_16 = R_feat / safe(Z+_16)
     LRPX_TRY(lrpx_divide_stab(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, STAB_SAFE, stream));
     for (int l = kNL - 1; l >= 0; --l) {
@@ -254,6 +256,8 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
         d.in = S[cur]; d.wpacked = pk + p.bwd[l];
         d.n_maps = n_maps; d.hw = L.hw; d.cin = L.cout; d.taps = 9; d.map2img = map2img;
         d.x = tr + t.act[l];
+        d.in_chunked = cur_chunked;
+        cur_chunked = 0;
         if (l == 0) {
             // 3 output channels: direct VALU conv (first_layer.hip) instead of a 32-wide MFMA tile
             LRPX_TRY(first_layer_relevance(S[cur], pk + p.first6, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 0,
@@ -269,8 +273,13 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             // a pool lies below: R at the pool output, then the Pool2d rule + division by Z+ of the conv under it
             d.out0 = R;
             LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
+            // wide maps: hand the conv below its input in K-chunks (32-byte pixel slices would drag every 128-byte
+            // line through the fabric four times: measured L2 hit 36 %, 3x the unique bytes on conv1_2)
+            const int below_hw = 2 * L.hw;
+            const int chunk = below_hw >= 112 ? lrpx_conv_kc(below_hw, 9, L.cin) : 0;
             LRPX_TRY(lrpx_maxpool2x2_relevance(tr + t.act[l - 1], R, tr + t.zpos[l - 2], map2img, nullptr, S[cur ^ 1],
-                                               n_maps, L.hw, L.hw, L.cin, stream));
+                                               n_maps, L.hw, L.hw, L.cin, chunk, stream));
+            cur_chunked = chunk ? 1 : 0;
         }
         cur ^= 1;
     }

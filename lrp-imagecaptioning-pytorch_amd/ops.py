@@ -76,7 +76,7 @@ def maxpool2x2_relevance(x, r_out, zdiv, map2img, n_maps, h_out, w_out, c, want_
     r_in = torch.empty(n_maps, 4 * h_out * w_out, c, dtype=torch.float32, device=x.device) if want_r else None
     s_out = torch.empty(n_maps, 4 * h_out * w_out, c, dtype=torch.float32, device=x.device) if want_s else None
     check(_lib.load().lrpx_maxpool2x2_relevance(ptr(x), ptr(r_out), ptr(zdiv), ptr(map2img), ptr(r_in), ptr(s_out),
-                                                n_maps, h_out, w_out, c, stream_ptr()))
+                                                n_maps, h_out, w_out, c, 0, stream_ptr()))
     return r_in, s_out
 
 
@@ -172,16 +172,39 @@ class Vgg16:
                                              ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
         return out
 
-    def relevance(self, r_feat_nhwc, map2img=None, out=None):
-        """compute_lrp (LRPtools/lrp_wrapper.py:63-87) for N maps: (N,196,512) -> (N,3,224,224)."""
+    def relevance(self, r_feat_nhwc, map2img=None, out=None, streams=1):
+        """compute_lrp (LRPtools/lrp_wrapper.py:63-87) for N maps: (N,196,512) -> (N,3,224,224).
+        streams=2 splits the maps over two HIP streams (maps are independent): the HBM-bound pool / first-layer
+        kernels and the tail wave of each MFMA launch of one half overlap with MFMA work of the other half."""
         lib = _lib.load()
         n_maps = r_feat_nhwc.shape[0]
-        need = lib.lrpx_vgg16_workspace_bytes(n_maps) // 4
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        r_feat_nhwc = r_feat_nhwc.contiguous()
         if out is None:
             out = torch.empty(n_maps, 3, 224, 224, dtype=torch.float32, device=self.device)
-        check(lib.lrpx_vgg16_relevance(ptr(self.packed), ptr(self.trace), self.n_img, ptr(r_feat_nhwc.contiguous()),
-                                       ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
+        if streams <= 1 or n_maps < 2 * streams or map2img is None:
+            need = lib.lrpx_vgg16_workspace_bytes(n_maps) // 4
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            check(lib.lrpx_vgg16_relevance(ptr(self.packed), ptr(self.trace), self.n_img, ptr(r_feat_nhwc),
+                                           ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
+            return out
+        per = -(-n_maps // streams)
+        need = lib.lrpx_vgg16_workspace_bytes(per) // 4
+        if getattr(self, "_ws_multi", None) is None or self._ws_multi[0].numel() < need or len(self._ws_multi) < streams:
+            self._ws_multi = [torch.empty(need, dtype=torch.float32, device=self.device) for _ in range(streams)]
+            self._side = [torch.cuda.Stream() for _ in range(streams)]
+        cur = torch.cuda.current_stream()
+        for i in range(streams):
+            lo, hi = i * per, min((i + 1) * per, n_maps)
+            if lo >= hi:
+                break
+            st = self._side[i]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                check(lib.lrpx_vgg16_relevance(ptr(self.packed), ptr(self.trace), self.n_img, ptr(r_feat_nhwc[lo:hi]),
+                                               ptr(map2img[lo:hi]), hi - lo, ptr(self._ws_multi[i]), ptr(out[lo:hi]),
+                                               C.c_void_p(st.cuda_stream)))
+        for i in range(streams):
+            cur.wait_stream(self._side[i])
         return out

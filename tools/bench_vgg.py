@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--images", type=int, default=4)
 ap.add_argument("--maps", type=int, default=80)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--streams", type=int, default=1)
 a = ap.parse_args()
 
 sd = weights.make_gridtd_state(seed=0, vocab_size=64)
@@ -26,7 +27,7 @@ feats = vgg.forward(img)
 torch.manual_seed(0)
 r_feat = torch.randn(a.maps, 196, 512, device="cuda")
 m2i = (torch.arange(a.maps, device="cuda") * a.images // a.maps).to(torch.int32)
-out = vgg.relevance(r_feat, m2i)
+out = vgg.relevance(r_feat, m2i, streams=a.streams)
 torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(a.iters):
@@ -35,7 +36,7 @@ torch.cuda.synchronize()
 tf = (time.time() - t0) / a.iters
 t0 = time.time()
 for _ in range(a.iters):
-    vgg.relevance(r_feat, m2i, out=out)
+    vgg.relevance(r_feat, m2i, out=out, streams=a.streams)
 torch.cuda.synchronize()
 tr = (time.time() - t0) / a.iters
 print(f"forward(+Z+): {tf*1e3:.2f} ms for {a.images} images = {a.images*61.4e9/tf/1e12:.1f} TFLOP/s")
