@@ -27,7 +27,8 @@ int launch_conv_cfg(const ConvArgs& a, hipStream_t stream) {
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a, (int)m_tiles, n_blocks);
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, ks), dim3(C::NT), C::LDS_BYTES, stream, a, (int)m_tiles, n_blocks);
     return check_launch("conv_mfma");
 }
 

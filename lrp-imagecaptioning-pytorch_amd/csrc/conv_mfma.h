@@ -47,6 +47,8 @@ struct ConvArgs {
     int stab;               // how out1 divides by Zdiv
     int oc_split;           // EPI_FWD_DUAL: number of plain channels; else: real output channels
     int relu;               // EPI_PLAIN: apply relu
+    int ksplit;             // >1 (dense GEMMs with few rows): blockIdx.y splits the K-chunks, partial results are
+                            // atomically added into pre-zeroed outputs (REL out0 / PLAIN out0 only)
     const float* bias;      // [oc]                      (FWD_DUAL / PLAIN, may be null)
     const float* X;         // [n_img*P][oc_split]       multiplicand (REL / FIRST / GUIDED mask)
     const float* U;         // [n_maps][oc_split]        per-map addend inside the bracket (REL, may be null)
@@ -72,10 +74,10 @@ struct ConvCfg {
     // rows of the tile + a halo row above/below + one zero row per map boundary that can fall inside the tile
     // (none when tiles are aligned to maps, H % R == 0)
     static constexpr int NSLOT = (TAPS == 9) ? R + 2 + ((H % (R ? R : 1) == 0) ? 0 : (R - 1 + H - 1) / H) : 0;
-    // floats per LDS pixel.  KC >= 16: padded by 4 (conflict-free ds_read_b128).  KC == 8: un-padded 32-byte pixels,
-    // the two 16-byte halves XOR-swizzled with bit 3 of the pixel index (equally conflict-free, 1/3 less LDS, so the
-    // double-buffered tiles of the 224^2 / 112^2 layers leave room for two workgroups per CU)
-    static constexpr bool SWZ = (KC == 8);
+    // floats per LDS pixel: padded by 4 (conflict-free ds_read_b128, tap shifts are immediate offsets).  SWZ (the
+    // 2-row tile of the 224^2 relevance layer): un-padded 32-byte pixels, the two 16-byte halves XOR-swizzled with bit 3
+    // of the pixel index — equally conflict-free and 1/3 less LDS (two workgroups per CU), at ~5 VALU per (tile, tap)
+    static constexpr bool SWZ = (KC == 8) && (HW == 224) && (MT >= 2);   // only where the padded image would not fit twice
     static constexpr int STRIDE = SWZ ? 8 : KC + 4;
     static constexpr int LDS_PIX = (TAPS == 9) ? NSLOT * WP : PIX;
     static constexpr int LDS_BYTES = 2 * LDS_PIX * STRIDE * 4;   // double-buffered A tile
@@ -217,8 +219,12 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
             if (oc < ncol) {
                 if (Uu) v += Uu[(TAPS == 9 ? (long)(((unsigned)cx.g0 + (unsigned)q / (unsigned)HW) / (unsigned)HW)
                                            : (long)((unsigned)gp / P)) * ncol + oc];
+                if (Uu && a.ksplit > 1 && blockIdx.y != 0) v = accj[e];    // the addend joins exactly one K-split
                 const float rel = r.xv[e] * v;
-                if (o0) o0[gp * ncol + oc] = rel;
+                if (o0) {
+                    if (a.ksplit > 1) atomicAdd(&o0[gp * ncol + oc], rel);
+                    else o0[gp * ncol + oc] = rel;
+                }
                 if (o1) {
                     float z = r.zv[e];
                     z = (a.stab == STAB_SAFE) ? stab_safe(z) : ((a.stab == STAB_EPS) ? stab_eps(z) : z);
@@ -227,9 +233,13 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
             }
         } else if (EPI == EPI_PLAIN) {
             if (oc < ncol) {
-                v += bias;
-                if (a.relu) v = v > 0.f ? v : 0.f;
-                o0[gp * ncol + oc] = v;
+                if (a.ksplit > 1) {
+                    atomicAdd(&o0[gp * ncol + oc], blockIdx.y == 0 ? v + bias : v);   // (no relu with split-K)
+                } else {
+                    v += bias;
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    o0[gp * ncol + oc] = v;
+                }
             }
         } else {   // EPI_GUIDED: ReLU hook of the layer below, out = max(g,0) * [y > 0]
             if (oc < ncol) o0[gp * ncol + oc] = (r.xv[e] > 0.f && v > 0.f) ? v : 0.f;
@@ -259,6 +269,9 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
     const int ocb = nblk * NWN + wn;                         // 32-channel block of this wave
     const bool wave_active = ocb * 32 < a.n_oc;
     const int nchunk = a.cin / KC;
+    const int ks_n = a.ksplit > 1 ? a.ksplit : 1;
+    const int ks_i = ks_n > 1 ? (int)blockIdx.y : 0;
+    const int chunk_lo = (int)((long)nchunk * ks_i / ks_n), chunk_hi = (int)((long)nchunk * (ks_i + 1) / ks_n);
     const long total_pix = (long)a.n_maps * a.pix_per_map;
 
     // ---- per-lane A addresses (floats into lds) ----
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
     _Pragma("unroll") for (int u = 0; u < U; ++u)                                                            \
         if (sdst[u] >= 0) *reinterpret_cast<f32x4*>(lds + (BUFIDX) * BUF + (sdst[u] & 0x0fffffff)) = sv[u];
 
-    LRPX_STAGE_ISSUE(0)
+    LRPX_STAGE_ISSUE(chunk_lo)
     // zero both LDS buffers once: halo columns and inter-map zero rows are never written afterwards
     for (int i = tid; i < 2 * BUF / 4; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0, 0, 0, 0};
     __syncthreads();
@@ -345,21 +358,21 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
 
     // B fragments: one contiguous stream of (nchunk * STEPS) 1-KiB wave-loads per channel block
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.wp) + (long)ocb * nchunk * (STEPS * 64) + lane;
-    const int last_step = nchunk * STEPS - 1;
+    const int last_step = chunk_hi * STEPS - 1;
     f32x4 bq[NB];     // bq[0] = fragment of the current k-step, bq[i] = i steps ahead (L2 latency under load ~2 us)
 #pragma unroll
     for (int i = 0; i < NB; ++i) bq[i] = f32x4{0, 0, 0, 0};
     if (wave_active) {
 #pragma unroll
-        for (int i = 0; i < NB - 1; ++i) bq[i] = wp[(long)min(i, last_step) * 64];
+        for (int i = 0; i < NB - 1; ++i) bq[i] = wp[(long)min(chunk_lo * STEPS + i, last_step) * 64];
     }
     __syncthreads();
 
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        const bool more = chunk + 1 < nchunk;
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+        const bool more = chunk + 1 < chunk_hi;
         if (more) { LRPX_STAGE_ISSUE(chunk + 1) }
         if (wave_active) {
-            const float* abuf = lds + (chunk & 1) * BUF;
+            const float* abuf = lds + ((chunk - chunk_lo) & 1) * BUF;
             const int g0step = chunk * STEPS;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
             }
         }
         // the other buffer was last read one iteration ago and every wave has passed a barrier since
-        if (more) { LRPX_STAGE_COMMIT((chunk + 1) & 1) }
+        if (more) { LRPX_STAGE_COMMIT((chunk + 1 - chunk_lo) & 1) }
         __syncthreads();
     }
 #undef LRPX_STAGE_ISSUE

@@ -19,6 +19,18 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     a.in = d->in; a.wp = d->wpacked; a.n_maps = d->n_maps; a.cin = d->cin; a.n_oc = d->n_oc;
     a.pix_per_map = d->taps == 9 ? d->hw * d->hw : d->pix_per_map;
     a.in_chunk_stride = d->in_chunked ? (long)d->n_maps * a.pix_per_map * kc : 0;
+    // dense GEMMs with few rows are latency-bound by one wave's serial MFMA chain over K: split K over blockIdx.y and
+    // add the partial results atomically (outputs zeroed first).  Only where the epilogue is linear in the accumulator.
+    a.ksplit = 1;
+    if (d->taps == 1 && (long)d->n_maps * a.pix_per_map <= 2048 && d->cin >= 4 * kc && !d->out1 &&
+        ((d->epi == EPI_REL) || (d->epi == EPI_PLAIN && !d->relu))) {
+        a.ksplit = d->cin / kc >= 16 ? 4 : 2;
+        const int ncol = d->oc_split;
+        if (hipMemsetAsync(d->out0, 0, (size_t)d->n_maps * a.pix_per_map * ncol * sizeof(float), s) != hipSuccess) {
+            set_error("conv_mfma: cannot zero the split-K output");
+            return LRPX_ELAUNCH;
+        }
+    }
     a.epi = d->epi; a.stab = d->stab; a.oc_split = d->oc_split; a.relu = d->relu;
     a.bias = d->bias; a.X = d->x; a.U = d->u; a.Zdiv = d->zdiv; a.map2img = d->map2img;
     a.out0 = d->out0; a.out1 = d->out1;
