@@ -52,6 +52,10 @@ enum {
 size_t lrpx_packed_floats(int n_oc, int k, int taps, int kc);
 /* w: conv (cout,cin,3,3) or dense matrix; kc = K-chunk the consuming kernel will use (lrpx_conv_kc) */
 int lrpx_pack_weights(const float* w, int cout, int cin, int taps, int mode, int kc, float* packed, void* stream);
+/* bf16x3 split of the same fragment layout for the fp32-accurate bf16 path (lrpx_conv_desc.bf16x6): every weight is
+ * stored as three bf16 planes w = w0 + w1 + w2; modes BWD_POS / BWD_PLAIN / FWD, 3x3 kernels */
+size_t lrpx_packed_bf16x3_bytes(int n_oc, int k, int taps);
+int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream);
 /* K-chunk used by lrpx_conv_mfma for a given image width / taps / input channels */
 int lrpx_conv_kc(int hw, int taps, int cin);
 
@@ -65,6 +69,9 @@ typedef struct lrpx_conv_desc {
     int n_maps, hw, cin, n_oc, taps, pix_per_map;
     int epi, stab, oc_split, relu;
     int in_chunked;       /* input stored in K-chunks of lrpx_conv_kc(hw,taps,cin) channels (see lrpx_maxpool2x2_relevance) */
+    int bf16x6;           /* 1: contraction on the bf16 matrix cores with exact 3-way operand splits and the 6 leading
+                             partial products (fp32 accuracy, 2.67x less matrix-pipe time); wpacked must come from
+                             lrpx_pack_weights_bf16x3; 3x3 convs on 56/28/14-pixel maps, cin %% 16 == 0 */
     const float* bias;
     const float* x;
     const float* u;
@@ -109,6 +116,11 @@ int lrpx_fold_halves(const float* in, float* out, long rows, int half, void* str
 /* NaN/Inf + all-zero check of a buffer (the asserts of lrp_modules.py:154-155, lrp_wrapper.py:81);
  * synchronises the stream.  flags: bit0 = fail on non-finite, bit1 = fail on all-zero */
 int lrpx_check(const float* buf, long n, int flags, void* stream);
+
+/* Process-wide switch for lrpx_vgg16_relevance: 1 (default) runs the relevance passes of the 56/28/14-pixel layers on
+ * the bf16 matrix cores with exact operand splits (fp32 accuracy, see lrpx_conv_desc.bf16x6), 0 keeps the fp32 MFMA
+ * everywhere; a negative value only queries.  Returns the previous setting. */
+int lrpx_set_bf16x6(int enable);
 
 /* ---- VGG16 encoder: trace + relevance chain ------------------------------------------------------ */
 /* bytes of the packed-weight blob / per-batch trace / relevance workspace */

@@ -48,7 +48,7 @@ class AoaRelState(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("in_", _f), ("wpacked", _f),
                 ("n_maps", _i), ("hw", _i), ("cin", _i), ("n_oc", _i), ("taps", _i), ("pix_per_map", _i),
-                ("epi", _i), ("stab", _i), ("oc_split", _i), ("relu", _i), ("in_chunked", _i),
+                ("epi", _i), ("stab", _i), ("oc_split", _i), ("relu", _i), ("in_chunked", _i), ("bf16x6", _i),
                 ("bias", _f), ("x", _f), ("u", _f), ("zdiv", _f), ("map2img", _f),
                 ("out0", _f), ("out1", _f)]
 
@@ -59,6 +59,8 @@ SIGNATURES = {
     "lrpx_last_error_string": (C.c_char_p, []),
     "lrpx_packed_floats": (_sz, [_i, _i, _i, _i]),
     "lrpx_pack_weights": (_i, [_f, _i, _i, _i, _i, _i, _f, _f]),
+    "lrpx_packed_bf16x3_bytes": (_sz, [_i, _i, _i]),
+    "lrpx_pack_weights_bf16x3": (_i, [_f, _i, _i, _i, _i, _f, _f]),
     "lrpx_conv_kc": (_i, [_i, _i, _i]),
     "lrpx_conv_mfma": (_i, [C.POINTER(ConvDesc), _f]),
     "lrpx_nchw_to_nhwc": (_i, [_f, _f, _i, _i, _i, _i, _f]),
@@ -98,6 +100,7 @@ SIGNATURES = {
     "lrpx_scale": (_i, [_f, _f, _l, C.c_float, _f]),
     "lrpx_positive_mask": (_i, [_f, _f, _l, _f]),
     "lrpx_vgg16_guided_backprop": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, _f]),
+    "lrpx_set_bf16x6": (_i, [_i]),
     "lrpx_vgg16_packed_bytes": (_sz, []),
     "lrpx_vgg16_trace_bytes": (_sz, [_i]),
     "lrpx_vgg16_workspace_bytes": (_sz, [_i]),

@@ -6,6 +6,7 @@
 
 #include "common.h"
 #include "conv_mfma.h"
+#include "conv_bf16x6.h"
 
 namespace lrpx {
 
@@ -80,6 +81,39 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
             break;
     }
     out[idx] = v;
+}
+
+// bf16x3 split of the packed weights for conv_bf16x6.h: [ocb][chunk 16][tap][plane 3][lane 64][8 bf16]; lane l holds
+// B[k = 16*chunk + 8*(l>>5) + j][oc = 32*ocb + (l&31)], j = 0..7  (operand map of v_mfma_f32_32x32x16_bf16)
+__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout,
+                                           int cin, int taps, int mode, int k_pad, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (.., lane, j): writes the 3 planes
+    if (idx >= total) return;
+    const int j = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    long rest = idx >> 9;
+    const int tap = rest % taps; rest /= taps;
+    const int nchunk = k_pad / 16;
+    const int chunk = rest % nchunk; rest /= nchunk;
+    const int ocb = (int)rest;
+    const int oc = ocb * 32 + (lane & 31);
+    const int k = chunk * 16 + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    switch (mode) {
+        case LRPX_PACK_BWD_POS:
+            if (k < cout && oc < cin) v = fmaxf(w[((long)k * cin + oc) * taps + (taps - 1 - tap)], 0.f);
+            break;
+        case LRPX_PACK_BWD_PLAIN:
+            if (k < cout && oc < cin) v = w[((long)k * cin + oc) * taps + (taps - 1 - tap)];
+            break;
+        case LRPX_PACK_FWD:
+            if (k < cin && oc < cout) v = w[((long)oc * cin + k) * taps + tap];
+            break;
+    }
+    unsigned short p0, p1, p2;
+    split3(v, p0, p1, p2);
+    const long base = ((((long)ocb * nchunk + chunk) * taps + tap) * 3) * 512 + lane * 8 + j;
+    out[base] = p0; out[base + 512] = p1; out[base + 1024] = p2;
 }
 
 static void pack_dims(int cout, int cin, int mode, int kc, int* n_oc_pad, int* k_pad) {
@@ -335,6 +369,22 @@ int lrpx_pack_weights(const float* w, int cout, int cin, int taps, int mode, int
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, packed, cout,
                        cin, taps, mode, kc, n_oc_pad, k_pad, total);
     return check_launch("pack_weights");
+}
+
+size_t lrpx_packed_bf16x3_bytes(int n_oc, int k, int taps) {
+    return (size_t)round_up(n_oc, 32) * (size_t)round_up(k, 16) * (size_t)taps * 3 * sizeof(unsigned short);
+}
+
+int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream) {
+    LRPX_REQUIRE(w && packed && taps == 9, "pack_weights_bf16x3: bad arguments (3x3 kernels only)");
+    LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN || mode == LRPX_PACK_FWD,
+                 "pack_weights_bf16x3: mode %d not supported", mode);
+    int n_oc_pad, k_pad;
+    pack_dims(cout, cin, mode, 16, &n_oc_pad, &k_pad);
+    long total = (long)n_oc_pad * k_pad * taps;     // threads: one per (oc, k, tap)
+    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w,
+                       (unsigned short*)packed, cout, cin, taps, mode, k_pad, total);
+    return check_launch("pack_weights_bf16x3");
 }
 
 int lrpx_nchw_to_nhwc(const float* src, float* dst, int n, int c, int hw_pix, int c_pad, void* stream) {

@@ -13,7 +13,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     LRPX_REQUIRE(d && d->in && d->wpacked && (d->out0 || d->out1), "conv_mfma: null pointer");
     LRPX_REQUIRE(d->taps == 9 || d->taps == 1, "conv_mfma: taps must be 9 or 1");
     LRPX_REQUIRE(d->n_maps > 0 && d->cin > 0 && d->n_oc > 0 && d->n_oc % 32 == 0, "conv_mfma: bad sizes (n_oc %% 32)");
-    const int kc = lrpx_conv_kc(d->hw, d->taps, d->cin);
+    const int kc = d->bf16x6 ? 16 : lrpx_conv_kc(d->hw, d->taps, d->cin);
     LRPX_REQUIRE(kc > 0 && d->cin % kc == 0, "conv_mfma: cin=%d is not a multiple of the K-chunk %d", d->cin, kc);
     ConvArgs a;
     a.in = d->in; a.wp = d->wpacked; a.n_maps = d->n_maps; a.cin = d->cin; a.n_oc = d->n_oc;
@@ -43,6 +43,15 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
         case EPI_PLAIN: LRPX_REQUIRE(d->out0, "conv_mfma: PLAIN needs out0"); break;
         case EPI_GUIDED: LRPX_REQUIRE(d->out0 && d->x, "conv_mfma: GUIDED needs x,out0"); break;
         default: LRPX_REQUIRE(false, "conv_mfma: epilogue %d not built", d->epi);
+    }
+    if (d->bf16x6) {
+        LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0 && !d->in_chunked, "conv_mfma: bf16x6 needs a 3x3 conv, cin %% 16 == 0");
+        if (d->epi == EPI_REL) {
+            if (d->hw == 56) return launch_x6_56_rel(a, s);
+            if (d->hw == 28) return launch_x6_28_rel(a, s);
+            if (d->hw == 14) return launch_x6_14_rel(a, s);
+        }
+        LRPX_REQUIRE(false, "conv_mfma: no bf16x6 kernel built for hw=%d epi=%d", d->hw, d->epi);
     }
     if (d->taps == 1) {
         if (d->epi == EPI_REL) return launch_conv_14_32_1_4_1_rel(a, s);
@@ -105,20 +114,24 @@ int guided_gate(const float* g, const float* y, const int* map2img, float* out, 
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
                        int c, hipStream_t s);
 
+// relevance passes of the 56/28/14-pixel layers on the bf16 matrix cores (conv_bf16x6.h); lrpx_set_bf16x6()
+static int g_bf16x6 = 1;
+
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bias[17], first6, first6p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bias[17], first6, first6p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
     size_t off = 0;
     for (int l = 0; l < kNL; ++l) {
-        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bias[l] = 0;
+        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bias[l] = 0;
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
         p.bwd[l] = off; off += lrpx_packed_floats(l == 0 ? 32 : L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout));
         p.bias[l] = off; off += (size_t)L.cout;
         if (l > 0) { p.bwdp[l] = off; off += lrpx_packed_floats(L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout)); }
+        if (L.hw <= 56) { p.bwd6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float); }
     }
     p.first6 = off; off += (size_t)64 * 9 * 6;   // direct-conv weights of the first layer's rule
     p.first6p = off; off += (size_t)64 * 9 * 6;  // ... and of its plain transposed conv (guided backprop)
@@ -162,6 +175,12 @@ int lrpx_conv_kc(int hw, int taps, int cin) {
 
 int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream) { return conv_dispatch(d, (hipStream_t)stream); }
 
+int lrpx_set_bf16x6(int enable) {
+    const int prev = g_bf16x6;
+    if (enable >= 0) g_bf16x6 = enable ? 1 : 0;
+    return prev;
+}
+
 size_t lrpx_vgg16_packed_bytes(void) { return vgg_packed_layout().total * sizeof(float); }
 size_t lrpx_vgg16_trace_bytes(int n_img) { return vgg_trace_layout(n_img).total * sizeof(float); }
 size_t lrpx_vgg16_workspace_bytes(int n_maps) {
@@ -195,6 +214,8 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
             LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, lrpx_conv_kc(L.hw, 9, L.cout),
                                        base + p.bwdp[l], stream));
         }
+        if (L.hw <= 56)
+            LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwd6[l], stream));
         ++ci;
     }
     return LRPX_OK;
@@ -277,6 +298,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
+        if (g_bf16x6 && L.hw <= 56) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
         if (kVgg[l - 1].conv) {
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
             d.out1 = S[cur ^ 1]; d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE;

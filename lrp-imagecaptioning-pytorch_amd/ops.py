@@ -40,12 +40,22 @@ def pack_weights(w, cout, cin, taps, mode, kc):
     return out
 
 
+def pack_weights_bf16x3(w, cout, cin, mode):
+    """3x3 conv weights -> three bf16 planes in fragment layout (for conv_mfma(..., bf16x6=1))."""
+    lib = _lib.load()
+    n_oc, k = (cout, cin) if mode == _lib.PACK_FWD else (cin, cout)
+    out = torch.empty(lib.lrpx_packed_bf16x3_bytes(n_oc, k, 9) // 2, dtype=torch.int16, device=w.device)
+    check(lib.lrpx_pack_weights_bf16x3(ptr(w.contiguous()), cout, cin, 9, mode, ptr(out), stream_ptr()))
+    return out
+
+
 def conv_mfma(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, *, pix_per_map=0, stab=STAB_NONE, oc_split=0,
-              relu=0, bias=None, x=None, u=None, zdiv=None, map2img=None, out0=None, out1=None):
+              relu=0, bias=None, x=None, u=None, zdiv=None, map2img=None, out0=None, out1=None, bf16x6=0):
     d = ConvDesc()
     d.in_, d.wpacked = ptr(_dev(inp)), ptr(_dev(wpacked))
     d.n_maps, d.hw, d.cin, d.n_oc, d.taps, d.pix_per_map = n_maps, hw, cin, n_oc, taps, pix_per_map
     d.epi, d.stab, d.oc_split, d.relu = epi, stab, oc_split, relu
+    d.bf16x6 = bf16x6
     d.bias, d.x, d.u, d.zdiv, d.map2img = ptr(bias), ptr(x), ptr(u), ptr(zdiv), ptr(map2img)
     d.out0, d.out1 = ptr(out0), ptr(out1)
     check(_lib.load().lrpx_conv_mfma(C.byref(d), stream_ptr()))

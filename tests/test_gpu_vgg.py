@@ -37,7 +37,7 @@ def from_nhwc(x, c, h, w):
     return x[:, :, :c].reshape(x.shape[0], h, w, c).permute(0, 3, 1, 2).contiguous()
 
 
-def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None):
+def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False):
     """alpha1beta0 rule for one conv layer with non-negative input x (n_img,cin,hw,hw); r_out per map."""
     from lrp_amd import _lib
     n_img, cin, hw, _ = x.shape
@@ -62,9 +62,13 @@ def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None):
     m2i = None if map2img is None else torch.tensor(map2img, dtype=torch.int32, device=dev)
     s = ops.divide_stab(to_nhwc(r_out, cout_p).to(dev), zpos, m2i, _lib.STAB_SAFE)
     kc_b = ops.conv_kc(hw, 9, cout_p)
-    wb = ops.pack_weights(wg, cout_p, cin_p, 9, _lib.PACK_BWD_POS, kc_b)
+    if bf16x6:
+        wb = ops.pack_weights_bf16x3(wg, cout_p, cin_p, _lib.PACK_BWD_POS)
+    else:
+        wb = ops.pack_weights(wg, cout_p, cin_p, 9, _lib.PACK_BWD_POS, kc_b)
     r_in = torch.empty(n_maps, hw * hw, cin_p, device=dev)
-    ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL, oc_split=cin_p, x=xg, map2img=m2i, out0=r_in)
+    ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL, oc_split=cin_p, x=xg, map2img=m2i, out0=r_in,
+                  bf16x6=int(bf16x6))
     torch.cuda.synchronize()
     return (from_nhwc(r_in.cpu(), cin, hw, hw), from_nhwc(act.cpu(), cout, hw, hw),
             from_nhwc(zpos.cpu(), cout, hw, hw))
@@ -87,6 +91,24 @@ def test_conv_rule_vs_oracle(ops, hw, cin, cout, n_img, n_maps):
     assert rel_err(zpos, F.conv2d(x, w.clamp(min=0), padding=1)) < 1e-5
     assert rel_err(got, want) < TOL
     assert cosine(got, want) > 0.99999
+
+
+@pytest.mark.parametrize("hw,cin,cout,n_img,n_maps", [(14, 64, 96, 3, 5), (28, 32, 64, 2, 3), (56, 64, 128, 1, 2)])
+def test_conv_rule_bf16x6_is_fp32_accurate(ops, hw, cin, cout, n_img, n_maps):
+    """the bf16 matrix-core path (exact 3-way operand split, 6 partial products) against the oracle AND against the
+    fp32-MFMA kernel: same 1e-4 bound, and the two GPU paths agree to ~1e-6"""
+    from oracle import lrp_oracle as O
+    g = torch.Generator().manual_seed(hw * 77 + cin)
+    x = torch.relu(torch.randn(n_img, cin, hw, hw, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    r = torch.randn(n_maps, cout, hw, hw, generator=g) * torch.exp(4 * torch.randn(n_maps, cout, hw, hw, generator=g))
+    m2i = [i % n_img for i in range(n_maps)]
+    got6, _, _ = gpu_conv_rule(ops, x, w, r, m2i, bf16x6=True)
+    got32, _, _ = gpu_conv_rule(ops, x, w, r, m2i, bf16x6=False)
+    want = torch.cat([O.conv_alpha1beta0(x[m2i[i]:m2i[i] + 1], w, r[i:i + 1]) for i in range(n_maps)])
+    assert rel_err(got6, want) < TOL
+    assert rel_err(got6, got32) < 1e-5
+    assert cosine(got6, want) > 0.99999
 
 
 def test_reference_conv_fixture_embedded(ops):
