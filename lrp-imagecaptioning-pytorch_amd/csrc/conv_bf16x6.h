@@ -35,19 +35,22 @@ __device__ __forceinline__ void split3(float x, unsigned short& p0, unsigned sho
     p2 = f32_to_bf16_rn(r2);
 }
 
-template <int HW, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvArgs a, int m_tiles, int n_blocks) {
-    constexpr int KC = 16, MT = 1, NWN = 4, TAPS = 9;
+// DB: double-buffered A tile (one barrier per chunk).  DB = false (tiles whose two buffers would not leave room for two
+// workgroups per CU: the 112-pixel layers): one buffer, the prefetched registers are committed between two barriers.
+template <int HW, int MT, int NWN, bool DB, int EPI>
+__global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+    constexpr int KC = 16, TAPS = 9;
     using C = ConvCfg<HW, KC, MT, NWN, TAPS>;
     constexpr int W = C::W, H = C::H, WP = C::WP, NT = C::NT;
     constexpr int PSTRIDE = 112;                       // bytes per LDS pixel
     constexpr int BUFB = C::NSLOT * WP * PSTRIDE;      // bytes per LDS buffer
+    constexpr int NBUF = DB ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
     const int mtile = (idx / n_blocks) * 8 + xcd;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvArgs a, int m_t
     int abase[7];      // byte offset of the 3x3 window corner of this lane's pixel, k-half lh
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-        const int q = 32 * j + li;
+        const int q = wm * 224 + 32 * j + li;
         const int r = q / W, c = q % W;
         const long g = g0 + r;
         const int slot = (int)(g + g / H - v0) + 1;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvArgs a, int m_t
         }
 
     LRPX6_ISSUE(0)
-    for (int i = tid; i < 2 * BUFB / 16; i += NT) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
+    for (int i = tid; i < NBUF * BUFB / 16; i += NT) reinterpret_cast<u32x4*>(ldsb)[i] = u32x4{0, 0, 0, 0};
     __syncthreads();
     LRPX6_COMMIT(0)
 
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvArgs a, int m_t
         const bool more = chunk + 1 < nchunk;
         if (more) { LRPX6_ISSUE(chunk + 1) }
         if (wave_active) {
-            const char* abuf = ldsb + (chunk & 1) * BUFB;
+            const char* abuf = ldsb + (DB ? (chunk & 1) : 0) * BUFB;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int tapoff = ((tap / 3) * WP + (tap % 3)) * PSTRIDE;
@@ -176,8 +179,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvArgs a, int m_t
                     for (int p = 0; p < 3; ++p) bq[i][p] = bq[i + 1][p];
             }
         }
-        if (more) { LRPX6_COMMIT((chunk + 1) & 1) }
-        __syncthreads();
+        if constexpr (DB) {
+            if (more) { LRPX6_COMMIT((chunk + 1) & 1) }
+            __syncthreads();
+        } else {
+            __syncthreads();                       // every wave is done reading the single buffer
+            if (more) { LRPX6_COMMIT(0) }
+            __syncthreads();
+        }
     }
 #undef LRPX6_ISSUE
 #undef LRPX6_COMMIT
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvArgs a, int m_t
     EpiCtx cx;
     cx.oc = ocb * 32 + li;
     cx.lane = lane;
-    cx.q0 = 4 * lh;
+    cx.q0 = wm * 224 + 4 * lh;
     cx.g0 = (int)g0;
     cx.pix0 = g0 * W;
     cx.total_pix = total_pix;
@@ -216,14 +225,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvArgs a, int m_t
     epi_finish<EPI, HW, TAPS, AL>(a, cx, 6, acc[6], ra);
 }
 
-template <int HW, int EPI>
+template <int HW, int MT, int NWN, bool DB, int EPI>
 int launch_conv_bf16x6(const ConvArgs& a, hipStream_t stream) {
-    using C = ConvCfg<HW, 16, 1, 4, 9>;
-    constexpr int LDS = 2 * C::NSLOT * C::WP * 112;
+    using C = ConvCfg<HW, 16, MT, NWN, 9>;
+    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * C::WP * 112;
     const long m_tiles = ceil_div((long)a.n_maps * HW, C::R);
-    const int n_blocks = (int)ceil_div(a.n_oc, 128);
+    const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
     const long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
-    auto kern = conv_bf16x6_kernel<HW, EPI>;
+    auto kern = conv_bf16x6_kernel<HW, MT, NWN, DB, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
@@ -233,7 +242,7 @@ int launch_conv_bf16x6(const ConvArgs& a, hipStream_t stream) {
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, a, (int)m_tiles, n_blocks);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MT * NWN), LDS, stream, a, (int)m_tiles, n_blocks);
     return check_launch("conv_bf16x6");
 }
 

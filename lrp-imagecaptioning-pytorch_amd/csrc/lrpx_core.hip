@@ -109,6 +109,13 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned
         case LRPX_PACK_FWD:
             if (k < cin && oc < cout) v = w[((long)oc * cin + k) * taps + tap];
             break;
+        case LRPX_PACK_FWD_DUAL:
+            if (k < cin && oc < 2 * cout) {
+                const int co = oc < cout ? oc : oc - cout;
+                const float x = w[((long)co * cin + k) * taps + tap];
+                v = oc < cout ? x : fmaxf(x, 0.f);
+            }
+            break;
     }
     unsigned short p0, p1, p2;
     split3(v, p0, p1, p2);
@@ -377,8 +384,8 @@ size_t lrpx_packed_bf16x3_bytes(int n_oc, int k, int taps) {
 
 int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream) {
     LRPX_REQUIRE(w && packed && taps == 9, "pack_weights_bf16x3: bad arguments (3x3 kernels only)");
-    LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN || mode == LRPX_PACK_FWD,
-                 "pack_weights_bf16x3: mode %d not supported", mode);
+    LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN || mode == LRPX_PACK_FWD ||
+                     mode == LRPX_PACK_FWD_DUAL, "pack_weights_bf16x3: mode %d not supported", mode);
     int n_oc_pad, k_pad;
     pack_dims(cout, cin, mode, 16, &n_oc_pad, &k_pad);
     long total = (long)n_oc_pad * k_pad * taps;     // threads: one per (oc, k, tap)

@@ -45,11 +45,18 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
         default: LRPX_REQUIRE(false, "conv_mfma: epilogue %d not built", d->epi);
     }
     if (d->bf16x6) {
-        LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0 && !d->in_chunked, "conv_mfma: bf16x6 needs a 3x3 conv, cin %% 16 == 0");
+        LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0, "conv_mfma: bf16x6 needs a 3x3 conv, cin %% 16 == 0");
         if (d->epi == EPI_REL) {
+            if (d->hw == 112) return d->n_oc <= 64 ? launch_x6_112n_rel(a, s) : launch_x6_112_rel(a, s);
             if (d->hw == 56) return launch_x6_56_rel(a, s);
             if (d->hw == 28) return launch_x6_28_rel(a, s);
             if (d->hw == 14) return launch_x6_14_rel(a, s);
+        }
+        if (d->epi == EPI_FWD_DUAL) {
+            if (d->hw == 112) return launch_x6_112_fwd(a, s);
+            if (d->hw == 56) return launch_x6_56_fwd(a, s);
+            if (d->hw == 28) return launch_x6_28_fwd(a, s);
+            if (d->hw == 14) return launch_x6_14_fwd(a, s);
         }
         LRPX_REQUIRE(false, "conv_mfma: no bf16x6 kernel built for hw=%d epi=%d", d->hw, d->epi);
     }
@@ -118,20 +125,23 @@ int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, f
 static int g_bf16x6 = 1;
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bias[17], first6, first6p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], fwd6[17], bias[17], first6, first6p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
     size_t off = 0;
     for (int l = 0; l < kNL; ++l) {
-        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bias[l] = 0;
+        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.fwd6[l] = p.bias[l] = 0;
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
         p.bwd[l] = off; off += lrpx_packed_floats(l == 0 ? 32 : L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout));
         p.bias[l] = off; off += (size_t)L.cout;
         if (l > 0) { p.bwdp[l] = off; off += lrpx_packed_floats(L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout)); }
-        if (L.hw <= 56) { p.bwd6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float); }
+        if (L.hw <= 112) {
+            p.bwd6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float);
+            p.fwd6[l] = off; off += lrpx_packed_bf16x3_bytes(2 * L.cout, L.cin, 9) / sizeof(float);
+        }
     }
     p.first6 = off; off += (size_t)64 * 9 * 6;   // direct-conv weights of the first layer's rule
     p.first6p = off; off += (size_t)64 * 9 * 6;  // ... and of its plain transposed conv (guided backprop)
@@ -214,8 +224,10 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
             LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, lrpx_conv_kc(L.hw, 9, L.cout),
                                        base + p.bwdp[l], stream));
         }
-        if (L.hw <= 56)
+        if (L.hw <= 112) {
             LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwd6[l], stream));
+            LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwd6[l], stream));
+        }
         ++ci;
     }
     return LRPX_OK;
@@ -250,6 +262,7 @@ int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, voi
             d.n_maps = n_img; d.hw = L.hw; d.cin = cin_pad(l); d.n_oc = 2 * L.cout; d.taps = 9;
             d.epi = EPI_FWD_DUAL; d.oc_split = L.cout; d.bias = pk + p.bias[l];
             d.out0 = tr + t.act[l + 1]; d.out1 = tr + t.zpos[l];
+            if (g_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
             LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
         } else {
             LRPX_TRY(lrpx_maxpool2x2_fwd(tr + t.act[l], tr + t.act[l + 1], n_img, L.hw, L.hw, L.cin, stream));
@@ -298,7 +311,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
-        if (g_bf16x6 && L.hw <= 56) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
+        if (g_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
         if (kVgg[l - 1].conv) {
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
             d.out1 = S[cur ^ 1]; d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE;
@@ -310,7 +323,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             // wide maps: hand the conv below its input in K-chunks (32-byte pixel slices would drag every 128-byte
             // line through the fabric four times: measured L2 hit 36 %, 3x the unique bytes on conv1_2)
             const int below_hw = 2 * L.hw;
-            const int chunk = below_hw >= 112 ? lrpx_conv_kc(below_hw, 9, L.cin) : 0;
+            const int chunk = below_hw < 112 ? 0 : ((g_bf16x6 && below_hw <= 112) ? 16 : lrpx_conv_kc(below_hw, 9, L.cin));
             LRPX_TRY(lrpx_maxpool2x2_relevance(tr + t.act[l - 1], R, tr + t.zpos[l - 2], map2img, nullptr, S[cur ^ 1],
                                                n_maps, L.hw, L.hw, L.cin, chunk, stream));
             cur_chunked = chunk ? 1 : 0;
