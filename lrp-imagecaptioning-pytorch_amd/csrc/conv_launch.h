@@ -60,6 +60,7 @@ int launch_x6_56_rel(const ConvArgs& a, hipStream_t s);
 int launch_x6_28_rel(const ConvArgs& a, hipStream_t s);
 int launch_x6_14_rel(const ConvArgs& a, hipStream_t s);
 int launch_x6_112_rel(const ConvArgs& a, hipStream_t s);
+int launch_x6_224_rel(const ConvArgs& a, hipStream_t s);
 int launch_x6_112n_rel(const ConvArgs& a, hipStream_t s);
 int launch_x6_112_fwd(const ConvArgs& a, hipStream_t s);
 int launch_x6_56_fwd(const ConvArgs& a, hipStream_t s);

@@ -47,6 +47,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     if (d->bf16x6) {
         LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0, "conv_mfma: bf16x6 needs a 3x3 conv, cin %% 16 == 0");
         if (d->epi == EPI_REL) {
+            if (d->hw == 224) return launch_x6_224_rel(a, s);
             if (d->hw == 112) return d->n_oc <= 64 ? launch_x6_112n_rel(a, s) : launch_x6_112_rel(a, s);
             if (d->hw == 56) return launch_x6_56_rel(a, s);
             if (d->hw == 28) return launch_x6_28_rel(a, s);
@@ -138,8 +139,8 @@ static VggPacked vgg_packed_layout() {
         p.bwd[l] = off; off += lrpx_packed_floats(l == 0 ? 32 : L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout));
         p.bias[l] = off; off += (size_t)L.cout;
         if (l > 0) { p.bwdp[l] = off; off += lrpx_packed_floats(L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout)); }
+        if (l > 0) { p.bwd6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (L.hw <= 112) {
-            p.bwd6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float);
             p.fwd6[l] = off; off += lrpx_packed_bf16x3_bytes(2 * L.cout, L.cin, 9) / sizeof(float);
         }
     }
@@ -224,8 +225,8 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
             LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, lrpx_conv_kc(L.hw, 9, L.cout),
                                        base + p.bwdp[l], stream));
         }
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwd6[l], stream));
         if (L.hw <= 112) {
-            LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwd6[l], stream));
             LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwd6[l], stream));
         }
         ++ci;
@@ -311,7 +312,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
-        if (g_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
+        if (g_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
         if (kVgg[l - 1].conv) {
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
             d.out1 = S[cur ^ 1]; d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE;
@@ -323,7 +324,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             // wide maps: hand the conv below its input in K-chunks (32-byte pixel slices would drag every 128-byte
             // line through the fabric four times: measured L2 hit 36 %, 3x the unique bytes on conv1_2)
             const int below_hw = 2 * L.hw;
-            const int chunk = below_hw < 112 ? 0 : ((g_bf16x6 && below_hw <= 112) ? 16 : lrpx_conv_kc(below_hw, 9, L.cin));
+            const int chunk = below_hw < 112 ? 0 : (g_bf16x6 ? 16 : lrpx_conv_kc(below_hw, 9, L.cin));
             LRPX_TRY(lrpx_maxpool2x2_relevance(tr + t.act[l - 1], R, tr + t.zpos[l - 2], map2img, nullptr, S[cur ^ 1],
                                                n_maps, L.hw, L.hw, L.cin, chunk, stream));
             cur_chunked = chunk ? 1 : 0;
