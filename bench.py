@@ -27,12 +27,17 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_MAP = 30.69          # one transposed conv per VGG16 layer = 15.35 GMAC
+GFLOP_PER_MAP = 30.69          # one transposed conv per VGG16 layer = 15.35 GMAC (algorithmic, fp32)
 PEAK_FP32_MFMA_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+# The 12 relevance convs with >= 64 input channels run as "bf16x6": each fp32 product is evaluated as 6 bf16 MFMA
+# products of exact operand thirds (fp32-accurate, csrc/conv_bf16x6.h); the 3-channel first layer is a VALU kernel.
+# Executed matrix work = 6 x the algorithmic flops of those 12 layers (15.26 of the 15.35 GMAC).
+BF16X6_SHARE = (15.35 - 0.087) / 15.35
 # HBM traffic of one relevance pass over 320 maps, from rocprofv3 --pmc (separate passes, tools/pmc_passes.sh;
-# profiles/r01_pmc_traffic.txt): FETCH_SIZE 42.9 GB raw (x2 for wide coalesced streams on gfx950, per
-# MI355X_MICROARCH.md §HBM) + WRITE_SIZE 22.2 GB.  Scaled linearly with the map count below.
-TRAFFIC_BYTES_PER_MAP = (2 * 42.9e9 + 22.2e9) / 320
+# profiles/r01_pmc_traffic_bf16x6.txt): FETCH_SIZE 37.4 GB raw (x2 for wide coalesced streams on gfx950, per
+# MI355X_MICROARCH.md §HBM) + WRITE_SIZE 21.5 GB.  Scaled linearly with the map count below.
+TRAFFIC_BYTES_PER_MAP = (2 * 37.4e9 + 21.5e9) / 320
 
 
 def host_cores():
@@ -80,6 +85,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="gather the maps to rank 0 over RCCL inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--fp32-mfma", action="store_true", help="keep every conv on the fp32 MFMA (disable bf16x6)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,6 +108,9 @@ def main():
     from lrp_amd import ops
 
     B, T, V = a.batch, a.words, a.vocab
+    if a.fp32_mfma:
+        from lrp_amd import _lib
+        _lib.load().lrpx_set_bf16x6(0)
     torch.set_num_threads(min(8, host_cores()))
     if rank == 0:
         log(f"building weights + engine (B={B}, T={T}, V={V}, world={world})")
@@ -179,10 +188,22 @@ def main():
                 e1.synchronize()
                 ms.append(e0.elapsed_time(e1))
             avg = sum(ms) / len(ms)
-            tf = GFLOP_PER_MAP * B * T / avg          # GFLOP / ms = TFLOP/s
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel relevance pass (13 launches/step)",
-                               "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_FP32_MFMA_TF, 4),
+            tf = GFLOP_PER_MAP * B * T / avg          # GFLOP / ms = TFLOP/s (algorithmic, fp32-equivalent)
+            from lrp_amd import _lib
+            x6 = bool(_lib.load().lrpx_set_bf16x6(-1))
+            if x6:
+                exe = 6.0 * BF16X6_SHARE * tf         # bf16 flops actually issued to the matrix cores
+                rf = {"bound": "mfma", "kernel": "conv_bf16x6_kernel relevance pass (12 launches/step; + first-layer "
+                                                 "VALU kernel and 4 pool kernels inside the timed chain)",
+                      "achieved": round(exe, 1), "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s",
+                      "frac": round(exe / PEAK_BF16_MFMA_TF, 4), "mfma_dtype": "bf16 (exact 3-way split, 6 products, "
+                      "fp32 accumulate)", "algorithmic_tflops_fp32": round(tf, 2),
+                      "vs_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TF, 3)}
+            else:
+                rf = {"bound": "mfma", "kernel": "conv_mfma_kernel relevance pass (13 launches/step)",
+                      "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
+                      "frac": round(tf / PEAK_FP32_MFMA_TF, 4), "mfma_dtype": "f32"}
+            out["roofline"] = {**rf,
                                "traffic": round(TRAFFIC_BYTES_PER_MAP * B * T),
                                "ms_per_step": round(avg, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * B * T}
             if not a.no_cpu_baseline:
