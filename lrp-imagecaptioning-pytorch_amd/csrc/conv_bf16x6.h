@@ -10,7 +10,8 @@
 //   * A is split while it is staged: LDS pixel = 3 planes x 16 bf16 (32 B each) + 16 B pad = 112 B (conflict-free
 //     ds_read_b128: 28 dwords stride);
 //   * weights are split at pack time: per k-step three 1-KiB fragments (lrpx_pack_weights_bf16x3).
-// Used for the relevance passes of the 56x56 / 28x28 / 14x14 VGG16 layers.
+// Used for the relevance pass of every VGG16 layer with >= 64 input channels (conv1_2 .. conv5_3) and for the forward
+// trace of the 112^2 .. 14^2 layers; lrpx_set_bf16x6(0) switches back to the fp32-MFMA kernels of conv_mfma.h.
 #pragma once
 #include "conv_mfma.h"
 
