@@ -29,15 +29,22 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_MAP = 30.69          # one transposed conv per VGG16 layer = 15.35 GMAC (algorithmic, fp32)
 PEAK_FP32_MFMA_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
-# The 12 relevance convs with >= 64 input channels run as "bf16x6": each fp32 product is evaluated as 6 bf16 MFMA
-# products of exact operand thirds (fp32-accurate, csrc/conv_bf16x6.h); the 3-channel first layer is a VALU kernel.
-# Executed matrix work = 6 x the algorithmic flops of those 12 layers (15.26 of the 15.35 GMAC).
-BF16X6_SHARE = (15.35 - 0.087) / 15.35
-# HBM traffic of one relevance pass over 320 maps, from rocprofv3 --pmc (separate passes, tools/pmc_passes.sh;
-# profiles/r01_pmc_traffic_bf16x6.txt): FETCH_SIZE 37.4 GB raw (x2 for wide coalesced streams on gfx950, per
-# MI355X_MICROARCH.md §HBM) + WRITE_SIZE 21.5 GB.  Scaled linearly with the map count below.
-TRAFFIC_BYTES_PER_MAP = (2 * 37.4e9 + 21.5e9) / 320
+PEAK_16BIT_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (no sparsity)
+# The dominant kernel: the relevance step of a 256->256 conv on 56x56 maps (conv3_2 / conv3_3; the three conv3 and
+# three conv4 launches are 55 % of the chain).  Algorithmic work per launch and map: one transposed 3x3 conv =
+# 2*9*256*256*56*56 flop.  The matrix cores execute PRODUCTS[mode] 16-bit MFMA products per fp32 product (operand
+# splits, csrc/conv_f16x3.h / conv_bf16x6.h), so `achieved` counts executed MFMA flop against the 16-bit dense peak;
+# `algorithmic_tflops` is the fp32-equivalent rate.
+DOM_FLOP_PER_MAP = 2.0 * 9 * 256 * 256 * 56 * 56
+MODE_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "bf16x6: exact 3-way bf16 split, 6 products, fp32 accumulate",
+             2: "f16x3: per-map power-of-two scaling, 2-way fp16 split, 3 products, fp32 accumulate"}
+MODE_KERNEL = {0: "conv_mfma_kernel<56,16,1,4,9,REL>", 1: "conv_bf16x6_kernel<56,1,4,true,REL>",
+               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL>"}
+PRODUCTS = {0: 1, 1: 6, 2: 3}
+# HBM traffic of ONE launch of that kernel over 320 maps, from rocprofv3 --pmc (separate passes, tools/pmc_passes.sh;
+# profiles/r01_pmc_traffic_f16x3.txt, ..._bf16x6.txt, r01_pmc_traffic.txt): (2 x FETCH_SIZE raw [gfx950 reports half of wide streaming reads,
+# MI355X_MICROARCH.md §HBM] + WRITE_SIZE) per launch.  Scaled linearly with the map count.
+DOM_TRAFFIC_BYTES_PER_MAP = {0: (2 * 1.9e9 + 0.86e9) / 320, 1: (2 * 1.55e9 + 0.86e9) / 320, 2: (2 * 1.22e9 + 0.86e9) / 320}
 
 
 def host_cores():
@@ -85,7 +92,9 @@ def main():
     ap.add_argument("--gather", action="store_true", help="gather the maps to rank 0 over RCCL inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
-    ap.add_argument("--fp32-mfma", action="store_true", help="keep every conv on the fp32 MFMA (disable bf16x6)")
+    ap.add_argument("--fp32-mfma", action="store_true", help="same as --conv-mode 0")
+    ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 1, 2],
+                    help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3 relevance (default)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,9 +117,9 @@ def main():
     from lrp_amd import ops
 
     B, T, V = a.batch, a.words, a.vocab
-    if a.fp32_mfma:
-        from lrp_amd import _lib
-        _lib.load().lrpx_set_bf16x6(0)
+    from lrp_amd import _lib
+    mode = 0 if a.fp32_mfma else a.conv_mode
+    _lib.load().lrpx_set_conv_mode(mode)
     torch.set_num_threads(min(8, host_cores()))
     if rank == 0:
         log(f"building weights + engine (B={B}, T={T}, V={V}, world={world})")
@@ -173,8 +182,7 @@ def main():
                           "images_per_gpu": B, "words": T, "vocab": V, "maps_per_step": world * B * T,
                           "sharding": f"images x{world}, no data-path collective" + (" + gather" if a.gather else "")}}
         if world == 1:
-            # roofline of the dominant kernel family: the 13 conv_mfma launches (+ pool / first-layer kernels between
-            # them) of one relevance pass, timed live with HIP events on the launch stream, outside the headline timing
+            # (1) the whole VGG16 relevance chain (12 conv launches + first-layer kernel + 4 pool kernels), HIP events
             if "chain_in" not in state:
                 enc = eng.encode(images)
                 state["chain_in"] = eng.relevance(enc, eng.trace(enc, caps, predictions=False))[::2]
@@ -187,25 +195,37 @@ def main():
                 e1.record()
                 e1.synchronize()
                 ms.append(e0.elapsed_time(e1))
-            avg = sum(ms) / len(ms)
-            tf = GFLOP_PER_MAP * B * T / avg          # GFLOP / ms = TFLOP/s (algorithmic, fp32-equivalent)
-            from lrp_amd import _lib
-            x6 = bool(_lib.load().lrpx_set_bf16x6(-1))
-            if x6:
-                exe = 6.0 * BF16X6_SHARE * tf         # bf16 flops actually issued to the matrix cores
-                rf = {"bound": "mfma", "kernel": "conv_bf16x6_kernel relevance pass (12 launches/step; + first-layer "
-                                                 "VALU kernel and 4 pool kernels inside the timed chain)",
-                      "achieved": round(exe, 1), "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s",
-                      "frac": round(exe / PEAK_BF16_MFMA_TF, 4), "mfma_dtype": "bf16 (exact 3-way split, 6 products, "
-                      "fp32 accumulate)", "algorithmic_tflops_fp32": round(tf, 2),
-                      "vs_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TF, 3)}
-            else:
-                rf = {"bound": "mfma", "kernel": "conv_mfma_kernel relevance pass (13 launches/step)",
-                      "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                      "frac": round(tf / PEAK_FP32_MFMA_TF, 4), "mfma_dtype": "f32"}
-            out["roofline"] = {**rf,
-                               "traffic": round(TRAFFIC_BYTES_PER_MAP * B * T),
-                               "ms_per_step": round(avg, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * B * T}
+            chain_ms = sum(ms) / len(ms)
+            # (2) roofline of the dominant kernel: the 56x56 relevance conv kernel (3 launches per pass: conv3_3, conv3_2
+            # with 256 and conv3_1 with 128 output channels), HIP events recorded by the library on the launch stream
+            # around every conv launch of the same chain on the same inputs
+            import ctypes as C
+            lib = _lib.load()
+            per_layer = [0.0] * 17
+            reps = max(3, a.steps)
+            lib.lrpx_vgg16_layer_timing(1, None)
+            buf = (C.c_float * 17)()
+            for _ in range(reps):
+                eng.vgg.relevance(r_feat, row2img, out=maps.view(B * T, 3, 224, 224))
+                lib.lrpx_vgg16_layer_timing(-1, buf)
+                per_layer = [p + float(v) for p, v in zip(per_layer, buf)]
+            lib.lrpx_vgg16_layer_timing(0, None)
+            per_layer = [p / reps for p in per_layer]
+            dom_ms = (per_layer[6] + per_layer[7] + per_layer[8]) / 3.0      # average launch of that kernel
+            flop = DOM_FLOP_PER_MAP * B * T * (0.5 + 1.0 + 1.0) / 3.0         # average algorithmic flop per launch
+            alg = flop / dom_ms / 1e9                                        # TFLOP/s, fp32-equivalent
+            exe = PRODUCTS[mode] * alg
+            peak = PEAK_FP32_MFMA_TF if mode == 0 else PEAK_16BIT_MFMA_TF
+            out["roofline"] = {
+                "bound": "mfma", "kernel": MODE_KERNEL[mode] + f" (relevance step of conv3_1/3_2/3_3 on 56x56 maps, "
+                f"{B * T} maps per launch, 3 launches per step)", "achieved": round(exe, 1), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(exe / peak, 4), "mfma_dtype": MODE_NAME[mode],
+                "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
+                "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,
+                "traffic": round(DOM_TRAFFIC_BYTES_PER_MAP[mode] * B * T),
+                "chain": {"ms_per_step": round(chain_ms, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * B * T,
+                          "algorithmic_tflops": round(GFLOP_PER_MAP * B * T / chain_ms, 1),
+                          "conv_ms_by_layer": {str(l): round(v, 3) for l, v in enumerate(per_layer) if v > 0}}}
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(V, T, [0, 5, 10, 15, 19])
         print(json.dumps(out), flush=True)

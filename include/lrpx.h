@@ -56,11 +56,18 @@ int lrpx_pack_weights(const float* w, int cout, int cin, int taps, int mode, int
  * stored as three bf16 planes w = w0 + w1 + w2; modes BWD_POS / BWD_PLAIN / FWD, 3x3 kernels */
 size_t lrpx_packed_bf16x3_bytes(int n_oc, int k, int taps);
 int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream);
+/* f16x2 split for the fp16 matrix-core path (lrpx_conv_desc.f16x3): the layer's weights are scaled by a power of two
+ * 2^kW (max|w| * 2^kW in [2^14, 2^15)) and stored as two fp16 planes w * 2^kW ~= hi + lo (22 significand bits); a
+ * 64-byte header carries 2^-kW for the consumer's epilogue.  Same modes as lrpx_pack_weights_bf16x3. */
+size_t lrpx_packed_f16x2_bytes(int n_oc, int k, int taps);
+int lrpx_pack_weights_f16x2(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream);
 /* K-chunk used by lrpx_conv_mfma for a given image width / taps / input channels */
 int lrpx_conv_kc(int hw, int taps, int cin);
 
 /* ---- the contraction engine ------------------------------------------------------------------ */
-enum { LRPX_EPI_FWD_DUAL = 0, LRPX_EPI_REL = 1, LRPX_EPI_FIRST = 2, LRPX_EPI_PLAIN = 3, LRPX_EPI_GUIDED = 4 };
+enum { LRPX_EPI_FWD_DUAL = 0, LRPX_EPI_REL = 1, LRPX_EPI_FIRST = 2, LRPX_EPI_PLAIN = 3, LRPX_EPI_GUIDED = 4,
+       LRPX_EPI_REL_MUL = 5 /* out0 and/or out1 = x * acc: the rule with the next layer's division folded into the
+                               multiplicand (x = X for R, x = X / safe(Z_below) for S_next); the f16x3 epilogue */ };
 enum { LRPX_STAB_NONE = 0, LRPX_STAB_SAFE = 1, LRPX_STAB_EPS = 2 };
 
 typedef struct lrpx_conv_desc {
@@ -79,6 +86,14 @@ typedef struct lrpx_conv_desc {
     const int32_t* map2img;
     float* out0;
     float* out1;
+    int f16x3;            /* 1: contraction on the fp16 matrix cores: operands scaled into the fp16 range (per map /
+                             per layer, powers of two) and split in two halves, 3 partial products, fp32 accumulate
+                             (22-bit operands: below the rounding of the fp32 accumulation itself; half the matrix
+                             time of bf16x6).  wpacked from lrpx_pack_weights_f16x2; needs in_amax; REL_MUL epilogue,
+                             3x3 convs, cin %% 16 == 0 */
+    int reserved_;
+    const uint32_t* in_amax;  /* f16x3: [n_maps] float bits of max|in| per map (lrpx_amax_maps, or a producer's out1_amax) */
+    uint32_t* out1_amax;      /* f16x3 + out1: max|out1| per map is atomicMax-ed into it (zero it first); may be null */
 } lrpx_conv_desc;
 /* 3x3/pad-1 convolution (taps=9, square hw x hw maps) or dense GEMM (taps=1) on the fp32 MFMA with
  * the fused epilogues of the relevance rules.  Replaces F.conv2d / conv backward inside
@@ -105,6 +120,8 @@ int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* z
 /* s[n,p,c] = r[n,p,c] / stab(z[img(n),p,c])   (LRPtools/utils.py:16-18 safe_divide with broadcast) */
 int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c,
                      int stab, void* stream);
+/* amax[n] = float bits of max |s[n,:]| (zeroes amax first): the per-map operand scale of the f16x3 convolution */
+int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* stream);
 /* running sum over the maps of one image: out[b,t] = sum_{t'<=t} in[b,t']  (the reference's
  * `sample.grad` accumulation, LRPtools/lrp_wrapper.py:64-82); per = floats per map */
 int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long per, void* stream);
@@ -121,6 +138,9 @@ int lrpx_check(const float* buf, long n, int flags, void* stream);
  * the bf16 matrix cores with exact operand splits (fp32 accuracy, see lrpx_conv_desc.bf16x6), 0 keeps the fp32 MFMA
  * everywhere; a negative value only queries.  Returns the previous setting. */
 int lrpx_set_bf16x6(int enable);
+/* Matrix-core mode of the fused VGG16 chains: 0 fp32 MFMA, 1 bf16x6 (exact splits), 2 f16x3 for the relevance pass
+ * (forward trace stays bf16x6).  Negative: query only.  Returns the previous mode. */
+int lrpx_set_conv_mode(int mode);
 
 /* ---- VGG16 encoder: trace + relevance chain ------------------------------------------------------ */
 /* bytes of the packed-weight blob / per-batch trace / relevance workspace */
@@ -129,6 +149,13 @@ size_t lrpx_vgg16_trace_bytes(int n_img);
 size_t lrpx_vgg16_workspace_bytes(int n_maps);
 /* w[13], b[13]: device pointers to the conv weights (cout,cin,3,3) / biases in layer order */
 int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, void* stream);
+/* Per-layer timing of lrpx_vgg16_relevance for profiling: enable = 1 makes the following calls record HIP events on
+ * their launch stream around every conv launch; ms17 (may be null) receives the elapsed milliseconds per VGG16 layer
+ * index (0 for pools / the first layer) of the last such call (synchronises on its events).  enable < 0: query only. */
+int lrpx_vgg16_layer_timing(int enable, float* ms17);
+/* recompute the trace tensors derived from the saved activations (x / safe(Z+_below), the multiplicand of the fused
+ * conv->conv relevance step); lrpx_vgg16_forward calls it, callers that overwrite activations in the trace must too */
+int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream);
 /* Encoder.forward (models/gridTDmodel.py:40-43) + the per-layer inputs `save_input_hook` keeps
  * (LRPtools/lrp_wrapper.py:24-25) + Z+ of every conv.  img: (n_img,3,224,224) NCHW.
  * feat_nhwc: (n_img,196,512) encoder output (may be null: it also lives in the trace). */

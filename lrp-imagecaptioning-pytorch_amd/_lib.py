@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblrpx.so")
 
 OK, EINVAL, EARCH, ELAUNCH, ENONFINITE, EZERO = range(6)
 PACK_FWD_DUAL, PACK_BWD_POS, PACK_BWD_FIRST, PACK_BWD_PLAIN, PACK_DENSE_T, PACK_DENSE, PACK_FWD, PACK_FWD_DUAL_FIRST = range(8)
-EPI_FWD_DUAL, EPI_REL, EPI_FIRST, EPI_PLAIN, EPI_GUIDED = range(5)
+EPI_FWD_DUAL, EPI_REL, EPI_FIRST, EPI_PLAIN, EPI_GUIDED, EPI_REL_MUL = range(6)
 STAB_NONE, STAB_SAFE, STAB_EPS = range(3)
 
 _f = C.c_void_p      # device pointers travel as void*
@@ -50,7 +50,8 @@ class ConvDesc(C.Structure):
                 ("n_maps", _i), ("hw", _i), ("cin", _i), ("n_oc", _i), ("taps", _i), ("pix_per_map", _i),
                 ("epi", _i), ("stab", _i), ("oc_split", _i), ("relu", _i), ("in_chunked", _i), ("bf16x6", _i),
                 ("bias", _f), ("x", _f), ("u", _f), ("zdiv", _f), ("map2img", _f),
-                ("out0", _f), ("out1", _f)]
+                ("out0", _f), ("out1", _f),
+                ("f16x3", _i), ("reserved_", _i), ("in_amax", _f), ("out1_amax", _f)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/lrpx.h (tests/test_abi.py checks it)
@@ -61,6 +62,8 @@ SIGNATURES = {
     "lrpx_pack_weights": (_i, [_f, _i, _i, _i, _i, _i, _f, _f]),
     "lrpx_packed_bf16x3_bytes": (_sz, [_i, _i, _i]),
     "lrpx_pack_weights_bf16x3": (_i, [_f, _i, _i, _i, _i, _f, _f]),
+    "lrpx_packed_f16x2_bytes": (_sz, [_i, _i, _i]),
+    "lrpx_pack_weights_f16x2": (_i, [_f, _i, _i, _i, _i, _f, _f]),
     "lrpx_conv_kc": (_i, [_i, _i, _i]),
     "lrpx_conv_mfma": (_i, [C.POINTER(ConvDesc), _f]),
     "lrpx_nchw_to_nhwc": (_i, [_f, _f, _i, _i, _i, _i, _f]),
@@ -69,6 +72,7 @@ SIGNATURES = {
     "lrpx_maxpool2x2_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "lrpx_maxpool2x2_relevance": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "lrpx_divide_stab": (_i, [_f, _f, _f, _f, _i, _l, _i, _f]),
+    "lrpx_amax_maps": (_i, [_f, _i, _l, _f, _f]),
     "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),
     "lrpx_accumulate": (_i, [_f, _f, _l, _f]),
     "lrpx_fold_halves": (_i, [_f, _f, _l, _i, _f]),
@@ -101,12 +105,15 @@ SIGNATURES = {
     "lrpx_positive_mask": (_i, [_f, _f, _l, _f]),
     "lrpx_vgg16_guided_backprop": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, _f]),
     "lrpx_set_bf16x6": (_i, [_i]),
+    "lrpx_set_conv_mode": (_i, [_i]),
     "lrpx_vgg16_packed_bytes": (_sz, []),
     "lrpx_vgg16_trace_bytes": (_sz, [_i]),
     "lrpx_vgg16_workspace_bytes": (_sz, [_i]),
     "lrpx_vgg16_pack": (_i, [C.POINTER(_f), C.POINTER(_f), _f, _f]),
     "lrpx_vgg16_forward": (_i, [_f, _f, _i, _f, _f, _f]),
     "lrpx_vgg16_relevance": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, _f]),
+    "lrpx_vgg16_layer_timing": (_i, [_i, _f]),
+    "lrpx_vgg16_trace_derive": (_i, [_f, _i, _f]),
     "lrpx_vgg16_trace_layout": (_i, [_i, C.POINTER(_sz), C.POINTER(_sz)]),
     "lrpx_vgg16_trace_features": (_f, [_f, _i]),
 }

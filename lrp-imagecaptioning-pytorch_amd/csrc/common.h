@@ -33,6 +33,13 @@ inline int check_launch(const char* what) {
         if (rc__ != LRPX_OK) return rc__; \
     } while (0)
 
+// elementwise producers of S that also record max|S| per map for an f16x3 consumer (lrpx_core.hip)
+int maxpool_relevance_amax(const float* x, const float* r_out, const float* zdiv, const int32_t* map2img, float* r_in,
+                           float* s_out, int n_maps, int h_out, int w_out, int c, int s_chunk, unsigned* amax,
+                           hipStream_t stream);
+int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c, int stab,
+                     unsigned* amax, hipStream_t stream);
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 

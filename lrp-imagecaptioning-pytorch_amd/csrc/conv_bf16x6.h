@@ -15,6 +15,13 @@
 #pragma once
 #include "conv_mfma.h"
 
+#ifndef LRPX6_NBQ
+#define LRPX6_NBQ ((HW <= 56) ? 5 : 4)   // B-fragment register queue depth (k-steps in flight: NBQ-1); 5 spills at 112/224
+#endif
+#ifndef LRPX6_APIPE
+#define LRPX6_APIPE 0    // 1: A fragments read one accumulator tile ahead (sched_group_barrier pinned)
+#endif
+
 namespace lrpx {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -36,18 +43,36 @@ __device__ __forceinline__ void split3(float x, unsigned short& p0, unsigned sho
     p2 = f32_to_bf16_rn(r2);
 }
 
+#ifdef LRPX_STAMP
+// profiling build only (make STAMP=1): per-phase shader-clock totals over all waves, read by lrpx_debug_stamps()
+static __device__ unsigned long long g_stamp[8];
+#define LRPX_T(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); \
+                  __builtin_amdgcn_sched_barrier(0)
+#else
+#define LRPX_T(v)
+#endif
+
 // DB: double-buffered A tile (one barrier per chunk).  DB = false (tiles whose two buffers would not leave room for two
 // workgroups per CU: the 112-pixel layers): one buffer, the prefetched registers are committed between two barriers.
 template <int HW, int MT, int NWN, bool DB, int EPI>
 __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     constexpr int KC = 16, TAPS = 9;
     using C = ConvCfg<HW, KC, MT, NWN, TAPS>;
-    constexpr int W = C::W, H = C::H, WP = C::WP, NT = C::NT;
+    constexpr int W = C::W, H = C::H, NT = C::NT;
     constexpr int PSTRIDE = 112;                       // bytes per LDS pixel
-    constexpr int BUFB = C::NSLOT * WP * PSTRIDE;      // bytes per LDS buffer
+    // LDS row pitch: (W+2) pixels rounded up so that pitch/16 == 7*W (mod 16).  The 16-byte slot of pixel q = r*W + c of
+    // a tile is then 7*q + const (mod 16) even when the 32 pixels of an MFMA row-tile wrap onto the next image row, so
+    // every 16-lane group of a ds_read_b128 hits 16 distinct slots (with pitch = (W+2)*112 the wrapped lanes collided:
+    // 30-50 % extra LDS cycles on the 56/28/14 layers)
+    constexpr int PITCH = W * PSTRIDE + 256;
+    constexpr int BUFB = C::NSLOT * PITCH;             // bytes per LDS buffer
     constexpr int NBUF = DB ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
+    LRPX_T(t_start);
+#ifdef LRPX_STAMP
+    unsigned long long s_issue = 0, s_mfma = 0, s_commit = 0, s_barrier = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,7 +98,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs 
         const int r = q / W, c = q % W;
         const long g = g0 + r;
         const int slot = (int)(g + g / H - v0) + 1;
-        abase[j] = ((slot - 1) * WP + c) * PSTRIDE + lh * 16;
+        abase[j] = (slot - 1) * PITCH + c * PSTRIDE + lh * 16;
     }
 
     // ---- staging descriptors (16 channels = 4 float4 segments per pixel) ----
@@ -93,7 +118,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs 
             const long n = v_ / (H + 1);
             const int y = (int)(v_ - n * (H + 1));
             if ((v_ >= 0) && (y < H) && (n < a.n_maps)) {
-                sdst[u] = ((s * WP + px + 1) * PSTRIDE + seg * 8) | (seg << 28);   // byte offset of plane 0, 4 bf16
+                sdst[u] = (s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28);   // byte offset of plane 0, 4 bf16
                 sgp[u] = (int)((n * H + y) * W + px);
             }
         }
@@ -130,7 +155,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs 
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
     // B fragments: per k-step three planes of 64 lanes x 16 B, one contiguous stream per channel block
-    constexpr int NBQ = 4;
+    constexpr int NBQ = LRPX6_NBQ;
     const u32x4* wp = reinterpret_cast<const u32x4*>(a.wp) + (long)ocb * nchunk * (TAPS * 3 * 64) + lane;
     const int last_step = nchunk * TAPS - 1;
     u32x4 bq[NBQ][3];
@@ -146,14 +171,24 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs 
     }
     __syncthreads();
 
+    LRPX_T(t_loop);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = chunk + 1 < nchunk;
+        LRPX_T(ta);
         if (more) { LRPX6_ISSUE(chunk + 1) }
+        LRPX_T(tb);
         if (wave_active) {
             const char* abuf = ldsb + (DB ? (chunk & 1) : 0) * BUFB;
+            // A fragments run one accumulator tile ahead of the MFMAs that consume them (the LDS latency of a read
+            // issued right before its MFMA is otherwise exposed 63 times per chunk)
+#if LRPX6_APIPE
+            bf16x8 n0 = *reinterpret_cast<const bf16x8*>(abuf + abase[0]);
+            bf16x8 n1 = *reinterpret_cast<const bf16x8*>(abuf + abase[0] + 32);
+            bf16x8 n2 = *reinterpret_cast<const bf16x8*>(abuf + abase[0] + 64);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);           // (tile 0 of tap 0)
+#endif
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
-                const int tapoff = ((tap / 3) * WP + (tap % 3)) * PSTRIDE;
                 const long nxt = (long)min(chunk * TAPS + tap + NBQ - 1, last_step) * 3;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bq[NBQ - 1][p] = wp[(nxt + p) * 64];
@@ -162,10 +197,21 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs 
                 const bf16x8 b2 = __builtin_bit_cast(bf16x8, bq[0][2]);
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
-                    const char* ap = abuf + abase[j] + tapoff;
+#if LRPX6_APIPE
+                    const bf16x8 a0 = n0, a1 = n1, a2 = n2;
+                    if (!(tap == TAPS - 1 && j == 6)) {
+                        const int jn = (j + 1) % 7, tn = tap + (j == 6 ? 1 : 0);
+                        const char* ap = abuf + abase[jn] + (tn / 3) * PITCH + (tn % 3) * PSTRIDE;
+                        n2 = *reinterpret_cast<const bf16x8*>(ap + 64);
+                        n1 = *reinterpret_cast<const bf16x8*>(ap + 32);
+                        n0 = *reinterpret_cast<const bf16x8*>(ap);
+                    }
+#else
+                    const char* ap = abuf + abase[j] + (tap / 3) * PITCH + (tap % 3) * PSTRIDE;
                     const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap);
                     const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32);
                     const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ap + 64);
+#endif
                     // smallest terms first
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
@@ -173,6 +219,10 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs 
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+#if LRPX6_APIPE
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the 3 reads of the NEXT tile ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... then the 6 MFMAs of this one
+#endif
                 }
 #pragma unroll
                 for (int i = 0; i < NBQ - 1; ++i)
@@ -180,9 +230,15 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs 
                     for (int p = 0; p < 3; ++p) bq[i][p] = bq[i + 1][p];
             }
         }
+        LRPX_T(tc);
         if constexpr (DB) {
             if (more) { LRPX6_COMMIT((chunk + 1) & 1) }
+            LRPX_T(td);
             __syncthreads();
+            LRPX_T(te);
+#ifdef LRPX_STAMP
+            s_issue += tb - ta; s_mfma += tc - tb; s_commit += td - tc; s_barrier += te - td;
+#endif
         } else {
             __syncthreads();                       // every wave is done reading the single buffer
             if (more) { LRPX6_COMMIT(0) }
@@ -192,6 +248,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs 
 #undef LRPX6_ISSUE
 #undef LRPX6_COMMIT
     if (!wave_active) return;
+    LRPX_T(t_epi);
 
     EpiCtx cx;
     cx.oc = ocb * 32 + li;
@@ -224,12 +281,26 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_bf16x6_kernel(ConvArgs 
     epi_gather<EPI, HW, TAPS, AL>(a, cx, 6, ra);
     epi_finish<EPI, HW, TAPS, AL>(a, cx, 5, acc[5], rb);
     epi_finish<EPI, HW, TAPS, AL>(a, cx, 6, acc[6], ra);
+#ifdef LRPX_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LRPX_T(t_end);
+    if (lane == 0) {
+        atomicAdd(&g_stamp[0], t_loop - t_start);
+        atomicAdd(&g_stamp[1], s_issue);
+        atomicAdd(&g_stamp[2], s_mfma);
+        atomicAdd(&g_stamp[3], s_commit);
+        atomicAdd(&g_stamp[4], s_barrier);
+        atomicAdd(&g_stamp[5], t_end - t_epi);
+        atomicAdd(&g_stamp[6], t_end - t_start);
+        atomicAdd(&g_stamp[7], 1ull);
+    }
+#endif
 }
 
 template <int HW, int MT, int NWN, bool DB, int EPI>
 int launch_conv_bf16x6(const ConvArgs& a, hipStream_t stream) {
     using C = ConvCfg<HW, 16, MT, NWN, 9>;
-    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * C::WP * 112;
+    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 112 + 256);
     const long m_tiles = ceil_div((long)a.n_maps * HW, C::R);
     const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
     const long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;

@@ -1,0 +1,427 @@
+// fp32-grade 3x3 convolution on the fp16 matrix cores ("f16x3"): both operands are scaled by a power of two into the
+// fp16 range and split into two halves a = a0 + a1 (11 + 11 significand bits, |a - a0 - a1| <= 2^-22 |a|); the three
+// products
+//        a*b ~= a0b0 + (a0b1 + a1b0)
+// are accumulated in fp32 by v_mfma_f32_32x32x16_f16.  The dropped a1b1 term and the split residue are <= 2^-21
+// relative PER PRODUCT with random sign - an order of magnitude below the rounding of the fp32 accumulation over
+// K = 576..4608 terms that every fp32 implementation (the reference's included) carries - while 3 fp16 MFMAs of K=16
+// cost 96 SIMD-cycles against 192 for bf16x6 and 512 on the fp32 MFMA.
+//
+// Range: fp16 has 5 exponent bits, so the A operand (S = R / Z, any magnitude) is scaled PER MAP by 2^kA with
+// max|S_map| * 2^kA in [2^14, 2^15); the producer of S records max|S| per map (`amax`, float bits, atomicMax) and this
+// kernel records it for the S it writes (out1).  Weights are scaled per layer at pack time (2^kW, header of the packed
+// blob).  Entries more than ~2^29 below their map's maximum flush to zero: an absolute error of 2^-29 max|S|, far
+// inside the 1e-4 * max|R| contract of the path.  The epilogue multiplies the accumulators by 2^-kA * 2^-kW (exact).
+// An amax that is too small (stale) overflows to inf and is caught by lrpx_check - never silently wrong.
+//
+// Tiling, LDS double buffering, B-fragment queue and epilogues as conv_bf16x6.h; LDS pixel = 2 planes x 16 fp16 (32 B
+// each) + 16 B pad = 80 B; row pitch 80*W + 256 so that the 16-byte slot of tile pixel q is 5q + const (mod 16) across
+// image-row wraps (conflict-free ds_read_b128).
+#pragma once
+#include "conv_mfma.h"
+
+namespace lrpx {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+
+constexpr int F16X3_HEADER_FLOATS = 16;   // packed weights: [0] = 2^-kW, [1] = bits of max|W| (diagnostic)
+
+// exponent k with amax * 2^k in [2^14, 2^15); 0 for an all-zero / denormal-only / non-finite tensor
+__host__ __device__ __forceinline__ int f16_scale_exp(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xff);
+    if (e == 0 || e == 255) return 0;
+    const int k = 14 - (e - 127);
+    return k > 120 ? 120 : k;
+}
+__host__ __device__ __forceinline__ float exp2i(int k) {   // 2^k, |k| <= 126
+    const unsigned b = (unsigned)(k + 127) << 23;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(float, b);
+#else
+    float f; __builtin_memcpy(&f, &b, 4); return f;
+#endif
+}
+
+__device__ __forceinline__ unsigned pack_f16(_Float16 a, _Float16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+// two-way split of an (already scaled) value: x ~= hi + lo
+__device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;                 // v_cvt_f16_f32, round to nearest even; inf / nan stay inf / nan
+    lo = (_Float16)(x - (float)hi);   // exact difference in fp32, rounded once
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// amax[.] = max(amax[.], m) on float bits.  Up to a million callers update a few hundred words: the plain cached read
+// first turns all but the first few updates per word into an L1/L2 hit - a stale (smaller) value only costs a
+// redundant atomic, never a wrong maximum.
+__device__ __forceinline__ void amax_update(unsigned* p, float m) {
+    const unsigned b = __builtin_bit_cast(unsigned, m);
+    if (m > 0.f && b > *reinterpret_cast<const volatile unsigned*>(p)) atomicMax(p, b);
+}
+
+#ifdef LRPX_STAMP
+// profiling build only (make STAMP=1): per-phase shader-clock totals of the kernels with HW == LRPX_STAMP_HW
+#ifndef LRPX_STAMP_HW
+#define LRPX_STAMP_HW 224
+#endif
+static __device__ unsigned long long g_stamp_h3[8];
+#define LRPXH_T(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); \
+                   __builtin_amdgcn_sched_barrier(0)
+#else
+#define LRPXH_T(v)
+#endif
+
+template <int HW, int MT, int NWN, bool DB, int EPI>
+__global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+    LRPXH_T(t_start);
+#ifdef LRPX_STAMP
+    unsigned long long s_issue = 0, s_mfma = 0, s_commit = 0, s_barrier = 0;
+#endif
+    constexpr int KC = 16, TAPS = 9;
+    using C = ConvCfg<HW, KC, MT, NWN, TAPS>;
+    constexpr int W = C::W, H = C::H, NT = C::NT;
+    constexpr int PSTRIDE = 80;                        // bytes per LDS pixel
+    constexpr int PITCH = W * PSTRIDE + 256;           // pitch/16 == 5*W (mod 16), >= (W+2) pixels
+    constexpr int BUFB = C::NSLOT * PITCH;
+    constexpr int NBUF = DB ? 2 : 1;
+    constexpr bool AL = (H % C::R == 0);               // a workgroup tile never straddles two maps
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int mtile = (idx / n_blocks) * 8 + xcd;
+    const int nblk = idx % n_blocks;
+    if (mtile >= m_tiles) return;
+
+    const int ocb = nblk * NWN + wn;
+    const bool wave_active = ocb * 32 < a.n_oc;
+    const int nchunk = a.cin / KC;
+    const long total_pix = (long)a.n_maps * a.pix_per_map;
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned* __restrict__ in_amax = a.in_amax;
+
+    const long g0 = (long)mtile * C::R;
+    const long v0 = g0 + g0 / H;
+    int abase[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int q = wm * 224 + 32 * j + li;
+        const int r = q / W, c = q % W;
+        const long g = g0 + r;
+        const int slot = (int)(g + g / H - v0) + 1;
+        abase[j] = (slot - 1) * PITCH + c * PSTRIDE + lh * 16;
+    }
+
+    // ---- staging descriptors (16 channels = 4 float4 segments per pixel) ----
+    // item `it` = (LDS row s, pixel px, 16-byte segment seg) -> LDS byte offset of its 4 fp16 in plane 0 (segment index in
+    // the top bits; -1: never written, stays zero) and global pixel (-1: nothing to load).  Map-aligned tiles (224/112/
+    // 56) derive both from `it` when needed - the tile sits inside one map, rows outside it are the zero padding;
+    // tiles that can straddle maps (28/14: virtual zero row between maps) keep them in registers with the map's scale.
+    constexpr int SEG = KC / 4;
+    constexpr int NITEM = C::NSLOT * W * SEG;
+    constexpr int U = (NITEM + NT - 1) / NT;
+    constexpr int UR = AL ? 1 : U;
+    int sdst[UR], sgp[UR];
+    float ssc[UR];         // 2^kA of the item's map (one value per workgroup when tiles are map-aligned)
+    const int n_al = (int)((unsigned)g0 / (unsigned)H), y_al = (int)g0 - n_al * H;
+    if constexpr (AL) {
+        ssc[0] = exp2i(f16_scale_exp(in_amax[min(n_al, a.n_maps - 1)]));
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = tid + u * NT;
+            sdst[u] = -1; sgp[u] = -1; ssc[u] = 1.f;
+            if (it < NITEM) {
+                const int s = it / (W * SEG);
+                const int rem = it - s * (W * SEG);
+                const int px = rem / SEG, seg = rem - px * SEG;
+                const long v_ = v0 - 1 + s;
+                const long n = v_ / (H + 1);
+                const int y = (int)(v_ - n * (H + 1));
+                if ((v_ >= 0) && (y < H) && (n < a.n_maps)) {
+                    sdst[u] = (s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28);
+                    sgp[u] = (int)((n * H + y) * W + px);
+                    ssc[u] = exp2i(f16_scale_exp(in_amax[n]));
+                }
+            }
+        }
+    }
+    auto item = [&](const int u, int& dst, int& gp) {
+        if constexpr (AL) {
+            int it = tid + u * NT;
+            asm volatile("" : "+v"(it));     // recompute per use: hoisted out of the chunk loop it costs 2U registers
+            const int s = it / (W * SEG);
+            const int rem = it - s * (W * SEG);
+            const int px = rem / SEG, seg = rem - px * SEG;
+            const int y = y_al - 1 + s;
+            const bool ok = (it < NITEM) && (y >= 0) && (y < H);
+            dst = ok ? ((s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28)) : -1;
+            gp = ok ? (n_al * H + y) * W + px : -1;
+        } else {
+            dst = sdst[u]; gp = sgp[u];
+        }
+    };
+    f32x4 sv[U];
+#define LRPXH_ISSUE(CHUNK)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
+        int dst_, gp_;                                                                                       \
+        item(u, dst_, gp_);                                                                                  \
+        sv[u] = f32x4{0, 0, 0, 0};                                                                           \
+        if (gp_ >= 0)                                                                                        \
+            sv[u] = *reinterpret_cast<const f32x4*>(                                                         \
+                a.in_chunk_stride ? a.in + (CHUNK) * a.in_chunk_stride + (long)gp_ * KC + ((dst_ >> 28) & 7) * 4 \
+                                  : a.in + (long)gp_ * a.cin + (CHUNK) * KC + ((dst_ >> 28) & 7) * 4);        \
+    }
+#define LRPXH_COMMIT(BUFIDX)                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
+        int dst_, gp_;                                                                                       \
+        item(u, dst_, gp_);                                                                                  \
+        if (dst_ >= 0) {                                                                                     \
+            _Float16 h[4], l[4];                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * ssc[AL ? 0 : u], h[e], l[e]);     \
+            char* d = ldsb + (BUFIDX) * BUFB + (dst_ & 0x0fffffff);                                          \
+            *reinterpret_cast<u32x2_*>(d) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};              \
+            *reinterpret_cast<u32x2_*>(d + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};         \
+        }                                                                                                    \
+    }
+
+    LRPXH_ISSUE(0)
+    for (int i = tid; i < NBUF * BUFB / 16; i += NT) reinterpret_cast<u32x4_*>(ldsb)[i] = u32x4_{0, 0, 0, 0};
+    __syncthreads();
+    LRPXH_COMMIT(0)
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // B fragments: per k-step two planes (hi, lo) of 64 lanes x 16 B, one contiguous stream per channel block
+    constexpr int NBQ = (HW == 224) ? 5 : 6;
+    const float inv_w = a.wp[0];
+    const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
+                       (long)ocb * nchunk * (TAPS * 2 * 64) + lane;
+    const int last_step = nchunk * TAPS - 1;
+    u32x4_ bq[NBQ][2];
+#pragma unroll
+    for (int i = 0; i < NBQ; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bq[i][p] = u32x4_{0, 0, 0, 0};
+    if (wave_active) {
+#pragma unroll
+        for (int i = 0; i < NBQ - 1; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bq[i][p] = wp[((long)min(i, last_step) * 2 + p) * 64];
+    }
+    __syncthreads();
+
+    LRPXH_T(t_loop);
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const bool more = chunk + 1 < nchunk;
+        LRPXH_T(ta);
+        if (more) { LRPXH_ISSUE(chunk + 1) }
+        LRPXH_T(tb);
+        if (wave_active) {
+            const char* abuf = ldsb + (DB ? (chunk & 1) : 0) * BUFB;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int tapoff = (tap / 3) * PITCH + (tap % 3) * PSTRIDE;
+                const long nxt = (long)min(chunk * TAPS + tap + NBQ - 1, last_step) * 2;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bq[NBQ - 1][p] = wp[(nxt + p) * 64];
+                const f16x8 b0 = __builtin_bit_cast(f16x8, bq[0][0]);
+                const f16x8 b1 = __builtin_bit_cast(f16x8, bq[0][1]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const char* ap = abuf + abase[j] + tapoff;
+                    const f16x8 a0 = *reinterpret_cast<const f16x8*>(ap);
+                    const f16x8 a1 = *reinterpret_cast<const f16x8*>(ap + 32);
+                    // small terms first
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NBQ - 1; ++i)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) bq[i][p] = bq[i + 1][p];
+            }
+        }
+        LRPXH_T(tc);
+        if constexpr (DB) {
+            if (more) { LRPXH_COMMIT((chunk + 1) & 1) }
+            LRPXH_T(td);
+            __syncthreads();
+            LRPXH_T(te);
+#ifdef LRPX_STAMP
+            s_issue += tb - ta; s_mfma += tc - tb; s_commit += td - tc; s_barrier += te - td;
+#endif
+        } else {
+            __syncthreads();                       // every wave is done reading the single buffer
+            LRPXH_T(td0);
+            if (more) { LRPXH_COMMIT(0) }
+            LRPXH_T(td);
+            __syncthreads();
+            LRPXH_T(te);
+#ifdef LRPX_STAMP
+            s_issue += tb - ta; s_mfma += tc - tb; s_commit += td - td0; s_barrier += (te - td) + (td0 - tc);
+#endif
+        }
+    }
+#undef LRPXH_ISSUE
+#undef LRPXH_COMMIT
+    if (!wave_active) return;
+    LRPXH_T(t_epi);
+
+    EpiCtx cx;
+    cx.oc = ocb * 32 + li;
+    cx.lane = lane;
+    cx.q0 = wm * 224 + 4 * lh;
+    cx.g0 = (int)g0;
+    cx.pix0 = g0 * W;
+    cx.total_pix = total_pix;
+    cx.xi_base = 0;
+    if constexpr (AL) {
+        const unsigned rr = (unsigned)cx.q0 / (unsigned)HW, cc = (unsigned)cx.q0 - rr * HW;
+        const unsigned g = (unsigned)cx.g0 + rr;
+        const unsigned n = g / (unsigned)HW;
+        const long img = a.map2img ? a.map2img[n] : n;
+        cx.xi_base = (img * a.pix_per_map + (long)((g - n * HW) * HW + cc)) * a.oc_split + cx.oc;
+    }
+
+    // ---- undo the operand scales: acc * 2^-kA(map of the pixel) * 2^-kW ----
+    const int nmax = a.n_maps - 1;
+    if constexpr (AL) {
+        const unsigned n = (unsigned)g0 / (unsigned)H;
+        const float inv_a = exp2i(-f16_scale_exp(in_amax[min((int)n, nmax)]));
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = acc[j][e] * inv_a * inv_w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            // a 32-pixel accumulator tile is shorter than a map: at most one boundary inside it (cf. epi_gather)
+            const unsigned q0t = (unsigned)(cx.q0 + 32 * j);
+            const unsigned rr = q0t / (unsigned)HW, c0 = q0t - rr * HW;
+            const unsigned g = (unsigned)cx.g0 + rr;
+            const unsigned n0 = g / (unsigned)HW;
+            const int p0 = (int)((g - n0 * HW) * HW + c0);
+            const float i0 = exp2i(-f16_scale_exp(in_amax[min((int)n0, nmax)]));
+            const float i1 = exp2i(-f16_scale_exp(in_amax[min((int)n0 + 1, nmax)]));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dq = (e & 3) + 8 * (e >> 2);
+                acc[j][e] = acc[j][e] * (p0 + dq < a.pix_per_map ? i0 : i1) * inv_w;
+            }
+        }
+    }
+
+    // ---- epilogue (software-pipelined per tile); max|out1| per map goes to a.out1_amax for the next f16x3 consumer ----
+    unsigned* __restrict__ oamax = ((EPI == EPI_REL || EPI == EPI_REL_MUL) && a.out1) ? a.out1_amax : nullptr;
+    EpiMax mx0 = {0.f, 0.f}, mx1 = mx0, mx2 = mx0, mx3 = mx0, mx4 = mx0, mx5 = mx0, mx6 = mx0;   // (scalars: an array
+    if constexpr (EPI == EPI_REL_MUL) {                                                  //  would live in scratch)
+        // one multiplicand per element: all 112 loads are issued before the first store (stores share the in-order
+        // vmcnt with loads - a load behind a store waits for the store's write acknowledgement)
+        EpiRegs r0, r1, r2, r3, r4, r5, r6;
+        epi_gather<EPI, HW, TAPS, AL>(a, cx, 0, r0);
+        epi_gather<EPI, HW, TAPS, AL>(a, cx, 1, r1);
+        epi_gather<EPI, HW, TAPS, AL>(a, cx, 2, r2);
+        epi_gather<EPI, HW, TAPS, AL>(a, cx, 3, r3);
+        epi_gather<EPI, HW, TAPS, AL>(a, cx, 4, r4);
+        epi_gather<EPI, HW, TAPS, AL>(a, cx, 5, r5);
+        epi_gather<EPI, HW, TAPS, AL>(a, cx, 6, r6);
+        epi_finish<EPI, HW, TAPS, AL>(a, cx, 0, acc[0], r0, &mx0);
+        epi_finish<EPI, HW, TAPS, AL>(a, cx, 1, acc[1], r1, &mx1);
+        epi_finish<EPI, HW, TAPS, AL>(a, cx, 2, acc[2], r2, &mx2);
+        epi_finish<EPI, HW, TAPS, AL>(a, cx, 3, acc[3], r3, &mx3);
+        epi_finish<EPI, HW, TAPS, AL>(a, cx, 4, acc[4], r4, &mx4);
+        epi_finish<EPI, HW, TAPS, AL>(a, cx, 5, acc[5], r5, &mx5);
+        epi_finish<EPI, HW, TAPS, AL>(a, cx, 6, acc[6], r6, &mx6);
+    } else {
+    EpiRegs ra, rb;
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 0, ra);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 1, rb);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 0, acc[0], ra, &mx0);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 2, ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 1, acc[1], rb, &mx1);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 3, rb);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 2, acc[2], ra, &mx2);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 4, ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 3, acc[3], rb, &mx3);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 5, rb);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 4, acc[4], ra, &mx4);
+    epi_gather<EPI, HW, TAPS, AL>(a, cx, 6, ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 5, acc[5], rb, &mx5);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 6, acc[6], ra, &mx6);
+    }
+    if (oamax) {
+        if constexpr (AL) {
+            float m = fmaxf(fmaxf(fmaxf(mx0.m0, mx1.m0), fmaxf(mx2.m0, mx3.m0)), fmaxf(fmaxf(mx4.m0, mx5.m0), mx6.m0));
+            m = wave_max(m);
+            const unsigned n = (unsigned)g0 / (unsigned)H;
+            if (lane == 0 && (int)n <= nmax) amax_update(&oamax[n], m);
+        } else {
+#define LRPXH_AMAX(J, MX)                                                                                       \
+            {                                                                                                   \
+                const unsigned q0t = (unsigned)(wm * 224 + 32 * (J));                                           \
+                const unsigned n0 = ((unsigned)cx.g0 + q0t / (unsigned)HW) / (unsigned)HW;                       \
+                const float m0 = wave_max(MX.m0), m1 = wave_max(MX.m1);                                         \
+                if (lane == 0 && (int)n0 <= nmax) amax_update(&oamax[n0], m0);                                       \
+                if (lane == 0 && (int)n0 + 1 <= nmax) amax_update(&oamax[n0 + 1], m1);                            \
+            }
+            LRPXH_AMAX(0, mx0) LRPXH_AMAX(1, mx1) LRPXH_AMAX(2, mx2) LRPXH_AMAX(3, mx3)
+            LRPXH_AMAX(4, mx4) LRPXH_AMAX(5, mx5) LRPXH_AMAX(6, mx6)
+#undef LRPXH_AMAX
+        }
+    }
+#ifdef LRPX_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LRPXH_T(t_end);
+    if (lane == 0 && HW == LRPX_STAMP_HW) {
+        atomicAdd(&g_stamp_h3[0], t_loop - t_start);
+        atomicAdd(&g_stamp_h3[1], s_issue);
+        atomicAdd(&g_stamp_h3[2], s_mfma);
+        atomicAdd(&g_stamp_h3[3], s_commit);
+        atomicAdd(&g_stamp_h3[4], s_barrier);
+        atomicAdd(&g_stamp_h3[5], t_end - t_epi);
+        atomicAdd(&g_stamp_h3[6], t_end - t_start);
+        atomicAdd(&g_stamp_h3[7], 1ull);
+    }
+#endif
+}
+
+template <int HW, int MT, int NWN, bool DB, int EPI>
+int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
+    using C = ConvCfg<HW, 16, MT, NWN, 9>;
+    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 80 + 256);
+    const long m_tiles = ceil_div((long)a.n_maps * HW, C::R);
+    const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
+    const long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
+    auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess) {
+            set_error("conv_f16x3: cannot reserve %d bytes of LDS", LDS);
+            return LRPX_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MT * NWN), LDS, stream, a, (int)m_tiles, n_blocks);
+    return check_launch("conv_f16x3");
+}
+
+}  // namespace lrpx

@@ -1,0 +1,15 @@
+// instantiations of the fp16 split-product convolution (conv_f16x3.h): relevance passes of the 56/28/14-pixel layers
+#include "conv_launch.h"
+#include "conv_f16x3.h"
+namespace lrpx {
+int launch_h3_56_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<56, 1, 4, true, EPI_REL_MUL>(a, s); }
+int launch_h3_28_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<28, 1, 4, true, EPI_REL_MUL>(a, s); }
+int launch_h3_14_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<14, 1, 4, true, EPI_REL_MUL>(a, s); }
+}
+#ifdef LRPX_STAMP
+extern "C" int lrpx_debug_stamps_h3(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lrpx::g_stamp_h3), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lrpx::g_stamp_h3), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

@@ -67,6 +67,13 @@ int launch_x6_56_fwd(const ConvArgs& a, hipStream_t s);
 int launch_x6_28_fwd(const ConvArgs& a, hipStream_t s);
 int launch_x6_14_fwd(const ConvArgs& a, hipStream_t s);
 
+int launch_h3_224_rel(const ConvArgs& a, hipStream_t s);
+int launch_h3_112_rel(const ConvArgs& a, hipStream_t s);
+int launch_h3_112n_rel(const ConvArgs& a, hipStream_t s);
+int launch_h3_56_rel(const ConvArgs& a, hipStream_t s);
+int launch_h3_28_rel(const ConvArgs& a, hipStream_t s);
+int launch_h3_14_rel(const ConvArgs& a, hipStream_t s);
+
 // host-side entry used by the C ABI and by the VGG16 / decoder chains
 int conv_dispatch(const lrpx_conv_desc* d, hipStream_t stream);
 

@@ -30,6 +30,8 @@ enum Epilogue : int {
     EPI_FIRST = 2,      // first VGG layer: r = X+ * acc[c] + X- * acc[c+3]  -> NCHW out0 (X stored split x+|x-)
     EPI_PLAIN = 3,      // out0 = acc (+ bias) (optionally relu)
     EPI_GUIDED = 4,     // guided backprop: out0 = max(acc,0) * [Y > 0]
+    EPI_REL_MUL = 5,    // r = X * acc -> out0 and/or out1 (max|r| per map -> out1_amax).  The relevance rule with its
+                        // following division folded into the multiplicand: X = x for R, X = x / safe(Z_below) for S_next
 };
 
 enum Stab : int { STAB_NONE = 0, STAB_SAFE = 1, STAB_EPS = 2 };
@@ -56,6 +58,8 @@ struct ConvArgs {
     const int* map2img;     // [n_maps] image index of every map for X/Zdiv (null: identity)
     float* out0;
     float* out1;
+    const unsigned* in_amax;   // f16x3 kernels: [n_maps] float bits of max|in| per map (operand scale), else unused
+    unsigned* out1_amax;       // f16x3 kernels, REL: [n_maps] max|out1| per map is atomically max-ed into it (may be null)
 };
 
 __device__ __forceinline__ float stab_safe(float z) { return z + 1e-7f * (z == 0.f ? 1.f : 0.f); }
@@ -119,7 +123,7 @@ __device__ __forceinline__ void epi_gather(const ConvArgs& a, const EpiCtx& cx, 
     const int oc = cx.oc;
     const int ncol = a.oc_split;
     const unsigned P = (unsigned)a.pix_per_map;
-    constexpr bool NEEDS_X = (EPI == EPI_REL || EPI == EPI_GUIDED || EPI == EPI_FIRST);
+    constexpr bool NEEDS_X = (EPI == EPI_REL || EPI == EPI_GUIDED || EPI == EPI_FIRST || EPI == EPI_REL_MUL);
     if constexpr (ALIGNED && EPI != EPI_FIRST) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -183,9 +187,12 @@ __device__ __forceinline__ void epi_gather(const ConvArgs& a, const EpiCtx& cx, 
     }
 }
 
+// mx (optional, REL with out1): running max|out1| of this tile, m0 for pixels of the tile's first map, m1 for pixels
+// past a map boundary inside the tile (only tiles of the 28x28 / 14x14 layers have one)
+struct EpiMax { float m0, m1; };
 template <int EPI, int HW, int TAPS, bool ALIGNED>
 __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, const int j, const f32x16 accj,
-                                           const EpiRegs& r) {
+                                           const EpiRegs& r, EpiMax* mx = nullptr) {
     float* __restrict__ o0 = a.out0;
     float* __restrict__ o1 = a.out1;
     const float* __restrict__ Uu = a.U;     // per-(map, channel) addend: only the small decoder GEMMs use it
@@ -194,6 +201,15 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
     const unsigned P = (unsigned)a.pix_per_map;
     float bias = 0.f;
     if (EPI == EPI_FWD_DUAL || EPI == EPI_PLAIN) bias = (a.bias && oc < ncol) ? a.bias[oc] : 0.f;
+    // pixel-in-map of this lane's first pixel, counted from the map of the TILE's first pixel (lanes 32-63 start 4
+    // pixels later): only needed to attribute mx across a map boundary
+    int p0_tile = 0;
+    if (mx && !ALIGNED && TAPS == 9) {
+        const unsigned q0t = (unsigned)(cx.q0 - 4 * (cx.lane >> 5) + 32 * j);
+        const unsigned rr = q0t / (unsigned)HW, c0 = q0t - rr * HW;
+        const unsigned g = (unsigned)cx.g0 + rr;
+        p0_tile = (int)((g - (g / (unsigned)HW) * HW) * HW + c0) + 4 * (cx.lane >> 5);
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int q = cx.q0 + 32 * j + (e & 3) + 8 * (e >> 2);
@@ -228,7 +244,24 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
                 if (o1) {
                     float z = r.zv[e];
                     z = (a.stab == STAB_SAFE) ? stab_safe(z) : ((a.stab == STAB_EPS) ? stab_eps(z) : z);
-                    o1[gp * ncol + oc] = fast_div(rel, z);
+                    const float sv = fast_div(rel, z);
+                    o1[gp * ncol + oc] = sv;
+                    if (mx) {
+                        const bool past = !ALIGNED && TAPS == 9 && p0_tile + (e & 3) + 8 * (e >> 2) >= (int)P;
+                        mx->m0 = fmaxf(mx->m0, past ? 0.f : fabsf(sv));
+                        mx->m1 = fmaxf(mx->m1, past ? fabsf(sv) : 0.f);
+                    }
+                }
+            }
+        } else if (EPI == EPI_REL_MUL) {
+            if (oc < ncol) {
+                const float rel = r.xv[e] * v;
+                if (o0) o0[gp * ncol + oc] = rel;
+                if (o1) o1[gp * ncol + oc] = rel;
+                if (mx) {
+                    const bool past = !ALIGNED && TAPS == 9 && p0_tile + (e & 3) + 8 * (e >> 2) >= (int)P;
+                    mx->m0 = fmaxf(mx->m0, past ? 0.f : fabsf(rel));
+                    mx->m1 = fmaxf(mx->m1, past ? fabsf(rel) : 0.f);
                 }
             }
         } else if (EPI == EPI_PLAIN) {

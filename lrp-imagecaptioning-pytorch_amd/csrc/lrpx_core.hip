@@ -7,6 +7,7 @@
 #include "common.h"
 #include "conv_mfma.h"
 #include "conv_bf16x6.h"
+#include "conv_f16x3.h"
 
 namespace lrpx {
 
@@ -123,6 +124,90 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned
     out[base] = p0; out[base + 512] = p1; out[base + 1024] = p2;
 }
 
+// max |x| over a flat tensor -> *out (float bits; non-negative floats order like unsigned integers)
+__global__ void amax_flat_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) amax_update(out, m);
+}
+
+// lane-local |max| of 4 values -> per-map amax.  Waves whose 64 lanes sit in one map (every layer of the path) reduce
+// in registers and issue one atomic; mixed waves fall back to one atomic per lane.
+__device__ __forceinline__ void amax_commit(unsigned* __restrict__ amax, long n, float m) {
+    // blocks of 256 threads; every launch that records an amax has whole blocks (host-checked)
+    __shared__ float red[4];
+    __shared__ long redn[4];
+    const int wv = threadIdx.x >> 6;
+    const long n0 = __shfl(n, 0, 64);
+    const bool wave_uniform = __all(n == n0);
+    float mw = wave_max(wave_uniform ? m : 0.f);
+    if (!wave_uniform) amax_update(&amax[n], m);          // (never on the path: maps are multiples of 1024 floats)
+    if ((threadIdx.x & 63) == 0) { red[wv] = mw; redn[wv] = n0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (redn[0] == redn[1] && redn[0] == redn[2] && redn[0] == redn[3]) {
+            amax_update(&amax[redn[0]], fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        } else {
+            for (int i = 0; i < 4; ++i) amax_update(&amax[redn[i]], red[i]);
+        }
+    }
+}
+
+__global__ void amax_maps_kernel(const float* __restrict__ s, long per4, long total, unsigned* __restrict__ amax) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 units
+    const bool ok = idx < total;
+    if (!ok) idx = total - 1;
+    const f32x4 v = reinterpret_cast<const f32x4*>(s)[idx];
+    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax_commit(amax, idx / per4, ok ? m : 0.f);
+}
+
+// f16x2 split of the packed weights for conv_f16x3.h: 64-byte header {2^-kW, amax bits, ...} then
+// [ocb][chunk 16][tap][plane 2][lane 64][8 fp16]; lane map as pack_weights_bf16x3_kernel
+__global__ void pack_weights_f16x2_kernel(const float* __restrict__ w, float* __restrict__ header, int cout, int cin,
+                                          int taps, int mode, int k_pad, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int kw = f16_scale_exp(reinterpret_cast<const unsigned*>(header)[1]);
+    if (idx == 0) header[0] = exp2i(-kw);
+    unsigned short* out = reinterpret_cast<unsigned short*>(header + F16X3_HEADER_FLOATS);
+    const int j = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    long rest = idx >> 9;
+    const int tap = rest % taps; rest /= taps;
+    const int nchunk = k_pad / 16;
+    const int chunk = rest % nchunk; rest /= nchunk;
+    const int ocb = (int)rest;
+    const int oc = ocb * 32 + (lane & 31);
+    const int k = chunk * 16 + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    switch (mode) {
+        case LRPX_PACK_BWD_POS:
+            if (k < cout && oc < cin) v = fmaxf(w[((long)k * cin + oc) * taps + (taps - 1 - tap)], 0.f);
+            break;
+        case LRPX_PACK_BWD_PLAIN:
+            if (k < cout && oc < cin) v = w[((long)k * cin + oc) * taps + (taps - 1 - tap)];
+            break;
+        case LRPX_PACK_FWD:
+            if (k < cin && oc < cout) v = w[((long)oc * cin + k) * taps + tap];
+            break;
+        case LRPX_PACK_FWD_DUAL:
+            if (k < cin && oc < 2 * cout) {
+                const int co = oc < cout ? oc : oc - cout;
+                const float x = w[((long)co * cin + k) * taps + tap];
+                v = oc < cout ? x : fmaxf(x, 0.f);
+            }
+            break;
+    }
+    _Float16 hi, lo;
+    split2(v * exp2i(kw), hi, lo);
+    const long base = ((((long)ocb * nchunk + chunk) * taps + tap) * 2) * 512 + lane * 8 + j;
+    out[base] = __builtin_bit_cast(unsigned short, hi);
+    out[base + 512] = __builtin_bit_cast(unsigned short, lo);
+}
+
 static void pack_dims(int cout, int cin, int mode, int kc, int* n_oc_pad, int* k_pad) {
     int n_oc, k;
     switch (mode) {
@@ -196,57 +281,69 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
     reinterpret_cast<f32x4*>(y)[idx] = m;
 }
 
-// Pool2d rule + division by the Z+ of the conv below.  One thread = one hi-res pixel x 4 channels.
+// Pool2d rule + division by the Z+ of the conv below.  One thread = ITER x (one hi-res pixel x 4 channels); a block
+// covers 256*ITER consecutive float4 (ITER > 1 only when that divides a map: one amax update per block).
+template <int ITER>
 __global__ void maxpool_relevance_kernel(const float* __restrict__ x, const float* __restrict__ r_out,
                                          const float* __restrict__ zdiv, const int* __restrict__ map2img,
                                          float* __restrict__ r_in, float* __restrict__ s_out, int ho, int wo, int c4,
-                                         long total, int s_chunk4, long total_pix) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n_maps*(2ho)*(2wo)*c4
-    if (idx >= total) return;
-    int cc = idx % c4;
-    long r = idx / c4;
+                                         long total, int s_chunk4, long total_pix, unsigned* __restrict__ amax) {
+    const long base = (long)blockIdx.x * (blockDim.x * ITER) + threadIdx.x;   // over n_maps*(2ho)*(2wo)*c4
+    if (base >= total) return;    // (total is a multiple of the block span whenever amax is used)
     const int wi = 2 * wo, hi = 2 * ho;
-    int xi = r % wi; r /= wi;
-    int yi = r % hi;
-    long n = r / hi;
-    long img = map2img ? map2img[n] : n;
-    const int yo = yi >> 1, xo = xi >> 1;
-    const int pos = (yi & 1) * 2 + (xi & 1);   // position of this pixel inside its window, row-major
-    const f32x4* xb = reinterpret_cast<const f32x4*>(x) + ((img * hi + 2 * yo) * wi + 2 * xo) * c4 + cc;
-    f32x4 w4[4] = {xb[0], xb[c4], xb[(long)wi * c4], xb[(long)wi * c4 + c4]};
-    f32x4 ro = reinterpret_cast<const f32x4*>(r_out)[((n * ho + yo) * wo + xo) * c4 + cc];
-    f32x4 z = {1.f, 1.f, 1.f, 1.f};
-    if (zdiv) z = reinterpret_cast<const f32x4*>(zdiv)[((img * hi + yi) * wi + xi) * c4 + cc];
-    f32x4 ri, so;
+    float mabs = 0.f;
+    long n_first = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        // first maximum in row-major window order wins (strict >), as max_pool2d's backward does
-        float m = w4[0][e];
-        int am = 0;
-        if (w4[1][e] > m) { m = w4[1][e]; am = 1; }
-        if (w4[2][e] > m) { m = w4[2][e]; am = 2; }
-        if (w4[3][e] > m) { m = w4[3][e]; am = 3; }
-        float v = 0.f;
-        if (am == pos) v = m * (ro[e] / stab_safe(m));
-        ri[e] = v;
-        so[e] = zdiv ? v / stab_safe(z[e]) : v;
-    }
-    if (r_in) reinterpret_cast<f32x4*>(r_in)[idx] = ri;
-    if (s_out) {
-        long o = idx;
-        if (s_chunk4) {   // channel-chunked: [c4 / s_chunk4][pixel][s_chunk4] in float4 units
-            const long pix = idx / c4;
-            o = ((long)(cc / s_chunk4) * total_pix + pix) * s_chunk4 + (cc % s_chunk4);
+    for (int it = 0; it < ITER; ++it) {
+        const long idx = base + (long)it * blockDim.x;
+        if (ITER > 1 && idx >= total) break;
+        int cc = idx % c4;
+        long r = idx / c4;
+        int xi = r % wi; r /= wi;
+        int yi = r % hi;
+        long n = r / hi;
+        if (it == 0) n_first = n;
+        long img = map2img ? map2img[n] : n;
+        const int yo = yi >> 1, xo = xi >> 1;
+        const int pos = (yi & 1) * 2 + (xi & 1);   // position of this pixel inside its window, row-major
+        const f32x4* xb = reinterpret_cast<const f32x4*>(x) + ((img * hi + 2 * yo) * wi + 2 * xo) * c4 + cc;
+        f32x4 w4[4] = {xb[0], xb[c4], xb[(long)wi * c4], xb[(long)wi * c4 + c4]};
+        f32x4 ro = reinterpret_cast<const f32x4*>(r_out)[((n * ho + yo) * wo + xo) * c4 + cc];
+        f32x4 z = {1.f, 1.f, 1.f, 1.f};
+        if (zdiv) z = reinterpret_cast<const f32x4*>(zdiv)[((img * hi + yi) * wi + xi) * c4 + cc];
+        f32x4 ri, so;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // first maximum in row-major window order wins (strict >), as max_pool2d's backward does
+            float m = w4[0][e];
+            int am = 0;
+            if (w4[1][e] > m) { m = w4[1][e]; am = 1; }
+            if (w4[2][e] > m) { m = w4[2][e]; am = 2; }
+            if (w4[3][e] > m) { m = w4[3][e]; am = 3; }
+            float v = 0.f;
+            if (am == pos) v = m * (ro[e] / stab_safe(m));
+            ri[e] = v;
+            so[e] = zdiv ? v / stab_safe(z[e]) : v;
         }
-        reinterpret_cast<f32x4*>(s_out)[o] = so;
+        if (r_in) reinterpret_cast<f32x4*>(r_in)[idx] = ri;
+        if (s_out) {
+            long o = idx;
+            if (s_chunk4) {   // channel-chunked: [c4 / s_chunk4][pixel][s_chunk4] in float4 units
+                const long pix = idx / c4;
+                o = ((long)(cc / s_chunk4) * total_pix + pix) * s_chunk4 + (cc % s_chunk4);
+            }
+            reinterpret_cast<f32x4*>(s_out)[o] = so;
+            mabs = fmaxf(mabs, fmaxf(fmaxf(fabsf(so[0]), fabsf(so[1])), fmaxf(fabsf(so[2]), fabsf(so[3]))));
+        }
     }
+    if (amax) amax_commit(amax, n_first, mabs);
 }
 
 __global__ void divide_stab_kernel(const float* __restrict__ r, const float* __restrict__ z,
                                    const int* __restrict__ map2img, float* __restrict__ s, long per4, int stab,
-                                   long total) {
+                                   long total, unsigned* __restrict__ amax) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 units over n_maps*per4
-    if (idx >= total) return;
+    if (idx >= total) return;     // (total is a multiple of 64 whenever amax is used)
     long n = idx / per4, i = idx - n * per4;
     long img = map2img ? map2img[n] : n;
     f32x4 rv = reinterpret_cast<const f32x4*>(r)[idx];
@@ -259,6 +356,7 @@ __global__ void divide_stab_kernel(const float* __restrict__ r, const float* __r
         o[e] = rv[e] / zz;
     }
     reinterpret_cast<f32x4*>(s)[idx] = o;
+    if (amax) amax_commit(amax, n, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
 }
 
 __global__ void cumsum_maps_kernel(const float* __restrict__ in, float* __restrict__ out, int t_per_img, long per4,
@@ -426,25 +524,86 @@ int lrpx_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, vo
     return check_launch("maxpool2x2_fwd");
 }
 
+}  // extern "C"
+namespace lrpx {
+int maxpool_relevance_amax(const float* x, const float* r_out, const float* zdiv, const int32_t* map2img, float* r_in,
+                           float* s_out, int n_maps, int h_out, int w_out, int c, int s_chunk, unsigned* amax,
+                           hipStream_t stream) {
+    LRPX_REQUIRE(x && r_out && (r_in || s_out) && (c % 4 == 0), "maxpool2x2_relevance: bad arguments");
+    LRPX_REQUIRE(s_chunk == 0 || (s_chunk % 4 == 0 && c % s_chunk == 0), "maxpool2x2_relevance: bad s_chunk");
+    const long per_map = (long)(2 * h_out) * (2 * w_out) * (c / 4);
+    const long total = (long)n_maps * per_map;
+    LRPX_REQUIRE(!amax || (s_out && per_map % 256 == 0), "maxpool2x2_relevance: amax needs s_out and whole blocks");
+    if (amax && per_map % 2048 == 0) {      // 8 float4 per thread: 8x fewer amax updates (they all hit n_maps words)
+        hipLaunchKernelGGL(maxpool_relevance_kernel<8>, dim3(grid_for(total, 2048)), dim3(256), 0, stream, x, r_out,
+                           zdiv, map2img, r_in, s_out, h_out, w_out, c / 4, total, s_chunk / 4,
+                           (long)n_maps * (2 * h_out) * (2 * w_out), amax);
+    } else {
+        hipLaunchKernelGGL(maxpool_relevance_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, x, r_out,
+                           zdiv, map2img, r_in, s_out, h_out, w_out, c / 4, total, s_chunk / 4,
+                           (long)n_maps * (2 * h_out) * (2 * w_out), amax);
+    }
+    return check_launch("maxpool2x2_relevance");
+}
+int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c, int stab,
+                     unsigned* amax, hipStream_t stream) {
+    LRPX_REQUIRE(r && z && s && (pix_c % 4 == 0), "divide_stab: bad arguments");
+    long total = (long)n_maps * (pix_c / 4);
+    LRPX_REQUIRE(!amax || total % 256 == 0, "divide_stab: amax needs whole blocks");
+    hipLaunchKernelGGL(divide_stab_kernel, dim3(grid_for(total)), dim3(256), 0, stream, r, z, map2img, s,
+                       pix_c / 4, stab, total, amax);
+    return check_launch("divide_stab");
+}
+}  // namespace lrpx
+extern "C" {
+
 int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* zdiv, const int32_t* map2img,
                               float* r_in, float* s_out, int n_maps, int h_out, int w_out, int c, int s_chunk,
                               void* stream) {
-    LRPX_REQUIRE(x && r_out && (r_in || s_out) && (c % 4 == 0), "maxpool2x2_relevance: bad arguments");
-    LRPX_REQUIRE(s_chunk == 0 || (s_chunk % 4 == 0 && c % s_chunk == 0), "maxpool2x2_relevance: bad s_chunk");
-    long total = (long)n_maps * (2 * h_out) * (2 * w_out) * (c / 4);
-    hipLaunchKernelGGL(maxpool_relevance_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, r_out,
-                       zdiv, map2img, r_in, s_out, h_out, w_out, c / 4, total, s_chunk / 4,
-                       (long)n_maps * (2 * h_out) * (2 * w_out));
-    return check_launch("maxpool2x2_relevance");
+    return maxpool_relevance_amax(x, r_out, zdiv, map2img, r_in, s_out, n_maps, h_out, w_out, c, s_chunk, nullptr,
+                                  (hipStream_t)stream);
+}
+
+int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* stream) {
+    LRPX_REQUIRE(s && amax && n_maps > 0 && per > 0 && per % 4 == 0, "amax_maps: bad arguments (per %% 4)");
+    if (hipMemsetAsync(amax, 0, (size_t)n_maps * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
+        set_error("amax_maps: memset failed");
+        return LRPX_ELAUNCH;
+    }
+    long total = (long)n_maps * (per / 4);
+    hipLaunchKernelGGL(amax_maps_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, per / 4, total,
+                       amax);
+    return check_launch("amax_maps");
+}
+
+size_t lrpx_packed_f16x2_bytes(int n_oc, int k, int taps) {
+    return F16X3_HEADER_FLOATS * sizeof(float) +
+           (size_t)round_up(n_oc, 32) * (size_t)round_up(k, 16) * (size_t)taps * 2 * sizeof(unsigned short);
+}
+
+int lrpx_pack_weights_f16x2(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream) {
+    LRPX_REQUIRE(w && packed && taps == 9, "pack_weights_f16x2: bad arguments (3x3 kernels only)");
+    LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN || mode == LRPX_PACK_FWD ||
+                     mode == LRPX_PACK_FWD_DUAL, "pack_weights_f16x2: mode %d not supported", mode);
+    int n_oc_pad, k_pad;
+    pack_dims(cout, cin, mode, 16, &n_oc_pad, &k_pad);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(packed, 0, F16X3_HEADER_FLOATS * sizeof(float), st) != hipSuccess) {
+        set_error("pack_weights_f16x2: memset failed");
+        return LRPX_ELAUNCH;
+    }
+    // layer scale from max|w| (an upper bound for every mode's transformed weights)
+    const long nw = (long)cout * cin * taps;
+    hipLaunchKernelGGL(amax_flat_kernel, dim3(256), dim3(256), 0, st, w, nw, (unsigned*)packed + 1);
+    long total = (long)n_oc_pad * k_pad * taps;
+    hipLaunchKernelGGL(pack_weights_f16x2_kernel, dim3(grid_for(total)), dim3(256), 0, st, w, (float*)packed, cout, cin,
+                       taps, mode, k_pad, total);
+    return check_launch("pack_weights_f16x2");
 }
 
 int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c,
                      int stab, void* stream) {
-    LRPX_REQUIRE(r && z && s && (pix_c % 4 == 0), "divide_stab: bad arguments");
-    long total = (long)n_maps * (pix_c / 4);
-    hipLaunchKernelGGL(divide_stab_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, r, z, map2img, s,
-                       pix_c / 4, stab, total);
-    return check_launch("divide_stab");
+    return divide_stab_amax(r, z, map2img, s, n_maps, pix_c, stab, nullptr, (hipStream_t)stream);
 }
 
 int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long per, void* stream) {

@@ -6,6 +6,7 @@
 //   relevance: LRPtools/lrp_wrapper.py:63-87 compute_lrp -> per leaf, in reverse order,
 //              Conv2d alpha1beta0 (lrp_modules.py:124-150), ReLU identity (:42-46), MaxPool2d (:182-195)
 #include "conv_launch.h"
+#include "conv_f16x3.h"
 
 namespace lrpx {
 
@@ -13,7 +14,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     LRPX_REQUIRE(d && d->in && d->wpacked && (d->out0 || d->out1), "conv_mfma: null pointer");
     LRPX_REQUIRE(d->taps == 9 || d->taps == 1, "conv_mfma: taps must be 9 or 1");
     LRPX_REQUIRE(d->n_maps > 0 && d->cin > 0 && d->n_oc > 0 && d->n_oc % 32 == 0, "conv_mfma: bad sizes (n_oc %% 32)");
-    const int kc = d->bf16x6 ? 16 : lrpx_conv_kc(d->hw, d->taps, d->cin);
+    const int kc = (d->bf16x6 || d->f16x3) ? 16 : lrpx_conv_kc(d->hw, d->taps, d->cin);
     LRPX_REQUIRE(kc > 0 && d->cin % kc == 0, "conv_mfma: cin=%d is not a multiple of the K-chunk %d", d->cin, kc);
     ConvArgs a;
     a.in = d->in; a.wp = d->wpacked; a.n_maps = d->n_maps; a.cin = d->cin; a.n_oc = d->n_oc;
@@ -34,6 +35,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     a.epi = d->epi; a.stab = d->stab; a.oc_split = d->oc_split; a.relu = d->relu;
     a.bias = d->bias; a.X = d->x; a.U = d->u; a.Zdiv = d->zdiv; a.map2img = d->map2img;
     a.out0 = d->out0; a.out1 = d->out1;
+    a.in_amax = d->in_amax; a.out1_amax = d->out1_amax;
     LRPX_REQUIRE(a.pix_per_map > 0, "conv_mfma: pix_per_map must be positive");
     LRPX_REQUIRE((long)a.n_maps * a.pix_per_map < 0x7fffffffL, "conv_mfma: too many pixels for 32-bit indexing");
     switch (d->epi) {
@@ -42,7 +44,18 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
         case EPI_FIRST: LRPX_REQUIRE(d->x && d->out0, "conv_mfma: FIRST needs x,out0"); break;
         case EPI_PLAIN: LRPX_REQUIRE(d->out0, "conv_mfma: PLAIN needs out0"); break;
         case EPI_GUIDED: LRPX_REQUIRE(d->out0 && d->x, "conv_mfma: GUIDED needs x,out0"); break;
+        case EPI_REL_MUL: LRPX_REQUIRE(d->x && d->f16x3, "conv_mfma: REL_MUL is the f16x3 epilogue (needs x)"); break;
         default: LRPX_REQUIRE(false, "conv_mfma: epilogue %d not built", d->epi);
+    }
+    if (d->f16x3) {
+        LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0 && d->epi == EPI_REL_MUL && d->in_amax && !d->bf16x6 && d->x,
+                     "conv_mfma: f16x3 needs a 3x3 conv, cin %% 16 == 0, the REL_MUL epilogue, x and in_amax");
+        if (d->hw == 224) return launch_h3_224_rel(a, s);
+        if (d->hw == 112) return d->n_oc <= 64 ? launch_h3_112n_rel(a, s) : launch_h3_112_rel(a, s);
+        if (d->hw == 56) return launch_h3_56_rel(a, s);
+        if (d->hw == 28) return launch_h3_28_rel(a, s);
+        if (d->hw == 14) return launch_h3_14_rel(a, s);
+        LRPX_REQUIRE(false, "conv_mfma: no f16x3 kernel built for hw=%d", d->hw);
     }
     if (d->bf16x6) {
         LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0, "conv_mfma: bf16x6 needs a 3x3 conv, cin %% 16 == 0");
@@ -122,17 +135,25 @@ int guided_gate(const float* g, const float* y, const int* map2img, float* out, 
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
                        int c, hipStream_t s);
 
-// relevance passes of the 56/28/14-pixel layers on the bf16 matrix cores (conv_bf16x6.h); lrpx_set_bf16x6()
-static int g_bf16x6 = 1;
+// matrix-core mode of the fused chains (lrpx_set_conv_mode): 0 fp32 MFMA, 1 bf16x6 (conv_bf16x6.h), 2 = bf16x6 forward
+// trace + f16x3 relevance pass (conv_f16x3.h)
+static int g_mode = 2;
+#define g_bf16x6 (g_mode >= 1)
+
+// optional per-layer timing of the relevance chain (lrpx_vgg16_layer_timing): HIP events recorded on the launch stream
+// around every conv launch of the NEXT lrpx_vgg16_relevance call; off by default, never inside a timed benchmark loop
+static int g_timing = 0;
+static hipEvent_t g_ev[17][2];
+static bool g_ev_made = false, g_ev_valid[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], fwd6[17], bias[17], first6, first6p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], fwd6[17], bias[17], first6, first6p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
     size_t off = 0;
     for (int l = 0; l < kNL; ++l) {
-        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.fwd6[l] = p.bias[l] = 0;
+        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.fwd6[l] = p.bias[l] = 0;
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
@@ -140,6 +161,7 @@ static VggPacked vgg_packed_layout() {
         p.bias[l] = off; off += (size_t)L.cout;
         if (l > 0) { p.bwdp[l] = off; off += lrpx_packed_floats(L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout)); }
         if (l > 0) { p.bwd6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float); }
+        if (l > 0) { p.bwdh[l] = off; off += lrpx_packed_f16x2_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (L.hw <= 112) {
             p.fwd6[l] = off; off += lrpx_packed_bf16x3_bytes(2 * L.cout, L.cin, 9) / sizeof(float);
         }
@@ -151,7 +173,7 @@ static VggPacked vgg_packed_layout() {
 }
 
 struct VggTrace {   // offsets in floats; act[l] = input of layer l, act[17] = encoder output
-    size_t act[18], zpos[17], total;
+    size_t act[18], zpos[17], xz[17], total;   // xz[l] = act[l] / safe(zpos[l-1]) for a conv l right above a conv
 };
 static VggTrace vgg_trace_layout(int n_img) {
     VggTrace t;
@@ -166,6 +188,13 @@ static VggTrace vgg_trace_layout(int n_img) {
     for (int l = 0; l < kNL; ++l) {
         t.zpos[l] = off;
         if (kVgg[l].conv) off += (size_t)n_img * kVgg[l].hw * kVgg[l].hw * kVgg[l].cout;
+    }
+    for (int l = 0; l < kNL; ++l) {
+        t.xz[l] = 0;
+        if (l >= 1 && kVgg[l].conv && kVgg[l - 1].conv) {
+            t.xz[l] = off;
+            off += (size_t)n_img * kVgg[l].hw * kVgg[l].hw * kVgg[l].cin;
+        }
     }
     t.total = off;
     return t;
@@ -187,8 +216,14 @@ int lrpx_conv_kc(int hw, int taps, int cin) {
 int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream) { return conv_dispatch(d, (hipStream_t)stream); }
 
 int lrpx_set_bf16x6(int enable) {
-    const int prev = g_bf16x6;
-    if (enable >= 0) g_bf16x6 = enable ? 1 : 0;
+    const int prev = g_mode >= 1;
+    if (enable >= 0) g_mode = enable ? 1 : 0;
+    return prev;
+}
+
+int lrpx_set_conv_mode(int mode) {
+    const int prev = g_mode;
+    if (mode >= 0) g_mode = mode > 2 ? 2 : mode;
     return prev;
 }
 
@@ -196,7 +231,8 @@ size_t lrpx_vgg16_packed_bytes(void) { return vgg_packed_layout().total * sizeof
 size_t lrpx_vgg16_trace_bytes(int n_img) { return vgg_trace_layout(n_img).total * sizeof(float); }
 size_t lrpx_vgg16_workspace_bytes(int n_maps) {
     // two ping-pong S buffers (largest: 224*224*64 per map) + one R buffer in front of a pool (112*112*64)
-    return ((size_t)2 * 224 * 224 * 64 + (size_t)112 * 112 * 64) * (size_t)n_maps * sizeof(float);
+    // + per-(layer, map) max|S| words of the f16x3 relevance pass
+    return ((size_t)2 * 224 * 224 * 64 + (size_t)112 * 112 * 64 + 32) * (size_t)n_maps * sizeof(float);
 }
 
 int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, void* stream) {
@@ -226,10 +262,25 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
                                        base + p.bwdp[l], stream));
         }
         if (l > 0) LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwd6[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwdh[l], stream));
         if (L.hw <= 112) {
             LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwd6[l], stream));
         }
         ++ci;
+    }
+    return LRPX_OK;
+}
+
+int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream) {
+    LRPX_REQUIRE(trace && n_img > 0, "vgg16_trace_derive: bad arguments");
+    const VggTrace t = vgg_trace_layout(n_img);
+    float* tr = (float*)trace;
+    for (int l = 1; l < kNL; ++l) {
+        if (!t.xz[l]) continue;
+        // multiplicand of the fused step  S_{l-1} = x_l * convT(S_l, W+) / safe(Z+_{l-1})   (lrp_modules.py:124-150 for
+        // conv l, then utils.py:16-18 safe_divide of the conv below)
+        LRPX_TRY(lrpx_divide_stab(tr + t.act[l], tr + t.zpos[l - 1], nullptr, tr + t.xz[l], n_img,
+                                  (long)kVgg[l].hw * kVgg[l].hw * kVgg[l].cin, STAB_SAFE, stream));
     }
     return LRPX_OK;
 }
@@ -269,6 +320,7 @@ int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, voi
             LRPX_TRY(lrpx_maxpool2x2_fwd(tr + t.act[l], tr + t.act[l + 1], n_img, L.hw, L.hw, L.cin, stream));
         }
     }
+    LRPX_TRY(lrpx_vgg16_trace_derive(trace, n_img, stream));
     if (feat_nhwc) {
         if (hipMemcpyAsync(feat_nhwc, tr + t.act[kNL], (size_t)n_img * 196 * 512 * sizeof(float),
                            hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
@@ -294,8 +346,32 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
     float* R = ws + 2 * sbuf;
     int cur = 0;
     int cur_chunked = 0;   // S[cur] is stored in K-chunks (written so by the pool kernel for the 224^2 / 112^2 layers)
+    // f16x3 mode: amax[l*n_maps + n] = bits of max|S| of map n in the S tensor that conv layer l consumes
+    const bool h3 = g_mode == 2;
+    unsigned* amax = h3 ? reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps) : nullptr;
+    if (h3 && hipMemsetAsync(amax, 0, (size_t)kNL * n_maps * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+        set_error("vgg16_relevance: cannot zero the amax words");
+        return LRPX_ELAUNCH;
+    }
     // S_16 = R_feat / safe(Z+_16)
-    LRPX_TRY(lrpx_divide_stab(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, STAB_SAFE, stream));
+    LRPX_TRY(divide_stab_amax(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, STAB_SAFE,
+                              h3 ? amax + (size_t)16 * n_maps : nullptr, (hipStream_t)stream));
+    const bool timing = g_timing != 0;
+    if (timing) {
+        if (!g_ev_made) {
+            for (int l = 0; l < kNL; ++l)
+                for (int k = 0; k < 2; ++k)
+                    if (hipEventCreate(&g_ev[l][k]) != hipSuccess) { set_error("vgg16_relevance: hipEventCreate failed"); return LRPX_ELAUNCH; }
+            g_ev_made = true;
+        }
+        for (int l = 0; l < kNL; ++l) g_ev_valid[l] = false;
+    }
+#define LRPX_TIMED_DISPATCH(L_, DESC)                                                   \
+    do {                                                                                \
+        if (timing) (void)hipEventRecord(g_ev[L_][0], (hipStream_t)stream);             \
+        LRPX_TRY(conv_dispatch(DESC, (hipStream_t)stream));                             \
+        if (timing) { (void)hipEventRecord(g_ev[L_][1], (hipStream_t)stream); g_ev_valid[L_] = true; } \
+    } while (0)
     for (int l = kNL - 1; l >= 0; --l) {
         const VggLayer& L = kVgg[l];
         if (!L.conv) continue;   // pools are handled together with the conv above them
@@ -312,25 +388,45 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
-        if (g_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
+        if (h3) { d.f16x3 = 1; d.epi = EPI_REL_MUL; d.wpacked = pk + p.bwdh[l]; d.in_amax = amax + (size_t)l * n_maps; }
+        else if (g_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
         if (kVgg[l - 1].conv) {
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
-            d.out1 = S[cur ^ 1]; d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE;
-            LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
+            d.out1 = S[cur ^ 1];
+            if (h3) { d.x = tr + t.xz[l]; d.out1_amax = amax + (size_t)(l - 1) * n_maps; }   // x / safe(Z+) precomputed
+            else { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
+            LRPX_TIMED_DISPATCH(l, &d);
         } else {
             // a pool lies below: R at the pool output, then the Pool2d rule + division by Z+ of the conv under it
             d.out0 = R;
-            LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
+            LRPX_TIMED_DISPATCH(l, &d);
             // wide maps: hand the conv below its input in K-chunks (32-byte pixel slices would drag every 128-byte
             // line through the fabric four times: measured L2 hit 36 %, 3x the unique bytes on conv1_2)
             const int below_hw = 2 * L.hw;
             const int chunk = below_hw < 112 ? 0 : (g_bf16x6 ? 16 : lrpx_conv_kc(below_hw, 9, L.cin));
-            LRPX_TRY(lrpx_maxpool2x2_relevance(tr + t.act[l - 1], R, tr + t.zpos[l - 2], map2img, nullptr, S[cur ^ 1],
-                                               n_maps, L.hw, L.hw, L.cin, chunk, stream));
+            LRPX_TRY(maxpool_relevance_amax(tr + t.act[l - 1], R, tr + t.zpos[l - 2], map2img, nullptr, S[cur ^ 1],
+                                            n_maps, L.hw, L.hw, L.cin, chunk,
+                                            h3 ? amax + (size_t)(l - 2) * n_maps : nullptr, (hipStream_t)stream));
             cur_chunked = chunk ? 1 : 0;
         }
         cur ^= 1;
     }
+    return LRPX_OK;
+}
+
+int lrpx_vgg16_layer_timing(int enable, float* ms17) {
+    if (ms17) {
+        for (int l = 0; l < kNL; ++l) {
+            ms17[l] = 0.f;
+            if (g_ev_made && g_ev_valid[l]) {
+                if (hipEventSynchronize(g_ev[l][1]) != hipSuccess || hipEventElapsedTime(&ms17[l], g_ev[l][0], g_ev[l][1]) != hipSuccess) {
+                    set_error("vgg16_layer_timing: event query failed");
+                    return LRPX_ELAUNCH;
+                }
+            }
+        }
+    }
+    if (enable >= 0) g_timing = enable ? 1 : 0;
     return LRPX_OK;
 }
 

@@ -49,13 +49,32 @@ def pack_weights_bf16x3(w, cout, cin, mode):
     return out
 
 
+def pack_weights_f16x2(w, cout, cin, mode):
+    """3x3 conv weights -> layer-scaled fp16 hi/lo planes in fragment layout (for conv_mfma(..., f16x3=1))."""
+    lib = _lib.load()
+    n_oc, k = (cout, cin) if mode == _lib.PACK_FWD else (cin, cout)
+    out = torch.empty(lib.lrpx_packed_f16x2_bytes(n_oc, k, 9) // 4, dtype=torch.float32, device=w.device)
+    check(lib.lrpx_pack_weights_f16x2(ptr(w.contiguous()), cout, cin, 9, mode, ptr(out), stream_ptr()))
+    return out
+
+
+def amax_maps(s, n_maps):
+    """Float bits of max|s[n]| per map (int32 tensor): the operand scale an f16x3 convolution needs for its input."""
+    s = _dev(s)
+    out = torch.empty(n_maps, dtype=torch.int32, device=s.device)
+    check(_lib.load().lrpx_amax_maps(ptr(s), n_maps, s.numel() // n_maps, ptr(out), stream_ptr()))
+    return out
+
+
 def conv_mfma(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, *, pix_per_map=0, stab=STAB_NONE, oc_split=0,
-              relu=0, bias=None, x=None, u=None, zdiv=None, map2img=None, out0=None, out1=None, bf16x6=0):
+              relu=0, bias=None, x=None, u=None, zdiv=None, map2img=None, out0=None, out1=None, bf16x6=0,
+              f16x3=0, in_amax=None, out1_amax=None):
     d = ConvDesc()
     d.in_, d.wpacked = ptr(_dev(inp)), ptr(_dev(wpacked))
     d.n_maps, d.hw, d.cin, d.n_oc, d.taps, d.pix_per_map = n_maps, hw, cin, n_oc, taps, pix_per_map
     d.epi, d.stab, d.oc_split, d.relu = epi, stab, oc_split, relu
-    d.bf16x6 = bf16x6
+    d.bf16x6, d.f16x3 = bf16x6, f16x3
+    d.in_amax, d.out1_amax = ptr(in_amax), ptr(out1_amax)
     d.bias, d.x, d.u, d.zdiv, d.map2img = ptr(bias), ptr(x), ptr(u), ptr(zdiv), ptr(map2img)
     d.out0, d.out1 = ptr(out0), ptr(out1)
     check(_lib.load().lrpx_conv_mfma(C.byref(d), stream_ptr()))
@@ -166,6 +185,10 @@ class Vgg16:
             else:
                 zs.append(None)
         return acts, zs
+
+    def derive(self):
+        """Recompute the trace tensors derived from the activations (call after writing into `trace_views()`)."""
+        check(_lib.load().lrpx_vgg16_trace_derive(ptr(self.trace), self.n_img, stream_ptr()))
 
     def guided_backprop(self, d_feat_nhwc, map2img=None, out=None):
         """explain_cnn of the guided-backprop explainer (models/gridTDmodel.py:1702-1723): (N,196,512) gradient at

@@ -37,7 +37,7 @@ def from_nhwc(x, c, h, w):
     return x[:, :, :c].reshape(x.shape[0], h, w, c).permute(0, 3, 1, 2).contiguous()
 
 
-def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False):
+def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False, f16x3=False, zdiv_next=None):
     """alpha1beta0 rule for one conv layer with non-negative input x (n_img,cin,hw,hw); r_out per map."""
     from lrp_amd import _lib
     n_img, cin, hw, _ = x.shape
@@ -62,13 +62,31 @@ def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False):
     m2i = None if map2img is None else torch.tensor(map2img, dtype=torch.int32, device=dev)
     s = ops.divide_stab(to_nhwc(r_out, cout_p).to(dev), zpos, m2i, _lib.STAB_SAFE)
     kc_b = ops.conv_kc(hw, 9, cout_p)
-    if bf16x6:
+    if f16x3:
+        wb = ops.pack_weights_f16x2(wg, cout_p, cin_p, _lib.PACK_BWD_POS)
+    elif bf16x6:
         wb = ops.pack_weights_bf16x3(wg, cout_p, cin_p, _lib.PACK_BWD_POS)
     else:
         wb = ops.pack_weights(wg, cout_p, cin_p, 9, _lib.PACK_BWD_POS, kc_b)
     r_in = torch.empty(n_maps, hw * hw, cin_p, device=dev)
-    ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL, oc_split=cin_p, x=xg, map2img=m2i, out0=r_in,
-                  bf16x6=int(bf16x6))
+    if f16x3:
+        # the f16x3 kernel has the REL_MUL epilogue (out = x * acc): R with x = X, and the fused S_next with the
+        # multiplicand x = X / safe(Z_next) precomputed (what lrpx_vgg16_trace_derive stores per image)
+        amax_in = ops.amax_maps(s, n_maps)
+        ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xg, map2img=m2i,
+                      out0=r_in, f16x3=1, in_amax=amax_in)
+        if zdiv_next is not None:
+            zn = to_nhwc(zdiv_next, cin_p).to(dev)
+            xz = xg / (zn + 1e-7 * (zn == 0))
+            out1 = torch.empty_like(r_in)
+            out1_amax = torch.zeros(n_maps, dtype=torch.int32, device=dev)
+            ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xz, map2img=m2i,
+                          out1=out1, f16x3=1, in_amax=amax_in, out1_amax=out1_amax)
+            torch.cuda.synchronize()
+            gpu_conv_rule.last_out1 = (out1.cpu(), out1_amax.cpu())
+    else:
+        ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL, oc_split=cin_p, x=xg, map2img=m2i, out0=r_in,
+                      bf16x6=int(bf16x6))
     torch.cuda.synchronize()
     return (from_nhwc(r_in.cpu(), cin, hw, hw), from_nhwc(act.cpu(), cout, hw, hw),
             from_nhwc(zpos.cpu(), cout, hw, hw))
@@ -109,6 +127,42 @@ def test_conv_rule_bf16x6_is_fp32_accurate(ops, hw, cin, cout, n_img, n_maps):
     assert rel_err(got6, want) < TOL
     assert rel_err(got6, got32) < 1e-5
     assert cosine(got6, want) > 0.99999
+
+
+@pytest.mark.parametrize("hw,cin,cout,n_img,n_maps", [
+    (14, 64, 96, 3, 5), (28, 32, 64, 2, 3), (56, 64, 128, 1, 2), (112, 64, 128, 1, 2), (112, 128, 128, 1, 1),
+    (224, 64, 64, 1, 2)])
+def test_conv_rule_f16x3_is_fp32_grade(ops, hw, cin, cout, n_img, n_maps):
+    """the fp16 matrix-core path (per-map / per-layer power-of-two scaling, 2-way operand split, 3 partial products):
+    same 1e-4 contract against the oracle, agreement with the fp32-MFMA kernel at the 1e-6 level, and its error
+    against an fp64 evaluation is no worse than twice that of the fp32 oracle itself.  Maps differ in scale by 1e6
+    and entries spread over e^(+-8): the per-map scaling must keep every map accurate."""
+    from oracle import lrp_oracle as O
+    g = torch.Generator().manual_seed(hw * 91 + cin)
+    x = torch.relu(torch.randn(n_img, cin, hw, hw, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.03
+    r = torch.randn(n_maps, cout, hw, hw, generator=g) * torch.exp(4 * torch.randn(n_maps, cout, hw, hw, generator=g))
+    r = r * torch.logspace(0, -6, n_maps).view(-1, 1, 1, 1)
+    m2i = [i % n_img for i in range(n_maps)]
+    zn = torch.rand(n_img, cin, hw, hw, generator=g) + 0.5
+    got, _, _ = gpu_conv_rule(ops, x, w, r, m2i, f16x3=True, zdiv_next=zn)
+    out1, out1_amax = gpu_conv_rule.last_out1
+    got32, _, _ = gpu_conv_rule(ops, x, w, r, m2i)
+    want = torch.cat([O.conv_alpha1beta0(x[m2i[i]:m2i[i] + 1], w, r[i:i + 1]) for i in range(n_maps)])
+    want64 = torch.cat([O.conv_alpha1beta0(x[m2i[i]:m2i[i] + 1].double(), w.double(), r[i:i + 1].double())
+                        for i in range(n_maps)])
+    for i in range(n_maps):       # per map: every map is held to the contract on its own scale
+        assert rel_err(got[i], want[i]) < TOL
+        assert rel_err(got[i], got32[i]) < 1e-5
+        e16, e32 = rel_err(got[i].double(), want64[i]), rel_err(want[i].double(), want64[i])
+        assert e16 < max(2 * e32, 2e-6), (i, e16, e32)
+        assert cosine(got[i], want[i]) > 0.99999
+    # fused second output and the amax it leaves for the next f16x3 layer
+    cin_p = out1.shape[-1]
+    s_next = to_nhwc(want64.float() / (zn[m2i] + 1e-7 * (zn[m2i] == 0)), cin_p)
+    for i in range(n_maps):
+        assert rel_err(out1[i], s_next[i]) < 1e-5
+        assert out1_amax[i:i + 1].view(torch.float32).item() == out1[i].abs().max().item()
 
 
 def test_reference_conv_fixture_embedded(ops):
@@ -184,6 +238,7 @@ def _inject_oracle_trace(vgg, sd, img):
             x = saved[l]
             z = F.conv2d(x.clamp(min=0), w.clamp(min=0), padding=1) + F.conv2d(x.clamp(max=0), w.clamp(max=0), padding=1)
             zs[l].copy_(to_nhwc(z))
+    vgg.derive()      # the fused conv->conv multiplicand x / safe(Z+) follows the injected activations
 
 
 def test_vgg_relevance_vs_reference_maps_same_trace(ops, gridtd_case):
