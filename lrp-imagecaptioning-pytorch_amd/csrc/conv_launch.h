@@ -74,6 +74,10 @@ int launch_h3_56_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_28_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_14_rel(const ConvArgs& a, hipStream_t s);
 
+// few-row dense GEMMs (dense_small.hip)
+bool dense_small_fits(const ConvArgs& a);
+int launch_dense_small(const ConvArgs& a, hipStream_t s);
+
 // host-side entry used by the C ABI and by the VGG16 / decoder chains
 int conv_dispatch(const lrpx_conv_desc* d, hipStream_t stream);
 

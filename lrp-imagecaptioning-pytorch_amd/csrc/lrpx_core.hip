@@ -339,24 +339,34 @@ __global__ void maxpool_relevance_kernel(const float* __restrict__ x, const floa
     if (amax) amax_commit(amax, n_first, mabs);
 }
 
+// ITER consecutive float4 per thread at block stride (ITER > 1 only when 256*ITER divides a map: one amax update/block)
+template <int ITER>
 __global__ void divide_stab_kernel(const float* __restrict__ r, const float* __restrict__ z,
                                    const int* __restrict__ map2img, float* __restrict__ s, long per4, int stab,
                                    long total, unsigned* __restrict__ amax) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 units over n_maps*per4
-    if (idx >= total) return;     // (total is a multiple of 64 whenever amax is used)
-    long n = idx / per4, i = idx - n * per4;
-    long img = map2img ? map2img[n] : n;
-    f32x4 rv = reinterpret_cast<const f32x4*>(r)[idx];
-    f32x4 zv = reinterpret_cast<const f32x4*>(z)[img * per4 + i];
-    f32x4 o;
+    const long base = (long)blockIdx.x * (blockDim.x * ITER) + threadIdx.x;   // float4 units over n_maps*per4
+    if (base >= total) return;     // (total is a multiple of the block span whenever amax is used)
+    const long n = base / per4;
+    const long img = map2img ? map2img[n] : n;
+    float mabs = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float zz = zv[e];
-        zz = stab == STAB_SAFE ? stab_safe(zz) : (stab == STAB_EPS ? stab_eps(zz) : zz);
-        o[e] = rv[e] / zz;
+    for (int it = 0; it < ITER; ++it) {
+        const long idx = base + (long)it * blockDim.x;
+        if (ITER > 1 && idx >= total) break;
+        const long i = idx - n * per4;
+        f32x4 rv = reinterpret_cast<const f32x4*>(r)[idx];
+        f32x4 zv = reinterpret_cast<const f32x4*>(z)[img * per4 + i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float zz = zv[e];
+            zz = stab == STAB_SAFE ? stab_safe(zz) : (stab == STAB_EPS ? stab_eps(zz) : zz);
+            o[e] = rv[e] / zz;
+        }
+        reinterpret_cast<f32x4*>(s)[idx] = o;
+        mabs = fmaxf(mabs, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
-    reinterpret_cast<f32x4*>(s)[idx] = o;
-    if (amax) amax_commit(amax, n, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+    if (amax) amax_commit(amax, n, mabs);
 }
 
 __global__ void cumsum_maps_kernel(const float* __restrict__ in, float* __restrict__ out, int t_per_img, long per4,
@@ -548,10 +558,15 @@ int maxpool_relevance_amax(const float* x, const float* r_out, const float* zdiv
 int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c, int stab,
                      unsigned* amax, hipStream_t stream) {
     LRPX_REQUIRE(r && z && s && (pix_c % 4 == 0), "divide_stab: bad arguments");
-    long total = (long)n_maps * (pix_c / 4);
-    LRPX_REQUIRE(!amax || total % 256 == 0, "divide_stab: amax needs whole blocks");
-    hipLaunchKernelGGL(divide_stab_kernel, dim3(grid_for(total)), dim3(256), 0, stream, r, z, map2img, s,
-                       pix_c / 4, stab, total, amax);
+    const long per4 = pix_c / 4, total = (long)n_maps * per4;
+    LRPX_REQUIRE(!amax || per4 % 256 == 0, "divide_stab: amax needs whole blocks per map");
+    if (amax && per4 % (256 * 7) == 0) {       // 14x14x512 features: 14 blocks per map instead of 98
+        hipLaunchKernelGGL(divide_stab_kernel<7>, dim3(grid_for(total, 256 * 7)), dim3(256), 0, stream, r, z, map2img, s,
+                           per4, stab, total, amax);
+    } else {
+        hipLaunchKernelGGL(divide_stab_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, r, z, map2img, s, per4,
+                           stab, total, amax);
+    }
     return check_launch("divide_stab");
 }
 }  // namespace lrpx

@@ -20,6 +20,16 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     a.in = d->in; a.wp = d->wpacked; a.n_maps = d->n_maps; a.cin = d->cin; a.n_oc = d->n_oc;
     a.pix_per_map = d->taps == 9 ? d->hw * d->hw : d->pix_per_map;
     a.in_chunk_stride = d->in_chunked ? (long)d->n_maps * a.pix_per_map * kc : 0;
+    a.epi = d->epi; a.stab = d->stab; a.oc_split = d->oc_split; a.relu = d->relu;
+    a.bias = d->bias; a.X = d->x; a.U = d->u; a.Zdiv = d->zdiv; a.map2img = d->map2img;
+    a.out0 = d->out0; a.out1 = d->out1;
+    a.in_amax = d->in_amax; a.out1_amax = d->out1_amax;
+    a.ksplit = 1;
+    // few rows (the decoder's lock-step rules): 32-row tiles, whole K per workgroup (dense_small.hip)
+    if (d->taps == 1 && !d->bf16x6 && !d->f16x3 && dense_small_fits(a)) {
+        LRPX_REQUIRE(d->epi != EPI_REL || d->x, "conv_mfma: REL needs x");
+        return launch_dense_small(a, s);
+    }
     // dense GEMMs with few rows are latency-bound by one wave's serial MFMA chain over K: split K over blockIdx.y and
     // add the partial results atomically (outputs zeroed first).  Only where the epilogue is linear in the accumulator.
     a.ksplit = 1;
@@ -32,10 +42,6 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
             return LRPX_ELAUNCH;
         }
     }
-    a.epi = d->epi; a.stab = d->stab; a.oc_split = d->oc_split; a.relu = d->relu;
-    a.bias = d->bias; a.X = d->x; a.U = d->u; a.Zdiv = d->zdiv; a.map2img = d->map2img;
-    a.out0 = d->out0; a.out1 = d->out1;
-    a.in_amax = d->in_amax; a.out1_amax = d->out1_amax;
     LRPX_REQUIRE(a.pix_per_map > 0, "conv_mfma: pix_per_map must be positive");
     LRPX_REQUIRE((long)a.n_maps * a.pix_per_map < 0x7fffffffL, "conv_mfma: too many pixels for 32-bit indexing");
     switch (d->epi) {
