@@ -94,6 +94,10 @@ typedef struct lrpx_conv_desc {
     int reserved_;
     const uint32_t* in_amax;  /* f16x3: [n_maps] float bits of max|in| per map (lrpx_amax_maps, or a producer's out1_amax) */
     uint32_t* out1_amax;      /* f16x3 + out1: max|out1| per map is atomicMax-ed into it (zero it first); may be null */
+    const uint8_t* pool_am;   /* f16x3 only: the conv sits under a 2x2 max-pool and `in` is the relevance at the pool's
+                                 OUTPUT [n_maps][hw/2*hw/2][cin]; pool_am [n_img][hw/2*hw/2][cin] = window position
+                                 (0..3, row-major) of each maximum (lrpx_pool_winner): Pool2d.propagate_relevance
+                                 (lrp_modules.py:182-195) is applied while the operand is staged */
 } lrpx_conv_desc;
 /* 3x3/pad-1 convolution (taps=9, square hw x hw maps) or dense GEMM (taps=1) on the fp32 MFMA with
  * the fused epilogues of the relevance rules.  Replaces F.conv2d / conv backward inside
@@ -120,6 +124,12 @@ int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* z
 /* s[n,p,c] = r[n,p,c] / stab(z[img(n),p,c])   (LRPtools/utils.py:16-18 safe_divide with broadcast) */
 int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c,
                      int stab, void* stream);
+/* Per image, for a 2x2 max-pool with input x (n,2h,2w,c) sitting on a conv with Z+ = z (n,2h,2w,c):
+ *   am[n,h,w,c]  = window position (0..3, row-major, first maximum wins as in max_pool2d's backward)
+ *   xzw[n,h,w,c] = max / safe(z at the winner): the multiplicand that turns the accumulator of the conv ABOVE the pool
+ *                  straight into S = R / Z+ of the conv BELOW it at the winner (Pool2d rule + safe_divide fused). */
+int lrpx_pool_winner(const float* x, const float* z, float* xzw, uint8_t* am, int n, int h_out, int w_out, int c,
+                     void* stream);
 /* amax[n] = float bits of max |s[n,:]| (zeroes amax first): the per-map operand scale of the f16x3 convolution */
 int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* stream);
 /* running sum over the maps of one image: out[b,t] = sum_{t'<=t} in[b,t']  (the reference's

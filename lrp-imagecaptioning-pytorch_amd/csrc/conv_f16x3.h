@@ -79,7 +79,7 @@ static __device__ unsigned long long g_stamp_h3[8];
 #define LRPXH_T(v)
 #endif
 
-template <int HW, int MT, int NWN, bool DB, int EPI>
+template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false>
 __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     LRPXH_T(t_start);
 #ifdef LRPX_STAMP
@@ -126,23 +126,35 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 
     // ---- staging descriptors (16 channels = 4 float4 segments per pixel) ----
     // item `it` = (LDS row s, pixel px, 16-byte segment seg) -> LDS byte offset of its 4 fp16 in plane 0 (segment index in
-    // the top bits; -1: never written, stays zero) and global pixel (-1: nothing to load).  Map-aligned tiles (224/112/
+    // bits 28-29; -1: never written, stays zero) and global pixel (-1: nothing to load).  Map-aligned tiles (224/112/
     // 56) derive both from `it` when needed - the tile sits inside one map, rows outside it are the zero padding;
     // tiles that can straddle maps (28/14: virtual zero row between maps) keep them in registers with the map's scale.
+    //
+    // POOL: the input is the relevance at the OUTPUT of the 2x2 max-pool under which this conv sits, S_lo
+    // [n_maps][H/2*W/2][cin] (already divided by this layer's Z+ at the winner, see lrpx_vgg16_trace_derive), and
+    // a.pool_am [n_img][H/2*W/2][cin] holds the window position (0..3, row-major) of each maximum: the Pool2d rule
+    // (lrp_modules.py:182-195) is applied while staging - pixel (y, x) receives S_lo[y/2][x/2] if it is the winner of
+    // its window, else 0 - so the 4x larger unpooled tensor (75 % zeros) never exists in HBM.  The global pixel is
+    // then the LOW-resolution one, the window position rides in bits 26-27 of the LDS offset.
     constexpr int SEG = KC / 4;
     constexpr int NITEM = C::NSLOT * W * SEG;
     constexpr int U = (NITEM + NT - 1) / NT;
     constexpr int UR = AL ? 1 : U;
+    constexpr int HO = H / 2, WO = W / 2;
     int sdst[UR], sgp[UR];
+    int sam[(POOL && !AL) ? U : 1];     // POOL: element offset into pool_am of the item's (image, low-res pixel)
     float ssc[UR];         // 2^kA of the item's map (one value per workgroup when tiles are map-aligned)
     const int n_al = (int)((unsigned)g0 / (unsigned)H), y_al = (int)g0 - n_al * H;
+    long img_al = 0;
     if constexpr (AL) {
         ssc[0] = exp2i(f16_scale_exp(in_amax[min(n_al, a.n_maps - 1)]));
+        if constexpr (POOL) img_al = a.map2img ? a.map2img[min(n_al, a.n_maps - 1)] : n_al;
     } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int it = tid + u * NT;
             sdst[u] = -1; sgp[u] = -1; ssc[u] = 1.f;
+            if constexpr (POOL) sam[u] = 0;
             if (it < NITEM) {
                 const int s = it / (W * SEG);
                 const int rem = it - s * (W * SEG);
@@ -154,11 +166,19 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                     sdst[u] = (s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28);
                     sgp[u] = (int)((n * H + y) * W + px);
                     ssc[u] = exp2i(f16_scale_exp(in_amax[n]));
+                    if constexpr (POOL) {
+                        const int lo = (y >> 1) * WO + (px >> 1);
+                        const long img = a.map2img ? a.map2img[n] : n;
+                        sdst[u] |= (((y & 1) << 1) | (px & 1)) << 26;
+                        sgp[u] = (int)(n * (HO * WO) + lo);
+                        sam[u] = (int)((img * (HO * WO) + lo) * a.cin);
+                    }
                 }
             }
         }
     }
-    auto item = [&](const int u, int& dst, int& gp) {
+    auto item = [&](const int u, int& dst, int& gp, int& amo) {
+        amo = 0;
         if constexpr (AL) {
             int it = tid + u * NT;
             asm volatile("" : "+v"(it));     // recompute per use: hoisted out of the chunk loop it costs 2U registers
@@ -168,30 +188,46 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             const int y = y_al - 1 + s;
             const bool ok = (it < NITEM) && (y >= 0) && (y < H);
             dst = ok ? ((s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28)) : -1;
-            gp = ok ? (n_al * H + y) * W + px : -1;
+            if constexpr (POOL) {
+                const int lo = (y >> 1) * WO + (px >> 1);
+                if (ok) dst |= (((y & 1) << 1) | (px & 1)) << 26;
+                gp = ok ? n_al * (HO * WO) + lo : -1;
+                amo = (int)((img_al * (HO * WO) + lo) * a.cin);
+            } else {
+                gp = ok ? (n_al * H + y) * W + px : -1;
+            }
         } else {
             dst = sdst[u]; gp = sgp[u];
+            if constexpr (POOL) amo = sam[u];
         }
     };
     f32x4 sv[U];
+    unsigned amv[POOL ? U : 1];
 #define LRPXH_ISSUE(CHUNK)                                                                                   \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
-        int dst_, gp_;                                                                                       \
-        item(u, dst_, gp_);                                                                                  \
+        int dst_, gp_, amo_;                                                                                 \
+        item(u, dst_, gp_, amo_);                                                                            \
         sv[u] = f32x4{0, 0, 0, 0};                                                                           \
-        if (gp_ >= 0)                                                                                        \
+        if (gp_ >= 0) {                                                                                      \
             sv[u] = *reinterpret_cast<const f32x4*>(                                                         \
-                a.in_chunk_stride ? a.in + (CHUNK) * a.in_chunk_stride + (long)gp_ * KC + ((dst_ >> 28) & 7) * 4 \
-                                  : a.in + (long)gp_ * a.cin + (CHUNK) * KC + ((dst_ >> 28) & 7) * 4);        \
+                a.in_chunk_stride ? a.in + (CHUNK) * a.in_chunk_stride + (long)gp_ * KC + ((dst_ >> 28) & 3) * 4 \
+                                  : a.in + (long)gp_ * a.cin + (CHUNK) * KC + ((dst_ >> 28) & 3) * 4);        \
+            if constexpr (POOL)                                                                              \
+                amv[u] = *reinterpret_cast<const unsigned*>(a.pool_am + amo_ + (CHUNK) * KC + ((dst_ >> 28) & 3) * 4); \
+        }                                                                                                    \
     }
 #define LRPXH_COMMIT(BUFIDX)                                                                                 \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
-        int dst_, gp_;                                                                                       \
-        item(u, dst_, gp_);                                                                                  \
+        int dst_, gp_, amo_;                                                                                 \
+        item(u, dst_, gp_, amo_);                                                                            \
         if (dst_ >= 0) {                                                                                     \
             _Float16 h[4], l[4];                                                                             \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * ssc[AL ? 0 : u], h[e], l[e]);     \
-            char* d = ldsb + (BUFIDX) * BUFB + (dst_ & 0x0fffffff);                                          \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
+                float x_ = sv[u][e] * ssc[AL ? 0 : u];                                                       \
+                if constexpr (POOL) x_ = (((amv[u] >> (8 * e)) & 0xffu) == (unsigned)((dst_ >> 26) & 3)) ? x_ : 0.f; \
+                split2(x_, h[e], l[e]);                                                                      \
+            }                                                                                                \
+            char* d = ldsb + (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                          \
             *reinterpret_cast<u32x2_*>(d) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};              \
             *reinterpret_cast<u32x2_*>(d + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};         \
         }                                                                                                    \
@@ -403,14 +439,14 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #endif
 }
 
-template <int HW, int MT, int NWN, bool DB, int EPI>
+template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false>
 int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
     using C = ConvCfg<HW, 16, MT, NWN, 9>;
     constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 80 + 256);
     const long m_tiles = ceil_div((long)a.n_maps * HW, C::R);
     const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
     const long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
-    auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI>;
+    auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI, POOL>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=

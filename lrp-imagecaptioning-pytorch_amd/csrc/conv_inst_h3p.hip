@@ -1,0 +1,7 @@
+// f16x3 relevance convolutions whose operand is unpooled while it is staged (conv_f16x3.h, POOL): conv1_2, conv2_2
+#include "conv_launch.h"
+#include "conv_f16x3.h"
+namespace lrpx {
+int launch_h3_224_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<224, 2, 2, false, EPI_REL_MUL, true>(a, s); }
+int launch_h3_112_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<112, 1, 4, true, EPI_REL_MUL, true>(a, s); }
+}

@@ -1,0 +1,7 @@
+// f16x3 relevance convolutions whose operand is unpooled while it is staged (conv_f16x3.h, POOL): conv3_3, conv4_3
+#include "conv_launch.h"
+#include "conv_f16x3.h"
+namespace lrpx {
+int launch_h3_56_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<56, 1, 4, true, EPI_REL_MUL, true>(a, s); }
+int launch_h3_28_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<28, 1, 4, true, EPI_REL_MUL, true>(a, s); }
+}

@@ -73,6 +73,10 @@ int launch_h3_112n_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_28_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_14_rel(const ConvArgs& a, hipStream_t s);
+int launch_h3_224_pool(const ConvArgs& a, hipStream_t s);   // operand unpooled while staged (a.pool_am)
+int launch_h3_112_pool(const ConvArgs& a, hipStream_t s);
+int launch_h3_56_pool(const ConvArgs& a, hipStream_t s);
+int launch_h3_28_pool(const ConvArgs& a, hipStream_t s);
 
 // few-row dense GEMMs (dense_small.hip)
 bool dense_small_fits(const ConvArgs& a);

@@ -60,6 +60,8 @@ struct ConvArgs {
     float* out1;
     const unsigned* in_amax;   // f16x3 kernels: [n_maps] float bits of max|in| per map (operand scale), else unused
     unsigned* out1_amax;       // f16x3 kernels, REL: [n_maps] max|out1| per map is atomically max-ed into it (may be null)
+    const unsigned char* pool_am;  // f16x3 POOL kernels: [n_img][H/2*W/2][cin] window position of each 2x2 maximum; `in`
+                                   // is then the low-resolution tensor [n_maps][H/2*W/2][cin]
 };
 
 __device__ __forceinline__ float stab_safe(float z) { return z + 1e-7f * (z == 0.f ? 1.f : 0.f); }

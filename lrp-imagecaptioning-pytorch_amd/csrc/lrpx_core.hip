@@ -281,6 +281,41 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
     reinterpret_cast<f32x4*>(y)[idx] = m;
 }
 
+// winners of a 2x2 max-pool + the fused multiplicand max / safe(Z+ at the winner); one thread = one pooled pixel x 4 ch
+__global__ void pool_winner_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ xzw,
+                                   unsigned char* __restrict__ am, int ho, int wo, int c4, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*ho*wo*c4
+    if (idx >= total) return;
+    const int cc = idx % c4;
+    long r = idx / c4;
+    const int xo = r % wo; r /= wo;
+    const int yo = r % ho;
+    const long n = r / ho;
+    const int wi = 2 * wo;
+    const long b0 = ((n * 2 * ho + 2 * yo) * wi + 2 * xo) * c4 + cc;
+    const long off[4] = {0, c4, (long)wi * c4, (long)wi * c4 + c4};
+    f32x4 w4[4], z4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w4[k] = reinterpret_cast<const f32x4*>(x)[b0 + off[k]];
+        z4[k] = reinterpret_cast<const f32x4*>(z)[b0 + off[k]];
+    }
+    f32x4 o;
+    unsigned pk = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float m = w4[0][e], zz = z4[0][e];
+        unsigned a_ = 0;
+        if (w4[1][e] > m) { m = w4[1][e]; zz = z4[1][e]; a_ = 1; }
+        if (w4[2][e] > m) { m = w4[2][e]; zz = z4[2][e]; a_ = 2; }
+        if (w4[3][e] > m) { m = w4[3][e]; zz = z4[3][e]; a_ = 3; }
+        o[e] = m / stab_safe(zz);
+        pk |= a_ << (8 * e);
+    }
+    reinterpret_cast<f32x4*>(xzw)[idx] = o;
+    reinterpret_cast<unsigned*>(am)[idx] = pk;
+}
+
 // Pool2d rule + division by the Z+ of the conv below.  One thread = ITER x (one hi-res pixel x 4 channels); a block
 // covers 256*ITER consecutive float4 (ITER > 1 only when that divides a map: one amax update per block).
 template <int ITER>
@@ -577,6 +612,15 @@ int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* z
                               void* stream) {
     return maxpool_relevance_amax(x, r_out, zdiv, map2img, r_in, s_out, n_maps, h_out, w_out, c, s_chunk, nullptr,
                                   (hipStream_t)stream);
+}
+
+int lrpx_pool_winner(const float* x, const float* z, float* xzw, uint8_t* am, int n, int h_out, int w_out, int c,
+                     void* stream) {
+    LRPX_REQUIRE(x && z && xzw && am && n > 0 && h_out > 0 && w_out > 0 && c % 4 == 0, "pool_winner: bad arguments");
+    const long total = (long)n * h_out * w_out * (c / 4);
+    hipLaunchKernelGGL(pool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, z, xzw, am,
+                       h_out, w_out, c / 4, total);
+    return check_launch("pool_winner");
 }
 
 int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* stream) {

@@ -23,7 +23,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     a.epi = d->epi; a.stab = d->stab; a.oc_split = d->oc_split; a.relu = d->relu;
     a.bias = d->bias; a.X = d->x; a.U = d->u; a.Zdiv = d->zdiv; a.map2img = d->map2img;
     a.out0 = d->out0; a.out1 = d->out1;
-    a.in_amax = d->in_amax; a.out1_amax = d->out1_amax;
+    a.in_amax = d->in_amax; a.out1_amax = d->out1_amax; a.pool_am = d->pool_am;
     a.ksplit = 1;
     // few rows (the decoder's lock-step rules): 32-row tiles, whole K per workgroup (dense_small.hip)
     if (d->taps == 1 && !d->bf16x6 && !d->f16x3 && dense_small_fits(a)) {
@@ -56,6 +56,13 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     if (d->f16x3) {
         LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0 && d->epi == EPI_REL_MUL && d->in_amax && !d->bf16x6 && d->x,
                      "conv_mfma: f16x3 needs a 3x3 conv, cin %% 16 == 0, the REL_MUL epilogue, x and in_amax");
+        if (d->pool_am) {
+            if (d->hw == 224 && d->n_oc <= 64) return launch_h3_224_pool(a, s);
+            if (d->hw == 112 && d->n_oc > 64) return launch_h3_112_pool(a, s);
+            if (d->hw == 56) return launch_h3_56_pool(a, s);
+            if (d->hw == 28) return launch_h3_28_pool(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no pooled-input f16x3 kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
         if (d->hw == 224) return launch_h3_224_rel(a, s);
         if (d->hw == 112) return d->n_oc <= 64 ? launch_h3_112n_rel(a, s) : launch_h3_112_rel(a, s);
         if (d->hw == 56) return launch_h3_56_rel(a, s);
@@ -179,7 +186,10 @@ static VggPacked vgg_packed_layout() {
 }
 
 struct VggTrace {   // offsets in floats; act[l] = input of layer l, act[17] = encoder output
-    size_t act[18], zpos[17], xz[17], total;   // xz[l] = act[l] / safe(zpos[l-1]) for a conv l right above a conv
+    size_t act[18], zpos[17], xz[17], am[17], total;
+    // xz[l]: multiplicand of conv l's fused relevance step = act[l] / safe(Z+ of the conv below): directly below
+    //        (zpos[l-1]) or under a pool (zpos[l-2] at the window's winner, lrpx_pool_winner);
+    // am[lp]: winner positions of pool lp (bytes, stored in a float-aligned region)
 };
 static VggTrace vgg_trace_layout(int n_img) {
     VggTrace t;
@@ -196,10 +206,14 @@ static VggTrace vgg_trace_layout(int n_img) {
         if (kVgg[l].conv) off += (size_t)n_img * kVgg[l].hw * kVgg[l].hw * kVgg[l].cout;
     }
     for (int l = 0; l < kNL; ++l) {
-        t.xz[l] = 0;
-        if (l >= 1 && kVgg[l].conv && kVgg[l - 1].conv) {
+        t.xz[l] = t.am[l] = 0;
+        if (l >= 1 && kVgg[l].conv) {
             t.xz[l] = off;
             off += (size_t)n_img * kVgg[l].hw * kVgg[l].hw * kVgg[l].cin;
+        }
+        if (!kVgg[l].conv) {
+            t.am[l] = off;
+            off += ((size_t)n_img * (kVgg[l].hw / 2) * (kVgg[l].hw / 2) * kVgg[l].cin + 3) / 4;
         }
     }
     t.total = off;
@@ -283,10 +297,16 @@ int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream) {
     float* tr = (float*)trace;
     for (int l = 1; l < kNL; ++l) {
         if (!t.xz[l]) continue;
-        // multiplicand of the fused step  S_{l-1} = x_l * convT(S_l, W+) / safe(Z+_{l-1})   (lrp_modules.py:124-150 for
-        // conv l, then utils.py:16-18 safe_divide of the conv below)
-        LRPX_TRY(lrpx_divide_stab(tr + t.act[l], tr + t.zpos[l - 1], nullptr, tr + t.xz[l], n_img,
-                                  (long)kVgg[l].hw * kVgg[l].hw * kVgg[l].cin, STAB_SAFE, stream));
+        if (kVgg[l - 1].conv) {
+            // multiplicand of the fused step  S_{l-1} = x_l * convT(S_l, W+) / safe(Z+_{l-1})   (lrp_modules.py:124-150
+            // for conv l, then utils.py:16-18 safe_divide of the conv below)
+            LRPX_TRY(lrpx_divide_stab(tr + t.act[l], tr + t.zpos[l - 1], nullptr, tr + t.xz[l], n_img,
+                                      (long)kVgg[l].hw * kVgg[l].hw * kVgg[l].cin, STAB_SAFE, stream));
+        } else {
+            // a pool lies below: max / safe(Z+_{l-2} at the winner) + the winner positions (lrp_modules.py:182-195)
+            LRPX_TRY(lrpx_pool_winner(tr + t.act[l - 1], tr + t.zpos[l - 2], tr + t.xz[l], (uint8_t*)(tr + t.am[l - 1]),
+                                      n_img, kVgg[l].hw, kVgg[l].hw, kVgg[l].cin, stream));
+        }
     }
     return LRPX_OK;
 }
@@ -394,7 +414,11 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
-        if (h3) { d.f16x3 = 1; d.epi = EPI_REL_MUL; d.wpacked = pk + p.bwdh[l]; d.in_amax = amax + (size_t)l * n_maps; }
+        if (h3) {
+            d.f16x3 = 1; d.epi = EPI_REL_MUL; d.wpacked = pk + p.bwdh[l]; d.in_amax = amax + (size_t)l * n_maps;
+            // under a pool: S[cur] is the low-resolution tensor the conv above the pool wrote, unpooled while staged
+            if (l + 1 < kNL && !kVgg[l + 1].conv) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
+        }
         else if (g_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
         if (kVgg[l - 1].conv) {
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
@@ -403,6 +427,14 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             else { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
             LRPX_TIMED_DISPATCH(l, &d);
         } else {
+            if (h3) {
+                // a pool lies below: x = max / safe(Z+ at the winner) turns the accumulator straight into S of the conv
+                // under the pool (at the winners); that conv unpools it while staging - no pool kernel, no 4x tensor
+                d.x = tr + t.xz[l]; d.out1 = S[cur ^ 1]; d.out1_amax = amax + (size_t)(l - 2) * n_maps;
+                LRPX_TIMED_DISPATCH(l, &d);
+                cur ^= 1;
+                continue;
+            }
             // a pool lies below: R at the pool output, then the Pool2d rule + division by Z+ of the conv under it
             d.out0 = R;
             LRPX_TIMED_DISPATCH(l, &d);
