@@ -201,8 +201,63 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             if constexpr (POOL) amo = sam[u];
         }
     };
-    f32x4 sv[U];
-    unsigned amv[POOL ? U : 1];
+    // POOL on map-aligned tiles: stage at LOW resolution - one item = 4 channels of one pooled pixel, loaded and split
+    // once, then written (or zero) to the 4 pixels of its window: 4x fewer loads and splits than per-pixel staging.
+    // Rows: pooled rows y_al/2 - 1 .. y_al/2 + R/2 (the first / last only reach the tile's halo row).
+    constexpr bool LOSTAGE = POOL && AL;
+    constexpr int RL = C::R / 2 + 2;
+    constexpr int NITEM_LO = RL * WO * SEG;
+    constexpr int UL = LOSTAGE ? (NITEM_LO + NT - 1) / NT : 1;
+    auto item_lo = [&](const int u, int& dst00, int& gp, int& amo, int& rowmask) {
+        int it = tid + u * NT;
+        asm volatile("" : "+v"(it));
+        const int sl = it / (WO * SEG);
+        const int rem = it - sl * (WO * SEG);
+        const int pxl = rem / SEG, seg = rem - pxl * SEG;
+        const int ylo = (y_al >> 1) - 1 + sl;
+        const bool ok = (it < NITEM_LO) && (ylo >= 0) && (ylo < HO);
+        const int s0 = 2 * sl - 1;                                   // LDS row of window row dy = 0 (dy = 1: s0 + 1)
+        rowmask = ok ? ((s0 >= 0 ? 1 : 0) | (s0 + 1 < C::NSLOT ? 2 : 0)) : 0;
+        dst00 = ((s0 < 0 ? 0 : s0) * PITCH + (2 * pxl + 1) * PSTRIDE + seg * 8) | (seg << 28);   // first row written
+        const int lo = ylo * WO + pxl;
+        gp = ok ? n_al * (HO * WO) + lo : -1;
+        amo = (int)((img_al * (HO * WO) + lo) * a.cin);
+    };
+    f32x4 sv[LOSTAGE ? UL : U];
+    unsigned amv[POOL ? (LOSTAGE ? UL : U) : 1];
+#define LRPXH_ISSUE_LO(CHUNK)                                                                                \
+    _Pragma("unroll") for (int u = 0; u < UL; ++u) {                                                         \
+        int dst_, gp_, amo_, rm_;                                                                            \
+        item_lo(u, dst_, gp_, amo_, rm_);                                                                    \
+        sv[u] = f32x4{0, 0, 0, 0};                                                                           \
+        amv[u] = 0;                                                                                          \
+        if (gp_ >= 0) {                                                                                      \
+            sv[u] = *reinterpret_cast<const f32x4*>(a.in + (long)gp_ * a.cin + (CHUNK) * KC + ((dst_ >> 28) & 3) * 4); \
+            amv[u] = *reinterpret_cast<const unsigned*>(a.pool_am + amo_ + (CHUNK) * KC + ((dst_ >> 28) & 3) * 4);    \
+        }                                                                                                    \
+    }
+#define LRPXH_COMMIT_LO(BUFIDX)                                                                              \
+    _Pragma("unroll") for (int u = 0; u < UL; ++u) {                                                         \
+        int dst_, gp_, amo_, rm_;                                                                            \
+        item_lo(u, dst_, gp_, amo_, rm_);                                                                    \
+        if (rm_) {                                                                                           \
+            _Float16 h[4], l[4];                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * ssc[0], h[e], l[e]);             \
+            char* d0 = ldsb + (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                         \
+            _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                            \
+                if (rm_ & (1 << (pos >> 1))) {                                                               \
+                    _Float16 hm[4], lm[4];                                                                   \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                          \
+                        const bool w_ = ((amv[u] >> (8 * e)) & 0xffu) == (unsigned)pos;                      \
+                        hm[e] = w_ ? h[e] : (_Float16)0; lm[e] = w_ ? l[e] : (_Float16)0;                    \
+                    }                                                                                        \
+                    char* d = d0 + (((pos >> 1) && (rm_ & 1)) ? PITCH : 0) + (pos & 1) * PSTRIDE;           \
+                    *reinterpret_cast<u32x2_*>(d) = u32x2_{pack_f16(hm[0], hm[1]), pack_f16(hm[2], hm[3])};  \
+                    *reinterpret_cast<u32x2_*>(d + 32) = u32x2_{pack_f16(lm[0], lm[1]), pack_f16(lm[2], lm[3])}; \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+    }
 #define LRPXH_ISSUE(CHUNK)                                                                                   \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
         int dst_, gp_, amo_;                                                                                 \
@@ -233,10 +288,10 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         }                                                                                                    \
     }
 
-    LRPXH_ISSUE(0)
+    if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(0) } else { LRPXH_ISSUE(0) }
     for (int i = tid; i < NBUF * BUFB / 16; i += NT) reinterpret_cast<u32x4_*>(ldsb)[i] = u32x4_{0, 0, 0, 0};
     __syncthreads();
-    LRPXH_COMMIT(0)
+    if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(0) } else { LRPXH_COMMIT(0) }
 
     f32x16 acc[7];
 #pragma unroll
@@ -267,7 +322,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = chunk + 1 < nchunk;
         LRPXH_T(ta);
-        if (more) { LRPXH_ISSUE(chunk + 1) }
+        if (more) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(chunk + 1) } else { LRPXH_ISSUE(chunk + 1) } }
         LRPXH_T(tb);
         if (wave_active) {
             const char* abuf = ldsb + (DB ? (chunk & 1) : 0) * BUFB;
@@ -297,7 +352,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         }
         LRPXH_T(tc);
         if constexpr (DB) {
-            if (more) { LRPXH_COMMIT((chunk + 1) & 1) }
+            if (more) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
             LRPXH_T(td);
             __syncthreads();
             LRPXH_T(te);
@@ -307,7 +362,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         } else {
             __syncthreads();                       // every wave is done reading the single buffer
             LRPXH_T(td0);
-            if (more) { LRPXH_COMMIT(0) }
+            if (more) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(0) } else { LRPXH_COMMIT(0) } }
             LRPXH_T(td);
             __syncthreads();
             LRPXH_T(te);
@@ -318,6 +373,8 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     }
 #undef LRPXH_ISSUE
 #undef LRPXH_COMMIT
+#undef LRPXH_ISSUE_LO
+#undef LRPXH_COMMIT_LO
     if (!wave_active) return;
     LRPXH_T(t_epi);
 
