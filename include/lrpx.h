@@ -66,7 +66,7 @@ int lrpx_conv_kc(int hw, int taps, int cin);
 
 /* ---- the contraction engine ------------------------------------------------------------------ */
 enum { LRPX_EPI_FWD_DUAL = 0, LRPX_EPI_REL = 1, LRPX_EPI_FIRST = 2, LRPX_EPI_PLAIN = 3, LRPX_EPI_GUIDED = 4,
-       LRPX_EPI_REL_MUL = 5 /* out0 and/or out1 = x * acc: the rule with the next layer's division folded into the
+       LRPX_EPI_REL_MUL = 5 /* out1 (or out0; exactly one of them) = x * acc: the rule with the next layer's division folded into the
                                multiplicand (x = X for R, x = X / safe(Z_below) for S_next); the f16x3 epilogue */ };
 enum { LRPX_STAB_NONE = 0, LRPX_STAB_SAFE = 1, LRPX_STAB_EPS = 2 };
 

@@ -127,13 +127,14 @@ __device__ __forceinline__ void epi_gather(const ConvArgs& a, const EpiCtx& cx, 
     const unsigned P = (unsigned)a.pix_per_map;
     constexpr bool NEEDS_X = (EPI == EPI_REL || EPI == EPI_GUIDED || EPI == EPI_FIRST || EPI == EPI_REL_MUL);
     if constexpr (ALIGNED && EPI != EPI_FIRST) {
+        const long xb = cx.xi_base + (long)(32 * j) * ncol;     // one 64-bit base per tile, 32-bit offsets per element
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             r.xv[e] = 0.f; r.zv[e] = 1.f;
             if (NEEDS_X && oc < ncol) {
-                const long xi = cx.xi_base + (32 * j + (e & 3) + 8 * (e >> 2)) * ncol;
-                r.xv[e] = X[xi];
-                if (EPI == EPI_REL && Zd && a.out1) r.zv[e] = Zd[xi];
+                const int xo = ((e & 3) + 8 * (e >> 2)) * ncol;
+                r.xv[e] = (X + xb)[xo];
+                if (EPI == EPI_REL && Zd && a.out1) r.zv[e] = (Zd + xb)[xo];
             }
         }
         return;
@@ -203,6 +204,32 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
     const unsigned P = (unsigned)a.pix_per_map;
     float bias = 0.f;
     if (EPI == EPI_FWD_DUAL || EPI == EPI_PLAIN) bias = (a.bias && oc < ncol) ? a.bias[oc] : 0.f;
+    if constexpr (EPI == EPI_REL_MUL) {
+        // one output (out1 if given, else out0), one base pointer per tile, compile-time pixel offsets: ~3 VALU per
+        // element instead of a 64-bit multiply-add and two uniform branches
+        if (oc >= ncol) return;
+        float* __restrict__ ob = (o1 ? o1 : o0) + (cx.pix0 + cx.q0 + 32 * j) * (long)ncol + oc;
+        int p0t = 0;
+        if (mx && !ALIGNED && TAPS == 9) {
+            const unsigned q0t = (unsigned)(cx.q0 - 4 * (cx.lane >> 5) + 32 * j);
+            const unsigned rr = q0t / (unsigned)HW, c0 = q0t - rr * HW;
+            const unsigned g = (unsigned)cx.g0 + rr;
+            p0t = (int)((g - (g / (unsigned)HW) * HW) * HW + c0) + 4 * (cx.lane >> 5);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int dq = (e & 3) + 8 * (e >> 2);
+            if (!ALIGNED && cx.pix0 + cx.q0 + 32 * j + dq >= cx.total_pix) continue;
+            const float rel = r.xv[e] * accj[e];
+            ob[dq * ncol] = rel;
+            if (mx) {
+                const bool past = !ALIGNED && TAPS == 9 && p0t + dq >= (int)P;
+                mx->m0 = fmaxf(mx->m0, past ? 0.f : fabsf(rel));
+                mx->m1 = fmaxf(mx->m1, past ? fabsf(rel) : 0.f);
+            }
+        }
+        return;
+    }
     // pixel-in-map of this lane's first pixel, counted from the map of the TILE's first pixel (lanes 32-63 start 4
     // pixels later): only needed to attribute mx across a map boundary
     int p0_tile = 0;
@@ -255,17 +282,6 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
                     }
                 }
             }
-        } else if (EPI == EPI_REL_MUL) {
-            if (oc < ncol) {
-                const float rel = r.xv[e] * v;
-                if (o0) o0[gp * ncol + oc] = rel;
-                if (o1) o1[gp * ncol + oc] = rel;
-                if (mx) {
-                    const bool past = !ALIGNED && TAPS == 9 && p0_tile + (e & 3) + 8 * (e >> 2) >= (int)P;
-                    mx->m0 = fmaxf(mx->m0, past ? 0.f : fabsf(rel));
-                    mx->m1 = fmaxf(mx->m1, past ? fabsf(rel) : 0.f);
-                }
-            }
         } else if (EPI == EPI_PLAIN) {
             if (oc < ncol) {
                 if (a.ksplit > 1) {
@@ -277,6 +293,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
                 }
             }
         } else {   // EPI_GUIDED: ReLU hook of the layer below, out = max(g,0) * [y > 0]
+            static_assert(EPI == EPI_FWD_DUAL || EPI == EPI_REL || EPI == EPI_FIRST || EPI == EPI_PLAIN || EPI == EPI_GUIDED || EPI == EPI_REL_MUL, "unknown epilogue");
             if (oc < ncol) o0[gp * ncol + oc] = (r.xv[e] > 0.f && v > 0.f) ? v : 0.f;
         }
     }

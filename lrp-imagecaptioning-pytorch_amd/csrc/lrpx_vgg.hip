@@ -50,7 +50,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
         case EPI_FIRST: LRPX_REQUIRE(d->x && d->out0, "conv_mfma: FIRST needs x,out0"); break;
         case EPI_PLAIN: LRPX_REQUIRE(d->out0, "conv_mfma: PLAIN needs out0"); break;
         case EPI_GUIDED: LRPX_REQUIRE(d->out0 && d->x, "conv_mfma: GUIDED needs x,out0"); break;
-        case EPI_REL_MUL: LRPX_REQUIRE(d->x && d->f16x3, "conv_mfma: REL_MUL is the f16x3 epilogue (needs x)"); break;
+        case EPI_REL_MUL: LRPX_REQUIRE(d->x && d->f16x3 && (!d->out0 != !d->out1), "conv_mfma: REL_MUL is the f16x3 epilogue (needs x and exactly one of out0 / out1)"); break;
         default: LRPX_REQUIRE(false, "conv_mfma: epilogue %d not built", d->epi);
     }
     if (d->f16x3) {
