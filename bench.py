@@ -39,7 +39,7 @@ DOM_FLOP_PER_MAP = 2.0 * 9 * 256 * 256 * 56 * 56
 MODE_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "bf16x6: exact 3-way bf16 split, 6 products, fp32 accumulate",
              2: "f16x3: per-map power-of-two scaling, 2-way fp16 split, 3 products, fp32 accumulate"}
 MODE_KERNEL = {0: "conv_mfma_kernel<56,16,1,4,9,REL>", 1: "conv_bf16x6_kernel<56,1,4,true,REL>",
-               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL>"}
+               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>"}
 PRODUCTS = {0: 1, 1: 6, 2: 3}
 # HBM traffic of ONE launch of that kernel over 320 maps, from rocprofv3 --pmc (separate passes, tools/pmc_passes.sh;
 # profiles/r01_pmc_traffic_f16x3.txt, ..._bf16x6.txt, r01_pmc_traffic.txt): (2 x FETCH_SIZE raw [gfx950 reports half of wide streaming reads,
@@ -211,14 +211,17 @@ def main():
                 per_layer = [p + float(v) for p, v in zip(per_layer, buf)]
             lib.lrpx_vgg16_layer_timing(0, None)
             per_layer = [p / reps for p in per_layer]
-            dom_ms = (per_layer[6] + per_layer[7] + per_layer[8]) / 3.0      # average launch of that kernel
-            flop = DOM_FLOP_PER_MAP * B * T * (0.5 + 1.0 + 1.0) / 3.0         # average algorithmic flop per launch
+            # launches of that kernel NAME per pass: conv3_1 (128 output channels) and conv3_2 (256); in mode 2 conv3_3
+            # is the pooled-input variant of the kernel (own name in rocprof), in modes 0/1 it is the same kernel
+            dom_layers, dom_w = ([6, 7], [0.5, 1.0]) if mode == 2 else ([6, 7, 8], [0.5, 1.0, 1.0])
+            dom_ms = sum(per_layer[l] for l in dom_layers) / len(dom_layers)          # average launch of that kernel
+            flop = DOM_FLOP_PER_MAP * B * T * sum(dom_w) / len(dom_w)                 # average algorithmic flop / launch
             alg = flop / dom_ms / 1e9                                        # TFLOP/s, fp32-equivalent
             exe = PRODUCTS[mode] * alg
             peak = PEAK_FP32_MFMA_TF if mode == 0 else PEAK_16BIT_MFMA_TF
             out["roofline"] = {
-                "bound": "mfma", "kernel": MODE_KERNEL[mode] + f" (relevance step of conv3_1/3_2/3_3 on 56x56 maps, "
-                f"{B * T} maps per launch, 3 launches per step)", "achieved": round(exe, 1), "peak": peak,
+                "bound": "mfma", "kernel": MODE_KERNEL[mode] + f" (relevance step of conv3_1/conv3_2"
+                + ("" if mode == 2 else "/conv3_3") + f" on 56x56 maps, {B * T} maps per launch, {len(dom_layers)} launches per step)", "achieved": round(exe, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(exe / peak, 4), "mfma_dtype": MODE_NAME[mode],
                 "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
                 "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,

@@ -201,34 +201,71 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             if constexpr (POOL) amo = sam[u];
         }
     };
-    // POOL on map-aligned tiles: stage at LOW resolution - one item = 4 channels of one pooled pixel, loaded and split
-    // once, then written (or zero) to the 4 pixels of its window: 4x fewer loads and splits than per-pixel staging.
-    // Rows: pooled rows y_al/2 - 1 .. y_al/2 + R/2 (the first / last only reach the tile's halo row).
-    constexpr bool LOSTAGE = POOL && AL;
-    constexpr int RL = C::R / 2 + 2;
+    // POOL: stage at LOW resolution - one item = 4 channels of one pooled pixel, loaded and split once, then written
+    // (or zero) to the 4 pixels of its window: 4x fewer loads and splits than per-pixel staging.
+    //   map-aligned tiles: pooled rows y_al/2 - 1 .. y_al/2 + R/2 (the first / last only reach the tile's halo row);
+    //   tiles that can straddle maps: one candidate per LDS row s_top = -1 .. NSLOT-1 holding a window's TOP row (even
+    //   y; its bottom row is the next LDS row, the same map), descriptors in registers.
+    constexpr bool LOSTAGE = POOL;
+    constexpr int RL = AL ? C::R / 2 + 2 : C::NSLOT + 1;
     constexpr int NITEM_LO = RL * WO * SEG;
     constexpr int UL = LOSTAGE ? (NITEM_LO + NT - 1) / NT : 1;
-    auto item_lo = [&](const int u, int& dst00, int& gp, int& amo, int& rowmask) {
-        int it = tid + u * NT;
-        asm volatile("" : "+v"(it));
-        const int sl = it / (WO * SEG);
-        const int rem = it - sl * (WO * SEG);
-        const int pxl = rem / SEG, seg = rem - pxl * SEG;
-        const int ylo = (y_al >> 1) - 1 + sl;
-        const bool ok = (it < NITEM_LO) && (ylo >= 0) && (ylo < HO);
-        const int s0 = 2 * sl - 1;                                   // LDS row of window row dy = 0 (dy = 1: s0 + 1)
-        rowmask = ok ? ((s0 >= 0 ? 1 : 0) | (s0 + 1 < C::NSLOT ? 2 : 0)) : 0;
-        dst00 = ((s0 < 0 ? 0 : s0) * PITCH + (2 * pxl + 1) * PSTRIDE + seg * 8) | (seg << 28);   // first row written
-        const int lo = ylo * WO + pxl;
-        gp = ok ? n_al * (HO * WO) + lo : -1;
-        amo = (int)((img_al * (HO * WO) + lo) * a.cin);
+    constexpr int ULR = (LOSTAGE && !AL) ? UL : 1;
+    int ldst[ULR], lgp[ULR], lam[ULR];
+    float lsc[ULR];
+    if constexpr (LOSTAGE && !AL) {
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int it = tid + u * NT;
+            ldst[u] = 0; lgp[u] = -1; lam[u] = 0; lsc[u] = 1.f;
+            if (it < NITEM_LO) {
+                const int c_ = it / (WO * SEG);
+                const int rem = it - c_ * (WO * SEG);
+                const int pxl = rem / SEG, seg = rem - pxl * SEG;
+                const int s0 = c_ - 1;
+                const long v_ = v0 - 1 + s0;
+                const long n = v_ >= 0 ? v_ / (H + 1) : 0;
+                const int y = (int)(v_ - n * (H + 1));
+                if ((v_ >= 0) && (y < H) && ((y & 1) == 0) && (n < a.n_maps)) {
+                    const int rowmask = (s0 >= 0 ? 1 : 0) | (s0 + 1 < C::NSLOT ? 2 : 0);
+                    const int lo = (y >> 1) * WO + pxl;
+                    const long img = a.map2img ? a.map2img[n] : n;
+                    ldst[u] = ((s0 < 0 ? 0 : s0) * PITCH + (2 * pxl + 1) * PSTRIDE + seg * 8) | (seg << 28) | (rowmask << 26);
+                    lgp[u] = (int)(n * (HO * WO) + lo);
+                    lam[u] = (int)((img * (HO * WO) + lo) * a.cin);
+                    lsc[u] = exp2i(f16_scale_exp(in_amax[n]));
+                }
+            }
+        }
+    }
+    auto item_lo = [&](const int u, int& dst00, int& gp, int& amo, int& rowmask, float& sc) {
+        if constexpr (AL) {
+            int it = tid + u * NT;
+            asm volatile("" : "+v"(it));
+            const int sl = it / (WO * SEG);
+            const int rem = it - sl * (WO * SEG);
+            const int pxl = rem / SEG, seg = rem - pxl * SEG;
+            const int ylo = (y_al >> 1) - 1 + sl;
+            const bool ok = (it < NITEM_LO) && (ylo >= 0) && (ylo < HO);
+            const int s0 = 2 * sl - 1;                               // LDS row of window row dy = 0 (dy = 1: s0 + 1)
+            rowmask = ok ? ((s0 >= 0 ? 1 : 0) | (s0 + 1 < C::NSLOT ? 2 : 0)) : 0;
+            dst00 = ((s0 < 0 ? 0 : s0) * PITCH + (2 * pxl + 1) * PSTRIDE + seg * 8) | (seg << 28);   // first row written
+            const int lo = ylo * WO + pxl;
+            gp = ok ? n_al * (HO * WO) + lo : -1;
+            amo = (int)((img_al * (HO * WO) + lo) * a.cin);
+            sc = ssc[0];
+        } else {
+            dst00 = ldst[u]; gp = lgp[u]; amo = lam[u]; sc = lsc[u];
+            rowmask = gp >= 0 ? (dst00 >> 26) & 3 : 0;
+        }
     };
     f32x4 sv[LOSTAGE ? UL : U];
     unsigned amv[POOL ? (LOSTAGE ? UL : U) : 1];
 #define LRPXH_ISSUE_LO(CHUNK)                                                                                \
     _Pragma("unroll") for (int u = 0; u < UL; ++u) {                                                         \
         int dst_, gp_, amo_, rm_;                                                                            \
-        item_lo(u, dst_, gp_, amo_, rm_);                                                                    \
+        float sc_;                                                                                           \
+        item_lo(u, dst_, gp_, amo_, rm_, sc_);                                                               \
         sv[u] = f32x4{0, 0, 0, 0};                                                                           \
         amv[u] = 0;                                                                                          \
         if (gp_ >= 0) {                                                                                      \
@@ -239,10 +276,11 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #define LRPXH_COMMIT_LO(BUFIDX)                                                                              \
     _Pragma("unroll") for (int u = 0; u < UL; ++u) {                                                         \
         int dst_, gp_, amo_, rm_;                                                                            \
-        item_lo(u, dst_, gp_, amo_, rm_);                                                                    \
+        float sc_;                                                                                           \
+        item_lo(u, dst_, gp_, amo_, rm_, sc_);                                                               \
         if (rm_) {                                                                                           \
             _Float16 h[4], l[4];                                                                             \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * ssc[0], h[e], l[e]);             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * sc_, h[e], l[e]);                \
             char* d0 = ldsb + (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                         \
             _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                            \
                 if (rm_ & (1 << (pos >> 1))) {                                                               \
