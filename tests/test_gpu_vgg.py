@@ -165,6 +165,59 @@ def test_conv_rule_f16x3_is_fp32_grade(ops, hw, cin, cout, n_img, n_maps):
         assert out1_amax[i:i + 1].view(torch.float32).item() == out1[i].abs().max().item()
 
 
+@pytest.mark.parametrize("hw,cpool,cin,n_img,n_maps", [(28, 64, 32, 2, 3), (56, 32, 64, 1, 2), (112, 32, 128, 1, 2),
+                                                        (224, 16, 64, 1, 1)])
+def test_pooled_input_conv_rule(ops, hw, cpool, cin, n_img, n_maps):
+    """Pool2d rule (lrp_modules.py:182-195) + the conv rule under the pool in ONE kernel: the conv receives the
+    relevance at the pool's OUTPUT and the winner positions (lrpx_pool_winner) and unpools while staging.
+    Checked against the oracle's two-step evaluation: maxpool_rule -> safe_divide by Z+ -> conv_alpha1beta0's
+    transposed conv, with ties in the pooling windows (first maximum must win, as in max_pool2d's backward)."""
+    from lrp_amd import _lib
+    from oracle import lrp_oracle as O
+    g = torch.Generator().manual_seed(hw * 13 + cpool)
+    ho = hw // 2
+    xin = torch.relu(torch.randn(n_img, cin, hw, hw, generator=g))                  # input of the conv under the pool
+    w = torch.randn(cpool, cin, 3, 3, generator=g) * 0.05
+    y = torch.relu(F.conv2d(xin, w, padding=1))                                      # pool input
+    y[:, :, ::4, ::4] = y[:, :, ::4, 1::4]                                           # exact ties inside windows
+    z = F.conv2d(xin, w.clamp(min=0), padding=1)                                     # Z+ of the conv under the pool
+    z[:, :, 1::6, ::5] = 0.0                                                         # exact zeros (safe_divide guard)
+    m2i = [i % n_img for i in range(n_maps)]
+    r_pool_out = torch.randn(n_maps, cpool, ho, ho, generator=g)                     # relevance at the pool output
+    # oracle: pool rule, then S = R / safe(Z), then the conv rule's transposed conv and input multiplication
+    want = []
+    for i in range(n_maps):
+        r_hi = O.maxpool_rule(y[m2i[i]:m2i[i] + 1], r_pool_out[i:i + 1])
+        s_hi = O.safe_divide(r_hi, z[m2i[i]:m2i[i] + 1])
+        want.append(xin[m2i[i]:m2i[i] + 1] * F.conv_transpose2d(s_hi, w.clamp(min=0), padding=1))
+    want = torch.cat(want)
+    # GPU: winners + fused multiplicand per image, S at the winners per map, pooled-input conv
+    dev = "cuda"
+    cin_p, cp = max(-(-cin // 32) * 32, 32), max(-(-cpool // 32) * 32, 32)
+    yg, zg = to_nhwc(y, cp).to(dev), to_nhwc(z, cp).to(dev)
+    xzw = torch.empty(n_img, ho * ho, cp, device=dev)
+    am = torch.empty(n_img, ho * ho, cp, dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.lrpx_pool_winner(_lib.ptr(yg), _lib.ptr(zg), _lib.ptr(xzw), _lib.ptr(am), n_img, ho, ho, cp,
+                                    _lib.stream_ptr()))
+    pooled = F.max_pool2d(y, 2, 2)
+    # S at the winners = (pooled / safe(Z_w)) * (R_out / safe(pooled)) : what the conv above the pool writes with xzw
+    s_lo = to_nhwc(r_pool_out, cp).to(dev) / (to_nhwc(pooled, cp).to(dev)[m2i] + 1e-7 * (to_nhwc(pooled, cp).to(dev)[m2i] == 0))
+    s_lo = (s_lo * xzw[m2i]).contiguous()
+    wpad = torch.zeros(cp, cin_p, 3, 3); wpad[:cpool, :cin] = w
+    wb = ops.pack_weights_f16x2(wpad.to(dev), cp, cin_p, _lib.PACK_BWD_POS)
+    xg = to_nhwc(xin, cin_p).to(dev)
+    r_in = torch.empty(n_maps, hw * hw, cin_p, device=dev)
+    ops.conv_mfma(s_lo, wb, n_maps, hw, cp, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xg,
+                  map2img=torch.tensor(m2i, dtype=torch.int32, device=dev), out0=r_in, f16x3=1,
+                  in_amax=ops.amax_maps(s_lo, n_maps), pool_am=am)
+    torch.cuda.synchronize()
+    got = from_nhwc(r_in.cpu(), cin, hw, hw)
+    for i in range(n_maps):
+        assert rel_err(got[i], want[i]) < TOL
+        assert cosine(got[i], want[i]) > 0.99999
+
+
 def test_reference_conv_fixture_embedded(ops):
     """The reference's own Conv2d.propagate_relevance output (layers.npz, 6x6 maps incl. an exact-zero
     region) through the MFMA kernel, embedded in a zero 14x14 canvas (zero surroundings == zero padding).
