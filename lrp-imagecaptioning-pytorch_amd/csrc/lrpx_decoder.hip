@@ -53,18 +53,20 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            float* __restrict__ out, long ldo, int B, int K, int N,
                                                            int act) {
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n0 = wave * NPW;
-    if (n0 >= N) return;
+    // one workgroup per NPW output features; its 4 waves split K (a 16-row problem has too few outputs to fill the
+    // chip with one wave per feature group, and one wave's serial K loop is a chain of L2 round trips)
+    __shared__ float red[4][NPW * BCH];
+    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * NPW;
     const int K4 = K >> 2;
+    const int kq = (K4 + 3) / 4, k_lo = wv_ * kq, k_hi = min(K4, k_lo + kq);
     for (int b0 = 0; b0 < B; b0 += BCH) {
         float acc[NPW][BCH];
 #pragma unroll
         for (int j = 0; j < NPW; ++j)
 #pragma unroll
             for (int bb = 0; bb < BCH; ++bb) acc[j][bb] = 0.f;
-        for (int k4 = lane; k4 < K4; k4 += 64) {
+        for (int k4 = k_lo + lane; k4 < k_hi; k4 += 64) {
             f32x4 wv[NPW];
 #pragma unroll
             for (int j = 0; j < NPW; ++j) {
@@ -80,18 +82,25 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
                     acc[j][bb] += wv[j][0] * xv[0] + wv[j][1] * xv[1] + wv[j][2] * xv[2] + wv[j][3] * xv[3];
             }
         }
+        __syncthreads();                 // (previous row chunk's reduction has been read)
 #pragma unroll
         for (int j = 0; j < NPW; ++j)
 #pragma unroll
             for (int bb = 0; bb < BCH; ++bb) {
-                float v = wave_sum(acc[j][bb]);
-                const int n = n0 + j, b = b0 + bb;
-                if (lane == 0 && n < N && b < B) {
-                    if (bias) v += bias[n];
-                    if (act == 1) v = v > 0.f ? v : 0.f;
-                    out[(long)b * ldo + n] = v;
-                }
+                const float v = wave_sum(acc[j][bb]);
+                if (lane == 0) red[wv_][j * BCH + bb] = v;
             }
+        __syncthreads();
+        if (threadIdx.x < NPW * BCH) {
+            const int j = threadIdx.x / BCH, bb = threadIdx.x % BCH;
+            const int n = n0 + j, b = b0 + bb;
+            float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            if (n < N && b < B) {
+                if (bias) v += bias[n];
+                if (act == 1) v = v > 0.f ? v : 0.f;
+                out[(long)b * ldo + n] = v;
+            }
+        }
     }
 }
 
@@ -768,8 +777,7 @@ extern "C" {
 int lrpx_linear_small(const float* x, long ldx, const float* w, const float* bias, float* out, long ldo, int B, int K,
                       int N, int act, void* stream) {
     LRPX_REQUIRE(x && w && out && B > 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0, "linear_small: bad arguments");
-    const int waves = (N + 3) / 4;
-    hipLaunchKernelGGL((linear_small_kernel<4, 16>), dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
+    hipLaunchKernelGGL((linear_small_kernel<4, 16>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
                        bias, out, ldo, B, K, N, act);
     return check_launch("linear_small");
 }
