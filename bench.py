@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--gather", action="store_true", help="gather the maps to rank 0 over RCCL inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="independent batches in flight on separate HIP streams (1 = serial steps); every step is still "
+                         "one full pass over one batch, the decoder's latency-bound kernels of one batch overlap the "
+                         "MFMA-bound CNN chain of another")
     ap.add_argument("--fp32-mfma", action="store_true", help="same as --conv-mode 0")
     ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 1, 2],
                     help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3 relevance (default)")
@@ -123,7 +127,11 @@ def main():
     torch.set_num_threads(min(8, host_cores()))
     if rank == 0:
         log(f"building weights + engine (B={B}, T={T}, V={V}, world={world})")
-    eng = GridTDEngine(weights.make_gridtd_state(seed=0, vocab_size=V))
+    sd0 = weights.make_gridtd_state(seed=0, vocab_size=V)
+    eng = GridTDEngine(sd0)
+    n_pipe = 1 if a.graph else max(1, a.pipeline)
+    engines = [eng] + [eng.replica() for _ in range(n_pipe - 1)]     # shared weights, own trace / workspace buffers
+    streams = [torch.cuda.Stream() for _ in range(n_pipe)] if n_pipe > 1 else [None]
     # every rank gets its own shard of a global synthetic batch (seed offset by rank)
     images = torch.from_numpy(weights.make_images(100 + rank, B)).cuda()
     caps = torch.from_numpy(weights.make_captions(200 + rank, B, T, V)).cuda()
@@ -133,7 +141,25 @@ def main():
 
     state = {}
 
+    step_no = [0]
+
     def step(timed):
+        if n_pipe > 1:
+            k = step_no[0] % n_pipe
+            step_no[0] += 1
+            with torch.cuda.stream(streams[k]):
+                e = engines[k]
+                enc = e.encode(images)
+                tr = e.trace(enc, caps, predictions=False)
+                r_feat, r_words, row2img = e.relevance(enc, tr)
+                if "maps%d" % k not in state:
+                    state["maps%d" % k] = torch.empty(B * T, 3, 224, 224, device="cuda")
+                maps = e.vgg.relevance(r_feat, row2img, out=state["maps%d" % k])
+                if k == 0:
+                    state["chain_in"] = (r_feat, row2img)
+                if a.gather and world > 1:
+                    dist.gather(maps, gathered, dst=0)
+            return maps, r_words
         if a.graph:
             maps, r_words = eng.explain_batch_graph(images, caps)
             if a.gather and world > 1:
@@ -180,7 +206,8 @@ def main():
                "config": {"workload": "BASELINE configs[1]: batch-16 224x224 images x 20-word captions per GPU, "
                                       "VGG16+gridTD, LRP alpha1beta0 (conv) + epsilon (decoder), V=9586, random-init",
                           "images_per_gpu": B, "words": T, "vocab": V, "maps_per_step": world * B * T,
-                          "sharding": f"images x{world}, no data-path collective" + (" + gather" if a.gather else "")}}
+                          "sharding": f"images x{world}, no data-path collective" + (" + gather" if a.gather else ""),
+                          "batches_in_flight": n_pipe}}
         if world == 1:
             # (1) the whole VGG16 relevance chain (12 conv launches + first-layer kernel + 4 pool kernels), HIP events
             if "chain_in" not in state:

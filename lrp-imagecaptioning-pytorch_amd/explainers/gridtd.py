@@ -355,6 +355,49 @@ class GridTDEngine:
             out = out + (r_feat.view(B, T, self.P, self.C), tr, enc)
         return out
 
+    def replica(self):
+        """A second execution context over the SAME weights (device tensors and packed blobs are shared): own VGG16
+        trace / workspace buffers, so two batches can be in flight on two HIP streams."""
+        import copy
+        r = copy.copy(self)
+        r.vgg = self.vgg.replica()
+        r._idx_cache = {}
+        if hasattr(r, "_graphs"):
+            del r._graphs
+        return r
+
+    def explain_stream(self, batches, depth=2, accumulate=False):
+        """Explain an iterable of independent (images, captions) batches with `depth` batches in flight, each on its own
+        HIP stream and buffer set.  Batches are independent (no exchange step), and roughly a seventh of
+        a batch's time is the decoder's lock-step chain of small latency-bound kernels: it overlaps the MFMA-bound CNN
+        relevance chain of the neighbouring batch.  Yields (maps, r_words) in input order; each result is complete
+        (its stream has been synchronised) when it is yielded.  Results are bit-identical to `explain_batch`."""
+        depth = max(1, int(depth))
+        if not hasattr(self, "_replicas"):
+            self._replicas, self._streams = [self], [torch.cuda.Stream(device=self.device)]
+        while len(self._replicas) < depth:
+            self._replicas.append(self.replica())
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        pending = []
+        for i, (images, captions) in enumerate(batches):
+            k = i % depth
+            st = self._streams[k]
+            st.wait_stream(torch.cuda.current_stream(self.device))     # inputs produced on the caller's stream
+            with torch.cuda.stream(st):
+                out = self._replicas[k].explain_batch(images, captions, accumulate=accumulate)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            for t in out:
+                t.record_stream(torch.cuda.current_stream(self.device))
+            pending.append((out, ev))
+            if len(pending) >= depth:
+                o, e = pending.pop(0)
+                e.synchronize()
+                yield o
+        for o, e in pending:
+            e.synchronize()
+            yield o
+
 
 # ------------------------------------------------------------------------------------------------
 # drop-in explainer (models/gridTDmodel.py:705-1211)

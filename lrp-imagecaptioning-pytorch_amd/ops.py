@@ -145,6 +145,15 @@ class Vgg16:
         self.n_img = 0
         self._ws = None
 
+    def replica(self):
+        """Same packed weights, own trace / workspace buffers (for a second batch in flight on another stream)."""
+        import copy
+        r = copy.copy(self)
+        r.trace, r.n_img, r._ws = None, 0, None
+        if hasattr(r, "_ws_multi"):
+            del r._ws_multi
+        return r
+
     def forward(self, img_nchw):
         """Encoder.forward + trace (models/gridTDmodel.py:40-43).  Returns features (B,196,512) NHWC (a view
         into the trace)."""

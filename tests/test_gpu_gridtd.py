@@ -90,3 +90,24 @@ def test_greedy_tokens_bit_exact(case):
     enc = eng.encode(img.cuda())
     toks = eng.greedy(enc, len(gg["tokens"]), V - 2, V - 1)
     assert toks[0].cpu().tolist() == [int(x) for x in gg["tokens"]]
+
+
+def test_explain_stream_matches_serial():
+    """independent batches in flight on separate HIP streams (GridTDEngine.explain_stream, shared weights, own
+    buffers per stream) give bit-identical maps and word relevances to explaining them one after the other"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine
+    eng = GridTDEngine(weights.make_gridtd_state(seed=3, vocab_size=50))
+    batches = [(torch.from_numpy(weights.make_images(10 + i, 2)), torch.from_numpy(weights.make_captions(20 + i, 2, 3, 50)))
+               for i in range(5)]
+    serial = [tuple(t.clone() for t in eng.explain_batch(im, cp)) for im, cp in batches]
+    torch.cuda.synchronize()
+    piped = list(eng.explain_stream(batches, depth=2))
+    assert len(piped) == len(serial)
+    for (m0, w0), (m1, w1) in zip(serial, piped):
+        assert torch.equal(m0, m1) and torch.equal(w0, w1)
+    again = eng.explain_batch(*batches[0])          # the engine is usable serially afterwards
+    torch.cuda.synchronize()
+    assert torch.equal(again[0], serial[0][0])
