@@ -134,6 +134,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise LrpxError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
                         "(or __graft_entry__.build()); there is no CPU fallback for the LRP hot path")
+    # torch first: it ships its own libamdhip64; liblrpx.so must bind to THAT runtime (same device context, same
+    # streams).  Loaded the other way round the process holds two HIP runtimes and ours sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
