@@ -72,7 +72,7 @@ __device__ __forceinline__ void amax_update(unsigned* p, float m) {
 #ifndef LRPX_STAMP_HW
 #define LRPX_STAMP_HW 224
 #endif
-static __device__ unsigned long long g_stamp_h3[8];
+static __device__ unsigned long long g_stamp_h3[12];
 #define LRPXH_T(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); \
                    __builtin_amdgcn_sched_barrier(0)
 #else
@@ -83,7 +83,7 @@ template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false>
 __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     LRPXH_T(t_start);
 #ifdef LRPX_STAMP
-    unsigned long long s_issue = 0, s_mfma = 0, s_commit = 0, s_barrier = 0;
+    unsigned long long s_issue = 0, s_mfma = 0, s_commit = 0, s_barrier = 0, s_tap0 = 0, s_tap1 = 0, s_tap2 = 0;
 #endif
     constexpr int KC = 16, TAPS = 9;
     using C = ConvCfg<HW, KC, MT, NWN, TAPS>;
@@ -93,6 +93,10 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     constexpr int BUFB = C::NSLOT * PITCH;
     constexpr int NBUF = DB ? 2 : 1;
     constexpr bool AL = (H % C::R == 0);               // a workgroup tile never straddles two maps
+#ifndef LRPXH_APIPE_MIN_HW
+#define LRPXH_APIPE_MIN_HW 14
+#endif
+    constexpr bool APIPE = HW >= LRPXH_APIPE_MIN_HW;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
     const int tid = threadIdx.x;
@@ -338,7 +342,13 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
     // B fragments: per k-step two planes (hi, lo) of 64 lanes x 16 B, one contiguous stream per channel block
-    constexpr int NBQ = (HW == 224) ? 5 : 6;
+#ifdef LRPXH_NBQ
+    constexpr int NBQ = LRPXH_NBQ;
+#else
+    // measured (tools/variant_sweep2.sh, chain of 320 maps): depth 2 -> 28.9 ms, 4 -> 26.9, 6 -> 25.9, 8 -> 25.0; the
+    // map-straddling tiles (28/14) spill beyond 7
+    constexpr int NBQ = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : ((HW == 112 && NWN == 2) ? 8 : 9));
+#endif
     const float inv_w = a.wp[0];
     const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
                        (long)ocb * nchunk * (TAPS * 2 * 64) + lane;
@@ -364,6 +374,17 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         LRPXH_T(tb);
         if (wave_active) {
             const char* abuf = ldsb + (DB ? (chunk & 1) : 0) * BUFB;
+#ifdef LRPX_STAMP
+            unsigned long long tprev = tb;
+#endif
+            // APIPE (wide maps with few K-chunks: the partner wave of the SIMD is mostly outside its MFMA phase, so this
+            // wave's LDS latency is not covered by the partner's MFMAs): A fragments are read one accumulator tile ahead
+            f16x8 n0, n1;
+            if constexpr (APIPE) {
+                n0 = *reinterpret_cast<const f16x8*>(abuf + abase[0]);
+                n1 = *reinterpret_cast<const f16x8*>(abuf + abase[0] + 32);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int tapoff = (tap / 3) * PITCH + (tap % 3) * PSTRIDE;
@@ -374,18 +395,40 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[0][1]);
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
-                    const char* ap = abuf + abase[j] + tapoff;
-                    const f16x8 a0 = *reinterpret_cast<const f16x8*>(ap);
-                    const f16x8 a1 = *reinterpret_cast<const f16x8*>(ap + 32);
+                    f16x8 a0, a1;
+                    if constexpr (APIPE) {
+                        a0 = n0; a1 = n1;
+                        if (!(tap == TAPS - 1 && j == 6)) {
+                            const int jn = (j + 1) % 7, tn = tap + (j == 6 ? 1 : 0);
+                            const char* apn = abuf + abase[jn] + (tn / 3) * PITCH + (tn % 3) * PSTRIDE;
+                            n1 = *reinterpret_cast<const f16x8*>(apn + 32);
+                            n0 = *reinterpret_cast<const f16x8*>(apn);
+                        }
+                    } else {
+                        const char* ap = abuf + abase[j] + tapoff;
+                        a0 = *reinterpret_cast<const f16x8*>(ap);
+                        a1 = *reinterpret_cast<const f16x8*>(ap + 32);
+                    }
                     // small terms first
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[j], 0, 0, 0);
+                    if constexpr (APIPE) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the 2 reads of the NEXT tile ...
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the 3 MFMAs of this one
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < NBQ - 1; ++i)
 #pragma unroll
                     for (int p = 0; p < 2; ++p) bq[i][p] = bq[i + 1][p];
+#ifdef LRPX_STAMP
+                if (tap == 2 || tap == 5 || tap == 8) {
+                    LRPXH_T(tt);
+                    if (tap == 2) s_tap0 += tt - tprev; else if (tap == 5) s_tap1 += tt - tprev; else s_tap2 += tt - tprev;
+                    tprev = tt;
+                }
+#endif
             }
         }
         LRPXH_T(tc);
@@ -530,6 +573,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         atomicAdd(&g_stamp_h3[5], t_end - t_epi);
         atomicAdd(&g_stamp_h3[6], t_end - t_start);
         atomicAdd(&g_stamp_h3[7], 1ull);
+        atomicAdd(&g_stamp_h3[8], s_tap0); atomicAdd(&g_stamp_h3[9], s_tap1); atomicAdd(&g_stamp_h3[10], s_tap2);
     }
 #endif
 }

@@ -6,9 +6,9 @@ int launch_h3_56_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16
 int launch_h3_28_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<28, 1, 4, true, EPI_REL_MUL, true>(a, s); }
 }
 #ifdef LRPX_STAMP
-extern "C" int lrpx_debug_stamps_h3q(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lrpx::g_stamp_h3), 64) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lrpx::g_stamp_h3), z, 64) != hipSuccess) return 1; }
+extern "C" int lrpx_debug_stamps_h3q(unsigned long long* out12, int reset) {
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(lrpx::g_stamp_h3), 96) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lrpx::g_stamp_h3), z, 96) != hipSuccess) return 1; }
     return 0;
 }
 #endif

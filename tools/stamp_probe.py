@@ -22,7 +22,7 @@ r_feat = torch.randn(320, 196, 512, device="cuda")
 m2i = (torch.arange(320, device="cuda") * 16 // 320).to(torch.int32)
 out = vgg.relevance(r_feat, m2i)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 12)()
 raw = C.CDLL(_lib.LIB_PATH)
 fn = getattr(raw, sys.argv[1] if len(sys.argv) > 1 else "lrpx_debug_stamps")   # _h3 (56/28/14) / _h3b (224/112) / bf16x6
 fn(buf, 1)
@@ -35,3 +35,6 @@ names = ["prologue", "issue(next chunk loads)", "mfma phase", "commit(split+ds_w
 print(f"waves: {v[7]}   ({sys.argv[1:]} one chain pass of 320 maps)")
 for k, x in zip(names, v[:7]):
     print(f"  {k:28s} {x / n:12.0f} clk/wave  {100.0 * x / max(v[6], 1):6.1f} %")
+if v[8]:
+    for k, x in zip(["mfma taps 0-2", "mfma taps 3-5", "mfma taps 6-8"], v[8:11]):
+        print(f"    {k:26s} {x / n:12.0f} clk/wave  {100.0 * x / max(v[6], 1):6.1f} %")
