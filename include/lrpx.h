@@ -89,11 +89,12 @@ typedef struct lrpx_conv_desc {
     int f16x3;            /* 1: contraction on the fp16 matrix cores: operands scaled into the fp16 range (per map /
                              per layer, powers of two) and split in two halves, 3 partial products, fp32 accumulate
                              (22-bit operands: below the rounding of the fp32 accumulation itself; half the matrix
-                             time of bf16x6).  wpacked from lrpx_pack_weights_f16x2; needs in_amax; REL_MUL epilogue,
+                             time of bf16x6).  wpacked from lrpx_pack_weights_f16x2; needs in_amax; REL_MUL or FWD_DUAL epilogue,
                              3x3 convs, cin %% 16 == 0 */
     int reserved_;
     const uint32_t* in_amax;  /* f16x3: [n_maps] float bits of max|in| per map (lrpx_amax_maps, or a producer's out1_amax) */
     uint32_t* out1_amax;      /* f16x3 + out1: max|out1| per map is atomicMax-ed into it (zero it first); may be null */
+    uint32_t* out0_amax;      /* f16x3 + FWD_DUAL: max of out0 (the activations) per map is atomicMax-ed into it; may be null */
     const uint8_t* pool_am;   /* f16x3 only: the conv sits under a 2x2 max-pool and `in` is the relevance at the pool's
                                  OUTPUT [n_maps][hw/2*hw/2][cin]; pool_am [n_img][hw/2*hw/2][cin] = window position
                                  (0..3, row-major) of each maximum (lrpx_pool_winner): Pool2d.propagate_relevance
@@ -151,6 +152,9 @@ int lrpx_set_bf16x6(int enable);
 /* Matrix-core mode of the fused VGG16 chains: 0 fp32 MFMA, 1 bf16x6 (exact splits), 2 f16x3 for the relevance pass
  * (forward trace stays bf16x6).  Negative: query only.  Returns the previous mode. */
 int lrpx_set_conv_mode(int mode);
+/* 1: the forward trace of conv1_2..conv5_3 also runs on the fp16 split-product kernels (operand scale = per-image maximum of
+ * the layer input); 0: bf16x6 / fp32 as selected by the conv mode.  Negative: query.  Returns the previous value. */
+int lrpx_set_forward_f16(int enable);
 
 /* ---- VGG16 encoder: trace + relevance chain ------------------------------------------------------ */
 /* bytes of the packed-weight blob / per-batch trace / relevance workspace */

@@ -504,7 +504,8 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     }
 
     // ---- epilogue (software-pipelined per tile); max|out1| per map goes to a.out1_amax for the next f16x3 consumer ----
-    unsigned* __restrict__ oamax = ((EPI == EPI_REL || EPI == EPI_REL_MUL) && a.out1) ? a.out1_amax : nullptr;
+    unsigned* __restrict__ oamax = (EPI == EPI_FWD_DUAL) ? a.out0_amax
+                                   : (((EPI == EPI_REL || EPI == EPI_REL_MUL) && a.out1) ? a.out1_amax : nullptr);
     EpiMax mx0 = {0.f, 0.f}, mx1 = mx0, mx2 = mx0, mx3 = mx0, mx4 = mx0, mx5 = mx0, mx6 = mx0;   // (scalars: an array
     if constexpr (EPI == EPI_REL_MUL) {                                                  //  would live in scratch)
         // one multiplicand per element: all 112 loads are issued before the first store (stores share the in-order

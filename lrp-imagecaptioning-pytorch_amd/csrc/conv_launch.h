@@ -73,6 +73,11 @@ int launch_h3_112n_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_28_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_14_rel(const ConvArgs& a, hipStream_t s);
+int launch_h3_224_fwd(const ConvArgs& a, hipStream_t s);    // forward trace (ReLU(conv+b) and Z+) on the fp16 matrix cores
+int launch_h3_112_fwd(const ConvArgs& a, hipStream_t s);
+int launch_h3_56_fwd(const ConvArgs& a, hipStream_t s);
+int launch_h3_28_fwd(const ConvArgs& a, hipStream_t s);
+int launch_h3_14_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_224_pool(const ConvArgs& a, hipStream_t s);   // operand unpooled while staged (a.pool_am)
 int launch_h3_112_pool(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_pool(const ConvArgs& a, hipStream_t s);

@@ -60,6 +60,7 @@ struct ConvArgs {
     float* out1;
     const unsigned* in_amax;   // f16x3 kernels: [n_maps] float bits of max|in| per map (operand scale), else unused
     unsigned* out1_amax;       // f16x3 kernels, REL: [n_maps] max|out1| per map is atomically max-ed into it (may be null)
+    unsigned* out0_amax;       // f16x3 kernels, FWD_DUAL: [n_maps] max of out0 (activations) per map (may be null)
     const unsigned char* pool_am;  // f16x3 POOL kernels: [n_img][H/2*W/2][cin] window position of each 2x2 maximum; `in`
                                    // is then the low-resolution tensor [n_maps][H/2*W/2][cin]
 };
@@ -256,7 +257,13 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
         if (EPI == EPI_FWD_DUAL) {
             if (oc < ncol) {
                 v += bias;
-                o0[gp * ncol + oc] = v > 0.f ? v : 0.f;
+                v = v > 0.f ? v : 0.f;
+                o0[gp * ncol + oc] = v;
+                if (mx) {     // activations are the next layer's operand: per-image maximum for its fp16 scale
+                    const bool past = !ALIGNED && TAPS == 9 && p0_tile + (e & 3) + 8 * (e >> 2) >= (int)P;
+                    mx->m0 = fmaxf(mx->m0, past ? 0.f : v);
+                    mx->m1 = fmaxf(mx->m1, past ? v : 0.f);
+                }
             } else if (oc < 2 * ncol) {
                 o1[gp * ncol + (oc - ncol)] = v;
             }

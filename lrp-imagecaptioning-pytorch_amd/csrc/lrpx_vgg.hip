@@ -23,7 +23,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     a.epi = d->epi; a.stab = d->stab; a.oc_split = d->oc_split; a.relu = d->relu;
     a.bias = d->bias; a.X = d->x; a.U = d->u; a.Zdiv = d->zdiv; a.map2img = d->map2img;
     a.out0 = d->out0; a.out1 = d->out1;
-    a.in_amax = d->in_amax; a.out1_amax = d->out1_amax; a.pool_am = d->pool_am;
+    a.in_amax = d->in_amax; a.out1_amax = d->out1_amax; a.pool_am = d->pool_am; a.out0_amax = d->out0_amax;
     a.ksplit = 1;
     // few rows (the decoder's lock-step rules): 32-row tiles, whole K per workgroup (dense_small.hip)
     if (d->taps == 1 && !d->bf16x6 && !d->f16x3 && dense_small_fits(a)) {
@@ -54,8 +54,17 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
         default: LRPX_REQUIRE(false, "conv_mfma: epilogue %d not built", d->epi);
     }
     if (d->f16x3) {
-        LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0 && d->epi == EPI_REL_MUL && d->in_amax && !d->bf16x6 && d->x,
-                     "conv_mfma: f16x3 needs a 3x3 conv, cin %% 16 == 0, the REL_MUL epilogue, x and in_amax");
+        LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0 && d->in_amax && !d->bf16x6 &&
+                         ((d->epi == EPI_REL_MUL && d->x) || (d->epi == EPI_FWD_DUAL && !d->pool_am)),
+                     "conv_mfma: f16x3 needs a 3x3 conv, cin %% 16 == 0, in_amax and the REL_MUL (with x) or FWD_DUAL epilogue");
+        if (d->epi == EPI_FWD_DUAL) {
+            if (d->hw == 224) return launch_h3_224_fwd(a, s);
+            if (d->hw == 112) return launch_h3_112_fwd(a, s);
+            if (d->hw == 56) return launch_h3_56_fwd(a, s);
+            if (d->hw == 28) return launch_h3_28_fwd(a, s);
+            if (d->hw == 14) return launch_h3_14_fwd(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no f16x3 forward kernel built for hw=%d", d->hw);
+        }
         if (d->pool_am) {
             if (d->hw == 224 && d->n_oc <= 64) return launch_h3_224_pool(a, s);
             if (d->hw == 112 && d->n_oc > 64) return launch_h3_112_pool(a, s);
@@ -152,6 +161,7 @@ int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, f
 // trace + f16x3 relevance pass (conv_f16x3.h)
 static int g_mode = 2;
 #define g_bf16x6 (g_mode >= 1)
+static int g_fwd_f16 = 1;   // lrpx_set_forward_f16: forward trace of conv1_2..conv5_3 on the fp16 split-product kernels (default on)
 
 // optional per-layer timing of the relevance chain (lrpx_vgg16_layer_timing): HIP events recorded on the launch stream
 // around every conv launch of the NEXT lrpx_vgg16_relevance call; off by default, never inside a timed benchmark loop
@@ -160,13 +170,13 @@ static hipEvent_t g_ev[17][2];
 static bool g_ev_made = false, g_ev_valid[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], fwd6[17], bias[17], first6, first6p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], fwd6[17], fwdh[17], bias[17], first6, first6p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
     size_t off = 0;
     for (int l = 0; l < kNL; ++l) {
-        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.fwd6[l] = p.bias[l] = 0;
+        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.fwd6[l] = p.fwdh[l] = p.bias[l] = 0;
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
@@ -175,6 +185,7 @@ static VggPacked vgg_packed_layout() {
         if (l > 0) { p.bwdp[l] = off; off += lrpx_packed_floats(L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout)); }
         if (l > 0) { p.bwd6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (l > 0) { p.bwdh[l] = off; off += lrpx_packed_f16x2_bytes(L.cin, L.cout, 9) / sizeof(float); }
+        if (l > 0) { p.fwdh[l] = off; off += lrpx_packed_f16x2_bytes(2 * L.cout, L.cin, 9) / sizeof(float); }
         if (L.hw <= 112) {
             p.fwd6[l] = off; off += lrpx_packed_bf16x3_bytes(2 * L.cout, L.cin, 9) / sizeof(float);
         }
@@ -186,7 +197,7 @@ static VggPacked vgg_packed_layout() {
 }
 
 struct VggTrace {   // offsets in floats; act[l] = input of layer l, act[17] = encoder output
-    size_t act[18], zpos[17], xz[17], am[17], total;
+    size_t act[18], zpos[17], xz[17], am[17], famax, total;   // famax: [18][n_img] max of act[l] per image (f16x3 forward)
     // xz[l]: multiplicand of conv l's fused relevance step = act[l] / safe(Z+ of the conv below): directly below
     //        (zpos[l-1]) or under a pool (zpos[l-2] at the window's winner, lrpx_pool_winner);
     // am[lp]: winner positions of pool lp (bytes, stored in a float-aligned region)
@@ -216,6 +227,8 @@ static VggTrace vgg_trace_layout(int n_img) {
             off += ((size_t)n_img * (kVgg[l].hw / 2) * (kVgg[l].hw / 2) * kVgg[l].cin + 3) / 4;
         }
     }
+    t.famax = off;
+    off += (size_t)18 * n_img;
     t.total = off;
     return t;
 }
@@ -238,6 +251,12 @@ int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream) { return conv_dispatch
 int lrpx_set_bf16x6(int enable) {
     const int prev = g_mode >= 1;
     if (enable >= 0) g_mode = enable ? 1 : 0;
+    return prev;
+}
+
+int lrpx_set_forward_f16(int enable) {
+    const int prev = g_fwd_f16;
+    if (enable >= 0) g_fwd_f16 = enable ? 1 : 0;
     return prev;
 }
 
@@ -283,6 +302,7 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
         }
         if (l > 0) LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwd6[l], stream));
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwdh[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwdh[l], stream));
         if (L.hw <= 112) {
             LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwd6[l], stream));
         }
@@ -330,6 +350,10 @@ int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, voi
     const VggTrace t = vgg_trace_layout(n_img);
     const float* pk = (const float*)packed;
     float* tr = (float*)trace;
+    if (g_fwd_f16 && g_mode == 2 && hipMemsetAsync(tr + t.famax, 0, (size_t)18 * n_img * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+        set_error("vgg16_forward: cannot zero the amax words");
+        return LRPX_ELAUNCH;
+    }
     // the signed image is kept split into x+ / x- (channels 0-2 / 3-5 of 8): Z of the first conv needs both
     LRPX_TRY(lrpx_nchw_to_nhwc_posneg(img_nchw, tr + t.act[0], n_img, 3, 224 * 224, 8, stream));
     for (int l = 0; l < kNL; ++l) {
@@ -340,7 +364,14 @@ int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, voi
             d.n_maps = n_img; d.hw = L.hw; d.cin = cin_pad(l); d.n_oc = 2 * L.cout; d.taps = 9;
             d.epi = EPI_FWD_DUAL; d.oc_split = L.cout; d.bias = pk + p.bias[l];
             d.out0 = tr + t.act[l + 1]; d.out1 = tr + t.zpos[l];
-            if (g_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
+            if (g_fwd_f16 && g_mode == 2 && l >= 1) {
+                // fp16 split products (conv_f16x3.h): operand scale = max of the layer input per image; a max-pool keeps it
+                unsigned* fam = reinterpret_cast<unsigned*>(tr + t.famax);
+                const int in_l = kVgg[l - 1].conv ? l : l - 1;
+                if (l == 1) LRPX_TRY(lrpx_amax_maps(tr + t.act[1], n_img, (long)L.hw * L.hw * L.cin, fam + (size_t)1 * n_img, stream));
+                d.f16x3 = 1; d.wpacked = pk + p.fwdh[l];
+                d.in_amax = fam + (size_t)in_l * n_img; d.out0_amax = fam + (size_t)(l + 1) * n_img;
+            } else if (g_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
             LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
         } else {
             LRPX_TRY(lrpx_maxpool2x2_fwd(tr + t.act[l], tr + t.act[l + 1], n_img, L.hw, L.hw, L.cin, stream));
