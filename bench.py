@@ -108,8 +108,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # LRPX_BENCH_BACKEND=gloo + LRPX_BENCH_ONE_GPU=1: rehearsal of the multi-rank path on a one-GPU box (all ranks on cuda:0)
+        backend = os.environ.get("LRPX_BENCH_BACKEND", "nccl")
+        if os.environ.get("LRPX_BENCH_ONE_GPU") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(0)
