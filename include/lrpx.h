@@ -91,7 +91,7 @@ typedef struct lrpx_conv_desc {
                              (22-bit operands: below the rounding of the fp32 accumulation itself; half the matrix
                              time of bf16x6).  wpacked from lrpx_pack_weights_f16x2; needs in_amax; REL_MUL or FWD_DUAL epilogue,
                              3x3 convs, cin %% 16 == 0 */
-    int reserved_;
+    int out_chunk;        /* REL_MUL: > 0 writes the output channel-chunked [C/out_chunk][n_maps*pixels][out_chunk] (16) */
     const uint32_t* in_amax;  /* f16x3: [n_maps] float bits of max|in| per map (lrpx_amax_maps, or a producer's out1_amax) */
     uint32_t* out1_amax;      /* f16x3 + out1: max|out1| per map is atomicMax-ed into it (zero it first); may be null */
     uint32_t* out0_amax;      /* f16x3 + FWD_DUAL: max of out0 (the activations) per map is atomicMax-ed into it; may be null */

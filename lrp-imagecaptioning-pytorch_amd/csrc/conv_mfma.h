@@ -60,6 +60,7 @@ struct ConvArgs {
     float* out1;
     const unsigned* in_amax;   // f16x3 kernels: [n_maps] float bits of max|in| per map (operand scale), else unused
     unsigned* out1_amax;       // f16x3 kernels, REL: [n_maps] max|out1| per map is atomically max-ed into it (may be null)
+    int out_chunk;             // REL_MUL: > 0 = the output is written channel-chunked [C/out_chunk][pixels][out_chunk]
     unsigned* out0_amax;       // f16x3 kernels, FWD_DUAL: [n_maps] max of out0 (activations) per map (may be null)
     const unsigned char* pool_am;  // f16x3 POOL kernels: [n_img][H/2*W/2][cin] window position of each 2x2 maximum; `in`
                                    // is then the low-resolution tensor [n_maps][H/2*W/2][cin]
@@ -209,7 +210,12 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
         // one output (out1 if given, else out0), one base pointer per tile, compile-time pixel offsets: ~3 VALU per
         // element instead of a 64-bit multiply-add and two uniform branches
         if (oc >= ncol) return;
-        float* __restrict__ ob = (o1 ? o1 : o0) + (cx.pix0 + cx.q0 + 32 * j) * (long)ncol + oc;
+        // pixel stride / channel base of the output: NHWC, or channel-chunked [C/ch][pixels][ch] (whole 64-byte runs per
+        // pixel for a consumer that walks the channels chunk by chunk: the first-layer kernel)
+        const int ch = a.out_chunk;
+        const int ostr = ch > 0 ? ch : ncol;
+        const long obase = ch > 0 ? (long)(oc / ch) * cx.total_pix * ch + (oc % ch) : (long)oc;
+        float* __restrict__ ob = (o1 ? o1 : o0) + (cx.pix0 + cx.q0 + 32 * j) * (long)ostr + obase;
         int p0t = 0;
         if (mx && !ALIGNED && TAPS == 9) {
             const unsigned q0t = (unsigned)(cx.q0 - 4 * (cx.lane >> 5) + 32 * j);
@@ -222,7 +228,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
             const int dq = (e & 3) + 8 * (e >> 2);
             if (!ALIGNED && cx.pix0 + cx.q0 + 32 * j + dq >= cx.total_pix) continue;
             const float rel = r.xv[e] * accj[e];
-            ob[dq * ncol] = rel;
+            ob[dq * ostr] = rel;
             if (mx) {
                 const bool past = !ALIGNED && TAPS == 9 && p0t + dq >= (int)P;
                 mx->m0 = fmaxf(mx->m0, past ? 0.f : fabsf(rel));

@@ -30,7 +30,7 @@ __global__ void pack_first_layer_kernel(const float* __restrict__ w, float* __re
 __global__ __launch_bounds__(256) void first_layer_rel_kernel(const float* __restrict__ S, const float* __restrict__ w6,
                                                               const float* __restrict__ X8,
                                                               const int* __restrict__ map2img, float* __restrict__ out,
-                                                              int cin, int plain) {
+                                                              int cin, int plain, long chunk_stride) {
     constexpr int HW = 224;
     __shared__ __attribute__((aligned(16))) float lds[FL_HP * FL_WP * FL_STRIDE];
     const int n = blockIdx.z, ty0 = blockIdx.y * FL_TH, tx0 = blockIdx.x * FL_TW;
@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void first_layer_rel_kernel(const float* __res
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gy >= 0 && gy < HW && gx >= 0 && gx < HW)
-                v = *reinterpret_cast<const f32x4*>(Sn + ((long)gy * HW + gx) * cin + chunk * FL_KC + seg * 4);
+                v = chunk_stride   // channel-chunked S [cin/16][n_maps*HW*HW][16]: contiguous 64-byte runs per pixel
+                        ? *reinterpret_cast<const f32x4*>(S + chunk * chunk_stride + (((long)n * HW + gy) * HW + gx) * FL_KC + seg * 4)
+                        : *reinterpret_cast<const f32x4*>(Sn + ((long)gy * HW + gx) * cin + chunk * FL_KC + seg * 4);
             *reinterpret_cast<f32x4*>(lds + p * FL_STRIDE + seg * 4) = v;
         }
         __syncthreads();
@@ -88,9 +90,10 @@ int first_layer_pack(const float* w, float* w6, int cout, int plain, hipStream_t
 }
 
 int first_layer_relevance(const float* S, const float* w6, const float* X8, const int* map2img, float* out, int n_maps,
-                          int cin, int plain, hipStream_t s) {
+                          int cin, int plain, int s_chunked, hipStream_t s) {
+    const long chunk_stride = s_chunked ? (long)n_maps * 224 * 224 * FL_KC : 0;
     hipLaunchKernelGGL(first_layer_rel_kernel, dim3(224 / FL_TW, 224 / FL_TH, n_maps), dim3(256), 0, s, S, w6, X8,
-                       map2img, out, cin, plain);
+                       map2img, out, cin, plain, chunk_stride);
     return check_launch("first_layer_relevance");
 }
 

@@ -24,6 +24,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     a.bias = d->bias; a.X = d->x; a.U = d->u; a.Zdiv = d->zdiv; a.map2img = d->map2img;
     a.out0 = d->out0; a.out1 = d->out1;
     a.in_amax = d->in_amax; a.out1_amax = d->out1_amax; a.pool_am = d->pool_am; a.out0_amax = d->out0_amax;
+    a.out_chunk = d->epi == EPI_REL_MUL ? d->out_chunk : 0;
     a.ksplit = 1;
     // few rows (the decoder's lock-step rules): 32-row tiles, whole K per workgroup (dense_small.hip)
     if (d->taps == 1 && !d->bf16x6 && !d->f16x3 && dense_small_fits(a)) {
@@ -152,7 +153,7 @@ static inline int cin_pad(int l) { return l == 0 ? 8 : kVgg[l].cin; }   // image
 
 int first_layer_pack(const float* w, float* w6, int cout, int plain, hipStream_t s);
 int first_layer_relevance(const float* S, const float* w6, const float* X8, const int* map2img, float* out, int n_maps,
-                          int cin, int plain, hipStream_t s);
+                          int cin, int plain, int s_chunked, hipStream_t s);
 int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, hipStream_t s);
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
                        int c, hipStream_t s);
@@ -441,7 +442,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
         if (l == 0) {
             // 3 output channels: direct VALU conv (first_layer.hip) instead of a 32-wide MFMA tile
             LRPX_TRY(first_layer_relevance(S[cur], pk + p.first6, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 0,
-                                           (hipStream_t)stream));
+                                           h3 ? 1 : 0, (hipStream_t)stream));
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
@@ -455,6 +456,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
             d.out1 = S[cur ^ 1];
             if (h3) { d.x = tr + t.xz[l]; d.out1_amax = amax + (size_t)(l - 1) * n_maps; }   // x / safe(Z+) precomputed
+            if (h3 && l == 1) d.out_chunk = 16;   // the first-layer kernel walks S in 16-channel chunks: whole 64-byte runs
             else { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
             LRPX_TIMED_DISPATCH(l, &d);
         } else {
@@ -520,7 +522,7 @@ int lrpx_vgg16_guided_backprop(const void* packed, const void* trace, int n_img,
         const VggLayer& L = kVgg[l];
         if (!L.conv) continue;
         if (l == 0) {
-            LRPX_TRY(first_layer_relevance(G[cur], pk + p.first6p, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 1, st));
+            LRPX_TRY(first_layer_relevance(G[cur], pk + p.first6p, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 1, 0, st));
             break;
         }
         lrpx_conv_desc d = {};
