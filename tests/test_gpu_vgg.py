@@ -374,6 +374,39 @@ def test_vgg_relevance_conservation(ops, gridtd_case):
         assert abs(maps[i].double().sum().item() / r_feat[i].double().sum().item() - 1) < 2e-3
 
 
+def test_full_size_chain_properties(ops):
+    """BASELINE config 2 size (16 images x 20 words = 320 maps), size-independent properties of the CNN relevance chain:
+    (1) conservation: sum(R_img) == sum(target) per map for a positive target on active features (SURVEY §8c);
+    (2) the default chain (f16x3 kernels, Pool2d rule fused into the conv under the pool, per-map operand scales
+        spanning 1e-3..1e3) agrees per map within 1e-4 with the bf16x6 chain + separate pool kernels on the SAME trace;
+    (3) determinism: two runs are bit-identical (per-map maxima are atomicMax, order independent)."""
+    from lrp_amd import _lib, weights
+    lib = _lib.load()
+    sd = weights.make_gridtd_state(seed=5, vocab_size=32)
+    vgg = _vgg(ops, sd)
+    n_img, n_maps = 16, 320
+    img = torch.from_numpy(weights.make_images(7, n_img)).cuda()
+    feats = vgg.forward(img)
+    m2i = (torch.arange(n_maps, device="cuda") * n_img // n_maps).to(torch.int32)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    r_feat = (torch.rand(n_maps, 196, 512, device="cuda", generator=g) + 0.1) * (feats[m2i.long()] > 0)
+    r_feat = r_feat * torch.logspace(-3, 3, n_maps, device="cuda").view(-1, 1, 1)
+    prev = lib.lrpx_set_conv_mode(2)
+    try:
+        maps = vgg.relevance(r_feat, m2i).clone()
+        again = vgg.relevance(r_feat, m2i).clone()
+        lib.lrpx_set_conv_mode(1)
+        maps_x6 = vgg.relevance(r_feat, m2i).clone()
+    finally:
+        lib.lrpx_set_conv_mode(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(maps, again)
+    tot = maps.double().sum(dim=(1, 2, 3)) / r_feat.double().sum(dim=(1, 2))
+    assert (tot - 1).abs().max().item() < 2e-3
+    err = (maps.double() - maps_x6.double()).abs().amax(dim=(1, 2, 3)) / maps_x6.double().abs().amax(dim=(1, 2, 3))
+    assert err.max().item() < TOL, err.max().item()
+
+
 def test_errors_raise_like_the_reference(ops):
     z = torch.zeros(1, 8, device="cuda")
     with pytest.raises(AssertionError):          # lrp_wrapper.py:81 `assert sample.grad.sum()!=0`
