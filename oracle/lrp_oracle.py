@@ -150,6 +150,36 @@ def vgg_guided_backprop(sd, saved, g_feat, prefix="img_encoder.encoder."):
     return g
 
 
+def vgg_gradient(sd, saved, g_feat, prefix="img_encoder.encoder."):
+    """models/gridTDmodel.py:1507-1521 `ExplainGridTDGradient.explain_cnn`: the plain autograd gradient of the encoder
+    output w.r.t. the image (`image_feature.backward(d_img_feature)`): g_in = g_out * [relu_out > 0] at every ReLU,
+    arg-max routing through the pools."""
+    layers = vgg_layers()
+    g = g_feat
+    for li in range(len(layers) - 1, -1, -1):
+        kind, idx, cin, cout = layers[li]
+        x = saved[li]
+        if kind == 'conv':
+            w, b = sd[f"{prefix}{idx}.weight"], sd[f"{prefix}{idx}.bias"]
+            y = F.relu(F.conv2d(x, w, b, padding=1))
+            g = g * (y > 0).to(g.dtype)
+            g = F.conv_transpose2d(g, w, padding=1)
+        else:
+            z, pidx = F.max_pool2d(x, 2, 2, return_indices=True)
+            if pidx.shape[0] != g.shape[0]:
+                pidx = pidx.expand(g.shape[0], -1, -1, -1)
+            g = F.max_unpool2d(g, pidx, 2, 2, output_size=x.shape[-2:])
+    return g
+
+
+def grad_cam(features, grads):
+    """models/gridTDmodel.py:1760-1771 `ExplainGridTDGradCam.grad_cam`: features, grads (1,C,h,w) ->
+    relu(sum_c features_c * mean_hw(grads_c)) / (max|.| + 1e-6), flattened to (h*w,)."""
+    weights = grads.mean(dim=(2, 3), keepdim=True)
+    cam = (features * weights).sum(dim=(0, 1)).clamp(min=0)
+    return (cam / (cam.abs().max() + 1e-6)).reshape(-1)
+
+
 # ----------------------------------------------------------------------------------------------
 # gridTD decoder (adaptive attention + two LSTMs)
 # ----------------------------------------------------------------------------------------------
@@ -373,11 +403,13 @@ def gridtd_grad_trace(sd, features, avg, caption):
     return tr
 
 
-def gridtd_guided_wordt(sd, tr, t):
+def gridtd_guided_wordt(sd, tr, t, mask_features=True):
     """models/gridTDmodel.py:1588-1675 `ExplainiGridTDGuidedGradient.explain_caption_wordt`: hand-written BPTT with
     alpha / beta treated as constants.  Quirks kept: `d_h1[i]` from the AdaLSTM recurrence is overwritten by
     :1646 (no h1 recurrence), the sentinel gate's own inputs get no gradient, and the two projector 'ReLU gates'
     test `< 0` on post-ReLU tensors (:1663, :1665), i.e. never fire; only `features <= 0` (:1674) does.
+    mask_features=False gives the parent class's `ExplainGridTDGradient.explain_caption_wordt` (:1424-1505): the same
+    BPTT (same quirks) without any of the three gates.
     Returns (d_feat (P,C), r_words (t+1,))."""
     Hd = tr["h1"].shape[1]
     P = tr["P"]
@@ -426,7 +458,8 @@ def gridtd_guided_wordt(sd, tr, t):
     d_avg = d_glob @ sd["global_img_feature_proj.weight"]
     w_proj = sd["img_projector.weight"].reshape(Hd, -1)
     d_feat = d_avg.unsqueeze(0) / P + d_proj @ w_proj
-    d_feat = d_feat * (tr["F_pix"] > 0).float()          # :1674
+    if mask_features:
+        d_feat = d_feat * (tr["F_pix"] > 0).float()      # :1674
     r_words = d_emb.sum(-1)
     m = r_words.abs().max()
     if m > 0:
@@ -445,6 +478,23 @@ def gridtd_guided_explain_caption(sd, img, caption, words=None, return_feat=Fals
         d_feat = pix_to_nchw(d_feat, feats.shape[-2:])
         dfs.append(d_feat)
         maps.append(vgg_guided_backprop(sd, saved, d_feat))
+        rws.append(r_words)
+    if return_feat:
+        return maps, rws, dfs, tr
+    return maps, rws
+
+
+def gridtd_gradient_explain_caption(sd, img, caption, words=None, return_feat=False, cam=False):
+    """`ExplainGridTDGradient.explain_caption` (:1523-1537): plain decoder gradient + autograd through the encoder;
+    cam=True: `ExplainGridTDGradCam` (:1752-1771), the per-word result is the (1, h*w) Grad-CAM heat map instead."""
+    feats, avg, saved = vgg_forward(sd, img)
+    tr = gridtd_grad_trace(sd, feats[0], avg[0], caption)
+    maps, rws, dfs = [], [], []
+    for t in (range(tr["T"]) if words is None else words):
+        d_feat, r_words = gridtd_guided_wordt(sd, tr, t, mask_features=False)
+        d_feat = pix_to_nchw(d_feat, feats.shape[-2:])
+        dfs.append(d_feat)
+        maps.append(grad_cam(feats, d_feat).unsqueeze(0) if cam else vgg_gradient(sd, saved, d_feat))
         rws.append(r_words)
     if return_feat:
         return maps, rws, dfs, tr

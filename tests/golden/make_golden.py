@@ -314,6 +314,61 @@ def gen_guided(out, weights, T=3, V=9586, seed=0):
     print("guided_T3.npz written; map absmax:", [float(m.abs().max()) for m in maps])
 
 
+def _gen_grad_family(cls_name, out, weights, T, V, seed):
+    """Shared driver for the gradient-family explainers that build their own model from args.weight."""
+    import models.gridTDmodel as gtd
+    sd = weights.make_gridtd_state(seed=seed, vocab_size=V)
+    wm = weights.make_word_map(V)
+    img = weights.make_images(seed, 1)
+    cap = weights.make_captions(seed + 1, 1, T, V)[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        args = make_args(tmp)
+        real_load = torch.load
+        torch.load = lambda *a, **k: {"state_dict": to_torch_sd(sd)}
+        try:
+            ex = getattr(gtd, cls_name)(args, wm)
+        finally:
+            torch.load = real_load
+        _patch_explainer(ex, img, cap)
+        feats = []
+        orig = ex.explain_caption_wordt
+
+        def wrapped(t):
+            rf, rw = orig(t)
+            feats.append(rf.clone())
+            return rf, rw
+        ex.explain_caption_wordt = wrapped
+        maps, rws = ex.explain_caption("synthetic.jpg")
+    return cap, feats, maps, rws
+
+
+def gen_gradient(out, weights, T=3, V=9586, seed=0):
+    """ExplainGridTDGradient (models/gridTDmodel.py:1214-1539): plain-gradient maps (autograd through the encoder,
+    :1507-1521) + the hand-written decoder BPTT (:1424-1505) + word scores."""
+    cap, feats, maps, rws = _gen_grad_family("ExplainGridTDGradient", out, weights, T, V, seed)
+    g = dict(seed=np.int64(seed), V=np.int64(V), caption=cap)
+    for t in range(T):
+        g[f"d_feat_{t}"] = feats[t].detach().numpy()
+        g[f"r_words_{t}"] = rws[t].detach().numpy()
+        g[f"map_stats_{t}"] = stats(maps[t])
+        g[f"map_sub4_{t}"] = sub4(maps[t]).numpy()
+    g[f"map_full_{T - 1}"] = maps[T - 1].numpy()
+    np.savez(os.path.join(out, "gradient_T3.npz"), **g)
+    print("gradient_T3.npz written; map absmax:", [float(m.abs().max()) for m in maps])
+
+
+def gen_gradcam(out, weights, T=3, V=9586, seed=0):
+    """ExplainGridTDGradCam (models/gridTDmodel.py:1752-1771): per word the (1,196) Grad-CAM heat map
+    relu(sum_c features_c * mean_hw(grad_c)) / (max + 1e-6) of the plain decoder gradient."""
+    cap, feats, maps, rws = _gen_grad_family("ExplainGridTDGradCam", out, weights, T, V, seed)
+    g = dict(seed=np.int64(seed), V=np.int64(V), caption=cap)
+    for t in range(T):
+        g[f"cam_{t}"] = maps[t].detach().numpy()
+        g[f"r_words_{t}"] = rws[t].detach().numpy()
+    np.savez(os.path.join(out, "gradcam_T3.npz"), **g)
+    print("gradcam_T3.npz written; cam shapes:", [tuple(m.shape) for m in maps], "max:", [float(m.max()) for m in maps])
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -332,7 +387,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -352,6 +407,10 @@ def main():
         gen_greedy(HERE, weights)
     if "guided" in todo:
         gen_guided(HERE, weights)
+    if "gradient" in todo:
+        gen_gradient(HERE, weights)
+    if "gradcam" in todo:
+        gen_gradcam(HERE, weights)
 
 
 if __name__ == "__main__":

@@ -112,3 +112,32 @@ def test_guided_backprop_vs_reference():
         scale = g[f"map_stats_{t}"][1]
         assert np.abs(maps[t][..., ::4, ::4].numpy() - g[f"map_sub4_{t}"]).max() / scale < TOL_REL
     assert rel_err(maps[2], g["map_full_2"]) < TOL_REL
+
+
+def test_plain_gradient_vs_reference():
+    # ExplainGridTDGradient (models/gridTDmodel.py:1214-1539): decoder BPTT without the guided gates + autograd
+    # gradient through VGG16
+    g = np.load(os.path.join(GOLDEN, "gradient_T3.npz"))
+    sd = O.state_to_torch(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=int(g["V"])))
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    maps, rws, dfs, tr = O.gridtd_gradient_explain_caption(sd, img, g["caption"], return_feat=True)
+    for t in range(3):
+        assert rel_err(dfs[t], g[f"d_feat_{t}"]) < TOL_REL
+        assert np.abs(rws[t].numpy() - g[f"r_words_{t}"]).max() < TOL_WORDS
+        scale = g[f"map_stats_{t}"][1]
+        assert np.abs(maps[t][..., ::4, ::4].numpy() - g[f"map_sub4_{t}"]).max() / scale < TOL_REL
+    assert rel_err(maps[2], g["map_full_2"]) < TOL_REL
+
+
+def test_grad_cam_vs_reference():
+    # ExplainGridTDGradCam (models/gridTDmodel.py:1752-1771): (1,196) heat map per word, in [0,1]; word 1 of the
+    # fixture is the all-negative case (clamp -> all zeros)
+    g = np.load(os.path.join(GOLDEN, "gradcam_T3.npz"))
+    sd = O.state_to_torch(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=int(g["V"])))
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    cams, rws = O.gridtd_gradient_explain_caption(sd, img, g["caption"], cam=True)
+    for t in range(3):
+        assert tuple(cams[t].shape) == tuple(g[f"cam_{t}"].shape) == (1, 196)
+        assert np.abs(cams[t].numpy() - g[f"cam_{t}"]).max() < 1e-4
+        assert np.abs(rws[t].numpy() - g[f"r_words_{t}"]).max() < TOL_WORDS
+    assert g["cam_1"].max() == 0.0 and cams[1].max().item() == 0.0
