@@ -303,6 +303,14 @@ int lrpx_positive_mask(const float* x, float* y, long n, void* stream);   /* y =
  * ReLU rule clamp(g,min=0)*[relu_out>0] at every ReLU.  Same trace / workspace as lrpx_vgg16_relevance. */
 int lrpx_vgg16_guided_backprop(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
                                const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream);
+/* ExplainGridTDGradient.explain_cnn (models/gridTDmodel.py:1507-1521): the plain autograd gradient of the encoder
+ * output w.r.t. the image, `image_feature.backward(d_img_feature)`; same arguments as the guided variant. */
+int lrpx_vgg16_gradient(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                        const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream);
+/* ExplainGridTDGradCam.grad_cam (models/gridTDmodel.py:1760-1771): feats (n_img,P,C) NHWC, grads (rows,P,C) ->
+ * cam (rows,P) = relu(sum_c feats_c * mean_p grads_c) / (max + 1e-6); P <= 256. */
+int lrpx_gradcam(const float* feats, const float* grads, const int32_t* map2img, float* cam, int rows, int P, int C,
+                 void* stream);
 
 #ifdef __cplusplus
 }

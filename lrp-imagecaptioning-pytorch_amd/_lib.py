@@ -105,6 +105,8 @@ SIGNATURES = {
     "lrpx_scale": (_i, [_f, _f, _l, C.c_float, _f]),
     "lrpx_positive_mask": (_i, [_f, _f, _l, _f]),
     "lrpx_vgg16_guided_backprop": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, _f]),
+    "lrpx_vgg16_gradient": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, _f]),
+    "lrpx_gradcam": (_i, [_f, _f, _f, _f, _i, _i, _i, _f]),
     "lrpx_set_bf16x6": (_i, [_i]),
     "lrpx_set_conv_mode": (_i, [_i]),
     "lrpx_set_forward_f16": (_i, [_i]),

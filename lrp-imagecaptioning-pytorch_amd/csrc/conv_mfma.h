@@ -29,7 +29,7 @@ enum Epilogue : int {
     EPI_REL = 1,        // r = X * (acc + U);  out0 = r;  out1 = r / stab(Zdiv)
     EPI_FIRST = 2,      // first VGG layer: r = X+ * acc[c] + X- * acc[c+3]  -> NCHW out0 (X stored split x+|x-)
     EPI_PLAIN = 3,      // out0 = acc (+ bias) (optionally relu)
-    EPI_GUIDED = 4,     // guided backprop: out0 = max(acc,0) * [Y > 0]
+    EPI_GUIDED = 4,     // guided backprop: out0 = max(acc,0) * [Y > 0]   (relu == 2: plain gradient, out0 = acc * [Y > 0])
     EPI_REL_MUL = 5,    // r = X * acc -> out0 and/or out1 (max|r| per map -> out1_amax).  The relevance rule with its
                         // following division folded into the multiplicand: X = x for R, X = x / safe(Z_below) for S_next
 };
@@ -307,7 +307,8 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
             }
         } else {   // EPI_GUIDED: ReLU hook of the layer below, out = max(g,0) * [y > 0]
             static_assert(EPI == EPI_FWD_DUAL || EPI == EPI_REL || EPI == EPI_FIRST || EPI == EPI_PLAIN || EPI == EPI_GUIDED || EPI == EPI_REL_MUL, "unknown epilogue");
-            if (oc < ncol) o0[gp * ncol + oc] = (r.xv[e] > 0.f && v > 0.f) ? v : 0.f;
+            // a.relu == 2: plain autograd ReLU backward (mask only), else the guided rule (mask and clamp)
+            if (oc < ncol) o0[gp * ncol + oc] = (r.xv[e] > 0.f && (a.relu == 2 || v > 0.f)) ? v : 0.f;
         }
     }
 }

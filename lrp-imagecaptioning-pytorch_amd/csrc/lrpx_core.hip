@@ -418,9 +418,39 @@ __global__ void cumsum_maps_kernel(const float* __restrict__ in, float* __restri
     }
 }
 
+// Grad-CAM (models/gridTDmodel.py:1760-1771): cam[p] = relu(sum_c F[img][p][c] * mean_p'(G[row][p'][c])) / (max + 1e-6).
+// One workgroup per (image, word) row; P <= 256 pixels, any C (multiple of 4).
+__global__ __launch_bounds__(256) void gradcam_kernel(const float* __restrict__ feats, const float* __restrict__ grads,
+                                                      const int* __restrict__ map2img, float* __restrict__ cam, int P,
+                                                      int C) {
+    extern __shared__ float wsh[];            // [C] channel weights, then [4] wave maxima
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const long img = map2img ? map2img[row] : row;
+    const float* G = grads + (long)row * P * C;
+    for (int c = tid; c < C; c += 256) {
+        float s_ = 0.f;
+        for (int p = 0; p < P; ++p) s_ += G[(long)p * C + c];
+        wsh[c] = s_ / (float)P;
+    }
+    __syncthreads();
+    float v = 0.f;
+    if (tid < P) {
+        const float* Fp = feats + (img * P + tid) * C;
+        for (int c = 0; c < C; ++c) v += Fp[c] * wsh[c];
+        v = v > 0.f ? v : 0.f;
+    }
+    float m = wave_max(v);
+    if ((tid & 63) == 0) wsh[C + (tid >> 6)] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wsh[C], wsh[C + 1]), fmaxf(wsh[C + 2], wsh[C + 3]));
+    if (tid < P) cam[(long)row * P + tid] = v / (m + 1e-6f);
+}
+
 // top ReLU hook of the guided pass: out = max(g,0) * [y > 0]   (models/gridTDmodel.py:1680-1686)
+// plain != 0: the autograd ReLU backward only (g * [y > 0]; ExplainGridTDGradient.explain_cnn, :1507-1521)
 __global__ void guided_gate_kernel(const float* __restrict__ g, const float* __restrict__ y,
-                                   const int* __restrict__ map2img, float* __restrict__ out, long per4, long total) {
+                                   const int* __restrict__ map2img, float* __restrict__ out, long per4, long total,
+                                   int plain) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 units over n_maps*per4
     if (idx >= total) return;
     long n = idx / per4, i = idx - n * per4;
@@ -429,7 +459,7 @@ __global__ void guided_gate_kernel(const float* __restrict__ g, const float* __r
     f32x4 yv = reinterpret_cast<const f32x4*>(y)[img * per4 + i];
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (yv[e] > 0.f && gv[e] > 0.f) ? gv[e] : 0.f;
+    for (int e = 0; e < 4; ++e) o[e] = (yv[e] > 0.f && (plain || gv[e] > 0.f)) ? gv[e] : 0.f;
     reinterpret_cast<f32x4*>(out)[idx] = o;
 }
 
@@ -437,7 +467,7 @@ __global__ void guided_gate_kernel(const float* __restrict__ g, const float* __r
 // below: out = [this pixel is the window's arg-max and a > 0] * max(g, 0)
 __global__ void maxpool_guided_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g_out,
                                           const int* __restrict__ map2img, float* __restrict__ g_in, int ho, int wo,
-                                          int c4, long total) {
+                                          int c4, long total, int plain) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n_maps*(2ho)*(2wo)*c4
     if (idx >= total) return;
     int cc = idx % c4;
@@ -460,7 +490,7 @@ __global__ void maxpool_guided_bwd_kernel(const float* __restrict__ x, const flo
         if (w4[1][e] > m) { m = w4[1][e]; am = 1; }
         if (w4[2][e] > m) { m = w4[2][e]; am = 2; }
         if (w4[3][e] > m) { m = w4[3][e]; am = 3; }
-        o[e] = (am == pos && m > 0.f && go[e] > 0.f) ? go[e] : 0.f;
+        o[e] = (am == pos && m > 0.f && (plain || go[e] > 0.f)) ? go[e] : 0.f;
     }
     reinterpret_cast<f32x4*>(g_in)[idx] = o;
 }
@@ -675,20 +705,30 @@ int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long
 
 extern "C++" {
 namespace lrpx {
-int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, hipStream_t s) {
+int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, int plain,
+                hipStream_t s) {
     long total = (long)n_maps * (per / 4);
-    hipLaunchKernelGGL(guided_gate_kernel, dim3(grid_for(total)), dim3(256), 0, s, g, y, map2img, out, per / 4, total);
+    hipLaunchKernelGGL(guided_gate_kernel, dim3(grid_for(total)), dim3(256), 0, s, g, y, map2img, out, per / 4, total,
+                       plain);
     return check_launch("guided_gate");
 }
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
-                       int c, hipStream_t s) {
+                       int c, int plain, hipStream_t s) {
     long total = (long)n_maps * (2 * ho) * (2 * wo) * (c / 4);
     hipLaunchKernelGGL(maxpool_guided_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, g_out, map2img, g_in, ho,
-                       wo, c / 4, total);
+                       wo, c / 4, total, plain);
     return check_launch("maxpool_guided_bwd");
 }
 }  // namespace lrpx
 }  // extern "C++"
+
+int lrpx_gradcam(const float* feats, const float* grads, const int32_t* map2img, float* cam, int rows, int P, int C,
+                 void* stream) {
+    LRPX_REQUIRE(feats && grads && cam && rows > 0 && P > 0 && P <= 256 && C > 0, "gradcam: bad arguments (P <= 256)");
+    hipLaunchKernelGGL(gradcam_kernel, dim3(rows), dim3(256), (C + 4) * sizeof(float), (hipStream_t)stream, feats, grads,
+                       map2img, cam, P, C);
+    return check_launch("gradcam");
+}
 
 int lrpx_accumulate(float* dst, const float* src, long n, void* stream) {
     LRPX_REQUIRE(dst && src && n > 0 && n % 4 == 0, "accumulate: bad arguments");

@@ -154,9 +154,10 @@ static inline int cin_pad(int l) { return l == 0 ? 8 : kVgg[l].cin; }   // image
 int first_layer_pack(const float* w, float* w6, int cout, int plain, hipStream_t s);
 int first_layer_relevance(const float* S, const float* w6, const float* X8, const int* map2img, float* out, int n_maps,
                           int cin, int plain, int s_chunked, hipStream_t s);
-int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, hipStream_t s);
+int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, int plain,
+                hipStream_t s);
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
-                       int c, hipStream_t s);
+                       int c, int plain, hipStream_t s);
 
 // matrix-core mode of the fused chains (lrpx_set_conv_mode): 0 fp32 MFMA, 1 bf16x6 (conv_bf16x6.h), 2 = bf16x6 forward
 // trace + f16x3 relevance pass (conv_f16x3.h)
@@ -501,8 +502,11 @@ int lrpx_vgg16_layer_timing(int enable, float* ms17) {
     return LRPX_OK;
 }
 
-int lrpx_vgg16_guided_backprop(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
-                               const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream) {
+}  // extern "C"
+
+// guided backprop (plain = 0) or the plain autograd gradient (plain = 1) of the encoder output w.r.t. the image
+static int vgg16_backprop(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                          const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, int plain, void* stream) {
     LRPX_REQUIRE(packed && trace && d_feat_nhwc && workspace && out_nchw && n_maps > 0 && n_img > 0,
                  "vgg16_guided_backprop: bad arguments");
     LRPX_REQUIRE(map2img || n_maps == n_img, "vgg16_guided_backprop: map2img is required when n_maps != n_img");
@@ -517,7 +521,7 @@ int lrpx_vgg16_guided_backprop(const void* packed, const void* trace, int n_img,
     hipStream_t st = (hipStream_t)stream;
     int cur = 0;
     // hook of the last ReLU (the encoder ends with one): clamp(d,0) * [features > 0]
-    LRPX_TRY(guided_gate(d_feat_nhwc, tr + t.act[kNL], map2img, G[cur], n_maps, (long)196 * 512, st));
+    LRPX_TRY(guided_gate(d_feat_nhwc, tr + t.act[kNL], map2img, G[cur], n_maps, (long)196 * 512, plain, st));
     for (int l = kNL - 1; l >= 0; --l) {
         const VggLayer& L = kVgg[l];
         if (!L.conv) continue;
@@ -531,15 +535,28 @@ int lrpx_vgg16_guided_backprop(const void* packed, const void* trace, int n_img,
         d.n_oc = L.cin; d.oc_split = L.cin;
         if (kVgg[l - 1].conv) {
             d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];      // ReLU hook of conv l-1 fused
+            d.relu = plain ? 2 : 0;
             LRPX_TRY(conv_dispatch(&d, st));
         } else {
             d.epi = EPI_PLAIN; d.out0 = R;
             LRPX_TRY(conv_dispatch(&d, st));
-            LRPX_TRY(maxpool_guided_bwd(tr + t.act[l - 1], R, map2img, G[cur ^ 1], n_maps, L.hw, L.hw, L.cin, st));
+            LRPX_TRY(maxpool_guided_bwd(tr + t.act[l - 1], R, map2img, G[cur ^ 1], n_maps, L.hw, L.hw, L.cin, plain, st));
         }
         cur ^= 1;
     }
     return LRPX_OK;
+}
+
+extern "C" {
+
+int lrpx_vgg16_guided_backprop(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                               const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream) {
+    return vgg16_backprop(packed, trace, n_img, d_feat_nhwc, map2img, n_maps, workspace, out_nchw, 0, stream);
+}
+
+int lrpx_vgg16_gradient(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                        const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream) {
+    return vgg16_backprop(packed, trace, n_img, d_feat_nhwc, map2img, n_maps, workspace, out_nchw, 1, stream);
 }
 
 }  // extern "C"

@@ -281,7 +281,7 @@ class GridTDEngine:
         graph.replay()
         return out
 
-    def guided_gradient(self, enc, tr, lens=None):
+    def guided_gradient(self, enc, tr, lens=None, mask_features=True):
         """ExplainiGridTDGuidedGradient.explain_caption_wordt (gridTDmodel.py:1588-1675) for every (image, word)
         row: decoder BPTT with alpha/beta constant.  `tr` must be a grad=True trace.
         Returns d_feat (B*T, P, C), r_words (B*T, T), row2img."""
@@ -314,8 +314,11 @@ class GridTDEngine:
         check(lib.lrpx_scale(ptr(d_avg), ptr(U), d_avg.numel(), 1.0 / P, st))                    # :1667
         a_proj = e(rows, P, H)
         check(lib.lrpx_spread_pixels(ptr(gs["wacc"]), ptr(tr["alpha"]), ptr(lens), ptr(a_proj), B, T, H, P, st))
-        mask = e(B, P, Cc)
-        check(lib.lrpx_positive_mask(ptr(enc["feats"]), ptr(mask), mask.numel(), st))             # :1674
+        if mask_features:
+            mask = e(B, P, Cc)
+            check(lib.lrpx_positive_mask(ptr(enc["feats"]), ptr(mask), mask.numel(), st))         # :1674
+        else:   # ExplainGridTDGradient.explain_caption_wordt (:1424-1505): same BPTT, no `features <= 0` gate
+            mask = torch.ones(B, P, Cc, device=self.device, dtype=torch.float32)
         d_feat = e(rows, P, Cc)
         ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=mask, u=U,
                       map2img=row2img, out0=d_feat)                                              # :1668, :1674
@@ -336,6 +339,33 @@ class GridTDEngine:
         if return_features:
             out = out + (d_feat.view(B, T, self.P, self.C), tr, enc)
         return out
+
+    def explain_batch_gradient(self, images, captions, lens=None, cam=False, return_features=False):
+        """Batched `ExplainGridTDGradient.explain_caption` (models/gridTDmodel.py:1214-1539): plain
+        decoder gradient + autograd gradient through the encoder -> maps (B,T,3,224,224), word scores (B,T,T).
+        cam=True: `ExplainGridTDGradCam` (:1752-1771) - the per-word result is the Grad-CAM heat map (B,T,196)."""
+        images = images.to(self.device, torch.float32).contiguous()
+        captions = captions.to(self.device, torch.int64).contiguous()
+        B, T = captions.shape[0], captions.shape[1] - 1
+        enc = self.encode(images)
+        tr = self.trace(enc, captions, predictions=False, grad=True)
+        d_feat, r_words, row2img = self.guided_gradient(enc, tr, lens, mask_features=False)
+        if cam:
+            maps = self.grad_cam(enc, d_feat, row2img).view(B, T, self.P)
+        else:
+            maps = self.vgg.gradient(d_feat, row2img).view(B, T, 3, 224, 224)
+        out = (maps, r_words.view(B, T, T))
+        if return_features:
+            out = out + (d_feat.view(B, T, self.P, self.C), tr, enc)
+        return out
+
+    def grad_cam(self, enc, d_feat, row2img):
+        """`grad_cam` (models/gridTDmodel.py:1760-1771) for every (image, word) row: (rows,P,C) gradients -> (rows,P)."""
+        rows = d_feat.shape[0]
+        cam = torch.empty(rows, self.P, device=self.device, dtype=torch.float32)
+        check(_lib.load().lrpx_gradcam(ptr(enc["feats"]), ptr(d_feat.contiguous()), ptr(row2img), ptr(cam), rows, self.P,
+                                       self.C, stream_ptr()))
+        return cam
 
     def explain_batch(self, images, captions, lens=None, accumulate=False, return_features=False):
         """Batched `explain_caption` (gridTDmodel.py:1141-1156): images (B,3,224,224), captions (B,T+1) int64.
@@ -539,3 +569,53 @@ class ExplainiGridTDGuidedGradient(ExplainGridTDAttention):
         maps = self.engine.vgg.guided_backprop(d_feat, row2img)
         return ([maps[t:t + 1] for t in range(self.caption_length)],
                 [r_words[t, :t + 1] for t in range(self.caption_length)])
+
+
+class ExplainGridTDGradient(ExplainiGridTDGuidedGradient):
+    """Drop-in for the reference's `ExplainGridTDGradient` (models/gridTDmodel.py:1214-1539): plain gradient - the same
+    hand-written decoder BPTT as the guided explainer without its three gates, and the autograd gradient through the
+    encoder (`explain_cnn`, :1507-1521).  (In the reference the guided class derives from this one; here the
+    inheritance runs the other way, the surface is the same.)"""
+    EX_TYPE = 'gradient'
+
+    def _relevance(self):
+        if self._rel is None:
+            self._rel = self.engine.guided_gradient(self._enc, self._tr, mask_features=False)
+        return self._rel
+
+    def explain_cnn(self, d_img_feature):
+        t_nhwc = ops.nchw_to_nhwc(d_img_feature.to(torch.float32))
+        return self.engine.vgg.gradient(t_nhwc, torch.zeros(d_img_feature.shape[0], dtype=torch.int32,
+                                                            device=self.engine.device))
+
+    def explain_caption(self, img_filepath, t_list=None, caption_encode=None):
+        self.img_filepath = img_filepath
+        self.get_hidden_parameters(img_filepath, caption_encode)
+        d_feat, r_words, row2img = self._relevance()
+        maps = self._maps(d_feat, row2img)
+        return ([maps[t:t + 1] for t in range(self.caption_length)],
+                [r_words[t, :t + 1] for t in range(self.caption_length)])
+
+    def _maps(self, d_feat, row2img):
+        return self.engine.vgg.gradient(d_feat, row2img)
+
+
+class ExplainGridTDGradCam(ExplainGridTDGradient):
+    """Drop-in for `ExplainGridTDGradCam` (models/gridTDmodel.py:1752-1771): `explain_caption` returns per word the
+    (1, 196) Grad-CAM heat map of the plain decoder gradient."""
+    EX_TYPE = 'GradCam'
+
+    def grad_cam(self, img_feature, grads):
+        """(1,C,h,w) features and gradients -> (h*w,) heat map, as the reference's method of the same name."""
+        f = ops.nchw_to_nhwc(img_feature.to(torch.float32))
+        g = ops.nchw_to_nhwc(grads.to(torch.float32))
+        P, Cc = f.shape[1], f.shape[2]
+        cam = torch.empty(1, P, device=self.engine.device, dtype=torch.float32)
+        check(_lib.load().lrpx_gradcam(ptr(f), ptr(g), ptr(None), ptr(cam), 1, P, Cc, stream_ptr()))
+        return cam.view(-1)
+
+    def explain_cnn(self, d_img_feature):
+        return self.grad_cam(self.image_features, d_img_feature).unsqueeze(0)
+
+    def _maps(self, d_feat, row2img):
+        return self.engine.grad_cam(self._enc, d_feat, row2img)

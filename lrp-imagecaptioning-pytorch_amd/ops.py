@@ -199,7 +199,12 @@ class Vgg16:
         """Recompute the trace tensors derived from the activations (call after writing into `trace_views()`)."""
         check(_lib.load().lrpx_vgg16_trace_derive(ptr(self.trace), self.n_img, stream_ptr()))
 
-    def guided_backprop(self, d_feat_nhwc, map2img=None, out=None):
+    def gradient(self, d_feat_nhwc, map2img=None, out=None):
+        """explain_cnn of the plain-gradient explainer (models/gridTDmodel.py:1507-1521): the autograd gradient of the
+        encoder output w.r.t. the image for (N,196,512) output gradients -> (N,3,224,224)."""
+        return self.guided_backprop(d_feat_nhwc, map2img, out, _fn="lrpx_vgg16_gradient")
+
+    def guided_backprop(self, d_feat_nhwc, map2img=None, out=None, _fn="lrpx_vgg16_guided_backprop"):
         """explain_cnn of the guided-backprop explainer (models/gridTDmodel.py:1702-1723): (N,196,512) gradient at
         the encoder output -> (N,3,224,224) image gradient with the guided ReLU rule."""
         lib = _lib.load()
@@ -210,8 +215,8 @@ class Vgg16:
             self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
         if out is None:
             out = torch.empty(n_maps, 3, 224, 224, dtype=torch.float32, device=self.device)
-        check(lib.lrpx_vgg16_guided_backprop(ptr(self.packed), ptr(self.trace), self.n_img, ptr(d_feat_nhwc.contiguous()),
-                                             ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
+        check(getattr(lib, _fn)(ptr(self.packed), ptr(self.trace), self.n_img, ptr(d_feat_nhwc.contiguous()),
+                                ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
         return out
 
     def relevance(self, r_feat_nhwc, map2img=None, out=None, streams=1):
