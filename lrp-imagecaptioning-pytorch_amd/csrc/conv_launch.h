@@ -78,6 +78,15 @@ int launch_h3_112_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_28_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_14_fwd(const ConvArgs& a, hipStream_t s);
+int launch_h3_224_guided(const ConvArgs& a, hipStream_t s);   // image-gradient chains (guided backprop / plain gradient)
+int launch_h3_112_guided(const ConvArgs& a, hipStream_t s);
+int launch_h3_56_guided(const ConvArgs& a, hipStream_t s);
+int launch_h3_28_guided(const ConvArgs& a, hipStream_t s);
+int launch_h3_14_guided(const ConvArgs& a, hipStream_t s);
+int launch_h3_112n_plain(const ConvArgs& a, hipStream_t s);
+int launch_h3_56_plain(const ConvArgs& a, hipStream_t s);
+int launch_h3_28_plain(const ConvArgs& a, hipStream_t s);
+int launch_h3_14_plain(const ConvArgs& a, hipStream_t s);
 int launch_h3_224_pool(const ConvArgs& a, hipStream_t s);   // operand unpooled while staged (a.pool_am)
 int launch_h3_112_pool(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_pool(const ConvArgs& a, hipStream_t s);

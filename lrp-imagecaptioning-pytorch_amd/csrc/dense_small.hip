@@ -2,7 +2,8 @@
 // on the fp32 MFMA.  The big-tile engine (conv_mfma.h, 224 rows x 128 columns per workgroup) leaves most of the chip
 // idle on a 320-row problem and pays its pipeline fill/drain plus split-K atomics: ~110 us per GEMM, 42 GEMMs per
 // step.  Here one workgroup = 32 rows x 128 columns (4 waves, one 32x32 accumulator tile each, the whole K in one pass):
-//   * the 32 x K slab of A is staged ONCE into LDS (row stride K+4 floats: conflict-free ds_read_b128),
+//   * the 32 x K slab of A is staged ONCE into LDS (row stride K+4 floats: conflict-free ds_read_b128; K > 1024 in
+//     slabs of 1024 columns),
 //   * B fragments stream from the fragment-major packed weights (lrpx_pack_weights, kc = 32: one contiguous 1-KiB
 //     k-step of 8 per channel block) through an 8-deep register queue,
 //   * 10 x N/128 workgroups for 320 rows - 120..160 per GEMM, no split-K, deterministic.
@@ -19,7 +20,9 @@ __global__ __launch_bounds__(256, 2) void dense_small_kernel(ConvArgs a, int m_t
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mtile = blockIdx.x / n_blocks, nblk = blockIdx.x % n_blocks;
     const int K = a.cin;                         // multiple of 32
-    const int stride = K + 4;
+    constexpr int KSLAB = 1024;                  // LDS slab of A: 32 rows x min(K, 1024) floats (+4 pad per row)
+    const int kslab = K < KSLAB ? K : KSLAB;
+    const int stride = kslab + 4;
     const long rows = (long)a.n_maps * a.pix_per_map;
     const long row0 = (long)mtile * 32;
     const int ocb = nblk * 4 + wave;
@@ -37,39 +40,45 @@ __global__ __launch_bounds__(256, 2) void dense_small_kernel(ConvArgs a, int m_t
 #pragma unroll
         for (int i = 0; i < NB - 1; ++i) bq[i] = wp[(long)min(i, nsteps - 1) * 64];
     }
-
-    // stage the A slab: 32 rows x K floats, float4 items, rows past the end are zeros
-    const int k4 = K / 4;
-    for (int it = tid; it < 32 * k4; it += 256) {
-        const int r = it / k4, c4 = it - r * k4;
-        f32x4 v = f32x4{0, 0, 0, 0};
-        if (row0 + r < rows) v = *reinterpret_cast<const f32x4*>(a.in + (row0 + r) * K + c4 * 4);
-        *reinterpret_cast<f32x4*>(lds + r * stride + c4 * 4) = v;
-    }
-    __syncthreads();
-    if (!wave_active) return;
-
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const float* ap = lds + li * stride + lh * 4;
-    for (int ks = 0; ks < nsteps; ks += NB) {         // nsteps = K/8 is a multiple of 4; handle tails by clamping
+
+    for (int k0 = 0; k0 < K; k0 += KSLAB) {
+        const int kw = min(KSLAB, K - k0);           // width of this slab (multiple of 32)
+        if (k0) __syncthreads();                     // everybody is done with the previous slab
+        // stage the A slab: 32 rows x kw floats, float4 items, rows past the end are zeros
+        const int k4 = kw / 4;
+        for (int it = tid; it < 32 * k4; it += 256) {
+            const int r = it / k4, c4 = it - r * k4;
+            f32x4 v = f32x4{0, 0, 0, 0};
+            if (row0 + r < rows) v = *reinterpret_cast<const f32x4*>(a.in + (row0 + r) * K + k0 + c4 * 4);
+            *reinterpret_cast<f32x4*>(lds + r * stride + c4 * 4) = v;
+        }
+        __syncthreads();
+        if (wave_active) {
+            const int s0 = k0 / 8, sn = kw / 8;      // global k-step range of the slab
+            for (int ks = 0; ks < sn; ks += NB) {
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int step = ks + u;
-            bq[NB - 1] = wp[(long)min(step + NB - 1, nsteps - 1) * 64];
-            if (step < nsteps) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(ap + step * 8);
-                const f32x4 bv = bq[0];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc, 0, 0, 0);
+                for (int u = 0; u < NB; ++u) {
+                    const int step = ks + u;
+                    if (step < sn) {
+                        bq[NB - 1] = wp[(long)min(s0 + step + NB - 1, nsteps - 1) * 64];
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + step * 8);
+                        const f32x4 bv = bq[0];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc, 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < NB - 1; ++i) bq[i] = bq[i + 1];
+                    }
+                }
             }
-#pragma unroll
-            for (int i = 0; i < NB - 1; ++i) bq[i] = bq[i + 1];
         }
     }
+    if (!wave_active) return;
 
     // epilogue: acc[e] is row (e&3) + 8*(e>>2) + 4*lh, column oc
     const int oc = ocb * 32 + li;
@@ -112,7 +121,7 @@ static int launch_dense_small_t(const ConvArgs& a, hipStream_t stream) {
     const long rows = (long)a.n_maps * a.pix_per_map;
     const int m_tiles = (int)ceil_div(rows, 32);
     const int n_blocks = (int)ceil_div(a.n_oc, 128);
-    const int lds = 32 * (a.cin + 4) * (int)sizeof(float);
+    const int lds = 32 * ((a.cin < 1024 ? a.cin : 1024) + 4) * (int)sizeof(float);
     auto kern = dense_small_kernel<EPI>;
     static int lds_reserved = 0;
     if (lds > lds_reserved) {
@@ -127,9 +136,9 @@ static int launch_dense_small_t(const ConvArgs& a, hipStream_t stream) {
     return check_launch("dense_small");
 }
 
-// rows <= 4096, K <= 1024 (LDS slab 32 x (K+4) floats), REL (out0 only) or PLAIN
+// rows <= 4096, K in LDS slabs of 1024 (32 x 1028 floats), REL (out0 only) or PLAIN
 bool dense_small_fits(const ConvArgs& a) {
-    return a.pix_per_map > 0 && (long)a.n_maps * a.pix_per_map <= 4096 && a.cin % 32 == 0 && a.cin <= 1024 && !a.out1 && a.out0 &&
+    return a.pix_per_map > 0 && (long)a.n_maps * a.pix_per_map <= 4096 && a.cin % 32 == 0 && a.cin <= 8192 && !a.out1 && a.out0 &&
            (a.epi == EPI_REL || a.epi == EPI_PLAIN);
 }
 

@@ -155,13 +155,21 @@ __device__ __forceinline__ void amax_commit(unsigned* __restrict__ amax, long n,
     }
 }
 
+// ITER float4 per thread at block stride (ITER > 1 only when 256*ITER divides a map: one amax update per block of
+// 256*ITER float4 instead of one per 256 - the updates all land on n_maps words)
+template <int ITER>
 __global__ void amax_maps_kernel(const float* __restrict__ s, long per4, long total, unsigned* __restrict__ amax) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 units
-    const bool ok = idx < total;
-    if (!ok) idx = total - 1;
-    const f32x4 v = reinterpret_cast<const f32x4*>(s)[idx];
-    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    amax_commit(amax, idx / per4, ok ? m : 0.f);
+    const long base = (long)blockIdx.x * (blockDim.x * ITER) + threadIdx.x;   // float4 units
+    float m = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const long idx = base + (long)it * blockDim.x;
+        if (idx < total) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(s)[idx];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+    amax_commit(amax, (base < total ? base : total - 1) / per4, m);
 }
 
 // f16x2 split of the packed weights for conv_f16x3.h: 64-byte header {2^-kW, amax bits, ...} then
@@ -659,9 +667,13 @@ int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* s
         set_error("amax_maps: memset failed");
         return LRPX_ELAUNCH;
     }
-    long total = (long)n_maps * (per / 4);
-    hipLaunchKernelGGL(amax_maps_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, per / 4, total,
-                       amax);
+    const long per4 = per / 4, total = (long)n_maps * per4;
+    if (per4 % 2048 == 0)
+        hipLaunchKernelGGL(amax_maps_kernel<8>, dim3(grid_for(total, 2048)), dim3(256), 0, (hipStream_t)stream, s, per4, total, amax);
+    else if (per4 % 1792 == 0)
+        hipLaunchKernelGGL(amax_maps_kernel<7>, dim3(grid_for(total, 1792)), dim3(256), 0, (hipStream_t)stream, s, per4, total, amax);
+    else
+        hipLaunchKernelGGL(amax_maps_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, per4, total, amax);
     return check_launch("amax_maps");
 }
 

@@ -56,8 +56,25 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     }
     if (d->f16x3) {
         LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0 && d->in_amax && !d->bf16x6 &&
-                         ((d->epi == EPI_REL_MUL && d->x) || (d->epi == EPI_FWD_DUAL && !d->pool_am)),
-                     "conv_mfma: f16x3 needs a 3x3 conv, cin %% 16 == 0, in_amax and the REL_MUL (with x) or FWD_DUAL epilogue");
+                         ((d->epi == EPI_REL_MUL && d->x) || ((d->epi == EPI_FWD_DUAL || d->epi == EPI_GUIDED ||
+                                                               (d->epi == EPI_PLAIN && !d->relu && !d->bias)) && !d->pool_am)),
+                     "conv_mfma: f16x3 needs a 3x3 conv, cin %% 16 == 0, in_amax and the REL_MUL (with x), FWD_DUAL, GUIDED "
+                     "or bias-free PLAIN epilogue");
+        if (d->epi == EPI_GUIDED) {
+            if (d->hw == 224 && d->n_oc <= 64) return launch_h3_224_guided(a, s);
+            if (d->hw == 112 && d->n_oc > 64) return launch_h3_112_guided(a, s);
+            if (d->hw == 56) return launch_h3_56_guided(a, s);
+            if (d->hw == 28) return launch_h3_28_guided(a, s);
+            if (d->hw == 14) return launch_h3_14_guided(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no f16x3 GUIDED kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
+        if (d->epi == EPI_PLAIN) {
+            if (d->hw == 112 && d->n_oc <= 64) return launch_h3_112n_plain(a, s);
+            if (d->hw == 56) return launch_h3_56_plain(a, s);
+            if (d->hw == 28) return launch_h3_28_plain(a, s);
+            if (d->hw == 14) return launch_h3_14_plain(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no f16x3 PLAIN kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
         if (d->epi == EPI_FWD_DUAL) {
             if (d->hw == 224) return launch_h3_224_fwd(a, s);
             if (d->hw == 112) return launch_h3_112_fwd(a, s);
@@ -172,13 +189,13 @@ static hipEvent_t g_ev[17][2];
 static bool g_ev_made = false, g_ev_valid[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], fwd6[17], fwdh[17], bias[17], first6, first6p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], fwd6[17], fwdh[17], bias[17], first6, first6p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
     size_t off = 0;
     for (int l = 0; l < kNL; ++l) {
-        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.fwd6[l] = p.fwdh[l] = p.bias[l] = 0;
+        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.bwdph[l] = p.fwd6[l] = p.fwdh[l] = p.bias[l] = 0;
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
@@ -188,6 +205,7 @@ static VggPacked vgg_packed_layout() {
         if (l > 0) { p.bwd6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (l > 0) { p.bwdh[l] = off; off += lrpx_packed_f16x2_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (l > 0) { p.fwdh[l] = off; off += lrpx_packed_f16x2_bytes(2 * L.cout, L.cin, 9) / sizeof(float); }
+        if (l > 0) { p.bwdph[l] = off; off += lrpx_packed_f16x2_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (L.hw <= 112) {
             p.fwd6[l] = off; off += lrpx_packed_bf16x3_bytes(2 * L.cout, L.cin, 9) / sizeof(float);
         }
@@ -305,6 +323,7 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
         if (l > 0) LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwd6[l], stream));
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwdh[l], stream));
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwdh[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, base + p.bwdph[l], stream));
         if (L.hw <= 112) {
             LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwd6[l], stream));
         }
@@ -533,6 +552,12 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
         d.in = G[cur]; d.wpacked = pk + p.bwdp[l];
         d.n_maps = n_maps; d.hw = L.hw; d.cin = L.cout; d.taps = 9; d.map2img = map2img;
         d.n_oc = L.cin; d.oc_split = L.cin;
+        if (g_mode == 2) {
+            // fp16 split-product kernels: operand scale = per-map maximum of the incoming gradient (one streaming read)
+            unsigned* gam = reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps) + (size_t)l * n_maps;
+            LRPX_TRY(lrpx_amax_maps(G[cur], n_maps, (long)L.hw * L.hw * L.cout, gam, st));
+            d.f16x3 = 1; d.wpacked = pk + p.bwdph[l]; d.in_amax = gam;
+        }
         if (kVgg[l - 1].conv) {
             d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];      // ReLU hook of conv l-1 fused
             d.relu = plain ? 2 : 0;

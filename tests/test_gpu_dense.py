@@ -37,7 +37,7 @@ def test_dense_rel_few_rows(ops, rows, k, n, n_src):
     assert rel_err(out.cpu(), want) < 2e-6
 
 
-@pytest.mark.parametrize("rows,k,n,relu", [(320, 512, 1536, 0), (16, 64, 96, 1)])
+@pytest.mark.parametrize("rows,k,n,relu", [(320, 512, 1536, 0), (16, 64, 96, 1), (320, 2048, 1536, 0), (100, 1056, 64, 0)])
 def test_dense_plain_few_rows(ops, rows, k, n, relu):
     """out = A W^T + b (PACK_DENSE: W is (n rows, k cols)), optional ReLU"""
     from lrp_amd import _lib
