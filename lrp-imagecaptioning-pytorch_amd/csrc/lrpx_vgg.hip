@@ -84,6 +84,9 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
             LRPX_REQUIRE(false, "conv_mfma: no f16x3 forward kernel built for hw=%d", d->hw);
         }
         if (d->pool_am) {
+            // the kernels index pool_am with 32-bit element offsets (image * pooled pixels * channels)
+            LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
+                         "conv_mfma: too many (image, pooled pixel, channel) elements for the pooled-input kernel");
             if (d->hw == 224 && d->n_oc <= 64) return launch_h3_224_pool(a, s);
             if (d->hw == 112 && d->n_oc > 64) return launch_h3_112_pool(a, s);
             if (d->hw == 56) return launch_h3_56_pool(a, s);
