@@ -191,14 +191,15 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             const int px = rem / SEG, seg = rem - px * SEG;
             const int y = y_al - 1 + s;
             const bool ok = (it < NITEM) && (y >= 0) && (y < H);
-            dst = ok ? ((s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28)) : -1;
+            const int nm = ok ? 0 : -1;      // "| nm" instead of "ok ? x : -1": the latter compiles to an exec-masked branch
+            dst = ((s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28)) | nm;
             if constexpr (POOL) {
                 const int lo = (y >> 1) * WO + (px >> 1);
                 if (ok) dst |= (((y & 1) << 1) | (px & 1)) << 26;
                 gp = ok ? n_al * (HO * WO) + lo : -1;
                 amo = (int)((img_al * (HO * WO) + lo) * a.cin);
             } else {
-                gp = ok ? (n_al * H + y) * W + px : -1;
+                gp = ((n_al * H + y) * W + px) | nm;
             }
         } else {
             dst = sdst[u]; gp = sgp[u];
@@ -263,77 +264,97 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             rowmask = gp >= 0 ? (dst00 >> 26) & 3 : 0;
         }
     };
+    // input addressing: NHWC (pixel stride cin, chunk step KC) or channel-chunked (pixel stride KC, chunk step = stride)
+    const long in_pix_stride = a.in_chunk_stride ? KC : a.cin;
+    const long in_chunk_step = a.in_chunk_stride ? a.in_chunk_stride : KC;
     f32x4 sv[LOSTAGE ? UL : U];
     unsigned amv[POOL ? (LOSTAGE ? UL : U) : 1];
-#define LRPXH_ISSUE_LO(CHUNK)                                                                                \
-    _Pragma("unroll") for (int u = 0; u < UL; ++u) {                                                         \
+#define LRPXH_ISSUE_LO(CHUNK) _Pragma("unroll") for (int u = 0; u < UL; ++u) LRPXH_ISSUE_LO1(u, CHUNK)
+#define LRPXH_COMMIT_LO(BUFIDX) _Pragma("unroll") for (int u = 0; u < UL; ++u) LRPXH_COMMIT_LO1(u, BUFIDX)
+#define LRPXH_ISSUE_LO1(u, CHUNK)                                                                            \
+    {                                                                                                        \
         int dst_, gp_, amo_, rm_;                                                                            \
         float sc_;                                                                                           \
         item_lo(u, dst_, gp_, amo_, rm_, sc_);                                                               \
-        sv[u] = f32x4{0, 0, 0, 0};                                                                           \
-        amv[u] = 0;                                                                                          \
-        if (gp_ >= 0) {                                                                                      \
-            sv[u] = *reinterpret_cast<const f32x4*>(a.in + (long)gp_ * a.cin + (CHUNK) * KC + ((dst_ >> 28) & 3) * 4); \
-            amv[u] = *reinterpret_cast<const unsigned*>(a.pool_am + amo_ + (CHUNK) * KC + ((dst_ >> 28) & 3) * 4);    \
-        }                                                                                                    \
+        const long g_ = gp_ >= 0 ? gp_ : 0;                                                                  \
+        const int am_ = gp_ >= 0 ? amo_ : 0;                                                                 \
+        const int sg_ = ((dst_ >> 28) & 3) * 4;                                                              \
+        sv[u] = *reinterpret_cast<const f32x4*>(a.in + g_ * a.cin + (CHUNK) * KC + sg_);                      \
+        amv[u] = *reinterpret_cast<const unsigned*>(a.pool_am + am_ + (CHUNK) * KC + sg_);                    \
     }
-#define LRPXH_COMMIT_LO(BUFIDX)                                                                              \
-    _Pragma("unroll") for (int u = 0; u < UL; ++u) {                                                         \
+#define LRPXH_COMMIT_LO1(u, BUFIDX)                                                                          \
+    {                                                                                                        \
         int dst_, gp_, amo_, rm_;                                                                            \
         float sc_;                                                                                           \
         item_lo(u, dst_, gp_, amo_, rm_, sc_);                                                               \
-        if (rm_) {                                                                                           \
-            _Float16 h[4], l[4];                                                                             \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * sc_, h[e], l[e]);                \
-            char* d0 = ldsb + (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                         \
-            _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                            \
-                if (rm_ & (1 << (pos >> 1))) {                                                               \
-                    _Float16 hm[4], lm[4];                                                                   \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                          \
-                        const bool w_ = ((amv[u] >> (8 * e)) & 0xffu) == (unsigned)pos;                      \
-                        hm[e] = w_ ? h[e] : (_Float16)0; lm[e] = w_ ? l[e] : (_Float16)0;                    \
-                    }                                                                                        \
-                    char* d = d0 + (((pos >> 1) && (rm_ & 1)) ? PITCH : 0) + (pos & 1) * PSTRIDE;           \
-                    *reinterpret_cast<u32x2_*>(d) = u32x2_{pack_f16(hm[0], hm[1]), pack_f16(hm[2], hm[3])};  \
-                    *reinterpret_cast<u32x2_*>(d + 32) = u32x2_{pack_f16(lm[0], lm[1]), pack_f16(lm[2], lm[3])}; \
-                }                                                                                            \
-            }                                                                                                \
-        }                                                                                                    \
-    }
-#define LRPXH_ISSUE(CHUNK)                                                                                   \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
-        int dst_, gp_, amo_;                                                                                 \
-        item(u, dst_, gp_, amo_);                                                                            \
-        sv[u] = f32x4{0, 0, 0, 0};                                                                           \
-        if (gp_ >= 0) {                                                                                      \
-            sv[u] = *reinterpret_cast<const f32x4*>(                                                         \
-                a.in_chunk_stride ? a.in + (CHUNK) * a.in_chunk_stride + (long)gp_ * KC + ((dst_ >> 28) & 3) * 4 \
-                                  : a.in + (long)gp_ * a.cin + (CHUNK) * KC + ((dst_ >> 28) & 3) * 4);        \
-            if constexpr (POOL)                                                                              \
-                amv[u] = *reinterpret_cast<const unsigned*>(a.pool_am + amo_ + (CHUNK) * KC + ((dst_ >> 28) & 3) * 4); \
-        }                                                                                                    \
-    }
-#define LRPXH_COMMIT(BUFIDX)                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
-        int dst_, gp_, amo_;                                                                                 \
-        item(u, dst_, gp_, amo_);                                                                            \
-        if (dst_ >= 0) {                                                                                     \
-            _Float16 h[4], l[4];                                                                             \
+        _Float16 h[4], l[4];                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * sc_, h[e], l[e]);                    \
+        char* db_ = ldsb + (BUFIDX) * BUFB;                                                                  \
+        const int o0_ = dst_ & 0x03ffffff;                                                                   \
+        _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                                \
+            const bool wr_ = (rm_ >> (pos >> 1)) & 1;         /* this window row lies inside the LDS tile */  \
+            _Float16 hm[4], lm[4];                                                                           \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
-                float x_ = sv[u][e] * ssc[AL ? 0 : u];                                                       \
-                if constexpr (POOL) x_ = (((amv[u] >> (8 * e)) & 0xffu) == (unsigned)((dst_ >> 26) & 3)) ? x_ : 0.f; \
-                split2(x_, h[e], l[e]);                                                                      \
+                const bool w_ = ((amv[u] >> (8 * e)) & 0xffu) == (unsigned)pos;                              \
+                hm[e] = w_ ? h[e] : (_Float16)0; lm[e] = w_ ? l[e] : (_Float16)0;                            \
             }                                                                                                \
-            char* d = ldsb + (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                          \
-            *reinterpret_cast<u32x2_*>(d) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};              \
-            *reinterpret_cast<u32x2_*>(d + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};         \
+            const int o_ = o0_ + (((pos >> 1) && (rm_ & 1)) ? PITCH : 0) + (pos & 1) * PSTRIDE;              \
+            *reinterpret_cast<u32x2_*>(db_ + (wr_ ? o_ : 64)) = u32x2_{pack_f16(hm[0], hm[1]), pack_f16(hm[2], hm[3])};      \
+            *reinterpret_cast<u32x2_*>(db_ + (wr_ ? o_ + 32 : 72)) = u32x2_{pack_f16(lm[0], lm[1]), pack_f16(lm[2], lm[3])}; \
         }                                                                                                    \
+    }
+#define LRPXH_ISSUE(CHUNK) _Pragma("unroll") for (int u = 0; u < U; ++u) LRPXH_ISSUE1(u, CHUNK)
+#define LRPXH_COMMIT(BUFIDX) _Pragma("unroll") for (int u = 0; u < U; ++u) LRPXH_COMMIT1(u, BUFIDX)
+// Branch-free: an item that has nothing to load reads element 0 (and is zeroed at commit), an item that has nothing to
+// write targets the 16 pad bytes of LDS pixel 0 - no exec-mask regions, so the scheduler can place these instructions
+// between the MFMAs of a tap.
+#define LRPXH_ISSUE1(u, CHUNK)                                                                               \
+    {                                                                                                        \
+        int dst_, gp_, amo_;                                                                                 \
+        item(u, dst_, gp_, amo_);                                                                            \
+        const long g_ = gp_ >= 0 ? gp_ : 0;                                                                  \
+        const int sg_ = dst_ >= 0 ? ((dst_ >> 28) & 3) * 4 : 0;                                              \
+        sv[u] = *reinterpret_cast<const f32x4*>(a.in + g_ * in_pix_stride + (CHUNK) * in_chunk_step + sg_);  \
+    }
+#define LRPXH_COMMIT1(u, BUFIDX)                                                                             \
+    {                                                                                                        \
+        int dst_, gp_, amo_;                                                                                 \
+        item(u, dst_, gp_, amo_);                                                                            \
+        const bool okl_ = gp_ >= 0;                                                                          \
+        _Float16 h[4], l[4];                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
+            const float x_ = okl_ ? sv[u][e] * ssc[AL ? 0 : u] : 0.f;                                        \
+            split2(x_, h[e], l[e]);                                                                          \
+        }                                                                                                    \
+        char* db_ = ldsb + (BUFIDX) * BUFB;                                                                  \
+        *reinterpret_cast<u32x2_*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) : 64)) =                           \
+            u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};                                              \
+        *reinterpret_cast<u32x2_*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) + 32 : 72)) =                      \
+            u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};                                              \
     }
 
     if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(0) } else { LRPXH_ISSUE(0) }
     for (int i = tid; i < NBUF * BUFB / 16; i += NT) reinterpret_cast<u32x4_*>(ldsb)[i] = u32x4_{0, 0, 0, 0};
     __syncthreads();
     if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(0) } else { LRPXH_COMMIT(0) }
+    // INTERLEAVE (experiment, off): staging software-pipelined INTO the MFMA phase instead of running as separate phases
+    // between barriers - during the taps of chunk c the wave commits chunk c+1 (loaded during chunk c-1) to the other
+    // LDS buffer, one item per tap, and then re-issues the same registers for chunk c+2.  Measured: 26.1 ms against
+    // 24.9 ms for the phased schedule (chain of 320 maps).  The two waves of a SIMD already time-slice the matrix pipe
+    // - one wave's staging phase runs under the other's MFMAs - and VALU placed between a wave's own dependent MFMAs
+    // only delays that wave's next MFMA issue (in-order issue).
+#ifndef LRPXH_INTERLEAVE
+#define LRPXH_INTERLEAVE 0
+#endif
+#ifndef LRPXH_ILV_VALU
+#define LRPXH_ILV_VALU 8      // VALU instructions of the staging work scheduled after each accumulator tile's 3 MFMAs
+#endif
+    constexpr int UE = LOSTAGE ? UL : U;
+    constexpr bool ILV = (LRPXH_INTERLEAVE != 0) && DB && UE <= 8;
+    constexpr int OFF = TAPS - UE;               // item u: committed at tap u, re-issued at tap u + OFF
+    if constexpr (ILV) {
+        if (nchunk > 1) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(1) } else { LRPXH_ISSUE(1) } }
+    }
 
     f32x16 acc[7];
 #pragma unroll
@@ -376,7 +397,9 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #if LRPXH_PRIO
         __builtin_amdgcn_s_setprio(LRPXH_PRIO);      // short VALU/VMEM phases first: the partner wave is mid-MFMA
 #endif
-        if (more) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(chunk + 1) } else { LRPXH_ISSUE(chunk + 1) } }
+        if constexpr (!ILV) {
+            if (more) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(chunk + 1) } else { LRPXH_ISSUE(chunk + 1) } }
+        }
 #if LRPXH_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -400,6 +423,19 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                 const long nxt = (long)min(chunk * TAPS + tap + NBQ - 1, last_step) * 2;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) bq[NBQ - 1][p] = wp[(nxt + p) * 64];
+                if constexpr (ILV) {
+                    // no run-time conditions (they would fence the scheduler): past the last chunk the commit writes
+                    // stale registers into the buffer nobody reads again, the issue re-reads the last chunk
+                    if (tap < UE) {          // (compile-time after unrolling)
+                        if constexpr (LOSTAGE) { LRPXH_COMMIT_LO1(tap < UE ? tap : 0, (chunk + 1) & 1) }
+                        else { LRPXH_COMMIT1(tap < UE ? tap : 0, (chunk + 1) & 1) }
+                    }
+                    if (tap >= OFF) {
+                        const int cn_ = min(chunk + 2, nchunk - 1);
+                        if constexpr (LOSTAGE) { LRPXH_ISSUE_LO1(tap >= OFF ? tap - OFF : 0, cn_) }
+                        else { LRPXH_ISSUE1(tap >= OFF ? tap - OFF : 0, cn_) }
+                    }
+                }
                 const f16x8 b0 = __builtin_bit_cast(f16x8, bq[0][0]);
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[0][1]);
 #pragma unroll
@@ -425,6 +461,10 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                     if constexpr (APIPE) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the 2 reads of the NEXT tile ...
                         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the 3 MFMAs of this one
+                        if constexpr (ILV) {      // ... and a slice of the staging work of this tap in their shadow
+                            __builtin_amdgcn_sched_group_barrier(0x002, LRPXH_ILV_VALU, 0);
+                            if (j == 6) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                        }
                     }
                 }
 #pragma unroll
@@ -444,8 +484,16 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #if LRPXH_PRIO
         __builtin_amdgcn_s_setprio(LRPXH_PRIO);
 #endif
+        if constexpr (ILV) {
+            if (!wave_active) {          // waves without a channel block still stage their share of the tile
+                if (more) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
+                if (chunk + 2 < nchunk) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(chunk + 2) } else { LRPXH_ISSUE(chunk + 2) } }
+            }
+        }
         if constexpr (DB) {
-            if (more) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
+            if constexpr (!ILV) {
+                if (more) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
+            }
             LRPXH_T(td);
             __syncthreads();
             LRPXH_T(te);

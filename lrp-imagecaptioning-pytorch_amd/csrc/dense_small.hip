@@ -12,8 +12,106 @@
 
 namespace lrpx {
 
+// K <= 1024: the whole 32 x K slab of A in LDS, one pass
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void dense_small_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mtile = blockIdx.x / n_blocks, nblk = blockIdx.x % n_blocks;
+    const int K = a.cin;                         // multiple of 32
+    const int stride = K + 4;
+    const long rows = (long)a.n_maps * a.pix_per_map;
+    const long row0 = (long)mtile * 32;
+    const int ocb = nblk * 4 + wave;
+    const bool wave_active = ocb * 32 < a.n_oc;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // B queue first (independent of LDS): k-steps of 8, 1 KiB each, contiguous per channel block
+    constexpr int NB = 8;
+    const int nsteps = K / 8;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wp) + (long)ocb * nsteps * 64 + lane;
+    f32x4 bq[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bq[i] = f32x4{0, 0, 0, 0};
+    if (wave_active) {
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) bq[i] = wp[(long)min(i, nsteps - 1) * 64];
+    }
+
+    // stage the A slab: 32 rows x K floats, float4 items, rows past the end are zeros
+    const int k4 = K / 4;
+    for (int it = tid; it < 32 * k4; it += 256) {
+        const int r = it / k4, c4 = it - r * k4;
+        f32x4 v = f32x4{0, 0, 0, 0};
+        if (row0 + r < rows) v = *reinterpret_cast<const f32x4*>(a.in + (row0 + r) * K + c4 * 4);
+        *reinterpret_cast<f32x4*>(lds + r * stride + c4 * 4) = v;
+    }
+    __syncthreads();
+    if (!wave_active) return;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float* ap = lds + li * stride + lh * 4;
+    for (int ks = 0; ks < nsteps; ks += NB) {         // nsteps = K/8 is a multiple of 4; handle tails by clamping
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int step = ks + u;
+            bq[NB - 1] = wp[(long)min(step + NB - 1, nsteps - 1) * 64];
+            if (step < nsteps) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ap + step * 8);
+                const f32x4 bv = bq[0];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB - 1; ++i) bq[i] = bq[i + 1];
+        }
+    }
+
+    // epilogue: acc[e] is row (e&3) + 8*(e>>2) + 4*lh, column oc
+    const int oc = ocb * 32 + li;
+    const int ncol = a.oc_split;
+    if (oc >= ncol) return;
+    const unsigned P = (unsigned)a.pix_per_map;
+    float bias = 0.f;
+    if (EPI == EPI_PLAIN && a.bias) bias = a.bias[oc];
+    float xv[16];
+    long nn[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const long row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        xv[e] = 0.f; nn[e] = 0;
+        if (EPI == EPI_REL && row < rows) {
+            const long n = row / P, p = row - n * P;
+            const long img = a.map2img ? a.map2img[n] : n;
+            nn[e] = n;
+            xv[e] = a.X[(img * P + p) * ncol + oc];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const long row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row >= rows) continue;
+        float v = acc[e];
+        if (EPI == EPI_REL) {
+            if (a.U) v += a.U[nn[e] * ncol + oc];
+            a.out0[row * ncol + oc] = xv[e] * v;
+        } else {
+            v += bias;
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            a.out0[row * ncol + oc] = v;
+        }
+    }
+}
+
+// K > 1024: the same with A staged in slabs of 1024 columns
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void dense_slab_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -122,15 +220,16 @@ static int launch_dense_small_t(const ConvArgs& a, hipStream_t stream) {
     const int m_tiles = (int)ceil_div(rows, 32);
     const int n_blocks = (int)ceil_div(a.n_oc, 128);
     const int lds = 32 * ((a.cin < 1024 ? a.cin : 1024) + 4) * (int)sizeof(float);
-    auto kern = dense_small_kernel<EPI>;
-    static int lds_reserved = 0;
-    if (lds > lds_reserved) {
+    const bool slabs = a.cin > 1024;
+    auto kern = slabs ? dense_slab_kernel<EPI> : dense_small_kernel<EPI>;
+    static int lds_reserved[2] = {0, 0};
+    if (lds > lds_reserved[slabs]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
             hipSuccess) {
             set_error("dense_small: cannot reserve %d bytes of LDS", lds);
             return LRPX_ELAUNCH;
         }
-        lds_reserved = lds;
+        lds_reserved[slabs] = lds;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks);
     return check_launch("dense_small");
