@@ -11,14 +11,25 @@ B, T, V = 16, 20, 9586
 eng = GridTDEngine(weights.make_gridtd_state(seed=0, vocab_size=V))
 images = torch.from_numpy(weights.make_images(100, B)).cuda()
 caps = torch.from_numpy(weights.make_captions(200, B, T, V)).cuda()
+sizes = {}
 runs = {"LRP (explain_batch)": lambda: eng.explain_batch(images, caps),
         "guided backprop (explain_batch_guided)": lambda: eng.explain_batch_guided(images, caps),
         "plain gradient (explain_batch_gradient)": lambda: eng.explain_batch_gradient(images, caps),
         "Grad-CAM (explain_batch_gradient cam=True)": lambda: eng.explain_batch_gradient(images, caps, cam=True)}
+from lrp_amd.explainers.aoa import AOAEngine
+VA = 11027
+aoa = AOAEngine(weights.make_aoa_state(seed=0, vocab_size=VA))
+caps_a = torch.from_numpy(weights.make_captions(201, B, T, VA)).cuda()
+runs["AoA LRP, head 0 (config 3 model, B=16)"] = lambda: aoa.explain_batch(caps_a, 0, images=images)
+bu = AOAEngine(weights.make_aoa_state(seed=0, vocab_size=VA, feat_dim=2048, with_encoder=False))
+feats_bu = torch.from_numpy(weights.make_bu_features(5, 32)).cuda()
+caps_b = torch.from_numpy(weights.make_captions(202, 32, T, VA)).cuda()
+runs["AoA bottom-up LRP, head 0 (config 5, B=32, no CNN)"] = lambda: bu.explain_batch(caps_b, 0, features=feats_bu)
+sizes = {"AoA bottom-up LRP, head 0 (config 5, B=32, no CNN)": 32 * T}
 for name, fn in runs.items():
     fn(); fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5): fn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
-    print(f"{name:45s} {dt*1e3:8.2f} ms/step  {B*T/dt:9.1f} maps/s")
+    print(f"{name:52s} {dt*1e3:8.2f} ms/step  {sizes.get(name, B*T)/dt:9.1f} maps/s")
