@@ -84,8 +84,8 @@ def cpu_baseline(V, T, words):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (config 2)")
     ap.add_argument("--words", type=int, default=20)
     ap.add_argument("--vocab", type=int, default=9586)
