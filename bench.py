@@ -264,7 +264,7 @@ def main():
                           "algorithmic_tflops": round(GFLOP_PER_MAP * B * T / chain_ms, 1),
                           "conv_ms_by_layer": {str(l): round(v, 3) for l, v in enumerate(per_layer) if v > 0}}}
             if not a.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(V, T, [0, 5, 10, 15, 19])
+                out["cpu_baseline"] = cpu_baseline(V, T, sorted({round(i * (T - 1) / 9) for i in range(10)}))   # 10 words, mean index (T-1)/2
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
