@@ -93,6 +93,11 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     constexpr int BUFB = C::NSLOT * PITCH;
     constexpr int NBUF = DB ? 2 : 1;
     constexpr bool AL = (H % C::R == 0);               // a workgroup tile never straddles two maps
+#ifdef LRPXH_NO_HOIST
+    constexpr bool HOIST = false;
+#else
+    constexpr bool HOIST = (HW == 56) && !POOL;        // staging descriptors stay in registers (see item())
+#endif
 #ifndef LRPXH_APIPE_MIN_HW
 #define LRPXH_APIPE_MIN_HW 14
 #endif
@@ -185,7 +190,9 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         amo = 0;
         if constexpr (AL) {
             int it = tid + u * NT;
-            asm volatile("" : "+v"(it));     // recompute per use: hoisted out of the chunk loop it costs 2U registers
+            // recompute per use: hoisted out of the chunk loop the descriptors cost 2U registers and spill - except in the
+            // 56x56 kernel with a B queue of 8, where keeping them resident saves 6 % (measured, tools/variant_sweep2.sh)
+            if constexpr (!HOIST) asm volatile("" : "+v"(it));
             const int s = it / (W * SEG);
             const int rem = it - s * (W * SEG);
             const int px = rem / SEG, seg = rem - px * SEG;
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #else
     // measured (tools/variant_sweep2.sh, chain of 320 maps): depth 2 -> 28.9 ms, 4 -> 26.9, 6 -> 25.9, 8 -> 25.0; the
     // map-straddling tiles (28/14) spill beyond 7
-    constexpr int NBQ = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : ((HW == 112 && NWN == 2) ? 8 : 9));
+    constexpr int NBQ = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : (((HW == 112 && NWN == 2) || HOIST) ? 8 : 9));
 #endif
     const float inv_w = a.wp[0];
     const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
