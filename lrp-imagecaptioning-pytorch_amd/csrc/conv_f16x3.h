@@ -93,11 +93,12 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     constexpr int BUFB = C::NSLOT * PITCH;
     constexpr int NBUF = DB ? 2 : 1;
     constexpr bool AL = (H % C::R == 0);               // a workgroup tile never straddles two maps
-#ifdef LRPXH_NO_HOIST
-    constexpr bool HOIST = false;
-#else
-    constexpr bool HOIST = (HW == 56) && !POOL;        // staging descriptors stay in registers (see item())
+#ifndef LRPXH_HOIST_MASK
+#define LRPXH_HOIST_MASK 1
 #endif
+    // staging descriptors stay in registers (see item()): bit 0: 56 non-pooled, 1: 56 pooled, 2: 112 pooled, 3: 224 pooled
+    constexpr bool HOIST = AL && (((LRPXH_HOIST_MASK & 1) && HW == 56 && !POOL) || ((LRPXH_HOIST_MASK & 2) && HW == 56 && POOL) ||
+                                  ((LRPXH_HOIST_MASK & 4) && HW == 112 && POOL) || ((LRPXH_HOIST_MASK & 8) && HW == 224 && POOL));
 #ifndef LRPXH_APIPE_MIN_HW
 #define LRPXH_APIPE_MIN_HW 14
 #endif
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     auto item_lo = [&](const int u, int& dst00, int& gp, int& amo, int& rowmask, float& sc) {
         if constexpr (AL) {
             int it = tid + u * NT;
-            asm volatile("" : "+v"(it));
+            if constexpr (!HOIST) asm volatile("" : "+v"(it));
             const int sl = it / (WO * SEG);
             const int rem = it - sl * (WO * SEG);
             const int pxl = rem / SEG, seg = rem - pxl * SEG;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #else
     // measured (tools/variant_sweep2.sh, chain of 320 maps): depth 2 -> 28.9 ms, 4 -> 26.9, 6 -> 25.9, 8 -> 25.0; the
     // map-straddling tiles (28/14) spill beyond 7
-    constexpr int NBQ = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : (((HW == 112 && NWN == 2) || HOIST) ? 8 : 9));
+    constexpr int NBQ = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : (((HW == 112 && NWN == 2) || (HOIST && !POOL)) ? 8 : 9));
 #endif
     const float inv_w = a.wp[0];
     const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
