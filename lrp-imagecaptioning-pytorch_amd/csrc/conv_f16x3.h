@@ -395,22 +395,13 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     }
     __syncthreads();
 
-#ifndef LRPXH_PRIO
-#define LRPXH_PRIO 0
-#endif
     LRPXH_T(t_loop);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = chunk + 1 < nchunk;
         LRPXH_T(ta);
-#if LRPXH_PRIO
-        __builtin_amdgcn_s_setprio(LRPXH_PRIO);      // short VALU/VMEM phases first: the partner wave is mid-MFMA
-#endif
         if constexpr (!ILV) {
             if (more) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(chunk + 1) } else { LRPXH_ISSUE(chunk + 1) } }
         }
-#if LRPXH_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         LRPXH_T(tb);
         if (wave_active) {
             const char* abuf = ldsb + (DB ? (chunk & 1) : 0) * BUFB;
@@ -489,9 +480,6 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             }
         }
         LRPXH_T(tc);
-#if LRPXH_PRIO
-        __builtin_amdgcn_s_setprio(LRPXH_PRIO);
-#endif
         if constexpr (ILV) {
             if (!wave_active) {          // waves without a channel block still stage their share of the tile
                 if (more) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
