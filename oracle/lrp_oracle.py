@@ -504,9 +504,11 @@ def gridtd_gradient_explain_caption(sd, img, caption, words=None, return_feat=Fa
 # ----------------------------------------------------------------------------------------------
 # AoA decoder (multi-head attention on attention)
 # ----------------------------------------------------------------------------------------------
-def aoa_trace(sd, F_pix, caption, num_head=8):
+def aoa_trace(sd, F_pix, caption, num_head=8, grad=False):
     """models/aoamodel.py:990-1062 `get_hidden_parameters` for one image.
-    F_pix: (P,C) encoder features, pixel-major.  Quirk: bias_ih added twice (:873)."""
+    F_pix: (P,C) encoder features, pixel-major.  Quirk: bias_ih added twice (:873).
+    grad=True: the trace of the gradient explainers (:1309-1376): the LSTM uses bias_ih + bias_hh (:1298) and the
+    output gate is kept (tr["o"])."""
     Hd = sd["fc.weight"].shape[1]
     P, C = F_pix.shape
     T = len(caption) - 1
@@ -518,10 +520,10 @@ def aoa_trace(sd, F_pix, caption, num_head=8):
     key = Vp @ sd["decoder_k_proj.weight"].t() + sd["decoder_k_proj.bias"]
     value = Vp @ sd["decoder_v_proj.weight"].t() + sd["decoder_v_proj.bias"]
     l_wi, l_wh = sd["LanguageLSTM.weight_ih"], sd["LanguageLSTM.weight_hh"]
-    l_b = sd["LanguageLSTM.bias_ih"] + sd["LanguageLSTM.bias_ih"]
+    l_b = sd["LanguageLSTM.bias_ih"] + (sd["LanguageLSTM.bias_hh"] if grad else sd["LanguageLSTM.bias_ih"])
     E = sd["embedding.weight"].shape[1]
     z = lambda *s: torch.zeros(*s)
-    tr = dict(T=T, P=P, F_pix=F_pix, proj_pre=proj_pre, Vp=Vp, glob=glob, key=key, value=value,
+    tr = dict(T=T, P=P, F_pix=F_pix, proj_pre=proj_pre, Vp=Vp, glob=glob, key=key, value=value, o=z(T, Hd),
               caption=list(int(c) for c in caption), num_head=num_head)
     tr["h"], tr["c"] = z(T + 1, Hd), z(T + 1, Hd)
     for k in ("g", "i", "f", "ctx", "c_aoa", "c_aoa_lin", "c_aoa_gate"):
@@ -535,6 +537,7 @@ def aoa_trace(sd, F_pix, caption, num_head=8):
         emb = sd["embedding.weight"][caption[t]]
         x = torch.cat([emb, glob])
         h, c, g, i, f = _lstm_cell(x, tr["h"][t], tr["c"][t], l_wi, l_wh, l_b)
+        tr["o"][t] = torch.sigmoid((l_wi @ x + l_wh @ tr["h"][t] + l_b).chunk(4)[3])
         q = sd["decoder_multihead_attention.q_proj.weight"] @ h + sd["decoder_multihead_attention.q_proj.bias"]
         qh = q.view(num_head, 1, dk)
         scores = (qh @ kh.transpose(1, 2)) / math.sqrt(dk)           # (heads,1,P)  aoamodel.py:77-85
@@ -653,4 +656,80 @@ def aoa_explain_caption(sd, img, caption, head_idx, words=None, return_feat=Fals
         maps = _accumulate(maps)
     if return_feat:
         return maps, rws, rfs, tr
+    return maps, rws
+
+
+# ----------------------------------------------------------------------------------------------
+# AoA gradient family: models/aoamodel.py:1257-1776
+# ----------------------------------------------------------------------------------------------
+def aoa_gradient_wordt(sd, tr, t, head_idx):
+    """models/aoamodel.py:1435-1499 `ExplainAOAGradient.explain_caption_wordt` (+ `gradient_mha` :1415-1433): BPTT
+    through the language LSTM with the attention weights constant and only head `head_idx` passing gradient.
+    Quirks kept: `d_global_img_feature = d_xt[i][E:]` is an assignment (:1487), so only the i = 0 step survives;
+    the projector ReLU gets no derivative; `ExplainAOAGuidedGradient` inherits this method unchanged.
+    `tr` must be a grad=True trace.  Returns (d_feat (P,C), r_words (t+1,))."""
+    Hd = tr["h"].shape[1]
+    E = tr["x"].shape[1] - Hd
+    P, nh = tr["P"], tr["num_head"]
+    dk = Hd // nh
+    k = tr["caption"][t + 1]
+    l_wi, l_wh = sd["LanguageLSTM.weight_ih"], sd["LanguageLSTM.weight_hh"]
+    n = t + 1
+    d_h, d_c = torch.zeros(n + 1, Hd), torch.zeros(n + 1, Hd)
+    d_emb = torch.zeros(n, E)
+    d_hc = sd["fc.weight"][k].clone()
+    d_h[t + 1] = d_hc
+    sg = torch.sigmoid(tr["c_aoa_gate"][t])
+    d_A = d_hc * sg
+    d_B = d_hc * tr["c_aoa_lin"][t] * (1 - sg) * sg
+    d_ctx = d_A @ sd["decoder_aoa_linear.weight"]
+    d_h[t + 1] = d_h[t + 1] + d_B @ sd["decoder_aoa_linear_gate.weight"]
+    d_value = torch.zeros(P, Hd)
+    sl = slice(head_idx * dk, (head_idx + 1) * dk)
+    d_value[:, sl] = tr["alpha"][t, head_idx].unsqueeze(1) * d_ctx[sl].unsqueeze(0)
+    d_glob = torch.zeros(Hd)
+    for i in range(t, -1, -1):
+        tc = torch.tanh(tr["c"][i + 1])
+        d_oa = d_h[i + 1] * tc
+        d_c[i + 1] = d_c[i + 1] + d_h[i + 1] * tr["o"][i] * (1 - tc ** 2)
+        d_fa = d_c[i + 1] * tr["c"][i]
+        d_c[i] = d_c[i + 1] * tr["f"][i]
+        d_ia, d_ga = d_c[i + 1] * torch.tanh(tr["g"][i]), d_c[i + 1] * tr["i"][i]
+        gt = torch.tanh(tr["g"][i])
+        gates = torch.cat([d_ia * tr["i"][i] * (1 - tr["i"][i]), d_fa * tr["f"][i] * (1 - tr["f"][i]),
+                           d_ga * (1 - gt ** 2), d_oa * tr["o"][i] * (1 - tr["o"][i])])
+        d_h[i] = gates @ l_wh
+        d_x = gates @ l_wi
+        d_glob = d_x[E:]                      # assignment, :1487
+        d_emb[i] = d_x[:E]
+    d_proj = d_value @ sd["decoder_v_proj.weight"] + d_glob.unsqueeze(0) / P
+    w_proj = sd["img_projector.weight"].reshape(Hd, -1)
+    d_feat = d_proj @ w_proj
+    r_words = d_emb.sum(-1)
+    m = r_words.abs().max()
+    if m > 0:
+        r_words = r_words / m
+    return d_feat, r_words
+
+
+def aoa_gradient_explain_caption(sd, img, caption, head_idx, kind="gradient", num_head=8, return_feat=False):
+    """`explain_caption` of ExplainAOAGradient (kind="gradient", :1501-1534), ExplainAOAGuidedGradient ("guided",
+    :1621-1640: guided backprop through the encoder) and ExplainAOAGradCam ("gradcam", :1669-1689)."""
+    feats, avg, saved = vgg_forward(sd, img)
+    F_pix = feats[0].reshape(feats.shape[1], -1).t().contiguous()
+    tr = aoa_trace(sd, F_pix, caption, num_head, grad=True)
+    maps, rws, dfs = [], [], []
+    for t in range(tr["T"]):
+        d_feat, r_words = aoa_gradient_wordt(sd, tr, t, head_idx)
+        d_feat = pix_to_nchw(d_feat, feats.shape[-2:])
+        dfs.append(d_feat)
+        if kind == "gradcam":
+            maps.append(grad_cam(feats, d_feat).unsqueeze(0))
+        elif kind == "guided":
+            maps.append(vgg_guided_backprop(sd, saved, d_feat))
+        else:
+            maps.append(vgg_gradient(sd, saved, d_feat))
+        rws.append(r_words)
+    if return_feat:
+        return maps, rws, dfs, tr
     return maps, rws

@@ -369,6 +369,50 @@ def gen_gradcam(out, weights, T=3, V=9586, seed=0):
     print("gradcam_T3.npz written; cam shapes:", [tuple(m.shape) for m in maps], "max:", [float(m.max()) for m in maps])
 
 
+def gen_aoa_gradient(out, weights, T=3, V=11027, seed=0, head=5):
+    """ExplainAOAGradient / ExplainAOAGuidedGradient / ExplainAOAGradCam (models/aoamodel.py:1257-1711), head `head`."""
+    import models.aoamodel as aoa
+    sd = weights.make_aoa_state(seed=seed, vocab_size=V)
+    wm = weights.make_word_map(V)
+    img = weights.make_images(seed, 1)
+    cap = weights.make_captions(seed + 1, 1, T, V)[0]
+    g = dict(seed=np.int64(seed), V=np.int64(V), caption=cap, head=np.int64(head))
+    for cls_name, tag in (("ExplainAOAGradient", "grad"), ("ExplainAOAGuidedGradient", "guided"),
+                          ("ExplainAOAGradCam", "cam")):
+        with tempfile.TemporaryDirectory() as tmp:
+            args = make_args(tmp)
+            real_load = torch.load
+            torch.load = lambda *a, **k: {"state_dict": to_torch_sd(sd)}
+            try:
+                ex = getattr(aoa, cls_name)(args, wm)
+            finally:
+                torch.load = real_load
+            _patch_explainer(ex, img, cap)
+            feats = []
+            orig = ex.explain_caption_wordt
+
+            def wrapped(t, head_idx, _orig=orig, _feats=feats):
+                rf, rw = _orig(t, head_idx)
+                _feats.append(rf.clone())
+                return rf, rw
+            ex.explain_caption_wordt = wrapped
+            maps, rws = ex.explain_caption("synthetic.jpg", head)
+        for t in range(T):
+            if tag == "cam":
+                g[f"cam_{t}"] = maps[t].detach().numpy()
+            else:
+                g[f"{tag}_map_stats_{t}"] = stats(maps[t])
+                g[f"{tag}_map_sub4_{t}"] = sub4(maps[t]).numpy()
+            if tag == "grad":
+                g[f"d_feat_{t}"] = feats[t].detach().numpy()
+                g[f"r_words_{t}"] = rws[t].detach().numpy()
+        if tag == "grad":
+            g["tr_ot_act"] = ex.ot_act.detach().numpy()
+            g["tr_ht"] = ex.ht.detach().numpy()
+    np.savez(os.path.join(out, "aoa_gradient_T3.npz"), **g)
+    print("aoa_gradient_T3.npz written")
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -387,7 +431,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -411,6 +455,8 @@ def main():
         gen_gradient(HERE, weights)
     if "gradcam" in todo:
         gen_gradcam(HERE, weights)
+    if "aoa_gradient" in todo:
+        gen_aoa_gradient(HERE, weights)
 
 
 if __name__ == "__main__":

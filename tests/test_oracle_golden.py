@@ -141,3 +141,24 @@ def test_grad_cam_vs_reference():
         assert np.abs(cams[t].numpy() - g[f"cam_{t}"]).max() < 1e-4
         assert np.abs(rws[t].numpy() - g[f"r_words_{t}"]).max() < TOL_WORDS
     assert g["cam_1"].max() == 0.0 and cams[1].max().item() == 0.0
+
+
+def test_aoa_gradient_family_vs_reference():
+    # ExplainAOAGradient / ExplainAOAGuidedGradient / ExplainAOAGradCam (models/aoamodel.py:1257-1711), one head
+    g = np.load(os.path.join(GOLDEN, "aoa_gradient_T3.npz"))
+    head = int(g["head"])
+    sd = O.state_to_torch(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=int(g["V"])))
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    maps, rws, dfs, tr = O.aoa_gradient_explain_caption(sd, img, g["caption"], head, "gradient", return_feat=True)
+    assert rel_err(tr["o"], g["tr_ot_act"]) < 2e-5 and rel_err(tr["h"], g["tr_ht"]) < 2e-5
+    for t in range(3):
+        assert rel_err(dfs[t], g[f"d_feat_{t}"]) < TOL_REL
+        assert np.abs(rws[t].numpy() - g[f"r_words_{t}"]).max() < TOL_WORDS
+        scale = g[f"grad_map_stats_{t}"][1]
+        assert np.abs(maps[t][..., ::4, ::4].numpy() - g[f"grad_map_sub4_{t}"]).max() / scale < TOL_REL
+    gmaps, _ = O.aoa_gradient_explain_caption(sd, img, g["caption"], head, "guided")
+    cams, _ = O.aoa_gradient_explain_caption(sd, img, g["caption"], head, "gradcam")
+    for t in range(3):
+        scale = g[f"guided_map_stats_{t}"][1]
+        assert np.abs(gmaps[t][..., ::4, ::4].numpy() - g[f"guided_map_sub4_{t}"]).max() / scale < TOL_REL
+        assert np.abs(cams[t].numpy() - g[f"cam_{t}"]).max() < 1e-4
