@@ -254,6 +254,7 @@ typedef struct lrpx_aoa_trace {
     float *g, *i, *f;              /* [B][T][H] */
     float *ctx, *lin, *c_aoa, *hc; /* [B][T][H]: context, decoder_aoa_linear(context), gated, fc input */
     float* alpha;                  /* [B][T][NH][P] */
+    float *o, *sg;                 /* optional (gradient explainers, :1309-1376): [B][T][H] output gate, sigmoid(aoa gate) */
 } lrpx_aoa_trace;
 int lrpx_aoa_fwd_pre(const lrpx_aoa_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
                      int tok_ld, void* stream);
@@ -262,6 +263,28 @@ int lrpx_aoa_fwd_lstm(const lrpx_aoa_trace* tr, int t, const float* zz, int ldz,
 int lrpx_aoa_fwd_attention(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* key,
                            const float* value, void* stream);
 int lrpx_aoa_fwd_post(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* lin, void* stream);
+
+/* ---- AoA decoder: gradient explainers (ExplainAOAGradient.explain_caption_wordt, models/aoamodel.py:1435-1499;
+ *      inherited unchanged by the guided / Grad-CAM variants) --------------------------------------------------- */
+typedef struct lrpx_aoa_gradstate {
+    const int32_t* lens;
+    float *d_h, *d_c;              /* [B*T][H] */
+    float *dA, *dB;                /* [B*T][H]: gradient into decoder_aoa_linear / decoder_aoa_linear_gate outputs (:1468-1470) */
+    float *gates, *dx;             /* [B*T][4H] LSTM gate gradients / [B*T][E+2H] = gates @ [W_ih | W_hh] */
+    float *d_glob;                 /* [B*T][H]   (assignment quirk :1487: the i = 0 step survives) */
+    float* r_words;                /* [B*T][T] */
+} lrpx_aoa_gradstate;
+/* seed: d_h = fc.weight[target], dA, dB from the saved gate / linear outputs; needs tr->o and tr->sg */
+int lrpx_aoa_grad_init(const lrpx_aoa_trace* tr, const lrpx_aoa_gradstate* gs, const float* fcw, const long long* tok,
+                       int tok_ld, void* stream);
+/* lock-step s (time index i = t - s): phase 0 LSTM cell backward -> gates; phase 1 after dx = gates @ [W_ih|W_hh] */
+int lrpx_aoa_grad_step(const lrpx_aoa_trace* tr, const lrpx_aoa_gradstate* gs, int s, int phase, void* stream);
+/* d_feat[row][p][:] = alpha[b,t,head,p] * v1[row][:] + v2[row][:]  (gradient_mha :1415-1433 folded through v_proj and
+ * the projector: both are rank-1 in the pixel index) */
+int lrpx_aoa_grad_pix(const lrpx_aoa_trace* tr, int head, const float* v1, const float* v2, float* d_feat, int C,
+                      void* stream);
+/* x[row][c] = 0 for c outside [lo, hi)  (only one head passes gradient, :1428) */
+int lrpx_keep_cols(float* x, long rows, int ncol, int lo, int hi, void* stream);
 
 /* ---- AoA decoder: relevance (explain_caption_wordt :1064-1156, lrp_mha :812-862) ----------------------- */
 typedef struct lrpx_aoa_relstate {

@@ -38,7 +38,11 @@ class GridRelState(C.Structure):
 
 class AoaTrace(C.Structure):
     _fields_ = [("B", _i), ("T", _i), ("H", _i), ("E", _i), ("P", _i), ("NH", _i)] + [(k, _f) for k in (
-        "xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha")]
+        "xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha", "o", "sg")]
+
+
+class AoaGradState(C.Structure):
+    _fields_ = [(k, _f) for k in ("lens", "d_h", "d_c", "dA", "dB", "gates", "dx", "d_glob", "r_words")]
 
 
 class AoaRelState(C.Structure):
@@ -73,6 +77,10 @@ SIGNATURES = {
     "lrpx_maxpool2x2_relevance": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "lrpx_divide_stab": (_i, [_f, _f, _f, _f, _i, _l, _i, _f]),
     "lrpx_pool_winner": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_aoa_grad_init": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaGradState), _f, _f, _i, _f]),
+    "lrpx_aoa_grad_step": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaGradState), _i, _i, _f]),
+    "lrpx_aoa_grad_pix": (_i, [C.POINTER(AoaTrace), _i, _f, _f, _f, _i, _f]),
+    "lrpx_keep_cols": (_i, [_f, _l, _i, _i, _i, _f]),
     "lrpx_amax_maps": (_i, [_f, _i, _l, _f, _f]),
     "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),
     "lrpx_accumulate": (_i, [_f, _f, _l, _f]),

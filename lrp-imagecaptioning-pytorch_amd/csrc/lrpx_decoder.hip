@@ -604,6 +604,7 @@ struct AoaFwd {
     float *g, *i, *f;            // [B][T][H]
     float *ctx, *lin, *c_aoa, *hc;   // [B][T][H]  context, decoder_aoa_linear(context), gated, fc input
     float *alpha;                // [B][T][NH][P]
+    float *o, *sg;               // optional: [B][T][H] output gate, sigmoid(aoa gate)   (gradient explainers)
 };
 
 // xh[b,t] = [emb[tok[b,t]] | glob[b] | h[b,t]]   (:1030, :1075)
@@ -631,6 +632,7 @@ __global__ void aoa_fwd_lstm_kernel(AoaFwd g, int t, const float* __restrict__ z
         const float cn = f * g.c[st0 + c] + i * tanhf(zg);
         g.c[st1 + c] = cn; g.h[st1 + c] = o * tanhf(cn);
         g.g[tr + c] = zg; g.i[tr + c] = i; g.f[tr + c] = f;
+        if (g.o) g.o[tr + c] = o;
     }
 }
 
@@ -678,9 +680,104 @@ __global__ void aoa_fwd_post_kernel(AoaFwd g, int t, const float* __restrict__ q
     const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = ((long)b * g.T + t) * H;
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         const float l = lin[(long)b * H + c];
-        const float ca = sigmoidf_(qg[(long)b * ldq + H + c]) * l;
+        const float sgv = sigmoidf_(qg[(long)b * ldq + H + c]);
+        const float ca = sgv * l;
         g.lin[tr + c] = l; g.c_aoa[tr + c] = ca; g.hc[tr + c] = ca + g.h[st1 + c];
+        if (g.sg) g.sg[tr + c] = sgv;
     }
+}
+
+// ---- AoA gradient explainers (models/aoamodel.py:1435-1499), all (image, word) rows in lock-step -------------------
+struct AoaGrad {
+    int B, T, H, E, P, NH;
+    const int* lens;
+    const float *c, *g, *i, *f, *o, *sg, *lin, *alpha;
+    float *d_h, *d_c, *dA, *dB, *gates, *dx, *d_glob, *r_words;
+};
+
+__device__ __forceinline__ bool aoa_grow_active(const AoaGrad& g, int b, int t, int s) {
+    const int len = g.lens ? g.lens[b] : g.T;
+    return t < len && t >= s;
+}
+
+// :1461-1470: d_word_pred one-hot -> fc row; gradient into the gated sum  c_aoa = sigmoid(gate) * lin
+__global__ void aoa_grad_init_kernel(AoaGrad g, const float* __restrict__ fcw, const long long* __restrict__ tok,
+                                     int tok_ld) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    const long long k = tok[(long)b * tok_ld + t + 1];
+    const long r = (long)row * H;          // trace tensors [B][T][H] are indexed by the same row
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float d = fcw[k * H + c], sgv = g.sg[r + c];
+        g.d_h[r + c] = d; g.d_c[r + c] = 0.f; g.d_glob[r + c] = 0.f;
+        g.dA[r + c] = d * sgv;
+        g.dB[r + c] = d * g.lin[r + c] * (1.f - sgv) * sgv;
+    }
+    for (int c = threadIdx.x; c < g.T; c += blockDim.x) g.r_words[(long)row * g.T + c] = 0.f;
+}
+
+// phase 0 (:1474-1484): LSTM cell backward at time i = t - s -> gate gradients [i | f | g | o]
+__global__ void aoa_grad_step0_kernel(AoaGrad g, int s) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    const long r = (long)row * H;
+    float* gt = g.gates + (long)row * 4 * H;
+    if (!aoa_grow_active(g, b, t, s)) {
+        for (int c = threadIdx.x; c < 4 * H; c += blockDim.x) gt[c] = 0.f;
+        return;
+    }
+    const int i = t - s;
+    const long ti = ((long)b * g.T + i) * H, ci = ((long)b * (g.T + 1) + i) * H, ci1 = ci + H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float dh = g.d_h[r + c], tc = tanhf(g.c[ci1 + c]);
+        const float iv = g.i[ti + c], fv = g.f[ti + c], gv = tanhf(g.g[ti + c]), ov = g.o[ti + c];
+        const float dc = g.d_c[r + c] + dh * ov * (1.f - tc * tc);
+        gt[c] = dc * gv * iv * (1.f - iv);
+        gt[H + c] = dc * g.c[ci + c] * fv * (1.f - fv);
+        gt[2 * H + c] = dc * iv * (1.f - gv * gv);
+        gt[3 * H + c] = dh * tc * ov * (1.f - ov);
+        g.d_c[r + c] = dc * fv;
+    }
+}
+
+// phase 1 (:1485-1488): dx = gates @ [W_ih | W_hh] = [d_emb (E) | d_glob (H) | d_h (H)]
+__global__ void aoa_grad_step1_kernel(AoaGrad g, int s) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, E = g.E;
+    if (!aoa_grow_active(g, b, t, s)) return;
+    const int i = t - s;
+    const long r = (long)row * H;
+    const float* dx = g.dx + (long)row * (E + 2 * H);
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < E; c += blockDim.x) acc += dx[c];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) g.r_words[(long)row * g.T + i] = acc;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        g.d_glob[r + c] = dx[E + c];            // assignment, not accumulation (:1487)
+        g.d_h[r + c] = dx[E + H + c];
+    }
+}
+
+__global__ void aoa_grad_pix_kernel(const float* __restrict__ alpha, int T, int NH, int P, int head,
+                                    const float* __restrict__ v1, const float* __restrict__ v2,
+                                    float* __restrict__ d_feat, int C4, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over rows*P*C4
+    if (idx >= total) return;
+    const int c4 = idx % C4;
+    const long rp = idx / C4;
+    const int p = rp % P;
+    const long row = rp / P;
+    const float a = alpha[(row * NH + head) * P + p];
+    const f32x4 x1 = reinterpret_cast<const f32x4*>(v1)[row * C4 + c4], x2 = reinterpret_cast<const f32x4*>(v2)[row * C4 + c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = a * x1[e] + x2[e];
+    reinterpret_cast<f32x4*>(d_feat)[idx] = o;
+}
+
+__global__ void keep_cols_kernel(float* __restrict__ x, int ncol, int lo, int hi, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % ncol;
+    if (c < lo || c >= hi) x[idx] = 0.f;
 }
 
 struct AoaRel {
@@ -995,6 +1092,7 @@ static AoaFwd to_afwd(const lrpx_aoa_trace* t) {
     g.B = t->B; g.T = t->T; g.H = t->H; g.E = t->E; g.P = t->P; g.NH = t->NH;
     g.xh = t->xh; g.h = t->h; g.c = t->c; g.g = t->g; g.i = t->i; g.f = t->f;
     g.ctx = t->ctx; g.lin = t->lin; g.c_aoa = t->c_aoa; g.hc = t->hc; g.alpha = t->alpha;
+    g.o = t->o; g.sg = t->sg;
     return g;
 }
 
@@ -1037,6 +1135,56 @@ int lrpx_aoa_fwd_post(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq,
     LRPX_REQUIRE(qg && lin && t >= 0 && t < tr->T, "aoa_fwd_post: bad arguments");
     hipLaunchKernelGGL(aoa_fwd_post_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), t, qg, ldq, lin);
     return check_launch("aoa_fwd_post");
+}
+
+static int to_agrad(const lrpx_aoa_trace* t, const lrpx_aoa_gradstate* r, AoaGrad* out) {
+    LRPX_TRY(check_atrace(t));
+    LRPX_REQUIRE(t->o && t->sg, "aoa gradient: the trace lacks the output gate / aoa gate (allocate it with grad=True)");
+    LRPX_REQUIRE(r && r->d_h && r->d_c && r->dA && r->dB && r->gates && r->dx && r->d_glob && r->r_words,
+                 "aoa gradient: null state tensor");
+    AoaGrad g;
+    g.B = t->B; g.T = t->T; g.H = t->H; g.E = t->E; g.P = t->P; g.NH = t->NH; g.lens = r->lens;
+    g.c = t->c; g.g = t->g; g.i = t->i; g.f = t->f; g.o = t->o; g.sg = t->sg; g.lin = t->lin; g.alpha = t->alpha;
+    g.d_h = r->d_h; g.d_c = r->d_c; g.dA = r->dA; g.dB = r->dB; g.gates = r->gates; g.dx = r->dx; g.d_glob = r->d_glob;
+    g.r_words = r->r_words;
+    *out = g;
+    return LRPX_OK;
+}
+
+int lrpx_aoa_grad_init(const lrpx_aoa_trace* tr, const lrpx_aoa_gradstate* gs, const float* fcw, const long long* tok,
+                       int tok_ld, void* stream) {
+    AoaGrad g;
+    LRPX_TRY(to_agrad(tr, gs, &g));
+    LRPX_REQUIRE(fcw && tok, "aoa_grad_init: null pointer");
+    hipLaunchKernelGGL(aoa_grad_init_kernel, dim3(g.B * g.T), dim3(256), 0, (hipStream_t)stream, g, fcw, tok, tok_ld);
+    return check_launch("aoa_grad_init");
+}
+
+int lrpx_aoa_grad_step(const lrpx_aoa_trace* tr, const lrpx_aoa_gradstate* gs, int s, int phase, void* stream) {
+    AoaGrad g;
+    LRPX_TRY(to_agrad(tr, gs, &g));
+    LRPX_REQUIRE(s >= 0 && s < g.T && (phase == 0 || phase == 1), "aoa_grad_step: bad step / phase");
+    if (phase == 0) hipLaunchKernelGGL(aoa_grad_step0_kernel, dim3(g.B * g.T), dim3(256), 0, (hipStream_t)stream, g, s);
+    else hipLaunchKernelGGL(aoa_grad_step1_kernel, dim3(g.B * g.T), dim3(256), 0, (hipStream_t)stream, g, s);
+    return check_launch("aoa_grad_step");
+}
+
+int lrpx_aoa_grad_pix(const lrpx_aoa_trace* tr, int head, const float* v1, const float* v2, float* d_feat, int C,
+                      void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(v1 && v2 && d_feat && head >= 0 && head < tr->NH && C > 0 && C % 4 == 0, "aoa_grad_pix: bad arguments");
+    const long total = (long)tr->B * tr->T * tr->P * (C / 4);
+    hipLaunchKernelGGL(aoa_grad_pix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       tr->alpha, tr->T, tr->NH, tr->P, head, v1, v2, d_feat, C / 4, total);
+    return check_launch("aoa_grad_pix");
+}
+
+int lrpx_keep_cols(float* x, long rows, int ncol, int lo, int hi, void* stream) {
+    LRPX_REQUIRE(x && rows > 0 && ncol > 0 && lo >= 0 && hi <= ncol && lo < hi, "keep_cols: bad arguments");
+    const long total = rows * ncol;
+    hipLaunchKernelGGL(keep_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ncol,
+                       lo, hi, total);
+    return check_launch("keep_cols");
 }
 
 static AoaRel to_arel(const lrpx_aoa_trace* t, const lrpx_aoa_relstate* r) {

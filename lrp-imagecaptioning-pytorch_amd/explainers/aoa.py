@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
-from .._lib import (AoaRelState, AoaTrace, EPI_PLAIN, EPI_REL, PACK_DENSE, PACK_DENSE_T, STAB_EPS, check, ptr, ptr_at,
+from .._lib import (AoaGradState, AoaRelState, AoaTrace, EPI_PLAIN, EPI_REL, PACK_DENSE, PACK_DENSE_T, STAB_EPS, check, ptr, ptr_at,
                     stream_ptr)
 from .gridtd import VGG_PREFIX, _t
 
@@ -54,6 +54,9 @@ class AOAEngine:
         self.p_lin_rel = ops.pack_weights(sd["decoder_aoa_linear.weight"], H, H, 1, PACK_DENSE_T, kc)
         self.p_v_rel = ops.pack_weights(sd["decoder_v_proj.weight"], H, H, 1, PACK_DENSE_T, kc)
         self.p_proj_rel = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE_T, kc)
+        # gradient explainers (:1435-1499): contraction over the 4H gate rows / over the outputs of the two aoa linears
+        self.p_gates_grad = ops.pack_weights(self.Wcat, 4 * H, E + 2 * H, 1, PACK_DENSE_T, kc)
+        self.p_gate_grad = ops.pack_weights(sd["decoder_aoa_linear_gate.weight"], H, H, 1, PACK_DENSE_T, kc)
         torch.cuda.synchronize()
         self._idx_cache = {}
 
@@ -86,7 +89,7 @@ class AOAEngine:
                       bias=self.sd["decoder_v_proj.bias"], out0=enc["value"])
         return enc
 
-    def _alloc_trace(self, B, T, P):
+    def _alloc_trace(self, B, T, P, grad=False):
         dev, H, E, NH = self.device, self.H, self.E, self.NH
         z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
         tr = dict(B=B, T=T, P=P)
@@ -97,18 +100,24 @@ class AOAEngine:
         tr["alpha"] = z(B, T, NH, P)
         c = AoaTrace()
         c.B, c.T, c.H, c.E, c.P, c.NH = B, T, H, E, P, NH
-        for k in ("xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha"):
+        names = ["xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha"]
+        if grad:      # the gradient explainers also keep the output gate and sigmoid(aoa gate)  (:1309-1376)
+            tr["o"], tr["sg"] = z(B, T, H), z(B, T, H)
+            names += ["o", "sg"]
+        for k in names:
             setattr(c, k, ptr(tr[k]))
         tr["_c"] = c
         return tr
 
-    def trace(self, enc, captions, model_bias=False, predictions=True):
+    def trace(self, enc, captions, model_bias=False, predictions=True, grad=False):
+        """grad=True: the trace of the gradient explainers (:1309-1376): correct LSTM bias, output gate and aoa gate kept."""
+        model_bias = model_bias or grad
         lib = _lib.load()
         st = stream_ptr()
         B, T = captions.shape[0], captions.shape[1] - 1
         H, E = self.H, self.E
         captions = captions.to(self.device, torch.int64).contiguous()
-        tr = self._alloc_trace(B, T, enc["P"])
+        tr = self._alloc_trace(B, T, enc["P"], grad)
         c = C.byref(tr["_c"])
         W = E + 2 * H
         zz = torch.empty(B, 4 * H, device=self.device)
@@ -134,6 +143,71 @@ class AOAEngine:
         if predictions:
             tr["pred"] = self.logits(tr["hc"].view(B * T, H)).view(B, T, self.V)
         return tr
+
+    def gradient(self, enc, tr, head_idx, lens=None):
+        """`ExplainAOAGradient.explain_caption_wordt` (models/aoamodel.py:1435-1499; the guided and Grad-CAM classes
+        inherit it unchanged) for every (image, word) row in lock-step.  `tr` must be a grad=True trace.
+        Returns d_feat (B*T, P, C), r_words (B*T, T), row2img."""
+        lib = _lib.load()
+        st = stream_ptr()
+        B, T, H, E, P, Cc = tr["B"], tr["T"], self.H, self.E, tr["P"], self.C
+        rows = B * T
+        e = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        gs = dict(d_h=e(rows, H), d_c=e(rows, H), dA=e(rows, H), dB=e(rows, H), gates=e(rows, 4 * H),
+                  dx=e(rows, E + 2 * H), d_glob=e(rows, H), r_words=e(rows, T))
+        c = AoaGradState()
+        c.lens = ptr(lens)
+        for k, v in gs.items():
+            setattr(c, k, ptr(v))
+        ctr, cgs = C.byref(tr["_c"]), C.byref(c)
+        _, row2img, _ = self._row_index(B, T)
+        check(lib.lrpx_aoa_grad_init(ctr, cgs, ptr(self.sd["fc.weight"]), ptr(tr["captions"]), T + 1, st))
+
+        def dense(a, wp, n):      # (rows, K) @ packed (K, n) -> (rows, n), fp32 MFMA
+            out = e(rows, n)
+            ops.conv_mfma(a, wp, rows, 0, a.shape[1], -(-n // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=n, out0=out)
+            return out
+        d_ctx = dense(gs["dA"], self.p_lin_rel, H)                                   # :1469  d_A @ W_aoa_linear
+        t1 = dense(gs["dB"], self.p_gate_grad, H)                                    # :1470  d_B @ W_aoa_linear_gate
+        check(lib.lrpx_accumulate(ptr(gs["d_h"]), ptr(t1), rows * H, st))
+        dk = H // self.NH
+        check(lib.lrpx_keep_cols(ptr(d_ctx), rows, H, head_idx * dk, (head_idx + 1) * dk, st))   # gradient_mha :1428
+        for s in range(T):
+            check(lib.lrpx_aoa_grad_step(ctr, cgs, s, 0, st))
+            ops.conv_mfma(gs["gates"], self.p_gates_grad, rows, 0, 4 * H, E + 2 * H, 1, EPI_PLAIN, pix_per_map=1,
+                          oc_split=E + 2 * H, out0=gs["dx"])
+            check(lib.lrpx_aoa_grad_step(ctr, cgs, s, 1, st))
+        # pixels: d_value = alpha (x) d_ctx[head]; through v_proj and the projector both stay rank-1 in the pixel index
+        u = dense(d_ctx, self.p_v_rel, H)                                            # :1489  d_value @ W_v
+        v1 = dense(u, self.p_proj_rel, Cc)                                           # :1492
+        v2 = dense(gs["d_glob"], self.p_proj_rel, Cc)
+        check(lib.lrpx_scale(ptr(v2), ptr(v2), v2.numel(), 1.0 / P, st))             # :1491  d_glob / P
+        d_feat = e(rows, P, Cc)
+        check(lib.lrpx_aoa_grad_pix(ctr, head_idx, ptr(v1), ptr(v2), ptr(d_feat), Cc, st))
+        check(lib.lrpx_rel_words_norm(ptr(gs["r_words"]), rows, T, st))
+        return d_feat, gs["r_words"], row2img
+
+    def explain_batch_gradient(self, captions, head_idx, images, kind="gradient", lens=None, return_features=False):
+        """Batched `explain_caption` of ExplainAOAGradient (kind="gradient", :1501-1534), ExplainAOAGuidedGradient
+        ("guided", :1621-1640) and ExplainAOAGradCam ("gradcam", :1669-1689; result (B,T,P) heat maps)."""
+        enc = self.encode(images)
+        captions = captions.to(self.device, torch.int64).contiguous()
+        B, T = captions.shape[0], captions.shape[1] - 1
+        tr = self.trace(enc, captions, predictions=False, grad=True)
+        d_feat, r_words, row2img = self.gradient(enc, tr, head_idx, lens)
+        if kind == "gradcam":
+            maps = torch.empty(B * T, enc["P"], device=self.device, dtype=torch.float32)
+            check(_lib.load().lrpx_gradcam(ptr(enc["feats"]), ptr(d_feat), ptr(row2img), ptr(maps), B * T, enc["P"], self.C,
+                                           stream_ptr()))
+            maps = maps.view(B, T, enc["P"])
+        elif kind == "guided":
+            maps = self.vgg.guided_backprop(d_feat, row2img).view(B, T, 3, 224, 224)
+        else:
+            maps = self.vgg.gradient(d_feat, row2img).view(B, T, 3, 224, 224)
+        out = (maps, r_words.view(B, T, T))
+        if return_features:
+            out = out + (d_feat.view(B, T, enc["P"], self.C), tr, enc)
+        return out
 
     def logits(self, hc_rows):
         R = hc_rows.shape[0]
@@ -291,3 +365,60 @@ class ExplainAOAAttention(object):
         self.get_hidden_parameters(img, caption_encode)
         _, r_words, _ = self._relevance(0)
         return [r_words[t, :t + 1] for t in range(self.caption_length)]
+
+
+class ExplainAOAGradient(ExplainAOAAttention):
+    """Drop-in for the reference's `ExplainAOAGradient` (models/aoamodel.py:1257-1592): hand-written BPTT through the
+    language LSTM for one attention head (`explain_caption_wordt`, :1435-1499) and the autograd gradient through the
+    encoder (`explain_cnn`, :1501-1515).  Same surface: `explain_caption(img, head_idx) -> (maps, word scores)`."""
+    EX_TYPE = 'gradient'
+
+    def get_hidden_parameters(self, img, caption_encode):
+        super().get_hidden_parameters(img, caption_encode)
+        cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=self.engine.device)
+        self._tr = self.engine.trace(self._enc, cap, predictions=True, grad=True)      # :1309-1376 (correct LSTM bias)
+        self.predictions = self._tr["pred"][0]
+        self.alphas = self._tr["alpha"][0]
+
+    def _relevance(self, head_idx):
+        if head_idx not in self._rel:
+            self._rel[head_idx] = self.engine.gradient(self._enc, self._tr, head_idx)
+        return self._rel[head_idx]
+
+    def _cnn(self, d_feat_nhwc, row2img):
+        return self.engine.vgg.gradient(d_feat_nhwc, row2img)
+
+    def explain_cnn(self, d_img_feature):
+        t_nhwc = ops.nchw_to_nhwc(d_img_feature.to(torch.float32))
+        return self._cnn(t_nhwc, torch.zeros(d_img_feature.shape[0], dtype=torch.int32, device=self.engine.device))
+
+    def explain_caption(self, img, head_idx, t_list=None, caption_encode=None):
+        """(:1517-1534) no running sums here: the image gradient is a fresh tensor per word."""
+        if caption_encode is None:
+            raise ValueError("caption_encode is required (the reference's beam search is outside the hot path)")
+        self.get_hidden_parameters(img, caption_encode)
+        d_feat, r_words, row2img = self._relevance(head_idx)
+        maps = self._cnn(d_feat, row2img)
+        return ([maps[t:t + 1] for t in range(self.caption_length)],
+                [r_words[t, :t + 1] for t in range(self.caption_length)])
+
+
+class ExplainAOAGuidedGradient(ExplainAOAGradient):
+    """Drop-in for `ExplainAOAGuidedGradient` (models/aoamodel.py:1594-1667): same decoder gradient, guided backprop
+    through the encoder (:1621-1640)."""
+    EX_TYPE = 'GuidedBackpropagate'
+
+    def _cnn(self, d_feat_nhwc, row2img):
+        return self.engine.vgg.guided_backprop(d_feat_nhwc, row2img)
+
+
+class ExplainAOAGradCam(ExplainAOAGradient):
+    """Drop-in for `ExplainAOAGradCam` (models/aoamodel.py:1669-1711): per word the (1, h*w) Grad-CAM heat map."""
+    EX_TYPE = 'GradCam'
+
+    def _cnn(self, d_feat_nhwc, row2img):
+        rows, P = d_feat_nhwc.shape[0], d_feat_nhwc.shape[1]
+        cam = torch.empty(rows, P, device=self.engine.device, dtype=torch.float32)
+        check(_lib.load().lrpx_gradcam(ptr(self._enc["feats"]), ptr(d_feat_nhwc.contiguous()), ptr(row2img), ptr(cam), rows,
+                                       P, self.engine.C, stream_ptr()))
+        return cam

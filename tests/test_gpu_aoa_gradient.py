@@ -1,0 +1,121 @@
+"""GPU parity of the AoA gradient family (reference models/aoamodel.py:1257-1711): plain gradient,
+guided backprop and Grad-CAM for one attention head, against the reference's golden (tests/golden/aoa_gradient_T3.npz)
+and the oracle, through the C ABI (lrpx_aoa_grad_*, lrpx_vgg16_gradient / _guided_backprop, lrpx_gradcam)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lrp_amd  # noqa: F401
+from conftest import GOLDEN, rel_err, assert_close_modulo_pool_ties
+
+pytestmark = pytest.mark.gpu
+# End to end the ReLU masks come from the GPU forward (see tests/test_gpu_gradient.py).  The AoA decoder gradient is dense
+# with both signs at the encoder output, so a handful of flipped ReLU paths weigh more than for gridTD: cosine 0.99995
+# ... 0.99989 / relative L2 up to 1.5e-2 on the golden image.  The decoder itself is held to 1e-4 (d_feat below, and per row against the
+# oracle on identical features); the CNN backward kernels are held to 1e-4 on identical activations in
+# tests/test_gpu_gradient.py / test_gpu_guided.py.
+E2E = dict(frac=0.3, l2=3e-2, cos=0.9995, hard=0.15)
+
+
+@pytest.fixture(scope="module")
+def case():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    g = np.load(os.path.join(GOLDEN, "aoa_gradient_T3.npz"))
+    sd = weights.make_aoa_state(seed=int(g["seed"]), vocab_size=int(g["V"]))
+    eng = AOAEngine(sd)
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    cap = torch.from_numpy(g["caption"]).view(1, -1)
+    return g, sd, eng, img, cap, int(g["head"])
+
+
+def test_aoa_gradient_decoder_and_maps_vs_reference(case):
+    g, sd, eng, img, cap, head = case
+    maps, r_words, d_feat, tr, enc = eng.explain_batch_gradient(cap, head, img, kind="gradient", return_features=True)
+    assert rel_err(tr["o"][0].cpu(), g["tr_ot_act"]) < 1e-4 and rel_err(tr["h"][0].cpu(), g["tr_ht"]) < 1e-4
+    for t in range(3):
+        want = torch.from_numpy(g[f"d_feat_{t}"])[0].reshape(512, 196).t()
+        assert rel_err(d_feat[0, t].cpu(), want) < 1e-4, t
+        assert np.abs(r_words[0, t, :t + 1].cpu().numpy() - g[f"r_words_{t}"]).max() < 5e-5
+        assert_close_modulo_pool_ties(maps[0, t][None, :, ::4, ::4].cpu(), g[f"grad_map_sub4_{t}"], what=t, **E2E)
+
+
+def test_aoa_guided_and_gradcam_vs_reference(case):
+    g, sd, eng, img, cap, head = case
+    gmaps, _ = eng.explain_batch_gradient(cap, head, img, kind="guided")
+    cams, _ = eng.explain_batch_gradient(cap, head, img, kind="gradcam")
+    assert tuple(cams.shape) == (1, 3, 196)
+    for t in range(3):
+        assert_close_modulo_pool_ties(gmaps[0, t][None, :, ::4, ::4].cpu(), g[f"guided_map_sub4_{t}"], what=t, **E2E)
+        assert np.abs(cams[0, t].cpu().numpy() - g[f"cam_{t}"][0]).max() < 1e-3, t
+
+
+def test_aoa_cnn_backward_strict_on_identical_activations(case):
+    """the AoA decoder gradients of the golden through the plain-gradient and guided VGG16 backward on the oracle's
+    own activations (same ReLU masks, same pool winners): 1e-4 - the end-to-end differences above are flips only"""
+    from test_gpu_vgg import _inject_oracle_trace, to_nhwc
+    from oracle import lrp_oracle as O
+    g, sd, eng, img, cap, head = case
+    eng.vgg.forward(img.cuda())
+    _inject_oracle_trace(eng.vgg, sd, img)
+    d = torch.cat([torch.from_numpy(g[f"d_feat_{t}"]) for t in range(3)])
+    z = torch.zeros(3, dtype=torch.int32, device="cuda")
+    sdt = O.state_to_torch(sd)
+    _, _, saved = O.vgg_forward(sdt, img)
+    got = eng.vgg.gradient(to_nhwc(d).cuda(), z).cpu()
+    assert rel_err(got, O.vgg_gradient(sdt, saved, d)) < 1e-4
+    for t in range(3):
+        scale = g[f"grad_map_stats_{t}"][1]
+        assert np.abs(got[t:t + 1, :, ::4, ::4].numpy() - g[f"grad_map_sub4_{t}"]).max() / scale < 1e-4
+    got = eng.vgg.guided_backprop(to_nhwc(d).cuda(), z).cpu()
+    assert rel_err(got, O.vgg_guided_backprop(sdt, saved, d)) < 1e-4
+    for t in range(3):
+        scale = g[f"guided_map_stats_{t}"][1]
+        assert np.abs(got[t:t + 1, :, ::4, ::4].numpy() - g[f"guided_map_sub4_{t}"]).max() / scale < 1e-4
+
+
+def test_aoa_gradient_batch_vs_oracle():
+    """two images, another head: every (image, word) row against the oracle's per-word BPTT (lock-step batching,
+    the `d_global_img_feature` assignment quirk and the single-head spread)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    from oracle import lrp_oracle as O
+    V, T, head = 211, 4, 2
+    sd = weights.make_aoa_state(seed=4, vocab_size=V)
+    eng = AOAEngine(sd)
+    imgs = torch.from_numpy(weights.make_images(9, 2))
+    caps = torch.from_numpy(weights.make_captions(10, 2, T, V))
+    _, r_words, d_feat, tr, enc = eng.explain_batch_gradient(caps, head, imgs, return_features=True)
+    sdt = O.state_to_torch(sd)
+    for b in range(2):
+        F_pix = enc["feats"][b].cpu()                      # same features: the decoder alone is compared strictly
+        otr = O.aoa_trace(sdt, F_pix, caps[b].numpy(), grad=True)
+        for t in range(T):
+            w_df, w_rw = O.aoa_gradient_wordt(sdt, otr, t, head)
+            assert rel_err(d_feat[b, t].cpu(), w_df) < 1e-4, (b, t)
+            assert np.abs(r_words[b, t, :t + 1].cpu().numpy() - w_rw.numpy()).max() < 5e-5
+
+
+def test_aoa_drop_in_classes(case):
+    """`ExplainAOAGradient` / `ExplainAOAGuidedGradient` / `ExplainAOAGradCam`: the reference's surface"""
+    import types
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import ExplainAOAGradient, ExplainAOAGuidedGradient, ExplainAOAGradCam
+    g, sd, eng, img, cap, head = case
+    args = types.SimpleNamespace(embed_dim=512, hidden_dim=512, encoder="vgg16", height=224, width=224, save_path="/tmp",
+                                 dataset="synthetic", weight=None, num_head=8)
+    wm = weights.make_word_map(int(g["V"]))
+    ce = [int(c) for c in g["caption"]]
+    maps, rws = ExplainAOAGradient(args, wm, model=sd).explain_caption(img, head, caption_encode=ce)
+    assert len(maps) == 3 and tuple(maps[0].shape) == (1, 3, 224, 224) and tuple(rws[2].shape) == (3,)
+    assert np.abs(rws[2].cpu().numpy() - g["r_words_2"]).max() < 5e-5
+    gm, _ = ExplainAOAGuidedGradient(args, wm, model=sd).explain_caption(img, head, caption_encode=ce)
+    assert_close_modulo_pool_ties(gm[1][:, :, ::4, ::4].cpu(), g["guided_map_sub4_1"], what="guided drop-in", **E2E)
+    cams, _ = ExplainAOAGradCam(args, wm, model=sd).explain_caption(img, head, caption_encode=ce)
+    assert tuple(cams[0].shape) == (1, 196) and np.abs(cams[0].cpu().numpy() - g["cam_0"]).max() < 1e-3
