@@ -41,6 +41,9 @@ MODE_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "bf16x6: exact 3-way bf
 MODE_KERNEL = {0: "conv_mfma_kernel<56,16,1,4,9,REL>", 1: "conv_bf16x6_kernel<56,1,4,true,REL>",
                2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>"}
 PRODUCTS = {0: 1, 1: 6, 2: 3}
+# arithmetic the contractions run in: all tensors are fp32; modes 1 / 2 evaluate each fp32 product as split 16-bit MFMA
+# products with fp32 accumulation (fp32-grade results), everything else is fp32 VALU
+MODE_DTYPE = {0: "f32", 1: "f32 (bf16x6 split-product MFMA, f32 accumulate)", 2: "f32 (f16x3 split-product MFMA, f32 accumulate)"}
 # HBM traffic of ONE launch of that kernel over 320 maps, from rocprofv3 --pmc (separate passes, tools/pmc_passes.sh;
 # profiles/r01_pmc_traffic_f16x3.txt, ..._bf16x6.txt, r01_pmc_traffic.txt): (2 x FETCH_SIZE raw [gfx950 reports half of wide streaming reads,
 # MI355X_MICROARCH.md §HBM] + WRITE_SIZE) per launch.  Scaled linearly with the map count.
@@ -209,7 +212,7 @@ def main():
         out = {"metric": "LRP relevance maps/sec (VGG16+gridTD, 224x224, 20-token caption)",
                "value": round(n_maps / dt, 2), "unit": "maps/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": MODE_DTYPE[mode], "data": "synthetic",
                "config": {"workload": "BASELINE configs[1]: batch-16 224x224 images x 20-word captions per GPU, "
                                       "VGG16+gridTD, LRP alpha1beta0 (conv) + epsilon (decoder), V=9586, random-init",
                           "images_per_gpu": B, "words": T, "vocab": V, "maps_per_step": world * B * T,
