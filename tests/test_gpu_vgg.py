@@ -407,6 +407,31 @@ def test_full_size_chain_properties(ops):
     assert err.max().item() < TOL, err.max().item()
 
 
+def test_f16x3_chain_extreme_scales(ops, gridtd_case):
+    """per-map power-of-two operand scaling of the f16x3 kernels at the edges: the same target scaled by 1e-30, 1 and
+    1e+25 gives the same map up to that factor (relevance propagation is linear; scales are exact powers of two away
+    from the fp16 range), an all-zero target gives an all-zero map (amax = 0 -> scale 1), and a non-finite target is
+    caught by the reference's finiteness assert (lrp_modules.py:154) instead of being silently rescaled."""
+    g, sd, img = gridtd_case
+    vgg = _vgg(ops, sd)
+    feats = vgg.forward(img.cuda())
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    base = torch.randn(1, 196, 512, device="cuda", generator=gen) * (feats > 0)
+    scales = [1e-30, 1.0, 1e25, 0.0]
+    r_feat = torch.cat([base * s_ for s_ in scales])
+    maps = vgg.relevance(r_feat, torch.zeros(4, dtype=torch.int32, device="cuda")).cpu().double()
+    ref = maps[1]
+    assert ref.abs().max() > 0
+    assert rel_err(maps[0] / 1e-30, ref) < 1e-5
+    assert rel_err(maps[2] / 1e25, ref) < 1e-5
+    assert maps[3].abs().max().item() == 0.0
+    bad = base.clone()
+    bad[0, 5, 7] = float("inf")
+    out = vgg.relevance(bad, torch.zeros(1, dtype=torch.int32, device="cuda"))
+    with pytest.raises(AssertionError):
+        ops.check_relevance(out, finite=True)
+
+
 def test_errors_raise_like_the_reference(ops):
     z = torch.zeros(1, 8, device="cuda")
     with pytest.raises(AssertionError):          # lrp_wrapper.py:81 `assert sample.grad.sum()!=0`
