@@ -156,6 +156,21 @@ int lrpx_set_conv_mode(int mode);
  * the layer input); 0: bf16x6 / fp32 as selected by the conv mode.  Negative: query.  Returns the previous value. */
 int lrpx_set_forward_f16(int enable);
 
+/* ---- device-side consumers of the relevance maps (evaluation.py) -------------------------- */
+/* (n,c,hw) -> (n,hw): mode 0 mean over channels (evaluation.py:134), 1 mean of max(x,0) (:410-412), 2 mean of max(-x,0) (:406-408) */
+int lrpx_spatial_reduce(const float* maps, int n, int c, long hw, int mode, float* out, void* stream);
+/* `_project_maxabs` (evaluation.py:338-343): every map divided by its max |x| in place (all-zero maps stay zero) */
+int lrpx_project_maxabs(float* x, int n, long per, void* stream);
+/* `block_image` (evaluation.py:57-80): sums over patch x patch squares, mask = 0 on the k squares with the largest sum
+ * (ties: lower index first), 1 elsewhere; spatial, mask: (n,h,w) */
+int lrpx_patch_mask(const float* spatial, int n, int h, int w, int patch, int k, float* mask, void* stream);
+/* `_calculate_overlaped_pixels` (evaluation.py:313-336) for every threshold: boxes [n][4] = x0,y0,x1,y1 (pixels),
+ * out[n][nthr] = sum of the relevance > thr inside the box / sum of the relevance > thr (0 if that is 0, capped at 1) */
+int lrpx_bbox_ratio(const float* spatial, int n, int h, int w, const int32_t* boxes, const float* thresholds, int nthr,
+                    float* out, void* stream);
+/* tpfp statistics (evaluation.py:506-513): out[n][4] = mean, mean |x|, mean of the positive entries (0 if none), max */
+int lrpx_map_stats(const float* spatial, int n, long per, float* out4, void* stream);
+
 /* ---- VGG16 encoder: trace + relevance chain ------------------------------------------------------ */
 /* bytes of the packed-weight blob / per-batch trace / relevance workspace */
 size_t lrpx_vgg16_packed_bytes(void);

@@ -81,6 +81,11 @@ SIGNATURES = {
     "lrpx_aoa_grad_step": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaGradState), _i, _i, _f]),
     "lrpx_aoa_grad_pix": (_i, [C.POINTER(AoaTrace), _i, _f, _f, _f, _i, _f]),
     "lrpx_keep_cols": (_i, [_f, _l, _i, _i, _i, _f]),
+    "lrpx_spatial_reduce": (_i, [_f, _i, _i, _l, _i, _f, _f]),
+    "lrpx_project_maxabs": (_i, [_f, _i, _l, _f]),
+    "lrpx_patch_mask": (_i, [_f, _i, _i, _i, _i, _i, _f, _f]),
+    "lrpx_bbox_ratio": (_i, [_f, _i, _i, _i, _f, _f, _i, _f, _f]),
+    "lrpx_map_stats": (_i, [_f, _i, _l, _f, _f]),
     "lrpx_amax_maps": (_i, [_f, _i, _l, _f, _f]),
     "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),
     "lrpx_accumulate": (_i, [_f, _f, _l, _f]),

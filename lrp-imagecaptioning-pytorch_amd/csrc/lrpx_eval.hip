@@ -1,0 +1,205 @@
+// Device-side consumers of the relevance maps: the reductions the reference's evaluation
+// experiments run on every map after copying it to the host (evaluation.py) - here the maps never leave HBM.
+//   spatial reduce      evaluation.py:124-134 (mean over channels), :410-412 (mean of the positive / negative part)
+//   _project_maxabs     evaluation.py:338-343
+//   block_image         evaluation.py:57-80   (8x8 patch sums, the k most relevant patches are masked out)
+//   _calculate_overlaped_pixels   evaluation.py:313-336 (share of the thresholded relevance inside a bounding box)
+//   tpfp statistics     evaluation.py:506-513 (mean, mean |x|, mean of the positives, max, quantiles)
+// All HBM-bound single-pass kernels: one workgroup per map (maps are 50 176 pixels), block reductions in LDS.
+#include <math.h>
+
+#include "common.h"
+
+namespace lrpx {
+
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// 256-thread blocks; red: >= 4 floats of LDS
+__device__ __forceinline__ float bsum(float v, float* red) {
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float bmax(float v, float* red) {
+    v = wmax(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// (n, c, hw) -> (n, hw): mode 0 mean_c(x), 1 mean_c(max(x, 0)), 2 mean_c(max(-x, 0))
+__global__ void spatial_reduce_kernel(const float* __restrict__ maps, int c, long hw, int mode, float* __restrict__ out,
+                                      long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over n*hw
+    if (idx >= total) return;
+    const long n = idx / hw, p = idx - n * hw;
+    float s = 0.f;
+    for (int k = 0; k < c; ++k) {
+        float v = maps[(n * c + k) * hw + p];
+        if (mode == 1) v = fmaxf(v, 0.f);
+        else if (mode == 2) v = fmaxf(-v, 0.f);
+        s += v;
+    }
+    out[idx] = s / (float)c;
+}
+
+__global__ __launch_bounds__(256) void project_maxabs_kernel(float* __restrict__ x, long per) {
+    __shared__ float red[4];
+    float* xm = x + (long)blockIdx.x * per;
+    float m = 0.f;
+    for (long i = threadIdx.x; i < per; i += 256) m = fmaxf(m, fabsf(xm[i]));
+    m = bmax(m, red);
+    if (m == 0.f) return;                  // `np.zeros(x.shape)`: the map is all zeros already
+    for (long i = threadIdx.x; i < per; i += 256) xm[i] = xm[i] / m;
+}
+
+// one workgroup per map: patch sums in LDS, k rounds of arg-max (first index wins), then the mask
+__global__ __launch_bounds__(256) void patch_mask_kernel(const float* __restrict__ sp, int h, int w, int patch, int k,
+                                                         float* __restrict__ mask) {
+    extern __shared__ float sm[];          // [np] patch sums, [np] selected flag, [4] + [4] reduction scratch
+    const int nph = h / patch, npw = w / patch, np_ = nph * npw, tid = threadIdx.x;
+    float* psum = sm;
+    float* sel = sm + np_;
+    float* redv = sel + np_;
+    int* redi = reinterpret_cast<int*>(redv + 4);
+    const float* s = sp + (long)blockIdx.x * h * w;
+    for (int q = tid; q < np_; q += 256) {
+        const int py = q / npw, px = q - py * npw;
+        float a = 0.f;
+        for (int y = 0; y < patch; ++y)
+            for (int x = 0; x < patch; ++x) a += s[(long)(py * patch + y) * w + px * patch + x];
+        psum[q] = a; sel[q] = 0.f;
+    }
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int q = tid; q < np_; q += 256)
+            if (sel[q] == 0.f && (psum[q] > bv)) { bv = psum[q]; bi = q; }
+        // wave arg-max (larger value, then smaller index), then across the 4 waves
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { redv[tid >> 6] = bv; redi[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = redv[0]; int i = redi[0];
+            for (int j = 1; j < 4; ++j)
+                if (redv[j] > v || (redv[j] == v && redi[j] < i)) { v = redv[j]; i = redi[j]; }
+            if (i != 0x7fffffff) sel[i] = 1.f;
+        }
+        __syncthreads();
+    }
+    float* m = mask + (long)blockIdx.x * h * w;
+    for (int i = tid; i < h * w; i += 256) {
+        const int y = i / w, x = i - y * w;
+        m[i] = sel[(y / patch) * npw + x / patch] != 0.f ? 0.f : 1.f;
+    }
+}
+
+// ratio[n][j] = sum(rel[rel > thr_j] inside box) / sum(rel[rel > thr_j]), 0 if the total is 0, capped at 1
+__global__ __launch_bounds__(256) void bbox_ratio_kernel(const float* __restrict__ sp, int h, int w,
+                                                         const int* __restrict__ boxes, const float* __restrict__ thr,
+                                                         int nthr, float* __restrict__ out) {
+    __shared__ float red[4];
+    const float* s = sp + (long)blockIdx.x * h * w;
+    const int x0 = boxes[blockIdx.x * 4], y0 = boxes[blockIdx.x * 4 + 1], x1 = boxes[blockIdx.x * 4 + 2],
+              y1 = boxes[blockIdx.x * 4 + 3];
+    for (int j = 0; j < nthr; ++j) {
+        const float t = thr[j];
+        float tot = 0.f, ins = 0.f;
+        for (int i = threadIdx.x; i < h * w; i += 256) {
+            const float v = s[i];
+            if (!(v <= t)) {                    // `relevance[relevance <= threshold] = 0`
+                const int y = i / w, x = i - y * w;
+                tot += v;
+                if (y >= y0 && y < y1 && x >= x0 && x < x1) ins += v;
+            }
+        }
+        tot = bsum(tot, red);
+        ins = bsum(ins, red);
+        if (threadIdx.x == 0) {
+            float r = 0.f;
+            if (tot != 0.f) { r = ins / tot; if (r > 1.f) r = 1.f; }
+            out[(long)blockIdx.x * nthr + j] = r;
+        }
+    }
+}
+
+// out[n] = {mean, mean |x|, sum(max(x,0)) / count(x > 0) (0 if none), max}
+__global__ __launch_bounds__(256) void map_stats_kernel(const float* __restrict__ sp, long per, float* __restrict__ out) {
+    __shared__ float red[4];
+    const float* s = sp + (long)blockIdx.x * per;
+    float sm_ = 0.f, sa = 0.f, spos = 0.f, cnt = 0.f, mx = -INFINITY;
+    for (long i = threadIdx.x; i < per; i += 256) {
+        const float v = s[i];
+        sm_ += v; sa += fabsf(v); mx = fmaxf(mx, v);
+        if (v > 0.f) { spos += v; cnt += 1.f; }
+    }
+    sm_ = bsum(sm_, red); sa = bsum(sa, red); spos = bsum(spos, red); cnt = bsum(cnt, red); mx = bmax(mx, red);
+    if (threadIdx.x == 0) {
+        float* o = out + (long)blockIdx.x * 4;
+        o[0] = sm_ / (float)per; o[1] = sa / (float)per; o[2] = cnt > 0.f ? spos / cnt : 0.f; o[3] = mx;
+    }
+}
+
+}  // namespace lrpx
+
+using namespace lrpx;
+
+extern "C" {
+
+int lrpx_spatial_reduce(const float* maps, int n, int c, long hw, int mode, float* out, void* stream) {
+    LRPX_REQUIRE(maps && out && n > 0 && c > 0 && hw > 0 && mode >= 0 && mode <= 2, "spatial_reduce: bad arguments");
+    const long total = (long)n * hw;
+    hipLaunchKernelGGL(spatial_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, maps,
+                       c, hw, mode, out, total);
+    return check_launch("spatial_reduce");
+}
+
+int lrpx_project_maxabs(float* x, int n, long per, void* stream) {
+    LRPX_REQUIRE(x && n > 0 && per > 0, "project_maxabs: bad arguments");
+    hipLaunchKernelGGL(project_maxabs_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, per);
+    return check_launch("project_maxabs");
+}
+
+int lrpx_patch_mask(const float* spatial, int n, int h, int w, int patch, int k, float* mask, void* stream) {
+    LRPX_REQUIRE(spatial && mask && n > 0 && patch > 0 && h % patch == 0 && w % patch == 0, "patch_mask: bad arguments");
+    const int np_ = (h / patch) * (w / patch);
+    LRPX_REQUIRE(k >= 0 && k <= np_ && np_ <= 8192, "patch_mask: k must not exceed the number of patches (<= 8192)");
+    hipLaunchKernelGGL(patch_mask_kernel, dim3(n), dim3(256), (size_t)(2 * np_ + 8) * sizeof(float), (hipStream_t)stream,
+                       spatial, h, w, patch, k, mask);
+    return check_launch("patch_mask");
+}
+
+int lrpx_bbox_ratio(const float* spatial, int n, int h, int w, const int32_t* boxes, const float* thresholds, int nthr,
+                    float* out, void* stream) {
+    LRPX_REQUIRE(spatial && boxes && thresholds && out && n > 0 && h > 0 && w > 0 && nthr > 0, "bbox_ratio: bad arguments");
+    hipLaunchKernelGGL(bbox_ratio_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, spatial, h, w, boxes, thresholds, nthr,
+                       out);
+    return check_launch("bbox_ratio");
+}
+
+int lrpx_map_stats(const float* spatial, int n, long per, float* out4, void* stream) {
+    LRPX_REQUIRE(spatial && out4 && n > 0 && per > 0, "map_stats: bad arguments");
+    hipLaunchKernelGGL(map_stats_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, spatial, per, out4);
+    return check_launch("map_stats");
+}
+
+}  // extern "C"

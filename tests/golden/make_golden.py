@@ -413,6 +413,39 @@ def gen_aoa_gradient(out, weights, T=3, V=11027, seed=0, head=5):
     print("aoa_gradient_T3.npz written")
 
 
+def gen_eval(out, weights, seed=0):
+    """Relevance-map consumers of evaluation.py called on seeded maps: `block_image` (:57-80),
+    `_calculate_overlaped_pixels` (:313-336), `_project_maxabs` (:338-343).  (2,3,224,224) maps with the statistics
+    of real relevance maps: heavy-tailed, both signs, one of them with an exactly-zero border."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    plt.show = lambda *a, **k: None
+    import evaluation
+    rs = np.random.RandomState(seed)
+    maps = (rs.standard_normal((2, 3, 224, 224)) * np.exp(2 * rs.standard_normal((2, 3, 224, 224)))).astype(np.float32)
+    maps[1, :, :16, :] = 0
+    maps[1, :, :, -24:] = 0
+    ex = types.SimpleNamespace(model=types.SimpleNamespace(eval=lambda: None), word_map={"<start>": 0})
+    ev = evaluation.EvaluationExperiments(ex)
+    g = dict(seed=np.int64(seed))        # the maps are regenerated from the seed by the tests (same two lines)
+    boxes = np.array([[30, 40, 150, 200], [0, 0, 224, 100]], np.int64)
+    g["boxes"] = boxes
+    thresholds = [0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
+    g["thresholds"] = np.array(thresholds, np.float32)
+    for i in range(2):
+        spatial = torch.from_numpy(maps[i:i + 1]).mean(dim=(0, 1))                    # evaluation.py:134
+        g[f"mask_{i}"] = ev.block_image(spatial).numpy().astype(np.uint8)
+        rel = np.mean(np.maximum(maps[i:i + 1], 0), axis=(0, 1))                      # evaluation.py:410-411
+        rel = ev._project_maxabs(rel)
+        g[f"proj_{i}"] = rel.astype(np.float32)
+        work = rel.copy()
+        g[f"ratio_{i}"] = np.array([ev._calculate_overlaped_pixels(list(boxes[i]), work, t) for t in thresholds], np.float64)
+    plt.close("all")
+    np.savez(os.path.join(out, "eval_consumers.npz"), **g)
+    print("eval_consumers.npz written; ratios:", g["ratio_0"][:3], g["ratio_1"][:3])
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -431,7 +464,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -457,6 +490,8 @@ def main():
         gen_gradcam(HERE, weights)
     if "aoa_gradient" in todo:
         gen_aoa_gradient(HERE, weights)
+    if "eval" in todo:
+        gen_eval(HERE, weights)
 
 
 if __name__ == "__main__":

@@ -33,3 +33,21 @@ for name, fn in runs.items():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     print(f"{name:52s} {dt*1e3:8.2f} ms/step  {sizes.get(name, B*T)/dt:9.1f} maps/s")
+
+# device-side consumers of the maps (evaluation.py reductions): 320 maps that never leave HBM
+from lrp_amd import evaluation as ev
+maps, _ = eng.explain_batch(images, caps)
+m = maps.view(B * T, 3, 224, 224)
+boxes = torch.tensor([[30, 40, 150, 200]] * (B * T))
+def consumers():
+    sp = ev.spatial_relevance(m, "mean")
+    ev.block_image(sp, 8, 20)
+    ev.overlapped_pixels(ev.project_maxabs(ev.spatial_relevance(m, "pos")), boxes)
+    ev.map_statistics(sp)
+consumers(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10): consumers()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 10
+gb = B * T * 224 * 224 * 4 * (3 + 1 + 1 + 1 + 3 + 1 + 1 + 1 + 10 + 1) / 1e9
+print(f"{'map consumers (mask, bbox ratios x10, statistics)':52s} {dt*1e3:8.2f} ms/step  {B*T/dt:9.1f} maps/s  ~{gb/dt:.0f} GB/s of algorithmic traffic")
