@@ -171,6 +171,13 @@ int lrpx_bbox_ratio(const float* spatial, int n, int h, int w, const int32_t* bo
 /* tpfp statistics (evaluation.py:506-513): out[n][4] = mean, mean |x|, mean of the positive entries (0 if none), max */
 int lrpx_map_stats(const float* spatial, int n, long per, float* out4, void* stream);
 
+/* `LRPutil.heatmap(LRPutil.gamma(hm))` (LRPtools/utils.py:67-145) as the explainers' visualize_explanations call it
+ * (models/gridTDmodel.py:1196-1198): gamma correction with the map's own max |x|, sum over the channels, projection to
+ * [0, 255] with the summed map's max |x|, colour-map lookup.  maps (n,c,hw) -> out (n,hw,3); lut [nlut][3] (the
+ * colour map sampled at its nlut = 256 entries); tmp: n*hw floats of scratch. */
+int lrpx_heatmap(const float* maps, int n, int c, long hw, float gamma, const float* lut, int nlut, float* tmp, float* out,
+                 void* stream);
+
 /* ---- VGG16 encoder: trace + relevance chain ------------------------------------------------------ */
 /* bytes of the packed-weight blob / per-batch trace / relevance workspace */
 size_t lrpx_vgg16_packed_bytes(void);

@@ -5,6 +5,8 @@
 //   block_image         evaluation.py:57-80   (8x8 patch sums, the k most relevant patches are masked out)
 //   _calculate_overlaped_pixels   evaluation.py:313-336 (share of the thresholded relevance inside a bounding box)
 //   tpfp statistics     evaluation.py:506-513 (mean, mean |x|, mean of the positives, max, quantiles)
+//   heat maps           LRPtools/utils.py:67-145 `gamma` + `heatmap` (+ `project`), as the explainers' visualize_explanations
+//                       call them (models/gridTDmodel.py:1196-1198): (N,C,H,W) relevance -> (N,H,W,3) colours
 // All HBM-bound single-pass kernels: one workgroup per map (maps are 50 176 pixels), block reductions in LDS.
 #include <math.h>
 
@@ -159,6 +161,44 @@ __global__ __launch_bounds__(256) void map_stats_kernel(const float* __restrict_
     }
 }
 
+// gamma(X) (utils.py:97-145, minamp = 0, maxamp = max|X| of the map) followed by heatmap(.) (utils.py:67-90: sum over
+// the channels, project to [0,255] with the map's own max |.|, integer colour-map lookup).  One workgroup per map;
+// `tmp` holds the channel sums between the two passes.
+__global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ maps, int c, long hw, float gamma_,
+                                                      const float* __restrict__ lut, int nlut, float* __restrict__ tmp,
+                                                      float* __restrict__ out) {
+    __shared__ float red[4];
+    const float* m = maps + (long)blockIdx.x * c * hw;
+    float* t = tmp + (long)blockIdx.x * hw;
+    float amax = 0.f;
+    for (long i = threadIdx.x; i < c * hw; i += 256) amax = fmaxf(amax, fabsf(m[i]));
+    amax = bmax(amax, red);
+    float tmax = 0.f;
+    for (long p = threadIdx.x; p < hw; p += 256) {
+        float s = 0.f;
+        for (int k = 0; k < c; ++k) {
+            float x = m[k * hw + p];
+            if (amax != 0.f) {                                   // `if maxamp == 0: return X`
+                x = x / amax;
+                x = (x >= 0.f ? powf(x, gamma_) : -powf(-x, gamma_)) * amax;
+            }
+            s += x;
+        }
+        t[p] = s;
+        tmax = fmaxf(tmax, fabsf(s));
+    }
+    tmax = bmax(tmax, red);
+    float* o = out + (long)blockIdx.x * hw * 3;
+    for (long p = threadIdx.x; p < hw; p += 256) {
+        float x = t[p];
+        if (tmax != 0.f) x = x / tmax;                           // project(): only maps with a non-zero maximum are scaled
+        x = fminf(fmaxf((x + 1.f) * 0.5f, 0.f), 1.f) * 255.f;   // (X+1)/2, clip, output_range (0, 255)
+        int idx = (int)x;                                        // .astype(np.int64) truncates
+        idx = idx < 0 ? 0 : (idx >= nlut ? nlut - 1 : idx);
+        o[p * 3] = lut[idx * 3]; o[p * 3 + 1] = lut[idx * 3 + 1]; o[p * 3 + 2] = lut[idx * 3 + 2];
+    }
+}
+
 }  // namespace lrpx
 
 using namespace lrpx;
@@ -200,6 +240,13 @@ int lrpx_map_stats(const float* spatial, int n, long per, float* out4, void* str
     LRPX_REQUIRE(spatial && out4 && n > 0 && per > 0, "map_stats: bad arguments");
     hipLaunchKernelGGL(map_stats_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, spatial, per, out4);
     return check_launch("map_stats");
+}
+
+int lrpx_heatmap(const float* maps, int n, int c, long hw, float gamma, const float* lut, int nlut, float* tmp, float* out,
+                 void* stream) {
+    LRPX_REQUIRE(maps && lut && tmp && out && n > 0 && c > 0 && hw > 0 && nlut > 0 && gamma > 0.f, "heatmap: bad arguments");
+    hipLaunchKernelGGL(heatmap_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, maps, c, hw, gamma, lut, nlut, tmp, out);
+    return check_launch("heatmap");
 }
 
 }  // extern "C"

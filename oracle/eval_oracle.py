@@ -52,3 +52,21 @@ def map_statistics(rel):
     pos = rel > 0
     mean_pos = 0.0 if pos.sum() == 0 else float(np.maximum(rel, 0).sum(dtype=np.float64) / pos.sum())
     return np.array([rel.mean(dtype=np.float64), np.abs(rel).mean(dtype=np.float64), mean_pos, rel.max()], np.float64)
+
+
+def relevance_heatmap(m, lut, gamma=0.7):
+    """LRPtools/utils.py `gamma` (:97-145, minamp 0, maxamp = max|X|) then `heatmap` (:67-90) with `project` (:34-52):
+    m (C,H,W) -> (H,W,3) colours from the 256-entry table `lut`."""
+    x = m.astype(np.float32)
+    maxamp = np.abs(x).max()
+    if maxamp != 0:
+        xs = x / maxamp
+        y = np.where(xs >= 0, np.abs(xs) ** np.float32(gamma), -(np.abs(xs) ** np.float32(gamma))).astype(np.float32) * maxamp
+    else:
+        y = x
+    t = y.sum(axis=0)
+    absmax = np.abs(t).max()
+    if absmax != 0:
+        t = t / absmax
+    t = np.clip((t + 1) / 2, 0, 1) * 255
+    return lut[t.astype(np.int64)]

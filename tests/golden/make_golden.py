@@ -441,6 +441,13 @@ def gen_eval(out, weights, seed=0):
         g[f"proj_{i}"] = rel.astype(np.float32)
         work = rel.copy()
         g[f"ratio_{i}"] = np.array([ev._calculate_overlaped_pixels(list(boxes[i]), work, t) for t in thresholds], np.float64)
+    # heat-map rendering of visualize_explanations (models/gridTDmodel.py:1196-1198): LRPutil.gamma + LRPutil.heatmap
+    from LRPtools import utils as LRPutil
+    for i in range(2):
+        hm = maps[i:i + 1].transpose(0, 2, 3, 1).copy()
+        hm = LRPutil.heatmap(LRPutil.gamma(hm))[0]                                    # (224,224,3) float32
+        g[f"heatmap_sub2_{i}"] = hm[::2, ::2].astype(np.float32)
+    g["lut"] = np.asarray(plt.cm.get_cmap("seismic")(np.arange(256)))[:, :3].astype(np.float32)
     plt.close("all")
     np.savez(os.path.join(out, "eval_consumers.npz"), **g)
     print("eval_consumers.npz written; ratios:", g["ratio_0"][:3], g["ratio_1"][:3])

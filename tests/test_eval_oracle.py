@@ -34,3 +34,13 @@ def test_consumers_vs_reference():
     assert np.array_equal(E.project_maxabs(np.zeros((4, 4), np.float32)), np.zeros((4, 4), np.float32))
     st = E.map_statistics(np.array([[1.0, -3.0], [0.0, 2.0]], np.float32))
     assert np.allclose(st, [0.0, 1.5, 1.5, 2.0])
+
+
+def test_heatmap_vs_reference():
+    # LRPutil.heatmap(LRPutil.gamma(hm)) of /root/reference/LRPtools/utils.py on the seeded maps (every 2nd pixel stored)
+    g = np.load(os.path.join(GOLDEN, "eval_consumers.npz"))
+    maps = golden_maps(int(g["seed"]))
+    for i in range(2):
+        hm = E.relevance_heatmap(maps[i], g["lut"])
+        d = np.abs(hm[::2, ::2] - g[f"heatmap_sub2_{i}"]).max(axis=-1)
+        assert (d > 0).mean() < 1e-3 and d.max() < 0.05            # at most a LUT step on a few rounding boundaries

@@ -67,3 +67,25 @@ def test_statistics_and_edge_cases_vs_oracle(ev):
         ev.block_image(torch.zeros(1, 30, 30, device="cuda"), 8, 2)             # evaluation.py:59-60 asserts
     with pytest.raises(ValueError):
         ev.block_image(torch.zeros(1, 16, 16, device="cuda"), 8, 5)             # more patches than exist (:65 assert)
+
+
+def test_relevance_heatmap_vs_reference():
+    """gamma + heatmap of LRPtools/utils.py in one kernel: colours equal the reference's except where powf rounding moves
+    a value across an integer boundary of the 256-entry table (one table step, < 0.2 % of the pixels)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd.LRPtools import utils as U
+    g = np.load(os.path.join(GOLDEN, "eval_consumers.npz"))
+    maps = torch.from_numpy(golden_maps(int(g["seed"]))).cuda()
+    hm = U.relevance_heatmap(maps, gamma=0.7, lut=torch.from_numpy(g["lut"])).cpu().numpy()
+    assert hm.shape == (2, 224, 224, 3)
+    for i in range(2):
+        d = np.abs(hm[i, ::2, ::2] - g[f"heatmap_sub2_{i}"]).max(axis=-1)
+        assert (d > 0).mean() < 2e-3 and d.max() < 0.05, ((d > 0).mean(), d.max())
+    zero = U.relevance_heatmap(torch.zeros(1, 3, 8, 8, device="cuda"), lut=torch.from_numpy(g["lut"])).cpu().numpy()
+    assert np.allclose(zero, g["lut"][127])            # all-zero map: (0+1)/2*255 = 127.5 -> entry 127 everywhere
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        return
+    assert np.allclose(U.colormap_lut("seismic").cpu().numpy(), g["lut"], atol=1e-6)
