@@ -222,6 +222,8 @@ int lrpx_mean_pixels(const float* f, float* avg, int B, int P, int C, void* stre
 int lrpx_relu(const float* x, float* y, long n, void* stream);
 /* first maximum per row -> int64 (torch.argmax / topk(1), models/gridTDmodel.py:499, :849) */
 int lrpx_argmax_rows(const float* x, long ld, int rows, int n, long long* out, void* stream);
+/* greedy `sample_next_word` (models/gridTDmodel.py:522-526): argmax of log_softmax(x[r]) and its value */
+int lrpx_argmax_logprob_rows(const float* x, long ld, int rows, int n, long long* out, float* logprob, void* stream);
 /* logit[b*T+t] = fc.weight[tok[b][t+1]] . hc[b][t] + fc.bias[...]  (the one entry of `predictions`
  * that explain_caption_wordt reads, models/gridTDmodel.py:1027,1034) */
 int lrpx_target_logit(const float* hc, const float* fcw, const float* fcb, const long long* tok, int tok_ld,
@@ -242,6 +244,18 @@ typedef struct lrpx_gridtd_trace {
 int lrpx_gridtd_fwd_pre(const lrpx_gridtd_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
                         int tok_ld, void* stream);
 int lrpx_gridtd_fwd_lstm(const lrpx_gridtd_trace* tr, int t, const float* zz, int ldz, int which, void* stream);
+/* LRP-inference decoding, `GridTDModel.sample_lrp` / `forwardlrp_context` (models/gridTDmodel.py:631-702, :579-630).
+ * Their forward differs from the model's own in one place: the sentinel gate sees the NEW h1 (:672, :610).
+ *   fwd_gate_input: xg[b] = [h2_old | glob | emb | h1_new]  ((B, 2E+2H) floats), the input of x_gate|h_gate;
+ *   fwd_sentinel:   s[b,t] = sigmoid(zg[b]) * tanh(c1_new)  with zg = [x_gate|h_gate] xg + biases, (B, ldz);
+ *   lrp_reweight:   `get_lrp_weight_step` (:548-577) for step t: k = argmax pred[b]; unless skip[k] (stop words and
+ *                   special tokens), R = pred[b][k] goes back through fc (epsilon rule) to h2 + ctx_hat and is split
+ *                   between the two; both vectors are normalised to weights x / max|x| + 1 (LRPtools/utils.py:55-64);
+ *                   hcw[b] = ctx_hat * w_ctx + w_h2 * h2, the re-weighted fc input (:687).  skip: V bytes. */
+int lrpx_gridtd_fwd_gate_input(const lrpx_gridtd_trace* tr, int t, float* xg, void* stream);
+int lrpx_gridtd_fwd_sentinel(const lrpx_gridtd_trace* tr, int t, const float* zg, int ldz, void* stream);
+int lrpx_gridtd_lrp_reweight(const lrpx_gridtd_trace* tr, int t, const float* pred, long ld, int V, const float* fc_w,
+                             const unsigned char* skip, float* hcw, void* stream);
 /* scratch: [B][3*P] floats (scores, W_g h, W_s s) */
 int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img,
                               const float* Wg, const float* Ws, const float* bs, const float* wh, float* scratch,

@@ -299,6 +299,111 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// LRP-inference decoding (models/gridTDmodel.py:548-577, :631-702): per step the predicted word's logit is
+// redistributed to the two fc summands, both relevance vectors become weights around 1, and the logits are
+// recomputed from the re-weighted fc input.
+// ------------------------------------------------------------------------------------------------
+// xg[b] = [h2_old | glob | emb | h1_NEW]: the sentinel gate of sample_lrp sees the new h1 (:672), not h_{t-1}
+__global__ void gridtd_gate_input_kernel(GridFwd g, int t, float* __restrict__ xg) {
+    const int b = blockIdx.x;
+    const int W = 2 * g.E + 2 * g.H;
+    const float* src = g.xh1 + ((long)b * g.T + t) * W;
+    const float* h1n = g.h1 + ((long)b * (g.T + 1) + t + 1) * g.H;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) xg[(long)b * W + c] = c < W - g.H ? src[c] : h1n[c - (W - g.H)];
+}
+
+// s = sigmoid(gate) * tanh(c1_new)   (:672-673)
+__global__ void gridtd_sentinel_kernel(GridFwd g, int t, const float* __restrict__ zg, int ldz) {
+    const int b = blockIdx.x;
+    const long st1 = ((long)b * (g.T + 1) + t + 1) * g.H, tr = ((long)b * g.T + t) * g.H;
+    for (int c = threadIdx.x; c < g.H; c += blockDim.x) {
+        const float sg = sigmoidf_(zg[(long)b * ldz + c]);
+        g.s[tr + c] = sg * tanhf(g.c1[st1 + c]);
+        if (g.sgate) g.sgate[tr + c] = sg;
+    }
+}
+
+// get_lrp_weight_step (:548-577) + the re-weighted fc input (:687).  One block per image, H = 512, 256 threads.
+__global__ __launch_bounds__(256) void gridtd_lrp_reweight_kernel(GridFwd g, int t, const float* __restrict__ pred,
+                                                                  long ld, int V, const float* __restrict__ fcw,
+                                                                  const unsigned char* __restrict__ skip,
+                                                                  float* __restrict__ hcw) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    __shared__ float red[8];
+    const int b = blockIdx.x, H = g.H, tid = threadIdx.x;
+    const float* r = pred + (long)b * ld;
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) { const float v = r[i]; if (v > best) { best = v; idx = i; } }
+    bv[tid] = best; bi[tid] = idx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float v = bv[tid + s]; const int i2 = bi[tid + s];
+            if (v > bv[tid] || (v == bv[tid] && i2 < bi[tid])) { bv[tid] = v; bi[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    const int k = min(bi[0], V - 1);            // (all-NaN row: keep the index in range)
+    const float pk = bv[0];
+    const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = ((long)b * g.T + t) * H;
+    float* out = hcw + (long)b * H;
+    if (skip[k]) {                                 // stop words and specials: both weights are 1 (:557-558)
+        for (int c = tid; c < H; c += 256) out[c] = g.ctx_hat[tr + c] * 1.f + 1.f * g.h2[st1 + c];
+        return;
+    }
+    const float zt = stab_eps(pk);
+    float rh[2], rc[2], mh = 0.f, mc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = tid + j * 256;
+        const float h2 = g.h2[st1 + c], ch = g.ctx_hat[tr + c];
+        const float hc = h2 + ch;
+        const float r_hc = (fcw[(long)k * H + c] * hc / zt) * pk;     // one-hot epsilon rule through fc
+        rh[j] = eps_id(r_hc, h2, hc);
+        rc[j] = eps_id(r_hc, ch, hc);
+        mh = fmaxf(mh, fabsf(rh[j])); mc = fmaxf(mc, fabsf(rc[j]));
+    }
+    mh = block_max(mh, red);
+    __syncthreads();
+    mc = block_max(mc, red);
+    if (mh == 0.f) mh = 1.f;                       // LRPtools/utils.py:59
+    if (mc == 0.f) mc = 1.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = tid + j * 256;
+        const float w_h = rh[j] / mh + 1.f, w_c = rc[j] / mc + 1.f;
+        out[c] = g.ctx_hat[tr + c] * w_c + w_h * g.h2[st1 + c];
+    }
+}
+
+// argmax of log_softmax(x) and its value (sample_next_word greedy, :522-526): one block per row
+__global__ __launch_bounds__(256) void argmax_logprob_rows_kernel(const float* __restrict__ x, long ld, int n,
+                                                                  long long* __restrict__ out, float* __restrict__ lp) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    const float* r = x + (long)blockIdx.x * ld;
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) { const float v = r[i]; if (v > best) { best = v; idx = i; } }
+    bv[tid] = best; bi[tid] = idx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float v = bv[tid + s]; const int i2 = bi[tid + s];
+            if (v > bv[tid] || (v == bv[tid] && i2 < bi[tid])) { bv[tid] = v; bi[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    const float mx = bv[0];
+    float se = 0.f;
+    for (int i = tid; i < n; i += 256) se += expf(r[i] - mx);
+    se = block_sum(se, red);
+    if (tid == 0) { out[blockIdx.x] = min(bi[0], n - 1); lp[blockIdx.x] = -logf(se); }   // x[k] - mx = 0
+}
+
+// ------------------------------------------------------------------------------------------------
 // gridTD relevance — models/gridTDmodel.py:1014-1135.  One block (256 threads) per row, H = 512.
 // ------------------------------------------------------------------------------------------------
 struct GridRel {
@@ -924,6 +1029,37 @@ int lrpx_gridtd_fwd_pre(const lrpx_gridtd_trace* tr, int t, const float* glob, c
     hipLaunchKernelGGL(gridtd_fwd_pre_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, glob, emb,
                        tok, tok_ld);
     return check_launch("gridtd_fwd_pre");
+}
+
+int lrpx_gridtd_fwd_gate_input(const lrpx_gridtd_trace* tr, int t, float* xg, void* stream) {
+    LRPX_TRY(check_trace(tr));
+    LRPX_REQUIRE(xg && t >= 0 && t < tr->T, "gridtd_fwd_gate_input: bad arguments");
+    hipLaunchKernelGGL(gridtd_gate_input_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, xg);
+    return check_launch("gridtd_fwd_gate_input");
+}
+
+int lrpx_gridtd_fwd_sentinel(const lrpx_gridtd_trace* tr, int t, const float* zg, int ldz, void* stream) {
+    LRPX_TRY(check_trace(tr));
+    LRPX_REQUIRE(zg && ldz >= tr->H && t >= 0 && t < tr->T, "gridtd_fwd_sentinel: bad arguments");
+    hipLaunchKernelGGL(gridtd_sentinel_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, zg, ldz);
+    return check_launch("gridtd_fwd_sentinel");
+}
+
+int lrpx_gridtd_lrp_reweight(const lrpx_gridtd_trace* tr, int t, const float* pred, long ld, int V, const float* fc_w,
+                             const unsigned char* skip, float* hcw, void* stream) {
+    LRPX_TRY(check_trace(tr));
+    LRPX_REQUIRE(pred && fc_w && skip && hcw && V > 0 && ld >= V && t >= 0 && t < tr->T,
+                 "gridtd_lrp_reweight: bad arguments");
+    hipLaunchKernelGGL(gridtd_lrp_reweight_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, pred,
+                       ld, V, fc_w, skip, hcw);
+    return check_launch("gridtd_lrp_reweight");
+}
+
+int lrpx_argmax_logprob_rows(const float* x, long ld, int rows, int n, long long* out, float* logprob, void* stream) {
+    LRPX_REQUIRE(x && out && logprob && rows > 0 && n > 0, "argmax_logprob_rows: bad arguments");
+    hipLaunchKernelGGL(argmax_logprob_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, out,
+                       logprob);
+    return check_launch("argmax_logprob_rows");
 }
 
 int lrpx_gridtd_fwd_lstm(const lrpx_gridtd_trace* tr, int t, const float* zz, int ldz, int which, void* stream) {

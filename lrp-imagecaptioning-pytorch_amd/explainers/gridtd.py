@@ -121,7 +121,7 @@ class GridTDEngine:
                       bias=self.sd["AdaAttention.W_v_proj.bias"], out0=enc["att_img"])
         return enc
 
-    def _step(self, tr, enc, t, tokens, model_bias):
+    def _step(self, tr, enc, t, tokens, model_bias, after_lstm1=None):
         lib = _lib.load()
         st = stream_ptr()
         B, T, H, E = tr["B"], tr["T"], self.H, self.E
@@ -138,6 +138,8 @@ class GridTDEngine:
         check(lib.lrpx_linear_small(ptr_at(tr["xh1"], t * W1), T * W1, ptr(self.Wcat1), ptr(self.bcat1), ptr(zz1),
                                     5 * H, B, W1, 5 * H, 0, st))
         check(lib.lrpx_gridtd_fwd_lstm(c, t, ptr(zz1), 5 * H, 1, st))
+        if after_lstm1 is not None:
+            after_lstm1(t)
         aa = "AdaAttention."
         scr = tr["_att_scr"]
         check(lib.lrpx_gridtd_fwd_attention(c, t, ptr(enc["Vp"]), ptr(enc["att_img"]), ptr(sd[aa + "W_g_proj.weight"]),
@@ -194,6 +196,51 @@ class GridTDEngine:
             unfinished = unfinished & (nxt != end_id)          # token bookkeeping (integers), :500-505
             toks[:, t + 1] = nxt * unfinished
         return toks
+
+    def sample_lrp(self, enc, max_length, start_id, end_id, skip_ids):
+        """GridTDModel.sample_lrp, greedy (gridTDmodel.py:631-702): LRP-inference decoding.  Every step's logits are
+        recomputed from the fc input re-weighted by the predicted word's relevance (`get_lrp_weight_step` :548-577)
+        before the next word is taken.  `skip_ids`: ids exempt from the re-weighting (the reference's STOP_WORDS and
+        special tokens).  Returns (seq int64 (B,max_length), seq_logprobs float32 (B,max_length)); like the reference,
+        tokens after <end> are 0 and nothing is written once every sequence has finished (:699-700)."""
+        lib = _lib.load()
+        B, T, H, E = enc["B"], max_length, self.H, self.E
+        W1 = 2 * E + 2 * H
+        dev = self.device
+        skip = torch.zeros(self.V, dtype=torch.uint8, device=dev)
+        skip[torch.as_tensor(sorted(int(i) for i in skip_ids), dtype=torch.int64, device=dev)] = 1
+        toks = torch.zeros(B, T + 1, dtype=torch.int64, device=dev)
+        toks[:, 0] = start_id
+        lps = torch.zeros(B, T, dtype=torch.float32, device=dev)
+        tr = self._alloc_trace(B, T)
+        c = C.byref(tr["_c"])
+        xg = torch.empty(B, W1, device=dev)
+        zg = torch.empty(B, H, device=dev)
+        hcw = torch.empty(B, H, device=dev)
+        nxt = torch.empty(B, dtype=torch.int64, device=dev)
+        lp = torch.empty(B, dtype=torch.float32, device=dev)
+        w_gate, b_gate = self.Wcat1[4 * H:], self.bcat1[4 * H:]          # [x_gate | h_gate] rows of the fused weight
+        unfinished = torch.ones(B, dtype=torch.bool, device=dev)
+
+        def sentinel_new_h(t):
+            st = stream_ptr()
+            check(lib.lrpx_gridtd_fwd_gate_input(c, t, ptr(xg), st))
+            check(lib.lrpx_linear_small(ptr(xg), W1, ptr(w_gate), ptr(b_gate), ptr(zg), H, B, W1, H, 0, st))
+            check(lib.lrpx_gridtd_fwd_sentinel(c, t, ptr(zg), H, st))
+
+        for t in range(T):
+            self._step(tr, enc, t, toks, True, after_lstm1=sentinel_new_h)
+            st = stream_ptr()
+            pred = self.logits(tr["hc"][:, t].contiguous())
+            check(lib.lrpx_gridtd_lrp_reweight(c, t, ptr(pred), self.V, self.V, ptr(self.sd["fc.weight"]), ptr(skip),
+                                               ptr(hcw), st))
+            wpred = self.logits(hcw)
+            check(lib.lrpx_argmax_logprob_rows(ptr(wpred), self.V, B, self.V, ptr(nxt), ptr(lp), st))
+            alive = unfinished.any()                                        # the reference's `break` (:699-700)
+            unfinished = unfinished & (nxt != end_id)
+            toks[:, t + 1] = torch.where(alive, nxt * unfinished, torch.zeros_like(nxt))
+            lps[:, t] = torch.where(alive, lp, torch.zeros_like(lp))
+        return toks[:, 1:].contiguous(), lps
 
     # ------------------------------------------------------------------------------------------
     def _row_index(self, B, T):

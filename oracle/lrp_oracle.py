@@ -210,12 +210,13 @@ def _adaptive_attention(sd, V, h, s):
     return ctx_hat, ctx, alpha.squeeze(1), beta
 
 
-def gridtd_trace(sd, features, avg, caption, model_bias=False):
+def gridtd_trace(sd, features, avg, caption, model_bias=False, gate_h_new=False):
     """models/gridTDmodel.py:933-1012 `get_hidden_parameters` for one image with a given caption
     (`caption[0]` = <start>; T = len(caption)-1 words).  features (512,h,w), avg (512,).
     Keeps the reference's quirks: LanguageLSTM adds bias_ih twice (:789); the sentinel gate uses
     h_{t-1} (:982).  `model_bias=True` gives the MODEL's own forward instead
-    (`predict_next_word` :137-144 through nn.LSTMCell: bias_ih + bias_hh), used for decoding."""
+    (`predict_next_word` :137-144 through nn.LSTMCell: bias_ih + bias_hh), used for decoding.
+    `gate_h_new=True` feeds the sentinel gate the NEW h1 as `sample_lrp`/`forwardlrp_context` do (:610, :672)."""
     Hd = sd["fc.weight"].shape[1]
     C, hh, ww = features.shape
     P = hh * ww
@@ -248,7 +249,8 @@ def gridtd_trace(sd, features, avg, caption, model_bias=False):
         x1 = torch.cat([tr["h2"][t], glob, emb])
         h1, c1, g1, i1, f1 = _lstm_cell(x1, tr["h1"][t], tr["c1"][t], a_wi, a_wh, a_b)
         gate = torch.sigmoid(sd["AdaLSTM.x_gate.weight"] @ x1 + sd["AdaLSTM.x_gate.bias"]
-                             + sd["AdaLSTM.h_gate.weight"] @ tr["h1"][t] + sd["AdaLSTM.h_gate.bias"])
+                             + sd["AdaLSTM.h_gate.weight"] @ (h1 if gate_h_new else tr["h1"][t])
+                             + sd["AdaLSTM.h_gate.bias"])
         s = gate * torch.tanh(c1)
         ctx_hat, ctx, alpha, beta = _adaptive_attention(sd, Vp, h1, s)
         x2 = torch.cat([ctx_hat, h1])
@@ -287,6 +289,50 @@ def gridtd_model_greedy(sd, img, max_cap_length, start_id, end_id):
         unfinished = unfinished and (top != end_id)
         seq.append(top if unfinished else 0)
     return seq
+
+
+def normalize_relevance(x):
+    """LRPtools/utils.py:55-64 with temperature = 1: x / max|x| + 1 (an all-zero row stays 0 -> weight 1)."""
+    v = x.abs().max()
+    v = v if v != 0 else torch.ones(())
+    return x / v + 1
+
+
+def gridtd_lrp_weights(sd, pred, h2, ctx_hat, skip_ids):
+    """models/gridTDmodel.py:548-577 `get_lrp_weight_step` for one row: the predicted word's logit is redistributed
+    to h2 + ctx_hat through fc (epsilon rule, one-hot relevance) and split between the two summands; both relevance
+    vectors are normalised to weights around 1.  Words in `skip_ids` (stop words and specials) get weights of 1."""
+    k = int(torch.argmax(pred))
+    Hd = h2.shape[0]
+    if k in skip_ids:
+        return torch.ones(Hd), torch.ones(Hd)
+    hc = h2 + ctx_hat
+    r_hc = (sd["fc.weight"][k] * hc / eps_stabilise(pred[k])) * pred[k]
+    r_h2 = eps_identity(r_hc, h2, hc)
+    r_ctx = eps_identity(r_hc, ctx_hat, hc)
+    return normalize_relevance(r_ctx), normalize_relevance(r_h2)
+
+
+def gridtd_sample_lrp(sd, img, max_length, start_id, end_id, skip_ids):
+    """models/gridTDmodel.py:631-702 `sample_lrp` (greedy) for one image: every step's logits are recomputed from the
+    LRP-reweighted fc input `ctx_hat * w_ctx + w_h2 * h2` before the next word is taken.
+    Returns (seq (max_length,) int64, seq_logprobs (max_length,))."""
+    feats, avg, _ = vgg_forward(sd, img)
+    toks, unfinished = [start_id], True
+    seq, lps = [], []
+    for t in range(max_length):
+        tr = gridtd_trace(sd, feats[0], avg[0], toks + [0], model_bias=True, gate_h_new=True)
+        h2, ctx_hat = tr["h2"][t + 1], tr["ctx_hat"][t]
+        w_ctx, w_h2 = gridtd_lrp_weights(sd, tr["pred"][t], h2, ctx_hat, skip_ids)
+        wp = sd["fc.weight"] @ (ctx_hat * w_ctx + w_h2 * h2) + sd["fc.bias"]
+        lsm = torch.log_softmax(wp, dim=-1)
+        it = int(torch.argmax(lsm))
+        lps.append(float(lsm[it]))
+        unfinished = unfinished and (it != end_id)
+        it = it if unfinished else 0
+        seq.append(it)
+        toks.append(it)
+    return seq, lps
 
 
 def gridtd_explain_wordt(sd, tr, t):

@@ -92,6 +92,45 @@ def test_greedy_tokens_bit_exact(case):
     assert toks[0].cpu().tolist() == [int(x) for x in gg["tokens"]]
 
 
+def test_sample_lrp_tokens_bit_exact():
+    """LRP-inference decoding (GridTDEngine.sample_lrp = `GridTDModel.sample_lrp` greedy, models/gridTDmodel.py:631-702)
+    against the reference's own output (tests/golden/sample_lrp.npz): token ids bit-exact, log-probabilities to 1e-4
+    absolute; case 2 has a stop word (exempt from the re-weighting) and an <end> that is hit (zero padding)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine
+    g = np.load(os.path.join(GOLDEN, "sample_lrp.npz"))
+    V, L = int(g["V"]), int(g["max_len"])
+    eng = GridTDEngine(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=V))
+    imgs = torch.from_numpy(weights.make_images(int(g["seed"]) + 3, g["seq"].shape[0]))
+    wm = weights.make_word_map(V)
+    enc = eng.encode(imgs.cuda())
+    for seq_k, lp_k, skip_k, end_id in (("seq", "logprobs", "skip", wm['<end>']),
+                                        ("seq2", "logprobs2", "skip2", int(g["end2"]))):
+        seq, lps = eng.sample_lrp(enc, L, wm['<start>'], end_id, g[skip_k].tolist())
+        assert seq.cpu().tolist() == g[seq_k].tolist()
+        assert np.abs(lps.cpu().numpy() - g[lp_k]).max() < 1e-4
+
+
+def test_sample_lrp_stops_writing_once_all_finished():
+    """the reference leaves the loop when every sequence has produced <end> (:699-700): later columns stay 0"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine
+    g = np.load(os.path.join(GOLDEN, "sample_lrp.npz"))
+    V = int(g["V"])
+    eng = GridTDEngine(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=V))
+    imgs = torch.from_numpy(weights.make_images(int(g["seed"]) + 3, 2))
+    wm = weights.make_word_map(V)
+    first = int(g["seq"][0, 0])                         # both images start with this word: let it play <end>
+    assert int(g["seq"][1, 0]) == first
+    seq, lps = eng.sample_lrp(eng.encode(imgs.cuda()), 5, wm['<start>'], first, g["skip"].tolist())
+    assert seq.abs().sum().item() == 0
+    assert (lps[:, 0] < 0).all() and lps[:, 1:].abs().sum().item() == 0
+
+
 def test_explain_stream_matches_serial():
     """independent batches in flight on separate HIP streams (GridTDEngine.explain_stream, shared weights, own
     buffers per stream) give bit-identical maps and word relevances to explaining them one after the other"""

@@ -98,6 +98,23 @@ def test_greedy_tokens_bit_exact():
     assert toks == [int(x) for x in g["tokens"]]
 
 
+def test_sample_lrp_tokens_bit_exact():
+    # LRP-inference decoding, `GridTDModel.sample_lrp` greedy (models/gridTDmodel.py:631-702): token ids bit-exact,
+    # log-probabilities to 1e-4 absolute.  Case 2 makes one word a stop word (exempt from the re-weighting) and
+    # lets another play <end> (zero padding after it).
+    g = np.load(os.path.join(GOLDEN, "sample_lrp.npz"))
+    V, L = int(g["V"]), int(g["max_len"])
+    sd = O.state_to_torch(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=V))
+    imgs = torch.from_numpy(weights.make_images(int(g["seed"]) + 3, g["seq"].shape[0]))
+    wm = weights.make_word_map(V)
+    for seq_k, lp_k, skip_k, end_id in (("seq", "logprobs", "skip", wm['<end>']),
+                                        ("seq2", "logprobs2", "skip2", int(g["end2"]))):
+        for b in range(imgs.shape[0]):
+            seq, lps = O.gridtd_sample_lrp(sd, imgs[b:b + 1], L, wm['<start>'], end_id, set(g[skip_k].tolist()))
+            assert seq == g[seq_k][b].tolist()
+            assert np.abs(np.array(lps) - g[lp_k][b]).max() < 1e-4
+
+
 def test_guided_backprop_vs_reference():
     # ExplainiGridTDGuidedGradient (models/gridTDmodel.py:1585-1723): decoder BPTT + guided backprop through VGG16
     g = np.load(os.path.join(GOLDEN, "guided_T3.npz"))

@@ -51,3 +51,16 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 10
 gb = B * T * 224 * 224 * 4 * (3 + 1 + 1 + 1 + 3 + 1 + 1 + 1 + 10 + 1) / 1e9
 print(f"{'map consumers (mask, bbox ratios x10, statistics)':52s} {dt*1e3:8.2f} ms/step  {B*T/dt:9.1f} maps/s  ~{gb/dt:.0f} GB/s of algorithmic traffic")
+
+# LRP-inference decoding (GridTDEngine.sample_lrp) next to plain greedy decoding: 16 images x 20 words
+enc = eng.encode(images)
+wm = weights.make_word_map(V)
+skip = [wm[k] for k in ('<start>', '<end>', '<pad>', '<unk>')]
+for name, fn in (("greedy decoding (greedy)", lambda: eng.greedy(enc, T + 1, wm['<start>'], wm['<end>'])),
+                 ("LRP-inference decoding (sample_lrp)", lambda: eng.sample_lrp(enc, T, wm['<start>'], wm['<end>'], skip))):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"{name:52s} {dt*1e3:8.2f} ms/step  {B*T/dt:9.1f} words/s")
