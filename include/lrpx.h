@@ -171,6 +171,13 @@ int lrpx_bbox_ratio(const float* spatial, int n, int h, int w, const int32_t* bo
 /* tpfp statistics (evaluation.py:506-513): out[n][4] = mean, mean |x|, mean of the positive entries (0 if none), max */
 int lrpx_map_stats(const float* spatial, int n, long per, float* out4, void* stream);
 
+/* np.quantile(map, q) ('linear' method) of every (H*W) map: the 100-point quantiles of the tpfp statistics
+ * (evaluation.py:451, :510, :543).  spatial (n, per) floats, q (nq) doubles in [0,1], out (n, nq).
+ * `workspace`: lrpx_map_quantiles_workspace(n, per) bytes of device memory (sorted copy + sort scratch; 0 = the
+ * shape is unsupported, n*per must stay below 2^31). */
+size_t lrpx_map_quantiles_workspace(int n, long per);
+int lrpx_map_quantiles(const float* spatial, int n, long per, const double* q, int nq, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
 /* `LRPutil.heatmap(LRPutil.gamma(hm))` (LRPtools/utils.py:67-145) as the explainers' visualize_explanations call it
  * (models/gridTDmodel.py:1196-1198): gamma correction with the map's own max |x|, sum over the channels, projection to
  * [0, 255] with the summed map's max |x|, colour-map lookup.  maps (n,c,hw) -> out (n,hw,3); lut [nlut][3] (the

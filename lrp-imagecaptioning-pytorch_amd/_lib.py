@@ -86,6 +86,8 @@ SIGNATURES = {
     "lrpx_patch_mask": (_i, [_f, _i, _i, _i, _i, _i, _f, _f]),
     "lrpx_bbox_ratio": (_i, [_f, _i, _i, _i, _f, _f, _i, _f, _f]),
     "lrpx_map_stats": (_i, [_f, _i, _l, _f, _f]),
+    "lrpx_map_quantiles_workspace": (C.c_size_t, [_i, _l]),
+    "lrpx_map_quantiles": (_i, [_f, _i, _l, _f, _i, _f, _f, C.c_size_t, _f]),
     "lrpx_heatmap": (_i, [_f, _i, _i, _l, C.c_float, _f, _i, _f, _f, _f]),
     "lrpx_amax_maps": (_i, [_f, _i, _l, _f, _f]),
     "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),

@@ -10,6 +10,8 @@
 // All HBM-bound single-pass kernels: one workgroup per map (maps are 50 176 pixels), block reductions in LDS.
 #include <math.h>
 
+#include <hipcub/hipcub.hpp>
+
 #include "common.h"
 
 namespace lrpx {
@@ -161,6 +163,28 @@ __global__ __launch_bounds__(256) void map_stats_kernel(const float* __restrict_
     }
 }
 
+// np.quantile(map, q) with the default 'linear' method (evaluation.py:510, :543 on the channel-mean map; 100 points):
+// the maps are sorted per segment (rocPRIM segmented radix sort: a utility sort, not a hot kernel) and the order
+// statistics around q*(n-1) are interpolated the way numpy's _lerp does.
+__global__ void segment_offsets_kernel(int* __restrict__ off, int n_seg, long per) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_seg) off[i] = (int)((long)i * per);
+}
+
+__global__ void quantile_lerp_kernel(const float* __restrict__ sorted, long per, const double* __restrict__ q, int nq,
+                                     float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nq) return;
+    const float* s = sorted + (long)blockIdx.y * per;
+    const double pos = q[j] * (double)(per - 1);
+    long lo = (long)floor(pos);
+    lo = lo < 0 ? 0 : (lo > per - 1 ? per - 1 : lo);
+    const long hi = lo + 1 > per - 1 ? per - 1 : lo + 1;
+    const double t = pos - (double)lo;
+    const double a = s[lo], b = s[hi], d = b - a;
+    out[(long)blockIdx.y * nq + j] = (float)(t >= 0.5 ? b - d * (1.0 - t) : a + d * t);
+}
+
 // gamma(X) (utils.py:97-145, minamp = 0, maxamp = max|X| of the map) followed by heatmap(.) (utils.py:67-90: sum over
 // the channels, project to [0,255] with the map's own max |.|, integer colour-map lookup).  One workgroup per map;
 // `tmp` holds the channel sums between the two passes.
@@ -240,6 +264,40 @@ int lrpx_map_stats(const float* spatial, int n, long per, float* out4, void* str
     LRPX_REQUIRE(spatial && out4 && n > 0 && per > 0, "map_stats: bad arguments");
     hipLaunchKernelGGL(map_stats_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, spatial, per, out4);
     return check_launch("map_stats");
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t lrpx_map_quantiles_workspace(int n, long per) {
+    if (n <= 0 || per <= 0 || (long)n * per >= 0x7fffffffL) return 0;
+    size_t tmp = 0;
+    const float* kin = nullptr; float* kout = nullptr; const int* off = nullptr;
+    if (hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp, kin, kout, (int)((long)n * per), n, off, off + 1) !=
+        hipSuccess)
+        return 0;
+    return align256((size_t)n * per * sizeof(float)) + align256((size_t)(n + 1) * sizeof(int)) + align256(tmp);
+}
+
+int lrpx_map_quantiles(const float* spatial, int n, long per, const double* q, int nq, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    LRPX_REQUIRE(spatial && q && out && workspace && n > 0 && per > 0 && nq > 0, "map_quantiles: bad arguments");
+    LRPX_REQUIRE((long)n * per < 0x7fffffffL, "map_quantiles: more than 2^31 values in one call");
+    const size_t need = lrpx_map_quantiles_workspace(n, per);
+    LRPX_REQUIRE(need && workspace_bytes >= need, "map_quantiles: workspace too small (lrpx_map_quantiles_workspace)");
+    char* w = static_cast<char*>(workspace);
+    float* sorted = reinterpret_cast<float*>(w);
+    int* off = reinterpret_cast<int*>(w + align256((size_t)n * per * sizeof(float)));
+    void* tmp = w + align256((size_t)n * per * sizeof(float)) + align256((size_t)(n + 1) * sizeof(int));
+    size_t tmp_bytes = workspace_bytes - (size_t)(static_cast<char*>(tmp) - w);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(segment_offsets_kernel, dim3((n + 256) / 256), dim3(256), 0, st, off, n, per);
+    if (hipcub::DeviceSegmentedRadixSort::SortKeys(tmp, tmp_bytes, spatial, sorted, (int)((long)n * per), n, off, off + 1,
+                                                   0, 32, st) != hipSuccess) {
+        set_error("map_quantiles: segmented sort failed");
+        return LRPX_ELAUNCH;
+    }
+    hipLaunchKernelGGL(quantile_lerp_kernel, dim3((nq + 127) / 128, n), dim3(128), 0, st, sorted, per, q, nq, out);
+    return check_launch("map_quantiles");
 }
 
 int lrpx_heatmap(const float* maps, int n, int c, long hw, float gamma, const float* lut, int nlut, float* tmp, float* out,

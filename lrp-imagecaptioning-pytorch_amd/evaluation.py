@@ -61,3 +61,22 @@ def map_statistics(spatial):
     out = torch.empty(spatial.shape[0], 4, device=spatial.device, dtype=torch.float32)
     check(_lib.load().lrpx_map_stats(ptr(spatial), spatial.shape[0], spatial[0].numel(), ptr(out), stream_ptr()))
     return out
+
+
+def map_quantiles(spatial, points=None):
+    """The quantile row of the tpfp statistics (evaluation.py:451 `quantile_point`, :510, :543): np.quantile(map, points)
+    per map, (N,H,W) -> (N, len(points)); default points i/100, i = 0..99 like the reference."""
+    spatial = _dev(spatial)
+    lib = _lib.load()
+    pts = [i / 100 for i in range(100)] if points is None else [float(p) for p in points]
+    if not pts or min(pts) < 0 or max(pts) > 1:
+        raise ValueError("Quantiles must be in the range [0, 1]")       # numpy's own message
+    q = torch.tensor(pts, dtype=torch.float64, device=spatial.device)
+    n, per = spatial.shape[0], spatial[0].numel()
+    need = lib.lrpx_map_quantiles_workspace(n, per)
+    if need == 0:
+        raise ValueError(f"map_quantiles: {n} maps of {per} values are more than one call can sort (2^31 values)")
+    ws = torch.empty(need, dtype=torch.uint8, device=spatial.device)
+    out = torch.empty(n, len(pts), device=spatial.device, dtype=torch.float32)
+    check(lib.lrpx_map_quantiles(ptr(spatial), n, per, ptr(q), len(pts), ptr(out), ptr(ws), need, stream_ptr()))
+    return out

@@ -54,6 +54,11 @@ def map_statistics(rel):
     return np.array([rel.mean(dtype=np.float64), np.abs(rel).mean(dtype=np.float64), mean_pos, rel.max()], np.float64)
 
 
+def map_quantiles(rel, points=None):
+    """evaluation.py:451, :510: np.quantile of the (H,W) map at i/100, i = 0..99"""
+    return np.quantile(rel, [i / 100 for i in range(100)] if points is None else points)
+
+
 def relevance_heatmap(m, lut, gamma=0.7):
     """LRPtools/utils.py `gamma` (:97-145, minamp 0, maxamp = max|X|) then `heatmap` (:67-90) with `project` (:34-52):
     m (C,H,W) -> (H,W,3) colours from the 256-entry table `lut`."""

@@ -52,6 +52,14 @@ dt = (time.perf_counter() - t0) / 10
 gb = B * T * 224 * 224 * 4 * (3 + 1 + 1 + 1 + 3 + 1 + 1 + 1 + 10 + 1) / 1e9
 print(f"{'map consumers (mask, bbox ratios x10, statistics)':52s} {dt*1e3:8.2f} ms/step  {B*T/dt:9.1f} maps/s  ~{gb/dt:.0f} GB/s of algorithmic traffic")
 
+sp_ = ev.spatial_relevance(m, "mean")
+ev.map_quantiles(sp_); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10): ev.map_quantiles(sp_)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 10
+print(f"{'100-point quantiles (per-map sort)':52s} {dt*1e3:8.2f} ms/step  {B*T/dt:9.1f} maps/s")
+
 # LRP-inference decoding (GridTDEngine.sample_lrp) next to plain greedy decoding: 16 images x 20 words
 enc = eng.encode(images)
 wm = weights.make_word_map(V)
