@@ -263,6 +263,12 @@ int lrpx_gridtd_fwd_gate_input(const lrpx_gridtd_trace* tr, int t, float* xg, vo
 int lrpx_gridtd_fwd_sentinel(const lrpx_gridtd_trace* tr, int t, const float* zg, int ldz, void* stream);
 int lrpx_gridtd_lrp_reweight(const lrpx_gridtd_trace* tr, int t, const float* pred, long ld, int V, const float* fc_w,
                              const unsigned char* skip, float* hcw, void* stream);
+/* the same rule on plain rows: h / ctx = the two fc summands of row r (row strides ldh / ldc, H = 512).  log_softmax = 1
+ * is `AOAModel.get_lrp_weight_step` as `AOAModel.sample_lrp` calls it (models/aoamodel.py:597-626, :721-723): the rule
+ * sees log_softmax(pred), i.e. the relevance sent back through fc is log p(k). */
+int lrpx_lrp_reweight_rows(const float* pred, long ld, int V, const float* h, long ldh, const float* ctx, long ldc,
+                           const float* fc_w, const unsigned char* skip, float* hcw, int rows, int H, int log_softmax,
+                           void* stream);
 /* scratch: [B][3*P] floats (scores, W_g h, W_s s) */
 int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img,
                               const float* Wg, const float* Ws, const float* bs, const float* wh, float* scratch,

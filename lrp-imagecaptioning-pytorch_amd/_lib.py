@@ -104,6 +104,7 @@ SIGNATURES = {
     "lrpx_gridtd_fwd_gate_input": (_i, [C.POINTER(GridTrace), _i, _f, _f]),
     "lrpx_gridtd_fwd_sentinel": (_i, [C.POINTER(GridTrace), _i, _f, _i, _f]),
     "lrpx_gridtd_lrp_reweight": (_i, [C.POINTER(GridTrace), _i, _f, _l, _i, _f, _f, _f, _f]),
+    "lrpx_lrp_reweight_rows": (_i, [_f, _l, _i, _f, _l, _f, _l, _f, _f, _f, _i, _i, _i, _f]),
     "lrpx_argmax_logprob_rows": (_i, [_f, _l, _i, _i, _f, _f, _f]),
     "lrpx_gridtd_fwd_attention": (_i, [C.POINTER(GridTrace), _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "lrpx_gridtd_rel_init": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f, _i, _f]),

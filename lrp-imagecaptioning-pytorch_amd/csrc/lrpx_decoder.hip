@@ -324,15 +324,21 @@ __global__ void gridtd_sentinel_kernel(GridFwd g, int t, const float* __restrict
 }
 
 // get_lrp_weight_step (:548-577) + the re-weighted fc input (:687).  One block per image, H = 512, 256 threads.
-__global__ __launch_bounds__(256) void gridtd_lrp_reweight_kernel(GridFwd g, int t, const float* __restrict__ pred,
-                                                                  long ld, int V, const float* __restrict__ fcw,
-                                                                  const unsigned char* __restrict__ skip,
-                                                                  float* __restrict__ hcw) {
+// h / ctx: the two fc summands of row b (row strides ldh / ldc).  lsm: the AoA model hands the rule the log-softmax of
+// the scores instead of the scores (models/aoamodel.py:721-723): relevance and stabilised output are log p(k).
+__global__ __launch_bounds__(256) void lrp_reweight_kernel(const float* __restrict__ pred, long ld, int V,
+                                                           const float* __restrict__ hrow, long ldh,
+                                                           const float* __restrict__ crow, long ldc,
+                                                           const float* __restrict__ fcw,
+                                                           const unsigned char* __restrict__ skip,
+                                                           float* __restrict__ hcw, int H, int lsm) {
     __shared__ float bv[256];
     __shared__ int bi[256];
     __shared__ float red[8];
-    const int b = blockIdx.x, H = g.H, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float* r = pred + (long)b * ld;
+    const float* hp = hrow + (long)b * ldh;
+    const float* cp = crow + (long)b * ldc;
     float best = -INFINITY; int idx = 0x7fffffff;
     for (int i = tid; i < V; i += 256) { const float v = r[i]; if (v > best) { best = v; idx = i; } }
     bv[tid] = best; bi[tid] = idx;
@@ -345,19 +351,25 @@ __global__ __launch_bounds__(256) void gridtd_lrp_reweight_kernel(GridFwd g, int
         __syncthreads();
     }
     const int k = min(bi[0], V - 1);            // (all-NaN row: keep the index in range)
-    const float pk = bv[0];
-    const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = ((long)b * g.T + t) * H;
+    float pk = bv[0];
     float* out = hcw + (long)b * H;
     if (skip[k]) {                                 // stop words and specials: both weights are 1 (:557-558)
-        for (int c = tid; c < H; c += 256) out[c] = g.ctx_hat[tr + c] * 1.f + 1.f * g.h2[st1 + c];
+        for (int c = tid; c < H; c += 256) out[c] = cp[c] * 1.f + 1.f * hp[c];
         return;
+    }
+    if (lsm) {                                     // log_softmax(pred)[k] = -log sum exp(pred - max)
+        float se = 0.f;
+        for (int i = tid; i < V; i += 256) se += expf(r[i] - pk);
+        se = block_sum(se, red);
+        pk = -logf(se);
+        __syncthreads();
     }
     const float zt = stab_eps(pk);
     float rh[2], rc[2], mh = 0.f, mc = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = tid + j * 256;
-        const float h2 = g.h2[st1 + c], ch = g.ctx_hat[tr + c];
+        const float h2 = hp[c], ch = cp[c];
         const float hc = h2 + ch;
         const float r_hc = (fcw[(long)k * H + c] * hc / zt) * pk;     // one-hot epsilon rule through fc
         rh[j] = eps_id(r_hc, h2, hc);
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(256) void gridtd_lrp_reweight_kernel(GridFwd g, int
     for (int j = 0; j < 2; ++j) {
         const int c = tid + j * 256;
         const float w_h = rh[j] / mh + 1.f, w_c = rc[j] / mc + 1.f;
-        out[c] = g.ctx_hat[tr + c] * w_c + w_h * g.h2[st1 + c];
+        out[c] = cp[c] * w_c + w_h * hp[c];
     }
 }
 
@@ -1050,9 +1062,20 @@ int lrpx_gridtd_lrp_reweight(const lrpx_gridtd_trace* tr, int t, const float* pr
     LRPX_TRY(check_trace(tr));
     LRPX_REQUIRE(pred && fc_w && skip && hcw && V > 0 && ld >= V && t >= 0 && t < tr->T,
                  "gridtd_lrp_reweight: bad arguments");
-    hipLaunchKernelGGL(gridtd_lrp_reweight_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, pred,
-                       ld, V, fc_w, skip, hcw);
+    hipLaunchKernelGGL(lrp_reweight_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, pred, ld, V,
+                       tr->h2 + (long)(t + 1) * tr->H, (long)(tr->T + 1) * tr->H, tr->ctx_hat + (long)t * tr->H,
+                       (long)tr->T * tr->H, fc_w, skip, hcw, tr->H, 0);
     return check_launch("gridtd_lrp_reweight");
+}
+
+int lrpx_lrp_reweight_rows(const float* pred, long ld, int V, const float* h, long ldh, const float* ctx, long ldc,
+                           const float* fc_w, const unsigned char* skip, float* hcw, int rows, int H, int log_softmax,
+                           void* stream) {
+    LRPX_REQUIRE(pred && h && ctx && fc_w && skip && hcw && rows > 0 && V > 0 && ld >= V && H == 512 && ldh >= H &&
+                     ldc >= H, "lrp_reweight_rows: bad arguments (H must be 512)");
+    hipLaunchKernelGGL(lrp_reweight_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, ld, V, h, ldh, ctx, ldc,
+                       fc_w, skip, hcw, H, log_softmax ? 1 : 0);
+    return check_launch("lrp_reweight_rows");
 }
 
 int lrpx_argmax_logprob_rows(const float* x, long ld, int rows, int n, long long* out, float* logprob, void* stream) {

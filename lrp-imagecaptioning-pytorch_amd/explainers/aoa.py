@@ -109,6 +109,63 @@ class AOAEngine:
         tr["_c"] = c
         return tr
 
+    def _step(self, tr, enc, t, captions, bias):
+        """one decoder step of `get_hidden_parameters` (models/aoamodel.py:1020-1052) for all B images"""
+        lib = _lib.load()
+        st = stream_ptr()
+        B, T, H, E = tr["B"], tr["T"], self.H, self.E
+        c = C.byref(tr["_c"])
+        W = E + 2 * H
+        sd = self.sd
+        if "_zz" not in tr:
+            tr["_zz"] = torch.empty(B, 4 * H, device=self.device)
+            tr["_qg"] = torch.empty(B, 2 * H, device=self.device)
+            tr["_lin"] = torch.empty(B, H, device=self.device)
+        zz, qg, lin = tr["_zz"], tr["_qg"], tr["_lin"]
+        check(lib.lrpx_aoa_fwd_pre(c, t, ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), captions.shape[1], st))
+        check(lib.lrpx_linear_small(ptr_at(tr["xh"], t * W), T * W, ptr(self.Wcat), ptr(bias), ptr(zz), 4 * H, B, W,
+                                    4 * H, 0, st))
+        check(lib.lrpx_aoa_fwd_lstm(c, t, ptr(zz), 4 * H, st))
+        check(lib.lrpx_linear_small(ptr_at(tr["h"], (t + 1) * H), (T + 1) * H, ptr(self.Wqg), ptr(self.bqg), ptr(qg),
+                                    2 * H, B, H, 2 * H, 0, st))
+        check(lib.lrpx_aoa_fwd_attention(c, t, ptr(qg), 2 * H, ptr(enc["key"]), ptr(enc["value"]), st))
+        check(lib.lrpx_linear_small(ptr_at(tr["ctx"], t * H), T * H, ptr(sd["decoder_aoa_linear.weight"]),
+                                    ptr(sd["decoder_aoa_linear.bias"]), ptr(lin), H, B, H, H, 0, st))
+        check(lib.lrpx_aoa_fwd_post(c, t, ptr(qg), 2 * H, ptr(lin), st))
+
+    def sample_lrp(self, enc, max_length, start_id, end_id, skip_ids):
+        """AOAModel.sample_lrp, greedy (models/aoamodel.py:679-745): LRP-inference decoding.  `get_lrp_weight_step`
+        (:597-626) is handed the log-softmax of the scores (:721-723), unlike the gridTD model.  Returns (seq int64
+        (B,max_length), seq_logprobs (B,max_length)); tokens after <end> are 0, nothing is written once every sequence
+        has finished (:742-744)."""
+        lib = _lib.load()
+        B, T, H = enc["B"], max_length, self.H
+        dev = self.device
+        skip = torch.zeros(self.V, dtype=torch.uint8, device=dev)
+        skip[torch.as_tensor(sorted(int(i) for i in skip_ids), dtype=torch.int64, device=dev)] = 1
+        toks = torch.zeros(B, T + 1, dtype=torch.int64, device=dev)
+        toks[:, 0] = start_id
+        lps = torch.zeros(B, T, dtype=torch.float32, device=dev)
+        tr = self._alloc_trace(B, T, enc["P"])
+        hcw = torch.empty(B, H, device=dev)
+        nxt = torch.empty(B, dtype=torch.int64, device=dev)
+        lp = torch.empty(B, dtype=torch.float32, device=dev)
+        unfinished = torch.ones(B, dtype=torch.bool, device=dev)
+        for t in range(T):
+            self._step(tr, enc, t, toks, self.bcat_model)
+            st = stream_ptr()
+            pred = self.logits(tr["hc"][:, t].contiguous())
+            check(lib.lrpx_lrp_reweight_rows(ptr(pred), self.V, self.V, ptr_at(tr["h"], (t + 1) * H), (T + 1) * H,
+                                             ptr_at(tr["c_aoa"], t * H), T * H, ptr(self.sd["fc.weight"]), ptr(skip),
+                                             ptr(hcw), B, H, 1, st))
+            wpred = self.logits(hcw)
+            check(lib.lrpx_argmax_logprob_rows(ptr(wpred), self.V, B, self.V, ptr(nxt), ptr(lp), st))
+            alive = unfinished.any()
+            unfinished = unfinished & (nxt != end_id)
+            toks[:, t + 1] = torch.where(alive, nxt * unfinished, torch.zeros_like(nxt))
+            lps[:, t] = torch.where(alive, lp, torch.zeros_like(lp))
+        return toks[:, 1:].contiguous(), lps
+
     def trace(self, enc, captions, model_bias=False, predictions=True, grad=False):
         """grad=True: the trace of the gradient explainers (:1309-1376): correct LSTM bias, output gate and aoa gate kept."""
         model_bias = model_bias or grad
@@ -120,22 +177,10 @@ class AOAEngine:
         tr = self._alloc_trace(B, T, enc["P"], grad)
         c = C.byref(tr["_c"])
         W = E + 2 * H
-        zz = torch.empty(B, 4 * H, device=self.device)
-        qg = torch.empty(B, 2 * H, device=self.device)
-        lin = torch.empty(B, H, device=self.device)
         bias = self.bcat_model if model_bias else self.bcat_explainer
         sd = self.sd
         for t in range(T):
-            check(lib.lrpx_aoa_fwd_pre(c, t, ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), T + 1, st))
-            check(lib.lrpx_linear_small(ptr_at(tr["xh"], t * W), T * W, ptr(self.Wcat), ptr(bias), ptr(zz), 4 * H, B, W,
-                                        4 * H, 0, st))
-            check(lib.lrpx_aoa_fwd_lstm(c, t, ptr(zz), 4 * H, st))
-            check(lib.lrpx_linear_small(ptr_at(tr["h"], (t + 1) * H), (T + 1) * H, ptr(self.Wqg), ptr(self.bqg), ptr(qg),
-                                        2 * H, B, H, 2 * H, 0, st))
-            check(lib.lrpx_aoa_fwd_attention(c, t, ptr(qg), 2 * H, ptr(enc["key"]), ptr(enc["value"]), st))
-            check(lib.lrpx_linear_small(ptr_at(tr["ctx"], t * H), T * H, ptr(sd["decoder_aoa_linear.weight"]),
-                                        ptr(sd["decoder_aoa_linear.bias"]), ptr(lin), H, B, H, H, 0, st))
-            check(lib.lrpx_aoa_fwd_post(c, t, ptr(qg), 2 * H, ptr(lin), st))
+            self._step(tr, enc, t, captions, bias)
         tr["captions"] = captions
         tr["logit"] = torch.empty(B * T, device=self.device)
         check(lib.lrpx_target_logit(ptr(tr["hc"]), ptr(sd["fc.weight"]), ptr(sd["fc.bias"]), ptr(captions), T + 1,

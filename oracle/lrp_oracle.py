@@ -600,6 +600,39 @@ def aoa_trace(sd, F_pix, caption, num_head=8, grad=False):
     return tr
 
 
+def aoa_sample_lrp(sd, img, max_length, start_id, end_id, skip_ids, num_head=8):
+    """models/aoamodel.py:679-745 `AOAModel.sample_lrp` (greedy) for one image.  Unlike the gridTD version (:548-577 of
+    gridTDmodel.py) `get_lrp_weight_step` (:597-626) is handed the LOG-SOFTMAX of the scores (:721-723): the relevance
+    that goes back through fc is log p(k), stabilised with log p(k) itself.
+    Returns (seq (max_length,), seq_logprobs (max_length,))."""
+    feats, _, _ = vgg_forward(sd, img)
+    C, hh, ww = feats.shape[1:]
+    F_pix = feats[0].reshape(C, hh * ww).t().contiguous()
+    Hd = sd["fc.weight"].shape[1]
+    toks, unfinished = [start_id], True
+    seq, lps = [], []
+    for t in range(max_length):
+        tr = aoa_trace(sd, F_pix, toks + [0], num_head=num_head, grad=True)       # model forward: bias_ih + bias_hh
+        h, c_aoa = tr["h"][t + 1], tr["c_aoa"][t]
+        lsm0 = torch.log_softmax(tr["pred"][t], dim=-1)
+        k = int(torch.argmax(lsm0))
+        if k in skip_ids:
+            w_c, w_h = torch.ones(Hd), torch.ones(Hd)
+        else:
+            hc = h + c_aoa
+            r_hc = (sd["fc.weight"][k] * hc / eps_stabilise(lsm0[k])) * lsm0[k]
+            w_h = normalize_relevance(eps_identity(r_hc, h, hc))
+            w_c = normalize_relevance(eps_identity(r_hc, c_aoa, hc))
+        lsm = torch.log_softmax(sd["fc.weight"] @ (c_aoa * w_c + w_h * h) + sd["fc.bias"], dim=-1)
+        it = int(torch.argmax(lsm))
+        lps.append(float(lsm[it]))
+        unfinished = unfinished and (it != end_id)
+        it = it if unfinished else 0
+        seq.append(it)
+        toks.append(it)
+    return seq, lps
+
+
 def aoa_explain_wordt(sd, tr, t, head_idx):
     """models/aoamodel.py:1064-1156 `explain_caption_wordt` (+ `lrp_mha` :812-862).
     Returns (r_feat (P,C), r_words (t+1,))."""

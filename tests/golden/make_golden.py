@@ -485,6 +485,35 @@ def gen_sample_lrp(out, weights, V=9586, seed=0, max_len=8, batch=2):
     print("sample_lrp tokens:", seq.tolist(), seq2.tolist(), "stop", stop_id, "end2", end2)
 
 
+def gen_aoa_sample_lrp(out, weights, V=11027, seed=0, max_len=8, batch=2):
+    """`AOAModel.sample_lrp` (models/aoamodel.py:679-745, greedy): same two cases as gen_sample_lrp."""
+    import models.aoamodel as aoa
+    sd = weights.make_aoa_state(seed=seed, vocab_size=V)
+    model = aoa.AOAModel(512, 512, 8, V, 'vgg16')
+    model.load_state_dict(to_torch_sd(sd))
+    model.eval()
+    wm = weights.make_word_map(V)
+    rev = {v: k for k, v in wm.items()}
+    imgs = torch.from_numpy(weights.make_images(seed + 3, batch))
+    with torch.no_grad():
+        seq, lps, ml = model.sample_lrp(imgs, rev, wm, [max_len + 1] * batch, {})
+        ids, counts = np.unique(seq.numpy(), return_counts=True)
+        stop_id = int(ids[np.argmax(counts)])
+        aoa.STOP_WORDS = [rev[stop_id]]
+        wm2 = dict(wm)
+        others = [int(x) for x in seq[0] if int(x) != stop_id]
+        wm2['<end>'] = end2 = others[-1] if others else int(seq[0, -1])
+        seq2, lps2, _ = model.sample_lrp(imgs, rev, wm2, [max_len + 1] * batch, {})
+        aoa.STOP_WORDS = []
+    special = [wm[k] for k in ('<start>', '<end>', '<pad>', '<unk>')]
+    np.savez(os.path.join(out, "aoa_sample_lrp.npz"), seed=np.int64(seed), V=np.int64(V), max_len=np.int64(ml),
+             seq=seq.numpy().astype(np.int64), logprobs=lps.numpy().astype(np.float32),
+             skip=np.array(special, np.int64),
+             seq2=seq2.numpy().astype(np.int64), logprobs2=lps2.numpy().astype(np.float32),
+             skip2=np.array(special + [stop_id], np.int64), end2=np.int64(end2))
+    print("aoa_sample_lrp tokens:", seq.tolist(), seq2.tolist(), "stop", stop_id, "end2", end2)
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -503,7 +532,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -533,6 +562,8 @@ def main():
         gen_eval(HERE, weights)
     if "sample_lrp" in todo:
         gen_sample_lrp(HERE, weights)
+    if "aoa_sample_lrp" in todo:
+        gen_aoa_sample_lrp(HERE, weights)
 
 
 if __name__ == "__main__":

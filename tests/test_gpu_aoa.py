@@ -83,3 +83,24 @@ def test_aoa_batch_vs_oracle():
             assert rel_err(r_feat[b, t].cpu(), want) < 2e-4, (b, t)
             assert np.abs(r_words[b, t, :t + 1].cpu().numpy() - w_rw[t].numpy()).max() < 1e-4
             assert_close_modulo_pool_ties(maps[b, t].cpu(), w_maps[t][0], what=(b, t))
+
+
+def test_aoa_sample_lrp_tokens_bit_exact():
+    """LRP-inference decoding of the AoA model (AOAEngine.sample_lrp = `AOAModel.sample_lrp` greedy,
+    models/aoamodel.py:679-745) against the reference's own output (tests/golden/aoa_sample_lrp.npz): token ids
+    bit-exact, log-probabilities to 1e-4 absolute; case 2 has a stop word and an <end> that is hit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    g = np.load(os.path.join(GOLDEN, "aoa_sample_lrp.npz"))
+    V, L = int(g["V"]), int(g["max_len"])
+    eng = AOAEngine(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=V))
+    imgs = torch.from_numpy(weights.make_images(int(g["seed"]) + 3, g["seq"].shape[0]))
+    wm = weights.make_word_map(V)
+    enc = eng.encode(images=imgs.cuda())
+    for seq_k, lp_k, skip_k, end_id in (("seq", "logprobs", "skip", wm['<end>']),
+                                        ("seq2", "logprobs2", "skip2", int(g["end2"]))):
+        seq, lps = eng.sample_lrp(enc, L, wm['<start>'], end_id, g[skip_k].tolist())
+        assert seq.cpu().tolist() == g[seq_k].tolist()
+        assert np.abs(lps.cpu().numpy() - g[lp_k]).max() < 1e-4

@@ -115,6 +115,20 @@ def test_sample_lrp_tokens_bit_exact():
             assert np.abs(np.array(lps) - g[lp_k][b]).max() < 1e-4
 
 
+def test_aoa_sample_lrp_tokens_bit_exact():
+    # `AOAModel.sample_lrp` greedy (models/aoamodel.py:679-745; the rule sees log-softmax scores, :721-723)
+    g = np.load(os.path.join(GOLDEN, "aoa_sample_lrp.npz"))
+    V, L = int(g["V"]), int(g["max_len"])
+    sd = O.state_to_torch(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=V))
+    imgs = torch.from_numpy(weights.make_images(int(g["seed"]) + 3, g["seq"].shape[0]))
+    wm = weights.make_word_map(V)
+    for seq_k, lp_k, skip_k, end_id in (("seq", "logprobs", "skip", wm['<end>']),
+                                        ("seq2", "logprobs2", "skip2", int(g["end2"]))):
+        seq, lps = O.aoa_sample_lrp(sd, imgs[:1], L, wm['<start>'], end_id, set(g[skip_k].tolist()))
+        assert seq == g[seq_k][0].tolist()
+        assert np.abs(np.array(lps) - g[lp_k][0]).max() < 1e-4
+
+
 def test_guided_backprop_vs_reference():
     # ExplainiGridTDGuidedGradient (models/gridTDmodel.py:1585-1723): decoder BPTT + guided backprop through VGG16
     g = np.load(os.path.join(GOLDEN, "guided_T3.npz"))
