@@ -39,7 +39,7 @@ def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=5e-2, l2=2e-3, what
     near-tied windows out of 1.5 M, each moving one channel's relevance by one pixel — the reference itself moves
     by 1.6e-4 of max|R| between PyTorch's oneDNN and native CPU convs (2 flips); GPU vs oneDNN on the golden image:
     4 flips, relative L2 error 2.1e-4, 99th percentile 2.4e-5, 0.17 % of the pixels above 1e-4, max 1.8e-3
-    (tools/e2e_stats.py).  So: cosine >= 0.99999, relative L2 error < `l2`, at most `frac` of the
+    (tests/e2e_stats.py).  So: cosine >= 0.99999, relative L2 error < `l2`, at most `frac` of the
     pixels off by more than 1e-4 of max|R|, none by more than `hard`.  The strict 1e-4 bound is asserted
     separately on identical activations."""
     import torch
