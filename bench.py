@@ -37,17 +37,22 @@ PEAK_16BIT_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA pea
 # `algorithmic_tflops` is the fp32-equivalent rate.
 DOM_FLOP_PER_MAP = 2.0 * 9 * 256 * 256 * 56 * 56
 MODE_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "bf16x6: exact 3-way bf16 split, 6 products, fp32 accumulate",
-             2: "f16x3: per-map power-of-two scaling, 2-way fp16 split, 3 products, fp32 accumulate"}
+             2: "f16x3: per-map power-of-two scaling, 2-way fp16 split, 3 products, fp32 accumulate",
+             3: "f16+f8x2: as f16x3, the two cross products (2^-11 of the result) as fp8 e4m3 MFMAs (v_mfma_f32_32x32x64_f8f6f4)"}
 MODE_KERNEL = {0: "conv_mfma_kernel<56,16,1,4,9,REL>", 1: "conv_bf16x6_kernel<56,1,4,true,REL>",
-               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>"}
-PRODUCTS = {0: 1, 1: 6, 2: 3}
+               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>", 3: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false,true>"}
+# mode 3: one fp16 product + two fp8 products; the fp8 dense peak is twice the fp16 one, so an fp8 flop counts half:
+# `achieved` / `peak` is then (time the matrix cores need at their peaks) / (measured time), as in the other modes
+PRODUCTS = {0: 1, 1: 6, 2: 3, 3: 2}
 # arithmetic the contractions run in: all tensors are fp32; modes 1 / 2 evaluate each fp32 product as split 16-bit MFMA
 # products with fp32 accumulation (fp32-grade results), everything else is fp32 VALU
-MODE_DTYPE = {0: "f32", 1: "f32 (bf16x6 split-product MFMA, f32 accumulate)", 2: "f32 (f16x3 split-product MFMA, f32 accumulate)"}
+MODE_DTYPE = {0: "f32", 1: "f32 (bf16x6 split-product MFMA, f32 accumulate)", 2: "f32 (f16x3 split-product MFMA, f32 accumulate)",
+              3: "f32 (fp16 + 2 fp8 split-product MFMA, f32 accumulate)"}
 # HBM traffic of ONE launch of that kernel over 320 maps, from rocprofv3 --pmc (separate passes, tools/pmc_passes.sh;
 # profiles/r01_pmc_traffic_f16x3.txt, ..._bf16x6.txt, r01_pmc_traffic.txt): (2 x FETCH_SIZE raw [gfx950 reports half of wide streaming reads,
 # MI355X_MICROARCH.md §HBM] + WRITE_SIZE) per launch.  Scaled linearly with the map count.
-DOM_TRAFFIC_BYTES_PER_MAP = {0: (2 * 1.9e9 + 0.86e9) / 320, 1: (2 * 1.55e9 + 0.86e9) / 320, 2: (2 * 1.22e9 + 0.77e9) / 320}
+DOM_TRAFFIC_BYTES_PER_MAP = {0: (2 * 1.9e9 + 0.86e9) / 320, 1: (2 * 1.55e9 + 0.86e9) / 320, 2: (2 * 1.22e9 + 0.77e9) / 320,
+                             3: (2 * 1.22e9 + 0.77e9) / 320}
 
 
 def host_cores():
@@ -100,7 +105,7 @@ def main():
                          "one full pass over one batch, the decoder's latency-bound kernels of one batch overlap the "
                          "MFMA-bound CNN chain of another")
     ap.add_argument("--fp32-mfma", action="store_true", help="same as --conv-mode 0")
-    ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 1, 2],
+    ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 1, 2, 3],
                     help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3 relevance (default)")
     a = ap.parse_args()
 
@@ -250,7 +255,7 @@ def main():
             per_layer = [p / reps for p in per_layer]
             # launches of that kernel NAME per pass: conv3_1 (128 output channels) and conv3_2 (256); in mode 2 conv3_3
             # is the pooled-input variant of the kernel (own name in rocprof), in modes 0/1 it is the same kernel
-            dom_layers, dom_w = ([6, 7], [0.5, 1.0]) if mode == 2 else ([6, 7, 8], [0.5, 1.0, 1.0])
+            dom_layers, dom_w = ([6, 7], [0.5, 1.0]) if mode >= 2 else ([6, 7, 8], [0.5, 1.0, 1.0])
             dom_ms = sum(per_layer[l] for l in dom_layers) / len(dom_layers)          # average launch of that kernel
             flop = DOM_FLOP_PER_MAP * B * T * sum(dom_w) / len(dom_w)                 # average algorithmic flop / launch
             alg = flop / dom_ms / 1e9                                        # TFLOP/s, fp32-equivalent
@@ -258,7 +263,7 @@ def main():
             peak = PEAK_FP32_MFMA_TF if mode == 0 else PEAK_16BIT_MFMA_TF
             out["roofline"] = {
                 "bound": "mfma", "kernel": MODE_KERNEL[mode] + f" (relevance step of conv3_1/conv3_2"
-                + ("" if mode == 2 else "/conv3_3") + f" on 56x56 maps, {B * T} maps per launch, {len(dom_layers)} launches per step)", "achieved": round(exe, 1), "peak": peak,
+                + ("" if mode >= 2 else "/conv3_3") + f" on 56x56 maps, {B * T} maps per launch, {len(dom_layers)} launches per step)", "achieved": round(exe, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(exe / peak, 4), "mfma_dtype": MODE_NAME[mode],
                 "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
                 "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,

@@ -61,6 +61,11 @@ int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mo
  * 64-byte header carries 2^-kW for the consumer's epilogue.  Same modes as lrpx_pack_weights_bf16x3. */
 size_t lrpx_packed_f16x2_bytes(int n_oc, int k, int taps);
 int lrpx_pack_weights_f16x2(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream);
+/* weights for lrpx_conv_desc.f16x3 = 2 (fp16 hi.hi product + the two cross products on the fp8 matrix cores): scaled
+ * into [2^11, 2^12), stored per tap row as fp16 hi planes + fp8 e4m3 planes of w*2^-4 and (w - hi)*2^4 in the operand
+ * layout of v_mfma_f32_32x32x64_f8f6f4 (K = 3 taps + a zero slot, x 16 channels).  3x3 kernels, modes BWD_POS / BWD_PLAIN */
+size_t lrpx_packed_f16f8_bytes(int n_oc, int k);
+int lrpx_pack_weights_f16f8(const float* w, int cout, int cin, int mode, void* packed, void* stream);
 /* K-chunk used by lrpx_conv_mfma for a given image width / taps / input channels */
 int lrpx_conv_kc(int hw, int taps, int cin);
 
@@ -90,7 +95,10 @@ typedef struct lrpx_conv_desc {
                              per layer, powers of two) and split in two halves, 3 partial products, fp32 accumulate
                              (22-bit operands: below the rounding of the fp32 accumulation itself; half the matrix
                              time of bf16x6).  wpacked from lrpx_pack_weights_f16x2; needs in_amax; REL_MUL or FWD_DUAL epilogue,
-                             3x3 convs, cin %% 16 == 0 */
+                             3x3 convs, cin %% 16 == 0.
+                             2: as 1, but the two cross products hi*lo + lo*hi (2^-11 of the result) run on the fp8 matrix
+                             cores with both factors rounded to e4m3 (error 2^-15 of a product, random sign: the maps
+                             move by < 1e-5 of their maximum); wpacked from lrpx_pack_weights_f16f8; REL_MUL only */
     int out_chunk;        /* REL_MUL: > 0 writes the output channel-chunked [C/out_chunk][n_maps*pixels][out_chunk] (16) */
     const uint32_t* in_amax;  /* f16x3: [n_maps] float bits of max|in| per map (lrpx_amax_maps, or a producer's out1_amax) */
     uint32_t* out1_amax;      /* f16x3 + out1: max|out1| per map is atomicMax-ed into it (zero it first); may be null */
@@ -149,8 +157,9 @@ int lrpx_check(const float* buf, long n, int flags, void* stream);
  * the bf16 matrix cores with exact operand splits (fp32 accuracy, see lrpx_conv_desc.bf16x6), 0 keeps the fp32 MFMA
  * everywhere; a negative value only queries.  Returns the previous setting. */
 int lrpx_set_bf16x6(int enable);
-/* Matrix-core mode of the fused VGG16 chains: 0 fp32 MFMA, 1 bf16x6 (exact splits), 2 f16x3 for the relevance pass
- * (forward trace stays bf16x6).  Negative: query only.  Returns the previous mode. */
+/* Matrix-core mode of the fused VGG16 chains: 0 fp32 MFMA, 1 bf16x6 (exact splits), 2 f16x3 (fp16 split products),
+ * 3 = 2 with the cross products of the relevance pass on the fp8 matrix cores (lrpx_conv_desc.f16x3 = 2).
+ * Negative: query only.  Returns the previous mode. */
 int lrpx_set_conv_mode(int mode);
 /* 1: the forward trace of conv1_2..conv5_3 also runs on the fp16 split-product kernels (operand scale = per-image maximum of
  * the layer input); 0: bf16x6 / fp32 as selected by the conv mode.  Negative: query.  Returns the previous value. */

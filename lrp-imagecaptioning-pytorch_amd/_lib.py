@@ -68,6 +68,8 @@ SIGNATURES = {
     "lrpx_pack_weights_bf16x3": (_i, [_f, _i, _i, _i, _i, _f, _f]),
     "lrpx_packed_f16x2_bytes": (_sz, [_i, _i, _i]),
     "lrpx_pack_weights_f16x2": (_i, [_f, _i, _i, _i, _i, _f, _f]),
+    "lrpx_packed_f16f8_bytes": (_sz, [_i, _i]),
+    "lrpx_pack_weights_f16f8": (_i, [_f, _i, _i, _i, _f, _f]),
     "lrpx_conv_kc": (_i, [_i, _i, _i]),
     "lrpx_conv_mfma": (_i, [C.POINTER(ConvDesc), _f]),
     "lrpx_nchw_to_nhwc": (_i, [_f, _f, _i, _i, _i, _i, _f]),

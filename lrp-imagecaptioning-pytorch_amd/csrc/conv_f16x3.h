@@ -35,6 +35,16 @@ __host__ __device__ __forceinline__ int f16_scale_exp(unsigned amax_bits) {
     const int k = 14 - (e - 127);
     return k > 120 ? 120 : k;
 }
+// F8 variant (cross products on the fp8 matrix cores, see below): operands are scaled into [2^11, 2^12) instead, so
+// that x * 2^-4 fits fp8 e4m3 (max 448) and the fp16 residual * 2^4 does too
+template <bool F8>
+__host__ __device__ __forceinline__ int split_scale_exp(unsigned amax_bits) {
+    if constexpr (!F8) return f16_scale_exp(amax_bits);
+    const int e = (int)((amax_bits >> 23) & 0xff);
+    if (e == 0 || e == 255) return 0;
+    const int k = 11 - (e - 127);
+    return k > 120 ? 120 : k;
+}
 __host__ __device__ __forceinline__ float exp2i(int k) {   // 2^k, |k| <= 126
     const unsigned b = (unsigned)(k + 127) << 23;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -52,6 +62,14 @@ __device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;                 // v_cvt_f16_f32, round to nearest even; inf / nan stay inf / nan
     lo = (_Float16)(x - (float)hi);   // exact difference in fp32, rounded once
 }
+
+// two / four floats -> fp8 e4m3 (OCP, round to nearest even), packed
+__device__ __forceinline__ unsigned pack_fp8x4(float x0, float x1, float x2, float x3) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, w, true);
+    return (unsigned)w;
+}
+typedef int i32x8_ __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -79,7 +97,12 @@ static __device__ unsigned long long g_stamp_h3[12];
 #define LRPXH_T(v)
 #endif
 
-template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false>
+// F8 ("f16+f8x2"): the two CROSS products a0*b1 + a1*b0 - 2^-11 of the result - do not need fp16 operands: with both
+// factors rounded to fp8 e4m3 (4 significand bits) their error is 2^-11 * 2^-4 per product, random sign; simulated
+// through all 13 layers the maps move by < 1e-5 of their maximum (tolerance 1e-4; plain f16x3: ~1e-6).  They run on
+// v_mfma_f32_32x32x64_f8f6f4, K = 64 = (tap row dy: dx = 0,1,2 + one zero slot) x 16 channels: 2 fp8 MFMAs per tap
+// row instead of 6 fp16 ones.  LDS pixel (80 B as before): 16 fp16 hi | 16 fp8 of x*2^-4 | 16 fp8 of (x-hi)*2^4 | pad.
+template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
 __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     LRPXH_T(t_start);
 #ifdef LRPX_STAMP
@@ -97,12 +120,18 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #define LRPXH_HOIST_MASK 1
 #endif
     // staging descriptors stay in registers (see item()): bit 0: 56 non-pooled, 1: 56 pooled, 2: 112 pooled, 3: 224 pooled
-    constexpr bool HOIST = AL && (((LRPXH_HOIST_MASK & 1) && HW == 56 && !POOL) || ((LRPXH_HOIST_MASK & 2) && HW == 56 && POOL) ||
+#ifndef LRPXH_F8_HOIST
+#define LRPXH_F8_HOIST 0
+#endif
+#ifndef LRPXH_F8_ABASE
+#define LRPXH_F8_ABASE 0      // 1: the fp8 tap-slot offsets live in 14 registers; 0: derived from abase[] at each use
+#endif
+    constexpr bool HOIST = (!F8 || LRPXH_F8_HOIST) && AL && (((LRPXH_HOIST_MASK & 1) && HW == 56 && !POOL) || ((LRPXH_HOIST_MASK & 2) && HW == 56 && POOL) ||
                                   ((LRPXH_HOIST_MASK & 4) && HW == 112 && POOL) || ((LRPXH_HOIST_MASK & 8) && HW == 224 && POOL));
 #ifndef LRPXH_APIPE_MIN_HW
 #define LRPXH_APIPE_MIN_HW 14
 #endif
-    constexpr bool APIPE = HW >= LRPXH_APIPE_MIN_HW;
+    constexpr bool APIPE = (HW >= LRPXH_APIPE_MIN_HW) && !F8;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
     const int tid = threadIdx.x;
@@ -157,7 +186,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     const int n_al = (int)((unsigned)g0 / (unsigned)H), y_al = (int)g0 - n_al * H;
     long img_al = 0;
     if constexpr (AL) {
-        ssc[0] = exp2i(f16_scale_exp(in_amax[min(n_al, a.n_maps - 1)]));
+        ssc[0] = exp2i(split_scale_exp<F8>(in_amax[min(n_al, a.n_maps - 1)]));
         if constexpr (POOL) img_al = a.map2img ? a.map2img[min(n_al, a.n_maps - 1)] : n_al;
     } else {
 #pragma unroll
@@ -175,7 +204,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                 if ((v_ >= 0) && (y < H) && (n < a.n_maps)) {
                     sdst[u] = (s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28);
                     sgp[u] = (int)((n * H + y) * W + px);
-                    ssc[u] = exp2i(f16_scale_exp(in_amax[n]));
+                    ssc[u] = exp2i(split_scale_exp<F8>(in_amax[n]));
                     if constexpr (POOL) {
                         const int lo = (y >> 1) * WO + (px >> 1);
                         const long img = a.map2img ? a.map2img[n] : n;
@@ -246,7 +275,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                     ldst[u] = ((s0 < 0 ? 0 : s0) * PITCH + (2 * pxl + 1) * PSTRIDE + seg * 8) | (seg << 28) | (rowmask << 26);
                     lgp[u] = (int)(n * (HO * WO) + lo);
                     lam[u] = (int)((img * (HO * WO) + lo) * a.cin);
-                    lsc[u] = exp2i(f16_scale_exp(in_amax[n]));
+                    lsc[u] = exp2i(split_scale_exp<F8>(in_amax[n]));
                 }
             }
         }
@@ -296,19 +325,34 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         float sc_;                                                                                           \
         item_lo(u, dst_, gp_, amo_, rm_, sc_);                                                               \
         _Float16 h[4], l[4];                                                                                 \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * sc_, h[e], l[e]);                    \
+        float xs_[4];                                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { xs_[e] = sv[u][e] * sc_; split2(xs_[e], h[e], l[e]); } \
+        unsigned w8_ = 0, wl8_ = 0;                                                                          \
+        if constexpr (F8) {                                                                                  \
+            w8_ = pack_fp8x4(xs_[0] * 0.0625f, xs_[1] * 0.0625f, xs_[2] * 0.0625f, xs_[3] * 0.0625f);        \
+            wl8_ = pack_fp8x4((xs_[0] - (float)h[0]) * 16.f, (xs_[1] - (float)h[1]) * 16.f,                  \
+                              (xs_[2] - (float)h[2]) * 16.f, (xs_[3] - (float)h[3]) * 16.f);                 \
+        }                                                                                                    \
         char* db_ = ldsb + (BUFIDX) * BUFB;                                                                  \
         const int o0_ = dst_ & 0x03ffffff;                                                                   \
+        const int sg4_ = ((dst_ >> 28) & 3) * 4;                                                             \
         _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                                \
             const bool wr_ = (rm_ >> (pos >> 1)) & 1;         /* this window row lies inside the LDS tile */  \
             _Float16 hm[4], lm[4];                                                                           \
+            unsigned bm_ = 0;                                                                                \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
                 const bool w_ = ((amv[u] >> (8 * e)) & 0xffu) == (unsigned)pos;                              \
                 hm[e] = w_ ? h[e] : (_Float16)0; lm[e] = w_ ? l[e] : (_Float16)0;                            \
+                bm_ |= w_ ? (0xffu << (8 * e)) : 0u;                                                         \
             }                                                                                                \
             const int o_ = o0_ + (((pos >> 1) && (rm_ & 1)) ? PITCH : 0) + (pos & 1) * PSTRIDE;              \
             *reinterpret_cast<u32x2_*>(db_ + (wr_ ? o_ : 64)) = u32x2_{pack_f16(hm[0], hm[1]), pack_f16(hm[2], hm[3])};      \
-            *reinterpret_cast<u32x2_*>(db_ + (wr_ ? o_ + 32 : 72)) = u32x2_{pack_f16(lm[0], lm[1]), pack_f16(lm[2], lm[3])}; \
+            if constexpr (F8) {                                                                              \
+                *reinterpret_cast<unsigned*>(db_ + (wr_ ? o_ + 32 - sg4_ : 72)) = w8_ & bm_;                 \
+                *reinterpret_cast<unsigned*>(db_ + (wr_ ? o_ + 48 - sg4_ : 76)) = wl8_ & bm_;                \
+            } else {                                                                                         \
+                *reinterpret_cast<u32x2_*>(db_ + (wr_ ? o_ + 32 : 72)) = u32x2_{pack_f16(lm[0], lm[1]), pack_f16(lm[2], lm[3])}; \
+            }                                                                                                \
         }                                                                                                    \
     }
 #define LRPXH_ISSUE(CHUNK) _Pragma("unroll") for (int u = 0; u < U; ++u) LRPXH_ISSUE1(u, CHUNK)
@@ -330,15 +374,25 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         item(u, dst_, gp_, amo_);                                                                            \
         const bool okl_ = gp_ >= 0;                                                                          \
         _Float16 h[4], l[4];                                                                                 \
+        float xs_[4];                                                                                        \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
-            const float x_ = okl_ ? sv[u][e] * ssc[AL ? 0 : u] : 0.f;                                        \
-            split2(x_, h[e], l[e]);                                                                          \
+            xs_[e] = okl_ ? sv[u][e] * ssc[AL ? 0 : u] : 0.f;                                                \
+            split2(xs_[e], h[e], l[e]);                                                                      \
         }                                                                                                    \
         char* db_ = ldsb + (BUFIDX) * BUFB;                                                                  \
         *reinterpret_cast<u32x2_*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) : 64)) =                           \
             u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};                                              \
-        *reinterpret_cast<u32x2_*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) + 32 : 72)) =                      \
-            u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};                                              \
+        if constexpr (F8) {                                                                                  \
+            const int sg4_ = dst_ >= 0 ? ((dst_ >> 28) & 3) * 4 : 0;                                         \
+            *reinterpret_cast<unsigned*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) + 32 - sg4_ : 72)) =         \
+                pack_fp8x4(xs_[0] * 0.0625f, xs_[1] * 0.0625f, xs_[2] * 0.0625f, xs_[3] * 0.0625f);          \
+            *reinterpret_cast<unsigned*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) + 48 - sg4_ : 76)) =         \
+                pack_fp8x4((xs_[0] - (float)h[0]) * 16.f, (xs_[1] - (float)h[1]) * 16.f,                     \
+                           (xs_[2] - (float)h[2]) * 16.f, (xs_[3] - (float)h[3]) * 16.f);                    \
+        } else {                                                                                             \
+            *reinterpret_cast<u32x2_*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) + 32 : 72)) =                  \
+                u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};                                          \
+        }                                                                                                    \
     }
 
     if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(0) } else { LRPXH_ISSUE(0) }
@@ -379,19 +433,41 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     constexpr int NBQ = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : (((HW == 112 && NWN == 2) || (HOIST && !POOL)) ? 8 : 9));
 #endif
     const float inv_w = a.wp[0];
+    // F8: one queue entry per tap ROW = 7 planes of 64 lanes x 16 B: fp16 hi of dx = 0,1,2 | fp8 W*2^-4 (2 planes: the
+    // lane's two tap slots) | fp8 (W - hi)*2^4 (2 planes); lanes 0-31 hold slots dx = 0,1, lanes 32-63 dx = 2 and a zero
+    constexpr int BP = F8 ? 7 : 2;                  // planes per queue entry
+    constexpr int BSTEPS = F8 ? 3 : TAPS;           // queue entries per K-chunk
+    // measured (tools/variant_sweep3.sh, chain of 320 maps): 2 entries 24.1 ms, 3 entries 25.1 (spills), 4: 30.1
+#ifdef LRPXH_NBQ8
+    constexpr int NQ = F8 ? LRPXH_NBQ8 : NBQ;
+#else
+    constexpr int NQ = F8 ? 2 : NBQ;
+#endif
     const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
-                       (long)ocb * nchunk * (TAPS * 2 * 64) + lane;
-    const int last_step = nchunk * TAPS - 1;
-    u32x4_ bq[NBQ][2];
+                       (long)ocb * nchunk * (BSTEPS * BP * 64) + lane;
+    const int last_step = nchunk * BSTEPS - 1;
+    u32x4_ bq[NQ][BP];
 #pragma unroll
-    for (int i = 0; i < NBQ; ++i)
+    for (int i = 0; i < NQ; ++i)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) bq[i][p] = u32x4_{0, 0, 0, 0};
+        for (int p = 0; p < BP; ++p) bq[i][p] = u32x4_{0, 0, 0, 0};
     if (wave_active) {
 #pragma unroll
-        for (int i = 0; i < NBQ - 1; ++i)
+        for (int i = 0; i < NQ - 1; ++i)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) bq[i][p] = wp[((long)min(i, last_step) * 2 + p) * 64];
+            for (int p = 0; p < BP; ++p) bq[i][p] = wp[((long)min(i, last_step) * BP + p) * 64];
+    }
+    // F8: LDS byte offsets of the lane's two fp8 tap slots of a tap row (dx = 0 / 1 for lanes 0-31; dx = 2 / 2 for lanes
+    // 32-63, whose second slot carries zero weights)
+    int abase8a[(F8 && LRPXH_F8_ABASE) ? 7 : 1], abase8b[(F8 && LRPXH_F8_ABASE) ? 7 : 1];
+    const int d8a = lh ? 2 * PSTRIDE - 16 : 0, d8b = lh ? 2 * PSTRIDE - 16 : PSTRIDE;   // slot offsets relative to abase[]
+    if constexpr (F8 && LRPXH_F8_ABASE) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int b8 = abase[j] - lh * 16;
+            abase8a[j] = b8 + (lh ? 2 * PSTRIDE : 0);
+            abase8b[j] = b8 + (lh ? 2 * PSTRIDE : PSTRIDE);
+        }
     }
     __syncthreads();
 
@@ -410,6 +486,46 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #endif
             // APIPE (wide maps with few K-chunks: the partner wave of the SIMD is mostly outside its MFMA phase, so this
             // wave's LDS latency is not covered by the partner's MFMAs): A fragments are read one accumulator tile ahead
+            if constexpr (F8) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step) * BP;
+#pragma unroll
+                    for (int p = 0; p < BP; ++p) bq[NQ - 1][p] = wp[(nxt + p) * 64];
+                    const f16x8 bh0 = __builtin_bit_cast(f16x8, bq[0][0]);
+                    const f16x8 bh1 = __builtin_bit_cast(f16x8, bq[0][1]);
+                    const f16x8 bh2 = __builtin_bit_cast(f16x8, bq[0][2]);
+                    const i32x8_ bw8 = {(int)bq[0][3][0], (int)bq[0][3][1], (int)bq[0][3][2], (int)bq[0][3][3],
+                                        (int)bq[0][4][0], (int)bq[0][4][1], (int)bq[0][4][2], (int)bq[0][4][3]};
+                    const i32x8_ bl8 = {(int)bq[0][5][0], (int)bq[0][5][1], (int)bq[0][5][2], (int)bq[0][5][3],
+                                        (int)bq[0][6][0], (int)bq[0][6][1], (int)bq[0][6][2], (int)bq[0][6][3]};
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        const char* ap = abuf + abase[j] + g * PITCH;
+                        const char* pa = abuf + (LRPXH_F8_ABASE ? abase8a[j] : abase[j] + d8a) + g * PITCH;
+                        const char* pb = abuf + (LRPXH_F8_ABASE ? abase8b[j] : abase[j] + d8b) + g * PITCH;
+                        const u32x4_ s8a = *reinterpret_cast<const u32x4_*>(pa + 32), l8a = *reinterpret_cast<const u32x4_*>(pa + 48);
+                        // (lanes 32-63 re-read dx = 2 for their zero-weight slot: leaving them out of the read with an
+                        //  exec mask was 45 % slower - every masked region fences the scheduler)
+                        const u32x4_ s8b = *reinterpret_cast<const u32x4_*>(pb + 32), l8b = *reinterpret_cast<const u32x4_*>(pb + 48);
+                        const f16x8 h0 = *reinterpret_cast<const f16x8*>(ap);
+                        const f16x8 h1 = *reinterpret_cast<const f16x8*>(ap + PSTRIDE);
+                        const f16x8 h2 = *reinterpret_cast<const f16x8*>(ap + 2 * PSTRIDE);
+                        const i32x8_ as8 = {(int)s8a[0], (int)s8a[1], (int)s8a[2], (int)s8a[3], (int)s8b[0], (int)s8b[1], (int)s8b[2], (int)s8b[3]};
+                        const i32x8_ al8 = {(int)l8a[0], (int)l8a[1], (int)l8a[2], (int)l8a[3], (int)l8b[0], (int)l8b[1], (int)l8b[2], (int)l8b[3]};
+                        // small terms first: (x - hi) * W and x * (W - hi_W) on the fp8 cores, then hi * hi_W
+                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al8, bw8, acc[j], 0, 0, 0, 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(as8, bl8, acc[j], 0, 0, 0, 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh0, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh1, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, bh2, acc[j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NQ - 1; ++i)
+#pragma unroll
+                        for (int p = 0; p < BP; ++p) bq[i][p] = bq[i + 1][p];
+                }
+            } else {
             f16x8 n0, n1;
             if constexpr (APIPE) {
                 n0 = *reinterpret_cast<const f16x8*>(abuf + abase[0]);
@@ -478,6 +594,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                 }
 #endif
             }
+            }   // !F8
         }
         LRPXH_T(tc);
         if constexpr (ILV) {
@@ -535,7 +652,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     const int nmax = a.n_maps - 1;
     if constexpr (AL) {
         const unsigned n = (unsigned)g0 / (unsigned)H;
-        const float inv_a = exp2i(-f16_scale_exp(in_amax[min((int)n, nmax)]));
+        const float inv_a = exp2i(-split_scale_exp<F8>(in_amax[min((int)n, nmax)]));
 #pragma unroll
         for (int j = 0; j < 7; ++j)
 #pragma unroll
@@ -549,8 +666,8 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             const unsigned g = (unsigned)cx.g0 + rr;
             const unsigned n0 = g / (unsigned)HW;
             const int p0 = (int)((g - n0 * HW) * HW + c0);
-            const float i0 = exp2i(-f16_scale_exp(in_amax[min((int)n0, nmax)]));
-            const float i1 = exp2i(-f16_scale_exp(in_amax[min((int)n0 + 1, nmax)]));
+            const float i0 = exp2i(-split_scale_exp<F8>(in_amax[min((int)n0, nmax)]));
+            const float i1 = exp2i(-split_scale_exp<F8>(in_amax[min((int)n0 + 1, nmax)]));
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int dq = (e & 3) + 8 * (e >> 2);
@@ -635,14 +752,14 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #endif
 }
 
-template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false>
+template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
 int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
     using C = ConvCfg<HW, 16, MT, NWN, 9>;
     constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 80 + 256);
     const long m_tiles = ceil_div((long)a.n_maps * HW, C::R);
     const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
     const long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
-    auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI, POOL>;
+    auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI, POOL, F8>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=

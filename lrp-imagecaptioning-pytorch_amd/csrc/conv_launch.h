@@ -73,6 +73,17 @@ int launch_h3_112n_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_28_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_14_rel(const ConvArgs& a, hipStream_t s);
+// f16+f8 relevance kernels (conv_f16x3.h, F8 = true): hi.hi on the fp16 matrix cores, the two cross products on fp8
+int launch_h8_56_rel(const ConvArgs& a, hipStream_t s);
+int launch_h8_28_rel(const ConvArgs& a, hipStream_t s);
+int launch_h8_14_rel(const ConvArgs& a, hipStream_t s);
+int launch_h8_112_rel(const ConvArgs& a, hipStream_t s);
+int launch_h8_112n_rel(const ConvArgs& a, hipStream_t s);
+int launch_h8_224_rel(const ConvArgs& a, hipStream_t s);
+int launch_h8_224_pool(const ConvArgs& a, hipStream_t s);
+int launch_h8_112_pool(const ConvArgs& a, hipStream_t s);
+int launch_h8_56_pool(const ConvArgs& a, hipStream_t s);
+int launch_h8_28_pool(const ConvArgs& a, hipStream_t s);
 int launch_h3_224_fwd(const ConvArgs& a, hipStream_t s);    // forward trace (ReLU(conv+b) and Z+) on the fp16 matrix cores
 int launch_h3_112_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_fwd(const ConvArgs& a, hipStream_t s);

@@ -216,6 +216,54 @@ __global__ void pack_weights_f16x2_kernel(const float* __restrict__ w, float* __
     out[base + 512] = __builtin_bit_cast(unsigned short, lo);
 }
 
+// weights for the F8 variant of conv_f16x3.h (fp16 hi.hi product + two fp8 cross products): 64-byte header {2^-kW, amax
+// bits}, then [ocb][chunk 16][tap row 3][plane 7][lane 64][16 B]: planes 0-2 = fp16 hi of dx = 0,1,2 (lane map as the
+// f16x2 pack), planes 3/4 = fp8 e4m3 of W*2^-4 for the lane's two tap slots x 16 channels (lanes 0-31: dx = 0 / 1, lanes
+// 32-63: dx = 2 / zero), planes 5/6 = fp8 of (W - hi)*2^4 likewise.  W is scaled into [2^11, 2^12) first.
+__global__ void pack_weights_f16f8_kernel(const float* __restrict__ w, float* __restrict__ header, int cout, int cin,
+                                          int mode, int k_pad, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int kw = split_scale_exp<true>(reinterpret_cast<const unsigned*>(header)[1]);
+    if (idx == 0) header[0] = exp2i(-kw);
+    const float sc = exp2i(kw);
+    const int lane = idx & 63;
+    long rest = idx >> 6;
+    const int g = rest % 3; rest /= 3;
+    const int nchunk = k_pad / 16;
+    const int chunk = rest % nchunk; rest /= nchunk;
+    const int ocb = (int)rest;
+    const int oc = ocb * 32 + (lane & 31), lh = lane >> 5;
+    auto wv = [&](int k, int dx) -> float {      // scaled weight of (input channel k of this pass, tap (g, dx))
+        const int tap = g * 3 + dx;
+        float v = 0.f;
+        if (mode == LRPX_PACK_BWD_POS) { if (k < cout && oc < cin) v = fmaxf(w[((long)k * cin + oc) * 9 + (8 - tap)], 0.f); }
+        else if (mode == LRPX_PACK_BWD_PLAIN) { if (k < cout && oc < cin) v = w[((long)k * cin + oc) * 9 + (8 - tap)]; }
+        return v * sc;
+    };
+    unsigned char* out = reinterpret_cast<unsigned char*>(header + F16X3_HEADER_FLOATS) +
+                         ((((long)ocb * nchunk + chunk) * 3 + g) * 7) * 1024 + lane * 16;
+    for (int dx = 0; dx < 3; ++dx) {
+        unsigned short* o = reinterpret_cast<unsigned short*>(out + dx * 1024);
+        for (int j = 0; j < 8; ++j) o[j] = __builtin_bit_cast(unsigned short, (_Float16)wv(chunk * 16 + 8 * lh + j, dx));
+    }
+    for (int slot = 0; slot < 2; ++slot) {
+        const int dx = lh ? 2 : slot;
+        const bool zero = lh && slot;
+        unsigned* o8 = reinterpret_cast<unsigned*>(out + (3 + slot) * 1024);
+        unsigned* ol = reinterpret_cast<unsigned*>(out + (5 + slot) * 1024);
+        for (int q = 0; q < 4; ++q) {
+            float x[4], r[4];
+            for (int e = 0; e < 4; ++e) {
+                x[e] = zero ? 0.f : wv(chunk * 16 + q * 4 + e, dx);
+                r[e] = x[e] - (float)(_Float16)x[e];
+            }
+            o8[q] = pack_fp8x4(x[0] * 0.0625f, x[1] * 0.0625f, x[2] * 0.0625f, x[3] * 0.0625f);
+            ol[q] = pack_fp8x4(r[0] * 16.f, r[1] * 16.f, r[2] * 16.f, r[3] * 16.f);
+        }
+    }
+}
+
 static void pack_dims(int cout, int cin, int mode, int kc, int* n_oc_pad, int* k_pad) {
     int n_oc, k;
     switch (mode) {
@@ -680,6 +728,27 @@ int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* s
 size_t lrpx_packed_f16x2_bytes(int n_oc, int k, int taps) {
     return F16X3_HEADER_FLOATS * sizeof(float) +
            (size_t)round_up(n_oc, 32) * (size_t)round_up(k, 16) * (size_t)taps * 2 * sizeof(unsigned short);
+}
+
+size_t lrpx_packed_f16f8_bytes(int n_oc, int k) {
+    return F16X3_HEADER_FLOATS * sizeof(float) + (size_t)(round_up(n_oc, 32) / 32) * (size_t)(round_up(k, 16) / 16) * 3 * 7 * 1024;
+}
+
+int lrpx_pack_weights_f16f8(const float* w, int cout, int cin, int mode, void* packed, void* stream) {
+    LRPX_REQUIRE(w && packed, "pack_weights_f16f8: bad arguments");
+    LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN, "pack_weights_f16f8: mode %d not supported", mode);
+    int n_oc_pad, k_pad;
+    pack_dims(cout, cin, mode, 16, &n_oc_pad, &k_pad);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(packed, 0, F16X3_HEADER_FLOATS * sizeof(float), st) != hipSuccess) {
+        set_error("pack_weights_f16f8: memset failed");
+        return LRPX_ELAUNCH;
+    }
+    hipLaunchKernelGGL(amax_flat_kernel, dim3(256), dim3(256), 0, st, w, (long)cout * cin * 9, (unsigned*)packed + 1);
+    const long total = (long)(n_oc_pad / 32) * (k_pad / 16) * 3 * 64;
+    hipLaunchKernelGGL(pack_weights_f16f8_kernel, dim3(grid_for(total)), dim3(256), 0, st, w, (float*)packed, cout, cin,
+                       mode, k_pad, total);
+    return check_launch("pack_weights_f16f8");
 }
 
 int lrpx_pack_weights_f16x2(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream) {

@@ -83,15 +83,32 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
             if (d->hw == 14) return launch_h3_14_fwd(a, s);
             LRPX_REQUIRE(false, "conv_mfma: no f16x3 forward kernel built for hw=%d", d->hw);
         }
+        const bool f8 = d->f16x3 == 2;
+        LRPX_REQUIRE(!f8 || d->epi == EPI_REL_MUL, "conv_mfma: the f16+f8 kernels are built for the REL_MUL epilogue only");
         if (d->pool_am) {
             // the kernels index pool_am with 32-bit element offsets (image * pooled pixels * channels)
             LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
                          "conv_mfma: too many (image, pooled pixel, channel) elements for the pooled-input kernel");
+            if (f8) {
+                if (d->hw == 224 && d->n_oc <= 64) return launch_h8_224_pool(a, s);
+                if (d->hw == 112 && d->n_oc > 64) return launch_h8_112_pool(a, s);
+                if (d->hw == 56) return launch_h8_56_pool(a, s);
+                if (d->hw == 28) return launch_h8_28_pool(a, s);
+                LRPX_REQUIRE(false, "conv_mfma: no pooled-input f16+f8 kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+            }
             if (d->hw == 224 && d->n_oc <= 64) return launch_h3_224_pool(a, s);
             if (d->hw == 112 && d->n_oc > 64) return launch_h3_112_pool(a, s);
             if (d->hw == 56) return launch_h3_56_pool(a, s);
             if (d->hw == 28) return launch_h3_28_pool(a, s);
             LRPX_REQUIRE(false, "conv_mfma: no pooled-input f16x3 kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
+        if (f8) {
+            if (d->hw == 224) return launch_h8_224_rel(a, s);
+            if (d->hw == 112) return d->n_oc <= 64 ? launch_h8_112n_rel(a, s) : launch_h8_112_rel(a, s);
+            if (d->hw == 56) return launch_h8_56_rel(a, s);
+            if (d->hw == 28) return launch_h8_28_rel(a, s);
+            if (d->hw == 14) return launch_h8_14_rel(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no f16+f8 kernel built for hw=%d", d->hw);
         }
         if (d->hw == 224) return launch_h3_224_rel(a, s);
         if (d->hw == 112) return d->n_oc <= 64 ? launch_h3_112n_rel(a, s) : launch_h3_112_rel(a, s);
@@ -192,13 +209,13 @@ static hipEvent_t g_ev[17][2];
 static bool g_ev_made = false, g_ev_valid[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], fwd6[17], fwdh[17], bias[17], first6, first6p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], fwd6[17], fwdh[17], bias[17], first6, first6p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
     size_t off = 0;
     for (int l = 0; l < kNL; ++l) {
-        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.bwdph[l] = p.fwd6[l] = p.fwdh[l] = p.bias[l] = 0;
+        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.bwdph[l] = p.bwd8[l] = p.fwd6[l] = p.fwdh[l] = p.bias[l] = 0;
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
@@ -209,6 +226,7 @@ static VggPacked vgg_packed_layout() {
         if (l > 0) { p.bwdh[l] = off; off += lrpx_packed_f16x2_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (l > 0) { p.fwdh[l] = off; off += lrpx_packed_f16x2_bytes(2 * L.cout, L.cin, 9) / sizeof(float); }
         if (l > 0) { p.bwdph[l] = off; off += lrpx_packed_f16x2_bytes(L.cin, L.cout, 9) / sizeof(float); }
+        if (l > 0) { p.bwd8[l] = off; off += lrpx_packed_f16f8_bytes(L.cin, L.cout) / sizeof(float); }
         if (L.hw <= 112) {
             p.fwd6[l] = off; off += lrpx_packed_bf16x3_bytes(2 * L.cout, L.cin, 9) / sizeof(float);
         }
@@ -285,7 +303,7 @@ int lrpx_set_forward_f16(int enable) {
 
 int lrpx_set_conv_mode(int mode) {
     const int prev = g_mode;
-    if (mode >= 0) g_mode = mode > 2 ? 2 : mode;
+    if (mode >= 0) g_mode = mode > 3 ? 3 : mode;
     return prev;
 }
 
@@ -327,6 +345,7 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwdh[l], stream));
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwdh[l], stream));
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, base + p.bwdph[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16f8(w[ci], L.cout, L.cin, LRPX_PACK_BWD_POS, base + p.bwd8[l], stream));
         if (L.hw <= 112) {
             LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwd6[l], stream));
         }
@@ -374,7 +393,7 @@ int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, voi
     const VggTrace t = vgg_trace_layout(n_img);
     const float* pk = (const float*)packed;
     float* tr = (float*)trace;
-    if (g_fwd_f16 && g_mode == 2 && hipMemsetAsync(tr + t.famax, 0, (size_t)18 * n_img * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+    if (g_fwd_f16 && g_mode >= 2 && hipMemsetAsync(tr + t.famax, 0, (size_t)18 * n_img * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
         set_error("vgg16_forward: cannot zero the amax words");
         return LRPX_ELAUNCH;
     }
@@ -388,7 +407,7 @@ int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, voi
             d.n_maps = n_img; d.hw = L.hw; d.cin = cin_pad(l); d.n_oc = 2 * L.cout; d.taps = 9;
             d.epi = EPI_FWD_DUAL; d.oc_split = L.cout; d.bias = pk + p.bias[l];
             d.out0 = tr + t.act[l + 1]; d.out1 = tr + t.zpos[l];
-            if (g_fwd_f16 && g_mode == 2 && l >= 1) {
+            if (g_fwd_f16 && g_mode >= 2 && l >= 1) {
                 // fp16 split products (conv_f16x3.h): operand scale = max of the layer input per image; a max-pool keeps it
                 unsigned* fam = reinterpret_cast<unsigned*>(tr + t.famax);
                 const int in_l = kVgg[l - 1].conv ? l : l - 1;
@@ -428,7 +447,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
     int cur = 0;
     int cur_chunked = 0;   // S[cur] is stored in K-chunks (written so by the pool kernel for the 224^2 / 112^2 layers)
     // f16x3 mode: amax[l*n_maps + n] = bits of max|S| of map n in the S tensor that conv layer l consumes
-    const bool h3 = g_mode == 2;
+    const bool h3 = g_mode >= 2;
     unsigned* amax = h3 ? reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps) : nullptr;
     if (h3 && hipMemsetAsync(amax, 0, (size_t)kNL * n_maps * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
         set_error("vgg16_relevance: cannot zero the amax words");
@@ -471,6 +490,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
         if (h3) {
             d.f16x3 = 1; d.epi = EPI_REL_MUL; d.wpacked = pk + p.bwdh[l]; d.in_amax = amax + (size_t)l * n_maps;
+            if (g_mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }   // cross products on the fp8 matrix cores
             // under a pool: S[cur] is the low-resolution tensor the conv above the pool wrote, unpooled while staged
             if (l + 1 < kNL && !kVgg[l + 1].conv) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
         }
@@ -555,7 +575,7 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
         d.in = G[cur]; d.wpacked = pk + p.bwdp[l];
         d.n_maps = n_maps; d.hw = L.hw; d.cin = L.cout; d.taps = 9; d.map2img = map2img;
         d.n_oc = L.cin; d.oc_split = L.cin;
-        if (g_mode == 2) {
+        if (g_mode >= 2) {
             // fp16 split-product kernels: operand scale = per-map maximum of the incoming gradient (one streaming read)
             unsigned* gam = reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps) + (size_t)l * n_maps;
             LRPX_TRY(lrpx_amax_maps(G[cur], n_maps, (long)L.hw * L.hw * L.cout, gam, st));

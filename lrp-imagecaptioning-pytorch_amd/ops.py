@@ -58,6 +58,15 @@ def pack_weights_f16x2(w, cout, cin, mode):
     return out
 
 
+def pack_weights_f16f8(w, cout, cin, mode):
+    """3x3 conv weights for conv_mfma(..., f16x3=2): fp16 hi planes + fp8 planes of the cross-product operands."""
+    lib = _lib.load()
+    n_oc, k = (cin, cout)
+    out = torch.empty(lib.lrpx_packed_f16f8_bytes(n_oc, k) // 4, dtype=torch.float32, device=w.device)
+    check(lib.lrpx_pack_weights_f16f8(ptr(w.contiguous()), cout, cin, mode, ptr(out), stream_ptr()))
+    return out
+
+
 def amax_maps(s, n_maps):
     """Float bits of max|s[n]| per map (int32 tensor): the operand scale an f16x3 convolution needs for its input."""
     s = _dev(s)

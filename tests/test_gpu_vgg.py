@@ -63,7 +63,7 @@ def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False, f16x3
     s = ops.divide_stab(to_nhwc(r_out, cout_p).to(dev), zpos, m2i, _lib.STAB_SAFE)
     kc_b = ops.conv_kc(hw, 9, cout_p)
     if f16x3:
-        wb = ops.pack_weights_f16x2(wg, cout_p, cin_p, _lib.PACK_BWD_POS)
+        wb = (ops.pack_weights_f16f8 if int(f16x3) == 2 else ops.pack_weights_f16x2)(wg, cout_p, cin_p, _lib.PACK_BWD_POS)
     elif bf16x6:
         wb = ops.pack_weights_bf16x3(wg, cout_p, cin_p, _lib.PACK_BWD_POS)
     else:
@@ -74,14 +74,14 @@ def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False, f16x3
         # multiplicand x = X / safe(Z_next) precomputed (what lrpx_vgg16_trace_derive stores per image)
         amax_in = ops.amax_maps(s, n_maps)
         ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xg, map2img=m2i,
-                      out0=r_in, f16x3=1, in_amax=amax_in)
+                      out0=r_in, f16x3=int(f16x3), in_amax=amax_in)
         if zdiv_next is not None:
             zn = to_nhwc(zdiv_next, cin_p).to(dev)
             xz = xg / (zn + 1e-7 * (zn == 0))
             out1 = torch.empty_like(r_in)
             out1_amax = torch.zeros(n_maps, dtype=torch.int32, device=dev)
             ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xz, map2img=m2i,
-                          out1=out1, f16x3=1, in_amax=amax_in, out1_amax=out1_amax)
+                          out1=out1, f16x3=int(f16x3), in_amax=amax_in, out1_amax=out1_amax)
             torch.cuda.synchronize()
             gpu_conv_rule.last_out1 = (out1.cpu(), out1_amax.cpu())
     else:
@@ -165,9 +165,45 @@ def test_conv_rule_f16x3_is_fp32_grade(ops, hw, cin, cout, n_img, n_maps):
         assert out1_amax[i:i + 1].view(torch.float32).item() == out1[i].abs().max().item()
 
 
+@pytest.mark.parametrize("hw,cin,cout,n_img,n_maps", [
+    (14, 64, 96, 3, 5), (28, 32, 64, 2, 3), (56, 64, 128, 1, 2), (112, 64, 128, 1, 2), (112, 128, 128, 1, 1),
+    (224, 64, 64, 1, 2)])
+def test_conv_rule_f16f8(ops, hw, cin, cout, n_img, n_maps):
+    """f16x3 = 2: the hi.hi product on the fp16 matrix cores, the two cross products (2^-11 of the result) on the fp8
+    ones with both factors rounded to e4m3.  Same 1e-4 contract against the oracle per map on maps whose scales differ
+    by 1e6; against the fp32-MFMA kernel a single layer stays below the worst case of ONE dominant term, 2 x 2^-15 (the
+    relevance here is heavy-tailed, e^(+-8): sums dominated by one entry do not average the fp8 rounding of the cross
+    terms; typical maps: ~1e-5, whole chain on the reference's maps: see test_vgg_relevance_f16f8_mode_same_trace)."""
+    from oracle import lrp_oracle as O
+    g = torch.Generator().manual_seed(hw * 91 + cin)
+    x = torch.relu(torch.randn(n_img, cin, hw, hw, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.03
+    r = torch.randn(n_maps, cout, hw, hw, generator=g) * torch.exp(4 * torch.randn(n_maps, cout, hw, hw, generator=g))
+    r = r * torch.logspace(0, -6, n_maps).view(-1, 1, 1, 1)
+    m2i = [i % n_img for i in range(n_maps)]
+    zn = torch.rand(n_img, cin, hw, hw, generator=g) + 0.5
+    got, _, _ = gpu_conv_rule(ops, x, w, r, m2i, f16x3=2, zdiv_next=zn)
+    out1, out1_amax = gpu_conv_rule.last_out1
+    got32, _, _ = gpu_conv_rule(ops, x, w, r, m2i)
+    want = torch.cat([O.conv_alpha1beta0(x[m2i[i]:m2i[i] + 1], w, r[i:i + 1]) for i in range(n_maps)])
+    errs = []
+    for i in range(n_maps):
+        errs.append(rel_err(got[i], got32[i]))
+        assert rel_err(got[i], want[i]) < TOL
+        assert errs[-1] < 6.2e-5, errs      # worst case of one dominant term: 2 cross products x 2^-15
+        assert cosine(got[i], want[i]) > 0.99999
+    cin_p = out1.shape[-1]
+    s_next = to_nhwc(want / (zn[m2i] + 1e-7 * (zn[m2i] == 0)), cin_p)
+    for i in range(n_maps):
+        assert rel_err(out1[i], s_next[i]) < 6.2e-5
+        assert out1_amax[i:i + 1].view(torch.float32).item() == out1[i].abs().max().item()
+    print("f16f8 single-layer error vs fp32 MFMA per map:", ["%.2e" % e for e in errs])
+
+
+@pytest.mark.parametrize("f8", [False, True])
 @pytest.mark.parametrize("hw,cpool,cin,n_img,n_maps", [(28, 64, 32, 2, 3), (56, 32, 64, 1, 2), (112, 32, 128, 1, 2),
                                                         (224, 16, 64, 1, 1)])
-def test_pooled_input_conv_rule(ops, hw, cpool, cin, n_img, n_maps):
+def test_pooled_input_conv_rule(ops, hw, cpool, cin, n_img, n_maps, f8):
     """Pool2d rule (lrp_modules.py:182-195) + the conv rule under the pool in ONE kernel: the conv receives the
     relevance at the pool's OUTPUT and the winner positions (lrpx_pool_winner) and unpools while staging.
     Checked against the oracle's two-step evaluation: maxpool_rule -> safe_divide by Z+ -> conv_alpha1beta0's
@@ -205,11 +241,11 @@ def test_pooled_input_conv_rule(ops, hw, cpool, cin, n_img, n_maps):
     s_lo = to_nhwc(r_pool_out, cp).to(dev) / (to_nhwc(pooled, cp).to(dev)[m2i] + 1e-7 * (to_nhwc(pooled, cp).to(dev)[m2i] == 0))
     s_lo = (s_lo * xzw[m2i]).contiguous()
     wpad = torch.zeros(cp, cin_p, 3, 3); wpad[:cpool, :cin] = w
-    wb = ops.pack_weights_f16x2(wpad.to(dev), cp, cin_p, _lib.PACK_BWD_POS)
+    wb = (ops.pack_weights_f16f8 if f8 else ops.pack_weights_f16x2)(wpad.to(dev), cp, cin_p, _lib.PACK_BWD_POS)
     xg = to_nhwc(xin, cin_p).to(dev)
     r_in = torch.empty(n_maps, hw * hw, cin_p, device=dev)
     ops.conv_mfma(s_lo, wb, n_maps, hw, cp, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xg,
-                  map2img=torch.tensor(m2i, dtype=torch.int32, device=dev), out0=r_in, f16x3=1,
+                  map2img=torch.tensor(m2i, dtype=torch.int32, device=dev), out0=r_in, f16x3=2 if f8 else 1,
                   in_amax=ops.amax_maps(s_lo, n_maps), pool_am=am)
     torch.cuda.synchronize()
     got = from_nhwc(r_in.cpu(), cin, hw, hw)
@@ -314,6 +350,33 @@ def test_vgg_relevance_vs_reference_maps_same_trace(ops, gridtd_case):
     assert rel_err(cum[2:3], g["map_full_2"]) < TOL
     assert cosine(cum[2:3], g["map_full_2"]) > 0.99999
     assert (cum[2:3] - torch.from_numpy(g["map_full_2"])).abs().max() < 1e-4
+
+
+def test_vgg_relevance_f16f8_mode_same_trace(ops, gridtd_case):
+    """the whole relevance chain with the cross products on the fp8 matrix cores (conv mode 3) against the reference's
+    maps on the reference's own activations: the strict 1e-4 bound, and within 2e-5 of the f16x3 chain"""
+    from lrp_amd import _lib
+    g, sd, img = gridtd_case
+    vgg = _vgg(ops, sd)
+    vgg.forward(img.cuda())
+    _inject_oracle_trace(vgg, sd, img)
+    r_feat = torch.cat([torch.from_numpy(g[f"r_feat_{t}"]) for t in range(3)])
+    m2i = torch.zeros(3, dtype=torch.int32, device="cuda")
+    lib = _lib.load()
+    prev = lib.lrpx_set_conv_mode(3)
+    try:
+        maps8 = vgg.relevance(to_nhwc(r_feat).cuda(), m2i).clone()
+        lib.lrpx_set_conv_mode(2)
+        maps3 = vgg.relevance(to_nhwc(r_feat).cuda(), m2i).clone()
+    finally:
+        lib.lrpx_set_conv_mode(prev)
+    ops.check_relevance(maps8, finite=True, nonzero=True)
+    e83 = [rel_err(maps8[t].cpu(), maps3[t].cpu()) for t in range(3)]
+    print("f16f8 chain vs f16x3 chain per map:", ["%.2e" % e for e in e83])
+    assert max(e83) < 3e-5
+    cum = ops.cumsum_maps(maps8, 1, 3).cpu()
+    assert rel_err(cum[2:3], g["map_full_2"]) < TOL
+    assert cosine(cum[2:3], g["map_full_2"]) > 0.99999
 
 
 def test_vgg_relevance_vs_reference_maps_end_to_end(ops, gridtd_case):

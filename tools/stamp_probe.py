@@ -12,6 +12,8 @@ import lrp_amd  # noqa: E402,F401
 from lrp_amd import _lib, ops, weights  # noqa: E402
 
 lib = _lib.load()
+if os.environ.get("LRPX_CONV_MODE"):
+    lib.lrpx_set_conv_mode(int(os.environ["LRPX_CONV_MODE"]))
 sd = weights.make_gridtd_state(seed=0, vocab_size=64)
 names = [k for k in sd if k.startswith("img_encoder.encoder.") and k.endswith(".weight")]
 vgg = ops.Vgg16([torch.from_numpy(sd[k]).cuda() for k in names],
