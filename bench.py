@@ -105,7 +105,7 @@ def main():
                          "one full pass over one batch, the decoder's latency-bound kernels of one batch overlap the "
                          "MFMA-bound CNN chain of another")
     ap.add_argument("--fp32-mfma", action="store_true", help="same as --conv-mode 0")
-    ap.add_argument("--conv-mode", type=int, default=2, choices=[0, 1, 2, 3],
+    ap.add_argument("--conv-mode", type=int, default=3, choices=[0, 1, 2, 3],
                     help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3 relevance (default)")
     a = ap.parse_args()
 

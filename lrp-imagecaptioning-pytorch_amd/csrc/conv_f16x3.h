@@ -97,11 +97,17 @@ static __device__ unsigned long long g_stamp_h3[12];
 #define LRPXH_T(v)
 #endif
 
+// F8 slot map (shared with pack_weights_f16f8_kernel).  The 18 cross-product (tap, 16 channels) K-slices of a K-chunk -
+// slots 0-8: (x - hi) * W of taps 0-8 ("L"), slots 9-17: x * (W - hi_W) of taps 0-8 ("S"), 18/19: zero weights - fill
+// five K = 64 fp8 MFMAs of four slots each; lanes 0-31 feed slots 4m, 4m+1 of MFMA m, lanes 32-63 slots 4m+2, 4m+3.
+__host__ __device__ constexpr int f8_slot_tap(int s) { return s < 9 ? s : (s < 18 ? s - 9 : 8); }
+__host__ __device__ constexpr int f8_slot_kind(int s) { return s < 9 ? 0 : (s < 18 ? 1 : 2); }   // 0 L, 1 S, 2 pad
+
 // F8 ("f16+f8x2"): the two CROSS products a0*b1 + a1*b0 - 2^-11 of the result - do not need fp16 operands: with both
 // factors rounded to fp8 e4m3 (4 significand bits) their error is 2^-11 * 2^-4 per product, random sign; simulated
 // through all 13 layers the maps move by < 1e-5 of their maximum (tolerance 1e-4; plain f16x3: ~1e-6).  They run on
-// v_mfma_f32_32x32x64_f8f6f4, K = 64 = (tap row dy: dx = 0,1,2 + one zero slot) x 16 channels: 2 fp8 MFMAs per tap
-// row instead of 6 fp16 ones.  LDS pixel (80 B as before): 16 fp16 hi | 16 fp8 of x*2^-4 | 16 fp8 of (x-hi)*2^4 | pad.
+// v_mfma_f32_32x32x64_f8f6f4, K = 64 = 4 (tap, 16-channel) slices: 5 fp8 MFMAs per K-chunk (f8_slot_*) instead of 18
+// fp16 ones.  LDS pixel (80 B as before): 16 fp16 hi | 16 fp8 of x*2^-4 | 16 fp8 of (x-hi)*2^4 | pad.
 template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
 __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     LRPXH_T(t_start);
@@ -122,9 +128,6 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     // staging descriptors stay in registers (see item()): bit 0: 56 non-pooled, 1: 56 pooled, 2: 112 pooled, 3: 224 pooled
 #ifndef LRPXH_F8_HOIST
 #define LRPXH_F8_HOIST 0
-#endif
-#ifndef LRPXH_F8_ABASE
-#define LRPXH_F8_ABASE 0      // 1: the fp8 tap-slot offsets live in 14 registers; 0: derived from abase[] at each use
 #endif
     constexpr bool HOIST = (!F8 || LRPXH_F8_HOIST) && AL && (((LRPXH_HOIST_MASK & 1) && HW == 56 && !POOL) || ((LRPXH_HOIST_MASK & 2) && HW == 56 && POOL) ||
                                   ((LRPXH_HOIST_MASK & 4) && HW == 112 && POOL) || ((LRPXH_HOIST_MASK & 8) && HW == 224 && POOL));
@@ -433,8 +436,8 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     constexpr int NBQ = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : (((HW == 112 && NWN == 2) || (HOIST && !POOL)) ? 8 : 9));
 #endif
     const float inv_w = a.wp[0];
-    // F8: one queue entry per tap ROW = 7 planes of 64 lanes x 16 B: fp16 hi of dx = 0,1,2 | fp8 W*2^-4 (2 planes: the
-    // lane's two tap slots) | fp8 (W - hi)*2^4 (2 planes); lanes 0-31 hold slots dx = 0,1, lanes 32-63 dx = 2 and a zero
+    // F8: one queue entry per tap ROW g = 7 planes of 64 lanes x 16 B: fp16 hi of dx = 0,1,2 | the B operands of fp8
+    // MFMAs 2g and 2g+1 (2 planes each = the lane's two slots x 16 channels; row 2 has MFMA 4 only)
     constexpr int BP = F8 ? 7 : 2;                  // planes per queue entry
     constexpr int BSTEPS = F8 ? 3 : TAPS;           // queue entries per K-chunk
     // measured (tools/variant_sweep3.sh, chain of 320 maps): 2 entries 24.1 ms, 3 entries 25.1 (spills), 4: 30.1
@@ -459,15 +462,20 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     }
     // F8: LDS byte offsets of the lane's two fp8 tap slots of a tap row (dx = 0 / 1 for lanes 0-31; dx = 2 / 2 for lanes
     // 32-63, whose second slot carries zero weights)
-    int abase8a[(F8 && LRPXH_F8_ABASE) ? 7 : 1], abase8b[(F8 && LRPXH_F8_ABASE) ? 7 : 1];
-    const int d8a = lh ? 2 * PSTRIDE - 16 : 0, d8b = lh ? 2 * PSTRIDE - 16 : PSTRIDE;   // slot offsets relative to abase[]
-    if constexpr (F8 && LRPXH_F8_ABASE) {
+    // F8: LDS byte offset (relative to abase[j]) of the lane's two slots of fp8 MFMA m: pixel shift of the slot's tap +
+    // plane (32: fp8 of x, 48: fp8 of x - hi; a pad slot re-reads tap 8 against zero weights)
+    int o8[F8 ? 5 : 1][2];
+    if constexpr (F8) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int b8 = abase[j] - lh * 16;
-            abase8a[j] = b8 + (lh ? 2 * PSTRIDE : 0);
-            abase8b[j] = b8 + (lh ? 2 * PSTRIDE : PSTRIDE);
-        }
+        for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s0 = 4 * m + i, s1 = 4 * m + 2 + i;
+                const int t0 = f8_slot_tap(s0), t1 = f8_slot_tap(s1);
+                const int c0 = (t0 / 3) * PITCH + (t0 % 3) * PSTRIDE + (f8_slot_kind(s0) == 0 ? 48 : 32);
+                const int c1 = (t1 / 3) * PITCH + (t1 % 3) * PSTRIDE + (f8_slot_kind(s1) == 0 ? 48 : 32) - 16;
+                o8[m][i] = lh ? c1 : c0;
+            }
     }
     __syncthreads();
 
@@ -495,27 +503,30 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                     const f16x8 bh0 = __builtin_bit_cast(f16x8, bq[0][0]);
                     const f16x8 bh1 = __builtin_bit_cast(f16x8, bq[0][1]);
                     const f16x8 bh2 = __builtin_bit_cast(f16x8, bq[0][2]);
-                    const i32x8_ bw8 = {(int)bq[0][3][0], (int)bq[0][3][1], (int)bq[0][3][2], (int)bq[0][3][3],
+                    const i32x8_ bm0 = {(int)bq[0][3][0], (int)bq[0][3][1], (int)bq[0][3][2], (int)bq[0][3][3],
                                         (int)bq[0][4][0], (int)bq[0][4][1], (int)bq[0][4][2], (int)bq[0][4][3]};
-                    const i32x8_ bl8 = {(int)bq[0][5][0], (int)bq[0][5][1], (int)bq[0][5][2], (int)bq[0][5][3],
+                    const i32x8_ bm1 = {(int)bq[0][5][0], (int)bq[0][5][1], (int)bq[0][5][2], (int)bq[0][5][3],
                                         (int)bq[0][6][0], (int)bq[0][6][1], (int)bq[0][6][2], (int)bq[0][6][3]};
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
                         const char* ap = abuf + abase[j] + g * PITCH;
-                        const char* pa = abuf + (LRPXH_F8_ABASE ? abase8a[j] : abase[j] + d8a) + g * PITCH;
-                        const char* pb = abuf + (LRPXH_F8_ABASE ? abase8b[j] : abase[j] + d8b) + g * PITCH;
-                        const u32x4_ s8a = *reinterpret_cast<const u32x4_*>(pa + 32), l8a = *reinterpret_cast<const u32x4_*>(pa + 48);
-                        // (lanes 32-63 re-read dx = 2 for their zero-weight slot: leaving them out of the read with an
-                        //  exec mask was 45 % slower - every masked region fences the scheduler)
-                        const u32x4_ s8b = *reinterpret_cast<const u32x4_*>(pb + 32), l8b = *reinterpret_cast<const u32x4_*>(pb + 48);
+                        const char* a8 = abuf + abase[j];
+                        // (lanes 32-63 of the last MFMA re-read tap 8 for their two zero-weight slots: leaving them out
+                        //  of the read with an exec mask was 45 % slower - every masked region fences the scheduler)
+                        const u32x4_ p0 = *reinterpret_cast<const u32x4_*>(a8 + o8[2 * g][0]);
+                        const u32x4_ p1 = *reinterpret_cast<const u32x4_*>(a8 + o8[2 * g][1]);
                         const f16x8 h0 = *reinterpret_cast<const f16x8*>(ap);
                         const f16x8 h1 = *reinterpret_cast<const f16x8*>(ap + PSTRIDE);
                         const f16x8 h2 = *reinterpret_cast<const f16x8*>(ap + 2 * PSTRIDE);
-                        const i32x8_ as8 = {(int)s8a[0], (int)s8a[1], (int)s8a[2], (int)s8a[3], (int)s8b[0], (int)s8b[1], (int)s8b[2], (int)s8b[3]};
-                        const i32x8_ al8 = {(int)l8a[0], (int)l8a[1], (int)l8a[2], (int)l8a[3], (int)l8b[0], (int)l8b[1], (int)l8b[2], (int)l8b[3]};
-                        // small terms first: (x - hi) * W and x * (W - hi_W) on the fp8 cores, then hi * hi_W
-                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al8, bw8, acc[j], 0, 0, 0, 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(as8, bl8, acc[j], 0, 0, 0, 0, 0, 0);
+                        const i32x8_ am0 = {(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3], (int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
+                        // small terms first: the cross products on the fp8 cores, then hi * hi_W
+                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am0, bm0, acc[j], 0, 0, 0, 0, 0, 0);
+                        if (g < 2) {          // (compile-time after unrolling)
+                            const u32x4_ q0 = *reinterpret_cast<const u32x4_*>(a8 + o8[g < 2 ? 2 * g + 1 : 0][0]);
+                            const u32x4_ q1 = *reinterpret_cast<const u32x4_*>(a8 + o8[g < 2 ? 2 * g + 1 : 0][1]);
+                            const i32x8_ am1 = {(int)q0[0], (int)q0[1], (int)q0[2], (int)q0[3], (int)q1[0], (int)q1[1], (int)q1[2], (int)q1[3]};
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am1, bm1, acc[j], 0, 0, 0, 0, 0, 0);
+                        }
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh0, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh1, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, bh2, acc[j], 0, 0, 0);

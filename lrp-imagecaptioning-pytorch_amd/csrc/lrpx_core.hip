@@ -217,9 +217,10 @@ __global__ void pack_weights_f16x2_kernel(const float* __restrict__ w, float* __
 }
 
 // weights for the F8 variant of conv_f16x3.h (fp16 hi.hi product + two fp8 cross products): 64-byte header {2^-kW, amax
-// bits}, then [ocb][chunk 16][tap row 3][plane 7][lane 64][16 B]: planes 0-2 = fp16 hi of dx = 0,1,2 (lane map as the
-// f16x2 pack), planes 3/4 = fp8 e4m3 of W*2^-4 for the lane's two tap slots x 16 channels (lanes 0-31: dx = 0 / 1, lanes
-// 32-63: dx = 2 / zero), planes 5/6 = fp8 of (W - hi)*2^4 likewise.  W is scaled into [2^11, 2^12) first.
+// bits}, then [ocb][chunk 16][tap row g 3][plane 7][lane 64][16 B]: planes 0-2 = fp16 hi of taps (g, dx = 0,1,2) (lane
+// map as the f16x2 pack), planes 3/4 and 5/6 = B operands of the fp8 MFMAs 2g and 2g+1 of the chunk (conv_f16x3.h,
+// f8_slot_*: per lane two (tap, 16 channels) slots of fp8 e4m3: W*2^-4 for an "L" slot, (W - hi)*2^4 for an "S" slot,
+// zero for a pad slot).  W is scaled into [2^11, 2^12) first.
 __global__ void pack_weights_f16f8_kernel(const float* __restrict__ w, float* __restrict__ header, int cout, int cin,
                                           int mode, int k_pad, long total) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,19 +248,31 @@ __global__ void pack_weights_f16f8_kernel(const float* __restrict__ w, float* __
         unsigned short* o = reinterpret_cast<unsigned short*>(out + dx * 1024);
         for (int j = 0; j < 8; ++j) o[j] = __builtin_bit_cast(unsigned short, (_Float16)wv(chunk * 16 + 8 * lh + j, dx));
     }
-    for (int slot = 0; slot < 2; ++slot) {
-        const int dx = lh ? 2 : slot;
-        const bool zero = lh && slot;
-        unsigned* o8 = reinterpret_cast<unsigned*>(out + (3 + slot) * 1024);
-        unsigned* ol = reinterpret_cast<unsigned*>(out + (5 + slot) * 1024);
-        for (int q = 0; q < 4; ++q) {
-            float x[4], r[4];
-            for (int e = 0; e < 4; ++e) {
-                x[e] = zero ? 0.f : wv(chunk * 16 + q * 4 + e, dx);
-                r[e] = x[e] - (float)(_Float16)x[e];
+    // planes 3/4: B operand of fp8 MFMA m = 2g (the lane's slots 4m + 2*lh + {0, 1}); planes 5/6: MFMA 2g+1 (none for g = 2)
+    for (int mm = 0; mm < 2; ++mm) {
+        const int m = 2 * g + mm;
+        for (int i = 0; i < 2; ++i) {
+            const int slot = 4 * m + 2 * lh + i;
+            const int kind = (m < 5) ? f8_slot_kind(slot) : 2;
+            const int tap = (m < 5) ? f8_slot_tap(slot) : 8;
+            unsigned* o = reinterpret_cast<unsigned*>(out + (3 + 2 * mm + i) * 1024);
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+                for (int e = 0; e < 4; ++e) {
+                    float x = 0.f;
+                    if (kind != 2) {
+                        const int k = chunk * 16 + q * 4 + e;
+                        float wsc = 0.f;
+                        if (mode == LRPX_PACK_BWD_POS) { if (k < cout && oc < cin) wsc = fmaxf(w[((long)k * cin + oc) * 9 + (8 - tap)], 0.f); }
+                        else if (mode == LRPX_PACK_BWD_PLAIN) { if (k < cout && oc < cin) wsc = w[((long)k * cin + oc) * 9 + (8 - tap)]; }
+                        wsc *= sc;
+                        // kind 0 ("L": activations' residual x - hi): weight operand W * 2^-4;  kind 1 ("S"): (W - hi_W) * 2^4
+                        x = kind == 0 ? wsc * 0.0625f : (wsc - (float)(_Float16)wsc) * 16.f;
+                    }
+                    v[e] = x;
+                }
+                o[q] = pack_fp8x4(v[0], v[1], v[2], v[3]);
             }
-            o8[q] = pack_fp8x4(x[0] * 0.0625f, x[1] * 0.0625f, x[2] * 0.0625f, x[3] * 0.0625f);
-            ol[q] = pack_fp8x4(r[0] * 16.f, r[1] * 16.f, r[2] * 16.f, r[3] * 16.f);
         }
     }
 }

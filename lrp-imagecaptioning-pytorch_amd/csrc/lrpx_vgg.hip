@@ -198,7 +198,7 @@ int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, f
 
 // matrix-core mode of the fused chains (lrpx_set_conv_mode): 0 fp32 MFMA, 1 bf16x6 (conv_bf16x6.h), 2 = bf16x6 forward
 // trace + f16x3 relevance pass (conv_f16x3.h)
-static int g_mode = 2;
+static int g_mode = 3;
 #define g_bf16x6 (g_mode >= 1)
 static int g_fwd_f16 = 1;   // lrpx_set_forward_f16: forward trace of conv1_2..conv5_3 on the fp16 split-product kernels (default on)
 
