@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #endif
     // staging descriptors stay in registers (see item()): bit 0: 56 non-pooled, 1: 56 pooled, 2: 112 pooled, 3: 224 pooled
 #ifndef LRPXH_F8_HOIST
-#define LRPXH_F8_HOIST 0
+#define LRPXH_F8_HOIST 1      // measured with the row-wise item layout: 56x56 F8 kernel 2.33 -> 2.12 ms per launch
 #endif
     constexpr bool HOIST = (!F8 || LRPXH_F8_HOIST) && AL && (((LRPXH_HOIST_MASK & 1) && HW == 56 && !POOL) || ((LRPXH_HOIST_MASK & 2) && HW == 56 && POOL) ||
                                   ((LRPXH_HOIST_MASK & 4) && HW == 112 && POOL) || ((LRPXH_HOIST_MASK & 8) && HW == 224 && POOL));
@@ -180,7 +180,17 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     // then the LOW-resolution one, the window position rides in bits 26-27 of the LDS offset.
     constexpr int SEG = KC / 4;
     constexpr int NITEM = C::NSLOT * W * SEG;
-    constexpr int U = (NITEM + NT - 1) / NT;
+    // map-aligned tiles: staging items are laid out ROW-WISE over the threads - item slot u of thread tid is LDS row
+    // u*RPS + tid/RI (narrow maps: RPS whole rows per slot) or row u/SPR, part u%SPR (wide maps: SPR slots per row) - so
+    // that row, pixel and segment need no division, the row validity is wave-uniform and the descriptors are not worth
+    // keeping in registers
+#ifndef LRPXH_ROWMAP
+#define LRPXH_ROWMAP 1
+#endif
+    constexpr int RI = W * SEG;                                   // items per LDS row
+    constexpr bool ROWMAP = AL && (LRPXH_ROWMAP != 0) && (RI <= NT ? (RI > NT / 2) : true);
+    constexpr int SPR = (RI + NT - 1) / NT;                       // slots per row (1 when a row fits the workgroup)
+    constexpr int U = ROWMAP ? C::NSLOT * SPR : (NITEM + NT - 1) / NT;
     constexpr int UR = AL ? 1 : U;
     constexpr int HO = H / 2, WO = W / 2;
     int sdst[UR], sgp[UR];
@@ -226,11 +236,22 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             // recompute per use: hoisted out of the chunk loop the descriptors cost 2U registers and spill - except in the
             // 56x56 kernel with a B queue of 8, where keeping them resident saves 6 % (measured, tools/variant_sweep2.sh)
             if constexpr (!HOIST) asm volatile("" : "+v"(it));
-            const int s = it / (W * SEG);
-            const int rem = it - s * (W * SEG);
+            int s, rem;
+            bool in_row;
+            if constexpr (ROWMAP) {
+                int t_ = tid;
+                if constexpr (!HOIST) asm volatile("" : "+v"(t_));
+                s = u / SPR;
+                rem = t_ + (u % SPR) * NT;
+                in_row = rem < RI;
+            } else {
+                s = it / (W * SEG);
+                rem = it - s * (W * SEG);
+                in_row = it < NITEM;
+            }
             const int px = rem / SEG, seg = rem - px * SEG;
             const int y = y_al - 1 + s;
-            const bool ok = (it < NITEM) && (y >= 0) && (y < H);
+            const bool ok = in_row && (y >= 0) && (y < H);
             const int nm = ok ? 0 : -1;      // "| nm" instead of "ok ? x : -1": the latter compiles to an exec-masked branch
             dst = ((s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28)) | nm;
             if constexpr (POOL) {
@@ -254,7 +275,13 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     constexpr bool LOSTAGE = POOL;
     constexpr int RL = AL ? C::R / 2 + 2 : C::NSLOT + 1;
     constexpr int NITEM_LO = RL * WO * SEG;
-    constexpr int UL = LOSTAGE ? (NITEM_LO + NT - 1) / NT : 1;
+    // row-wise item layout as above: RPSL pooled rows per slot (narrow) or SPRL slots per pooled row (wide)
+    constexpr int RIL = WO * SEG;
+    constexpr bool ROWMAP_LO = LOSTAGE && AL && (LRPXH_ROWMAP != 0);
+    constexpr int RPSL = RIL <= NT ? NT / RIL : 1;
+    constexpr int SPRL = (RIL + NT - 1) / NT;
+    constexpr int UL = !LOSTAGE ? 1 : (ROWMAP_LO ? (RIL <= NT ? (RL + RPSL - 1) / RPSL : RL * SPRL) : (NITEM_LO + NT - 1) / NT);
+    const int lo_q = tid / RIL, lo_r = tid - lo_q * RIL;          // (row within the slot, item within the row) of this thread
     constexpr int ULR = (LOSTAGE && !AL) ? UL : 1;
     int ldst[ULR], lgp[ULR], lam[ULR];
     float lsc[ULR];
@@ -287,11 +314,21 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
         if constexpr (AL) {
             int it = tid + u * NT;
             if constexpr (!HOIST) asm volatile("" : "+v"(it));
-            const int sl = it / (WO * SEG);
-            const int rem = it - sl * (WO * SEG);
+            int sl, rem;
+            bool in_row;
+            if constexpr (ROWMAP_LO) {
+                int q_ = lo_q, r_ = lo_r;
+                if constexpr (!HOIST) asm volatile("" : "+v"(q_), "+v"(r_));
+                if constexpr (RIL <= NT) { sl = u * RPSL + q_; rem = r_; in_row = (q_ < RPSL) && (sl < RL); }
+                else { sl = u / SPRL; rem = it - (u / SPRL) * SPRL * NT; in_row = rem < RIL; }
+            } else {
+                sl = it / (WO * SEG);
+                rem = it - sl * (WO * SEG);
+                in_row = it < NITEM_LO;
+            }
             const int pxl = rem / SEG, seg = rem - pxl * SEG;
             const int ylo = (y_al >> 1) - 1 + sl;
-            const bool ok = (it < NITEM_LO) && (ylo >= 0) && (ylo < HO);
+            const bool ok = in_row && (ylo >= 0) && (ylo < HO);
             const int s0 = 2 * sl - 1;                               // LDS row of window row dy = 0 (dy = 1: s0 + 1)
             rowmask = ok ? ((s0 >= 0 ? 1 : 0) | (s0 + 1 < C::NSLOT ? 2 : 0)) : 0;
             dst00 = ((s0 < 0 ? 0 : s0) * PITCH + (2 * pxl + 1) * PSTRIDE + seg * 8) | (seg << 28);   // first row written

@@ -490,7 +490,11 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
         if (h3) {
             d.f16x3 = 1; d.epi = EPI_REL_MUL; d.wpacked = pk + p.bwdh[l]; d.in_amax = amax + (size_t)l * n_maps;
-            if (g_mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }   // cross products on the fp8 matrix cores
+            // mode 3: cross products on the fp8 matrix cores - except conv4_3 (28x28 under a pool): its map-straddling
+            // pooled-input kernel keeps the staging descriptors in registers and spills 42 VGPRs with the fp8 operands
+            // (3.1 ms against 2.75 ms with fp16 cross products)
+            const bool pooled_in = l + 1 < kNL && !kVgg[l + 1].conv;
+            if (g_mode == 3 && !(L.hw == 28 && pooled_in)) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
             // under a pool: S[cur] is the low-resolution tensor the conv above the pool wrote, unpooled while staged
             if (l + 1 < kNL && !kVgg[l + 1].conv) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
         }

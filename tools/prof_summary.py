@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Summaries of rocprofv3 output directories for profiles/:
+   prof_summary.py stats <dir>            kernel table (calls, total ms, avg us, %) from *_kernel_stats.csv
+   prof_summary.py traffic <dirB> <dirC>  per kernel FETCH_SIZE / WRITE_SIZE sums (GB) and L2 hit rate from two --pmc passes
+   prof_summary.py sq <dir> [<dir>...]    per kernel means of every SQ counter found (per launch)"""
+import collections, csv, glob, os, re, sys
+
+
+def newest(pattern):
+    fs = glob.glob(pattern, recursive=True)
+    if not fs:
+        sys.exit(f"no file matches {pattern}")
+    return max(fs, key=os.path.getmtime)
+
+
+def short(name):
+    n = re.sub(r"void lrpx::|lrpx::", "", name)
+    return re.sub(r"\(.*", "", n)
+
+
+def stats(d):
+    rows = list(csv.DictReader(open(newest(f"{d}/**/*_kernel_stats.csv"))))
+    print(f"{'kernel':70s} {'calls':>6s} {'total ms':>10s} {'avg us':>10s} {'%':>6s}")
+    for r in rows:
+        print(f"{short(r['Name'])[:70]:70s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:10.2f} "
+              f"{float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}")
+
+
+def counters(dirs):
+    data = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                data[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return data
+
+
+def traffic(dirs):
+    data = counters(dirs)
+    print(f"{'kernel':56s} {'launches':>8s} {'FETCH GB':>10s} {'WRITE GB':>10s} {'L2 hit %':>9s}")
+    for k, c in sorted(data.items()):
+        if "FETCH_SIZE" not in c:
+            continue
+        hit, miss = sum(c.get("TCC_HIT_sum", [0])), sum(c.get("TCC_MISS_sum", [0]))
+        print(f"{k[:56]:56s} {len(c['FETCH_SIZE']):8d} {sum(c['FETCH_SIZE'])*1024/1e9:10.2f} "
+              f"{sum(c.get('WRITE_SIZE', [0]))*1024/1e9:10.2f} {100*hit/max(hit+miss,1):9.1f}")
+
+
+def sq(dirs):
+    data = counters(dirs)
+    for k, c in sorted(data.items()):
+        if "conv_" not in k and "first_layer" not in k:
+            continue
+        print(k)
+        for name, v in sorted(c.items()):
+            print(f"   {name:36s} {sum(v)/len(v):16.0f}")
+
+
+if __name__ == "__main__":
+    {"stats": lambda a: stats(a[0]), "traffic": traffic, "sq": sq}[sys.argv[1]](sys.argv[2:])
