@@ -98,10 +98,10 @@ static __device__ unsigned long long g_stamp_h3[12];
 #endif
 
 // F8 slot map (shared with pack_weights_f16f8_kernel).  The 18 cross-product (tap, 16 channels) K-slices of a K-chunk -
-// slots 0-8: (x - hi) * W of taps 0-8 ("L"), slots 9-17: x * (W - hi_W) of taps 0-8 ("S"), 18/19: zero weights - fill
-// five K = 64 fp8 MFMAs of four slots each; lanes 0-31 feed slots 4m, 4m+1 of MFMA m, lanes 32-63 slots 4m+2, 4m+3.
-__host__ __device__ constexpr int f8_slot_tap(int s) { return s < 9 ? s : (s < 18 ? s - 9 : 8); }
-__host__ __device__ constexpr int f8_slot_kind(int s) { return s < 9 ? 0 : (s < 18 ? 1 : 2); }   // 0 L, 1 S, 2 pad
+// "L": (x - hi) * W and "S": x * (W - hi_W), taps 0-8 each - fill five K = 64 fp8 MFMAs of four slices: MFMA m covers
+// taps 2m and 2m+1 (tap 9 does not exist: zero weights), lanes 0-31 (k = 0..31) hold the L slices of both taps, lanes
+// 32-63 (k = 32..63) the S slices.  The two lane halves then read the same pixels, 16 bytes apart (planes 48 / 32).
+__host__ __device__ constexpr int f8_slot_tap(int m, int i) { return 2 * m + i; }        // > 8: zero weights
 
 // F8 ("f16+f8x2"): the two CROSS products a0*b1 + a1*b0 - 2^-11 of the result - do not need fp16 operands: with both
 // factors rounded to fp8 e4m3 (4 significand bits) their error is 2^-11 * 2^-4 per product, random sign; simulated
@@ -499,21 +499,9 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     }
     // F8: LDS byte offsets of the lane's two fp8 tap slots of a tap row (dx = 0 / 1 for lanes 0-31; dx = 2 / 2 for lanes
     // 32-63, whose second slot carries zero weights)
-    // F8: LDS byte offset (relative to abase[j]) of the lane's two slots of fp8 MFMA m: pixel shift of the slot's tap +
-    // plane (32: fp8 of x, 48: fp8 of x - hi; a pad slot re-reads tap 8 against zero weights)
-    int o8[F8 ? 5 : 1][2];
-    if constexpr (F8) {
-#pragma unroll
-        for (int m = 0; m < 5; ++m)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int s0 = 4 * m + i, s1 = 4 * m + 2 + i;
-                const int t0 = f8_slot_tap(s0), t1 = f8_slot_tap(s1);
-                const int c0 = (t0 / 3) * PITCH + (t0 % 3) * PSTRIDE + (f8_slot_kind(s0) == 0 ? 48 : 32);
-                const int c1 = (t1 / 3) * PITCH + (t1 % 3) * PSTRIDE + (f8_slot_kind(s1) == 0 ? 48 : 32) - 16;
-                o8[m][i] = lh ? c1 : c0;
-            }
-    }
+    // F8: lanes 0-31 read the fp8 plane of x - hi (byte 48 of the pixel), lanes 32-63 that of x (byte 32; abase[] already
+    // carries + 16 for them)
+    const int c8 = lh ? 16 : 48;
     __syncthreads();
 
     LRPXH_T(t_loop);
@@ -547,11 +535,14 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
                         const char* ap = abuf + abase[j] + g * PITCH;
-                        const char* a8 = abuf + abase[j];
-                        // (lanes 32-63 of the last MFMA re-read tap 8 for their two zero-weight slots: leaving them out
-                        //  of the read with an exec mask was 45 % slower - every masked region fences the scheduler)
-                        const u32x4_ p0 = *reinterpret_cast<const u32x4_*>(a8 + o8[2 * g][0]);
-                        const u32x4_ p1 = *reinterpret_cast<const u32x4_*>(a8 + o8[2 * g][1]);
+                        const char* a8 = abuf + abase[j] + c8;
+                        // taps 2m, 2m+1 of fp8 MFMA m = 2g (+1); the slice of the non-existent tap 9 re-reads tap 8 against
+                        // zero weights (leaving it out of the read with an exec mask was 45 % slower: every masked region
+                        // fences the scheduler)
+                        constexpr int TP[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 8};
+#define LRPXH_TOFF(t) ((TP[t] / 3) * PITCH + (TP[t] % 3) * PSTRIDE)
+                        const u32x4_ p0 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(4 * g));
+                        const u32x4_ p1 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(4 * g + 1));
                         const f16x8 h0 = *reinterpret_cast<const f16x8*>(ap);
                         const f16x8 h1 = *reinterpret_cast<const f16x8*>(ap + PSTRIDE);
                         const f16x8 h2 = *reinterpret_cast<const f16x8*>(ap + 2 * PSTRIDE);
@@ -559,8 +550,9 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                         // small terms first: the cross products on the fp8 cores, then hi * hi_W
                         acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am0, bm0, acc[j], 0, 0, 0, 0, 0, 0);
                         if (g < 2) {          // (compile-time after unrolling)
-                            const u32x4_ q0 = *reinterpret_cast<const u32x4_*>(a8 + o8[g < 2 ? 2 * g + 1 : 0][0]);
-                            const u32x4_ q1 = *reinterpret_cast<const u32x4_*>(a8 + o8[g < 2 ? 2 * g + 1 : 0][1]);
+                            const u32x4_ q0 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(g < 2 ? 4 * g + 2 : 0));
+                            const u32x4_ q1 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(g < 2 ? 4 * g + 3 : 0));
+#undef LRPXH_TOFF
                             const i32x8_ am1 = {(int)q0[0], (int)q0[1], (int)q0[2], (int)q0[3], (int)q1[0], (int)q1[1], (int)q1[2], (int)q1[3]};
                             acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am1, bm1, acc[j], 0, 0, 0, 0, 0, 0);
                         }

@@ -248,13 +248,13 @@ __global__ void pack_weights_f16f8_kernel(const float* __restrict__ w, float* __
         unsigned short* o = reinterpret_cast<unsigned short*>(out + dx * 1024);
         for (int j = 0; j < 8; ++j) o[j] = __builtin_bit_cast(unsigned short, (_Float16)wv(chunk * 16 + 8 * lh + j, dx));
     }
-    // planes 3/4: B operand of fp8 MFMA m = 2g (the lane's slots 4m + 2*lh + {0, 1}); planes 5/6: MFMA 2g+1 (none for g = 2)
+    // planes 3/4: B operand of fp8 MFMA m = 2g (taps 2m, 2m+1; lanes 0-31: "L" slices, lanes 32-63: "S" slices);
+    // planes 5/6: MFMA 2g+1 (none for g = 2)
     for (int mm = 0; mm < 2; ++mm) {
         const int m = 2 * g + mm;
         for (int i = 0; i < 2; ++i) {
-            const int slot = 4 * m + 2 * lh + i;
-            const int kind = (m < 5) ? f8_slot_kind(slot) : 2;
-            const int tap = (m < 5) ? f8_slot_tap(slot) : 8;
+            const int tap = f8_slot_tap(m, i);
+            const int kind = (m < 5 && tap <= 8) ? lh : 2;
             unsigned* o = reinterpret_cast<unsigned*>(out + (3 + 2 * mm + i) * 1024);
             for (int q = 0; q < 4; ++q) {
                 float v[4];
