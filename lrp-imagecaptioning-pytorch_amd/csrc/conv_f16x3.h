@@ -477,11 +477,12 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     // MFMAs 2g and 2g+1 (2 planes each = the lane's two slots x 16 channels; row 2 has MFMA 4 only)
     constexpr int BP = F8 ? 7 : 2;                  // planes per queue entry
     constexpr int BSTEPS = F8 ? 3 : TAPS;           // queue entries per K-chunk
-    // measured (tools/variant_sweep3.sh, chain of 320 maps): 2 entries 24.1 ms, 3 entries 25.1 (spills), 4: 30.1
+    // measured (tools/variant_sweep3.sh, chain of 320 maps): 2 entries 24.1 ms, 3 entries 25.1 (spills), 4: 30.1; the
+    // pooled-input 112 / 56 kernels have the registers for a third entry (2.39 -> 2.27 ms, 1.96 -> 1.89 ms)
 #ifdef LRPXH_NBQ8
     constexpr int NQ = F8 ? LRPXH_NBQ8 : NBQ;
 #else
-    constexpr int NQ = F8 ? 2 : NBQ;
+    constexpr int NQ = F8 ? ((POOL && AL && HW <= 112) ? 3 : 2) : NBQ;
 #endif
     const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
                        (long)ocb * nchunk * (BSTEPS * BP * 64) + lane;
@@ -523,8 +524,10 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step) * BP;
+                    // (the entry of tap row 2 has one fp8 MFMA: its last two planes are padding and stay out of registers)
 #pragma unroll
-                    for (int p = 0; p < BP; ++p) bq[NQ - 1][p] = wp[(nxt + p) * 64];
+                    for (int p = 0; p < BP; ++p)
+                        if (p < 5 || (g + NQ - 1) % 3 != 2) bq[NQ - 1][p] = wp[(nxt + p) * 64];
                     const f16x8 bh0 = __builtin_bit_cast(f16x8, bq[0][0]);
                     const f16x8 bh1 = __builtin_bit_cast(f16x8, bq[0][1]);
                     const f16x8 bh2 = __builtin_bit_cast(f16x8, bq[0][2]);

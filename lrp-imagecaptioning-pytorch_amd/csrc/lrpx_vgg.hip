@@ -494,7 +494,11 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             // pooled-input kernel keeps the staging descriptors in registers and spills 42 VGPRs with the fp8 operands
             // (3.1 ms against 2.75 ms with fp16 cross products)
             const bool pooled_in = l + 1 < kNL && !kVgg[l + 1].conv;
+#ifdef LRPX_F8_ALL      // (tuning builds: also conv4_3 on the F8 kernel)
+            if (g_mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
+#else
             if (g_mode == 3 && !(L.hw == 28 && pooled_in)) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
+#endif
             // under a pool: S[cur] is the low-resolution tensor the conv above the pool wrote, unpooled while staged
             if (l + 1 < kNL && !kVgg[l + 1].conv) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
         }
