@@ -52,7 +52,7 @@ MODE_DTYPE = {0: "f32", 1: "f32 (bf16x6 split-product MFMA, f32 accumulate)", 2:
 # profiles/r01_pmc_traffic_f16x3.txt, ..._bf16x6.txt, r01_pmc_traffic.txt): (2 x FETCH_SIZE raw [gfx950 reports half of wide streaming reads,
 # MI355X_MICROARCH.md §HBM] + WRITE_SIZE) per launch.  Scaled linearly with the map count.
 DOM_TRAFFIC_BYTES_PER_MAP = {0: (2 * 1.9e9 + 0.86e9) / 320, 1: (2 * 1.55e9 + 0.86e9) / 320, 2: (2 * 1.22e9 + 0.77e9) / 320,
-                             3: (2 * 1.22e9 + 0.77e9) / 320}
+                             3: (2 * 1.195e9 + 0.77e9) / 320}      # profiles/r01_pmc_traffic_f16f8.txt
 
 
 def host_cores():
