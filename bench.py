@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="gather the maps to rank 0 over RCCL inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="independent batches in flight on separate HIP streams (1 = serial steps); every step is still "
                          "one full pass over one batch, the decoder's latency-bound kernels of one batch overlap the "
                          "MFMA-bound CNN chain of another")

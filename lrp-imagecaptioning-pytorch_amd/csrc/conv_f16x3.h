@@ -521,6 +521,12 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             // APIPE (wide maps with few K-chunks: the partner wave of the SIMD is mostly outside its MFMA phase, so this
             // wave's LDS latency is not covered by the partner's MFMAs): A fragments are read one accumulator tile ahead
             if constexpr (F8) {
+#ifndef LRPXH_F8_SGB
+#define LRPXH_F8_SGB 0
+#endif
+                // (experiment) software pipeline by scheduling groups: the LDS reads of accumulator tile t+1 are placed
+                // before the MFMAs of tile t
+                if constexpr (LRPXH_F8_SGB != 0) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step) * BP;
@@ -562,6 +568,13 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh0, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh1, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, bh2, acc[j], 0, 0, 0);
+                        if constexpr (LRPXH_F8_SGB != 0) {
+                            const int gn = (j == 6) ? g + 1 : g;                     // tap row of the next tile
+                            if (gn < 2) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+                            else if (gn == 2) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                            if (g < 2) __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                            else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < NQ - 1; ++i)
