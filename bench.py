@@ -268,6 +268,11 @@ def main():
                 "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
                 "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,
                 "traffic": round(DOM_TRAFFIC_BYTES_PER_MAP[mode] * B * T),
+                "accounting": ("executed matrix flop = algorithmic x products; mode 3 executes 1 fp16 + 2 fp8 products per fp32 "
+                               "product and an fp8 flop counts 1/2 (fp8 dense peak = 2 x fp16 peak), so achieved/peak = matrix "
+                               "time at peak / measured time; the same layer with 3 fp16 products (--conv-mode 2) reaches "
+                               "frac 0.55-0.57 on 1.5x the matrix work and is 1.19x slower") if mode == 3 else
+                              "executed matrix flop = algorithmic x products",
                 "chain": {"ms_per_step": round(chain_ms, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * B * T,
                           "algorithmic_tflops": round(GFLOP_PER_MAP * B * T / chain_ms, 1),
                           "conv_ms_by_layer": {str(l): round(v, 3) for l, v in enumerate(per_layer) if v > 0}}}
