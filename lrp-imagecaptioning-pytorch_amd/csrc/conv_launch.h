@@ -84,6 +84,15 @@ int launch_h8_224_pool(const ConvArgs& a, hipStream_t s);
 int launch_h8_112_pool(const ConvArgs& a, hipStream_t s);
 int launch_h8_56_pool(const ConvArgs& a, hipStream_t s);
 int launch_h8_28_pool(const ConvArgs& a, hipStream_t s);
+int launch_h8_224_guided(const ConvArgs& a, hipStream_t s);   // image-gradient chains on the f16+f8 kernels
+int launch_h8_112_guided(const ConvArgs& a, hipStream_t s);
+int launch_h8_56_guided(const ConvArgs& a, hipStream_t s);
+int launch_h8_28_guided(const ConvArgs& a, hipStream_t s);
+int launch_h8_14_guided(const ConvArgs& a, hipStream_t s);
+int launch_h8_112n_plain(const ConvArgs& a, hipStream_t s);
+int launch_h8_56_plain(const ConvArgs& a, hipStream_t s);
+int launch_h8_28_plain(const ConvArgs& a, hipStream_t s);
+int launch_h8_14_plain(const ConvArgs& a, hipStream_t s);
 int launch_h3_224_fwd(const ConvArgs& a, hipStream_t s);    // forward trace (ReLU(conv+b) and Z+) on the fp16 matrix cores
 int launch_h3_112_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_fwd(const ConvArgs& a, hipStream_t s);

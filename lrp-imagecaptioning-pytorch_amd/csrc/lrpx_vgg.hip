@@ -60,6 +60,23 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
                                                                (d->epi == EPI_PLAIN && !d->relu && !d->bias)) && !d->pool_am)),
                      "conv_mfma: f16x3 needs a 3x3 conv, cin %% 16 == 0, in_amax and the REL_MUL (with x), FWD_DUAL, GUIDED "
                      "or bias-free PLAIN epilogue");
+        LRPX_REQUIRE(d->f16x3 != 2 || d->epi == EPI_REL_MUL || d->epi == EPI_GUIDED || d->epi == EPI_PLAIN,
+                     "conv_mfma: the f16+f8 kernels (f16x3 = 2) are built for the REL_MUL, GUIDED and PLAIN epilogues");
+        if (d->f16x3 == 2 && d->epi == EPI_GUIDED) {
+            if (d->hw == 224 && d->n_oc <= 64) return launch_h8_224_guided(a, s);
+            if (d->hw == 112 && d->n_oc > 64) return launch_h8_112_guided(a, s);
+            if (d->hw == 56) return launch_h8_56_guided(a, s);
+            if (d->hw == 28) return launch_h8_28_guided(a, s);
+            if (d->hw == 14) return launch_h8_14_guided(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no f16+f8 GUIDED kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
+        if (d->f16x3 == 2 && d->epi == EPI_PLAIN) {
+            if (d->hw == 112 && d->n_oc <= 64) return launch_h8_112n_plain(a, s);
+            if (d->hw == 56) return launch_h8_56_plain(a, s);
+            if (d->hw == 28) return launch_h8_28_plain(a, s);
+            if (d->hw == 14) return launch_h8_14_plain(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no f16+f8 PLAIN kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
         if (d->epi == EPI_GUIDED) {
             if (d->hw == 224 && d->n_oc <= 64) return launch_h3_224_guided(a, s);
             if (d->hw == 112 && d->n_oc > 64) return launch_h3_112_guided(a, s);
@@ -84,7 +101,6 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
             LRPX_REQUIRE(false, "conv_mfma: no f16x3 forward kernel built for hw=%d", d->hw);
         }
         const bool f8 = d->f16x3 == 2;
-        LRPX_REQUIRE(!f8 || d->epi == EPI_REL_MUL, "conv_mfma: the f16+f8 kernels are built for the REL_MUL epilogue only");
         if (d->pool_am) {
             // the kernels index pool_am with 32-bit element offsets (image * pooled pixels * channels)
             LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
@@ -209,13 +225,13 @@ static hipEvent_t g_ev[17][2];
 static bool g_ev_made = false, g_ev_valid[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], fwd6[17], fwdh[17], bias[17], first6, first6p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], first6, first6p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
     size_t off = 0;
     for (int l = 0; l < kNL; ++l) {
-        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.bwdph[l] = p.bwd8[l] = p.fwd6[l] = p.fwdh[l] = p.bias[l] = 0;
+        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.bwdph[l] = p.bwd8[l] = p.bwdp8[l] = p.fwd6[l] = p.fwdh[l] = p.bias[l] = 0;
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
@@ -227,6 +243,7 @@ static VggPacked vgg_packed_layout() {
         if (l > 0) { p.fwdh[l] = off; off += lrpx_packed_f16x2_bytes(2 * L.cout, L.cin, 9) / sizeof(float); }
         if (l > 0) { p.bwdph[l] = off; off += lrpx_packed_f16x2_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (l > 0) { p.bwd8[l] = off; off += lrpx_packed_f16f8_bytes(L.cin, L.cout) / sizeof(float); }
+        if (l > 0) { p.bwdp8[l] = off; off += lrpx_packed_f16f8_bytes(L.cin, L.cout) / sizeof(float); }
         if (L.hw <= 112) {
             p.fwd6[l] = off; off += lrpx_packed_bf16x3_bytes(2 * L.cout, L.cin, 9) / sizeof(float);
         }
@@ -346,6 +363,7 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwdh[l], stream));
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, base + p.bwdph[l], stream));
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16f8(w[ci], L.cout, L.cin, LRPX_PACK_BWD_POS, base + p.bwd8[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16f8(w[ci], L.cout, L.cin, LRPX_PACK_BWD_PLAIN, base + p.bwdp8[l], stream));
         if (L.hw <= 112) {
             LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwd6[l], stream));
         }
@@ -588,6 +606,7 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
             unsigned* gam = reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps) + (size_t)l * n_maps;
             LRPX_TRY(lrpx_amax_maps(G[cur], n_maps, (long)L.hw * L.hw * L.cout, gam, st));
             d.f16x3 = 1; d.wpacked = pk + p.bwdph[l]; d.in_amax = gam;
+            if (g_mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwdp8[l]; }      // cross products on the fp8 matrix cores
         }
         if (kVgg[l - 1].conv) {
             d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];      // ReLU hook of conv l-1 fused
