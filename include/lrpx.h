@@ -139,6 +139,10 @@ int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, flo
  *                  straight into S = R / Z+ of the conv BELOW it at the winner (Pool2d rule + safe_divide fused). */
 int lrpx_pool_winner(const float* x, const float* z, float* xzw, uint8_t* am, int n, int h_out, int w_out, int c,
                      void* stream);
+/* the Pool2d rule as a scatter for a conv that does not unpool while staging: s_hi (n_maps, 2*h_out, 2*w_out, c) =
+ * s_lo (n_maps, h_out, w_out, c) at the winner positions `am` (per image, from lrpx_pool_winner), 0 elsewhere */
+int lrpx_unpool_winner(const float* s_lo, const uint8_t* am, const int32_t* map2img, float* s_hi, int n_maps, int h_out,
+                       int w_out, int c, void* stream);
 /* amax[n] = float bits of max |s[n,:]| (zeroes amax first): the per-map operand scale of the f16x3 convolution */
 int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* stream);
 /* running sum over the maps of one image: out[b,t] = sum_{t'<=t} in[b,t']  (the reference's

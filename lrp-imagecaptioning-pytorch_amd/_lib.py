@@ -79,6 +79,7 @@ SIGNATURES = {
     "lrpx_maxpool2x2_relevance": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "lrpx_divide_stab": (_i, [_f, _f, _f, _f, _i, _l, _i, _f]),
     "lrpx_pool_winner": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
+    "lrpx_unpool_winner": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
     "lrpx_aoa_grad_init": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaGradState), _f, _f, _i, _f]),
     "lrpx_aoa_grad_step": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaGradState), _i, _i, _f]),
     "lrpx_aoa_grad_pix": (_i, [C.POINTER(AoaTrace), _i, _f, _f, _f, _i, _f]),

@@ -350,6 +350,33 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
     reinterpret_cast<f32x4*>(y)[idx] = m;
 }
 
+// Pool2d rule as a scatter (lrp_modules.py:182-195 with S already at the winners): s_hi[n][2yo+dy][2xo+dx][c] =
+// s_lo[n][yo][xo][c] if (dy,dx) is the window position am[img][yo][xo][c], else 0.  One thread = one pooled pixel x 4 ch.
+__global__ void unpool_winner_kernel(const float* __restrict__ s_lo, const unsigned char* __restrict__ am,
+                                     const int* __restrict__ map2img, float* __restrict__ s_hi, int ho, int wo, int c4,
+                                     long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*ho*wo*c4
+    if (idx >= total) return;
+    const int cc = idx % c4;
+    long r = idx / c4;
+    const int xo = r % wo; r /= wo;
+    const int yo = r % ho;
+    const long n = r / ho;
+    const long img = map2img ? map2img[n] : n;
+    const f32x4 v = reinterpret_cast<const f32x4*>(s_lo)[idx];
+    const unsigned pk = reinterpret_cast<const unsigned*>(am)[((img * ho + yo) * wo + xo) * c4 + cc];
+    const int wi = 2 * wo;
+    const long b0 = ((n * 2 * ho + 2 * yo) * wi + 2 * xo) * c4 + cc;
+    const long off[4] = {0, c4, (long)wi * c4, (long)wi * c4 + c4};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ((pk >> (8 * e)) & 0xffu) == (unsigned)k ? v[e] : 0.f;
+        reinterpret_cast<f32x4*>(s_hi)[b0 + off[k]] = o;
+    }
+}
+
 // winners of a 2x2 max-pool + the fused multiplicand max / safe(Z+ at the winner); one thread = one pooled pixel x 4 ch
 __global__ void pool_winner_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ xzw,
                                    unsigned char* __restrict__ am, int ho, int wo, int c4, long total) {
@@ -720,6 +747,15 @@ int lrpx_pool_winner(const float* x, const float* z, float* xzw, uint8_t* am, in
     hipLaunchKernelGGL(pool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, z, xzw, am,
                        h_out, w_out, c / 4, total);
     return check_launch("pool_winner");
+}
+
+int lrpx_unpool_winner(const float* s_lo, const uint8_t* am, const int32_t* map2img, float* s_hi, int n_maps, int h_out,
+                       int w_out, int c, void* stream) {
+    LRPX_REQUIRE(s_lo && am && s_hi && n_maps > 0 && h_out > 0 && w_out > 0 && c % 4 == 0, "unpool_winner: bad arguments");
+    const long total = (long)n_maps * h_out * w_out * (c / 4);
+    hipLaunchKernelGGL(unpool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s_lo, am, map2img,
+                       s_hi, h_out, w_out, c / 4, total);
+    return check_launch("unpool_winner");
 }
 
 int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* stream) {

@@ -508,17 +508,21 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
         if (h3) {
             d.f16x3 = 1; d.epi = EPI_REL_MUL; d.wpacked = pk + p.bwdh[l]; d.in_amax = amax + (size_t)l * n_maps;
-            // mode 3: cross products on the fp8 matrix cores - except conv4_3 (28x28 under a pool): its map-straddling
-            // pooled-input kernel keeps the staging descriptors in registers and spills 42 VGPRs with the fp8 operands
-            // (3.1 ms against 2.75 ms with fp16 cross products)
+            // mode 3: cross products on the fp8 matrix cores
             const bool pooled_in = l + 1 < kNL && !kVgg[l + 1].conv;
-#ifdef LRPX_F8_ALL      // (tuning builds: also conv4_3 on the F8 kernel)
             if (g_mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
-#else
-            if (g_mode == 3 && !(L.hw == 28 && pooled_in)) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
-#endif
             // under a pool: S[cur] is the low-resolution tensor the conv above the pool wrote, unpooled while staged
-            if (l + 1 < kNL && !kVgg[l + 1].conv) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
+            if (pooled_in) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
+#ifndef LRPX_F8_POOL28
+            // ... except conv4_3 in mode 3: the map-straddling pooled-input 28x28 kernel spills 40 VGPRs with the fp8
+            // operands (2.98 ms; with fp16 cross products 2.75 ms), so S is unpooled by a scatter kernel (0.5 GB written)
+            // and the conv runs on the plain 28x28 F8 kernel (2.13 ms)
+            if (g_mode == 3 && pooled_in && L.hw == 28) {
+                LRPX_TRY(lrpx_unpool_winner(S[cur], d.pool_am, map2img, S[cur ^ 1], n_maps, L.hw / 2, L.hw / 2, L.cout, stream));
+                cur ^= 1;
+                d.in = S[cur]; d.pool_am = nullptr;
+            }
+#endif
         }
         else if (g_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
         if (kVgg[l - 1].conv) {
