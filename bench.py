@@ -12,8 +12,8 @@ batch with no data-path collective (weak scaling: every rank runs the same per-G
 RCCL gather of the maps to rank 0 that north_star mentions.
 
 Rank 0 prints ONE JSON line.  At N=1 it also carries
-  roofline     : fp32-MFMA roofline of the dominant kernel family (conv_mfma_kernel relevance pass, 13 launches
-                 per step = 30.69 GFLOP per map), timed live with HIP events on the launch stream
+  roofline     : MFMA roofline of the dominant kernel (the relevance conv kernel with the largest total time of the
+                 12 conv launches per step = 30.69 GFLOP per map), timed live with HIP events on the launch stream
   cpu_baseline : the reference-equivalent CPU mode (oracle/ref_equiv.py, kind "port") on a bounded sample.
 """
 import argparse
@@ -30,9 +30,10 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_MAP = 30.69          # one transposed conv per VGG16 layer = 15.35 GMAC (algorithmic, fp32)
 PEAK_FP32_MFMA_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_16BIT_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (no sparsity)
-# The dominant kernel: the relevance step of a 256->256 conv on 56x56 maps (conv3_2 / conv3_3; the three conv3 and
-# three conv4 launches are 55 % of the chain).  Algorithmic work per launch and map: one transposed 3x3 conv =
-# 2*9*256*256*56*56 flop.  The matrix cores execute PRODUCTS[mode] 16-bit MFMA products per fp32 product (operand
+# The dominant kernel: the relevance step of a 256->256 conv on 56x56 maps (conv3_x) or of a 512->512 conv on 28x28 maps
+# (conv4_x) - the same work; the three conv3 and three conv4 launches are 55 % of the chain, and in the default mode the
+# 28x28 kernel has the largest total time (3 launches).  Algorithmic work per launch and map: one transposed 3x3 conv =
+# 2*9*256*256*56*56 = 2*9*512*512*28*28 flop.  The matrix cores execute PRODUCTS[mode] 16-bit MFMA products per fp32 product (operand
 # splits, csrc/conv_f16x3.h / conv_bf16x6.h), so `achieved` counts executed MFMA flop against the 16-bit dense peak;
 # `algorithmic_tflops` is the fp32-equivalent rate.
 DOM_FLOP_PER_MAP = 2.0 * 9 * 256 * 256 * 56 * 56
@@ -40,7 +41,7 @@ MODE_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "bf16x6: exact 3-way bf
              2: "f16x3: per-map power-of-two scaling, 2-way fp16 split, 3 products, fp32 accumulate",
              3: "f16+f8x2: as f16x3, the two cross products (2^-11 of the result) as fp8 e4m3 MFMAs (v_mfma_f32_32x32x64_f8f6f4)"}
 MODE_KERNEL = {0: "conv_mfma_kernel<56,16,1,4,9,REL>", 1: "conv_bf16x6_kernel<56,1,4,true,REL>",
-               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>", 3: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false,true>"}
+               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>", 3: "conv_f16x3_kernel<28,1,4,true,REL_MUL,false,true>"}
 # mode 3: one fp16 product + two fp8 products; the fp8 dense peak is twice the fp16 one, so an fp8 flop counts half:
 # `achieved` / `peak` is then (time the matrix cores need at their peaks) / (measured time), as in the other modes
 PRODUCTS = {0: 1, 1: 6, 2: 3, 3: 2}
@@ -52,7 +53,7 @@ MODE_DTYPE = {0: "f32", 1: "f32 (bf16x6 split-product MFMA, f32 accumulate)", 2:
 # profiles/r01_pmc_traffic_f16x3.txt, ..._bf16x6.txt, r01_pmc_traffic.txt): (2 x FETCH_SIZE raw [gfx950 reports half of wide streaming reads,
 # MI355X_MICROARCH.md §HBM] + WRITE_SIZE) per launch.  Scaled linearly with the map count.
 DOM_TRAFFIC_BYTES_PER_MAP = {0: (2 * 1.9e9 + 0.86e9) / 320, 1: (2 * 1.55e9 + 0.86e9) / 320, 2: (2 * 1.22e9 + 0.77e9) / 320,
-                             3: (2 * 1.195e9 + 0.77e9) / 320}      # profiles/r01_pmc_traffic_f16f8.txt
+                             3: (2 * 5.72e9 + 2.80e9) / 6 / 320}   # 28x28 kernel, 6 launches: profiles/r01_pmc_traffic_f16f8.txt
 
 
 def host_cores():
@@ -238,9 +239,9 @@ def main():
                 e1.synchronize()
                 ms.append(e0.elapsed_time(e1))
             chain_ms = sum(ms) / len(ms)
-            # (2) roofline of the dominant kernel: the 56x56 relevance conv kernel (3 launches per pass: conv3_3, conv3_2
-            # with 256 and conv3_1 with 128 output channels), HIP events recorded by the library on the launch stream
-            # around every conv launch of the same chain on the same inputs
+            # (2) roofline of the dominant kernel (default mode: the 28x28 relevance conv kernel, 3 launches per pass: conv4_3,
+            # conv4_2 with 512 and conv4_1 with 256 output channels), HIP events recorded by the library on the launch
+            # stream around every conv launch of the same chain on the same inputs
             import ctypes as C
             lib = _lib.load()
             per_layer = [0.0] * 17
@@ -255,15 +256,18 @@ def main():
             per_layer = [p / reps for p in per_layer]
             # launches of that kernel NAME per pass: conv3_1 (128 output channels) and conv3_2 (256); in mode 2 conv3_3
             # is the pooled-input variant of the kernel (own name in rocprof), in modes 0/1 it is the same kernel
-            dom_layers, dom_w = ([6, 7], [0.5, 1.0]) if mode >= 2 else ([6, 7, 8], [0.5, 1.0, 1.0])
+            # mode 3: the kernel with the largest total time is the 28x28 one (conv4_1 with 256 output channels, conv4_2,
+            # conv4_3 behind the unpool scatter): same flop per full launch as the 56x56 layers (2*9*512*512*28*28)
+            dom_layers, dom_w = ([10, 11, 12], [0.5, 1.0, 1.0]) if mode == 3 else (([6, 7], [0.5, 1.0]) if mode == 2 else ([6, 7, 8], [0.5, 1.0, 1.0]))
+            dom_desc = ("conv4_1/conv4_2/conv4_3 on 28x28 maps" if mode == 3 else
+                        ("conv3_1/conv3_2 on 56x56 maps" if mode == 2 else "conv3_1/conv3_2/conv3_3 on 56x56 maps"))
             dom_ms = sum(per_layer[l] for l in dom_layers) / len(dom_layers)          # average launch of that kernel
             flop = DOM_FLOP_PER_MAP * B * T * sum(dom_w) / len(dom_w)                 # average algorithmic flop / launch
             alg = flop / dom_ms / 1e9                                        # TFLOP/s, fp32-equivalent
             exe = PRODUCTS[mode] * alg
             peak = PEAK_FP32_MFMA_TF if mode == 0 else PEAK_16BIT_MFMA_TF
             out["roofline"] = {
-                "bound": "mfma", "kernel": MODE_KERNEL[mode] + f" (relevance step of conv3_1/conv3_2"
-                + ("" if mode >= 2 else "/conv3_3") + f" on 56x56 maps, {B * T} maps per launch, {len(dom_layers)} launches per step)", "achieved": round(exe, 1), "peak": peak,
+                "bound": "mfma", "kernel": MODE_KERNEL[mode] + f" (relevance step of {dom_desc}, {B * T} maps per launch, {len(dom_layers)} launches per step)", "achieved": round(exe, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(exe / peak, 4), "mfma_dtype": MODE_NAME[mode],
                 "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
                 "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,
