@@ -254,6 +254,34 @@ def test_pooled_input_conv_rule(ops, hw, cpool, cin, n_img, n_maps, f8):
         assert cosine(got[i], want[i]) > 0.99999
 
 
+def test_unpool_winner_is_the_pool_rule_scatter(ops):
+    """lrpx_unpool_winner (the Pool2d rule as a scatter, used in front of conv4_3 in the default mode): S at the winners of
+    every 2x2 window, zero elsewhere - bit-exact against max_unpool2d with the first-maximum indices, ties included, with
+    a map -> image table"""
+    from lrp_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    n_img, n_maps, c, ho = 2, 5, 32, 7
+    y = torch.relu(torch.randn(n_img, c, 2 * ho, 2 * ho, generator=g))
+    y[:, :, ::4, ::4] = y[:, :, ::4, 1::4]                       # ties: the first maximum (row-major) must win
+    z = torch.rand(n_img, c, 2 * ho, 2 * ho, generator=g) + 0.5
+    s_lo = torch.randn(n_maps, c, ho, ho, generator=g)
+    m2i = [0, 1, 1, 0, 1]
+    _, idx = F.max_pool2d(y, 2, 2, return_indices=True)
+    want = torch.cat([F.max_unpool2d(s_lo[i:i + 1], idx[m2i[i]:m2i[i] + 1], 2, 2) for i in range(n_maps)])
+    dev = "cuda"
+    lib = _lib.load()
+    yg, zg = to_nhwc(y, c).to(dev), to_nhwc(z, c).to(dev)
+    xzw = torch.empty(n_img, ho * ho, c, device=dev)
+    am = torch.empty(n_img, ho * ho, c, dtype=torch.uint8, device=dev)
+    _lib.check(lib.lrpx_pool_winner(_lib.ptr(yg), _lib.ptr(zg), _lib.ptr(xzw), _lib.ptr(am), n_img, ho, ho, c, _lib.stream_ptr()))
+    sl = to_nhwc(s_lo, c).to(dev).contiguous()
+    hi = torch.full((n_maps, 4 * ho * ho, c), float("nan"), device=dev)
+    _lib.check(lib.lrpx_unpool_winner(_lib.ptr(sl), _lib.ptr(am), _lib.ptr(torch.tensor(m2i, dtype=torch.int32, device=dev)),
+                                      _lib.ptr(hi), n_maps, ho, ho, c, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(hi.cpu(), c, 2 * ho, 2 * ho), want)
+
+
 def test_reference_conv_fixture_embedded(ops):
     """The reference's own Conv2d.propagate_relevance output (layers.npz, 6x6 maps incl. an exact-zero
     region) through the MFMA kernel, embedded in a zero 14x14 canvas (zero surroundings == zero padding).
