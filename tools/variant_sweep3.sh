@@ -4,7 +4,7 @@
 # usage: tools/variant_sweep3.sh "<flags1>" "<flags2>" ...
 cd $(dirname $0)/..
 for v in "$@"; do
-  rm -f lrp-imagecaptioning-pytorch_amd/csrc/build/conv_inst_h8*.o lrp-imagecaptioning-pytorch_amd/csrc/build/lrpx_vgg.o
+  rm -f lrp-imagecaptioning-pytorch_amd/csrc/build/conv_inst_h8*.o lrp-imagecaptioning-pytorch_amd/csrc/build/conv_inst_h3*.o lrp-imagecaptioning-pytorch_amd/csrc/build/lrpx_vgg.o
   make -C lrp-imagecaptioning-pytorch_amd/csrc -j16 EXTRA="$v" > /tmp/make.log 2>&1 || { tail -5 /tmp/make.log; exit 1; }
   timeout -k 10 200 python3 bench.py --conv-mode 3 --no-cpu-baseline --steps 6 --warmup 2 2>/dev/null | grep metric > /tmp/b.json || exit 1
   python3 - "$v" <<'PY'
