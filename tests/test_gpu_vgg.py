@@ -468,8 +468,9 @@ def test_vgg_relevance_conservation(ops, gridtd_case):
 def test_full_size_chain_properties(ops):
     """BASELINE config 2 size (16 images x 20 words = 320 maps), size-independent properties of the CNN relevance chain:
     (1) conservation: sum(R_img) == sum(target) per map for a positive target on active features (SURVEY §8c);
-    (2) the default chain (f16x3 kernels, Pool2d rule fused into the conv under the pool, per-map operand scales
-        spanning 1e-3..1e3) agrees per map within 1e-4 with the bf16x6 chain + separate pool kernels on the SAME trace;
+    (2) the f16x3 chain and the default chain (fp8 cross products; Pool2d rule fused into the conv under the pool, per-map
+        operand scales spanning 1e-3..1e3) agree per map within 1e-4 with the bf16x6 chain + separate pool kernels on the
+        SAME trace;
     (3) determinism: two runs are bit-identical (per-map maxima are atomicMax, order independent)."""
     from lrp_amd import _lib, weights
     lib = _lib.load()
@@ -488,9 +489,17 @@ def test_full_size_chain_properties(ops):
         again = vgg.relevance(r_feat, m2i).clone()
         lib.lrpx_set_conv_mode(1)
         maps_x6 = vgg.relevance(r_feat, m2i).clone()
+        lib.lrpx_set_conv_mode(3)
+        maps_f8 = vgg.relevance(r_feat, m2i).clone()
+        again_f8 = vgg.relevance(r_feat, m2i).clone()
     finally:
         lib.lrpx_set_conv_mode(prev)
     torch.cuda.synchronize()
+    # the default mode (fp8 cross products): same contract against the exact-split chain on all 320 maps, deterministic
+    assert torch.equal(maps_f8, again_f8)
+    err8 = (maps_f8.double() - maps_x6.double()).abs().amax(dim=(1, 2, 3)) / maps_x6.double().abs().amax(dim=(1, 2, 3))
+    print("mode 3 vs bf16x6 chain, 320 maps: max %.2e  mean %.2e" % (err8.max().item(), err8.mean().item()))
+    assert err8.max().item() < TOL, err8.max().item()
     assert torch.equal(maps, again)
     tot = maps.double().sum(dim=(1, 2, 3)) / r_feat.double().sum(dim=(1, 2))
     assert (tot - 1).abs().max().item() < 2e-3
