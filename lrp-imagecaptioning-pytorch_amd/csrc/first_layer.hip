@@ -36,23 +36,44 @@ __global__ __launch_bounds__(256) void first_layer_rel_kernel(const float* __res
     const int n = blockIdx.z, ty0 = blockIdx.y * FL_TH, tx0 = blockIdx.x * FL_TW;
     const int tid = threadIdx.x, ly = tid >> 5, lx = tid & 31;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* Sn = S + (long)n * HW * HW * cin;
     const int nchunk = cin / FL_KC;
+    // staging items of this thread: (halo pixel, 16-byte segment) -> LDS offset and global element offset (without the
+    // chunk term), fixed for all chunks.  The loads of chunk c+1 are in flight while chunk c is computed: one load at a
+    // time with a wait after each (the previous version) left the kernel bound by global-load latency.
+    constexpr int NIT = (FL_HP * FL_WP * (FL_KC / 4) + 255) / 256;
+    int lds_off[NIT];
+    long g_off[NIT];            // < 0: outside the image (stays zero) or no item
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int it = tid + k * 256;
+        const int seg = it & 3, p = it >> 2;
+        const int py = p / FL_WP, px = p - py * FL_WP;
+        const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+        lds_off[k] = p * FL_STRIDE + seg * 4;
+        const bool in_tile = it < FL_HP * FL_WP * (FL_KC / 4);
+        const bool in_img = gy >= 0 && gy < HW && gx >= 0 && gx < HW;
+        const long pix = ((long)n * HW + gy) * HW + gx;
+        // channel-chunked S [cin/16][n_maps*HW*HW][16]: contiguous 64-byte runs per pixel; else NHWC
+        g_off[k] = !in_tile ? -2 : (!in_img ? -1 : (chunk_stride ? pix * FL_KC + seg * 4 : pix * cin + seg * 4));
+    }
+    const long cstep = chunk_stride ? chunk_stride : FL_KC;
+    f32x4 stage[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        stage[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g_off[k] >= 0) stage[k] = *reinterpret_cast<const f32x4*>(S + g_off[k]);
+    }
     for (int chunk = 0; chunk < nchunk; ++chunk) {
+        __syncthreads();                              // the previous chunk has been consumed
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (g_off[k] >= -1) *reinterpret_cast<f32x4*>(lds + lds_off[k]) = stage[k];
         __syncthreads();
-        // stage (TH+2) x (TW+2) pixels x 16 channels, zero outside the image
-        for (int it = tid; it < FL_HP * FL_WP * (FL_KC / 4); it += 256) {
-            const int seg = it & 3, p = it >> 2;
-            const int py = p / FL_WP, px = p - py * FL_WP;
-            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < HW && gx >= 0 && gx < HW)
-                v = chunk_stride   // channel-chunked S [cin/16][n_maps*HW*HW][16]: contiguous 64-byte runs per pixel
-                        ? *reinterpret_cast<const f32x4*>(S + chunk * chunk_stride + (((long)n * HW + gy) * HW + gx) * FL_KC + seg * 4)
-                        : *reinterpret_cast<const f32x4*>(Sn + ((long)gy * HW + gx) * cin + chunk * FL_KC + seg * 4);
-            *reinterpret_cast<f32x4*>(lds + p * FL_STRIDE + seg * 4) = v;
+        if (chunk + 1 < nchunk) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k)
+                if (g_off[k] >= 0) stage[k] = *reinterpret_cast<const f32x4*>(S + g_off[k] + (long)(chunk + 1) * cstep);
         }
-        __syncthreads();
         const float* wc = w6 + chunk * 9 * FL_KC * 6;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
