@@ -443,7 +443,7 @@ class GridTDEngine:
             del r._graphs
         return r
 
-    def explain_stream(self, batches, depth=2, accumulate=False):
+    def explain_stream(self, batches, depth=3, accumulate=False):
         """Explain an iterable of independent (images, captions) batches with `depth` batches in flight, each on its own
         HIP stream and buffer set.  Batches are independent (no exchange step), and roughly a seventh of
         a batch's time is the decoder's lock-step chain of small latency-bound kernels: it overlaps the MFMA-bound CNN

@@ -143,7 +143,7 @@ def test_explain_stream_matches_serial():
                for i in range(5)]
     serial = [tuple(t.clone() for t in eng.explain_batch(im, cp)) for im, cp in batches]
     torch.cuda.synchronize()
-    piped = list(eng.explain_stream(batches, depth=2))
+    piped = list(eng.explain_stream(batches, depth=3))
     assert len(piped) == len(serial)
     for (m0, w0), (m1, w1) in zip(serial, piped):
         assert torch.equal(m0, m1) and torch.equal(w0, w1)
