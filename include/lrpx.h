@@ -107,6 +107,10 @@ typedef struct lrpx_conv_desc {
                                  OUTPUT [n_maps][hw/2*hw/2][cin]; pool_am [n_img][hw/2*hw/2][cin] = window position
                                  (0..3, row-major) of each maximum (lrpx_pool_winner): Pool2d.propagate_relevance
                                  (lrp_modules.py:182-195) is applied while the operand is staged */
+    int tile_group;           /* f16x3, performance hint only (results do not depend on it): maps [k*g, (k+1)*g) share an
+                                 image (the g words of a caption): their tiles of the same image rows are scheduled next to
+                                 each other on one XCD, so the per-image multiplicand `x` is fetched from HBM once, not g
+                                 times.  0 / 1: plain order.  Needs n_maps %% g == 0 and map-aligned tiles (hw >= 56) */
 } lrpx_conv_desc;
 /* 3x3/pad-1 convolution (taps=9, square hw x hw maps) or dense GEMM (taps=1) on the fp32 MFMA with
  * the fused epilogues of the relevance rules.  Replaces F.conv2d / conv backward inside

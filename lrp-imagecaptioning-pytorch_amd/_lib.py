@@ -55,7 +55,8 @@ class ConvDesc(C.Structure):
                 ("epi", _i), ("stab", _i), ("oc_split", _i), ("relu", _i), ("in_chunked", _i), ("bf16x6", _i),
                 ("bias", _f), ("x", _f), ("u", _f), ("zdiv", _f), ("map2img", _f),
                 ("out0", _f), ("out1", _f),
-                ("f16x3", _i), ("out_chunk", _i), ("in_amax", _f), ("out1_amax", _f), ("out0_amax", _f), ("pool_am", _f)]
+                ("f16x3", _i), ("out_chunk", _i), ("in_amax", _f), ("out1_amax", _f), ("out0_amax", _f), ("pool_am", _f),
+                ("tile_group", _i)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/lrpx.h (tests/test_abi.py checks it)

@@ -143,8 +143,25 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
     const int wm = wave / NWN, wn = wave % NWN;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int mtile = (idx / n_blocks) * 8 + xcd;
+    int mtile = (idx / n_blocks) * 8 + xcd;
     const int nblk = idx % n_blocks;
+#ifndef LRPXH_TILE_GROUP
+#define LRPXH_TILE_GROUP 1
+#endif
+    if constexpr (AL && (LRPXH_TILE_GROUP != 0)) {
+        // a.tile_group maps per image: the tiles (image row block r) of the words w of one image run back to back on ONE
+        // XCD (workgroup ids go round-robin over the 8 XCDs), so the image's multiplicand tile stays in that L2 for all
+        // of them instead of being fetched from HBM once per word
+        if (a.tile_group > 1) {
+            constexpr int TPM = H / C::R;                          // tiles per map
+            const int q = idx / n_blocks;                          // position in this XCD's sequence
+            const int gl = q / a.tile_group, w = q - gl * a.tile_group;
+            const int G = gl * 8 + xcd;                            // (image, row block) group
+            const int i = G / TPM, r = G - i * TPM;
+            mtile = (i * a.tile_group + w) * TPM + r;
+            if (G >= (a.n_maps / a.tile_group) * TPM) return;
+        }
+    }
     if (mtile >= m_tiles) return;
 
     const int ocb = nblk * NWN + wn;
@@ -814,7 +831,12 @@ int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 80 + 256);
     const long m_tiles = ceil_div((long)a.n_maps * HW, C::R);
     const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
-    const long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
+    long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
+    using CC = ConvCfg<HW, 16, MT, NWN, 9>;
+    if (HW % CC::R == 0 && a.tile_group > 1) {       // grouped order: every XCD walks whole (image, row block) groups
+        const long n_groups = (long)(a.n_maps / a.tile_group) * (HW / CC::R);
+        grid = ceil_div(n_groups, 8) * 8 * a.tile_group * n_blocks;
+    }
     auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI, POOL, F8>;
     static bool attr_done = false;
     if (!attr_done) {

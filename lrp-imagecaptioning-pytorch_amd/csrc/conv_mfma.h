@@ -64,6 +64,7 @@ struct ConvArgs {
     unsigned* out0_amax;       // f16x3 kernels, FWD_DUAL: [n_maps] max of out0 (activations) per map (may be null)
     const unsigned char* pool_am;  // f16x3 POOL kernels: [n_img][H/2*W/2][cin] window position of each 2x2 maximum; `in`
                                    // is then the low-resolution tensor [n_maps][H/2*W/2][cin]
+    int tile_group;                // f16x3 map-aligned kernels: > 1 = maps come in groups of this many per image (hint)
 };
 
 __device__ __forceinline__ float stab_safe(float z) { return z + 1e-7f * (z == 0.f ? 1.f : 0.f); }

@@ -25,6 +25,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
     a.out0 = d->out0; a.out1 = d->out1;
     a.in_amax = d->in_amax; a.out1_amax = d->out1_amax; a.pool_am = d->pool_am; a.out0_amax = d->out0_amax;
     a.out_chunk = d->epi == EPI_REL_MUL ? d->out_chunk : 0;
+    a.tile_group = (d->f16x3 && d->tile_group > 1 && d->n_maps % d->tile_group == 0) ? d->tile_group : 0;
     a.ksplit = 1;
     // few rows (the decoder's lock-step rules): 32-row tiles, whole K per workgroup (dense_small.hip)
     if (d->taps == 1 && !d->bf16x6 && !d->f16x3 && dense_small_fits(a)) {
@@ -508,6 +509,9 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
         if (h3) {
             d.f16x3 = 1; d.epi = EPI_REL_MUL; d.wpacked = pk + p.bwdh[l]; d.in_amax = amax + (size_t)l * n_maps;
+            // the maps of one image (the words of its caption) usually follow each other: tile-order hint for the
+            // multiplicand reuse in L2 (a wrong guess only costs the reuse)
+            d.tile_group = (n_maps % n_img == 0) ? n_maps / n_img : 0;
             // mode 3: cross products on the fp8 matrix cores
             const bool pooled_in = l + 1 < kNL && !kVgg[l + 1].conv;
             if (g_mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
