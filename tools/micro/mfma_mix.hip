@@ -1,4 +1,5 @@
 // Micro-benchmark: how long does one K-chunk of the conv kernel's MFMA phase take on the whole chip when the two
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/mfma_mix tools/micro/mfma_mix.hip   (run: ./tools/micro/mfma_mix)
 // cross products run as fp8 K=64 MFMAs instead of fp16 K=16?  (7 accumulator tiles per wave, random operands:
 // the sustained clock depends on the data.)
 //   variant 0: 27 x v_mfma_f32_32x32x16_f16 per chunk per tile        (f16x3 as shipped)
