@@ -1,11 +1,11 @@
 // Micro-benchmark: how long does one K-chunk of the conv kernel's MFMA phase take on the whole chip when the two
-// build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/mfma_mix tools/micro/mfma_mix.hip   (run: ./tools/micro/mfma_mix)
 // cross products run as fp8 K=64 MFMAs instead of fp16 K=16?  (7 accumulator tiles per wave, random operands:
 // the sustained clock depends on the data.)
 //   variant 0: 27 x v_mfma_f32_32x32x16_f16 per chunk per tile        (f16x3 as shipped)
 //   variant 1:  9 x f16  + 6 x v_mfma_f32_32x32x64_f8f6f4 (fp8 e4m3)  (hi.hi in fp16, cross terms in fp8, 12 tap slots)
 //   variant 2:  9 x f16  only                                          (floor)
 //   variant 3: 18 x f16 + 5 x fp8 per 2 chunks (2 taps x 32 channels)  (per-chunk cost = half)
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/mfma_mix tools/micro/mfma_mix.hip   (run: ./tools/micro/mfma_mix)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
