@@ -448,6 +448,14 @@ def test_vgg_chain_multi_image_vs_oracle(ops):
         _, _, saved = O.vgg_forward(sdt, img[b:b + 1])
         want = O.vgg_lrp(sdt, saved, r_feat[i:i + 1])
         assert rel_err(maps[i:i + 1], want) < TOL, i
+    # the word-grouped tile order is only a scheduling hint (lrpx_conv_desc.tile_group = n_maps / n_img when that divides):
+    # 4 maps on 2 images make the library guess "2 consecutive maps per image" - here WRONGLY (table [1, 0, 0, 1]) - and
+    # the maps must not change: same targets as above in another order, same results
+    m2i4 = [1, 0, 0, 1]
+    r4 = torch.stack([r_feat[0], r_feat[1], r_feat[1], r_feat[2]])
+    maps4 = vgg.relevance(to_nhwc(r4).cuda(), torch.tensor(m2i4, dtype=torch.int32, device="cuda")).cpu()
+    assert torch.equal(maps4[0], maps[0]) and torch.equal(maps4[1], maps[1]) and torch.equal(maps4[3], maps[2])
+    assert torch.equal(maps4[2], maps4[1])
 
 
 def test_vgg_relevance_conservation(ops, gridtd_case):

@@ -7,7 +7,7 @@ import lrp_amd  # noqa
 from lrp_amd import weights
 from lrp_amd.explainers.gridtd import GridTDEngine
 eng = GridTDEngine(weights.make_gridtd_state(seed=0, vocab_size=50))
-for B in (16, 4):
+for B in (16, 4, 32, 48, 64):
     images = torch.from_numpy(weights.make_images(100, B)).cuda()
     for _ in range(3): f = eng.vgg.forward(images)
     torch.cuda.synchronize()
