@@ -5,6 +5,8 @@
 //   variant 1:  9 x f16  + 6 x v_mfma_f32_32x32x64_f8f6f4 (fp8 e4m3)  (hi.hi in fp16, cross terms in fp8, 12 tap slots)
 //   variant 2:  9 x f16  only                                          (floor)
 //   variant 3: 18 x f16 + 5 x fp8 per 2 chunks (2 taps x 32 channels)  (per-chunk cost = half)
+//   variant 4:  9 x f16  + 5 x fp8                                     (as shipped: 18 cross-term slices in 5 MFMAs)
+//   variant 5:  9 x f16  + 5 x fp6 e2m3 (same instruction, cbsz = blgp = 2: 4x the fp16 rate)
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/mfma_mix tools/micro/mfma_mix.hip   (run: ./tools/micro/mfma_mix)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -26,7 +28,8 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* _
     for (int j = 0; j < 8; ++j) { b[j] = (_Float16)src[lane * 8 + j + 1]; b8[j] = __float_as_int(src[lane * 8 + j + 3]) & 0x3f3f3f3f; }
     for (int it = 0; it < iters; ++it) {
         constexpr int NF16 = VAR == 0 ? 27 : (VAR == 3 ? 18 : 9);
-        constexpr int NF8 = VAR == 1 ? 6 : (VAR == 3 ? 5 : 0);
+        constexpr int NF8 = VAR == 1 ? 6 : ((VAR == 3 || VAR == 4) ? 5 : 0);
+        constexpr int NF6 = VAR == 5 ? 5 : 0;
 #pragma unroll
         for (int t = 0; t < NF16; ++t)
 #pragma unroll
@@ -36,6 +39,11 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* _
 #pragma unroll
             for (int i = 0; i < 7; ++i)
                 acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8, acc[i], 0, 0, 0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NF6; ++t)
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8, acc[i], 2, 2, 0, 0, 0, 0);
     }
     float s = 0.f;
     for (int i = 0; i < 7; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
@@ -65,6 +73,8 @@ int main() {
         const float t0 = run<0>(src, dst, iters), t1 = run<1>(src, dst, iters), t2 = run<2>(src, dst, iters), t3 = run<3>(src, dst, iters / 2);
         // cycles per chunk per wave-tile group if the pipe were alone: 2 waves per SIMD share it
         printf("27 f16: %.3f ms   9 f16 + 6 fp8: %.3f ms (x%.2f)   9 f16: %.3f ms   (18 f16 + 5 fp8)/2: %.3f ms (x%.2f)\n", t0, t1, t0 / t1, t2, t3, t0 / t3);
+        const float t4 = run<4>(src, dst, iters), t5 = run<5>(src, dst, iters);
+        printf("   9 f16 + 5 fp8: %.3f ms   9 f16 + 5 fp6: %.3f ms (x%.2f of the fp8 mix)\n", t4, t5, t4 / t5);
         const double mf = 512.0 * 4 * iters * 7;   // waves * chunks * tiles
         printf("   f16 rate in variant 0: %.0f TFLOP/s\n", mf * 27 * 32768 / (t0 * 1e-3) / 1e12);
     }
