@@ -332,6 +332,50 @@ class AOAEngine:
         return out
 
 
+    def replica(self):
+        """A second execution context over the SAME weights: own VGG16 trace / workspace buffers, so that several
+        batches can be in flight on separate HIP streams (as GridTDEngine.replica)."""
+        import copy
+        r = copy.copy(self)
+        if self.vgg is not None:
+            r.vgg = self.vgg.replica()
+        r._idx_cache = {}
+        r.__dict__.pop("_replicas", None)
+        r.__dict__.pop("_streams", None)
+        return r
+
+    def explain_stream(self, batches, head_idx, depth=3, accumulate=False):
+        """`explain_batch` over an iterable of independent (images, captions) batches with `depth` batches in flight,
+        each on its own HIP stream and buffer set (the decoder's latency-bound kernels of one batch overlap the CNN
+        relevance chain of another).  Yields (maps, r_words) in input order, complete when yielded; bit-identical to
+        serial `explain_batch` calls."""
+        depth = max(1, int(depth))
+        if not hasattr(self, "_replicas"):
+            self._replicas, self._streams = [self], [torch.cuda.Stream(device=self.device)]
+        while len(self._replicas) < depth:
+            self._replicas.append(self.replica())
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        pending = []
+        for i, (images, captions) in enumerate(batches):
+            k = i % depth
+            st = self._streams[k]
+            st.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(st):
+                out = self._replicas[k].explain_batch(captions, head_idx, images=images, accumulate=accumulate)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            for t in out:
+                t.record_stream(torch.cuda.current_stream(self.device))
+            pending.append((out, ev))
+            if len(pending) >= depth:
+                o, e = pending.pop(0)
+                e.synchronize()
+                yield o
+        for o, e in pending:
+            e.synchronize()
+            yield o
+
+
 class ExplainAOAAttention(object):
     """Drop-in for the reference's `ExplainAOAAttention` (models/aoamodel.py:748-1194): `explain_caption(img, head_idx)`,
     `explain_caption_wordt(t, head_idx)`, `explain_cnn(R)`, `explain_caption_words(img)`; see

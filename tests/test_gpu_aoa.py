@@ -104,3 +104,21 @@ def test_aoa_sample_lrp_tokens_bit_exact():
         seq, lps = eng.sample_lrp(enc, L, wm['<start>'], end_id, g[skip_k].tolist())
         assert seq.cpu().tolist() == g[seq_k].tolist()
         assert np.abs(lps.cpu().numpy() - g[lp_k]).max() < 1e-4
+
+
+def test_aoa_explain_stream_matches_serial():
+    """independent batches in flight on separate HIP streams (AOAEngine.explain_stream) give bit-identical maps and word
+    relevances to explaining them one after the other"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    eng = AOAEngine(weights.make_aoa_state(seed=4, vocab_size=60))
+    batches = [(torch.from_numpy(weights.make_images(30 + i, 2)), torch.from_numpy(weights.make_captions(40 + i, 2, 3, 60)))
+               for i in range(5)]
+    serial = [tuple(t.clone() for t in eng.explain_batch(cp, 5, images=im)) for im, cp in batches]
+    torch.cuda.synchronize()
+    piped = list(eng.explain_stream(batches, 5, depth=3))
+    assert len(piped) == len(serial)
+    for (m0, w0), (m1, w1) in zip(serial, piped):
+        assert torch.equal(m0, m1) and torch.equal(w0, w1)

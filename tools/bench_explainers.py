@@ -72,3 +72,13 @@ for name, fn in (("greedy decoding (greedy)", lambda: eng.greedy(enc, T + 1, wm[
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     print(f"{name:52s} {dt*1e3:8.2f} ms/step  {B*T/dt:9.1f} words/s")
+
+# AoA LRP with three batches in flight (AOAEngine.explain_stream), config-3 model
+def aoa_stream(n):
+    return sum(1 for _ in aoa.explain_stream(((images, caps_a) for _ in range(n)), 0, depth=3))
+aoa_stream(4); torch.cuda.synchronize()
+t0 = time.perf_counter()
+aoa_stream(12)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 12
+print(f"{'AoA LRP, head 0, 3 batches in flight':52s} {dt*1e3:8.2f} ms/step  {B*T/dt:9.1f} maps/s")
