@@ -1,24 +1,38 @@
 #!/usr/bin/env python3
 """Headline benchmark: LRP relevance maps/sec (VGG16 + gridTD, 224x224, 20-token caption).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without RANK/WORLD_SIZE: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one batch per GPU (BASELINE.json configs[1]: 16 images x 20 words
-= 320 relevance maps, V=9586): VGG16 forward trace (+Z+), decoder trace, decoder relevance, VGG16 relevance.
-Inputs (images, token ids) are resident in HBM before the timed region; weights are random-init from the
-seeded generator (no network for checkpoints), data synthetic.  Images are independent, so ranks shard the
-batch with no data-path collective (weak scaling: every rank runs the same per-GPU batch); --gather adds the
-RCCL gather of the maps to rank 0 that north_star mentions.
+One step = one pass of the hot path over one batch per GPU.  Default = BASELINE.json configs[1]: 16 images x 20 words
+= 320 relevance maps, V=9586: VGG16 forward trace (+Z+), decoder trace incl. the (T,V) predictions the reference's
+explainer keeps (evaluation.py:109 reads them), decoder relevance, VGG16 relevance, running sums of the maps (what
+`explain_caption` returns: lrp_wrapper.py:64-82).  Inputs (images, token ids) are resident in HBM before the timed
+region; weights are random-init from the seeded generator (no network for checkpoints), data synthetic.  Images are
+independent, so ranks shard the batch with no data-path collective (weak scaling: every rank runs the same per-GPU
+batch); --gather adds the RCCL gather of the maps to rank 0 that north_star mentions.
+
+Other BASELINE configs as optional lines (the headline stays config 2):
+    --config 3                 AoA 8-head decoder, B=64, V=11027, head 0 (1280 maps / step)
+    --config 4                 gridTD, B=32 per GPU, LRP + Guided-Backprop side by side on the same encoder trace
+                               (= --explainer lrp+guided --batch 32; 2 x 640 maps / step)
+    --config 5                 AoA bottom-up, 36x2048 region features, B=32 per GPU, relevance back to the features
 
 Rank 0 prints ONE JSON line.  At N=1 it also carries
   roofline     : MFMA roofline of the dominant kernel (the relevance conv kernel with the largest total time of the
-                 12 conv launches per step = 30.69 GFLOP per map), timed live with HIP events on the launch stream
+                 12 conv launches per step = 30.69 GFLOP per map), timed live with HIP events on the launch stream;
+                 `traffic` is read from the PMC summary named in `traffic_source` (profiles/, separate --pmc passes);
+                 `modes`: the same step and chain in every matrix-core mode (0 fp32 MFMA ... 3 fp16+fp8), same process
+  sustained    : the same step repeated for >= --sustain seconds (power-limited clocks show here, not in 20 steps)
+  median_ms    : median interval between step completions (HIP events) inside the timed region
   cpu_baseline : the reference-equivalent CPU mode (oracle/ref_equiv.py, kind "port") on a bounded sample.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +44,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_MAP = 30.69          # one transposed conv per VGG16 layer = 15.35 GMAC (algorithmic, fp32)
 PEAK_FP32_MFMA_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_16BIT_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (no sparsity)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E
 # The dominant kernel: the relevance step of a 256->256 conv on 56x56 maps (conv3_x) or of a 512->512 conv on 28x28 maps
 # (conv4_x) - the same work; the three conv3 and three conv4 launches are 55 % of the chain, and in the default mode the
 # 28x28 kernel has the largest total time (3 launches).  Algorithmic work per launch and map: one transposed 3x3 conv =
@@ -45,15 +60,15 @@ MODE_KERNEL = {0: "conv_mfma_kernel<56,16,1,4,9,REL>", 1: "conv_bf16x6_kernel<56
 # mode 3: one fp16 product + two fp8 products; the fp8 dense peak is twice the fp16 one, so an fp8 flop counts half:
 # `achieved` / `peak` is then (time the matrix cores need at their peaks) / (measured time), as in the other modes
 PRODUCTS = {0: 1, 1: 6, 2: 3, 3: 2}
-# arithmetic the contractions run in: all tensors are fp32; modes 1 / 2 evaluate each fp32 product as split 16-bit MFMA
-# products with fp32 accumulation (fp32-grade results), everything else is fp32 VALU
-MODE_DTYPE = {0: "f32", 1: "f32 (bf16x6 split-product MFMA, f32 accumulate)", 2: "f32 (f16x3 split-product MFMA, f32 accumulate)",
-              3: "f32 (fp16 + 2 fp8 split-product MFMA, f32 accumulate)"}
-# HBM traffic of ONE launch of that kernel over 320 maps, from rocprofv3 --pmc (separate passes, tools/pmc_passes.sh;
-# profiles/r01_pmc_traffic_f16x3.txt, ..._bf16x6.txt, r01_pmc_traffic.txt): (2 x FETCH_SIZE raw [gfx950 reports half of wide streaming reads,
-# MI355X_MICROARCH.md §HBM] + WRITE_SIZE) per launch.  Scaled linearly with the map count.
-DOM_TRAFFIC_BYTES_PER_MAP = {0: (2 * 1.9e9 + 0.86e9) / 320, 1: (2 * 1.55e9 + 0.86e9) / 320, 2: (2 * 1.22e9 + 0.77e9) / 320,
-                             3: (2 * 5.72e9 + 2.80e9) / 6 / 320}   # 28x28 kernel, 6 launches: profiles/r01_pmc_traffic_f16f8.txt
+# arithmetic the contractions run in (tensors in HBM are fp32 in every mode; everything outside the convolutions is fp32 VALU)
+MODE_DTYPE = {0: "f32", 1: "bf16x6 split products, f32 accumulate", 2: "f16x3 split products, f32 accumulate",
+              3: "f16 + 2 x f8(e4m3) split products, f32 accumulate"}
+# HBM traffic of the dominant kernel per launch: tools/prof_summary.py traffic --json writes this file from the two --pmc
+# passes (FETCH_SIZE / WRITE_SIZE, separate from any tracing); bytes = 2 x FETCH_SIZE raw [gfx950 reports half of wide
+# streaming reads, MI355X_MICROARCH.md §HBM] + WRITE_SIZE, divided by the launches and scaled to the maps of this run
+TRAFFIC_FILES = ["profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
+TRAFFIC_KERNEL = {0: "conv_mfma_kernel<56, 16, 1, 4, 9, 1>", 1: "conv_bf16x6_kernel<56, 1, 4, true, 1>",
+                  2: "conv_f16x3_kernel<56, 1, 4, true, 5, false, false>", 3: "conv_f16x3_kernel<28, 1, 4, true, 5, false, true>"}
 
 
 def host_cores():
@@ -90,29 +105,82 @@ def cpu_baseline(V, T, words):
                       f"({t_words:.1f} s) + trace {t_trace:.1f} s, scaled to {T} words"}
 
 
-def main():
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` and relay its
+    output (rank 0's JSON line goes to our stdout).  This process never touches the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting ranks: " + " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def read_traffic(mode, n_maps):
+    """(bytes per launch of the dominant kernel for `n_maps` maps, source file) from the PMC summary under profiles/."""
+    for rel in TRAFFIC_FILES:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        try:
+            doc = json.load(open(path))
+            k = doc["kernels"][TRAFFIC_KERNEL[mode]]
+            per_map = (2.0 * k["fetch_bytes"] + k["write_bytes"]) / k["launches"] / doc["maps_per_launch"]
+            return round(per_map * n_maps), rel
+        except (KeyError, ValueError, ZeroDivisionError):
+            continue
+    return None, None
+
+
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (config 2)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] (1-based): see the docstring")
+    ap.add_argument("--explainer", default=None, choices=["lrp", "lrp+guided"], help="config 2 / 4: LRP only or LRP + Guided-Backprop")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: the config's)")
     ap.add_argument("--words", type=int, default=20)
-    ap.add_argument("--vocab", type=int, default=9586)
+    ap.add_argument("--vocab", type=int, default=None)
+    ap.add_argument("--head", type=int, default=0, help="AoA head explained (configs 3 / 5)")
     ap.add_argument("--gather", action="store_true", help="gather the maps to rank 0 over RCCL inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
-    ap.add_argument("--pipeline", type=int, default=3,
-                    help="independent batches in flight on separate HIP streams (1 = serial steps); every step is still "
-                         "one full pass over one batch, the decoder's latency-bound kernels of one batch overlap the "
-                         "MFMA-bound CNN chain of another")
+    ap.add_argument("--no-modes", action="store_true", help="skip the roofline.modes sweep (every conv mode, same process)")
+    ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained sub-measurement (0 = off)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (config 2, LRP)")
+    ap.add_argument("--pipeline", type=int, default=None,
+                    help="independent batches in flight on separate HIP streams (1 = serial steps; default 3, 2 for the "
+                         "large configs 3 / 4); every step is still one full pass over one batch, the decoder's "
+                         "latency-bound kernels of one batch overlap the MFMA-bound CNN chain of another")
     ap.add_argument("--fp32-mfma", action="store_true", help="same as --conv-mode 0")
     ap.add_argument("--conv-mode", type=int, default=3, choices=[0, 1, 2, 3],
-                    help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3 relevance (default)")
+                    help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp8 cross products (default)")
     a = ap.parse_args()
+    if a.explainer is None:
+        a.explainer = "lrp+guided" if a.config == 4 else "lrp"
+    if a.batch is None:
+        a.batch = {2: 16, 3: 64, 4: 32, 5: 32}[a.config]
+    if a.vocab is None:
+        a.vocab = 9586 if a.config in (2, 4) else 11027
+    if a.pipeline is None:
+        a.pipeline = 3 if a.config in (2, 5) else 2
+    return a
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))          # before anything touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -129,162 +197,285 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     import lrp_amd  # noqa: F401
-    from lrp_amd import weights
-    from lrp_amd.explainers.gridtd import GridTDEngine
-    from lrp_amd import ops
+    from lrp_amd import _lib, ops, weights
 
     B, T, V = a.batch, a.words, a.vocab
-    from lrp_amd import _lib
+    lib = _lib.load()
     mode = 0 if a.fp32_mfma else a.conv_mode
-    _lib.load().lrpx_set_conv_mode(mode)
+    lib.lrpx_set_conv_mode(mode)
     torch.set_num_threads(min(8, host_cores()))
     if rank == 0:
-        log(f"building weights + engine (B={B}, T={T}, V={V}, world={world})")
-    sd0 = weights.make_gridtd_state(seed=0, vocab_size=V)
-    eng = GridTDEngine(sd0)
+        log(f"config {a.config} ({a.explainer}): building weights + engine (B={B}, T={T}, V={V}, world={world})")
     n_pipe = 1 if a.graph else max(1, a.pipeline)
-    engines = [eng] + [eng.replica() for _ in range(n_pipe - 1)]     # shared weights, own trace / workspace buffers
     streams = [torch.cuda.Stream() for _ in range(n_pipe)] if n_pipe > 1 else [None]
-    # every rank gets its own shard of a global synthetic batch (seed offset by rank)
-    images = torch.from_numpy(weights.make_images(100 + rank, B)).cuda()
     caps = torch.from_numpy(weights.make_captions(200 + rank, B, T, V)).cuda()
+    state = {}
+    guided = a.explainer == "lrp+guided"
+    maps_per_gpu = B * T * (2 if guided else 1)
+    has_vgg = a.config != 5
+
+    def buf(name, k, *shape):
+        key = f"{name}{k}"
+        if key not in state:
+            state[key] = torch.empty(*shape, device="cuda")
+        return state[key]
+
+    if a.config in (2, 4):
+        from lrp_amd.explainers.gridtd import GridTDEngine
+        eng = GridTDEngine(weights.make_gridtd_state(seed=0, vocab_size=V))
+        images = torch.from_numpy(weights.make_images(100 + rank, B)).cuda()     # every rank: its own shard (seed offset)
+
+        def one_step(e, k):
+            enc = e.encode(images)
+            tr = e.trace(enc, caps, predictions=True)
+            r_feat, r_words, row2img = e.relevance(enc, tr)
+            maps = e.vgg.relevance(r_feat, row2img, out=buf("maps", k, B * T, 3, 224, 224))
+            cum = ops.cumsum_maps(maps, B, T, out=buf("cum", k, B * T, 3, 224, 224))   # explain_caption's running sums
+            if k == 0:
+                state["chain_in"] = (r_feat, row2img)
+            if guided:     # config 4: guided backprop of the same words on the same encoder trace (own decoder trace, :1323-1422)
+                trg = e.trace(enc, caps, predictions=False, grad=True)
+                d_feat, _, _ = e.guided_gradient(enc, trg)
+                state["gmaps"] = e.vgg.guided_backprop(d_feat, row2img, out=buf("gmaps", k, B * T, 3, 224, 224))
+            return cum, r_words
+        workload = (f"BASELINE configs[{a.config - 1}]: batch-{B} 224x224 images x {T}-word captions per GPU, VGG16+gridTD, "
+                    f"LRP alpha1beta0 (conv) + epsilon (decoder){' + Guided-Backprop side by side' if guided else ''}, V={V}, random-init")
+    elif a.config == 3:
+        from lrp_amd.explainers.aoa import AOAEngine
+        eng = AOAEngine(weights.make_aoa_state(seed=0, vocab_size=V))
+        images = torch.from_numpy(weights.make_images(100 + rank, B)).cuda()
+
+        def one_step(e, k):
+            enc = e.encode(images)
+            tr = e.trace(enc, caps, predictions=True)
+            r_feat, r_words, row2img = e.relevance(enc, tr, a.head)
+            maps = e.vgg.relevance(r_feat, row2img, out=buf("maps", k, B * T, 3, 224, 224))
+            cum = ops.cumsum_maps(maps, B, T, out=buf("cum", k, B * T, 3, 224, 224))
+            if k == 0:
+                state["chain_in"] = (r_feat, row2img)
+            return cum, r_words
+        workload = (f"BASELINE configs[2]: batch-{B} 224x224 images x {T}-word captions per GPU, VGG16 + AoA 8-head decoder, "
+                    f"LRP through multi-head attention (head {a.head}) + FC predictor, V={V}, random-init")
+    else:
+        from lrp_amd.explainers.aoa import AOAEngine
+        eng = AOAEngine(weights.make_aoa_state(seed=0, vocab_size=V, feat_dim=2048, with_encoder=False))
+        feats = torch.from_numpy(weights.make_bu_features(100 + rank, B)).cuda()
+
+        def one_step(e, k):
+            enc = e.encode(features=feats)
+            tr = e.trace(enc, caps, predictions=True)
+            r_feat, r_words, _ = e.relevance(enc, tr, a.head)
+            return r_feat, r_words
+        workload = (f"BASELINE configs[4]: batch-{B} x 36x2048 bottom-up region features x {T}-word captions per GPU, AoA-BU "
+                    f"decoder, LRP relevance back to the region features (head {a.head}), V={V}, random-init")
+    engines = [eng] + [eng.replica() for _ in range(n_pipe - 1)]     # shared weights, own trace / workspace buffers
     gathered = None
     if a.gather and world > 1 and rank == 0:
         gathered = [torch.empty(B * T, 3, 224, 224, device="cuda") for _ in range(world)]
 
-    state = {}
-
     step_no = [0]
 
-    def step(timed):
-        if n_pipe > 1:
-            k = step_no[0] % n_pipe
-            step_no[0] += 1
+    def step(end_events=None):
+        k = step_no[0] % n_pipe
+        step_no[0] += 1
+        if a.graph and a.config == 2 and not guided:
+            out = eng.explain_batch_graph(images, caps, accumulate=True)
+        elif n_pipe > 1:
             with torch.cuda.stream(streams[k]):
-                e = engines[k]
-                enc = e.encode(images)
-                tr = e.trace(enc, caps, predictions=False)
-                r_feat, r_words, row2img = e.relevance(enc, tr)
-                if "maps%d" % k not in state:
-                    state["maps%d" % k] = torch.empty(B * T, 3, 224, 224, device="cuda")
-                maps = e.vgg.relevance(r_feat, row2img, out=state["maps%d" % k])
-                if k == 0:
-                    state["chain_in"] = (r_feat, row2img)
-                if a.gather and world > 1:
-                    dist.gather(maps, gathered, dst=0)
-            return maps, r_words
-        if a.graph:
-            maps, r_words = eng.explain_batch_graph(images, caps)
-            if a.gather and world > 1:
-                dist.gather(maps.view(B * T, 3, 224, 224), gathered, dst=0)
-            return maps, r_words
-        enc = eng.encode(images)
-        tr = eng.trace(enc, caps, predictions=False)
-        r_feat, r_words, row2img = eng.relevance(enc, tr)
-        maps = eng.vgg.relevance(r_feat, row2img)
-        state["chain_in"] = (r_feat, row2img)
-        if a.gather and world > 1:
-            dist.gather(maps, gathered, dst=0)
-        return maps, r_words
+                out = one_step(engines[k], k)
+                if a.gather and world > 1 and has_vgg:
+                    dist.gather(out[0], gathered, dst=0)
+                if end_events is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    end_events.append(ev)
+            return out
+        else:
+            out = one_step(eng, 0)
+        if a.gather and world > 1 and has_vgg:
+            dist.gather(out[0].view(B * T, 3, 224, 224), gathered, dst=0)
+        if end_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            end_events.append(ev)
+        return out
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, events=None):
+        """n steps bracketed by barrier + synchronize on both sides; MAX over ranks"""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = step(events)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = tmax.item()
+        return dt, out
+
     for _ in range(a.warmup):
-        step(False)
+        step()
     barrier()
     if rank == 0:
         log("warm-up done, timing")
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        maps, _ = step(True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    events = [ev0]
+    dt, (maps, _) = timed(a.steps, events)
     ops.check_relevance(maps, finite=True, nonzero=True)      # the reference's asserts, outside the timed region
+    ends = [ev0.elapsed_time(e) for e in events[1:]]
+    gaps = sorted(b - c for b, c in zip(ends, [0.0] + ends[:-1]))
+    median_ms = gaps[len(gaps) // 2] if len(gaps) % 2 else 0.5 * (gaps[len(gaps) // 2 - 1] + gaps[len(gaps) // 2])
     if rank == 0:
-        log(f"timed region done: {dt / a.steps * 1e3:.1f} ms/step")
+        log(f"timed region done: {dt / a.steps * 1e3:.2f} ms/step (median step interval by HIP events {median_ms:.2f} ms)")
+    sustained = None
+    if a.sustain > 0:
+        n_sus = max(a.steps, int(math.ceil(a.sustain / (dt / a.steps))))
+        if dist is not None:           # the same count on every rank
+            t = torch.tensor([n_sus], device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n_sus = int(t.item())
+        dts, _ = timed(n_sus)
+        sustained = {"seconds": round(dts, 2), "steps": n_sus, "ms_per_step": round(dts / n_sus * 1e3, 3),
+                     "value": round(world * maps_per_gpu * n_sus / dts, 2), "unit": "maps/s"}
+        if rank == 0:
+            log(f"sustained: {n_sus} steps in {dts:.1f} s = {dts / n_sus * 1e3:.2f} ms/step")
 
     if rank == 0:
-        n_maps = world * B * T * a.steps
-        out = {"metric": "LRP relevance maps/sec (VGG16+gridTD, 224x224, 20-token caption)",
-               "value": round(n_maps / dt, 2), "unit": "maps/s", "n_gpus": world, "steps": a.steps,
+        n_maps = world * maps_per_gpu * a.steps
+        metric = {2: "LRP relevance maps/sec (VGG16+gridTD, 224x224, 20-token caption)",
+                  4: "LRP relevance maps/sec (VGG16+gridTD, 224x224, 20-token caption)" + ("; LRP + Guided-Backprop maps" if guided else ""),
+                  3: "LRP relevance maps/sec (VGG16+AoA, 224x224, 20-token caption)",
+                  5: "LRP relevance maps/sec (AoA bottom-up 36x2048 features, 20-token caption)"}[a.config]
+        out = {"metric": metric, "value": round(n_maps / dt, 2), "unit": "maps/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": MODE_DTYPE[mode], "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: batch-16 224x224 images x 20-word captions per GPU, "
-                                      "VGG16+gridTD, LRP alpha1beta0 (conv) + epsilon (decoder), V=9586, random-init",
-                          "images_per_gpu": B, "words": T, "vocab": V, "maps_per_step": world * B * T,
+               "scaling": "weak", "vs_baseline": None, "dtype": MODE_DTYPE[mode] if has_vgg else "f32", "data": "synthetic",
+               "config": {"workload": workload, "images_per_gpu": B, "words": T, "vocab": V,
+                          "maps_per_step": world * maps_per_gpu,
+                          "unit_of_work": "trace (VGG16 forward + decoder, predictions kept) + decoder relevance + CNN relevance + "
+                                          "running sums of the maps" if has_vgg else "decoder trace (predictions kept) + decoder relevance",
                           "sharding": f"images x{world}, no data-path collective" + (" + gather" if a.gather else ""),
-                          "batches_in_flight": n_pipe}}
-        if world == 1:
-            # (1) the whole VGG16 relevance chain (12 conv launches + first-layer kernel + 4 pool kernels), HIP events
-            if "chain_in" not in state:
-                enc = eng.encode(images)
-                state["chain_in"] = eng.relevance(enc, eng.trace(enc, caps, predictions=False))[::2]
-            r_feat, row2img = state["chain_in"]
-            ms = []
-            for _ in range(max(3, a.steps)):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                eng.vgg.relevance(r_feat, row2img, out=maps.view(B * T, 3, 224, 224))
-                e1.record()
-                e1.synchronize()
-                ms.append(e0.elapsed_time(e1))
-            chain_ms = sum(ms) / len(ms)
-            # (2) roofline of the dominant kernel (default mode: the 28x28 relevance conv kernel, 3 launches per pass: conv4_3,
-            # conv4_2 with 512 and conv4_1 with 256 output channels), HIP events recorded by the library on the launch
-            # stream around every conv launch of the same chain on the same inputs
-            import ctypes as C
-            lib = _lib.load()
-            per_layer = [0.0] * 17
-            reps = max(3, a.steps)
-            lib.lrpx_vgg16_layer_timing(1, None)
-            buf = (C.c_float * 17)()
-            for _ in range(reps):
-                eng.vgg.relevance(r_feat, row2img, out=maps.view(B * T, 3, 224, 224))
-                lib.lrpx_vgg16_layer_timing(-1, buf)
-                per_layer = [p + float(v) for p, v in zip(per_layer, buf)]
-            lib.lrpx_vgg16_layer_timing(0, None)
-            per_layer = [p / reps for p in per_layer]
-            # launches of that kernel NAME per pass: conv3_1 (128 output channels) and conv3_2 (256); in mode 2 conv3_3
-            # is the pooled-input variant of the kernel (own name in rocprof), in modes 0/1 it is the same kernel
-            # mode 3: the kernel with the largest total time is the 28x28 one (conv4_1 with 256 output channels, conv4_2,
-            # conv4_3 behind the unpool scatter): same flop per full launch as the 56x56 layers (2*9*512*512*28*28)
-            dom_layers, dom_w = ([10, 11, 12], [0.5, 1.0, 1.0]) if mode == 3 else (([6, 7], [0.5, 1.0]) if mode == 2 else ([6, 7, 8], [0.5, 1.0, 1.0]))
-            dom_desc = ("conv4_1/conv4_2/conv4_3 on 28x28 maps" if mode == 3 else
-                        ("conv3_1/conv3_2 on 56x56 maps" if mode == 2 else "conv3_1/conv3_2/conv3_3 on 56x56 maps"))
-            dom_ms = sum(per_layer[l] for l in dom_layers) / len(dom_layers)          # average launch of that kernel
-            flop = DOM_FLOP_PER_MAP * B * T * sum(dom_w) / len(dom_w)                 # average algorithmic flop / launch
-            alg = flop / dom_ms / 1e9                                        # TFLOP/s, fp32-equivalent
-            exe = PRODUCTS[mode] * alg
-            peak = PEAK_FP32_MFMA_TF if mode == 0 else PEAK_16BIT_MFMA_TF
-            out["roofline"] = {
-                "bound": "mfma", "kernel": MODE_KERNEL[mode] + f" (relevance step of {dom_desc}, {B * T} maps per launch, {len(dom_layers)} launches per step)", "achieved": round(exe, 1), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(exe / peak, 4), "mfma_dtype": MODE_NAME[mode],
-                "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
-                "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,
-                "traffic": round(DOM_TRAFFIC_BYTES_PER_MAP[mode] * B * T),
-                "accounting": ("executed matrix flop = algorithmic x products; mode 3 executes 1 fp16 + 2 fp8 products per fp32 "
-                               "product and an fp8 flop counts 1/2 (fp8 dense peak = 2 x fp16 peak), so achieved/peak = matrix "
-                               "time at peak / measured time; the same layer with 3 fp16 products (--conv-mode 2) reaches "
-                               "frac 0.55-0.57 on 1.5x the matrix work and is 1.19x slower") if mode == 3 else
-                              "executed matrix flop = algorithmic x products",
-                "chain": {"ms_per_step": round(chain_ms, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * B * T,
-                          "algorithmic_tflops": round(GFLOP_PER_MAP * B * T / chain_ms, 1),
-                          "conv_ms_by_layer": {str(l): round(v, 3) for l, v in enumerate(per_layer) if v > 0}}}
-            if not a.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(V, T, sorted({round(i * (T - 1) / 9) for i in range(10)}))   # 10 words, mean index (T-1)/2
+                          "batches_in_flight": n_pipe},
+               "median_ms": round(median_ms, 3), "hip_event_ms_per_step": round(ends[-1] / a.steps, 3), "sustained": sustained}
+        if world == 1 and has_vgg:
+            out["roofline"] = roofline(a, lib, eng, state, maps, B, T, mode)
+            if a.config == 2 and not guided and not a.no_modes and not a.graph:
+                out["roofline"]["modes"] = mode_sweep(lib, engines, streams, one_step, state, B, T, mode)
+        elif world == 1:
+            # config 5: no CNN stage; HBM-bound projector / v_proj rules.  Algorithmic bytes per map (SURVEY §8(d)): read F,
+            # write R_feat, read the projected features: 3 x 36 x 2048 x 4 B = 0.9 MB (weights amortised over the batch)
+            byts = 3.0 * 36 * 2048 * 4 * B * T
+            gbs = byts / (dt / a.steps) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "whole step (decoder relevance back to 36x2048 region features)",
+                               "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                               "traffic": None}
+        if world == 1 and a.config == 2 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(V, T, sorted({round(i * (T - 1) / 9) for i in range(10)}))   # 10 words, mean index (T-1)/2
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def chain_ms(eng, r_feat, row2img, out, reps):
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.vgg.relevance(r_feat, row2img, out=out)
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return sum(ms) / len(ms)
+
+
+def roofline(a, lib, eng, state, maps, B, T, mode):
+    import ctypes as C
+    torch.cuda.synchronize()
+    r_feat, row2img = state["chain_in"]
+    out = state["maps0"]
+    reps = max(3, min(a.steps, 10))
+    # (1) the whole VGG16 relevance chain (12 conv launches + first-layer kernel + unpool scatter), HIP events
+    c_ms = chain_ms(eng, r_feat, row2img, out, reps)
+    # (2) roofline of the dominant kernel (default mode: the 28x28 relevance conv kernel, 3 launches per pass: conv4_3,
+    # conv4_2 with 512 and conv4_1 with 256 output channels), HIP events recorded by the library on the launch
+    # stream around every conv launch of the same chain on the same inputs
+    per_layer = [0.0] * 17
+    lib.lrpx_vgg16_layer_timing(1, None)
+    buf = (C.c_float * 17)()
+    for _ in range(reps):
+        eng.vgg.relevance(r_feat, row2img, out=out)
+        lib.lrpx_vgg16_layer_timing(-1, buf)
+        per_layer = [p + float(v) for p, v in zip(per_layer, buf)]
+    lib.lrpx_vgg16_layer_timing(0, None)
+    per_layer = [p / reps for p in per_layer]
+    # launches of that kernel NAME per pass: mode 3: the kernel with the largest total time is the 28x28 one (conv4_1 with
+    # 256 output channels, conv4_2, conv4_3 behind the unpool scatter): same flop per full launch as the 56x56 layers
+    # (2*9*512*512*28*28); mode 2: conv3_1 / conv3_2 (conv3_3 is the pooled-input variant, own name in rocprof)
+    dom_layers, dom_w = ([10, 11, 12], [0.5, 1.0, 1.0]) if mode == 3 else (([6, 7], [0.5, 1.0]) if mode == 2 else ([6, 7, 8], [0.5, 1.0, 1.0]))
+    dom_desc = ("conv4_1/conv4_2/conv4_3 on 28x28 maps" if mode == 3 else
+                ("conv3_1/conv3_2 on 56x56 maps" if mode == 2 else "conv3_1/conv3_2/conv3_3 on 56x56 maps"))
+    dom_ms = sum(per_layer[l] for l in dom_layers) / len(dom_layers)          # average launch of that kernel
+    flop = DOM_FLOP_PER_MAP * B * T * sum(dom_w) / len(dom_w)                 # average algorithmic flop / launch
+    alg = flop / dom_ms / 1e9                                                 # TFLOP/s, fp32-equivalent
+    exe = PRODUCTS[mode] * alg
+    peak = PEAK_FP32_MFMA_TF if mode == 0 else PEAK_16BIT_MFMA_TF
+    traffic, src = read_traffic(mode, B * T)
+    return {
+        "bound": "mfma", "kernel": MODE_KERNEL[mode] + f" (relevance step of {dom_desc}, {B * T} maps per launch, {len(dom_layers)} launches per step)",
+        "achieved": round(exe, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(exe / peak, 4),
+        "frac_algorithmic": round(alg / peak, 4), "mfma_dtype": MODE_NAME[mode],
+        "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
+        "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,
+        "traffic": traffic, "traffic_source": src,
+        "accounting": ("executed matrix flop = algorithmic x products; mode 3 executes 1 fp16 + 2 fp8 products per fp32 "
+                       "product and an fp8 flop counts 1/2 (fp8 dense peak = 2 x fp16 peak), so achieved/peak = matrix "
+                       "time at peak / measured time; frac_algorithmic = fp32-equivalent flop against the same peak") if mode == 3 else
+                      "executed matrix flop = algorithmic x products; frac_algorithmic = fp32-equivalent flop against the same peak",
+        "chain": {"ms_per_step": round(c_ms, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * B * T,
+                  "algorithmic_tflops": round(GFLOP_PER_MAP * B * T / c_ms, 1),
+                  "conv_ms_by_layer": {str(l): round(v, 3) for l, v in enumerate(per_layer) if v > 0}}}
+
+
+def mode_sweep(lib, engines, streams, one_step, state, B, T, mode_now):
+    """The same step (and the chain alone) in every matrix-core mode, measured in this process: 2 warm-up + 6 timed steps
+    with the batches in flight of the headline; chain = HIP events around lrpx_vgg16_relevance, 3 repetitions."""
+    res = {}
+    n_pipe = len(engines)
+    for m in (0, 1, 2, 3):
+        torch.cuda.synchronize()
+        lib.lrpx_set_conv_mode(m)
+
+        def run(n):
+            for i in range(n):
+                k = i % n_pipe
+                if streams[k] is None:
+                    one_step(engines[k], k)
+                else:
+                    with torch.cuda.stream(streams[k]):
+                        one_step(engines[k], k)
+        run(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(6)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 6
+        r_feat, row2img = state["chain_in"]
+        c_ms = chain_ms(engines[0], r_feat, row2img, state["maps0"], 3)
+        res[str(m)] = {"maps_per_s": round(B * T / dt, 1), "ms_per_step": round(dt * 1e3, 3), "chain_ms": round(c_ms, 3),
+                       "dtype": MODE_DTYPE[m]}
+        log(f"mode {m}: {B * T / dt:.0f} maps/s, chain {c_ms:.2f} ms")
+    torch.cuda.synchronize()
+    lib.lrpx_set_conv_mode(mode_now)
+    return res
 
 
 if __name__ == "__main__":

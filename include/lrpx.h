@@ -401,6 +401,30 @@ int lrpx_vgg16_gradient(const void* packed, const void* trace, int n_img, const 
 int lrpx_gradcam(const float* feats, const float* grads, const int32_t* map2img, float* cam, int rows, int P, int C,
                  void* stream);
 
+/* ---- rules of the layers the VGG16 path never reaches (ResNet encoders), csrc/lrpx_rules.hip ---- */
+/* Linear.propagate_relevance, epsilon rule (LRPtools/lrp_modules.py:9-37).  x [n_rows][n_in] is the layer's SAVED input
+ * and is mutated in place like the reference's (:14): exact zeros become RELEVANCE_RECT = -1e-6.  Z = x W^T; with
+ * bias == NULL (ignore_bias, the preset of lrp_wrapper.py:7-12) Z += 0.01 sign(Z), exact zeros -> 0.01; otherwise
+ * Z += bias (:20-21).  r_in = x * ((r_out / Z) W).  w [n_out][n_in] as nn.Linear stores it; s_ws: workspace of
+ * n_rows * n_out floats (S = r_out / Z).  Any sizes. */
+int lrpx_linear_eps_rule(float* x, const float* w, const float* bias, const float* r_out, float* s_ws, float* r_in,
+                         int n_rows, int n_in, int n_out, void* stream);
+/* BatchNorm2d / BatchNorm1d.propagate_relevance, method != 'identity' (LRPtools/lrp_modules.py:197-246):
+ * r_in = safe_divide(|x w|, |x w| + |b|) * r_out with w = gamma / sqrt(var + eps), b = beta - mean gamma / sqrt(var + eps).
+ * The result has n_outer * channels * inner elements, element e in channel (e / inner) % channels.  broadcast_x = 0: x and
+ * r_out have the same shape (BatchNorm2d on (N,C,H,W): n_outer = N, inner = H*W).  broadcast_x = 1 (n_outer = 1): x and
+ * r_out hold `inner` elements and are indexed by e % inner - what the reference's `[:, None, None]` indexing makes of a
+ * (N,C) or (1,C,L) input of BatchNorm1d (:236-238): a (C, N, C) / (C, C, L) result. */
+int lrpx_batchnorm_rule(const float* x, const float* r_out, const float* gamma, const float* beta, const float* mean,
+                        const float* var, float eps, float* r_in, long n_outer, int channels, long inner, int broadcast_x,
+                        void* stream);
+/* Add.propagate_relevance (LRPtools/lrp_modules.py:256-280): r_k = r_out x_k / (x1 + x2 + 0.01 sign(x1 + x2)), NaN -> 0,
+ * plus r_out / 2 each where x1 + x2 == 0.  Non-finite results (x1 == -x2 != 0) are left for lrpx_check, as the reference's
+ * asserts (:276-279) catch them. */
+int lrpx_add_rule(const float* x1, const float* x2, const float* r_out, float* r1, float* r2, long n, void* stream);
+/* max |a - b| into one device float (Dropout.propagate_relevance's check, LRPtools/lrp_modules.py:251; NaN counts as inf) */
+int lrpx_max_abs_diff(const float* a, const float* b, long n, float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

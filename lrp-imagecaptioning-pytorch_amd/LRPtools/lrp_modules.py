@@ -6,9 +6,9 @@ lrp_params)` returns a tuple with the arity of `relevance_input` (:157-170).  `m
 layer input, as the reference's `save_input_hook` leaves it (lrp_wrapper.py:24-25).  Tensors are NCHW on the
 device, as in the reference; layouts are converted at this boundary.
 
-Built for the layers VGG16 exercises (Conv2d 3x3/pad 1, MaxPool2d(2,2), ReLU) on square maps of 224/112/56/28/14
-pixels; other shapes raise ValueError.  Linear/BatchNorm/Add/Flatten/Dropout rules (ResNet encoders only) are not
-part of the hot path."""
+Conv2d 3x3/pad 1, MaxPool2d(2,2) and ReLU are the layers VGG16 exercises (square maps of 224/112/56/28/14 pixels;
+other shapes raise ValueError).  Linear / BatchNorm2d / BatchNorm1d / Dropout / Add / Flatten (only
+reached with the reference's ResNet encoders) are HBM-bound streaming kernels (csrc/lrpx_rules.hip), any shape."""
 import torch
 import torch.nn as nn
 
@@ -122,10 +122,149 @@ class Pool2d:
         return (R,)
 
 
+class resAdd(nn.Module):
+    """The reference's explicit residual-sum module (models/resnet.py:32-37; imported as `resAdd` at lrp_modules.py:5)."""
+
+    def forward(self, x, y):
+        return x + y
+
+
+class resFlatten(nn.Module):
+    """models/resnet.py:24-29 (imported as `resFlatten` at lrp_modules.py:6)"""
+
+    def forward(self, x):
+        return x.view(x.size(0), -1)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class Linear:
+    """Epsilon rule (lrp_modules.py:9-37): the saved input's exact zeros become -1e-6 IN PLACE (:14, quirk h);
+    Z = x W^T + 0.01 sign(Z) (exact zeros -> 0.01), or + bias when `ignore_bias` is off; R = x * ((R_out / Z) W)."""
+
+    def propagate_relevance(self, module, relevance_input, relevance_output, lrp_method, lrp_params=None):
+        ignore_bias = (lrp_params or {}).get("ignore_bias", True)
+        input_ = module.input[0]
+        _require(input_.dim() == 2 and input_.shape[1] == module.in_features, "lrpx Linear rule: (N, in_features) input")
+        x = input_ if (input_.dtype == torch.float32 and input_.is_contiguous()) else _f32c(input_)
+        r_out = _f32c(relevance_output[0])
+        n, i = x.shape
+        o = module.out_features
+        _require(r_out.shape == (n, o), "relevance_output shape mismatch")
+        w = _f32c(module.weight)
+        b = None if ignore_bias else _f32c(module.bias)
+        s_ws = torch.empty(n, o, device=x.device)
+        R = torch.empty(n, i, device=x.device)
+        check(_lib.load().lrpx_linear_eps_rule(ptr(x.detach()), ptr(w), ptr(b), ptr(r_out), ptr(s_ws), ptr(R), n, i, o,
+                                               stream_ptr()))
+        if x is not input_:                                 # the mutation must land on the saved input (:14)
+            with torch.no_grad():
+                input_.copy_(x)
+        ops.check_relevance(R)                              # :26-27
+        if relevance_input is not None and len(relevance_input) == 3:
+            return relevance_input[0], R, relevance_input[2]
+        if relevance_input is not None and len(relevance_input) == 2:
+            return R, relevance_input[1]
+        return (R,)
+
+
+class _BatchNormRule:
+    """R = safe_divide(|x w|, |x w| + |b|) * R_out with the folded scale / shift of the running statistics
+    (lrp_modules.py:197-246); 'identity' passes R_out through.  Returns (R, relevance_input[1], relevance_input[2])."""
+
+    def _rule(self, module, relevance_output):
+        x = _f32c(module.input[0])
+        r_out = _f32c(relevance_output[0])
+        c = module.num_features
+        args = [_f32c(t) for t in (module.weight, module.bias, module.running_mean, module.running_var)]
+        lib = _lib.load()
+        if x.dim() == 4:                                    # (N,C,H,W) against w[:, None, None]: the per-channel rule
+            _require(x.shape[1] == c and r_out.shape == x.shape, "lrpx BatchNorm rule: (N,C,H,W) input and relevance")
+            R = torch.empty_like(x)
+            check(lib.lrpx_batchnorm_rule(ptr(x), ptr(r_out), *[ptr(a) for a in args], float(module.eps), ptr(R),
+                                          x.shape[0], c, x.shape[2] * x.shape[3], 0, stream_ptr()))
+            return R
+        # the reference indexes w[:, None, None] in BatchNorm1d too (:236-238): a (N,C) input broadcasts to (C,N,C), a
+        # (1,C,L) input to (C,C,L); any other shape fails to broadcast there as well
+        if x.dim() == 2:
+            _require(x.shape[1] in (c, 1) or c == 1, "lrpx BatchNorm1d rule: shapes do not broadcast")
+            shape = (c,) + tuple(x.shape)
+        elif x.dim() == 3 and x.shape[0] == 1:
+            shape = (c,) + tuple(x.shape[1:])
+        else:
+            raise RuntimeError("The size of tensor a ({}) must match the size of tensor b ({}) at non-singleton "
+                               "dimension 0".format(x.shape[0], c))
+        _require(r_out.shape == x.shape, "relevance_output shape mismatch")
+        R = torch.empty(shape, device=x.device, dtype=torch.float32)
+        check(lib.lrpx_batchnorm_rule(ptr(x), ptr(r_out), *[ptr(a) for a in args], float(module.eps), ptr(R), 1, c,
+                                      x.numel(), 1, stream_ptr()))
+        return R
+
+    def propagate_relevance(self, module, relevance_input, relevance_output, lrp_method, lrp_params=None):
+        R = relevance_output[0] if lrp_method == 'identity' else self._rule(module, relevance_output)
+        ops.check_relevance(R, finite=True, nonzero=True)   # :217-219 incl. `assert R.sum() != 0`
+        return R, relevance_input[1], relevance_input[2]
+
+
+class BatchNorm2d(_BatchNormRule):
+    pass
+
+
+class BatchNorm1d(_BatchNormRule):
+    pass
+
+
+class Dropout:
+    """(lrp_modules.py:248-254): relevance passes unchanged; asserts |R_out - R_in| < 1e-7 like the reference."""
+
+    def propagate_relevance(self, module, relevance_input, relevance_output, lrp_method, lrp_params=None):
+        a, b = _f32c(relevance_output[0]), _f32c(relevance_input[0])
+        assert a.shape == b.shape
+        m = torch.empty(1, device=a.device, dtype=torch.float32)
+        check(_lib.load().lrpx_max_abs_diff(ptr(a), ptr(b), a.numel(), ptr(m), stream_ptr()))
+        assert m.item() < 1e-7
+        return relevance_input
+
+
+class Add:
+    """`Add` (lrp_modules.py:256-280): proportional split between the two summands; both get R/2 where the sum is zero."""
+
+    def propagate_relevance(self, module, relevance_input, relevance_output, lrp_method, lrp_params=None):
+        x1, x2 = _f32c(module.input[0]), _f32c(module.input[1])
+        r_out = _f32c(relevance_output[0])
+        _require(x1.shape == x2.shape == r_out.shape, "lrpx Add rule: the summands and the relevance share one shape")
+        R1, R2 = torch.empty_like(x1), torch.empty_like(x1)
+        check(_lib.load().lrpx_add_rule(ptr(x1), ptr(x2), ptr(r_out), ptr(R1), ptr(R2), x1.numel(), stream_ptr()))
+        ops.check_relevance(R1)                             # :276-279
+        ops.check_relevance(R2)
+        return R1, R2
+
+
+class Flatten:
+    """`Flatten` (lrp_modules.py:282-291): the relevance in the shape of the layer input."""
+
+    def propagate_relevance(self, module, relevance_input, relevance_output, lrp_method, lrp_params=None):
+        r_out = _f32c(relevance_output[0])
+        R = torch.empty(module.input[0].size(), device=r_out.device, dtype=torch.float32)
+        check(_lib.load().lrpx_scale(ptr(r_out), ptr(R), r_out.numel(), 1.0, stream_ptr()))
+        ops.check_relevance(R)
+        return (R,)
+
+
+_RULES = {nn.ReLU: ReLU, nn.Conv2d: Conv2d, nn.MaxPool2d: Pool2d, nn.Linear: Linear, nn.BatchNorm2d: BatchNorm2d,
+          nn.BatchNorm1d: BatchNorm1d, nn.Dropout: Dropout, nn.Dropout2d: Dropout, resAdd: Add, resFlatten: Flatten}
+# the reference's own `models.resnet.Add` / `Flatten` classes (a user's ResNet is built from those) dispatch by name
+_RULES_BY_NAME = {"Add": Add, "Flatten": Flatten}
+
+
 def get_lrp_module(module):
-    """type(module) -> rule object; ValueError for leaves the path does not know (lrp_modules.py:321-341)."""
-    try:
-        cls = {nn.ReLU: ReLU, nn.Conv2d: Conv2d, nn.MaxPool2d: Pool2d}[type(module)]
-    except KeyError:
+    """type(module) -> rule object; ValueError for leaves the path does not know (lrp_modules.py:321-341).
+    (`nn.AvgPool2d` is in the reference's table but no encoder of the reference contains one: not built -> ValueError.)"""
+    cls = _RULES.get(type(module))
+    if cls is None and type(module).__module__.endswith("resnet"):
+        cls = _RULES_BY_NAME.get(type(module).__name__)
+    if cls is None:
         raise ValueError("Layer type {} not known.".format(type(module)))
     return cls()

@@ -145,6 +145,10 @@ SIGNATURES = {
     "lrpx_vgg16_trace_derive": (_i, [_f, _i, _f]),
     "lrpx_vgg16_trace_layout": (_i, [_i, C.POINTER(_sz), C.POINTER(_sz)]),
     "lrpx_vgg16_trace_features": (_f, [_f, _i]),
+    "lrpx_linear_eps_rule": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
+    "lrpx_batchnorm_rule": (_i, [_f, _f, _f, _f, _f, _f, C.c_float, _f, _l, _i, _l, _i, _f]),
+    "lrpx_add_rule": (_i, [_f, _f, _f, _f, _f, _l, _f]),
+    "lrpx_max_abs_diff": (_i, [_f, _f, _l, _f, _f]),
 }
 
 _lib = None

@@ -340,8 +340,8 @@ class AOAEngine:
         if self.vgg is not None:
             r.vgg = self.vgg.replica()
         r._idx_cache = {}
-        r.__dict__.pop("_replicas", None)
-        r.__dict__.pop("_streams", None)
+        for k in ("_graphs", "_replicas", "_streams"):
+            r.__dict__.pop(k, None)
         return r
 
     def explain_stream(self, batches, head_idx, depth=3, accumulate=False):
@@ -366,12 +366,12 @@ class AOAEngine:
                 ev.record(st)
             for t in out:
                 t.record_stream(torch.cuda.current_stream(self.device))
-            pending.append((out, ev))
+            pending.append((out, ev, images, captions))      # inputs stay alive until the side stream has read them
             if len(pending) >= depth:
-                o, e = pending.pop(0)
+                o, e, _, _ = pending.pop(0)
                 e.synchronize()
                 yield o
-        for o, e in pending:
+        for o, e, _, _ in pending:
             e.synchronize()
             yield o
 

@@ -439,8 +439,8 @@ class GridTDEngine:
         r = copy.copy(self)
         r.vgg = self.vgg.replica()
         r._idx_cache = {}
-        if hasattr(r, "_graphs"):
-            del r._graphs
+        for k in ("_graphs", "_replicas", "_streams"):     # a replica never shares another engine's streams / buffer sets
+            r.__dict__.pop(k, None)
         return r
 
     def explain_stream(self, batches, depth=3, accumulate=False):
@@ -466,12 +466,15 @@ class GridTDEngine:
                 ev.record(st)
             for t in out:
                 t.record_stream(torch.cuda.current_stream(self.device))
-            pending.append((out, ev))
+            # the side stream reads the caller's tensors (`.to()` copies nothing when they already are device fp32 / int64):
+            # keep them alive until the batch's event has completed, or the caching allocator could hand their memory to
+            # the caller's next batch while this one is still queued
+            pending.append((out, ev, images, captions))
             if len(pending) >= depth:
-                o, e = pending.pop(0)
+                o, e, _, _ = pending.pop(0)
                 e.synchronize()
                 yield o
-        for o, e in pending:
+        for o, e, _, _ in pending:
             e.synchronize()
             yield o
 

@@ -125,8 +125,10 @@ def divide_stab(r, z, map2img, stab):
     return s
 
 
-def cumsum_maps(maps, n_img, t_per_img):
-    out = torch.empty_like(maps)
+def cumsum_maps(maps, n_img, t_per_img, out=None):
+    """running sums over the words of each image: what `explain_caption` returns (lrp_wrapper.py:64-82 quirk)"""
+    if out is None:
+        out = torch.empty_like(maps)
     check(_lib.load().lrpx_cumsum_maps(ptr(maps), ptr(out), n_img, t_per_img, maps[0].numel(), stream_ptr()))
     return out
 

@@ -87,6 +87,50 @@ def maxpool_rule(x, r_out):
 
 
 # ----------------------------------------------------------------------------------------------
+# rules of the layers VGG16 never reaches (ResNet encoders)
+# ----------------------------------------------------------------------------------------------
+RELEVANCE_RECT = -1e-6   # LRPtools/utils.py:14
+
+
+def linear_eps_rule(x, w, r_out, bias=None):
+    """LRPtools/lrp_modules.py:9-37 `Linear.propagate_relevance` (epsilon rule): exact-zero inputs are nudged to -1e-6
+    IN PLACE on the saved input (:14, quirk h); Z = x W^T; ignore_bias (the preset, lrp_wrapper.py:7-12): Z += eps sign Z,
+    exact zeros -> eps; otherwise Z += bias; R = x * ((R_out / Z) W).  Returns (R, x_after)."""
+    x = x.clone()
+    x[x == 0] = RELEVANCE_RECT
+    z = x @ w.t()
+    if bias is None:
+        z = z + EPSILON * z.sign()
+        z = torch.where(z == 0, torch.full_like(z, EPSILON), z)
+    else:
+        z = z + bias
+    return x * ((r_out / z) @ w), x
+
+
+def batchnorm_rule(x, r_out, gamma, beta, mean, var, eps):
+    """LRPtools/lrp_modules.py:197-246 `BatchNorm2d` / `BatchNorm1d` (method != 'identity'):
+    w = gamma / sqrt(var + eps), b = beta - mean gamma / sqrt(var + eps), both indexed [:, None, None];
+    R = safe_divide(|x w|, |x w| + |b|) * R_out.  The indexing is the 2-d one in BOTH classes, so a (N,C) input of
+    BatchNorm1d broadcasts to a (C,N,C) result: torch's broadcasting reproduces it here as it does in the reference."""
+    w = (gamma / torch.sqrt(var + eps))[:, None, None]
+    b = (beta - (mean * gamma) / torch.sqrt(var + eps))[:, None, None]
+    xw = x * w
+    return safe_divide(xw.abs(), xw.abs() + b.abs()) * r_out
+
+
+def add_rule(x1, x2, r_out):
+    """LRPtools/lrp_modules.py:256-280 `Add`: proportional split R_k = R x_k / (x1 + x2 + eps sign(x1 + x2)); NaNs (0/0) -> 0;
+    entries whose sum is exactly zero additionally get R/2 each."""
+    out = x1 + x2
+    half = torch.zeros_like(out).masked_fill_(out == 0, 0.5)
+    out = out + EPSILON * out.sign()
+    r1, r2 = r_out * x1 / out, r_out * x2 / out
+    r1[r1 != r1] = 0
+    r2[r2 != r2] = 0
+    return r1 + r_out * half, r2 + r_out * half
+
+
+# ----------------------------------------------------------------------------------------------
 # VGG16 encoder: forward trace and LRP (lrp_wrapper.compute_lrp, LRPtools/lrp_wrapper.py:63-87)
 # ----------------------------------------------------------------------------------------------
 def vgg_layers():

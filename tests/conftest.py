@@ -19,6 +19,19 @@ def golden_dir():
     return GOLDEN
 
 
+_TIE_STATS = []
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """observed end-to-end deviations (assert_close_modulo_pool_ties) of this session -> gpurun_out/pool_tie_stats.json"""
+    if _TIE_STATS:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "pool_tie_stats.json"), "w") as f:
+            json.dump(_TIE_STATS, f, indent=0)
+
+
 def rel_err(a, b):
     """max|a-b| / max|b|  (the parity metric of SURVEY.md §8(d))"""
     import torch
@@ -46,6 +59,8 @@ def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=5e-2, l2=2e-3, what
     got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
     scale = want.abs().max().clamp_min(1e-300)
     d = (got - want).abs() / scale
+    _TIE_STATS.append({"what": str(what), "frac_gt_1e-4": (d > 1e-4).double().mean().item(), "max": d.max().item(),
+                       "rel_l2": ((got - want).norm() / want.norm().clamp_min(1e-300)).item(), "cos": cosine(got, want)})
     assert cosine(got, want) > cos, (what, cosine(got, want))
     assert ((got - want).norm() / want.norm().clamp_min(1e-300)).item() < l2, (what, "rel L2")
     assert (d > 1e-4).double().mean().item() < frac, (what, (d > 1e-4).double().mean().item())

@@ -133,6 +133,9 @@ def gen_layers(out):
     rpin = lrp_modules.Pool2d().propagate_relevance(pool, None, (rp,), 'alpha_beta', params)[0]
     g["pool_x"], g["pool_rout"], g["pool_rin"] = xp.numpy(), rp.numpy(), rpin.detach().numpy()
     lin = nn.Linear(10, 7)
+    rs_lin = np.random.RandomState(124)      # own stream: the draws below keep their values
+    lin.weight.data = torch.from_numpy(rs_lin.uniform(-0.3, 0.3, (7, 10)).astype(np.float32))
+    lin.bias.data = torch.from_numpy(rs_lin.uniform(-0.3, 0.3, (7,)).astype(np.float32))
     xl = torch.from_numpy(rs.standard_normal((3, 10)).astype(np.float32))
     xl[1, 4] = 0.0
     lin.input = (xl.clone(),)
@@ -514,6 +517,206 @@ def gen_aoa_sample_lrp(out, weights, V=11027, seed=0, max_len=8, batch=2):
     print("aoa_sample_lrp tokens:", seq.tolist(), seq2.tolist(), "stop", stop_id, "end2", end2)
 
 
+def stats4(x):
+    x = x.double()
+    return np.array([x.sum().item(), x.abs().max().item(), x.pow(2).sum().sqrt().item(), x.abs().sum().item()], np.float64)
+
+
+def gen_t20(out, weights, T=20, seed=0, n_img=2):
+    """Decoder relevance at the HEADLINE caption length (T=20; BASELINE configs 2, 3 and 5), where the lock-step
+    row machinery of the engines runs its full depth: `explain_caption_wordt` (models/gridTDmodel.py:1014-1135,
+    models/aoamodel.py:1064-1156) of the reference for every word of `n_img` images per model.  Stored per (image,
+    word): statistics of r_feat [sum, absmax, L2, L1], a channel subsample ((t % s)::s, s = 32 of 512 / 64 of 2048
+    channels), the full r_words; full r_feat for two rows per model; for gridTD image 0 also the pixel maps
+    (running sums, every 8th pixel) of the whole `explain_caption`."""
+    import models.gridTDmodel as gtd
+    import models.aoamodel as aoa
+    g = dict(seed=np.int64(seed), T=np.int64(T), n_img=np.int64(n_img), img_seed=np.int64(50))
+    imgs = weights.make_images(50, n_img)
+    # ---------------- gridTD, V = 9586
+    V = 9586
+    sd = weights.make_gridtd_state(seed=seed, vocab_size=V)
+    model = gtd.GridTDModel(512, 512, V, 'vgg16')
+    model.load_state_dict(to_torch_sd(sd))
+    wm = weights.make_word_map(V)
+    caps = weights.make_captions(51, n_img, T, V)
+    g["grid_V"], g["grid_caption"] = np.int64(V), caps
+    for b in range(n_img):
+        with tempfile.TemporaryDirectory() as tmp:
+            ex = gtd.ExplainGridTDAttention(make_args(tmp), wm, model=model)
+            _patch_explainer(ex, imgs[b:b + 1], caps[b])
+            if b == 0:
+                feats = []
+                orig = ex.explain_caption_wordt
+
+                def wrapped(t, _orig=orig, _feats=feats):
+                    rf, rw = _orig(t)
+                    _feats.append(rf.clone())
+                    return rf, rw
+                ex.explain_caption_wordt = wrapped
+                maps, rws = ex.explain_caption("synthetic.jpg")
+                for t in range(T):
+                    g[f"grid0_map_stats_{t}"] = stats4(maps[t])
+                    g[f"grid0_map_sub8_{t}"] = maps[t][..., ::8, ::8].contiguous().numpy()
+            else:
+                ex.get_hidden_parameters("synthetic.jpg")
+                feats, rws = [], []
+                for t in range(T):
+                    with torch.no_grad():
+                        rf, rw = ex.explain_caption_wordt(t)
+                    feats.append(rf.clone()); rws.append(rw.clone())
+        for t in range(T):
+            rf = feats[t].detach()[0]                                   # (512,14,14)
+            g[f"grid{b}_r_feat_stats_{t}"] = stats4(rf)
+            g[f"grid{b}_r_feat_sub_{t}"] = rf[(t % 32)::32].contiguous().numpy()
+            g[f"grid{b}_r_words_{t}"] = rws[t].detach().numpy()
+        g[f"grid{b}_r_feat_full_{T - 1 - 9 * b}"] = feats[T - 1 - 9 * b].detach()[0].numpy()
+        print("t20 gridTD image", b, "done", flush=True)
+    # ---------------- AoA, V = 11027, head 0 for both images and head 3 for image 1
+    V = 11027
+    sd = weights.make_aoa_state(seed=seed, vocab_size=V)
+    model = aoa.AOAModel(512, 512, 8, V, 'vgg16')
+    model.load_state_dict(to_torch_sd(sd))
+    wm = weights.make_word_map(V)
+    caps = weights.make_captions(52, n_img, T, V)
+    g["aoa_V"], g["aoa_caption"] = np.int64(V), caps
+    for b in range(n_img):
+        with tempfile.TemporaryDirectory() as tmp:
+            ex = aoa.ExplainAOAAttention(make_args(tmp), wm, model=model)
+            _patch_explainer(ex, imgs[b:b + 1], caps[b])
+            ex.get_hidden_parameters("synthetic.jpg")
+            for hd in ((0,) if b == 0 else (0, 3)):
+                for t in range(T):
+                    with torch.no_grad():
+                        rf, rw = ex.explain_caption_wordt(t, hd)
+                    rf = rf.detach()[0]
+                    g[f"aoa{b}_h{hd}_r_feat_stats_{t}"] = stats4(rf)
+                    g[f"aoa{b}_h{hd}_r_feat_sub_{t}"] = rf[(t % 32)::32].contiguous().numpy()
+                    g[f"aoa{b}_h{hd}_r_words_{t}"] = rw.detach().numpy()
+                    if hd == 0 and t == T - 1 - 9 * b:
+                        g[f"aoa{b}_h0_r_feat_full_{t}"] = rf.numpy()
+        print("t20 AoA image", b, "done", flush=True)
+    # ---------------- AoA bottom-up (config 5), 36 x 2048 region features, head 0
+    sd = weights.make_aoa_state(seed=seed, vocab_size=V, feat_dim=2048, with_encoder=False)
+    feats_np = weights.make_bu_features(50, n_img)
+    caps = weights.make_captions(53, n_img, T, V)
+    g["bu_caption"] = caps
+    for b in range(n_img):
+        class StubEnc(nn.Module):
+            feat_dim = 2048
+
+            def forward(self, img, _f=feats_np[b]):
+                f = torch.from_numpy(_f.T.copy()).reshape(1, 2048, 6, 6)
+                return f, f.mean(dim=(2, 3)).squeeze()
+        model = aoa.AOAModel(512, 512, 8, V, 'vgg16')
+        model.img_encoder = StubEnc()
+        model.encoder_raw_dim = 2048
+        model.img_projector = nn.Conv2d(2048, 512, 1)
+        model.load_state_dict(to_torch_sd(sd))
+        with tempfile.TemporaryDirectory() as tmp:
+            ex = aoa.ExplainAOAAttention(make_args(tmp), wm, model=model)
+            _patch_explainer(ex, np.zeros((1, 3, 8, 8), np.float32), caps[b])
+            ex.get_hidden_parameters("synthetic")
+            for t in range(T):
+                with torch.no_grad():
+                    rf, rw = ex.explain_caption_wordt(t, 0)
+                rf = rf.detach().reshape(2048, 36).t().contiguous()                     # (36,2048)
+                g[f"bu{b}_r_feat_stats_{t}"] = stats4(rf)
+                g[f"bu{b}_r_feat_sub_{t}"] = rf[:, (t % 64)::64].contiguous().numpy()
+                g[f"bu{b}_r_words_{t}"] = rw.detach().numpy()
+                if t == T - 1 - 9 * b:
+                    g[f"bu{b}_r_feat_full_{t}"] = rf.numpy()
+        print("t20 BU image", b, "done", flush=True)
+    np.savez(os.path.join(out, "t20.npz"), **g)
+    print("t20.npz written:", sum(v.nbytes for v in g.values() if hasattr(v, "nbytes")) / 1e6, "MB")
+
+
+
+def gen_m4(out):
+    """The rule classes the VGG16 path never reaches (ResNet encoders): Linear epsilon rule with the
+    in-place zero nudge (LRPtools/lrp_modules.py:9-37), BatchNorm2d / BatchNorm1d (:197-246), Dropout (:248-254),
+    Add (:256-280), Flatten (:282-291), each called directly on crafted inputs incl. the edge cases (exact-zero inputs,
+    Z == 0, |xw| + |b| == 0, zero sums)."""
+    from LRPtools import lrp_wrapper, lrp_modules
+    import models.resnet as resnet
+    rs = np.random.RandomState(321)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    params = lrp_wrapper.SequentialPresetA().lrp_params
+    g = {}
+    # ---- Linear: N=5 rows, 70 -> 41 features (no multiple of anything), zeros in x, a zero weight row (Z == 0 -> 0.01)
+    lin = nn.Linear(70, 41)
+    lin.weight.data = f32(rs.uniform(-0.2, 0.2, (41, 70)))
+    lin.bias.data = f32(rs.uniform(-0.2, 0.2, (41,)))
+    lin.weight.data[7] = 0.0
+    x = f32(rs.standard_normal((5, 70)))
+    x[1, 4] = 0.0
+    x[3, :] = 0.0                       # a whole row of zeros -> all -1e-6
+    g["lin_x"] = x.numpy().copy()
+    lin.input = (x,)
+    r = f32(rs.standard_normal((5, 41)))
+    res = lrp_modules.Linear().propagate_relevance(lin, (torch.zeros(41), torch.zeros(5, 70), torch.zeros(70, 41)), (r,),
+                                                   'epsilon', params)
+    g["lin_w"], g["lin_b"], g["lin_rout"], g["lin_rin"] = lin.weight.data.numpy(), lin.bias.data.numpy(), r.numpy(), res[1].detach().numpy()
+    g["lin_x_after"] = lin.input[0].numpy().copy()          # quirk (h): the saved input is mutated in place
+    # ---- BatchNorm2d, eval statistics; channel 2 has b == 0 and zero inputs (|xw| + |b| == 0 -> safe_divide guard)
+    bn = nn.BatchNorm2d(6).eval()
+    bn.weight.data, bn.bias.data = f32(rs.uniform(0.5, 1.5, 6)), f32(rs.uniform(-0.5, 0.5, 6))
+    bn.running_mean.data, bn.running_var.data = f32(rs.uniform(-0.5, 0.5, 6)), f32(rs.uniform(0.5, 2.0, 6))
+    bn.bias.data[2] = 0.0
+    bn.running_mean.data[2] = 0.0
+    bn.weight.data[4] = -0.7             # a negative gamma
+    xb = f32(rs.standard_normal((2, 6, 5, 7)))
+    xb[:, 2, 1:3] = 0.0
+    xb[0, 0, 0, 0] = 0.0
+    bn.input = (xb,)
+    rb = f32(rs.standard_normal((2, 6, 5, 7)))
+    res = lrp_modules.BatchNorm2d().propagate_relevance(bn, (None, 1, 2), (rb,), 'epsilon', params)
+    for k, v in (("gamma", bn.weight), ("beta", bn.bias), ("mean", bn.running_mean), ("var", bn.running_var)):
+        g["bn2_" + k] = v.detach().numpy()
+    g["bn2_eps"] = np.float64(bn.eps)
+    g["bn2_x"], g["bn2_rout"], g["bn2_rin"] = xb.numpy(), rb.numpy(), res[0].detach().numpy()
+    # ---- BatchNorm1d: the rule indexes w[:, None, None] like the 2-d one (:236-238), so a (N,C) input broadcasts to a
+    # (C,N,C) result and a (1,C,L) input to (C,C,L); reproduced as it is
+    b1 = nn.BatchNorm1d(6).eval()
+    b1.weight.data, b1.bias.data = f32(rs.uniform(0.5, 1.5, 6)), f32(rs.uniform(-0.5, 0.5, 6))
+    b1.running_mean.data, b1.running_var.data = f32(rs.uniform(-0.5, 0.5, 6)), f32(rs.uniform(0.5, 2.0, 6))
+    for k, v in (("gamma", b1.weight), ("beta", b1.bias), ("mean", b1.running_mean), ("var", b1.running_var)):
+        g["bn1_" + k] = v.detach().numpy()
+    x1 = f32(rs.standard_normal((4, 6)))
+    x1[2, 3] = 0.0
+    b1.input = (x1,)
+    r1 = f32(rs.standard_normal((4, 6)))
+    res = lrp_modules.BatchNorm1d().propagate_relevance(b1, (None, 1, 2), (r1,), 'epsilon', params)
+    g["bn1_x"], g["bn1_rout"], g["bn1_rin"] = x1.numpy(), r1.numpy(), res[0].detach().numpy()
+    x3 = f32(rs.standard_normal((1, 6, 5)))
+    b1.input = (x3,)
+    r3 = f32(rs.standard_normal((1, 6, 5)))
+    res = lrp_modules.BatchNorm1d().propagate_relevance(b1, (None, 1, 2), (r3,), 'epsilon', params)
+    g["bn1_x3"], g["bn1_rout3"], g["bn1_rin3"] = x3.numpy(), r3.numpy(), res[0].detach().numpy()
+    # ---- Add: proportional split; both-zero entries get 0.5 / 0.5 (:262-272)
+    add = resnet.Add()
+    a1, a2 = f32(rs.standard_normal((2, 4, 3, 3))), f32(rs.standard_normal((2, 4, 3, 3)))
+    a1[0, 1], a2[0, 1] = 0.0, 0.0        # zero sums from zero inputs
+    a1[1, 2, 0, 0], a2[1, 2, 0, 0] = 0.0, 0.7
+    add.input = (a1, a2)
+    ra = f32(rs.standard_normal((2, 4, 3, 3)))
+    R1, R2 = lrp_modules.Add().propagate_relevance(add, None, (ra,), 'alpha_beta', params)
+    g["add_x1"], g["add_x2"], g["add_rout"], g["add_r1"], g["add_r2"] = a1.numpy(), a2.numpy(), ra.numpy(), R1.numpy(), R2.numpy()
+    # ---- Flatten / Dropout
+    fl = resnet.Flatten()
+    xf = f32(rs.standard_normal((3, 4, 2, 2)))
+    fl.input = (xf,)
+    rf = f32(rs.standard_normal((3, 16)))
+    g["flat_rout"], g["flat_rin"] = rf.numpy(), lrp_modules.Flatten().propagate_relevance(fl, None, (rf,), 'alpha_beta', params)[0].numpy()
+    dr = nn.Dropout(0.5).eval()
+    rd = f32(rs.standard_normal((3, 16)))
+    got = lrp_modules.Dropout().propagate_relevance(dr, (rd.clone(),), (rd,), 'alpha_beta', params)
+    g["drop_r"], g["drop_rin"] = rd.numpy(), got[0].numpy()
+    np.savez(os.path.join(out, "m4.npz"), **g)
+    print("m4.npz:", {k: getattr(v, "shape", None) for k, v in g.items()})
+
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -532,7 +735,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,m4")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -550,6 +753,10 @@ def main():
         gen_aoa_bu(HERE, weights)
     if "greedy" in todo:
         gen_greedy(HERE, weights)
+    if "t20" in todo:
+        gen_t20(HERE, weights)
+    if "m4" in todo:
+        gen_m4(HERE)
     if "guided" in todo:
         gen_guided(HERE, weights)
     if "gradient" in todo:

@@ -1,0 +1,146 @@
+"""GPU parity of the rule classes the VGG16 path never reaches (Linear, BatchNorm2d, BatchNorm1d,
+Dropout, Add, Flatten; LRPtools/lrp_modules.py:9-37,197-291) through the drop-in classes of lrp_amd.LRPtools.lrp_modules
+(HIP kernels of csrc/lrpx_rules.hip), against the outputs of the reference's own classes (tests/golden/m4.npz, layers.npz)
+incl. the edge cases: exact-zero inputs and their in-place nudge, Z == 0, |xw| + |b| == 0, zero sums."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import lrp_amd  # noqa: F401
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+PARAMS = {"alpha": 1., "beta": 0., "ignore_bias": True}
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = np.load(os.path.join(GOLDEN, "m4.npz"))
+    return lambda k: torch.from_numpy(g[k]).cuda()
+
+
+def _rules():
+    from lrp_amd.LRPtools import lrp_modules
+    return lrp_modules
+
+
+def test_linear_rule_vs_reference_and_inplace_nudge(M):
+    R = _rules()
+    lin = nn.Linear(70, 41).cuda()
+    lin.weight.data, lin.bias.data = M("lin_w"), M("lin_b")
+    x = M("lin_x").clone()
+    lin.input = (x,)
+    rule = R.get_lrp_module(lin)
+    ri = (torch.zeros(41, device="cuda"), torch.zeros(5, 70, device="cuda"), torch.zeros(70, 41, device="cuda"))
+    out = rule.propagate_relevance(lin, ri, (M("lin_rout"),), "epsilon", PARAMS)
+    assert len(out) == 3 and out[0] is ri[0] and out[2] is ri[2]              # arity / pass-through of :30-33
+    assert rel_err(out[1].cpu(), M("lin_rin").cpu()) < 1e-5
+    assert torch.equal(lin.input[0].cpu(), M("lin_x_after").cpu())           # quirk (h): the saved input was nudged in place
+    out2 = rule.propagate_relevance(lin, ri[1:], (M("lin_rout"),), "epsilon", PARAMS)
+    assert len(out2) == 2 and rel_err(out2[0].cpu(), M("lin_rin").cpu()) < 1e-5
+    # the small fixture of layers.npz (3 x 10 -> 7) - the shape the round-1 oracle test pinned
+    L = np.load(os.path.join(GOLDEN, "layers.npz"))
+    lin2 = nn.Linear(10, 7).cuda()
+    lin2.weight.data = torch.from_numpy(L["lin_w"]).cuda()
+    lin2.input = (torch.from_numpy(L["lin_x"]).cuda(),)
+    got = R.Linear().propagate_relevance(lin2, None, (torch.from_numpy(L["lin_rout"]).cuda(),), "epsilon", PARAMS)[0]
+    assert rel_err(got.cpu(), L["lin_rin"]) < 2e-6
+    # non-contiguous saved input: the nudge still lands on it
+    base = torch.zeros(70, 5, device="cuda")
+    base.t().copy_(M("lin_x"))
+    lin.input = (base.t(),)
+    rule.propagate_relevance(lin, None, (M("lin_rout"),), "epsilon", PARAMS)
+    assert torch.equal(base.t().cpu(), M("lin_x_after").cpu())
+
+
+def test_linear_rule_with_bias_and_larger_shape_vs_oracle():
+    """ResNet-sized classifier (2048 -> 1000, 19 rows: more than one row chunk) with ignore_bias off (:20-21)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import lrp_oracle as O
+    R = _rules()
+    g = torch.Generator().manual_seed(3)
+    lin = nn.Linear(2048, 1000)
+    x = torch.randn(19, 2048, generator=g)
+    x[:, ::7] = 0.0
+    r = torch.randn(19, 1000, generator=g)
+    want, x_after = O.linear_eps_rule(x, lin.weight.data, r, bias=lin.bias.data)
+    lin = lin.cuda()
+    lin.input = (x.cuda(),)
+    got = R.Linear().propagate_relevance(lin, None, (r.cuda(),), "epsilon", {"ignore_bias": False})[0]
+    assert rel_err(got.cpu(), want) < 1e-5
+    assert torch.equal(lin.input[0].cpu(), x_after)
+    want0, _ = O.linear_eps_rule(x, lin.weight.data.cpu(), r)
+    lin.input = (x.cuda(),)
+    got0 = R.Linear().propagate_relevance(lin, None, (r.cuda(),), "epsilon", PARAMS)[0]
+    assert rel_err(got0.cpu(), want0) < 1e-5
+
+
+def _bn(cls, M, tag):
+    bn = cls(6).cuda().eval()
+    bn.weight.data, bn.bias.data = M(tag + "_gamma"), M(tag + "_beta")
+    bn.running_mean.data, bn.running_var.data = M(tag + "_mean"), M(tag + "_var")
+    return bn
+
+
+def test_batchnorm2d_rule_bit_exact(M):
+    R = _rules()
+    bn = _bn(nn.BatchNorm2d, M, "bn2")
+    bn.input = (M("bn2_x"),)
+    out = R.get_lrp_module(bn).propagate_relevance(bn, (None, 1, 2), (M("bn2_rout"),), "epsilon", PARAMS)
+    assert out[1:] == (1, 2)
+    assert torch.equal(out[0].cpu(), M("bn2_rin").cpu())                       # elementwise: bit-exact, incl. 0 / (0 + 1e-7)
+    ident = R.BatchNorm2d().propagate_relevance(bn, (None, 1, 2), (M("bn2_rout"),), "identity", PARAMS)
+    assert torch.equal(ident[0], M("bn2_rout"))
+    with pytest.raises(AssertionError):                                       # `assert R.sum() != 0` (:219)
+        R.BatchNorm2d().propagate_relevance(bn, (None, 1, 2), (torch.zeros_like(M("bn2_rout")),), "epsilon", PARAMS)
+
+
+def test_batchnorm1d_rule_reproduces_the_reference_broadcast(M):
+    R = _rules()
+    bn = _bn(nn.BatchNorm1d, M, "bn1")
+    bn.input = (M("bn1_x"),)
+    out = R.get_lrp_module(bn).propagate_relevance(bn, (None, 1, 2), (M("bn1_rout"),), "epsilon", PARAMS)
+    assert tuple(out[0].shape) == (6, 4, 6) and torch.equal(out[0].cpu(), M("bn1_rin").cpu())
+    bn.input = (M("bn1_x3"),)
+    out = R.BatchNorm1d().propagate_relevance(bn, (None, 1, 2), (M("bn1_rout3"),), "epsilon", PARAMS)
+    assert tuple(out[0].shape) == (6, 6, 5) and torch.equal(out[0].cpu(), M("bn1_rin3").cpu())
+    bn.input = (torch.zeros(2, 6, 5, device="cuda"),)                         # does not broadcast in the reference either
+    with pytest.raises(RuntimeError):
+        R.BatchNorm1d().propagate_relevance(bn, (None, 1, 2), (torch.zeros(2, 6, 5, device="cuda"),), "epsilon", PARAMS)
+
+
+def test_add_rule_bit_exact_and_zero_sums(M):
+    R = _rules()
+    add = R.resAdd()
+    add.input = (M("add_x1"), M("add_x2"))
+    r1, r2 = R.get_lrp_module(add).propagate_relevance(add, None, (M("add_rout"),), "alpha_beta", PARAMS)
+    assert torch.equal(r1.cpu(), M("add_r1").cpu()) and torch.equal(r2.cpu(), M("add_r2").cpu())
+    assert torch.equal(r1[0, 1], 0.5 * M("add_rout")[0, 1])                   # zero sums of zero inputs: half each
+    # x1 == -x2 != 0: the reference divides by an exact zero and its isinf / isnan asserts fire (:276-279)
+    a = M("add_x1").clone()
+    add.input = (a, -a)
+    with pytest.raises(AssertionError):
+        R.Add().propagate_relevance(add, None, (M("add_rout"),), "alpha_beta", PARAMS)
+
+
+def test_flatten_and_dropout_rules(M):
+    R = _rules()
+    fl = R.resFlatten()
+    fl.input = (torch.zeros(3, 4, 2, 2, device="cuda"),)
+    out = R.get_lrp_module(fl).propagate_relevance(fl, None, (M("flat_rout"),), "alpha_beta", PARAMS)
+    assert tuple(out[0].shape) == (3, 4, 2, 2) and torch.equal(out[0].cpu(), M("flat_rin").cpu())
+    dr = nn.Dropout(0.5).cuda().eval()
+    ri = (M("drop_r").clone(),)
+    out = R.get_lrp_module(dr).propagate_relevance(dr, ri, (M("drop_r"),), "alpha_beta", PARAMS)
+    assert out is ri                                                           # `return relevance_input` (:254)
+    bad = M("drop_r").clone()
+    bad[1, 3] += 1e-3
+    with pytest.raises(AssertionError):                                       # :251
+        R.Dropout().propagate_relevance(dr, (bad,), (M("drop_r"),), "alpha_beta", PARAMS)

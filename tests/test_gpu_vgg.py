@@ -553,3 +553,68 @@ def test_errors_raise_like_the_reference(ops):
         ops.check_relevance(z)
     with pytest.raises(ValueError):              # unsupported shape -> ValueError (lrp_modules.py:338 style)
         ops.conv_mfma(z, z, 1, 17, 32, 32, 9, 1, x=z, out0=z, oc_split=32)
+
+
+def _hostile_targets(feats, m2i, n_maps, golden):
+    """Four families of hostile relevance at the encoder output, 80 maps each: signed and
+    heavy-tailed; the same with per-map scales 1e-6..1e6; sparse maps dominated by one entry; the reference's own
+    decoder relevance (golden r_feat of gridtd_T3.npz, signed, tiled with per-map sign / scale changes)."""
+    dev = feats.device
+    g = torch.Generator(device=dev).manual_seed(2024)
+    per = n_maps // 4
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    heavy = rn(per, 196, 512) * torch.exp(4 * rn(per, 196, 512))
+    scaled = rn(per, 196, 512) * torch.exp(4 * rn(per, 196, 512)) * torch.logspace(-6, 6, per, device=dev).view(-1, 1, 1)
+    sparse = rn(per, 196, 512) * (torch.rand(per, 196, 512, device=dev, generator=g) < 0.002)
+    pos = torch.randint(0, 196 * 512, (per,), device=dev, generator=g)
+    sparse.view(per, -1)[torch.arange(per, device=dev), pos] = 1e4 * torch.sign(rn(per)).clamp(min=-1)
+    ref = torch.cat([to_nhwc(torch.from_numpy(golden[f"r_feat_{t}"])) for t in range(3)]).to(dev)      # (3,196,512)
+    ref = ref[torch.arange(per, device=dev) % 3] * torch.where(torch.arange(per, device=dev) % 2 == 0, 1.0, -3.7).view(-1, 1, 1)
+    names = ["heavy"] * per + ["scaled"] * per + ["sparse"] * per + ["reference"] * per
+    return torch.cat([heavy, scaled, sparse, ref]).contiguous(), names
+
+
+def test_full_size_chain_hostile_relevance_all_modes(ops, gridtd_case):
+    """The chain-level worst case of the reduced-precision matrix-core modes: all 320 maps of a
+    config-2 step (16 images x 20 words) through the 13-layer relevance chain in conv modes 3 (fp16 + fp8 cross
+    products), 2 (f16x3) and 0 (fp32 MFMA) on the SAME trace, against the exact-split bf16x6 chain (mode 1), with
+    hostile relevance at the encoder output: signed heavy-tailed randn*exp(4 randn), per-map scales 1e-6..1e6,
+    sparse maps dominated by one entry, and the reference's own signed decoder relevance.  Contract (BASELINE
+    north_star): max|dR| / max|R| < 1e-4 per map.  Prints the worst map of every family and mode; the fp32-MFMA
+    column is the floor two fp32-grade evaluations differ by on the same data."""
+    from lrp_amd import _lib, weights
+    lib = _lib.load()
+    g, _, _ = gridtd_case
+    sd = weights.make_gridtd_state(seed=5, vocab_size=32)
+    vgg = _vgg(ops, sd)
+    n_img, n_maps = 16, 320
+    img = torch.from_numpy(weights.make_images(7, n_img)).cuda()
+    feats = vgg.forward(img)
+    m2i = (torch.arange(n_maps, device="cuda") * n_img // n_maps).to(torch.int32)
+    r_feat, names = _hostile_targets(feats, m2i, n_maps, g)
+    out = {}
+    prev = lib.lrpx_set_conv_mode(1)
+    try:
+        for mode in (1, 0, 2, 3):
+            lib.lrpx_set_conv_mode(mode)
+            out[mode] = vgg.relevance(r_feat, m2i).clone()
+            ops.check_relevance(out[mode], finite=True, nonzero=True)
+    finally:
+        lib.lrpx_set_conv_mode(prev)
+    torch.cuda.synchronize()
+    base = out[1].double()
+    scale = base.abs().amax(dim=(1, 2, 3))
+    assert (scale > 0).all()
+    worst = {}
+    for mode in (0, 2, 3):
+        err = (out[mode].double() - base).abs().amax(dim=(1, 2, 3)) / scale
+        for fam in ("heavy", "scaled", "sparse", "reference"):
+            idx = [i for i, n in enumerate(names) if n == fam]
+            e = err[idx]
+            k = int(e.argmax())
+            worst[(mode, fam)] = (e.max().item(), e.mean().item(), idx[k])
+    for fam in ("heavy", "scaled", "sparse", "reference"):
+        print("hostile %-9s | " % fam + " | ".join(
+            "mode %d: max %.2e mean %.2e (map %d)" % ((m,) + worst[(m, fam)]) for m in (0, 2, 3)))
+    for (mode, fam), (mx, _, k) in worst.items():
+        assert mx < TOL, (mode, fam, mx, k)

@@ -193,3 +193,44 @@ def test_aoa_gradient_family_vs_reference():
         scale = g[f"guided_map_stats_{t}"][1]
         assert np.abs(gmaps[t][..., ::4, ::4].numpy() - g[f"guided_map_sub4_{t}"]).max() / scale < TOL_REL
         assert np.abs(cams[t].numpy() - g[f"cam_{t}"]).max() < 1e-4
+
+
+def _t20_rows(g, prefix, k, T, stride, get, tol_words, layout):
+    for t in range(T):
+        rf, rw = get(t)                                               # (P,C), (t+1,)
+        st = g[f"{prefix}{k}_r_feat_stats_{t}"]
+        sub = torch.from_numpy(g[f"{prefix}{k}_r_feat_sub_{t}"]).double()
+        want = sub.reshape(sub.shape[0], -1).t() if layout == "chw" else sub
+        assert ((rf.double()[:, (t % stride)::stride] - want).abs().max() / st[1]).item() < TOL_REL, (prefix, k, t)
+        assert abs(rf.double().norm().item() - st[2]) <= 1e-4 * st[2]
+        assert np.abs(rw.numpy() - g[f"{prefix}{k}_r_words_{t}"]).max() < tol_words, (prefix, k, t)
+
+
+def test_t20_decoder_relevance_at_headline_length():
+    # T = 20 (BASELINE configs 2 / 3 / 5): the reference's explain_caption_wordt for every word of two images per model
+    # (tests/golden/t20.npz; models/gridTDmodel.py:1014-1135, models/aoamodel.py:1064-1156) against the oracle's decoder
+    # relevance; the VGG16 forward is the oracle's own (same oneDNN convs as the reference's)
+    g = np.load(os.path.join(GOLDEN, "t20.npz"))
+    T, n_img = int(g["T"]), int(g["n_img"])
+    torch.set_num_threads(8)
+    imgs = torch.from_numpy(weights.make_images(int(g["img_seed"]), n_img))
+    sd = O.state_to_torch(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=int(g["grid_V"])))
+    sda = O.state_to_torch(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=int(g["aoa_V"])))
+    for k in range(n_img):
+        feats, avg, _ = O.vgg_forward(sd, imgs[k:k + 1])
+        tr = O.gridtd_trace(sd, feats[0], avg[0], g["grid_caption"][k])
+        _t20_rows(g, "grid", k, T, 32, lambda t: O.gridtd_explain_wordt(sd, tr, t), TOL_WORDS, "chw")
+        F_pix = feats[0].reshape(512, -1).t().contiguous()            # the two models share the seeded VGG16 weights
+        tra = O.aoa_trace(sda, F_pix, g["aoa_caption"][k])
+        gh = {key.replace(f"aoa{k}_h0_", f"aoa{k}_"): g[key] for key in g.files if key.startswith(f"aoa{k}_h0_")}
+        # AoA r_words at T = 20: the normalising entry is a 512-term sum with heavy cancellation; the REFERENCE's own fp32
+        # result is up to 4.3e-5 away from the fp64 evaluation of its formula on the same trace (image 0, words 17 / 19:
+        # reference 1.0e-5 / 4.3e-5, this oracle 1.3e-5 / 4.3e-5 from fp64; 2.4e-5 / 5e-6 from each other), so 1e-5 is
+        # not a property of the reference at this length: bound 1e-4 (gridTD stays at 1e-5: worst 1.7e-6)
+        _t20_rows(gh, "aoa", k, T, 32, lambda t: O.aoa_explain_wordt(sda, tra, t, 0), 1e-4, "chw")
+    sdb = O.state_to_torch(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=int(g["aoa_V"]), feat_dim=2048,
+                                                  with_encoder=False))
+    bu = weights.make_bu_features(int(g["img_seed"]), n_img)
+    for k in range(n_img):
+        trb = O.aoa_trace(sdb, torch.from_numpy(bu[k]), g["bu_caption"][k])
+        _t20_rows(g, "bu", k, T, 64, lambda t: O.aoa_explain_wordt(sdb, trb, t, 0), 1e-4, "pc")

@@ -59,3 +59,36 @@ def test_linear_module_rule_matches_formula():
     z[z == 0] = 0.01
     r = x * ((T("lin_rout") / z) @ T("lin_w"))
     assert rel_err(r, T("lin_rin")) < 1e-5
+
+
+M4 = np.load(os.path.join(GOLDEN, "m4.npz"))
+M = lambda k: torch.from_numpy(M4[k])
+
+
+def test_m4_linear_rule_with_inplace_nudge():
+    # LRPtools/lrp_modules.py:9-37 at 5 x 70 -> 41 with a zero input row, a zero weight row (Z == 0 -> 0.01)
+    r, x_after = O.linear_eps_rule(M("lin_x"), M("lin_w"), M("lin_rout"))
+    assert rel_err(r, M("lin_rin")) < 1e-5
+    assert torch.equal(x_after, M("lin_x_after"))            # quirk (h): zeros became -1e-6 on the saved input
+    assert (M("lin_x") == 0).sum() > 70 and (x_after == 0).sum() == 0
+
+
+def test_m4_batchnorm_rules():
+    # :197-246; channel 2 of the 2-d case has b == 0 and zero inputs (0 / (0 + 1e-7) = 0), channel 4 a negative gamma
+    args = [M("bn2_" + k) for k in ("gamma", "beta", "mean", "var")]
+    r = O.batchnorm_rule(M("bn2_x"), M("bn2_rout"), *args, float(M4["bn2_eps"]))
+    assert torch.equal(r, M("bn2_rin"))                      # elementwise: bit-exact
+    assert (r[:, 2, 1:3] == 0).all()
+    args = [M("bn1_" + k) for k in ("gamma", "beta", "mean", "var")]
+    r = O.batchnorm_rule(M("bn1_x"), M("bn1_rout"), *args, 1e-5)
+    assert tuple(r.shape) == (6, 4, 6) and torch.equal(r, M("bn1_rin"))      # the reference's broadcasting quirk
+    r = O.batchnorm_rule(M("bn1_x3"), M("bn1_rout3"), *args, 1e-5)
+    assert tuple(r.shape) == (6, 6, 5) and torch.equal(r, M("bn1_rin3"))
+
+
+def test_m4_add_flatten_dropout_rules():
+    r1, r2 = O.add_rule(M("add_x1"), M("add_x2"), M("add_rout"))
+    assert torch.equal(r1, M("add_r1")) and torch.equal(r2, M("add_r2"))
+    assert torch.equal(r1[0, 1], 0.5 * M("add_rout")[0, 1])                  # zero sums: half each (:262-272)
+    assert torch.equal(M("flat_rin").reshape(3, 16), M("flat_rout"))         # Flatten: a view (:282-291)
+    assert torch.equal(M("drop_rin"), M("drop_r"))                           # Dropout: passes relevance_input (:248-254)

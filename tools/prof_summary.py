@@ -2,6 +2,7 @@
 """Summaries of rocprofv3 output directories for profiles/:
    prof_summary.py stats <dir>            kernel table (calls, total ms, avg us, %) from *_kernel_stats.csv
    prof_summary.py traffic <dirB> <dirC>  per kernel FETCH_SIZE / WRITE_SIZE sums (GB) and L2 hit rate from two --pmc passes
+   prof_summary.py traffic-json <maps_per_launch> <dirB> <dirC>   the same as JSON (read by bench.py for roofline.traffic)
    prof_summary.py sq <dir> [<dir>...]    per kernel means of every SQ counter found (per launch)"""
 import collections, csv, glob, os, re, sys
 
@@ -46,6 +47,22 @@ def traffic(dirs):
               f"{sum(c.get('WRITE_SIZE', [0]))*1024/1e9:10.2f} {100*hit/max(hit+miss,1):9.1f}")
 
 
+def traffic_json(args):
+    import json
+    maps, dirs = int(args[0]), args[1:]
+    data = counters(dirs)
+    doc = {"maps_per_launch": maps, "source": "rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum "
+           "(separate passes of tools/pmc_passes.sh BC); bytes = counter x 1024 summed over the launches; FETCH_SIZE raw "
+           "(HBM bytes = 2 x FETCH + WRITE on gfx950)", "kernels": {}}
+    for k, c in sorted(data.items()):
+        if "FETCH_SIZE" not in c or ("conv_" not in k and "first_layer" not in k):
+            continue
+        hit, miss = sum(c.get("TCC_HIT_sum", [0])), sum(c.get("TCC_MISS_sum", [0]))
+        doc["kernels"][k] = {"launches": len(c["FETCH_SIZE"]), "fetch_bytes": sum(c["FETCH_SIZE"]) * 1024,
+                             "write_bytes": sum(c.get("WRITE_SIZE", [0])) * 1024, "l2_hit": round(hit / max(hit + miss, 1), 4)}
+    print(json.dumps(doc, indent=1))
+
+
 def sq(dirs):
     data = counters(dirs)
     for k, c in sorted(data.items()):
@@ -57,4 +74,4 @@ def sq(dirs):
 
 
 if __name__ == "__main__":
-    {"stats": lambda a: stats(a[0]), "traffic": traffic, "sq": sq}[sys.argv[1]](sys.argv[2:])
+    {"stats": lambda a: stats(a[0]), "traffic": traffic, "traffic-json": traffic_json, "sq": sq}[sys.argv[1]](sys.argv[2:])
