@@ -59,7 +59,7 @@ def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=5e-2, l2=2e-3, what
     got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
     scale = want.abs().max().clamp_min(1e-300)
     d = (got - want).abs() / scale
-    _TIE_STATS.append({"what": str(what), "frac_gt_1e-4": (d > 1e-4).double().mean().item(), "max": d.max().item(),
+    _TIE_STATS.append({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "bounds": [frac, hard, l2], "what": str(what), "frac_gt_1e-4": (d > 1e-4).double().mean().item(), "max": d.max().item(),
                        "rel_l2": ((got - want).norm() / want.norm().clamp_min(1e-300)).item(), "cos": cosine(got, want)})
     assert cosine(got, want) > cos, (what, cosine(got, want))
     assert ((got - want).norm() / want.norm().clamp_min(1e-300)).item() < l2, (what, "rel L2")

@@ -71,10 +71,14 @@ def test_linear_rule_with_bias_and_larger_shape_vs_oracle():
     x[:, ::7] = 0.0
     r = torch.randn(19, 1000, generator=g)
     want, x_after = O.linear_eps_rule(x, lin.weight.data, r, bias=lin.bias.data)
+    want64, _ = O.linear_eps_rule(x.double(), lin.weight.data.double(), r.double(), bias=lin.bias.data.double())
     lin = lin.cuda()
     lin.input = (x.cuda(),)
     got = R.Linear().propagate_relevance(lin, None, (r.cuda(),), "epsilon", {"ignore_bias": False})[0]
-    assert rel_err(got.cpu(), want) < 1e-5
+    # without the stabiliser Z = x W^T + b comes arbitrarily close to zero and R_out / Z amplifies the rounding of Z: two
+    # fp32 evaluations differ by ~1e-3 here, so the kernel is held to the fp32 oracle's own distance from fp64
+    e_gpu, e_cpu = rel_err(got.cpu().double(), want64), rel_err(want.double(), want64)
+    assert e_gpu < max(3 * e_cpu, 1e-5), (e_gpu, e_cpu)
     assert torch.equal(lin.input[0].cpu(), x_after)
     want0, _ = O.linear_eps_rule(x, lin.weight.data.cpu(), r)
     lin.input = (x.cuda(),)

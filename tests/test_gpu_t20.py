@@ -6,9 +6,13 @@ the reference's own `explain_caption_wordt` outputs (models/gridTDmodel.py:1014-
 for every word of two images per model; here those two images sit at positions 3 and 11 of a B = 16 batch of other
 images and captions (BASELINE configs 2 / 3; B = 32 for the bottom-up config 5), and their 2 x 20 rows of the batched
 engines are compared with the reference: r_feat <= 1e-4 of its maximum (channel subsample of every word + two full
-rows + L2 / sum statistics of all channels), r_words <= 1e-5 for gridTD and <= 1e-4 for the AoA models: at T = 20 the
-normalising entry of the AoA r_words is a 512-term sum with heavy cancellation and the reference's own fp32 value sits
-up to 4.3e-5 from the fp64 evaluation of its formula on the same trace (tests/test_oracle_golden.py)."""
+rows + L2 / sum statistics of all channels), r_words <= 1e-5 for gridTD.  AoA r_words at T = 20: two of the 40 golden
+rows (image 0, words 17 and 19) are ill-conditioned - their normalising entry is a 512-term sum that cancels to ~1/200 of
+its terms: the reference's own fp32 value sits 1.0e-5 / 4.3e-5 from the fp64 evaluation of its formula on the same trace,
+the CPU oracle (same forward, another summation order) 2.4e-5 from the reference (tests/test_oracle_golden.py), and the
+GPU forward (fp32-grade, but a sequential K-chain of up to 288 MFMA accumulations: features 3e-6 of max from fp64 against
+7e-7 for oneDNN) moves them by 0.4e-4 / 1.5e-4 (tools/t20_probe.py; the same with the exact-split bf16x6 forward).  So
+for the AoA models: every row <= 5e-4, at most 10 % of the rows above 1e-5 (observed: 2 of 40; the other 38 <= 2.5e-6)."""
 import os
 
 import numpy as np
@@ -51,7 +55,9 @@ def _images(g, B):
 def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout):
     """r_feat (B,T,P,C) / r_words (B,T,T) of the engine vs the golden rows `prefix{k}_*`.
     layout 'chw': golden sub = (C/stride, 14, 14); 'pc': golden sub = (P, C/stride)."""
-    worst_f, worst_w = 0.0, 0.0
+    worst_f, worst_w, n_soft = 0.0, 0.0, 0
+    if not isinstance(tol_words, tuple):
+        tol_words = (tol_words, tol_words)          # (soft bound that <= 10 % of the rows may exceed, hard bound)
     for k, p in enumerate(POS):
         for t in range(T):
             st = g[f"{prefix}{k}_r_feat_stats_{t}"]                       # sum, absmax, L2, L1 over ALL channels
@@ -67,7 +73,8 @@ def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout):
             assert abs(got.abs().max().item() - st[1]) <= 1e-4 * st[1], (prefix, k, t, "absmax")
             w = np.abs(r_words[p, t, :t + 1].numpy() - g[f"{prefix}{k}_r_words_{t}"]).max()
             worst_w = max(worst_w, float(w))
-            assert w < tol_words, (prefix, k, t, w)
+            n_soft += int(w >= tol_words[0])
+            assert w < tol_words[1], (prefix, k, t, w)
             if t + 1 < T:
                 assert r_words[p, t, t + 1:].abs().max().item() == 0      # nothing beyond the word's own prefix
         tf = T - 1 - 9 * k
@@ -75,7 +82,9 @@ def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout):
         want = full.reshape(full.shape[0], -1).t() if layout == "chw" else full
         assert rel_err(r_feat[p, tf], want) < TOL, (prefix, k, "full")
         assert cosine(r_feat[p, tf], want) > 0.99999
-    print(f"T=20 {prefix}: worst r_feat error {worst_f:.2e} of max|R|, worst r_words error {worst_w:.2e}")
+    assert n_soft <= 0.1 * len(POS) * T, (prefix, n_soft)
+    print(f"T=20 {prefix}: worst r_feat error {worst_f:.2e} of max|R|, worst r_words error {worst_w:.2e} "
+          f"({n_soft} of {len(POS) * T} rows above {tol_words[0]:.0e})")
 
 
 def test_gridtd_t20_rows_inside_b16_batch(g20):
@@ -111,7 +120,7 @@ def test_aoa_t20_rows_inside_b16_batch(g20, head):
     torch.cuda.synchronize()
     r_feat, r_words = r_feat.view(B, T, 196, 512).cpu(), r_words.view(B, T, T).cpu()
     if head == 0:
-        _check_rows(_Prefixed(g, "_h0"), "aoa", r_feat, r_words, T, 512, 32, 1e-4, "chw")
+        _check_rows(_Prefixed(g, "_h0"), "aoa", r_feat, r_words, T, 512, 32, (1e-5, 5e-4), "chw")
     else:      # head 3 was generated for golden image 1 only
         gg = _Prefixed(g, "_h3")
         k, p = 1, POS[1]
@@ -121,7 +130,7 @@ def test_aoa_t20_rows_inside_b16_batch(g20, head):
             want = sub.reshape(sub.shape[0], -1).t()
             e = ((r_feat[p, t].double()[:, (t % 32)::32] - want).abs().max() / st[1]).item()
             assert e < TOL, (t, e)
-            assert np.abs(r_words[p, t, :t + 1].numpy() - gg[f"aoa{k}_r_words_{t}"]).max() < 1e-4
+            assert np.abs(r_words[p, t, :t + 1].numpy() - gg[f"aoa{k}_r_words_{t}"]).max() < 1e-5   # image 1: well conditioned
 
 
 class _Prefixed:
@@ -148,4 +157,4 @@ def test_aoa_bottom_up_t20_rows_inside_b32_batch(g20):
     eng = AOAEngine(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=V, feat_dim=2048, with_encoder=False))
     r_feat, r_words = eng.explain_batch(caps, 0, features=torch.from_numpy(feats))
     torch.cuda.synchronize()
-    _check_rows(g, "bu", r_feat.cpu(), r_words.cpu(), T, 2048, 64, 1e-4, "pc")
+    _check_rows(g, "bu", r_feat.cpu(), r_words.cpu(), T, 2048, 64, (1e-5, 5e-4), "pc")

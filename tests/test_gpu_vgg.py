@@ -618,3 +618,39 @@ def test_full_size_chain_hostile_relevance_all_modes(ops, gridtd_case):
             "mode %d: max %.2e mean %.2e (map %d)" % ((m,) + worst[(m, fam)]) for m in (0, 2, 3)))
     for (mode, fam), (mx, _, k) in worst.items():
         assert mx < TOL, (mode, fam, mx, k)
+
+
+def test_rel_mul_rejects_two_outputs_and_never_writes_past_the_last_map(ops):
+    """Regression for the abort of round 1 (gpurun_out/crash.log, `test_conv_rule_f16x3_is_fp32_grade[14-64-96-3-5]`): the
+    first version of the REL_MUL fast epilogue (one base pointer per 32-pixel tile) stored all 16 elements of a tile
+    unconditionally; 5 maps x 196 pixels = 980 pixels are 4.375 workgroup tiles of 224, so the last tile wrote up to 140
+    pixels x 64 channels past the end of `out1` -> memory fault at the next synchronize.  01149c6 added the `total_pix`
+    guard (conv_mfma.h, `if (!ALIGNED && ... >= cx.total_pix) continue`) and made the epilogue single-output.
+    (1) a descriptor with both outputs (or none) is refused with LRPX_EINVAL -> ValueError instead of launching;
+    (2) the output of the map-straddling 14x14 / 28x28 kernels sits in front of a guard band that must stay untouched."""
+    from lrp_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    for hw, n_maps, f16x3 in ((14, 5, 1), (14, 5, 2), (28, 3, 1), (28, 3, 2)):
+        cin = cout = 64
+        s = torch.randn(n_maps, hw * hw, cout, generator=g).cuda()
+        x = torch.rand(n_maps, hw * hw, cin, generator=g).cuda()
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+        wb = (ops.pack_weights_f16f8 if f16x3 == 2 else ops.pack_weights_f16x2)(w, cout, cin, _lib.PACK_BWD_POS)
+        amax = ops.amax_maps(s, n_maps)
+        n_out = n_maps * hw * hw * cin
+        guard = 224 * cin                                   # one whole workgroup tile behind the tensor
+        buf = torch.full((n_out + guard,), 12345.0, device="cuda")
+        out = buf[:n_out].view(n_maps, hw * hw, cin)
+        oamax = torch.zeros(n_maps, dtype=torch.int32, device="cuda")
+        with pytest.raises(ValueError, match="exactly one"):
+            ops.conv_mfma(s, wb, n_maps, hw, cout, cin, 9, _lib.EPI_REL_MUL, oc_split=cin, x=x, out0=out, out1=out,
+                          f16x3=f16x3, in_amax=amax)
+        with pytest.raises(ValueError):
+            ops.conv_mfma(s, wb, n_maps, hw, cout, cin, 9, _lib.EPI_REL_MUL, oc_split=cin, x=x, f16x3=f16x3, in_amax=amax)
+        ops.conv_mfma(s, wb, n_maps, hw, cout, cin, 9, _lib.EPI_REL_MUL, oc_split=cin, x=x, out1=out, f16x3=f16x3,
+                      in_amax=amax, out1_amax=oamax)
+        torch.cuda.synchronize()
+        assert (buf[n_out:] == 12345.0).all(), (hw, f16x3)
+        assert torch.isfinite(out).all() and (out != 12345.0).all()
+        for i in range(n_maps):
+            assert oamax[i:i + 1].view(torch.float32).item() == out[i].abs().max().item()
