@@ -161,7 +161,23 @@ int lrpx_fold_halves(const float* in, float* out, long rows, int half, void* str
  * synchronises the stream.  flags: bit0 = fail on non-finite, bit1 = fail on all-zero */
 int lrpx_check(const float* buf, long n, int flags, void* stream);
 
-/* Process-wide switch for lrpx_vgg16_relevance: 1 (default) runs the relevance passes of the 56/28/14-pixel layers on
+/* THREADING.  Every entry point is thread-compatible: calls on different host threads / streams with different caller
+ * buffers never share mutable state.  What the library keeps is (a) the one-time kernel-attribute initialisation of each
+ * kernel instantiation (std::call_once), (b) the 4-byte flag word of lrpx_check behind a mutex, (c) the thread-local
+ * error string, (d) the PROCESS DEFAULTS set by lrpx_set_conv_mode / lrpx_set_forward_f16 / lrpx_set_bf16x6 (atomics).
+ * A caller that wants a mode of its own - or that runs while another thread changes the defaults - passes it per call in
+ * an lrpx_vgg16_opts to the *_ex entry points; such a call never reads the defaults. */
+typedef struct lrpx_vgg16_opts {
+    int conv_mode;     /* 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp8 cross products; < 0: the process default */
+    int forward_f16;   /* forward trace on the fp16 split-product kernels: 0 / 1; < 0: the process default */
+    float* layer_ms;   /* lrpx_vgg16_relevance_ex only, may be NULL.  HOST array of 17 floats: the call records HIP events of
+                          its own around every conv launch, WAITS for them and stores the milliseconds per VGG16 layer index
+                          (0 for pools / the first layer); the events are created and destroyed inside the call */
+} lrpx_vgg16_opts;
+/* the values a call with `opts` (NULL: none) would run with - host logic only, no device access */
+int lrpx_vgg16_resolve_opts(const lrpx_vgg16_opts* opts, int* conv_mode, int* forward_f16);
+
+/* Process-wide DEFAULT for lrpx_vgg16_relevance: 1 (default) runs the relevance passes of the 56/28/14-pixel layers on
  * the bf16 matrix cores with exact operand splits (fp32 accuracy, see lrpx_conv_desc.bf16x6), 0 keeps the fp32 MFMA
  * everywhere; a negative value only queries.  Returns the previous setting. */
 int lrpx_set_bf16x6(int enable);
@@ -209,9 +225,10 @@ size_t lrpx_vgg16_trace_bytes(int n_img);
 size_t lrpx_vgg16_workspace_bytes(int n_maps);
 /* w[13], b[13]: device pointers to the conv weights (cout,cin,3,3) / biases in layer order */
 int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, void* stream);
-/* Per-layer timing of lrpx_vgg16_relevance for profiling: enable = 1 makes the following calls record HIP events on
- * their launch stream around every conv launch; ms17 (may be null) receives the elapsed milliseconds per VGG16 layer
- * index (0 for pools / the first layer) of the last such call (synchronises on its events).  enable < 0: query only. */
+/* Per-layer timing of lrpx_vgg16_relevance for profiling, per calling THREAD: enable = 1 makes this thread's following
+ * plain lrpx_vgg16_relevance calls behave like lrpx_vgg16_relevance_ex with opts.layer_ms (events of their own, the
+ * call waits for them); ms17 (may be null) receives the milliseconds per VGG16 layer index of this thread's last such
+ * call.  enable < 0: query only.  (Kept for callers of the round-1 ABI; new code passes opts.layer_ms.) */
 int lrpx_vgg16_layer_timing(int enable, float* ms17);
 /* recompute the trace tensors derived from the saved activations (x / safe(Z+_below), the multiplicand of the fused
  * conv->conv relevance step); lrpx_vgg16_forward calls it, callers that overwrite activations in the trace must too */
@@ -424,6 +441,19 @@ int lrpx_batchnorm_rule(const float* x, const float* r_out, const float* gamma, 
 int lrpx_add_rule(const float* x1, const float* x2, const float* r_out, float* r1, float* r2, long n, void* stream);
 /* max |a - b| into one device float (Dropout.propagate_relevance's check, LRPtools/lrp_modules.py:251; NaN counts as inf) */
 int lrpx_max_abs_diff(const float* a, const float* b, long n, float* out_dev, void* stream);
+
+/* ---- the VGG16 chains with a per-call context (see THREADING above): same arguments + opts (NULL = process defaults) -- */
+int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, void* trace, float* feat_nhwc,
+                          const lrpx_vgg16_opts* opts, void* stream);
+int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, const float* r_feat_nhwc,
+                            const int32_t* map2img, int n_maps, void* workspace, float* out_nchw,
+                            const lrpx_vgg16_opts* opts, void* stream);
+int lrpx_vgg16_guided_backprop_ex(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                                  const int32_t* map2img, int n_maps, void* workspace, float* out_nchw,
+                                  const lrpx_vgg16_opts* opts, void* stream);
+int lrpx_vgg16_gradient_ex(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                           const int32_t* map2img, int n_maps, void* workspace, float* out_nchw,
+                           const lrpx_vgg16_opts* opts, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,11 @@ class ConvDesc(C.Structure):
                 ("tile_group", _i)]
 
 
+class VggOpts(C.Structure):
+    """lrpx_vgg16_opts: the per-call context of the VGG16 chains (conv mode, forward switch, per-layer timing)"""
+    _fields_ = [("conv_mode", _i), ("forward_f16", _i), ("layer_ms", C.POINTER(C.c_float))]
+
+
 # name -> (restype, argtypes); must list every symbol of include/lrpx.h (tests/test_abi.py checks it)
 SIGNATURES = {
     "lrpx_version": (_i, []),
@@ -145,6 +150,11 @@ SIGNATURES = {
     "lrpx_vgg16_trace_derive": (_i, [_f, _i, _f]),
     "lrpx_vgg16_trace_layout": (_i, [_i, C.POINTER(_sz), C.POINTER(_sz)]),
     "lrpx_vgg16_trace_features": (_f, [_f, _i]),
+    "lrpx_vgg16_resolve_opts": (_i, [C.POINTER(VggOpts), C.POINTER(_i), C.POINTER(_i)]),
+    "lrpx_vgg16_forward_ex": (_i, [_f, _f, _i, _f, _f, C.POINTER(VggOpts), _f]),
+    "lrpx_vgg16_relevance_ex": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, C.POINTER(VggOpts), _f]),
+    "lrpx_vgg16_guided_backprop_ex": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, C.POINTER(VggOpts), _f]),
+    "lrpx_vgg16_gradient_ex": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, C.POINTER(VggOpts), _f]),
     "lrpx_linear_eps_rule": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
     "lrpx_batchnorm_rule": (_i, [_f, _f, _f, _f, _f, _f, C.c_float, _f, _l, _i, _l, _i, _f]),
     "lrpx_add_rule": (_i, [_f, _f, _f, _f, _f, _l, _f]),

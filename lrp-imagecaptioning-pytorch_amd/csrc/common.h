@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/lrpx.h"
 
 namespace lrpx {
@@ -39,6 +41,21 @@ int maxpool_relevance_amax(const float* x, const float* r_out, const float* zdiv
                            hipStream_t stream);
 int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c, int stab,
                      unsigned* amax, hipStream_t stream);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel instantiation, set exactly once even when several host threads
+// make their first launch of it at the same time (no globals except an init-once cache behind a mutex).
+// `once` / `res` are the caller's function-local statics (one pair per template instantiation).
+template <typename K>
+inline int reserve_lds_once(std::once_flag& once, hipError_t& res, K kern, int bytes, const char* what) {
+    std::call_once(once, [&] {
+        res = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    });
+    if (res != hipSuccess) {
+        set_error("%s: cannot reserve %d bytes of LDS", what, bytes);
+        return LRPX_ELAUNCH;
+    }
+    return LRPX_OK;
+}
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline long ceil_div(long a, long b) { return (a + b - 1) / b; }

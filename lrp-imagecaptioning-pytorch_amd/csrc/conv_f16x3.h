@@ -838,15 +838,9 @@ int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
         grid = ceil_div(n_groups, 8) * 8 * a.tile_group * n_blocks;
     }
     auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI, POOL, F8>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-            hipSuccess) {
-            set_error("conv_f16x3: cannot reserve %d bytes of LDS", LDS);
-            return LRPX_ELAUNCH;
-        }
-        attr_done = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_res = hipSuccess;
+    LRPX_TRY(reserve_lds_once(attr_once, attr_res, kern, LDS, "conv_f16x3"));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MT * NWN), LDS, stream, a, (int)m_tiles, n_blocks);
     return check_launch("conv_f16x3");
 }

@@ -18,15 +18,9 @@ int launch_conv_cfg(const ConvArgs& a, hipStream_t stream) {
         return LRPX_EINVAL;
     }
     auto kern = conv_mfma_kernel<HW, KC, MT, NWN, TAPS, EPI>;
-    static bool attr_done = false;   // benign race: the attribute call is idempotent
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                C::LDS_BYTES) != hipSuccess) {
-            set_error("conv_mfma: cannot reserve %d bytes of LDS", C::LDS_BYTES);
-            return LRPX_ELAUNCH;
-        }
-        attr_done = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_res = hipSuccess;
+    LRPX_TRY(reserve_lds_once(attr_once, attr_res, kern, C::LDS_BYTES, "conv_mfma"));
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, ks), dim3(C::NT), C::LDS_BYTES, stream, a, (int)m_tiles, n_blocks);
     return check_launch("conv_mfma");

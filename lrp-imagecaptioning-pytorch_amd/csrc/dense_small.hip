@@ -222,15 +222,11 @@ static int launch_dense_small_t(const ConvArgs& a, hipStream_t stream) {
     const int lds = 32 * ((a.cin < 1024 ? a.cin : 1024) + 4) * (int)sizeof(float);
     const bool slabs = a.cin > 1024;
     auto kern = slabs ? dense_slab_kernel<EPI> : dense_small_kernel<EPI>;
-    static int lds_reserved[2] = {0, 0};
-    if (lds > lds_reserved[slabs]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess) {
-            set_error("dense_small: cannot reserve %d bytes of LDS", lds);
-            return LRPX_ELAUNCH;
-        }
-        lds_reserved[slabs] = lds;
-    }
+    // the largest LDS image either kernel ever asks for (32 rows x (1024 + 4) floats), reserved once per kernel
+    constexpr int LDS_MAX = 32 * (1024 + 4) * (int)sizeof(float);
+    static std::once_flag once[2];
+    static hipError_t res[2] = {hipSuccess, hipSuccess};
+    LRPX_TRY(reserve_lds_once(once[slabs], res[slabs], kern, LDS_MAX, "dense_small"));
     hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks);
     return check_launch("dense_small");
 }

@@ -5,6 +5,8 @@
 //              + LRPtools/lrp_wrapper.py:24-25 save_input_hook (every leaf keeps its input)
 //   relevance: LRPtools/lrp_wrapper.py:63-87 compute_lrp -> per leaf, in reverse order,
 //              Conv2d alpha1beta0 (lrp_modules.py:124-150), ReLU identity (:42-46), MaxPool2d (:182-195)
+#include <atomic>
+
 #include "conv_launch.h"
 #include "conv_f16x3.h"
 
@@ -213,17 +215,32 @@ int guided_gate(const float* g, const float* y, const int* map2img, float* out, 
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
                        int c, int plain, hipStream_t s);
 
-// matrix-core mode of the fused chains (lrpx_set_conv_mode): 0 fp32 MFMA, 1 bf16x6 (conv_bf16x6.h), 2 = bf16x6 forward
-// trace + f16x3 relevance pass (conv_f16x3.h)
-static int g_mode = 3;
-#define g_bf16x6 (g_mode >= 1)
-static int g_fwd_f16 = 1;   // lrpx_set_forward_f16: forward trace of conv1_2..conv5_3 on the fp16 split-product kernels (default on)
+// PROCESS DEFAULTS of the matrix-core mode of the fused chains (lrpx_set_conv_mode: 0 fp32 MFMA, 1 bf16x6 (conv_bf16x6.h),
+// 2 f16x3 (conv_f16x3.h), 3 = 2 with fp8 cross products in the relevance pass) and of the forward-trace switch
+// (lrpx_set_forward_f16).  Atomics: a setter racing with a call on another thread yields one of the two values, never a
+// torn one; callers that need a mode of their own pass it per call (lrpx_vgg16_opts, the *_ex entry points) and are not
+// affected by the setters at all.
+static std::atomic<int> g_default_mode{3};
+static std::atomic<int> g_default_fwd_f16{1};
 
-// optional per-layer timing of the relevance chain (lrpx_vgg16_layer_timing): HIP events recorded on the launch stream
-// around every conv launch of the NEXT lrpx_vgg16_relevance call; off by default, never inside a timed benchmark loop
-static int g_timing = 0;
-static hipEvent_t g_ev[17][2];
-static bool g_ev_made = false, g_ev_valid[17];
+// what one call runs with: resolved once at entry from its opts (or the process defaults)
+struct VggCtx {
+    int mode, fwd_f16;
+    float* layer_ms;      // host [17]: per-layer HIP-event times of THIS call (events live and die inside the call)
+    bool bf16x6() const { return mode >= 1; }
+};
+static VggCtx resolve_ctx(const lrpx_vgg16_opts* o) {
+    VggCtx c;
+    c.mode = (o && o->conv_mode >= 0) ? (o->conv_mode > 3 ? 3 : o->conv_mode) : g_default_mode.load(std::memory_order_relaxed);
+    c.fwd_f16 = (o && o->forward_f16 >= 0) ? (o->forward_f16 ? 1 : 0) : g_default_fwd_f16.load(std::memory_order_relaxed);
+    c.layer_ms = o ? o->layer_ms : nullptr;
+    return c;
+}
+
+// legacy profiling switch (lrpx_vgg16_layer_timing): per THREAD, so that two host threads driving two streams never share
+// an event table; it routes the thread's next plain lrpx_vgg16_relevance calls through opts.layer_ms
+static thread_local int tl_timing = 0;
+static thread_local float tl_ms[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
     size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], first6, first6p, total;
@@ -308,21 +325,25 @@ int lrpx_conv_kc(int hw, int taps, int cin) {
 int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream) { return conv_dispatch(d, (hipStream_t)stream); }
 
 int lrpx_set_bf16x6(int enable) {
-    const int prev = g_mode >= 1;
-    if (enable >= 0) g_mode = enable ? 1 : 0;
-    return prev;
+    if (enable >= 0) return g_default_mode.exchange(enable ? 1 : 0) >= 1;
+    return g_default_mode.load() >= 1;
 }
 
 int lrpx_set_forward_f16(int enable) {
-    const int prev = g_fwd_f16;
-    if (enable >= 0) g_fwd_f16 = enable ? 1 : 0;
-    return prev;
+    if (enable >= 0) return g_default_fwd_f16.exchange(enable ? 1 : 0);
+    return g_default_fwd_f16.load();
 }
 
 int lrpx_set_conv_mode(int mode) {
-    const int prev = g_mode;
-    if (mode >= 0) g_mode = mode > 3 ? 3 : mode;
-    return prev;
+    if (mode >= 0) return g_default_mode.exchange(mode > 3 ? 3 : mode);
+    return g_default_mode.load();
+}
+
+int lrpx_vgg16_resolve_opts(const lrpx_vgg16_opts* opts, int* conv_mode, int* forward_f16) {
+    const VggCtx c = resolve_ctx(opts);
+    if (conv_mode) *conv_mode = c.mode;
+    if (forward_f16) *forward_f16 = c.fwd_f16;
+    return LRPX_OK;
 }
 
 size_t lrpx_vgg16_packed_bytes(void) { return vgg_packed_layout().total * sizeof(float); }
@@ -407,12 +428,20 @@ const float* lrpx_vgg16_trace_features(const void* trace, int n_img) {
 
 int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, void* trace, float* feat_nhwc,
                        void* stream) {
+    return lrpx_vgg16_forward_ex(packed, img_nchw, n_img, trace, feat_nhwc, nullptr, stream);
+}
+
+int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, void* trace, float* feat_nhwc,
+                          const lrpx_vgg16_opts* opts, void* stream) {
     LRPX_REQUIRE(packed && img_nchw && trace && n_img > 0, "vgg16_forward: bad arguments");
+    const VggCtx cx = resolve_ctx(opts);
+    const int mode = cx.mode, fwd_f16 = cx.fwd_f16;      // this call's values
+    const bool use_bf16x6 = cx.bf16x6();
     const VggPacked p = vgg_packed_layout();
     const VggTrace t = vgg_trace_layout(n_img);
     const float* pk = (const float*)packed;
     float* tr = (float*)trace;
-    if (g_fwd_f16 && g_mode >= 2 && hipMemsetAsync(tr + t.famax, 0, (size_t)18 * n_img * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+    if (fwd_f16 && mode >= 2 && hipMemsetAsync(tr + t.famax, 0, (size_t)18 * n_img * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
         set_error("vgg16_forward: cannot zero the amax words");
         return LRPX_ELAUNCH;
     }
@@ -426,14 +455,14 @@ int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, voi
             d.n_maps = n_img; d.hw = L.hw; d.cin = cin_pad(l); d.n_oc = 2 * L.cout; d.taps = 9;
             d.epi = EPI_FWD_DUAL; d.oc_split = L.cout; d.bias = pk + p.bias[l];
             d.out0 = tr + t.act[l + 1]; d.out1 = tr + t.zpos[l];
-            if (g_fwd_f16 && g_mode >= 2 && l >= 1) {
+            if (fwd_f16 && mode >= 2 && l >= 1) {
                 // fp16 split products (conv_f16x3.h): operand scale = max of the layer input per image; a max-pool keeps it
                 unsigned* fam = reinterpret_cast<unsigned*>(tr + t.famax);
                 const int in_l = kVgg[l - 1].conv ? l : l - 1;
                 if (l == 1) LRPX_TRY(lrpx_amax_maps(tr + t.act[1], n_img, (long)L.hw * L.hw * L.cin, fam + (size_t)1 * n_img, stream));
                 d.f16x3 = 1; d.wpacked = pk + p.fwdh[l];
                 d.in_amax = fam + (size_t)in_l * n_img; d.out0_amax = fam + (size_t)(l + 1) * n_img;
-            } else if (g_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
+            } else if (use_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
             LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
         } else {
             LRPX_TRY(lrpx_maxpool2x2_fwd(tr + t.act[l], tr + t.act[l + 1], n_img, L.hw, L.hw, L.cin, stream));
@@ -452,8 +481,52 @@ int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, voi
 
 int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const float* r_feat_nhwc,
                          const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream) {
+    if (tl_timing) {       // legacy per-thread profiling switch: this call records and waits for its own events
+        lrpx_vgg16_opts o = {-1, -1, tl_ms};
+        return lrpx_vgg16_relevance_ex(packed, trace, n_img, r_feat_nhwc, map2img, n_maps, workspace, out_nchw, &o, stream);
+    }
+    return lrpx_vgg16_relevance_ex(packed, trace, n_img, r_feat_nhwc, map2img, n_maps, workspace, out_nchw, nullptr, stream);
+}
+
+// per-call HIP events around the conv launches of one relevance pass (opts.layer_ms)
+struct LayerTimer {
+    hipEvent_t ev[17][2];
+    bool made = false, valid[17] = {};
+    int begin() {
+        for (int l = 0; l < 17; ++l)
+            for (int k = 0; k < 2; ++k)
+                if (hipEventCreate(&ev[l][k]) != hipSuccess) { set_error("vgg16_relevance: hipEventCreate failed"); return LRPX_ELAUNCH; }
+        made = true;
+        return LRPX_OK;
+    }
+    int finish(float* ms17) {       // waits for the recorded events, then releases them
+        int rc = LRPX_OK;
+        for (int l = 0; l < 17; ++l) {
+            ms17[l] = 0.f;
+            if (valid[l] && (hipEventSynchronize(ev[l][1]) != hipSuccess ||
+                             hipEventElapsedTime(&ms17[l], ev[l][0], ev[l][1]) != hipSuccess)) {
+                set_error("vgg16_relevance: event query failed");
+                rc = LRPX_ELAUNCH;
+            }
+        }
+        return rc;
+    }
+    ~LayerTimer() {
+        if (made)
+            for (int l = 0; l < 17; ++l)
+                for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ev[l][k]);
+    }
+};
+
+int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, const float* r_feat_nhwc,
+                            const int32_t* map2img, int n_maps, void* workspace, float* out_nchw,
+                            const lrpx_vgg16_opts* opts, void* stream) {
     LRPX_REQUIRE(packed && trace && r_feat_nhwc && workspace && out_nchw && n_maps > 0 && n_img > 0,
                  "vgg16_relevance: bad arguments");
+    const VggCtx cx = resolve_ctx(opts);
+    const int mode = cx.mode;
+    const bool use_bf16x6 = cx.bf16x6();
+    LayerTimer timer;
     LRPX_REQUIRE(map2img || n_maps == n_img, "vgg16_relevance: map2img is required when n_maps != n_img");
     const VggPacked p = vgg_packed_layout();
     const VggTrace t = vgg_trace_layout(n_img);
@@ -466,7 +539,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
     int cur = 0;
     int cur_chunked = 0;   // S[cur] is stored in K-chunks (written so by the pool kernel for the 224^2 / 112^2 layers)
     // f16x3 mode: amax[l*n_maps + n] = bits of max|S| of map n in the S tensor that conv layer l consumes
-    const bool h3 = g_mode >= 2;
+    const bool h3 = mode >= 2;
     unsigned* amax = h3 ? reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps) : nullptr;
     if (h3 && hipMemsetAsync(amax, 0, (size_t)kNL * n_maps * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
         set_error("vgg16_relevance: cannot zero the amax words");
@@ -475,21 +548,13 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
     // S_16 = R_feat / safe(Z+_16)
     LRPX_TRY(divide_stab_amax(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, STAB_SAFE,
                               h3 ? amax + (size_t)16 * n_maps : nullptr, (hipStream_t)stream));
-    const bool timing = g_timing != 0;
-    if (timing) {
-        if (!g_ev_made) {
-            for (int l = 0; l < kNL; ++l)
-                for (int k = 0; k < 2; ++k)
-                    if (hipEventCreate(&g_ev[l][k]) != hipSuccess) { set_error("vgg16_relevance: hipEventCreate failed"); return LRPX_ELAUNCH; }
-            g_ev_made = true;
-        }
-        for (int l = 0; l < kNL; ++l) g_ev_valid[l] = false;
-    }
+    const bool timing = cx.layer_ms != nullptr;
+    if (timing) LRPX_TRY(timer.begin());
 #define LRPX_TIMED_DISPATCH(L_, DESC)                                                   \
     do {                                                                                \
-        if (timing) (void)hipEventRecord(g_ev[L_][0], (hipStream_t)stream);             \
+        if (timing) (void)hipEventRecord(timer.ev[L_][0], (hipStream_t)stream);         \
         LRPX_TRY(conv_dispatch(DESC, (hipStream_t)stream));                             \
-        if (timing) { (void)hipEventRecord(g_ev[L_][1], (hipStream_t)stream); g_ev_valid[L_] = true; } \
+        if (timing) { (void)hipEventRecord(timer.ev[L_][1], (hipStream_t)stream); timer.valid[L_] = true; } \
     } while (0)
     for (int l = kNL - 1; l >= 0; --l) {
         const VggLayer& L = kVgg[l];
@@ -514,21 +579,21 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             d.tile_group = (n_maps % n_img == 0) ? n_maps / n_img : 0;
             // mode 3: cross products on the fp8 matrix cores
             const bool pooled_in = l + 1 < kNL && !kVgg[l + 1].conv;
-            if (g_mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
+            if (mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
             // under a pool: S[cur] is the low-resolution tensor the conv above the pool wrote, unpooled while staged
             if (pooled_in) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
 #ifndef LRPX_F8_POOL28
             // ... except conv4_3 in mode 3: the map-straddling pooled-input 28x28 kernel spills 40 VGPRs with the fp8
             // operands (2.98 ms; with fp16 cross products 2.75 ms), so S is unpooled by a scatter kernel (0.5 GB written)
             // and the conv runs on the plain 28x28 F8 kernel (2.13 ms)
-            if (g_mode == 3 && pooled_in && L.hw == 28) {
+            if (mode == 3 && pooled_in && L.hw == 28) {
                 LRPX_TRY(lrpx_unpool_winner(S[cur], d.pool_am, map2img, S[cur ^ 1], n_maps, L.hw / 2, L.hw / 2, L.cout, stream));
                 cur ^= 1;
                 d.in = S[cur]; d.pool_am = nullptr;
             }
 #endif
         }
-        else if (g_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
+        else if (use_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
         if (kVgg[l - 1].conv) {
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
             d.out1 = S[cur ^ 1];
@@ -551,7 +616,7 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
             // wide maps: hand the conv below its input in K-chunks (32-byte pixel slices would drag every 128-byte
             // line through the fabric four times: measured L2 hit 36 %, 3x the unique bytes on conv1_2)
             const int below_hw = 2 * L.hw;
-            const int chunk = below_hw < 112 ? 0 : (g_bf16x6 ? 16 : lrpx_conv_kc(below_hw, 9, L.cin));
+            const int chunk = below_hw < 112 ? 0 : (use_bf16x6 ? 16 : lrpx_conv_kc(below_hw, 9, L.cin));
             LRPX_TRY(maxpool_relevance_amax(tr + t.act[l - 1], R, tr + t.zpos[l - 2], map2img, nullptr, S[cur ^ 1],
                                             n_maps, L.hw, L.hw, L.cin, chunk,
                                             h3 ? amax + (size_t)(l - 2) * n_maps : nullptr, (hipStream_t)stream));
@@ -559,22 +624,18 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
         }
         cur ^= 1;
     }
+    if (timing) LRPX_TRY(timer.finish(cx.layer_ms));
     return LRPX_OK;
 }
 
 int lrpx_vgg16_layer_timing(int enable, float* ms17) {
-    if (ms17) {
-        for (int l = 0; l < kNL; ++l) {
-            ms17[l] = 0.f;
-            if (g_ev_made && g_ev_valid[l]) {
-                if (hipEventSynchronize(g_ev[l][1]) != hipSuccess || hipEventElapsedTime(&ms17[l], g_ev[l][0], g_ev[l][1]) != hipSuccess) {
-                    set_error("vgg16_layer_timing: event query failed");
-                    return LRPX_ELAUNCH;
-                }
-            }
-        }
+    if (ms17)
+        for (int l = 0; l < kNL; ++l) ms17[l] = tl_ms[l];
+    if (enable >= 0) {
+        tl_timing = enable ? 1 : 0;
+        if (enable)
+            for (int l = 0; l < kNL; ++l) tl_ms[l] = 0.f;
     }
-    if (enable >= 0) g_timing = enable ? 1 : 0;
     return LRPX_OK;
 }
 
@@ -582,9 +643,11 @@ int lrpx_vgg16_layer_timing(int enable, float* ms17) {
 
 // guided backprop (plain = 0) or the plain autograd gradient (plain = 1) of the encoder output w.r.t. the image
 static int vgg16_backprop(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
-                          const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, int plain, void* stream) {
+                          const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, int plain,
+                          const lrpx_vgg16_opts* opts, void* stream) {
     LRPX_REQUIRE(packed && trace && d_feat_nhwc && workspace && out_nchw && n_maps > 0 && n_img > 0,
                  "vgg16_guided_backprop: bad arguments");
+    const int mode = resolve_ctx(opts).mode;
     LRPX_REQUIRE(map2img || n_maps == n_img, "vgg16_guided_backprop: map2img is required when n_maps != n_img");
     const VggPacked p = vgg_packed_layout();
     const VggTrace t = vgg_trace_layout(n_img);
@@ -609,12 +672,12 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
         d.in = G[cur]; d.wpacked = pk + p.bwdp[l];
         d.n_maps = n_maps; d.hw = L.hw; d.cin = L.cout; d.taps = 9; d.map2img = map2img;
         d.n_oc = L.cin; d.oc_split = L.cin;
-        if (g_mode >= 2) {
+        if (mode >= 2) {
             // fp16 split-product kernels: operand scale = per-map maximum of the incoming gradient (one streaming read)
             unsigned* gam = reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps) + (size_t)l * n_maps;
             LRPX_TRY(lrpx_amax_maps(G[cur], n_maps, (long)L.hw * L.hw * L.cout, gam, st));
             d.f16x3 = 1; d.wpacked = pk + p.bwdph[l]; d.in_amax = gam;
-            if (g_mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwdp8[l]; }      // cross products on the fp8 matrix cores
+            if (mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwdp8[l]; }      // cross products on the fp8 matrix cores
         }
         if (kVgg[l - 1].conv) {
             d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];      // ReLU hook of conv l-1 fused
@@ -634,12 +697,24 @@ extern "C" {
 
 int lrpx_vgg16_guided_backprop(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
                                const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream) {
-    return vgg16_backprop(packed, trace, n_img, d_feat_nhwc, map2img, n_maps, workspace, out_nchw, 0, stream);
+    return vgg16_backprop(packed, trace, n_img, d_feat_nhwc, map2img, n_maps, workspace, out_nchw, 0, nullptr, stream);
+}
+
+int lrpx_vgg16_guided_backprop_ex(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                                  const int32_t* map2img, int n_maps, void* workspace, float* out_nchw,
+                                  const lrpx_vgg16_opts* opts, void* stream) {
+    return vgg16_backprop(packed, trace, n_img, d_feat_nhwc, map2img, n_maps, workspace, out_nchw, 0, opts, stream);
 }
 
 int lrpx_vgg16_gradient(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
                         const int32_t* map2img, int n_maps, void* workspace, float* out_nchw, void* stream) {
-    return vgg16_backprop(packed, trace, n_img, d_feat_nhwc, map2img, n_maps, workspace, out_nchw, 1, stream);
+    return vgg16_backprop(packed, trace, n_img, d_feat_nhwc, map2img, n_maps, workspace, out_nchw, 1, nullptr, stream);
+}
+
+int lrpx_vgg16_gradient_ex(const void* packed, const void* trace, int n_img, const float* d_feat_nhwc,
+                           const int32_t* map2img, int n_maps, void* workspace, float* out_nchw,
+                           const lrpx_vgg16_opts* opts, void* stream) {
+    return vgg16_backprop(packed, trace, n_img, d_feat_nhwc, map2img, n_maps, workspace, out_nchw, 1, opts, stream);
 }
 
 }  // extern "C"

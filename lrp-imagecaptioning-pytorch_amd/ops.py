@@ -155,6 +155,17 @@ class Vgg16:
         self.trace = None
         self.n_img = 0
         self._ws = None
+        # per-context matrix-core mode (None = the process default of lrpx_set_conv_mode / lrpx_set_forward_f16): carried in
+        # every call (lrpx_vgg16_opts), so contexts with different modes can be in flight on different streams / threads
+        self.conv_mode = None
+        self.forward_f16 = None
+
+    def _opts(self, layer_ms=None):
+        o = _lib.VggOpts()
+        o.conv_mode = -1 if self.conv_mode is None else int(self.conv_mode)
+        o.forward_f16 = -1 if self.forward_f16 is None else int(self.forward_f16)
+        o.layer_ms = layer_ms
+        return C.byref(o)
 
     def replica(self):
         """Same packed weights, own trace / workspace buffers (for a second batch in flight on another stream)."""
@@ -175,8 +186,8 @@ class Vgg16:
         if self.trace is None or self.trace.numel() < need or self.n_img != n:
             self.trace = torch.empty(need, dtype=torch.float32, device=self.device)
         self.n_img = n
-        check(lib.lrpx_vgg16_forward(ptr(self.packed), ptr(img_nchw.contiguous()), n, ptr(self.trace), None,
-                                     stream_ptr()))
+        check(lib.lrpx_vgg16_forward_ex(ptr(self.packed), ptr(img_nchw.contiguous()), n, ptr(self.trace), None,
+                                        self._opts(), stream_ptr()))
         off = lib.lrpx_vgg16_trace_features(ptr(self.trace), n) - self.trace.data_ptr()
         return self.trace[off // 4: off // 4 + n * 196 * 512].view(n, 196, 512)
 
@@ -213,9 +224,9 @@ class Vgg16:
     def gradient(self, d_feat_nhwc, map2img=None, out=None):
         """explain_cnn of the plain-gradient explainer (models/gridTDmodel.py:1507-1521): the autograd gradient of the
         encoder output w.r.t. the image for (N,196,512) output gradients -> (N,3,224,224)."""
-        return self.guided_backprop(d_feat_nhwc, map2img, out, _fn="lrpx_vgg16_gradient")
+        return self.guided_backprop(d_feat_nhwc, map2img, out, _fn="lrpx_vgg16_gradient_ex")
 
-    def guided_backprop(self, d_feat_nhwc, map2img=None, out=None, _fn="lrpx_vgg16_guided_backprop"):
+    def guided_backprop(self, d_feat_nhwc, map2img=None, out=None, _fn="lrpx_vgg16_guided_backprop_ex"):
         """explain_cnn of the guided-backprop explainer (models/gridTDmodel.py:1702-1723): (N,196,512) gradient at
         the encoder output -> (N,3,224,224) image gradient with the guided ReLU rule."""
         lib = _lib.load()
@@ -227,13 +238,15 @@ class Vgg16:
         if out is None:
             out = torch.empty(n_maps, 3, 224, 224, dtype=torch.float32, device=self.device)
         check(getattr(lib, _fn)(ptr(self.packed), ptr(self.trace), self.n_img, ptr(d_feat_nhwc.contiguous()),
-                                ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
+                                ptr(map2img), n_maps, ptr(self._ws), ptr(out), self._opts(), stream_ptr()))
         return out
 
-    def relevance(self, r_feat_nhwc, map2img=None, out=None, streams=1):
+    def relevance(self, r_feat_nhwc, map2img=None, out=None, streams=1, layer_ms=None):
         """compute_lrp (LRPtools/lrp_wrapper.py:63-87) for N maps: (N,196,512) -> (N,3,224,224).
         streams=2 splits the maps over two HIP streams (maps are independent): the HBM-bound pool / first-layer
-        kernels and the tail wave of each MFMA launch of one half overlap with MFMA work of the other half."""
+        kernels and the tail wave of each MFMA launch of one half overlap with MFMA work of the other half.
+        layer_ms: a ctypes (c_float * 17) array - this call then times its conv launches with HIP events of its own and
+        waits for them (profiling; one stream only)."""
         lib = _lib.load()
         n_maps = r_feat_nhwc.shape[0]
         r_feat_nhwc = r_feat_nhwc.contiguous()
@@ -244,8 +257,15 @@ class Vgg16:
             if self._ws is None or self._ws.numel() < need:
                 self._ws = None
                 self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
-            check(lib.lrpx_vgg16_relevance(ptr(self.packed), ptr(self.trace), self.n_img, ptr(r_feat_nhwc),
-                                           ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
+            if layer_ms is None and self.conv_mode is None:
+                # plain entry point: honours the thread's legacy lrpx_vgg16_layer_timing switch
+                check(lib.lrpx_vgg16_relevance(ptr(self.packed), ptr(self.trace), self.n_img, ptr(r_feat_nhwc),
+                                               ptr(map2img), n_maps, ptr(self._ws), ptr(out), stream_ptr()))
+            else:
+                lm = None if layer_ms is None else C.cast(layer_ms, C.POINTER(C.c_float))
+                check(lib.lrpx_vgg16_relevance_ex(ptr(self.packed), ptr(self.trace), self.n_img, ptr(r_feat_nhwc),
+                                                  ptr(map2img), n_maps, ptr(self._ws), ptr(out), self._opts(lm),
+                                                  stream_ptr()))
             return out
         per = -(-n_maps // streams)
         need = lib.lrpx_vgg16_workspace_bytes(per) // 4
@@ -260,9 +280,9 @@ class Vgg16:
             st = self._side[i]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                check(lib.lrpx_vgg16_relevance(ptr(self.packed), ptr(self.trace), self.n_img, ptr(r_feat_nhwc[lo:hi]),
-                                               ptr(map2img[lo:hi]), hi - lo, ptr(self._ws_multi[i]), ptr(out[lo:hi]),
-                                               C.c_void_p(st.cuda_stream)))
+                check(lib.lrpx_vgg16_relevance_ex(ptr(self.packed), ptr(self.trace), self.n_img, ptr(r_feat_nhwc[lo:hi]),
+                                                  ptr(map2img[lo:hi]), hi - lo, ptr(self._ws_multi[i]), ptr(out[lo:hi]),
+                                                  self._opts(), C.c_void_p(st.cuda_stream)))
         for i in range(streams):
             cur.wait_stream(self._side[i])
         return out

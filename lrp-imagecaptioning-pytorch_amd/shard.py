@@ -24,7 +24,9 @@ def balanced_bounds(lens, world):
     for r in range(world):
         target = total * (r + 1) / world
         hi = lo
-        while hi < len(cost) and (acc + cost[hi] <= target + 1e-9 or hi == lo) and (len(cost) - hi) > (world - 1 - r):
+        # take the next image while that brings the running cost closer to this rank's share of the total
+        while hi < len(cost) and (acc + cost[hi] <= target + 1e-9 or target - acc > acc + cost[hi] - target or hi == lo) \
+                and (len(cost) - hi) > (world - 1 - r):
             acc += cost[hi]
             hi += 1
         if r == world - 1:
@@ -54,13 +56,23 @@ def gather_to_rank0(local, group=None):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
 
 
-def explain_sharded(explain_fn, images, captions, gather=True, group=None):
+def explain_sharded(explain_fn, images, captions, gather=True, group=None, lens=None):
     """Run `explain_fn(images_shard, captions_shard) -> (maps, r_words)` on this rank's block of the global
-    batch; with gather=True rank 0 gets the whole batch's results in input order."""
+    batch; with gather=True rank 0 gets the whole batch's results in input order.
+    lens (optional, one caption length per image; captions are then padded to a common width): the blocks are cut by
+    COST (`balanced_bounds`: ~T(T+1)/2 decoder rows + one CNN pass per word) instead of by count, so a rank that holds the
+    long captions holds fewer images (SURVEY §8(e) load balance), and `explain_fn(images, captions, lens_shard)` receives
+    its block's lengths."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lo, hi = shard_bounds(images.shape[0], world, rank)
-    maps, r_words = explain_fn(images[lo:hi], captions[lo:hi])
+    if lens is None:
+        lo, hi = shard_bounds(images.shape[0], world, rank)
+        maps, r_words = explain_fn(images[lo:hi], captions[lo:hi])
+    else:
+        lens = [int(t) for t in lens]
+        assert len(lens) == images.shape[0], "one caption length per image"
+        lo, hi = balanced_bounds(lens, world)[rank]
+        maps, r_words = explain_fn(images[lo:hi], captions[lo:hi], lens[lo:hi])
     if not gather:
         return maps, r_words
     return gather_to_rank0(maps, group), gather_to_rank0(r_words, group)

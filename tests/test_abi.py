@@ -56,3 +56,58 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liblrpx.so")
     with pytest.raises(_lib.LrpxError):
         _lib.load()
+
+
+def test_per_call_context_is_not_affected_by_other_threads_setters():
+    """SURVEY §8(b) threading: the conv mode / forward switch travel per call (lrpx_vgg16_opts); the setters only move the
+    process defaults.  Two threads with opts of their own resolve THEIR values 20 000 times each while a third thread keeps
+    flipping the defaults; a thread without opts sees one of the defaults, never a torn value.  (Host logic: no device.)"""
+    import ctypes as C
+    import threading
+    from lrp_amd import _lib
+    lib = _lib.load()
+    prev_mode, prev_fwd = lib.lrpx_set_conv_mode(-1), lib.lrpx_set_forward_f16(-1)
+    stop = threading.Event()
+    bad = []
+
+    def flipper():
+        k = 0
+        while not stop.is_set():
+            lib.lrpx_set_conv_mode(k % 4)
+            lib.lrpx_set_forward_f16(k % 2)
+            k += 1
+
+    def pinned(mode, fwd):
+        o = _lib.VggOpts(mode, fwd, None)
+        m, f = C.c_int(-9), C.c_int(-9)
+        for _ in range(20000):
+            lib.lrpx_vgg16_resolve_opts(C.byref(o), C.byref(m), C.byref(f))
+            if (m.value, f.value) != (mode, fwd):
+                bad.append((mode, fwd, m.value, f.value))
+                return
+
+    def defaults():
+        m, f = C.c_int(-9), C.c_int(-9)
+        for _ in range(20000):
+            lib.lrpx_vgg16_resolve_opts(None, C.byref(m), C.byref(f))
+            if m.value not in (0, 1, 2, 3) or f.value not in (0, 1):
+                bad.append(("default", m.value, f.value))
+                return
+    ts = [threading.Thread(target=pinned, args=(1, 0)), threading.Thread(target=pinned, args=(2, 1)),
+          threading.Thread(target=defaults)]
+    fl = threading.Thread(target=flipper)
+    fl.start()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    fl.join()
+    lib.lrpx_set_conv_mode(prev_mode)
+    lib.lrpx_set_forward_f16(prev_fwd)
+    assert not bad, bad[:3]
+    # half-specified opts: the unspecified half comes from the defaults
+    o = _lib.VggOpts(-1, 0, None)
+    m, f = C.c_int(), C.c_int()
+    lib.lrpx_vgg16_resolve_opts(C.byref(o), C.byref(m), C.byref(f))
+    assert (m.value, f.value) == (prev_mode, 0)

@@ -654,3 +654,46 @@ def test_rel_mul_rejects_two_outputs_and_never_writes_past_the_last_map(ops):
         assert torch.isfinite(out).all() and (out != 12345.0).all()
         for i in range(n_maps):
             assert oamax[i:i + 1].view(torch.float32).item() == out[i].abs().max().item()
+
+
+def test_per_context_conv_mode_in_flight_on_two_streams(ops, gridtd_case):
+    """the conv mode travels per call (lrpx_vgg16_opts): two contexts over the same weights with DIFFERENT modes run
+    interleaved on two streams and each reproduces, bit for bit, what a process-wide setter run of its mode gives - while
+    the process default is a third mode; the per-call layer timing (opts.layer_ms) returns one time per conv launch"""
+    import ctypes as C
+    from lrp_amd import _lib
+    lib = _lib.load()
+    g, sd, img = gridtd_case
+    a = _vgg(ops, sd)
+    b = a.replica()
+    imgs = img.cuda()
+    r_feat = torch.cat([to_nhwc(torch.from_numpy(g[f"r_feat_{t}"])) for t in range(3)]).cuda()
+    m2i = torch.zeros(3, dtype=torch.int32, device="cuda")
+    want = {}
+    prev = lib.lrpx_set_conv_mode(-1)
+    try:
+        for mode in (1, 3):
+            lib.lrpx_set_conv_mode(mode)
+            a.forward(imgs)
+            want[mode] = a.relevance(r_feat, m2i).clone()
+        lib.lrpx_set_conv_mode(0)                       # the default is neither of the two
+        a.conv_mode, b.conv_mode = 3, 1
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        outs = {}
+        for _ in range(2):
+            with torch.cuda.stream(sa):
+                a.forward(imgs)
+                outs[3] = a.relevance(r_feat, m2i)
+            with torch.cuda.stream(sb):
+                b.forward(imgs)
+                outs[1] = b.relevance(r_feat, m2i)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[3], want[3]) and torch.equal(outs[1], want[1])
+        assert not torch.equal(want[1], want[3])
+        ms = (C.c_float * 17)()
+        a.relevance(r_feat, m2i, layer_ms=ms)
+        convs = [l for l in range(1, 17) if ops.Vgg16.IS_CONV[l]]
+        assert all(ms[l] > 0 for l in convs) and ms[0] == 0 and all(ms[l] == 0 for l in (2, 5, 9, 13))
+    finally:
+        lib.lrpx_set_conv_mode(prev)

@@ -36,15 +36,33 @@ def _fake_explain(images, captions):
     return maps.expand(-1, -1, 4, 4).contiguous(), captions[:, 1:].float()
 
 
-def _worker(rank, world, port, n_img, out):
+def _fake_explain_lens(images, captions, lens):
+    """as above with per-image caption lengths: words past an image's length contribute nothing (as the engines treat `lens`)"""
+    keep = (torch.arange(captions.shape[1] - 1).view(1, -1) < torch.tensor(lens).view(-1, 1)).float()
+    rw = captions[:, 1:].float() * keep
+    maps = images.mean(dim=(2, 3), keepdim=True) * rw.sum(1).view(-1, 1, 1, 1)
+    return maps.expand(-1, -1, 4, 4).contiguous(), rw
+
+
+def _worker(rank, world, port, n_img, out, lens=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.Generator().manual_seed(0)
     images = torch.randn(n_img, 3, 8, 8, generator=g)
-    caps = torch.randint(1, 50, (n_img, 5), generator=g)
-    maps, rw = shard.explain_sharded(_fake_explain, images, caps, gather=True)
+    caps = torch.randint(1, 50, (n_img, 5 if lens is None else max(lens) + 1), generator=g)
+    if lens is None:
+        maps, rw = shard.explain_sharded(_fake_explain, images, caps, gather=True)
+    else:
+        seen = []
+
+        def fn(im, cp, ln):
+            seen.append(len(ln))
+            return _fake_explain_lens(im, cp, ln)
+        maps, rw = shard.explain_sharded(fn, images, caps, gather=True, lens=lens)
+        lo, hi = shard.balanced_bounds(lens, world)[rank]
+        assert seen == [hi - lo]                          # this rank explained exactly its cost-balanced block
     if rank == 0:
-        want_m, want_w = _fake_explain(images, caps)
+        want_m, want_w = _fake_explain(images, caps) if lens is None else _fake_explain_lens(images, caps, lens)
         out.put((torch.equal(maps, want_m), torch.equal(rw, want_w), tuple(maps.shape)))
     else:
         assert maps is None and rw is None
@@ -67,3 +85,25 @@ def test_two_ranks_gloo(n_img):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok_m and ok_w and shape[0] == n_img
+
+
+def test_two_ranks_gloo_unequal_caption_lengths():
+    """SURVEY §8(e) load balance: with caption lengths the blocks are cut by cost - rank 0 gets two of the three 20-word
+    captions (cost 2020), rank 1 the third and the five short ones (1598; by count it would be 3232 / 386) - and rank 0
+    still receives everything in input order"""
+    lens = [20, 20, 20, 3, 2, 4, 3, 2]
+    b = shard.balanced_bounds(lens, 2)
+    assert b == [(0, 2), (2, 8)]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, len(lens), q, lens)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok_m, ok_w, shape = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok_m and ok_w and shape[0] == len(lens)
