@@ -166,6 +166,35 @@ class AOAEngine:
             lps[:, t] = torch.where(alive, lp, torch.zeros_like(lp))
         return toks[:, 1:].contiguous(), lps
 
+    def forwardlrp_context(self, enc, captions, caption_lengths, skip_ids):
+        """The forward half of `AOAModel.forwardlrp_context` (models/aoamodel.py:628-677): teacher-forced decoding with the
+        model's own forward; every step's scores are recomputed from the fc input re-weighted by the relevance of the
+        step's arg-max word (`get_lrp_weight_step`, :597-626 - handed the RAW scores here, unlike `sample_lrp`).  Dropout is
+        the identity (evaluation mode).  Returns (predictions (B,L,V), weighted_predictions (B,L,V), L)."""
+        lib = _lib.load()
+        B, H = enc["B"], self.H
+        L = int(max(caption_lengths)) - 1
+        dev = self.device
+        captions = captions.to(dev, torch.int64).contiguous()
+        assert captions.shape[0] == B and captions.shape[1] >= L
+        skip = torch.zeros(self.V, dtype=torch.uint8, device=dev)
+        skip[torch.as_tensor(sorted(int(i) for i in skip_ids), dtype=torch.int64, device=dev)] = 1
+        toks = captions[:, :L + 1].contiguous() if captions.shape[1] > L else torch.cat(
+            [captions, captions.new_zeros(B, 1)], 1).contiguous()
+        tr = self._alloc_trace(B, L, enc["P"])
+        hcw = torch.empty(B, H, device=dev)
+        preds = torch.empty(B, L, self.V, device=dev)
+        wpreds = torch.empty(B, L, self.V, device=dev)
+        for t in range(L):
+            self._step(tr, enc, t, toks, self.bcat_model)
+            pred = self.logits(tr["hc"][:, t].contiguous())
+            check(lib.lrpx_lrp_reweight_rows(ptr(pred), self.V, self.V, ptr_at(tr["h"], (t + 1) * H), (L + 1) * H,
+                                             ptr_at(tr["c_aoa"], t * H), L * H, ptr(self.sd["fc.weight"]), ptr(skip),
+                                             ptr(hcw), B, H, 0, stream_ptr()))
+            preds[:, t] = pred
+            wpreds[:, t] = self.logits(hcw)
+        return preds, wpreds, L
+
     def trace(self, enc, captions, model_bias=False, predictions=True, grad=False):
         """grad=True: the trace of the gradient explainers (:1309-1376): correct LSTM bias, output gate and aoa gate kept."""
         model_bias = model_bias or grad

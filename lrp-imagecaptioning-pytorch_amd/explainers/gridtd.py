@@ -242,6 +242,46 @@ class GridTDEngine:
             lps[:, t] = torch.where(alive, lp, torch.zeros_like(lp))
         return toks[:, 1:].contiguous(), lps
 
+    def forwardlrp_context(self, enc, captions, caption_lengths, skip_ids):
+        """The forward half of `GridTDModel.forwardlrp_context` (models/gridTDmodel.py:579-630; LRP-inference fine-tuning,
+        SURVEY §8(f) row 2): teacher-forced decoding with the model's own forward (sentinel gate on the NEW h1, :617) where
+        every step's scores are recomputed from the fc input re-weighted by the relevance of the step's arg-max word
+        (`get_lrp_weight_step`, :548-577).  captions (B, >= L) int64 incl. <start> in column 0; L = max(caption_lengths) - 1.
+        Returns (predictions (B,L,V), weighted_predictions (B,L,V), L).  The loss and its gradients (train.py:211-263)
+        are training and stay outside the path."""
+        lib = _lib.load()
+        B, H, E = enc["B"], self.H, self.E
+        L = int(max(caption_lengths)) - 1
+        W1 = 2 * E + 2 * H
+        dev = self.device
+        captions = captions.to(dev, torch.int64).contiguous()
+        assert captions.shape[0] == B and captions.shape[1] >= L
+        skip = torch.zeros(self.V, dtype=torch.uint8, device=dev)
+        skip[torch.as_tensor(sorted(int(i) for i in skip_ids), dtype=torch.int64, device=dev)] = 1
+        toks = captions[:, :L + 1].contiguous() if captions.shape[1] > L else torch.cat(
+            [captions, captions.new_zeros(B, 1)], 1).contiguous()          # column t is the input of step t
+        tr = self._alloc_trace(B, L)
+        c = C.byref(tr["_c"])
+        xg, zg, hcw = torch.empty(B, W1, device=dev), torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+        w_gate, b_gate = self.Wcat1[4 * H:], self.bcat1[4 * H:]
+        preds = torch.empty(B, L, self.V, device=dev)
+        wpreds = torch.empty(B, L, self.V, device=dev)
+
+        def sentinel_new_h(t):
+            st = stream_ptr()
+            check(lib.lrpx_gridtd_fwd_gate_input(c, t, ptr(xg), st))
+            check(lib.lrpx_linear_small(ptr(xg), W1, ptr(w_gate), ptr(b_gate), ptr(zg), H, B, W1, H, 0, st))
+            check(lib.lrpx_gridtd_fwd_sentinel(c, t, ptr(zg), H, st))
+
+        for t in range(L):
+            self._step(tr, enc, t, toks, True, after_lstm1=sentinel_new_h)
+            pred = self.logits(tr["hc"][:, t].contiguous())
+            check(lib.lrpx_gridtd_lrp_reweight(c, t, ptr(pred), self.V, self.V, ptr(self.sd["fc.weight"]), ptr(skip),
+                                               ptr(hcw), stream_ptr()))
+            preds[:, t] = pred
+            wpreds[:, t] = self.logits(hcw)
+        return preds, wpreds, L
+
     # ------------------------------------------------------------------------------------------
     def _row_index(self, B, T):
         key = (B, T)

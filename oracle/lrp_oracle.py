@@ -379,6 +379,46 @@ def gridtd_sample_lrp(sd, img, max_length, start_id, end_id, skip_ids):
     return seq, lps
 
 
+def gridtd_forwardlrp_context(sd, img, caption, length, skip_ids):
+    """models/gridTDmodel.py:579-630 `forwardlrp_context` for one image, forward values only: teacher-forced model forward
+    (bias_ih + bias_hh, sentinel gate on the new h1 :617); per step the raw scores and the scores recomputed from the
+    LRP-reweighted fc input (:625-627).  caption: ids incl. <start>; length = caption_length - 1 steps.
+    Returns (predictions (L,V), weighted_predictions (L,V))."""
+    feats, avg, _ = vgg_forward(sd, img)
+    tr = gridtd_trace(sd, feats[0], avg[0], list(caption[:length]) + [0], model_bias=True, gate_h_new=True)
+    preds, wpreds = [], []
+    for t in range(length):
+        h2, ctx_hat = tr["h2"][t + 1], tr["ctx_hat"][t]
+        w_ctx, w_h2 = gridtd_lrp_weights(sd, tr["pred"][t], h2, ctx_hat, skip_ids)
+        preds.append(tr["pred"][t])
+        wpreds.append(sd["fc.weight"] @ (ctx_hat * w_ctx + w_h2 * h2) + sd["fc.bias"])
+    return torch.stack(preds), torch.stack(wpreds)
+
+
+def aoa_forwardlrp_context(sd, img, caption, length, skip_ids, num_head=8):
+    """models/aoamodel.py:628-677 `forwardlrp_context` for one image, forward values only; `get_lrp_weight_step`
+    (:597-626) sees the RAW scores here (`sample_lrp` hands it their log-softmax).  Dropout = identity (eval)."""
+    feats, _, _ = vgg_forward(sd, img)
+    C, hh, ww = feats.shape[1:]
+    F_pix = feats[0].reshape(C, hh * ww).t().contiguous()
+    tr = aoa_trace(sd, F_pix, list(caption[:length]) + [0], num_head=num_head, grad=True)   # model forward: bias_ih + bias_hh
+    Hd = sd["fc.weight"].shape[1]
+    preds, wpreds = [], []
+    for t in range(length):
+        h, c_aoa, pred = tr["h"][t + 1], tr["c_aoa"][t], tr["pred"][t]
+        k = int(torch.argmax(pred))
+        if k in skip_ids:
+            w_c, w_h = torch.ones(Hd), torch.ones(Hd)
+        else:
+            hc = h + c_aoa
+            r_hc = (sd["fc.weight"][k] * hc / eps_stabilise(pred[k])) * pred[k]
+            w_h = normalize_relevance(eps_identity(r_hc, h, hc))
+            w_c = normalize_relevance(eps_identity(r_hc, c_aoa, hc))
+        preds.append(pred)
+        wpreds.append(sd["fc.weight"] @ (w_c * c_aoa + h * w_h) + sd["fc.bias"])
+    return torch.stack(preds), torch.stack(wpreds)
+
+
 def gridtd_explain_wordt(sd, tr, t):
     """models/gridTDmodel.py:1014-1135 `explain_caption_wordt`.  Returns
     (r_feat (P,C) relevance of the encoder features, r_words (t+1,))."""

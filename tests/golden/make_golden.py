@@ -717,6 +717,50 @@ def gen_m4(out):
 
 
 
+def gen_forwardlrp(out, weights, seed=0, T=8, batch=2):
+    """The forward half of LRP-inference fine-tuning: `GridTDModel.forwardlrp_context` (models/gridTDmodel.py:579-630) and
+    `AOAModel.forwardlrp_context` (models/aoamodel.py:628-677) in evaluation mode (dropout = identity) on a teacher-forced
+    batch: raw and LRP-reweighted scores of every step.  Stored: every 13th vocabulary column, the arg-max of both per step,
+    two full rows.  A second gridTD case makes the most frequent arg-max word a stop word (weights of 1 -> both scores equal)."""
+    import models.gridTDmodel as gtd
+    import models.aoamodel as aoa
+    g = dict(seed=np.int64(seed), T=np.int64(T), batch=np.int64(batch))
+    imgs = torch.from_numpy(weights.make_images(seed + 5, batch))
+    for tag, mod, V, mk, ctor in (("grid", gtd, 9586, weights.make_gridtd_state, lambda V: gtd.GridTDModel(512, 512, V, 'vgg16')),
+                                  ("aoa", aoa, 11027, weights.make_aoa_state, lambda V: aoa.AOAModel(512, 512, 8, V, 'vgg16'))):
+        model = ctor(V)
+        model.load_state_dict(to_torch_sd(mk(seed=seed, vocab_size=V)))
+        model.eval()
+        wm = weights.make_word_map(V)
+        rev = {v: k for k, v in wm.items()}
+        caps = torch.from_numpy(weights.make_captions(seed + 6, batch, T, V))
+        lengths = [T + 1, T - 1]                       # (the reference only uses max(lengths) - 1)
+        special = [wm[k] for k in ('<start>', '<end>', '<pad>', '<unk>')]
+        with torch.no_grad():
+            p, wp, L = model.forwardlrp_context(imgs, caps, lengths, rev)
+            cases = [("", p, wp, special)]
+            if tag == "grid":
+                ids, counts = np.unique(p.argmax(-1).numpy(), return_counts=True)
+                stop_id = int(ids[np.argmax(counts)])
+                mod.STOP_WORDS = [rev[stop_id]]
+                p2, wp2, _ = model.forwardlrp_context(imgs, caps, lengths, rev)
+                mod.STOP_WORDS = []
+                cases.append(("2", p2, wp2, special + [stop_id]))
+        g[f"{tag}_V"], g[f"{tag}_caption"], g[f"{tag}_lengths"], g[f"{tag}_L"] = np.int64(V), caps.numpy(), np.array(lengths), np.int64(L)
+        for sfx, p_, wp_, skip in cases:
+            g[f"{tag}_pred_sub{sfx}"] = p_[:, :, ::13].numpy()
+            g[f"{tag}_wpred_sub{sfx}"] = wp_[:, :, ::13].numpy()
+            g[f"{tag}_pred_argmax{sfx}"] = p_.argmax(-1).numpy()
+            g[f"{tag}_wpred_argmax{sfx}"] = wp_.argmax(-1).numpy()
+            g[f"{tag}_pred_row{sfx}"] = p_[1, L - 1].numpy()
+            g[f"{tag}_wpred_row{sfx}"] = wp_[1, L - 1].numpy()
+            g[f"{tag}_skip{sfx}"] = np.array(skip, np.int64)
+        print(tag, "forwardlrp_context L =", L, "argmax", g[f"{tag}_pred_argmax"].tolist(), g[f"{tag}_wpred_argmax"].tolist())
+    np.savez(os.path.join(out, "forwardlrp.npz"), **g)
+    print("forwardlrp.npz written:", sum(v.nbytes for v in g.values() if hasattr(v, "nbytes")) / 1e6, "MB")
+
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -735,7 +779,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,m4")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,m4,forwardlrp")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -757,6 +801,8 @@ def main():
         gen_t20(HERE, weights)
     if "m4" in todo:
         gen_m4(HERE)
+    if "forwardlrp" in todo:
+        gen_forwardlrp(HERE, weights)
     if "guided" in todo:
         gen_guided(HERE, weights)
     if "gradient" in todo:

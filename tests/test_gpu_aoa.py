@@ -122,3 +122,21 @@ def test_aoa_explain_stream_matches_serial():
     assert len(piped) == len(serial)
     for (m0, w0), (m1, w1) in zip(serial, piped):
         assert torch.equal(m0, m1) and torch.equal(w0, w1)
+
+
+def test_aoa_forwardlrp_context_vs_reference():
+    """`AOAModel.forwardlrp_context` (models/aoamodel.py:628-677), forward values, against the reference's own outputs"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    from test_gpu_gridtd import _check_forwardlrp
+    g = np.load(os.path.join(GOLDEN, "forwardlrp.npz"))
+    V = int(g["aoa_V"])
+    eng = AOAEngine(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=V))
+    imgs = torch.from_numpy(weights.make_images(int(g["seed"]) + 5, int(g["batch"])))
+    enc = eng.encode(images=imgs.cuda())
+    preds, wpreds, L = eng.forwardlrp_context(enc, torch.from_numpy(g["aoa_caption"]), g["aoa_lengths"].tolist(),
+                                              g["aoa_skip"].tolist())
+    assert L == int(g["aoa_L"])
+    _check_forwardlrp(g, "aoa", "", preds, wpreds, L)

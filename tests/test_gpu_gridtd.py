@@ -150,3 +150,34 @@ def test_explain_stream_matches_serial():
     again = eng.explain_batch(*batches[0])          # the engine is usable serially afterwards
     torch.cuda.synchronize()
     assert torch.equal(again[0], serial[0][0])
+
+
+def _check_forwardlrp(g, tag, sfx, preds, wpreds, L):
+    preds, wpreds = preds.cpu(), wpreds.cpu()
+    assert tuple(preds.shape) == tuple(wpreds.shape) == (int(g["batch"]), L, int(g[f"{tag}_V"]))
+    assert rel_err(preds[:, :, ::13], g[f"{tag}_pred_sub{sfx}"]) < 1e-4
+    assert rel_err(wpreds[:, :, ::13], g[f"{tag}_wpred_sub{sfx}"]) < 1e-4
+    assert preds.argmax(-1).tolist() == g[f"{tag}_pred_argmax{sfx}"].tolist()          # token ids: bit-exact
+    assert wpreds.argmax(-1).tolist() == g[f"{tag}_wpred_argmax{sfx}"].tolist()
+    assert rel_err(preds[1, L - 1], g[f"{tag}_pred_row{sfx}"]) < 1e-4
+    assert rel_err(wpreds[1, L - 1], g[f"{tag}_wpred_row{sfx}"]) < 1e-4
+
+
+def test_forwardlrp_context_vs_reference():
+    """the forward half of LRP-inference fine-tuning (`GridTDModel.forwardlrp_context`, models/gridTDmodel.py:579-630):
+    raw and LRP-reweighted scores of every teacher-forced step against the reference's own outputs
+    (tests/golden/forwardlrp.npz), incl. the case with a stop word (exempt rows: weights of 1)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine
+    g = np.load(os.path.join(GOLDEN, "forwardlrp.npz"))
+    V = int(g["grid_V"])
+    eng = GridTDEngine(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=V))
+    imgs = torch.from_numpy(weights.make_images(int(g["seed"]) + 5, int(g["batch"])))
+    enc = eng.encode(imgs.cuda())
+    caps = torch.from_numpy(g["grid_caption"])
+    for sfx in ("", "2"):
+        preds, wpreds, L = eng.forwardlrp_context(enc, caps, g["grid_lengths"].tolist(), g[f"grid_skip{sfx}"].tolist())
+        assert L == int(g["grid_L"])
+        _check_forwardlrp(g, "grid", sfx, preds, wpreds, L)

@@ -81,9 +81,13 @@ def test_linear_rule_with_bias_and_larger_shape_vs_oracle():
     assert e_gpu < max(3 * e_cpu, 1e-5), (e_gpu, e_cpu)
     assert torch.equal(lin.input[0].cpu(), x_after)
     want0, _ = O.linear_eps_rule(x, lin.weight.data.cpu(), r)
+    want0_64, _ = O.linear_eps_rule(x.double(), lin.weight.data.cpu().double(), r.double())
     lin.input = (x.cuda(),)
     got0 = R.Linear().propagate_relevance(lin, None, (r.cuda(),), "epsilon", PARAMS)[0]
-    assert rel_err(got0.cpu(), want0) < 1e-5
+    # the stabiliser bounds |Z| from below by 0.01 only: over K = 2048 terms a Z of that size still amplifies its own
+    # rounding ~100x; same criterion (observed: GPU 1.4e-5 from the fp32 oracle)
+    e_gpu, e_cpu = rel_err(got0.cpu().double(), want0_64), rel_err(want0.double(), want0_64)
+    assert e_gpu < max(3 * e_cpu, 1e-5), (e_gpu, e_cpu)
 
 
 def _bn(cls, M, tag):

@@ -234,3 +234,25 @@ def test_t20_decoder_relevance_at_headline_length():
     for k in range(n_img):
         trb = O.aoa_trace(sdb, torch.from_numpy(bu[k]), g["bu_caption"][k])
         _t20_rows(g, "bu", k, T, 64, lambda t: O.aoa_explain_wordt(sdb, trb, t, 0), 1e-4, "pc")
+
+
+def test_forwardlrp_context_forward_values():
+    # `forwardlrp_context` of both models (models/gridTDmodel.py:579-630, models/aoamodel.py:628-677):
+    # raw and LRP-reweighted scores of every teacher-forced step; case "2" has a stop word (weights of 1)
+    g = np.load(os.path.join(GOLDEN, "forwardlrp.npz"))
+    B, L = int(g["batch"]), int(g["grid_L"])
+    imgs = torch.from_numpy(weights.make_images(int(g["seed"]) + 5, B))
+    for tag, mk, fn in (("grid", weights.make_gridtd_state, O.gridtd_forwardlrp_context),
+                        ("aoa", weights.make_aoa_state, O.aoa_forwardlrp_context)):
+        sd = O.state_to_torch(mk(seed=int(g["seed"]), vocab_size=int(g[f"{tag}_V"])))
+        for sfx in ("", "2") if tag == "grid" else ("",):
+            for b in range(B):
+                p, wp = fn(sd, imgs[b:b + 1], g[f"{tag}_caption"][b], L, set(g[f"{tag}_skip{sfx}"].tolist()))
+                assert rel_err(p[:, ::13], g[f"{tag}_pred_sub{sfx}"][b]) < 2e-5
+                assert rel_err(wp[:, ::13], g[f"{tag}_wpred_sub{sfx}"][b]) < 2e-5
+                assert p.argmax(-1).tolist() == g[f"{tag}_pred_argmax{sfx}"][b].tolist()
+                assert wp.argmax(-1).tolist() == g[f"{tag}_wpred_argmax{sfx}"][b].tolist()
+            assert rel_err(p[L - 1], g[f"{tag}_pred_row{sfx}"]) < 2e-5 and rel_err(wp[L - 1], g[f"{tag}_wpred_row{sfx}"]) < 2e-5
+    # the stop-word case: where the arg-max word is exempt the two score sets coincide
+    assert np.array_equal(g["grid_pred_sub2"][g["grid_pred_argmax2"] == g["grid_skip2"][-1]],
+                          g["grid_wpred_sub2"][g["grid_pred_argmax2"] == g["grid_skip2"][-1]])
