@@ -442,6 +442,14 @@ int lrpx_add_rule(const float* x1, const float* x2, const float* r_out, float* r
 /* max |a - b| into one device float (Dropout.propagate_relevance's check, LRPtools/lrp_modules.py:251; NaN counts as inf) */
 int lrpx_max_abs_diff(const float* a, const float* b, long n, float* out_dev, void* stream);
 
+/* Guided-Grad-CAM (ExplainGridTDGuidedGradCam.explain_cnn, models/gridTDmodel.py:1814-1836; AoA: models/aoamodel.py:1729-1751):
+ * out[n][c] = guided[n][c] * E_n with E_n = expand_m cam_n expand_m^T, the (hw x hw) `skimage.transform.pyramid_expand(cam,
+ * upscale = hw / p)` of the (p x p) Grad-CAM heat map cam_n.  guided / out: (rows, channels, hw, hw); cam: (rows, p*p);
+ * expand_m: (hw, p) row-major, Gaussian smoothing x bilinear resize as ONE matrix (both steps are linear and separable;
+ * built on the host by lrp_amd.ops.pyramid_expand_matrix). */
+int lrpx_guided_gradcam(const float* guided, const float* cam, const float* expand_m, float* out, int rows, int p, int hw,
+                        int channels, void* stream);
+
 /* ---- the VGG16 chains with a per-call context (see THREADING above): same arguments + opts (NULL = process defaults) -- */
 int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, void* trace, float* feat_nhwc,
                           const lrpx_vgg16_opts* opts, void* stream);

@@ -263,7 +263,8 @@ class AOAEngine:
 
     def explain_batch_gradient(self, captions, head_idx, images, kind="gradient", lens=None, return_features=False):
         """Batched `explain_caption` of ExplainAOAGradient (kind="gradient", :1501-1534), ExplainAOAGuidedGradient
-        ("guided", :1621-1640) and ExplainAOAGradCam ("gradcam", :1669-1689; result (B,T,P) heat maps)."""
+        ("guided", :1621-1640), ExplainAOAGradCam ("gradcam", :1669-1689; result (B,T,P) heat maps) and
+        ExplainAOAGuidedGradCam ("guided_gradcam", :1714-1751)."""
         enc = self.encode(images)
         captions = captions.to(self.device, torch.int64).contiguous()
         B, T = captions.shape[0], captions.shape[1] - 1
@@ -274,8 +275,14 @@ class AOAEngine:
             check(_lib.load().lrpx_gradcam(ptr(enc["feats"]), ptr(d_feat), ptr(row2img), ptr(maps), B * T, enc["P"], self.C,
                                            stream_ptr()))
             maps = maps.view(B, T, enc["P"])
-        elif kind == "guided":
-            maps = self.vgg.guided_backprop(d_feat, row2img).view(B, T, 3, 224, 224)
+        elif kind in ("guided", "guided_gradcam"):
+            maps = self.vgg.guided_backprop(d_feat, row2img)
+            if kind == "guided_gradcam":         # ExplainAOAGuidedGradCam (:1714-1751): x the expanded Grad-CAM map
+                cam = torch.empty(B * T, enc["P"], device=self.device, dtype=torch.float32)
+                check(_lib.load().lrpx_gradcam(ptr(enc["feats"]), ptr(d_feat), ptr(row2img), ptr(cam), B * T, enc["P"],
+                                               self.C, stream_ptr()))
+                maps = ops.guided_gradcam(maps, cam, int(round(enc["P"] ** 0.5)))
+            maps = maps.view(B, T, 3, 224, 224)
         else:
             maps = self.vgg.gradient(d_feat, row2img).view(B, T, 3, 224, 224)
         out = (maps, r_words.view(B, T, T))
@@ -528,6 +535,21 @@ class ExplainAOAGuidedGradient(ExplainAOAGradient):
 
     def _cnn(self, d_feat_nhwc, row2img):
         return self.engine.vgg.guided_backprop(d_feat_nhwc, row2img)
+
+
+class ExplainAOAGuidedGradCam(ExplainAOAGuidedGradient):
+    """Drop-in for `ExplainAOAGuidedGradCam` (models/aoamodel.py:1714-1751): the guided-backprop map of every word times
+    the Grad-CAM heat map of the same decoder gradient, expanded 16x by `skimage.transform.pyramid_expand` (:1741; here
+    one matrix product per axis, ops.pyramid_expand_matrix)."""
+    EX_TYPE = 'GuidedGradCam'
+
+    def _cnn(self, d_feat_nhwc, row2img):
+        rows, P = d_feat_nhwc.shape[0], d_feat_nhwc.shape[1]
+        guided = self.engine.vgg.guided_backprop(d_feat_nhwc, row2img)
+        cam = torch.empty(rows, P, device=self.engine.device, dtype=torch.float32)
+        check(_lib.load().lrpx_gradcam(ptr(self._enc["feats"]), ptr(d_feat_nhwc.contiguous()), ptr(row2img), ptr(cam), rows,
+                                       P, self.engine.C, stream_ptr()))
+        return ops.guided_gradcam(guided, cam, int(round(P ** 0.5)))
 
 
 class ExplainAOAGradCam(ExplainAOAGradient):

@@ -412,9 +412,11 @@ class GridTDEngine:
         check(lib.lrpx_rel_words_norm(ptr(gs["r_words"]), rows, T, st))
         return d_feat, gs["r_words"], row2img
 
-    def explain_batch_guided(self, images, captions, lens=None, return_features=False):
+    def explain_batch_guided(self, images, captions, lens=None, return_features=False, gradcam=False):
         """Batched `ExplainiGridTDGuidedGradient.explain_caption`: guided-backprop maps (B,T,3,224,224) and word
-        scores (B,T,T).  (No running sums here: the reference zeroes the image gradient per word, :1717.)"""
+        scores (B,T,T).  (No running sums here: the reference zeroes the image gradient per word, :1717.)
+        gradcam=True: `ExplainGridTDGuidedGradCam` (:1796-1836) - every map times the 16x expanded Grad-CAM heat map of the
+        same (guided) decoder gradient."""
         images = images.to(self.device, torch.float32).contiguous()
         captions = captions.to(self.device, torch.int64).contiguous()
         B, T = captions.shape[0], captions.shape[1] - 1
@@ -422,6 +424,8 @@ class GridTDEngine:
         tr = self.trace(enc, captions, predictions=False, grad=True)
         d_feat, r_words, row2img = self.guided_gradient(enc, tr, lens)
         maps = self.vgg.guided_backprop(d_feat, row2img)
+        if gradcam:
+            maps = ops.guided_gradcam(maps, self.grad_cam(enc, d_feat, row2img), int(round(self.P ** 0.5)))
         out = (maps.view(B, T, 3, 224, 224), r_words.view(B, T, T))
         if return_features:
             out = out + (d_feat.view(B, T, self.P, self.C), tr, enc)
@@ -657,6 +661,37 @@ class ExplainiGridTDGuidedGradient(ExplainGridTDAttention):
         self.get_hidden_parameters(img_filepath, caption_encode)
         d_feat, r_words, row2img = self._relevance()
         maps = self.engine.vgg.guided_backprop(d_feat, row2img)
+        return ([maps[t:t + 1] for t in range(self.caption_length)],
+                [r_words[t, :t + 1] for t in range(self.caption_length)])
+
+
+class ExplainGridTDGuidedGradCam(ExplainiGridTDGuidedGradient):
+    """Drop-in for `ExplainGridTDGuidedGradCam` (models/gridTDmodel.py:1796-1836): the guided-backprop map of every word
+    times the Grad-CAM heat map of the same decoder gradient expanded 16x by `skimage.transform.pyramid_expand` (:1826).
+    (`d_img_feature[self.image_features < 0] = 0`, :1815, never selects anything: the features are ReLU outputs.)"""
+    EX_TYPE = 'GuidedGradCam'
+
+    def grad_cam(self, img_feature, grads):
+        """(1,C,h,w) features and gradients -> (h, w) heat map (:1799-1810)"""
+        f = ops.nchw_to_nhwc(img_feature.to(torch.float32))
+        g = ops.nchw_to_nhwc(grads.to(torch.float32))
+        P, Cc = f.shape[1], f.shape[2]
+        cam = torch.empty(1, P, device=self.engine.device, dtype=torch.float32)
+        check(_lib.load().lrpx_gradcam(ptr(f), ptr(g), ptr(None), ptr(cam), 1, P, Cc, stream_ptr()))
+        return cam.view(img_feature.shape[-2], img_feature.shape[-1])
+
+    def explain_cnn(self, d_img_feature):
+        guided = super().explain_cnn(d_img_feature)
+        cam = self.grad_cam(self.image_features, d_img_feature).reshape(1, -1)
+        return ops.guided_gradcam(guided, cam, self.image_features.shape[-1])
+
+    def explain_caption(self, img_filepath, t_list=None, caption_encode=None):
+        self.img_filepath = img_filepath
+        self.get_hidden_parameters(img_filepath, caption_encode)
+        d_feat, r_words, row2img = self._relevance()
+        eng = self.engine
+        maps = ops.guided_gradcam(eng.vgg.guided_backprop(d_feat, row2img), eng.grad_cam(self._enc, d_feat, row2img),
+                                  int(round(eng.P ** 0.5)))
         return ([maps[t:t + 1] for t in range(self.caption_length)],
                 [r_words[t, :t + 1] for t in range(self.caption_length)])
 

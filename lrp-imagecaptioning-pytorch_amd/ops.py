@@ -138,6 +138,54 @@ def check_relevance(buf, finite=True, nonzero=False):
     check(_lib.load().lrpx_check(ptr(buf), buf.numel(), (1 if finite else 0) | (2 if nonzero else 0), stream_ptr()))
 
 
+_EXPAND_CACHE = {}
+
+
+def pyramid_expand_matrix(p, upscale, device="cuda"):
+    """`skimage.transform.pyramid_expand(cam, upscale)` of a (p x p) map as ONE matrix: E = M cam M^T, M (p*upscale, p).
+    scikit-image (the reference pins none; 0.16 was current for its PyTorch 1.4) computes
+      resize(cam, order=1, mode='reflect', anti_aliasing=False): output row o samples the input at (o + 0.5) / upscale - 0.5,
+          linear interpolation, out-of-range neighbours mirrored without repeating the edge (index -1 -> 1, p -> p - 2);
+      ndi.gaussian_filter(sigma = 2 * upscale / 6, truncate 4, mode='reflect'): 2 * int(4 sigma + 0.5) + 1 taps, edge-repeating
+          reflection (index -1 -> 0).
+    Both are linear and separable, so they compose into M = Gauss @ Bilinear (built in float64 on the host, stored fp32)."""
+    key = (p, upscale, str(device))
+    if key not in _EXPAND_CACHE:
+        import math
+        import numpy as np
+        hw = p * upscale
+        Bm = np.zeros((hw, p))
+        for o in range(hw):
+            r = (o + 0.5) / upscale - 0.5
+            r0 = math.floor(r)
+            d = r - r0
+            for idx, wgt in ((r0, 1.0 - d), (r0 + 1, d)):
+                idx = -idx if idx < 0 else (2 * (p - 1) - idx if idx > p - 1 else idx)
+                Bm[o, idx] += wgt
+        sigma = 2.0 * upscale / 6.0
+        lw = int(4.0 * sigma + 0.5)
+        w = np.exp(-0.5 * (np.arange(-lw, lw + 1) / sigma) ** 2)
+        w /= w.sum()
+        G = np.zeros((hw, hw))
+        for o in range(hw):
+            for k in range(-lw, lw + 1):
+                i = o + k
+                i = -i - 1 if i < 0 else (2 * hw - 1 - i if i >= hw else i)
+                G[o, i] += w[k + lw]
+        _EXPAND_CACHE[key] = torch.from_numpy((G @ Bm).astype(np.float32)).to(device).contiguous()
+    return _EXPAND_CACHE[key]
+
+
+def guided_gradcam(guided_maps, cam, p=14):
+    """guided_maps (N,C,HW,HW) * pyramid_expand(cam (N, p*p), upscale = HW / p)  (models/gridTDmodel.py:1826-1829)"""
+    n, c, hw, _ = guided_maps.shape
+    out = torch.empty_like(guided_maps)
+    m = pyramid_expand_matrix(p, hw // p, guided_maps.device)
+    check(_lib.load().lrpx_guided_gradcam(ptr(_dev(guided_maps).contiguous()), ptr(cam.contiguous()), ptr(m), ptr(out), n, p,
+                                          hw, c, stream_ptr()))
+    return out
+
+
 class Vgg16:
     """VGG16 encoder context: packed weights + per-batch trace (device memory owned by torch)."""
 

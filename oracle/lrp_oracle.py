@@ -227,6 +227,40 @@ def grad_cam(features, grads):
 # ----------------------------------------------------------------------------------------------
 # gridTD decoder (adaptive attention + two LSTMs)
 # ----------------------------------------------------------------------------------------------
+def pyramid_expand(cam, upscale=16):
+    """`skimage.transform.pyramid_expand(cam, upscale, multichannel=False)` as the Guided-Grad-CAM explainers call it
+    (models/gridTDmodel.py:1826, models/aoamodel.py:1741).  scikit-image is an un-vendored dependency of the reference
+    (no pinned version; 0.16.x matches its PyTorch 1.4) and is NOT installed here: this restates its published algorithm -
+    `resize(order=1, mode='reflect', anti_aliasing=False)` = sampling at (o + 0.5) / upscale - 0.5 with linear interpolation
+    and numpy-style 'reflect' borders, then `_smooth` = scipy.ndimage.gaussian_filter(sigma = 2 upscale / 6, mode='reflect')
+    (scipy IS here and is called as skimage calls it).  PARITY UNPINNED for this one function: no output of skimage itself
+    could be generated.  cam: (h, w) tensor -> (h*upscale, w*upscale) float32 tensor."""
+    import numpy as np
+    from scipy import ndimage as ndi
+    a = np.asarray(cam, dtype=np.float64)
+    h, w = a.shape
+    pad = np.pad(a, 1, mode="reflect")                      # index -1 -> 1, h -> h - 2
+    rr = (np.arange(h * upscale) + 0.5) / upscale - 0.5
+    cc = (np.arange(w * upscale) + 0.5) / upscale - 0.5
+    r0, c0 = np.floor(rr).astype(int), np.floor(cc).astype(int)
+    dr, dc = (rr - r0)[:, None], (cc - c0)[None, :]
+    R0, C0 = r0[:, None] + 1, c0[None, :] + 1               # indices into the padded image
+    top = (1 - dc) * pad[R0, C0] + dc * pad[R0, C0 + 1]
+    bot = (1 - dc) * pad[R0 + 1, C0] + dc * pad[R0 + 1, C0 + 1]
+    resized = (1 - dr) * top + dr * bot
+    out = ndi.gaussian_filter(resized, 2 * upscale / 6.0, mode="reflect", cval=0)
+    return torch.from_numpy(out).float()
+
+
+def guided_grad_cam(features, grads, guided_map, upscale=16):
+    """ExplainGridTDGuidedGradCam.explain_cnn (models/gridTDmodel.py:1814-1836) after the guided backward: the guided
+    gradient times the expanded Grad-CAM map of the same decoder gradient (:1825-1829).  `grad_cam` there returns the
+    (h, w) map (:1799-1810).  features, grads: (1,C,h,w); guided_map: (1,3,H,W)."""
+    h, w = features.shape[-2:]
+    cam = grad_cam(features, grads).view(h, w)
+    return guided_map * pyramid_expand(cam, upscale).expand_as(guided_map)
+
+
 def _lstm_cell(x, h, c, w_ih, w_hh, bias):
     """models/gridTDmodel.py:773-797: returns (h', c', z_g, sigmoid(z_i), sigmoid(z_f))."""
     z = w_ih @ x + w_hh @ h + bias

@@ -45,7 +45,7 @@ def cosine(a, b):
     return (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
 
 
-def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=5e-2, l2=2e-3, what="", cos=0.99999):
+def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=3e-3, l2=6e-4, what="", cos=0.99999):
     """End-to-end comparison of pixel relevance maps whose FORWARD passes were computed by different conv
     implementations.  Relevance through MaxPool2d goes to the arg-max of each 2x2 window
     (LRPtools/lrp_modules.py:182-195); rounding-level differences of the forward flip the winner of a few
@@ -54,7 +54,10 @@ def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=5e-2, l2=2e-3, what
     4 flips, relative L2 error 2.1e-4, 99th percentile 2.4e-5, 0.17 % of the pixels above 1e-4, max 1.8e-3
     (tests/e2e_stats.py).  So: cosine >= 0.99999, relative L2 error < `l2`, at most `frac` of the
     pixels off by more than 1e-4 of max|R|, none by more than `hard`.  The strict 1e-4 bound is asserted
-    separately on identical activations."""
+    separately on identical activations.
+    The default bounds are <= 3.5x the worst observation over all 65 LRP end-to-end comparisons of the suite (round 2,
+    gpurun_out/pool_tie_stats.json written by this function's callers: 0.29 % of the pixels, max 8.0e-4, relative L2
+    1.8e-4 - the B = 2 multi-image case of test_gpu_gridtd.py; the golden image alone: 0.12 %, 6.8e-4, 8.2e-5)."""
     import torch
     got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
     scale = want.abs().max().clamp_min(1e-300)

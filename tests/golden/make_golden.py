@@ -761,6 +761,46 @@ def gen_forwardlrp(out, weights, seed=0, T=8, batch=2):
 
 
 
+def gen_guided_gradcam(out, weights, T=3, seed=0, head=5):
+    """ExplainGridTDGuidedGradCam (models/gridTDmodel.py:1796-1836) and ExplainAOAGuidedGradCam (models/aoamodel.py:1714-1751):
+    guided backprop x the 16x expanded Grad-CAM map.  scikit-image is not installed here, so the ONE call into it,
+    `skimage.transform.pyramid_expand(cam, upscale=16, multichannel=False)`, is served by the restatement of its published
+    algorithm in oracle/lrp_oracle.py (scipy.ndimage.gaussian_filter called as skimage calls it): these vectors pin
+    everything around that call with the reference's own code; the expansion itself stays "parity unpinned"."""
+    from oracle import lrp_oracle as O
+    import models.gridTDmodel as gtd
+    import models.aoamodel as aoa
+    expand = lambda a, upscale=2, multichannel=False, **kw: O.pyramid_expand(torch.from_numpy(np.asarray(a)), upscale).double().numpy()
+    sys.modules["skimage.transform"].pyramid_expand = expand
+    sys.modules["skimage"].transform = sys.modules["skimage.transform"]
+    g = dict(seed=np.int64(seed), T=np.int64(T), head=np.int64(head))
+    img = weights.make_images(seed, 1)
+    for tag, mod, cls, V, mk in (("grid", gtd, "ExplainGridTDGuidedGradCam", 9586, weights.make_gridtd_state),
+                                 ("aoa", aoa, "ExplainAOAGuidedGradCam", 11027, weights.make_aoa_state)):
+        sd = mk(seed=seed, vocab_size=V)
+        wm = weights.make_word_map(V)
+        cap = weights.make_captions(seed + 1, 1, T, V)[0]
+        with tempfile.TemporaryDirectory() as tmp:
+            real_load = torch.load
+            torch.load = lambda *a, **k: {"state_dict": to_torch_sd(sd)}
+            try:
+                ex = getattr(mod, cls)(make_args(tmp), wm)
+            finally:
+                torch.load = real_load
+            _patch_explainer(ex, img, cap)
+            maps, rws = ex.explain_caption("synthetic.jpg") if tag == "grid" else ex.explain_caption("synthetic.jpg", head)
+        g[f"{tag}_V"], g[f"{tag}_caption"] = np.int64(V), cap
+        for t in range(T):
+            g[f"{tag}_map_stats_{t}"] = stats(maps[t])
+            g[f"{tag}_map_sub4_{t}"] = sub4(maps[t]).numpy()
+            g[f"{tag}_r_words_{t}"] = rws[t].detach().numpy()
+        g[f"{tag}_map_full_{T - 1}"] = maps[T - 1].numpy()
+        print(tag, "guided grad-cam absmax:", [float(m.abs().max()) for m in maps])
+    np.savez(os.path.join(out, "guided_gradcam_T3.npz"), **g)
+    print("guided_gradcam_T3.npz written")
+
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -779,7 +819,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,m4,forwardlrp")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,m4,forwardlrp,guided_gradcam")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -803,6 +843,8 @@ def main():
         gen_m4(HERE)
     if "forwardlrp" in todo:
         gen_forwardlrp(HERE, weights)
+    if "guided_gradcam" in todo:
+        gen_guided_gradcam(HERE, weights)
     if "guided" in todo:
         gen_guided(HERE, weights)
     if "gradient" in todo:

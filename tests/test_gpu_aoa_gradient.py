@@ -119,3 +119,27 @@ def test_aoa_drop_in_classes(case):
     assert_close_modulo_pool_ties(gm[1][:, :, ::4, ::4].cpu(), g["guided_map_sub4_1"], what="guided drop-in", **E2E)
     cams, _ = ExplainAOAGradCam(args, wm, model=sd).explain_caption(img, head, caption_encode=ce)
     assert tuple(cams[0].shape) == (1, 196) and np.abs(cams[0].cpu().numpy() - g["cam_0"]).max() < 1e-3
+
+
+def test_aoa_guided_gradcam_vs_reference_fixture():
+    """ExplainAOAGuidedGradCam (models/aoamodel.py:1714-1751) against the fixture made by the reference's class (its skimage
+    call served by the restated pyramid_expand): batched engine kind="guided_gradcam" and the drop-in class"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import types
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine, ExplainAOAGuidedGradCam
+    g = np.load(os.path.join(GOLDEN, "guided_gradcam_T3.npz"))
+    V, head = int(g["aoa_V"]), int(g["head"])
+    sd = weights.make_aoa_state(seed=int(g["seed"]), vocab_size=V)
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1)).cuda()
+    cap = torch.from_numpy(g["aoa_caption"]).view(1, -1)
+    eng = AOAEngine(sd)
+    maps, r_words = eng.explain_batch_gradient(cap, head, img, kind="guided_gradcam")
+    ex = ExplainAOAGuidedGradCam(types.SimpleNamespace(num_head=8), weights.make_word_map(V), model=sd)
+    dmaps, _ = ex.explain_caption(img, head, caption_encode=g["aoa_caption"].tolist())
+    for t in range(3):
+        assert torch.equal(dmaps[t][0], maps[0, t])
+        assert_close_modulo_pool_ties(maps[0, t][None, :, ::4, ::4].cpu(), g[f"aoa_map_sub4_{t}"], what=("aoa ggc", t), **E2E)
+        assert np.abs(r_words[0, t, :t + 1].cpu().numpy() - g[f"aoa_r_words_{t}"]).max() < 5e-5
+    assert_close_modulo_pool_ties(maps[0, 2].cpu(), g["aoa_map_full_2"][0], what="aoa ggc full", **E2E)

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 # discrete decision on values that are often within rounding of zero, so more pixels move by > 1e-4 of the maximum
 # than for LRP when the forward comes from a different conv implementation (5 % on the golden image); cosine and
 # the relative L2 error (< 2e-3) are unaffected.  The strict 1e-4 check runs on identical activations below.
-E2E = dict(frac=0.25)
+# Bounds = 3x the worst observation of this file's 13 comparisons (round 2: 2.2 % of the pixels, max 3.1e-3, rel. L2 2.7e-4).
+E2E = dict(frac=0.07, hard=1e-2, l2=8e-4)
 
 
 @pytest.fixture(scope="module")
@@ -99,3 +100,53 @@ def test_guided_explainer_class(case):
     for t in range(3):
         assert np.abs(rws[t].cpu().numpy() - g[f"r_words_{t}"]).max() < 5e-5
         assert_close_modulo_pool_ties(maps[t][..., ::4, ::4].cpu(), g[f"map_sub4_{t}"], what=t, **E2E)
+
+
+def test_guided_gradcam_kernel_is_the_expansion_operator():
+    """`lrpx_guided_gradcam` alone: guided (N,3,224,224) x expand(cam (N,196)) against the oracle's direct evaluation of
+    pyramid_expand (bilinear resize + scipy gaussian_filter) - strict, elementwise"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import ops
+    from oracle import lrp_oracle as O
+    g = torch.Generator().manual_seed(2)
+    guided = torch.randn(3, 3, 224, 224, generator=g)
+    cam = torch.relu(torch.randn(3, 196, generator=g))
+    cam[1] = 0
+    got = ops.guided_gradcam(guided.cuda(), cam.cuda(), 14).cpu()
+    for n in range(3):
+        want = guided[n] * O.pyramid_expand(cam[n].view(14, 14), 16)
+        assert (got[n] - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1e-30) or want.abs().max() == 0
+    assert got[1].abs().max().item() == 0
+
+
+def test_guided_gradcam_vs_reference_fixture():
+    """ExplainGridTDGuidedGradCam (models/gridTDmodel.py:1796-1836): batched engine and drop-in class against the fixture
+    made by the reference's class (tests/golden/guided_gradcam_T3.npz; its skimage call served by the restated
+    pyramid_expand, see make_golden.py).  Word 1 is the all-negative Grad-CAM case: a zero map."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import types
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine, ExplainGridTDGuidedGradCam
+    g = np.load(os.path.join(GOLDEN, "guided_gradcam_T3.npz"))
+    V = int(g["grid_V"])
+    sd = weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=V)
+    img = torch.from_numpy(weights.make_images(int(g["seed"]), 1))
+    cap = torch.from_numpy(g["grid_caption"]).view(1, -1)
+    eng = GridTDEngine(sd)
+    maps, r_words = eng.explain_batch_guided(img, cap, gradcam=True)
+    ex = ExplainGridTDGuidedGradCam(types.SimpleNamespace(height=224, width=224), weights.make_word_map(V), model=sd)
+    dmaps, drw = ex.explain_caption(img, caption_encode=g["grid_caption"].tolist())
+    for t in range(3):
+        assert torch.equal(dmaps[t][0], maps[0, t])                       # drop-in == batched engine
+        scale = g[f"grid_map_stats_{t}"][1]
+        if scale == 0:
+            assert maps[0, t].abs().max().item() == 0
+            continue
+        assert_close_modulo_pool_ties(maps[0, t][None, :, ::4, ::4].cpu(), g[f"grid_map_sub4_{t}"], what=("ggc", t), **E2E)
+        assert np.abs(r_words[0, t, :t + 1].cpu().numpy() - g[f"grid_r_words_{t}"]).max() < 5e-5
+    assert_close_modulo_pool_ties(maps[0, 2].cpu(), g["grid_map_full_2"][0], what="ggc full", **E2E)
+    # explain_cnn of the drop-in: one word's decoder gradient -> the same map
+    d_feat, _ = ex.explain_caption_wordt(2)
+    assert torch.equal(ex.explain_cnn(d_feat)[0], maps[0, 2])
