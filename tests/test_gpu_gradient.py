@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 # LRP (same situation as guided backprop, tests/test_gpu_guided.py), and without the guided clamp both signs of the
 # flipped paths survive: relative L2 up to 4e-3 on the golden image at cosine > 0.99999 (the bound cosine alone implies
 # is 4.5e-3).  The strict 1e-4 check runs on identical activations.
-E2E = dict(frac=0.25, l2=6e-3)
+E2E = dict(frac=0.25, l2=6e-3, hard=9e-2)     # observed (round 2): 12.4 % of the pixels, max 3.2e-2, rel. L2 3.8e-3
 
 
 @pytest.fixture(scope="module")
