@@ -303,6 +303,11 @@ int lrpx_gridtd_lrp_reweight(const lrpx_gridtd_trace* tr, int t, const float* pr
 int lrpx_lrp_reweight_rows(const float* pred, long ld, int V, const float* h, long ldh, const float* ctx, long ldc,
                            const float* fc_w, const unsigned char* skip, float* hcw, int rows, int H, int log_softmax,
                            void* stream);
+/* one beam-search step (GridTDModel.beam_search, models/gridTDmodel.py:437-444; AOAModel.beam_search): the k <= 4 best of
+ * cum[r] + log_softmax(x[r,:n])[w] over the n_rows <= 8 live beams; out_idx[j] = r * n + w (int64), out_val[j] the score,
+ * best first (ties: lower flat index).  cum may be NULL (zeros). */
+int lrpx_beam_topk(const float* x, long ld, int n_rows, int n, const float* cum, int k, long long* out_idx, float* out_val,
+                   void* stream);
 /* scratch: [B][3*P] floats (scores, W_g h, W_s s) */
 int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img,
                               const float* Wg, const float* Ws, const float* bs, const float* wh, float* scratch,

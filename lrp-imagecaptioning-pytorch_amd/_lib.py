@@ -155,6 +155,7 @@ SIGNATURES = {
     "lrpx_vgg16_relevance_ex": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, C.POINTER(VggOpts), _f]),
     "lrpx_vgg16_guided_backprop_ex": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, C.POINTER(VggOpts), _f]),
     "lrpx_vgg16_gradient_ex": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, C.POINTER(VggOpts), _f]),
+    "lrpx_beam_topk": (_i, [_f, _l, _i, _i, _f, _i, _f, _f, _f]),
     "lrpx_guided_gradcam": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
     "lrpx_linear_eps_rule": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
     "lrpx_batchnorm_rule": (_i, [_f, _f, _f, _f, _f, _f, C.c_float, _f, _l, _i, _l, _i, _f]),

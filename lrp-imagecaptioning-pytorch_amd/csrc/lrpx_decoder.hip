@@ -415,6 +415,63 @@ __global__ __launch_bounds__(256) void argmax_logprob_rows_kernel(const float* _
     if (tid == 0) { out[blockIdx.x] = min(bi[0], n - 1); lp[blockIdx.x] = -logf(se); }   // x[k] - mx = 0
 }
 
+
+// Beam-search step (GridTDModel.beam_search, models/gridTDmodel.py:437-444; AOAModel.beam_search): the k best of
+// cum[r] + log_softmax(x[r])[w] over the n_rows live beams (flat index r * n + w, value).  One workgroup: row maxima and
+// log-sum-exps, a per-thread top-k (k <= 4) over the flat range, then a serial merge of the 256 x k candidates.
+// Ties: lower flat index first.
+template <int KMAX>
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ x, long ld, int n_rows, int n,
+                                                        const float* __restrict__ cum, int k,
+                                                        long long* __restrict__ out_idx, float* __restrict__ out_val) {
+    __shared__ float red[8];
+    __shared__ float lse[8];
+    __shared__ float cv[256 * KMAX];
+    __shared__ int ci[256 * KMAX];
+    const int tid = threadIdx.x;
+    for (int r = 0; r < n_rows; ++r) {
+        const float* xr = x + (long)r * ld;
+        float m = -INFINITY;
+        for (int i = tid; i < n; i += 256) m = fmaxf(m, xr[i]);
+        m = block_max(m, red);
+        float se = 0.f;
+        for (int i = tid; i < n; i += 256) se += expf(xr[i] - m);
+        se = block_sum(se, red);
+        if (tid == 0) lse[r] = m + logf(se);
+        __syncthreads();
+    }
+    float bv[KMAX];
+    int bi[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { bv[j] = -INFINITY; bi[j] = 0x7fffffff; }
+    const int total = n_rows * n;
+    for (int f = tid; f < total; f += 256) {
+        const int r = f / n, w = f - r * n;
+        float v = (cum ? cum[r] : 0.f) + (x[(long)r * ld + w] - lse[r]);
+        int vi = f;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {          // insertion into the sorted list (descending value, ascending index)
+            const bool better = v > bv[j] || (v == bv[j] && vi < bi[j]);
+            const float tv = better ? bv[j] : v; const int ti = better ? bi[j] : vi;
+            bv[j] = better ? v : bv[j]; bi[j] = better ? vi : bi[j];
+            v = tv; vi = ti;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { cv[tid * KMAX + j] = bv[j]; ci[tid * KMAX + j] = bi[j]; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int o = 0; o < k; ++o) {
+            float best = -INFINITY; int bidx = 0x7fffffff, at = -1;
+            for (int c = 0; c < 256 * KMAX; ++c)
+                if (ci[c] != 0x7fffffff && (cv[c] > best || (cv[c] == best && ci[c] < bidx))) { best = cv[c]; bidx = ci[c]; at = c; }
+            if (at >= 0) ci[at] = 0x7fffffff;
+            out_idx[o] = at >= 0 ? bidx : 0;
+            out_val[o] = best;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // gridTD relevance — models/gridTDmodel.py:1014-1135.  One block (256 threads) per row, H = 512.
 // ------------------------------------------------------------------------------------------------
@@ -1083,6 +1140,15 @@ int lrpx_argmax_logprob_rows(const float* x, long ld, int rows, int n, long long
     hipLaunchKernelGGL(argmax_logprob_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, out,
                        logprob);
     return check_launch("argmax_logprob_rows");
+}
+
+int lrpx_beam_topk(const float* x, long ld, int n_rows, int n, const float* cum, int k, long long* out_idx, float* out_val,
+                   void* stream) {
+    LRPX_REQUIRE(x && out_idx && out_val && n_rows > 0 && n_rows <= 8 && n > 0 && k > 0 && k <= 4 && (long)n_rows * n < 0x7fffffffL,
+                 "beam_topk: bad arguments (at most 8 live beams, k <= 4)");
+    hipLaunchKernelGGL((beam_topk_kernel<4>), dim3(1), dim3(256), 0, (hipStream_t)stream, x, ld, n_rows, n, cum, k, out_idx,
+                       out_val);
+    return check_launch("beam_topk");
 }
 
 int lrpx_gridtd_fwd_lstm(const lrpx_gridtd_trace* tr, int t, const float* zz, int ldz, int which, void* stream) {

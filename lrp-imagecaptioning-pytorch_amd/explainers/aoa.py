@@ -166,6 +166,30 @@ class AOAEngine:
             lps[:, t] = torch.where(alive, lp, torch.zeros_like(lp))
         return toks[:, 1:].contiguous(), lps
 
+    def beam_search(self, enc, beam_size, max_cap_length, start_id, end_id):
+        """`AOAModel.beam_search` (models/aoamodel.py, the algorithm of models/gridTDmodel.py:400-478 on the AoA step) for
+        ONE image: returns the chosen token sequence incl. <start>."""
+        from .beam import run_beam_search
+        assert enc["B"] == 1, "beam search captions one image"
+        nb = int(beam_size)
+        encb = {k: (v.expand(nb, *v.shape[1:]).contiguous() if torch.is_tensor(v) else v) for k, v in enc.items()}
+        encb["B"] = nb
+        T = int(max_cap_length)
+        tr = self._alloc_trace(nb, T, enc["P"])
+        toks = torch.zeros(nb, T + 1, dtype=torch.int64, device=self.device)
+
+        def step(t, prev):
+            toks[:, t] = prev
+            self._step(tr, encb, t, toks, self.bcat_model)
+
+        def reorder(t, src):
+            sel = torch.tensor(src, dtype=torch.int64, device=self.device)
+            for k in ("h", "c"):
+                tr[k][:len(src), t + 1] = tr[k][sel, t + 1]
+
+        return run_beam_search(step, lambda t: self.logits(tr["hc"][:, t].contiguous()), reorder, self.V, nb, T,
+                               start_id, end_id, self.device)
+
     def forwardlrp_context(self, enc, captions, caption_lengths, skip_ids):
         """The forward half of `AOAModel.forwardlrp_context` (models/aoamodel.py:628-677): teacher-forced decoding with the
         model's own forward; every step's scores are recomputed from the fc input re-weighted by the relevance of the
@@ -415,8 +439,8 @@ class AOAEngine:
 class ExplainAOAAttention(object):
     """Drop-in for the reference's `ExplainAOAAttention` (models/aoamodel.py:748-1194): `explain_caption(img, head_idx)`,
     `explain_caption_wordt(t, head_idx)`, `explain_cnn(R)`, `explain_caption_words(img)`; see
-    explainers/gridtd.py:ExplainGridTDAttention for the conventions (greedy instead of beam search unless
-    `caption_encode=` is given; nothing written to disk)."""
+    explainers/gridtd.py:ExplainGridTDAttention for the conventions (without `caption_encode=` the image is captioned
+    by the reference's own procedure, beam search with beam 3 over 20 steps, :992; nothing written to disk)."""
     EPS = 0.01
     EX_TYPE = 'lrp'
 
@@ -435,15 +459,22 @@ class ExplainAOAAttention(object):
         self.engine = AOAEngine(state, self.num_head)
         self.rev_word_map = {v: k for k, v in word_map.items()}
 
-    def get_hidden_parameters(self, img, caption_encode):
+    def get_hidden_parameters(self, img, caption_encode=None):
         eng = self.engine
         self.img = img.to(eng.device, torch.float32)
         self._enc = eng.encode(self.img)
+        if caption_encode is None:       # the reference captions the image itself: beam 3, 20 steps (:992-995)
+            from .beam import caption_from_sequence
+            seq = eng.beam_search(self._enc, 3, 20, self.word_map['<start>'], self.word_map['<end>'])
+            caption_encode = caption_from_sequence(seq, self.word_map)
         self.beam_caption_encode = [int(c) for c in caption_encode]
         self.caption_length = len(self.beam_caption_encode) - 1
         special = {self.word_map[k] for k in ('<start>', '<end>', '<unk>', '<pad>') if k in self.word_map}
         self.beam_caption = [' '.join(self.rev_word_map.get(c, str(c)) for c in self.beam_caption_encode[1:]
                                       if c not in special)]
+        self._rel = {}
+        if self.caption_length == 0:
+            return
         cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=eng.device)
         self._tr = eng.trace(self._enc, cap, predictions=True)
         self.image_features = ops.nhwc_to_nchw(self._enc["feats"].contiguous(), eng.C, 14, 14)
@@ -475,9 +506,9 @@ class ExplainAOAAttention(object):
 
     def explain_caption(self, img, head_idx, t_list=None, caption_encode=None):
         """(:1165-1181); the returned maps are the reference's running sums (lrp_wrapper.py:64-82)."""
-        if caption_encode is None:
-            raise ValueError("caption_encode is required (the reference's beam search is outside the hot path)")
         self.get_hidden_parameters(img, caption_encode)
+        if self.caption_length == 0:
+            return [], []
         self._img_grad = None
         r_feat, r_words, row2img = self._relevance(head_idx)
         maps = ops.cumsum_maps(self.engine.vgg.relevance(r_feat, row2img), 1, self.caption_length)
@@ -498,8 +529,10 @@ class ExplainAOAGradient(ExplainAOAAttention):
     encoder (`explain_cnn`, :1501-1515).  Same surface: `explain_caption(img, head_idx) -> (maps, word scores)`."""
     EX_TYPE = 'gradient'
 
-    def get_hidden_parameters(self, img, caption_encode):
+    def get_hidden_parameters(self, img, caption_encode=None):
         super().get_hidden_parameters(img, caption_encode)
+        if self.caption_length == 0:
+            return
         cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=self.engine.device)
         self._tr = self.engine.trace(self._enc, cap, predictions=True, grad=True)      # :1309-1376 (correct LSTM bias)
         self.predictions = self._tr["pred"][0]
@@ -519,9 +552,9 @@ class ExplainAOAGradient(ExplainAOAAttention):
 
     def explain_caption(self, img, head_idx, t_list=None, caption_encode=None):
         """(:1517-1534) no running sums here: the image gradient is a fresh tensor per word."""
-        if caption_encode is None:
-            raise ValueError("caption_encode is required (the reference's beam search is outside the hot path)")
         self.get_hidden_parameters(img, caption_encode)
+        if self.caption_length == 0:
+            return [], []
         d_feat, r_words, row2img = self._relevance(head_idx)
         maps = self._cnn(d_feat, row2img)
         return ([maps[t:t + 1] for t in range(self.caption_length)],

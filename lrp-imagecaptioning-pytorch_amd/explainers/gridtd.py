@@ -197,6 +197,30 @@ class GridTDEngine:
             toks[:, t + 1] = nxt * unfinished
         return toks
 
+    def beam_search(self, enc, beam_size, max_cap_length, start_id, end_id):
+        """`GridTDModel.beam_search` (models/gridTDmodel.py:400-478) for ONE image (enc of a single image, as the
+        reference asserts :411): returns the chosen token sequence incl. <start> (`seq`, :469-472)."""
+        from .beam import run_beam_search
+        assert enc["B"] == 1, "beam search captions one image (models/gridTDmodel.py:411)"
+        nb = int(beam_size)
+        encb = {k: (v.expand(nb, *v.shape[1:]).contiguous() if torch.is_tensor(v) else v) for k, v in enc.items()}
+        encb["B"] = nb
+        T = int(max_cap_length)
+        tr = self._alloc_trace(nb, T)
+        toks = torch.zeros(nb, T + 1, dtype=torch.int64, device=self.device)
+
+        def step(t, prev):
+            toks[:, t] = prev
+            self._step(tr, encb, t, toks, True)
+
+        def reorder(t, src):
+            sel = torch.tensor(src, dtype=torch.int64, device=self.device)
+            for k in ("h1", "c1", "h2", "c2"):
+                tr[k][:len(src), t + 1] = tr[k][sel, t + 1]
+
+        return run_beam_search(step, lambda t: self.logits(tr["hc"][:, t].contiguous()), reorder, self.V, nb, T,
+                               start_id, end_id, self.device)
+
     def sample_lrp(self, enc, max_length, start_id, end_id, skip_ids):
         """GridTDModel.sample_lrp, greedy (gridTDmodel.py:631-702): LRP-inference decoding.  Every step's logits are
         recomputed from the fc input re-weighted by the predicted word's relevance (`get_lrp_weight_step` :548-577)
@@ -533,9 +557,9 @@ class ExplainGridTDAttention(object):
     .beam_caption .beam_caption_encode .predictions .alphas .betas .args`.
 
     `model` may be the reference's `GridTDModel` (any nn.Module with that `state_dict`), a `state_dict`, or None
-    (then `args.weight` is loaded like :717-718).  Differences, all outside the relevance math: the caption is
-    decoded greedily (beam_size=1) unless `caption_encode=` is given (the reference's beam search is not part of
-    the hot path), and nothing is written to disk (visualisation is out of scope)."""
+    (then `args.weight` is loaded like :717-718).  Without `caption_encode=` the image is captioned as the reference does
+    it (`beam_search(beam_size=2, max_cap_length=50)`, :935-937; `GridTDEngine.beam_search`), so the same caption is
+    explained.  Nothing is written to disk (visualisation is out of scope)."""
     EPS = 0.01
     EX_TYPE = 'lrp'
 
@@ -570,14 +594,18 @@ class ExplainGridTDAttention(object):
         eng = self.engine
         self._enc = eng.encode(self.img)
         if caption_encode is None:
-            toks = eng.greedy(self._enc, max_cap_length, self.word_map['<start>'], self.word_map['<end>'])[0].tolist()
-            words = [t for t in toks[1:] if t != 0]
-            caption_encode = [toks[0]] + words
+            from .beam import caption_from_sequence
+            seq = eng.beam_search(self._enc, 2, max_cap_length, self.word_map['<start>'], self.word_map['<end>'])   # :935
+            caption_encode = caption_from_sequence(seq, self.word_map)
         self.beam_caption_encode = [int(c) for c in caption_encode]
         special = {self.word_map[k] for k in ('<start>', '<end>', '<unk>', '<pad>') if k in self.word_map}
         self.beam_caption = [' '.join(self.rev_word_map.get(c, str(c)) for c in self.beam_caption_encode[1:]
                                       if c not in special)]
         self.caption_length = len(self.beam_caption_encode) - 1
+        self.num_pixels = eng.P
+        self._rel = None
+        if self.caption_length == 0:
+            return
         cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=eng.device)
         self._tr = eng.trace(self._enc, cap, predictions=True)
         self.image_features = ops.nhwc_to_nchw(self._enc["feats"].contiguous(), eng.C, 14, 14)
@@ -616,6 +644,8 @@ class ExplainGridTDAttention(object):
         """(:1141-1156) -> ([T] x (1,3,H,W), [T] x (t+1,)); maps are the reference's running sums."""
         self.img_filepath = img_filepath
         self.get_hidden_parameters(img_filepath, caption_encode)
+        if self.caption_length == 0:          # the beam search produced <end> first: nothing to explain (empty lists, :1147-1156)
+            return [], []
         self._img_grad = None
         r_feat, r_words, row2img = self._relevance()
         maps = self.engine.vgg.relevance(r_feat, row2img)
@@ -641,6 +671,8 @@ class ExplainiGridTDGuidedGradient(ExplainGridTDAttention):
 
     def get_hidden_parameters(self, img, caption_encode=None, max_cap_length=50):
         super().get_hidden_parameters(img, caption_encode, max_cap_length)
+        if self.caption_length == 0:
+            return
         cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=self.engine.device)
         self._tr = self.engine.trace(self._enc, cap, predictions=True, grad=True)     # :1323-1422 (correct LSTM bias)
         self.predictions = self._tr["pred"][0]
@@ -659,6 +691,8 @@ class ExplainiGridTDGuidedGradient(ExplainGridTDAttention):
     def explain_caption(self, img_filepath, t_list=None, caption_encode=None):
         self.img_filepath = img_filepath
         self.get_hidden_parameters(img_filepath, caption_encode)
+        if self.caption_length == 0:          # the beam search produced <end> first: nothing to explain (empty lists, :1147-1156)
+            return [], []
         d_feat, r_words, row2img = self._relevance()
         maps = self.engine.vgg.guided_backprop(d_feat, row2img)
         return ([maps[t:t + 1] for t in range(self.caption_length)],
@@ -688,6 +722,8 @@ class ExplainGridTDGuidedGradCam(ExplainiGridTDGuidedGradient):
     def explain_caption(self, img_filepath, t_list=None, caption_encode=None):
         self.img_filepath = img_filepath
         self.get_hidden_parameters(img_filepath, caption_encode)
+        if self.caption_length == 0:          # the beam search produced <end> first: nothing to explain (empty lists, :1147-1156)
+            return [], []
         d_feat, r_words, row2img = self._relevance()
         eng = self.engine
         maps = ops.guided_gradcam(eng.vgg.guided_backprop(d_feat, row2img), eng.grad_cam(self._enc, d_feat, row2img),
@@ -716,6 +752,8 @@ class ExplainGridTDGradient(ExplainiGridTDGuidedGradient):
     def explain_caption(self, img_filepath, t_list=None, caption_encode=None):
         self.img_filepath = img_filepath
         self.get_hidden_parameters(img_filepath, caption_encode)
+        if self.caption_length == 0:          # the beam search produced <end> first: nothing to explain (empty lists, :1147-1156)
+            return [], []
         d_feat, r_words, row2img = self._relevance()
         maps = self._maps(d_feat, row2img)
         return ([maps[t:t + 1] for t in range(self.caption_length)],

@@ -369,6 +369,62 @@ def gridtd_model_greedy(sd, img, max_cap_length, start_id, end_id):
     return seq
 
 
+def beam_search(step_logits, vocab, beam_size, max_cap_length, start_id, end_id):
+    """models/gridTDmodel.py:400-478 `beam_search` (AoA: the same code on its own step), host logic only.
+    step_logits(seqs) -> (len(seqs), vocab) scores of the NEXT word for every live sequence (teacher-forced re-run of the
+    model forward on each prefix: same values as carrying the LSTM states along the beams, :460-465).
+    `beam_idx = top_words / vocab_size` (:444) is the integer division of the pinned PyTorch 1.4.
+    Returns `seq` (:469-472): the best complete sequence, else the first live one cut at 20 tokens."""
+    seqs = [[start_id] for _ in range(beam_size)]
+    cum = torch.zeros(beam_size)
+    complete, complete_scores = [], []
+    n_live = beam_size
+    for step in range(max_cap_length):
+        scores = cum[:n_live].unsqueeze(1) + torch.log_softmax(step_logits(seqs), dim=-1)
+        if step == 0:
+            top_sc, top = scores[0].topk(beam_size, -1, True, True)
+        else:
+            top_sc, top = scores.reshape(-1).topk(n_live, -1, True, True)
+        beam_idx, nxt = (top // vocab).tolist(), (top % vocab).tolist()
+        seqs = [seqs[b] + [w] for b, w in zip(beam_idx, nxt)]
+        inc = [i for i, w in enumerate(nxt) if w != end_id]
+        for i in sorted(set(range(len(nxt))) - set(inc)):
+            complete.append(seqs[i])
+            complete_scores.append(float(top_sc[i]))
+        n_live -= len(nxt) - len(inc)
+        if n_live == 0:
+            break
+        seqs = [seqs[i] for i in inc]
+        cum = top_sc[inc]
+    if complete:
+        return complete[complete_scores.index(max(complete_scores))]
+    return seqs[0][:20]
+
+
+def gridtd_beam_caption(sd, img, beam_size, max_cap_length, word_map):
+    """what `get_hidden_parameters` (models/gridTDmodel.py:935-937) explains: [<start>] + sen_idx of beam_search (:474)."""
+    feats, avg, _ = vgg_forward(sd, img)
+    start, end = word_map['<start>'], word_map['<end>']
+
+    def step_logits(seqs):
+        return torch.stack([gridtd_trace(sd, feats[0], avg[0], s + [0], model_bias=True)["pred"][-1] for s in seqs])
+    seq = beam_search(step_logits, sd["fc.weight"].shape[0], beam_size, max_cap_length, start, end)
+    drop = {word_map[k] for k in ('<start>', '<end>', '<unk>', '<pad>')}
+    return [start] + [w for w in seq if w not in drop], seq
+
+
+def aoa_beam_caption(sd, img, beam_size, max_cap_length, word_map, num_head=8):
+    feats, _, _ = vgg_forward(sd, img)
+    F_pix = feats[0].reshape(feats.shape[1], -1).t().contiguous()
+    start, end = word_map['<start>'], word_map['<end>']
+
+    def step_logits(seqs):
+        return torch.stack([aoa_trace(sd, F_pix, s + [0], num_head=num_head, grad=True)["pred"][-1] for s in seqs])
+    seq = beam_search(step_logits, sd["fc.weight"].shape[0], beam_size, max_cap_length, start, end)
+    drop = {word_map[k] for k in ('<start>', '<end>', '<unk>', '<pad>')}
+    return [start] + [w for w in seq if w not in drop], seq
+
+
 def normalize_relevance(x):
     """LRPtools/utils.py:55-64 with temperature = 1: x / max|x| + 1 (an all-zero row stays 0 -> weight 1)."""
     v = x.abs().max()

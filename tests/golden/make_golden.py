@@ -801,6 +801,51 @@ def gen_guided_gradcam(out, weights, T=3, seed=0, head=5):
 
 
 
+def gen_beam(out, weights, seed=0):
+    """The captions the explainers explain when none is given: `GridTDModel.beam_search(beam_size=2, max_cap_length=50)`
+    (models/gridTDmodel.py:400-478, called at :935) and `AOAModel.beam_search(beam_size=3, max_cap_length=20)`
+    (models/aoamodel.py, called at :992).  gridTD's `beam_idx = top_words / vocab_size` (:444) is integer division in the
+    PyTorch 1.4 the reference pins and true division today (a float index then raises): the harness restores the 1.4
+    meaning of `/` on integer tensors for the duration of the call.  Three cases per model: the natural run (random-init
+    weights never emit <end>: the cut at 20 tokens, :472), a word map whose <end> is a word the best beam produces (complete
+    sequences, :449-453, :469-470) and one whose <unk> is such a word (dropped from the encoded caption, :474)."""
+    import models.gridTDmodel as gtd
+    import models.aoamodel as aoa
+    g = dict(seed=np.int64(seed))
+    img = torch.from_numpy(weights.make_images(seed + 7, 1))
+    orig_div = torch.Tensor.__truediv__
+
+    def div14(a, b):
+        if torch.is_tensor(a) and not a.is_floating_point() and isinstance(b, int):
+            return torch.div(a, b, rounding_mode="floor")
+        return orig_div(a, b)
+    for tag, V, mk, ctor, beam, steps in (("grid", 9586, weights.make_gridtd_state, lambda V: gtd.GridTDModel(512, 512, V, 'vgg16'), 2, 50),
+                                          ("aoa", 11027, weights.make_aoa_state, lambda V: aoa.AOAModel(512, 512, 8, V, 'vgg16'), 3, 20)):
+        model = ctor(V)
+        model.load_state_dict(to_torch_sd(mk(seed=seed, vocab_size=V)))
+        model.eval()
+        wm = weights.make_word_map(V)
+        torch.Tensor.__truediv__ = div14
+        try:
+            _, sen = model.beam_search(img, wm, beam_size=beam, max_cap_length=steps)
+            late = [w for w in sen[3:] if w not in sen[:2]][0]          # a word the best beam reaches after a few steps
+            wm_end = dict(wm); wm_end['<end>'] = int(late)
+            _, sen_end = model.beam_search(img, wm_end, beam_size=beam, max_cap_length=steps)
+            wm_end0 = dict(wm); wm_end0['<end>'] = int(sen[0])         # <end> as the very first word: an empty caption
+            _, sen_end0 = model.beam_search(img, wm_end0, beam_size=beam, max_cap_length=steps)
+            wm_unk = dict(wm); wm_unk['<unk>'] = int(sen[1])
+            _, sen_unk = model.beam_search(img, wm_unk, beam_size=beam, max_cap_length=steps)
+        finally:
+            torch.Tensor.__truediv__ = orig_div
+        g[f"{tag}_V"], g[f"{tag}_beam"], g[f"{tag}_steps"] = np.int64(V), np.int64(beam), np.int64(steps)
+        g[f"{tag}_sen"], g[f"{tag}_sen_end"], g[f"{tag}_sen_unk"] = np.array(sen, np.int64), np.array(sen_end, np.int64), np.array(sen_unk, np.int64)
+        g[f"{tag}_end2"], g[f"{tag}_unk2"] = np.int64(wm_end['<end>']), np.int64(wm_unk['<unk>'])
+        g[f"{tag}_end0"], g[f"{tag}_sen_end0"] = np.int64(wm_end0['<end>']), np.array(sen_end0, np.int64)
+        print(tag, "beam:", sen, "| <end> :=", wm_end['<end>'], sen_end, "| <end> first:", sen_end0, "| <unk> :=", wm_unk['<unk>'], sen_unk)
+    np.savez(os.path.join(out, "beam.npz"), **g)
+
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -819,7 +864,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,m4,forwardlrp,guided_gradcam")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,m4,forwardlrp,guided_gradcam,beam")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -845,6 +890,8 @@ def main():
         gen_forwardlrp(HERE, weights)
     if "guided_gradcam" in todo:
         gen_guided_gradcam(HERE, weights)
+    if "beam" in todo:
+        gen_beam(HERE, weights)
     if "guided" in todo:
         gen_guided(HERE, weights)
     if "gradient" in todo:

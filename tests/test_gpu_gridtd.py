@@ -181,3 +181,33 @@ def test_forwardlrp_context_vs_reference():
         preds, wpreds, L = eng.forwardlrp_context(enc, caps, g["grid_lengths"].tolist(), g[f"grid_skip{sfx}"].tolist())
         assert L == int(g["grid_L"])
         _check_forwardlrp(g, "grid", sfx, preds, wpreds, L)
+
+
+def test_beam_search_caption_bit_exact_and_drop_in_explains_it():
+    """the caption the reference explains when none is given: `beam_search(beam_size=2, max_cap_length=50)`
+    (models/gridTDmodel.py:935).  Token ids against the reference's own beam_search (tests/golden/beam.npz), bit-exact, for
+    the natural run (cut at 20 tokens), an <end> that is reached, an <end> as first word (empty caption) and a dropped
+    <unk>; the drop-in `explain_caption(img)` then explains exactly that caption."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import types
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine, ExplainGridTDAttention
+    from lrp_amd.explainers.beam import caption_from_sequence
+    from test_oracle_golden import _beam_cases
+    g = np.load(os.path.join(GOLDEN, "beam.npz"))
+    V, cases = _beam_cases(g, "grid")
+    sd = weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=V)
+    eng = GridTDEngine(sd)
+    img = torch.from_numpy(weights.make_images(int(g["seed"]) + 7, 1)).cuda()
+    enc = eng.encode(img)
+    for key, wm in cases:
+        seq = eng.beam_search(enc, int(g["grid_beam"]), int(g["grid_steps"]), wm['<start>'], wm['<end>'])
+        assert caption_from_sequence(seq, wm)[1:] == g[f"grid_{key}"].tolist(), key
+    ex = ExplainGridTDAttention(types.SimpleNamespace(height=224, width=224), cases[1][1], model=sd)   # <end> is reached
+    maps, rw = ex.explain_caption(img)
+    assert ex.beam_caption_encode[1:] == g["grid_sen_end"].tolist() and len(maps) == len(rw) == len(g["grid_sen_end"])
+    want, _ = eng.explain_batch(img, torch.tensor([ex.beam_caption_encode], dtype=torch.int64), accumulate=True)
+    assert torch.equal(torch.cat(maps), want[0])
+    ex0 = ExplainGridTDAttention(types.SimpleNamespace(height=224, width=224), cases[2][1], model=sd)  # empty caption
+    assert ex0.explain_caption(img) == ([], [])

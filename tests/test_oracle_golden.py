@@ -299,3 +299,29 @@ def test_pyramid_expand_restatement_properties():
     M = ops.pyramid_expand_matrix(14, 16, "cpu")
     assert ((M @ cam @ M.t()) - e).abs().max() < 1e-6
     assert e.min() >= 0 and e.max() <= cam.max()           # smoothing + interpolation never overshoot
+
+
+def _beam_cases(g, tag):
+    V = int(g[f"{tag}_V"])
+    wm = weights.make_word_map(V)
+    cases = [("sen", wm)]
+    for key, tok, name in (("sen_end", "end2", '<end>'), ("sen_end0", "end0", '<end>'), ("sen_unk", "unk2", '<unk>')):
+        w2 = dict(wm)
+        w2[name] = int(g[f"{tag}_{tok}"])
+        cases.append((key, w2))
+    return V, cases
+
+
+def test_beam_search_captions_vs_reference():
+    # the captions the explainers explain when none is given (models/gridTDmodel.py:935 beam 2 / 50 steps; aoamodel.py:992
+    # beam 3 / 20 steps): token ids of the reference's own beam_search, bit-exact, incl. complete sequences (<end> reached),
+    # an empty caption (<end> first) and the dropped <unk>
+    g = np.load(os.path.join(GOLDEN, "beam.npz"))
+    img = torch.from_numpy(weights.make_images(int(g["seed"]) + 7, 1))
+    for tag, mk, fn in (("grid", weights.make_gridtd_state, O.gridtd_beam_caption), ("aoa", weights.make_aoa_state, O.aoa_beam_caption)):
+        V, cases = _beam_cases(g, tag)
+        sd = O.state_to_torch(mk(seed=int(g["seed"]), vocab_size=V))
+        for key, wm in cases:
+            cap, _ = fn(sd, img, int(g[f"{tag}_beam"]), int(g[f"{tag}_steps"]), wm)
+            assert cap[1:] == g[f"{tag}_{key}"].tolist(), (tag, key)
+    assert len(g["grid_sen_end0"]) == 0 and len(g["grid_sen"]) == 19
