@@ -109,7 +109,7 @@ __host__ __device__ constexpr int f8_slot_tap(int m, int i) { return 2 * m + i; 
 // v_mfma_f32_32x32x64_f8f6f4, K = 64 = 4 (tap, 16-channel) slices: 5 fp8 MFMAs per K-chunk (f8_slot_*) instead of 18
 // fp16 ones.  LDS pixel (80 B as before): 16 fp16 hi | 16 fp8 of x*2^-4 | 16 fp8 of (x-hi)*2^4 | pad.
 template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
-__global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+__global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     LRPXH_T(t_start);
 #ifdef LRPX_STAMP
     unsigned long long s_issue = 0, s_mfma = 0, s_commit = 0, s_barrier = 0, s_tap0 = 0, s_tap1 = 0, s_tap2 = 0;
@@ -205,9 +205,12 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
 #define LRPXH_ROWMAP 1
 #endif
     constexpr int RI = W * SEG;                                   // items per LDS row
-    constexpr bool ROWMAP = AL && (LRPXH_ROWMAP != 0) && (RI <= NT ? (RI > NT / 2) : true);
+    // narrow maps under a wide workgroup (512 threads, 224 items per row): RPS = 2 rows per slot, 256 threads each
+    constexpr int RPS = (RI <= NT / 2) ? 2 : 1;
+    constexpr int TPR = NT / RPS;                                 // threads per row of a slot
+    constexpr bool ROWMAP = AL && (LRPXH_ROWMAP != 0) && (RI <= NT ? (RI > NT / 2 || (RPS == 2 && RI > NT / 4)) : true);
     constexpr int SPR = (RI + NT - 1) / NT;                       // slots per row (1 when a row fits the workgroup)
-    constexpr int U = ROWMAP ? C::NSLOT * SPR : (NITEM + NT - 1) / NT;
+    constexpr int U = ROWMAP ? ((C::NSLOT + RPS - 1) / RPS) * SPR : (NITEM + NT - 1) / NT;
     constexpr int UR = AL ? 1 : U;
     constexpr int HO = H / 2, WO = W / 2;
     int sdst[UR], sgp[UR];
@@ -258,9 +261,15 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_f16x3_kernel(ConvArgs a
             if constexpr (ROWMAP) {
                 int t_ = tid;
                 if constexpr (!HOIST) asm volatile("" : "+v"(t_));
-                s = u / SPR;
-                rem = t_ + (u % SPR) * NT;
-                in_row = rem < RI;
+                if constexpr (RPS == 2) {
+                    s = u * 2 + (t_ >= TPR ? 1 : 0);
+                    rem = t_ >= TPR ? t_ - TPR : t_;
+                    in_row = (rem < RI) && (s < C::NSLOT);
+                } else {
+                    s = u / SPR;
+                    rem = t_ + (u % SPR) * NT;
+                    in_row = rem < RI;
+                }
             } else {
                 s = it / (W * SEG);
                 rem = it - s * (W * SEG);

@@ -1,0 +1,9 @@
+// f16+f8 relevance convolutions with 8-wave workgroups (256 output channels per workgroup, one workgroup per CU): the
+// A tile is staged (scaled, split, converted) once per 256 channels instead of once per 128
+#include "conv_launch.h"
+#include "conv_f16x3.h"
+namespace lrpx {
+int launch_h8_56w_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<56, 1, 8, true, EPI_REL_MUL, false, true>(a, s); }
+int launch_h8_28w_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<28, 1, 8, true, EPI_REL_MUL, false, true>(a, s); }
+int launch_h8_14w_rel(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<14, 1, 8, true, EPI_REL_MUL, false, true>(a, s); }
+}

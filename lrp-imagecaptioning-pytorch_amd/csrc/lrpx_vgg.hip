@@ -6,6 +6,7 @@
 //   relevance: LRPtools/lrp_wrapper.py:63-87 compute_lrp -> per leaf, in reverse order,
 //              Conv2d alpha1beta0 (lrp_modules.py:124-150), ReLU identity (:42-46), MaxPool2d (:182-195)
 #include <atomic>
+#include <cstdlib>
 
 #include "conv_launch.h"
 #include "conv_f16x3.h"
@@ -109,6 +110,8 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
             LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
                          "conv_mfma: too many (image, pooled pixel, channel) elements for the pooled-input kernel");
             if (f8) {
+                static const int widep = getenv("LRPX_WIDE") ? atoi(getenv("LRPX_WIDE")) : 7;
+                if ((widep & 4) && d->hw == 56 && d->n_oc >= 256) return launch_h8_56w_pool(a, s);
                 if (d->hw == 224 && d->n_oc <= 64) return launch_h8_224_pool(a, s);
                 if (d->hw == 112 && d->n_oc > 64) return launch_h8_112_pool(a, s);
                 if (d->hw == 56) return launch_h8_56_pool(a, s);
@@ -122,6 +125,14 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
             LRPX_REQUIRE(false, "conv_mfma: no pooled-input f16x3 kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
         }
         if (f8) {
+            // 256 output channels and more: 8-wave workgroups (256 channels per workgroup, ONE workgroup per CU).  The chain
+            // alone is as fast as with two 4-wave workgroups per CU (20.9 ms either way), but the step with batches in
+            // flight is 2 % faster (12 410 -> 12 690 maps/s sustained, tools/ab_bench.sh): one double-buffered tile per CU
+            // instead of two leaves LDS for the other batches' kernels.  LRPX_WIDE=0 switches back (A/B only).
+            static const int wide = getenv("LRPX_WIDE") ? atoi(getenv("LRPX_WIDE")) : 7;
+            if ((wide & 1) && d->n_oc >= 256 && d->hw == 56) return launch_h8_56w_rel(a, s);
+            if ((wide & 1) && d->n_oc >= 256 && d->hw == 28) return launch_h8_28w_rel(a, s);
+            if ((wide & 2) && d->n_oc >= 256 && d->hw == 14) return launch_h8_14w_rel(a, s);
             if (d->hw == 224) return launch_h8_224_rel(a, s);
             if (d->hw == 112) return d->n_oc <= 64 ? launch_h8_112n_rel(a, s) : launch_h8_112_rel(a, s);
             if (d->hw == 56) return launch_h8_56_rel(a, s);
