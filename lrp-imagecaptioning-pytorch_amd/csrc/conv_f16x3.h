@@ -103,6 +103,112 @@ static __device__ unsigned long long g_stamp_h3[12];
 // 32-63 (k = 32..63) the S slices.  The two lane halves then read the same pixels, 16 bytes apart (planes 48 / 32).
 __host__ __device__ constexpr int f8_slot_tap(int m, int i) { return 2 * m + i; }        // > 8: zero weights
 
+// REL_MUL epilogue with 16-byte accesses ("wide"): out = x * acc for the wave's 7 accumulator tiles of 32 pixels x 32
+// channels.  In the MFMA result layout a lane owns ONE channel of 16 pixels, so the plain epilogue issues 112 dword loads
+// and 112 dword stores per lane, each touching two 128-byte runs - measured 21 % of a workgroup tile's time on the 28x28
+// layers (s_memtime stamps), not bandwidth: the memory pipeline of the CU moves 256 bytes per instruction.  Here every
+// tile goes through a wave-private LDS patch (32 rows x 36 floats; the staging buffers are free after the K loop) and
+// comes back as float4 along the channels: lane L owns the channel quad L % 8 of pixel rows L / 8 + 8k, k = 0..3 - 4
+// loads + 4 stores of 16 bytes per lane and tile, 4x fewer memory instructions, whole 128-byte runs per 8 lanes.
+// Arithmetic, results and the per-map maxima are the same as in epi_gather / epi_finish (bit-identical outputs).
+template <int HW, bool AL>
+__device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc)[7], float* __restrict__ scr, const int wm,
+                                                 const int ocb, const int lane, const long g0, const long total_pix,
+                                                 unsigned* __restrict__ oamax) {
+    constexpr int PITCH_F = 36;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qd = lane & 7, r0 = lane >> 3;
+    const int ncol = a.oc_split;
+    const int oc4 = ocb * 32 + 4 * qd;
+    const bool col_ok = oc4 < ncol;
+    const float* __restrict__ X = a.X;
+    float* __restrict__ O = a.out1 ? a.out1 : a.out0;
+    const int ch = a.out_chunk;
+    const int ostr = ch > 0 ? ch : ncol;
+    const long obase = ch > 0 ? (long)(oc4 / ch) * total_pix * ch + (oc4 % ch) : (long)oc4;
+    const unsigned P = (unsigned)a.pix_per_map;
+    const int nmax = a.n_maps - 1;
+    const long pix0 = g0 * HW;
+    // Per accumulator tile j (32 consecutive pixels, shorter than a map: at most ONE map boundary inside it) everything
+    // but the lane's pixel offset dq = r0 + 8k is wave-uniform: first map n0 and pixel-in-map p0 of the tile's first pixel,
+    // the images of n0 and n0 + 1.  (Aligned tiles: the whole workgroup tile lies in one map.)
+    auto tile_base = [&](const int j, unsigned& n0, int& p0, long& b0, long& b1) {
+        const unsigned q0t = (unsigned)(wm * 224 + 32 * j);
+        const unsigned rr = q0t / (unsigned)HW, c0 = q0t - rr * HW;
+        const unsigned g = (unsigned)g0 + rr;
+        n0 = g / (unsigned)HW;
+        p0 = (int)((g - n0 * HW) * HW + c0);
+        const long img0 = a.map2img ? a.map2img[min((int)n0, nmax)] : (long)n0;
+        const long img1 = AL ? img0 : (a.map2img ? a.map2img[min((int)n0 + 1, nmax)] : (long)n0 + 1);
+        b0 = (img0 * P + p0) * (long)ncol + oc4;
+        b1 = (img1 * P + p0 - (long)P) * (long)ncol + oc4;
+    };
+    // ---- multiplicand loads run ahead of the tiles: all 28 up front for aligned tiles; map-straddling tiles (two
+    // candidate addresses per load, more live registers) keep a ring of 3 tiles (issued two tiles ahead: such a load is
+    // older than the stores it would otherwise queue behind in the in-order vmcnt)
+    constexpr int RING = AL ? 7 : 3;
+    f32x4 xv[RING][4];
+    auto load_x = [&](const int j) {
+        unsigned n0; int p0; long b0, b1;
+        tile_base(j, n0, p0, b0, b1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dq = r0 + 8 * k;
+            const long gp = pix0 + wm * 224 + 32 * j + dq;
+            const bool ok = col_ok && (AL || gp < total_pix);
+            const long xi = ((AL || p0 + dq < (int)P) ? b0 : b1) + (long)dq * ncol;
+            xv[j % RING][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) xv[j % RING][k] = *reinterpret_cast<const f32x4*>(X + xi);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < (AL ? 7 : 2); ++j) load_x(j);
+    const unsigned n_first = (unsigned)g0 / (unsigned)HW;    // map of the workgroup tile's first pixel
+    float m_al = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        if constexpr (!AL) { if (j + 2 < 7) load_x(j + 2); }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * lh) * PITCH_F + li] = acc[j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private patch: LDS ops of one wave run in order
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(scr + (r0 + 8 * k) * PITCH_F + 4 * qd);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and the next tile's writes come after these reads
+        unsigned nt0; int p0; long b0_, b1_;
+        tile_base(j, nt0, p0, b0_, b1_);
+        float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 xk = xv[j % RING][k];
+            const f32x4 r = {v[k][0] * xk[0], v[k][1] * xk[1], v[k][2] * xk[2], v[k][3] * xk[3]};
+            const int dq = r0 + 8 * k;
+            const long gp = pix0 + wm * 224 + 32 * j + dq;
+            if (col_ok && (AL || gp < total_pix)) {
+                float* op = O + gp * (long)ostr + obase;
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(op));
+                const float m = fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3])));
+                if (AL || p0 + dq < (int)P) m0 = fmaxf(m0, m); else m1 = fmaxf(m1, m);
+            }
+        }
+        if (oamax) {
+            if constexpr (AL) {
+                m_al = fmaxf(m_al, m0);
+            } else {
+                m0 = wave_max(m0); m1 = wave_max(m1);
+                if (lane == 0 && (int)nt0 <= nmax) amax_update(&oamax[nt0], m0);
+                if (lane == 0 && (int)nt0 + 1 <= nmax) amax_update(&oamax[nt0 + 1], m1);
+            }
+        }
+    }
+    if constexpr (AL) {
+        if (oamax) {
+            m_al = wave_max(m_al);
+            if (lane == 0 && (int)n_first <= nmax) amax_update(&oamax[n_first], m_al);
+        }
+    }
+}
+
 // F8 ("f16+f8x2"): the two CROSS products a0*b1 + a1*b0 - 2^-11 of the result - do not need fp16 operands: with both
 // factors rounded to fp8 e4m3 (4 significand bits) their error is 2^-11 * 2^-4 per product, random sign; simulated
 // through all 13 layers the maps move by < 1e-5 of their maximum (tolerance 1e-4; plain f16x3: ~1e-6).  They run on
@@ -163,7 +269,6 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         }
     }
     if (mtile >= m_tiles) return;
-
     const int ocb = nblk * NWN + wn;
     const bool wave_active = ocb * 32 < a.n_oc;
     const int nchunk = a.cin / KC;
@@ -461,19 +566,37 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         }                                                                                                    \
     }
 
+    // STAGGER (8-wave workgroups, double-buffered): the two waves of a SIMD (wave w and w + 4 of the workgroup) share every
+    // barrier, so with one schedule for all waves both sit in their MFMA phase together and in their staging phase
+    // together - the matrix pipe idles while both convert and write LDS (measured: pipe busy 58 %).  Half a period of
+    // skew fixes that without another barrier: the upper half of the waves ("group 1") commits its share of chunk c + 1
+    // at the START of interval c (loaded one interval earlier) and then runs its MFMAs, the lower half runs its MFMAs
+    // first and commits at the end - on every SIMD one wave's conversions now run in the shadow of the other's MFMAs.
+    // Measured: +1 % (a single wave's MFMA phase does not saturate the pipe, so the overlap buys less than the idle share
+    // suggests); grouping odd / even waves instead is 1 % slower than no skew: w and w + 4 are the SIMD partners.
+    // Buffers: chunk c is read from buffer c & 1 between barrier c - 1 and barrier c by everyone; writes to it happen
+    // after barrier c - 2 (group 1, chunk c: right behind that barrier; group 0: at the end of interval c - 1).
+#ifndef LRPXH_STAGGER
+#define LRPXH_STAGGER 1
+#endif
+#ifndef LRPXH_INTERLEAVE
+#define LRPXH_INTERLEAVE 0
+#endif
+    constexpr bool STAG = DB && (LRPXH_STAGGER != 0) && (LRPXH_INTERLEAVE == 0) && (MT * NWN >= 8);
+    const int grp = STAG ? (wave >= MT * NWN / 2 ? 1 : 0) : 0;     // wave-uniform (waves w and w + 4 share a SIMD)
     if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(0) } else { LRPXH_ISSUE(0) }
     for (int i = tid; i < NBUF * BUFB / 16; i += NT) reinterpret_cast<u32x4_*>(ldsb)[i] = u32x4_{0, 0, 0, 0};
     __syncthreads();
     if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(0) } else { LRPXH_COMMIT(0) }
+    if constexpr (STAG) {
+        if (grp == 1 && a.cin / 16 > 1) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(1) } else { LRPXH_ISSUE(1) } }
+    }
     // INTERLEAVE (experiment, off): staging software-pipelined INTO the MFMA phase instead of running as separate phases
     // between barriers - during the taps of chunk c the wave commits chunk c+1 (loaded during chunk c-1) to the other
     // LDS buffer, one item per tap, and then re-issues the same registers for chunk c+2.  Measured: 26.1 ms against
     // 24.9 ms for the phased schedule (chain of 320 maps).  The two waves of a SIMD already time-slice the matrix pipe
     // - one wave's staging phase runs under the other's MFMAs - and VALU placed between a wave's own dependent MFMAs
     // only delays that wave's next MFMA issue (in-order issue).
-#ifndef LRPXH_INTERLEAVE
-#define LRPXH_INTERLEAVE 0
-#endif
 #ifndef LRPXH_ILV_VALU
 #define LRPXH_ILV_VALU 8      // VALU instructions of the staging work scheduled after each accumulator tile's 3 MFMAs
 #endif
@@ -530,13 +653,18 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // carries + 16 for them)
     const int c8 = lh ? 16 : 48;
     __syncthreads();
+    if constexpr (STAG) {
+        if (grp == 1 && nchunk > 1) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(1) } else { LRPXH_COMMIT(1) } }
+    }
 
     LRPXH_T(t_loop);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = chunk + 1 < nchunk;
         LRPXH_T(ta);
         if constexpr (!ILV) {
-            if (more) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(chunk + 1) } else { LRPXH_ISSUE(chunk + 1) } }
+            // group 0 loads the next chunk, group 1 (which has already committed the next chunk) the one after it
+            const int cn = chunk + 1 + grp;
+            if (cn < nchunk) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(cn) } else { LRPXH_ISSUE(cn) } }
         }
         LRPXH_T(tb);
         if (wave_active) {
@@ -687,10 +815,13 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         }
         if constexpr (DB) {
             if constexpr (!ILV) {
-                if (more) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
+                if (more && grp == 0) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
             }
             LRPXH_T(td);
             __syncthreads();
+            if constexpr (STAG) {     // group 1: chunk + 2 into the buffer everyone has just finished reading
+                if (grp == 1 && chunk + 2 < nchunk) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(chunk & 1) } else { LRPXH_COMMIT(chunk & 1) } }
+            }
             LRPXH_T(te);
 #ifdef LRPX_STAMP
             s_issue += tb - ta; s_mfma += tc - tb; s_commit += td - tc; s_barrier += te - td;
@@ -762,6 +893,19 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     unsigned* __restrict__ oamax = (EPI == EPI_FWD_DUAL) ? a.out0_amax
                                    : (((EPI == EPI_REL || EPI == EPI_REL_MUL) && a.out1) ? a.out1_amax : nullptr);
     EpiMax mx0 = {0.f, 0.f}, mx1 = mx0, mx2 = mx0, mx3 = mx0, mx4 = mx0, mx5 = mx0, mx6 = mx0;   // (scalars: an array
+#ifndef LRPXH_WIDE_EPI
+#define LRPXH_WIDE_EPI 1
+#endif
+    // measured per layer (chain of 320 maps, tools/ab_chain.sh): the map-straddling 28x28 / 14x14 kernels gain 4-6 % (and
+    // lose their 11-13 spilled VGPRs: the two-map dword epilogue held two candidate addresses per element); the aligned
+    // 56 / 112 / 224 kernels are 1-5 % SLOWER with it (their dword epilogue has compile-time offsets from one base), so
+    // LRPXH_WIDE_EPI = 1 selects it for the straddling kernels only, 2 everywhere
+    if constexpr (EPI == EPI_REL_MUL && ((LRPXH_WIDE_EPI == 1 && !AL) || LRPXH_WIDE_EPI == 2)) {
+        // (the K loop ends with a barrier: nobody reads the staging buffers any more; 32 x 36 floats per wave)
+        float* scr = reinterpret_cast<float*>(ldsb) + wave * (32 * 36);
+        epi_rel_mul_wide<HW, AL>(a, acc, scr, wm, ocb, lane, g0, total_pix, oamax);
+        return;
+    }
     if constexpr (EPI == EPI_REL_MUL) {                                                  //  would live in scratch)
         // one multiplicand per element: all 112 loads are issued before the first store (stores share the in-order
         // vmcnt with loads - a load behind a store waits for the store's write acknowledgement)

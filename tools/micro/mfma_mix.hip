@@ -77,6 +77,17 @@ int main() {
         printf("   9 f16 + 5 fp8: %.3f ms   9 f16 + 5 fp6: %.3f ms (x%.2f of the fp8 mix)\n", t4, t5, t4 / t5);
         const double mf = 512.0 * 4 * iters * 7;   // waves * chunks * tiles
         printf("   f16 rate in variant 0: %.0f TFLOP/s\n", mf * 27 * 32768 / (t0 * 1e-3) / 1e12);
+        // the shipped mix (variant 4) as the conv kernels count it: algorithmic = 9 x 32768 flop per (tile, chunk); executed
+        // fp16-equivalent = 9 f16 MFMAs + 5 fp8 MFMAs at half weight = 19 x 32768
+        printf("   variant 4 (shipped f16+f8 mix), pipe alone: %.0f algorithmic TFLOP/s = %.0f fp16-equivalent TFLOP/s\n",
+               mf * 9 * 32768 / (t4 * 1e-3) / 1e12, mf * 19 * 32768 / (t4 * 1e-3) / 1e12);
+    }
+    {   // sustained: the shipped mix back to back for ~5 s (power-limited clock)
+        const double mf = 512.0 * 4 * iters * 7;
+        double tot = 0; int n = 0; float last = 0;
+        while (tot < 5000.0) { last = run<4>(src, dst, iters); tot += last; ++n; }
+        printf("sustained variant 4 over %.1f s: last launch %.3f ms = %.0f algorithmic TFLOP/s = %.0f fp16-equivalent TFLOP/s\n",
+               tot * 1e-3, last, mf * 9 * 32768 / (last * 1e-3) / 1e12, mf * 19 * 32768 / (last * 1e-3) / 1e12);
     }
     float o; hipMemcpy(&o, dst, 4, hipMemcpyDeviceToHost); printf("checksum %g\n", o);
     return 0;
