@@ -56,7 +56,7 @@ MODE_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "bf16x6: exact 3-way bf
              2: "f16x3: per-map power-of-two scaling, 2-way fp16 split, 3 products, fp32 accumulate",
              3: "f16+f8x2: as f16x3, the two cross products (2^-11 of the result) as fp8 e4m3 MFMAs (v_mfma_f32_32x32x64_f8f6f4)"}
 MODE_KERNEL = {0: "conv_mfma_kernel<56,16,1,4,9,REL>", 1: "conv_bf16x6_kernel<56,1,4,true,REL>",
-               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>", 3: "conv_f16x3_kernel<28,1,4,true,REL_MUL,false,true>"}
+               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>", 3: "conv_f16x3_kernel<28,1,8,true,REL_MUL,false,true>"}
 # mode 3: one fp16 product + two fp8 products; the fp8 dense peak is twice the fp16 one, so an fp8 flop counts half:
 # `achieved` / `peak` is then (time the matrix cores need at their peaks) / (measured time), as in the other modes
 PRODUCTS = {0: 1, 1: 6, 2: 3, 3: 2}
@@ -68,7 +68,7 @@ MODE_DTYPE = {0: "f32", 1: "bf16x6 split products, f32 accumulate", 2: "f16x3 sp
 # streaming reads, MI355X_MICROARCH.md §HBM] + WRITE_SIZE, divided by the launches and scaled to the maps of this run
 TRAFFIC_FILES = ["profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
 TRAFFIC_KERNEL = {0: "conv_mfma_kernel<56, 16, 1, 4, 9, 1>", 1: "conv_bf16x6_kernel<56, 1, 4, true, 1>",
-                  2: "conv_f16x3_kernel<56, 1, 4, true, 5, false, false>", 3: "conv_f16x3_kernel<28, 1, 4, true, 5, false, true>"}
+                  2: "conv_f16x3_kernel<56, 1, 4, true, 5, false, false>", 3: "conv_f16x3_kernel<28, 1, 8, true, 5, false, true>"}
 
 
 def host_cores():
