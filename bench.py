@@ -150,7 +150,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the roofline.modes sweep (every conv mode, same process)")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained sub-measurement (0 = off)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (config 2, LRP)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph per batch in flight (config 2, LRP)")
     ap.add_argument("--pipeline", type=int, default=None,
                     help="independent batches in flight on separate HIP streams (1 = serial steps; default 3, 2 for the "
                          "large configs 3 / 4); every step is still one full pass over one batch, the decoder's "
@@ -208,10 +208,10 @@ def main():
     torch.set_num_threads(min(8, host_cores()))
     if rank == 0:
         log(f"config {a.config} ({a.explainer}): building weights + engine (B={B}, T={T}, V={V}, world={world})")
-    n_pipe = 1 if a.graph else max(1, a.pipeline)
+    n_pipe = max(1, a.pipeline)
     streams = [torch.cuda.Stream() for _ in range(n_pipe)] if n_pipe > 1 else [None]
     caps = torch.from_numpy(weights.make_captions(200 + rank, B, T, V)).cuda()
-    state = {}
+    state = {"caps": caps}
     guided = a.explainer == "lrp+guided"
     maps_per_gpu = B * T * (2 if guided else 1)
     has_vgg = a.config != 5
@@ -226,6 +226,7 @@ def main():
         from lrp_amd.explainers.gridtd import GridTDEngine
         eng = GridTDEngine(weights.make_gridtd_state(seed=0, vocab_size=V))
         images = torch.from_numpy(weights.make_images(100 + rank, B)).cuda()     # every rank: its own shard (seed offset)
+        state["images"] = images
 
         def one_step(e, k):
             enc = e.encode(images)
@@ -280,11 +281,12 @@ def main():
     def step(end_events=None):
         k = step_no[0] % n_pipe
         step_no[0] += 1
-        if a.graph and a.config == 2 and not guided:
-            out = eng.explain_batch_graph(images, caps, accumulate=True)
-        elif n_pipe > 1:
+        use_graph = a.graph and a.config == 2 and not guided
+        if n_pipe > 1:
             with torch.cuda.stream(streams[k]):
-                out = one_step(engines[k], k)
+                # --graph: the step replayed from a HIP graph captured per replica (same kernels, same buffers every step)
+                out = engines[k].explain_batch_graph(images, caps, accumulate=True, predictions=True) if use_graph \
+                    else one_step(engines[k], k)
                 if a.gather and world > 1 and has_vgg:
                     dist.gather(out[0], gathered, dst=0)
                 if end_events is not None:
@@ -292,6 +294,8 @@ def main():
                     ev.record()
                     end_events.append(ev)
             return out
+        elif use_graph:
+            out = eng.explain_batch_graph(images, caps, accumulate=True, predictions=True)
         else:
             out = one_step(eng, 0)
         if a.gather and world > 1 and has_vgg:
@@ -330,7 +334,8 @@ def main():
     torch.cuda.synchronize()
     ev0.record()
     events = [ev0]
-    dt, (maps, _) = timed(a.steps, events)
+    dt, outs = timed(a.steps, events)
+    maps = outs[0]
     ops.check_relevance(maps, finite=True, nonzero=True)      # the reference's asserts, outside the timed region
     # step completions by HIP events; with n_pipe batches in flight completions come in bursts, so the per-step time is
     # taken over windows of n_pipe consecutive completions: (end[i] - end[i - n_pipe]) / n_pipe, median over the region
@@ -373,7 +378,7 @@ def main():
                                  f"({w} batches in flight complete in bursts); hip_event_ms_per_step = last completion / steps")
         if world == 1 and has_vgg:
             out["roofline"] = roofline(a, lib, eng, state, maps, B, T, mode)
-            if a.config == 2 and not guided and not a.no_modes and not a.graph:
+            if a.config == 2 and not guided and not a.no_modes and not a.graph:      # (the sweep switches modes between eager steps)
                 out["roofline"]["modes"] = mode_sweep(lib, engines, streams, one_step, state, B, T, mode)
         elif world == 1:
             # config 5: no CNN stage; HBM-bound projector / v_proj rules.  Algorithmic bytes per map: read F,
@@ -388,6 +393,10 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def e_images(state):
+    return state["images"]
 
 
 def chain_ms(eng, r_feat, row2img, out, reps):
@@ -405,6 +414,11 @@ def chain_ms(eng, r_feat, row2img, out, reps):
 def roofline(a, lib, eng, state, maps, B, T, mode):
     import ctypes as C
     torch.cuda.synchronize()
+    if "chain_in" not in state:          # (--graph: the step ran inside a captured graph) one eager decoder pass for the chain's input
+        e = eng
+        enc = e.encode(e_images(state))
+        state["chain_in"] = e.relevance(enc, e.trace(enc, state["caps"], predictions=False))[::2]
+        state["maps0"] = torch.empty(B * T, 3, 224, 224, device="cuda")
     r_feat, row2img = state["chain_in"]
     out = state["maps0"]
     reps = max(3, min(a.steps, 10))

@@ -363,14 +363,14 @@ class GridTDEngine:
         check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
         return r_feat, rs["r_words"], row2img
 
-    def explain_batch_graph(self, images, captions, accumulate=False):
+    def explain_batch_graph(self, images, captions, accumulate=False, predictions=False):
         """`explain_batch` replayed from a captured HIP graph (one graph per (B,T) shape): the ~450 kernel launches
         of a step (decoder trace and lock-step relevance are launch-bound) are issued by one hipGraphLaunch instead
         of the Python loop.  Inputs are copied into the graph's static buffers; the returned tensors are the graph's
         static outputs (overwritten by the next call with the same shape)."""
         images = images.to(self.device, torch.float32)
         captions = captions.to(self.device, torch.int64)
-        key = (tuple(images.shape), tuple(captions.shape), bool(accumulate))
+        key = (tuple(images.shape), tuple(captions.shape), bool(accumulate), bool(predictions))
         g = self._graphs.get(key) if hasattr(self, "_graphs") else None
         if g is None:
             if not hasattr(self, "_graphs"):
@@ -379,12 +379,12 @@ class GridTDEngine:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                       # warm-up outside capture (kernel attributes, caches)
-                self.explain_batch(st_img, st_cap, accumulate=accumulate)
+                self.explain_batch(st_img, st_cap, accumulate=accumulate, predictions=predictions)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self.explain_batch(st_img, st_cap, accumulate=accumulate)
+                out = self.explain_batch(st_img, st_cap, accumulate=accumulate, predictions=predictions)
             g = self._graphs[key] = (graph, st_img, st_cap, out)
         graph, st_img, st_cap, out = g
         st_img.copy_(images)
@@ -482,20 +482,24 @@ class GridTDEngine:
                                        self.C, stream_ptr()))
         return cam
 
-    def explain_batch(self, images, captions, lens=None, accumulate=False, return_features=False):
+    def explain_batch(self, images, captions, lens=None, accumulate=False, return_features=False, predictions=False):
         """Batched `explain_caption` (gridTDmodel.py:1141-1156): images (B,3,224,224), captions (B,T+1) int64.
         Returns maps (B,T,3,224,224) and r_words (B,T,T) (row t holds t+1 valid entries).
-        accumulate=True reproduces the running sums the reference returns (lrp_wrapper.py:64-82 quirk)."""
+        accumulate=True reproduces the running sums the reference returns (lrp_wrapper.py:64-82 quirk).
+        predictions=True also computes the (B,T,V) scores the reference's explainer keeps (`self.predictions`, :1011; read
+        by evaluation.py:109) and returns them as a third tensor."""
         images = images.to(self.device, torch.float32).contiguous()
         captions = captions.to(self.device, torch.int64).contiguous()
         B, T = captions.shape[0], captions.shape[1] - 1
         enc = self.encode(images)
-        tr = self.trace(enc, captions, predictions=False)
+        tr = self.trace(enc, captions, predictions=predictions)
         r_feat, r_words, row2img = self.relevance(enc, tr, lens)
         maps = self.vgg.relevance(r_feat, row2img)
         if accumulate:
             maps = ops.cumsum_maps(maps, B, T)
         out = (maps.view(B, T, 3, 224, 224), r_words.view(B, T, T))
+        if predictions:
+            out = out + (tr["pred"],)
         if return_features:
             out = out + (r_feat.view(B, T, self.P, self.C), tr, enc)
         return out
