@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblrpx.so")
+# LRPX_LIB_PATH: another build of the same ABI (A/B of kernel variants on one box, tools/ab_chain.sh); default = in-tree
+LIB_PATH = os.environ.get("LRPX_LIB_PATH") or os.path.join(_HERE, "csrc", "liblrpx.so")
 
 OK, EINVAL, EARCH, ELAUNCH, ENONFINITE, EZERO = range(6)
 PACK_FWD_DUAL, PACK_BWD_POS, PACK_BWD_FIRST, PACK_BWD_PLAIN, PACK_DENSE_T, PACK_DENSE, PACK_FWD, PACK_FWD_DUAL_FIRST = range(8)

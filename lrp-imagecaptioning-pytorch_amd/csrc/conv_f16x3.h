@@ -681,6 +681,76 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 // (experiment) software pipeline by scheduling groups: the LDS reads of accumulator tile t+1 are placed
                 // before the MFMAs of tile t
                 if constexpr (LRPXH_F8_SGB != 0) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+#ifndef LRPXH_F8_PIPE
+#define LRPXH_F8_PIPE 3
+#endif
+                // (8-wave workgroups only: their staging needs half the registers per thread; the 4-wave kernels spill with the
+                // extra operand sets and run 27-38 % slower with the pipeline - measured per layer, tools/ab_chain.sh)
+                if constexpr (LRPXH_F8_PIPE != 0 && MT * NWN >= 8) {
+                // Operand pipeline of depth D = LRPXH_F8_PIPE.  Left to itself the compiler (at 240+ VGPRs) keeps ONE set of
+                // A-fragment registers and emits read -> s_waitcnt lgkmcnt(0) -> MFMA for every MFMA: each one waits for its
+                // own LDS round trip and only the partner wave fills the pipe (busy 79 % of the phase).  Here the 98 MFMAs
+                // of a K-chunk are one sequence of ops k = (tap row g, tile j, kind m); the A operand of op k + D is read
+                // before MFMA k is issued (D operand sets in a ring); `sched_barrier(0)` fences keep the compiler's scheduler
+                // from sinking the reads back to their uses (scheduling groups alone did not hold the order).  Measured
+                // (chain of 320 maps): 56x56 -10 %, 28x28 -7 %, 14x14 -9 % per launch at D = 2 (D = 3: the same).
+                constexpr int D = LRPXH_F8_PIPE != 0 ? LRPXH_F8_PIPE : 1;
+                constexpr int TPX[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 8};
+                // op k -> (g, j, m): tap rows 0 and 1 have 5 MFMAs per tile (2 fp8 + 3 fp16), row 2 has 4 (1 fp8 + 3 fp16)
+                auto og = [](const int k) constexpr { return k < 35 ? 0 : (k < 70 ? 1 : 2); };
+                auto oj = [](const int k) constexpr { return k < 70 ? (k % 35) / 5 : (k - 70) / 4; };
+                auto om = [](const int k) constexpr { return k < 70 ? (k % 35) % 5 : ((k - 70) % 4 == 0 ? 0 : (k - 70) % 4 + 1); };   // 0,1: fp8; 2..4: fp16 dx 0..2
+                auto rd = [&](const int k) {
+                    const int g = og(k), j = oj(k), m = om(k);
+                    if (m < 2) {                                   // fp8 operand: taps 4g + 2m, 4g + 2m + 1
+                        const char* a8 = abuf + abase[j] + c8;
+                        const int t = 4 * g + 2 * m;
+                        const u32x4_ x0 = *reinterpret_cast<const u32x4_*>(a8 + (TPX[t] / 3) * PITCH + (TPX[t] % 3) * PSTRIDE);
+                        const u32x4_ x1 = *reinterpret_cast<const u32x4_*>(a8 + (TPX[t + 1] / 3) * PITCH + (TPX[t + 1] % 3) * PSTRIDE);
+                        return i32x8_{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
+                    }
+                    const u32x4_ x0 = *reinterpret_cast<const u32x4_*>(abuf + abase[j] + g * PITCH + (m - 2) * PSTRIDE);
+                    return i32x8_{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], 0, 0, 0, 0};
+                };
+                i32x8_ ring[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) ring[d] = rd(d);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step) * BP;
+#pragma unroll
+                    for (int p = 0; p < BP; ++p)
+                        if (p < 5 || (g + NQ - 1) % 3 != 2) bq[NQ - 1][p] = wp[(nxt + p) * 64];
+                    const f16x8 bh[3] = {__builtin_bit_cast(f16x8, bq[0][0]), __builtin_bit_cast(f16x8, bq[0][1]),
+                                         __builtin_bit_cast(f16x8, bq[0][2])};
+                    const i32x8_ bm0 = {(int)bq[0][3][0], (int)bq[0][3][1], (int)bq[0][3][2], (int)bq[0][3][3],
+                                        (int)bq[0][4][0], (int)bq[0][4][1], (int)bq[0][4][2], (int)bq[0][4][3]};
+                    const i32x8_ bm1 = {(int)bq[0][5][0], (int)bq[0][5][1], (int)bq[0][5][2], (int)bq[0][5][3],
+                                        (int)bq[0][6][0], (int)bq[0][6][1], (int)bq[0][6][2], (int)bq[0][6][3]};
+                    constexpr int K0[3] = {0, 35, 70}, KN[3] = {35, 35, 28};
+#pragma unroll
+                    for (int kk = 0; kk < KN[g]; ++kk) {
+                        const int k = K0[g] + kk;
+                        const int j = oj(k), m = om(k);
+                        const i32x8_ cur = ring[k % D];
+                        if (k + D < 98) {
+                            ring[k % D] = rd(k + D);
+                            __builtin_amdgcn_sched_barrier(0);       // (a fence for the compiler's scheduler, no instruction)
+                        }
+                        if (m < 2) {
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cur, m == 0 ? bm0 : bm1, acc[j], 0, 0, 0, 0, 0, 0);
+                        } else {
+                            const u32x4_ c4 = {(unsigned)cur[0], (unsigned)cur[1], (unsigned)cur[2], (unsigned)cur[3]};
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, c4), bh[m - 2], acc[j], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NQ - 1; ++i)
+#pragma unroll
+                        for (int p = 0; p < BP; ++p) bq[i][p] = bq[i + 1][p];
+                }
+                } else {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step) * BP;
@@ -734,6 +804,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                     for (int i = 0; i < NQ - 1; ++i)
 #pragma unroll
                         for (int p = 0; p < BP; ++p) bq[i][p] = bq[i + 1][p];
+                }
                 }
             } else {
             f16x8 n0, n1;
