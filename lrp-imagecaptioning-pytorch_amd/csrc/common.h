@@ -42,6 +42,9 @@ int maxpool_relevance_amax(const float* x, const float* r_out, const float* zdiv
 int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c, int stab,
                      unsigned* amax, hipStream_t stream);
 
+// max|x| over a flat tensor, atomically max-ed into *out as float bits (lrpx_core.hip)
+int amax_flat(const float* x, long n, unsigned* out, hipStream_t stream);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize of one kernel instantiation, set exactly once even when several host threads
 // make their first launch of it at the same time (no globals except an init-once cache behind a mutex).
 // `once` / `res` are the caller's function-local statics (one pair per template instantiation).

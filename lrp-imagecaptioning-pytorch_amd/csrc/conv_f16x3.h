@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 const int y = (int)(v_ - n * (H + 1));
                 if ((v_ >= 0) && (y < H) && (n < a.n_maps)) {
                     sdst[u] = (s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28);
-                    sgp[u] = (int)((n * H + y) * W + px);
+                    sgp[u] = (int)((n * H + y - (g0 - 1)) * W + px);     // relative to the row above the tile's first
                     ssc[u] = exp2i(split_scale_exp<F8>(in_amax[n]));
                     if constexpr (POOL) {
                         const int lo = (y >> 1) * WO + (px >> 1);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 gp = ok ? n_al * (HO * WO) + lo : -1;
                 amo = (int)((img_al * (HO * WO) + lo) * a.cin);
             } else {
-                gp = ((n_al * H + y) * W + px) | nm;
+                gp = (s * W + px) | nm;          // relative to the row above the tile's first (LDS row 0)
             }
         } else {
             dst = sdst[u]; gp = sgp[u];
@@ -463,9 +463,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             const int s0 = 2 * sl - 1;                               // LDS row of window row dy = 0 (dy = 1: s0 + 1)
             rowmask = ok ? ((s0 >= 0 ? 1 : 0) | (s0 + 1 < C::NSLOT ? 2 : 0)) : 0;
             dst00 = ((s0 < 0 ? 0 : s0) * PITCH + (2 * pxl + 1) * PSTRIDE + seg * 8) | (seg << 28);   // first row written
-            const int lo = ylo * WO + pxl;
-            gp = ok ? n_al * (HO * WO) + lo : -1;
-            amo = (int)((img_al * (HO * WO) + lo) * a.cin);
+            gp = ok ? sl * WO + pxl : -1;        // relative to the pooled row above the tile's first
+            amo = 0;
             sc = ssc[0];
         } else {
             dst00 = ldst[u]; gp = lgp[u]; amo = lam[u]; sc = lsc[u];
@@ -473,8 +472,19 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         }
     };
     // input addressing: NHWC (pixel stride cin, chunk step KC) or channel-chunked (pixel stride KC, chunk step = stride)
-    const long in_pix_stride = a.in_chunk_stride ? KC : a.cin;
+    // Addresses are (workgroup-uniform 64-bit base of the tile) + (32-bit element offset of the item): one v_mul_u32_u24 per
+    // item instead of two v_mad_u64_u32 - the staging loads of the 4-row 112x112 tile (12 items per thread) spent 20 % of
+    // a wave's time on address arithmetic (s_memtime stamps).  The base is the row ABOVE the tile's first row (LDS row 0),
+    // so offsets are never negative; an item with nothing to load reads the tile's first pixel (always inside the tensor).
+    const unsigned in_pix_stride = a.in_chunk_stride ? KC : a.cin;
     const long in_chunk_step = a.in_chunk_stride ? a.in_chunk_stride : KC;
+    const float* __restrict__ in_tile = a.in + (g0 - 1) * W * (long)in_pix_stride;
+    const unsigned char* __restrict__ am_tile = a.pool_am;
+    if constexpr (LOSTAGE && AL) {
+        const long lo_row = (long)(y_al >> 1) - 1;
+        in_tile = a.in + ((long)n_al * (HO * WO) + lo_row * WO) * a.cin;
+        am_tile = a.pool_am + (img_al * (HO * WO) + lo_row * WO) * a.cin;
+    }
     f32x4 sv[LOSTAGE ? UL : U];
     unsigned amv[POOL ? (LOSTAGE ? UL : U) : 1];
 #define LRPXH_ISSUE_LO(CHUNK) _Pragma("unroll") for (int u = 0; u < UL; ++u) LRPXH_ISSUE_LO1(u, CHUNK)
@@ -484,11 +494,17 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         int dst_, gp_, amo_, rm_;                                                                            \
         float sc_;                                                                                           \
         item_lo(u, dst_, gp_, amo_, rm_, sc_);                                                               \
-        const long g_ = gp_ >= 0 ? gp_ : 0;                                                                  \
-        const int am_ = gp_ >= 0 ? amo_ : 0;                                                                 \
         const int sg_ = ((dst_ >> 28) & 3) * 4;                                                              \
-        sv[u] = *reinterpret_cast<const f32x4*>(a.in + g_ * a.cin + (CHUNK) * KC + sg_);                      \
-        amv[u] = *reinterpret_cast<const unsigned*>(a.pool_am + am_ + (CHUNK) * KC + sg_);                    \
+        if constexpr (AL) {                                                                                  \
+            const unsigned e_ = __umul24((unsigned)(gp_ >= 0 ? gp_ : WO), (unsigned)a.cin) + (unsigned)sg_;  \
+            sv[u] = *reinterpret_cast<const f32x4*>(in_tile + (CHUNK) * KC + e_);                            \
+            amv[u] = *reinterpret_cast<const unsigned*>(am_tile + (CHUNK) * KC + e_);                        \
+        } else {                                                                                             \
+            const long g_ = gp_ >= 0 ? gp_ : 0;                                                              \
+            const int am_ = gp_ >= 0 ? amo_ : 0;                                                             \
+            sv[u] = *reinterpret_cast<const f32x4*>(a.in + g_ * a.cin + (CHUNK) * KC + sg_);                  \
+            amv[u] = *reinterpret_cast<const unsigned*>(a.pool_am + am_ + (CHUNK) * KC + sg_);                \
+        }                                                                                                    \
     }
 #define LRPXH_COMMIT_LO1(u, BUFIDX)                                                                          \
     {                                                                                                        \
@@ -535,9 +551,9 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     {                                                                                                        \
         int dst_, gp_, amo_;                                                                                 \
         item(u, dst_, gp_, amo_);                                                                            \
-        const long g_ = gp_ >= 0 ? gp_ : 0;                                                                  \
         const int sg_ = dst_ >= 0 ? ((dst_ >> 28) & 3) * 4 : 0;                                              \
-        sv[u] = *reinterpret_cast<const f32x4*>(a.in + g_ * in_pix_stride + (CHUNK) * in_chunk_step + sg_);  \
+        const unsigned e_ = __umul24((unsigned)(gp_ >= 0 ? gp_ : W), in_pix_stride) + (unsigned)sg_;         \
+        sv[u] = *reinterpret_cast<const f32x4*>(in_tile + (CHUNK) * in_chunk_step + e_);                     \
     }
 #define LRPXH_COMMIT1(u, BUFIDX)                                                                             \
     {                                                                                                        \
@@ -579,10 +595,12 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #ifndef LRPXH_STAGGER
 #define LRPXH_STAGGER 1
 #endif
-#ifndef LRPXH_INTERLEAVE
-#define LRPXH_INTERLEAVE 0
+    constexpr bool STAG = DB && (LRPXH_STAGGER != 0) && (MT * NWN >= 8);
+#ifdef LRPXH_ISSUE_LATE
+    constexpr bool ISSUE_LATE = LRPXH_ISSUE_LATE != 0;
+#else
+    constexpr bool ISSUE_LATE = (HW == 112 && MT == 2);
 #endif
-    constexpr bool STAG = DB && (LRPXH_STAGGER != 0) && (LRPXH_INTERLEAVE == 0) && (MT * NWN >= 8);
     const int grp = STAG ? (wave >= MT * NWN / 2 ? 1 : 0) : 0;     // wave-uniform (waves w and w + 4 share a SIMD)
     if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(0) } else { LRPXH_ISSUE(0) }
     for (int i = tid; i < NBUF * BUFB / 16; i += NT) reinterpret_cast<u32x4_*>(ldsb)[i] = u32x4_{0, 0, 0, 0};
@@ -591,22 +609,6 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     if constexpr (STAG) {
         if (grp == 1 && a.cin / 16 > 1) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(1) } else { LRPXH_ISSUE(1) } }
     }
-    // INTERLEAVE (experiment, off): staging software-pipelined INTO the MFMA phase instead of running as separate phases
-    // between barriers - during the taps of chunk c the wave commits chunk c+1 (loaded during chunk c-1) to the other
-    // LDS buffer, one item per tap, and then re-issues the same registers for chunk c+2.  Measured: 26.1 ms against
-    // 24.9 ms for the phased schedule (chain of 320 maps).  The two waves of a SIMD already time-slice the matrix pipe
-    // - one wave's staging phase runs under the other's MFMAs - and VALU placed between a wave's own dependent MFMAs
-    // only delays that wave's next MFMA issue (in-order issue).
-#ifndef LRPXH_ILV_VALU
-#define LRPXH_ILV_VALU 8      // VALU instructions of the staging work scheduled after each accumulator tile's 3 MFMAs
-#endif
-    constexpr int UE = LOSTAGE ? UL : U;
-    constexpr bool ILV = (LRPXH_INTERLEAVE != 0) && DB && UE <= 8;
-    constexpr int OFF = TAPS - UE;               // item u: committed at tap u, re-issued at tap u + OFF
-    if constexpr (ILV) {
-        if (nchunk > 1) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(1) } else { LRPXH_ISSUE(1) } }
-    }
-
     f32x16 acc[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j)
@@ -633,20 +635,21 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #else
     constexpr int NQ = F8 ? ((POOL && AL && HW <= 112) ? 3 : 2) : NBQ;
 #endif
+    // (a wave without a channel block of its own - n_oc not a multiple of the workgroup's channels - multiplies the last
+    // valid block again and drops the result: one code path, see PRECISE below)
+    const int ocb_w = wave_active ? ocb : (a.n_oc - 1) / 32;
     const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
-                       (long)ocb * nchunk * (BSTEPS * BP * 64) + lane;
+                       (long)ocb_w * nchunk * (BSTEPS * BP * 64) + lane;
     const int last_step = nchunk * BSTEPS - 1;
     u32x4_ bq[NQ][BP];
 #pragma unroll
     for (int i = 0; i < NQ; ++i)
 #pragma unroll
         for (int p = 0; p < BP; ++p) bq[i][p] = u32x4_{0, 0, 0, 0};
-    if (wave_active) {
 #pragma unroll
-        for (int i = 0; i < NQ - 1; ++i)
+    for (int i = 0; i < NQ - 1; ++i)
 #pragma unroll
-            for (int p = 0; p < BP; ++p) bq[i][p] = wp[((long)min(i, last_step) * BP + p) * 64];
-    }
+        for (int p = 0; p < BP; ++p) bq[i][p] = wp[((long)min(i, last_step) * BP + p) * 64];
     // F8: LDS byte offsets of the lane's two fp8 tap slots of a tap row (dx = 0 / 1 for lanes 0-31; dx = 2 / 2 for lanes
     // 32-63, whose second slot carries zero weights)
     // F8: lanes 0-31 read the fp8 plane of x - hi (byte 48 of the pixel), lanes 32-63 that of x (byte 32; abase[] already
@@ -661,13 +664,27 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = chunk + 1 < nchunk;
         LRPXH_T(ta);
-        if constexpr (!ILV) {
-            // group 0 loads the next chunk, group 1 (which has already committed the next chunk) the one after it
-            const int cn = chunk + 1 + grp;
-            if (cn < nchunk) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(cn) } else { LRPXH_ISSUE(cn) } }
+        // PRECISE: the K loop has NO branch around a memory instruction.  `s_waitcnt vmcnt` counts in order, and at a
+        // control-flow merge the compiler must assume the path with the fewest younger loads: with `if (next chunk
+        // exists) issue` and `if (wave has a channel block) multiply` the first MFMA of every chunk waited for ALL
+        // staging loads just issued (vmcnt(7) with 7 B loads behind them) and the commit for the B prefetch too - the
+        // whole global-load latency sat in front of the matrix phase.  Now the staging loads of the next chunk are
+        // issued unconditionally (past the last chunk they re-read it; nobody commits them); ISSUE_LATE: AFTER the B
+        // loads of the second tap row, so they have two thirds of the chunk's matrix time to land before the next
+        // in-order wait that covers them (else at the top of the interval: one third).
+        // (measured, same-box A/B of three builds: chain of 320 maps 19.37 -> 19.22 ms with the precise waits; issuing after
+        // the first B loads is worth 4 % on the 4-row 112x112 tile - 12 staging items per thread - and costs 3 % through 5-10
+        // spilled registers elsewhere, so only that kernel does it)
+        // group 0 loads the next chunk, group 1 (which has already committed the next chunk) the one after it
+#define LRPXH_ISSUE_NEXT                                                                        \
+        {                                                                                       \
+            const int cn_ = min(chunk + 1 + grp, nchunk - 1);                                   \
+            if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(cn_) } else { LRPXH_ISSUE(cn_) }            \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
         }
+        if constexpr (!ISSUE_LATE) { LRPXH_ISSUE_NEXT }
         LRPXH_T(tb);
-        if (wave_active) {
+        {
             const char* abuf = ldsb + (DB ? (chunk & 1) : 0) * BUFB;
 #ifdef LRPX_STAMP
             unsigned long long tprev = tb;
@@ -714,13 +731,17 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 };
                 i32x8_ ring[D];
 #pragma unroll
-                for (int d = 0; d < D; ++d) ring[d] = rd(d);
-#pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step) * BP;
 #pragma unroll
                     for (int p = 0; p < BP; ++p)
                         if (p < 5 || (g + NQ - 1) % 3 != 2) bq[NQ - 1][p] = wp[(nxt + p) * 64];
+                    if (g == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (ISSUE_LATE) { LRPXH_ISSUE_NEXT }
+#pragma unroll
+                        for (int d = 0; d < D; ++d) ring[d] = rd(d);
+                    }
                     const f16x8 bh[3] = {__builtin_bit_cast(f16x8, bq[0][0]), __builtin_bit_cast(f16x8, bq[0][1]),
                                          __builtin_bit_cast(f16x8, bq[0][2])};
                     const i32x8_ bm0 = {(int)bq[0][3][0], (int)bq[0][3][1], (int)bq[0][3][2], (int)bq[0][3][3],
@@ -758,6 +779,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #pragma unroll
                     for (int p = 0; p < BP; ++p)
                         if (p < 5 || (g + NQ - 1) % 3 != 2) bq[NQ - 1][p] = wp[(nxt + p) * 64];
+                    if (g == 0 && ISSUE_LATE) { __builtin_amdgcn_sched_barrier(0); LRPXH_ISSUE_NEXT }
                     const f16x8 bh0 = __builtin_bit_cast(f16x8, bq[0][0]);
                     const f16x8 bh1 = __builtin_bit_cast(f16x8, bq[0][1]);
                     const f16x8 bh2 = __builtin_bit_cast(f16x8, bq[0][2]);
@@ -819,19 +841,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 const long nxt = (long)min(chunk * TAPS + tap + NBQ - 1, last_step) * 2;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) bq[NBQ - 1][p] = wp[(nxt + p) * 64];
-                if constexpr (ILV) {
-                    // no run-time conditions (they would fence the scheduler): past the last chunk the commit writes
-                    // stale registers into the buffer nobody reads again, the issue re-reads the last chunk
-                    if (tap < UE) {          // (compile-time after unrolling)
-                        if constexpr (LOSTAGE) { LRPXH_COMMIT_LO1(tap < UE ? tap : 0, (chunk + 1) & 1) }
-                        else { LRPXH_COMMIT1(tap < UE ? tap : 0, (chunk + 1) & 1) }
-                    }
-                    if (tap >= OFF) {
-                        const int cn_ = min(chunk + 2, nchunk - 1);
-                        if constexpr (LOSTAGE) { LRPXH_ISSUE_LO1(tap >= OFF ? tap - OFF : 0, cn_) }
-                        else { LRPXH_ISSUE1(tap >= OFF ? tap - OFF : 0, cn_) }
-                    }
-                }
+                if (tap == 0 && ISSUE_LATE) { __builtin_amdgcn_sched_barrier(0); LRPXH_ISSUE_NEXT }
                 const f16x8 b0 = __builtin_bit_cast(f16x8, bq[0][0]);
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[0][1]);
 #pragma unroll
@@ -857,10 +867,6 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                     if constexpr (APIPE) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the 2 reads of the NEXT tile ...
                         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the 3 MFMAs of this one
-                        if constexpr (ILV) {      // ... and a slice of the staging work of this tap in their shadow
-                            __builtin_amdgcn_sched_group_barrier(0x002, LRPXH_ILV_VALU, 0);
-                            if (j == 6) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-                        }
                     }
                 }
 #pragma unroll
@@ -878,16 +884,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             }   // !F8
         }
         LRPXH_T(tc);
-        if constexpr (ILV) {
-            if (!wave_active) {          // waves without a channel block still stage their share of the tile
-                if (more) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
-                if (chunk + 2 < nchunk) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(chunk + 2) } else { LRPXH_ISSUE(chunk + 2) } }
-            }
-        }
         if constexpr (DB) {
-            if constexpr (!ILV) {
-                if (more && grp == 0) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
-            }
+            if (more && grp == 0) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
             LRPXH_T(td);
             __syncthreads();
             if constexpr (STAG) {     // group 1: chunk + 2 into the buffer everyone has just finished reading
@@ -909,6 +907,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #endif
         }
     }
+#undef LRPXH_ISSUE_NEXT
 #undef LRPXH_ISSUE
 #undef LRPXH_COMMIT
 #undef LRPXH_ISSUE_LO

@@ -133,6 +133,11 @@ __global__ void amax_flat_kernel(const float* __restrict__ x, long n, unsigned* 
     if ((threadIdx.x & 63) == 0) amax_update(out, m);
 }
 
+int amax_flat(const float* x, long n, unsigned* out, hipStream_t s) {
+    hipLaunchKernelGGL(amax_flat_kernel, dim3(256), dim3(256), 0, s, x, n, out);
+    return check_launch("amax_flat");
+}
+
 // lane-local |max| of 4 values -> per-map amax.  Waves whose 64 lanes sit in one map (every layer of the path) reduce
 // in registers and issue one atomic; mixed waves fall back to one atomic per lane.
 __device__ __forceinline__ void amax_commit(unsigned* __restrict__ amax, long n, float m) {

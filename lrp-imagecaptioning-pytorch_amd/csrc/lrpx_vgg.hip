@@ -221,6 +221,9 @@ static inline int cin_pad(int l) { return l == 0 ? 8 : kVgg[l].cin; }   // image
 int first_layer_pack(const float* w, float* w6, int cout, int plain, hipStream_t s);
 int first_layer_relevance(const float* S, const float* w6, const float* X8, const int* map2img, float* out, int n_maps,
                           int cin, int plain, int s_chunked, hipStream_t s);
+int first_layer_pack_mfma(const float* w, float* packed, int plain, hipStream_t s);
+int first_layer_relevance_mfma(const float* S, const float* packed, const float* X8, const int* map2img,
+                               const unsigned* s_amax, float* out, int n_maps, int plain, int chunked32, hipStream_t s);
 int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, int plain,
                 hipStream_t s);
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
@@ -254,7 +257,7 @@ static thread_local int tl_timing = 0;
 static thread_local float tl_ms[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], first6, first6p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], first6, first6p, first16, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
@@ -279,6 +282,7 @@ static VggPacked vgg_packed_layout() {
     }
     p.first6 = off; off += (size_t)64 * 9 * 6;   // direct-conv weights of the first layer's rule
     p.first6p = off; off += (size_t)64 * 9 * 6;  // ... and of its plain transposed conv (guided backprop)
+    p.first16 = off; off += (size_t)16 + 2 * 9 * 64 * 4;   // first layer's rule on the matrix cores (header + A fragments)
     p.total = off;
     return p;
 }
@@ -387,6 +391,7 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
         if (l == 0) {
             LRPX_TRY(first_layer_pack(w[ci], base + p.first6, L.cout, 0, (hipStream_t)stream));
             LRPX_TRY(first_layer_pack(w[ci], base + p.first6p, L.cout, 1, (hipStream_t)stream));
+            LRPX_TRY(first_layer_pack_mfma(w[ci], base + p.first16, 0, (hipStream_t)stream));
         } else {
             LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, lrpx_conv_kc(L.hw, 9, L.cout),
                                        base + p.bwdp[l], stream));
@@ -577,9 +582,15 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
         d.in_chunked = cur_chunked;
         cur_chunked = 0;
         if (l == 0) {
-            // 3 output channels: direct VALU conv (first_layer.hip) instead of a 32-wide MFMA tile
-            LRPX_TRY(first_layer_relevance(S[cur], pk + p.first6, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 0,
-                                           h3 ? 1 : 0, (hipStream_t)stream));
+            // 3 output channels (first_layer.hip): 16x16x32 MFMAs on the split halves of S in the split-product modes (S
+            // comes with its per-map maximum, in 32-channel chunks), the direct fp32 VALU conv otherwise
+            static const int fl_mfma = getenv("LRPX_FIRST_VALU") ? 0 : 1;
+            if (h3 && fl_mfma)
+                LRPX_TRY(first_layer_relevance_mfma(S[cur], pk + p.first16, tr + t.act[0], map2img, amax, out_nchw, n_maps,
+                                                    0, 1, (hipStream_t)stream));
+            else
+                LRPX_TRY(first_layer_relevance(S[cur], pk + p.first6, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 0,
+                                               h3 ? 1 : 0, (hipStream_t)stream));
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
@@ -609,7 +620,9 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
             d.out1 = S[cur ^ 1];
             if (h3) { d.x = tr + t.xz[l]; d.out1_amax = amax + (size_t)(l - 1) * n_maps; }   // x / safe(Z+) precomputed
-            if (h3 && l == 1) d.out_chunk = 16;   // the first-layer kernel walks S in 16-channel chunks: whole 64-byte runs
+            // the first-layer kernel walks S in channel chunks (MFMA version: 32 = whole 128-byte lines per pixel; VALU: 16)
+            static const int fl_chunk = getenv("LRPX_FIRST_VALU") ? 16 : 32;
+            if (h3 && l == 1) d.out_chunk = fl_chunk;
             else { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
             LRPX_TIMED_DISPATCH(l, &d);
         } else {
