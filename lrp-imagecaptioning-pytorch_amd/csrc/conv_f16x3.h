@@ -25,6 +25,7 @@ namespace lrpx {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
 
 constexpr int F16X3_HEADER_FLOATS = 16;   // packed weights: [0] = 2^-kW, [1] = bits of max|W| (diagnostic)
 
@@ -227,6 +228,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     constexpr int PITCH = W * PSTRIDE + 256;           // pitch/16 == 5*W (mod 16), >= (W+2) pixels
     constexpr int BUFB = C::NSLOT * PITCH;
     constexpr int NBUF = DB ? 2 : 1;
+    constexpr int STAGE_SCRATCH = NBUF * BUFB + 16;    // 256 bytes behind the buffers take the writes of items with nothing to write
+    constexpr int POOL_SCRATCH = STAGE_SCRATCH;
     constexpr bool AL = (H % C::R == 0);               // a workgroup tile never straddles two maps
 #ifndef LRPXH_HOIST_MASK
 #define LRPXH_HOIST_MASK 1
@@ -354,49 +357,71 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             }
         }
     }
+    // Row-wise layout: everything about item u of a thread is (a value of the THREAD, the same for all its items) + (a
+    // compile-time constant of u): LDS offset, relative pixel and element offset each cost one add per use, the column
+    // predicate one compare; nothing worth keeping per item, nothing to multiply.  (The 12 items per thread of the 4-row
+    // 112x112 tile spent 94 VALU instructions each on issue + commit, 41 of them conversions: as much time as the
+    // chunk's MFMAs.)
+    const int t_half = (ROWMAP && RPS == 2 && tid >= TPR) ? 1 : 0;
+    const int t_rem = tid - t_half * TPR;                                   // position in the LDS row (RPS == 1: tid)
+    const int t_px = t_rem / SEG, t_seg = t_rem - t_px * SEG;
+    const int d_thr = (t_half * PITCH + (t_px + 1) * PSTRIDE + t_seg * 8) | (t_seg << 28);
+    const int g_thr = t_half * W + t_px;
+    const unsigned in_pix_stride_ = a.in_chunk_stride ? KC : a.cin;
+    const unsigned e_thr = __umul24((unsigned)g_thr, in_pix_stride_) + (unsigned)t_seg * 4;   // element offset, thread part
+    unsigned ethr_c = e_thr;
+    // Copies the compiler cannot see through, refreshed once per K-chunk (LRPXH_REFRESH): what is derived from them is
+    // recomputed per use (an add) instead of being hoisted out of the chunk loop into 2U registers - except in the
+    // 56x56 kernel with a B queue of 8, where keeping the descriptors resident saves 6 % (tools/variant_sweep2.sh)
+    int dthr_c = d_thr, gthr_c = g_thr, trem_c = t_rem, thalf_c = t_half;
+#define LRPXH_REFRESH                                                                                    \
+    if constexpr (!HOIST && AL && ROWMAP && !POOL) {                                                     \
+        dthr_c = d_thr; gthr_c = g_thr; trem_c = t_rem; thalf_c = t_half; ethr_c = e_thr;                \
+        asm volatile("" : "+v"(dthr_c), "+v"(gthr_c), "+v"(trem_c), "+v"(thalf_c), "+v"(ethr_c));        \
+    }
     auto item = [&](const int u, int& dst, int& gp, int& amo) {
         amo = 0;
-        if constexpr (AL) {
+        if constexpr (AL && ROWMAP && !POOL) {
+            // LDS row s = s_c + t_half, position in the row t_rem + rem_c
+            constexpr int RPSv = RPS, SPRv = SPR;
+            const int s_c = RPSv == 2 ? 2 * u : u / SPRv;
+            const int rem_c = RPSv == 2 ? 0 : (u % SPRv) * NT;
+            const int dt = dthr_c, gt = gthr_c, tr = trem_c, th = RPSv == 2 ? thalf_c : 0;
+            const int y = y_al - 1 + s_c + th;      // (one row per slot: wave-uniform, the row checks are scalar)
+            const bool ok = (tr < RI - rem_c) && (s_c + th < C::NSLOT) && (y >= 0) && (y < H);
+            const int nm = ok ? 0 : -1;      // "| nm" instead of "ok ? x : -1": the latter compiles to an exec-masked branch
+            dst = (dt + (s_c * PITCH + (rem_c / SEG) * PSTRIDE)) | nm;
+            gp = (gt + (s_c * W + rem_c / SEG)) | nm;          // relative to the row above the tile's first (LDS row 0)
+        } else if constexpr (AL) {
             int it = tid + u * NT;
             // recompute per use: hoisted out of the chunk loop the descriptors cost 2U registers and spill - except in the
             // 56x56 kernel with a B queue of 8, where keeping them resident saves 6 % (measured, tools/variant_sweep2.sh)
             if constexpr (!HOIST) asm volatile("" : "+v"(it));
-            int s, rem;
-            bool in_row;
-            if constexpr (ROWMAP) {
-                int t_ = tid;
-                if constexpr (!HOIST) asm volatile("" : "+v"(t_));
-                if constexpr (RPS == 2) {
-                    s = u * 2 + (t_ >= TPR ? 1 : 0);
-                    rem = t_ >= TPR ? t_ - TPR : t_;
-                    in_row = (rem < RI) && (s < C::NSLOT);
-                } else {
-                    s = u / SPR;
-                    rem = t_ + (u % SPR) * NT;
-                    in_row = rem < RI;
-                }
-            } else {
-                s = it / (W * SEG);
-                rem = it - s * (W * SEG);
-                in_row = it < NITEM;
-            }
+            const int s = it / (W * SEG);
+            const int rem = it - s * (W * SEG);
+            const bool in_row = it < NITEM;
             const int px = rem / SEG, seg = rem - px * SEG;
             const int y = y_al - 1 + s;
             const bool ok = in_row && (y >= 0) && (y < H);
-            const int nm = ok ? 0 : -1;      // "| nm" instead of "ok ? x : -1": the latter compiles to an exec-masked branch
+            const int nm = ok ? 0 : -1;
             dst = ((s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28)) | nm;
-            if constexpr (POOL) {
-                const int lo = (y >> 1) * WO + (px >> 1);
-                if (ok) dst |= (((y & 1) << 1) | (px & 1)) << 26;
-                gp = ok ? n_al * (HO * WO) + lo : -1;
-                amo = (int)((img_al * (HO * WO) + lo) * a.cin);
-            } else {
-                gp = (s * W + px) | nm;          // relative to the row above the tile's first (LDS row 0)
-            }
+            gp = (s * W + px) | nm;
         } else {
             dst = sdst[u]; gp = sgp[u];
             if constexpr (POOL) amo = sam[u];
         }
+    };
+    // element offset of item u's load (row-wise layout): (thread part) + (uniform part of u); nothing to load: the tile's
+    // first pixel
+    auto item_e = [&](const int u) -> unsigned {
+        constexpr int RPSv = RPS, SPRv = SPR;
+        const int s_c = RPSv == 2 ? 2 * u : u / SPRv;
+        const int rem_c = RPSv == 2 ? 0 : (u % SPRv) * NT;
+        const int tr = trem_c, th = RPSv == 2 ? thalf_c : 0;
+        const unsigned et = ethr_c;
+        const int y = y_al - 1 + s_c + th;
+        const bool ok = (tr < RI - rem_c) && (s_c + th < C::NSLOT) && (y >= 0) && (y < H);
+        return ok ? et + (unsigned)(s_c * W + rem_c / SEG) * in_pix_stride_ : (unsigned)W * in_pix_stride_;
     };
     // POOL: stage at LOW resolution - one item = 4 channels of one pooled pixel, loaded and split once, then written
     // (or zero) to the 4 pixels of its window: 4x fewer loads and splits than per-pixel staging.
@@ -506,6 +531,11 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             amv[u] = *reinterpret_cast<const unsigned*>(a.pool_am + am_ + (CHUNK) * KC + sg_);                \
         }                                                                                                    \
     }
+// The four window positions of an item differ only in the lanes that are kept: byte masks from one SWAR compare of the
+// four winner bytes (values 0..3) per position, halfword masks by v_perm_b32, row bases selected once per item (an absent
+// row - outside the LDS tile or nothing to load - goes to 256 scratch bytes behind the buffers), the position inside the
+// window as an immediate offset: ~90 VALU per item instead of 170 (46 v_cndmask, 16 compares, ...: the commit of the
+// pooled-input kernels cost 19-22 % of their time, timing experiment without commits).
 #define LRPXH_COMMIT_LO1(u, BUFIDX)                                                                          \
     {                                                                                                        \
         int dst_, gp_, amo_, rm_;                                                                            \
@@ -520,25 +550,25 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             wl8_ = pack_fp8x4((xs_[0] - (float)h[0]) * 16.f, (xs_[1] - (float)h[1]) * 16.f,                  \
                               (xs_[2] - (float)h[2]) * 16.f, (xs_[3] - (float)h[3]) * 16.f);                 \
         }                                                                                                    \
-        char* db_ = ldsb + (BUFIDX) * BUFB;                                                                  \
-        const int o0_ = dst_ & 0x03ffffff;                                                                   \
+        const unsigned hw0_ = pack_f16(h[0], h[1]), hw1_ = pack_f16(h[2], h[3]);                             \
+        const unsigned lw0_ = pack_f16(l[0], l[1]), lw1_ = pack_f16(l[2], l[3]);                             \
+        const int o0_ = (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                               \
         const int sg4_ = ((dst_ >> 28) & 3) * 4;                                                             \
+        const int rb0_ = (rm_ & 1) ? o0_ : POOL_SCRATCH;              /* window row dy = 0 */                \
+        const int rb1_ = (rm_ & 2) ? o0_ + ((rm_ & 1) ? PITCH : 0) : POOL_SCRATCH;      /* dy = 1 */         \
         _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                                \
-            const bool wr_ = (rm_ >> (pos >> 1)) & 1;         /* this window row lies inside the LDS tile */  \
-            _Float16 hm[4], lm[4];                                                                           \
-            unsigned bm_ = 0;                                                                                \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
-                const bool w_ = ((amv[u] >> (8 * e)) & 0xffu) == (unsigned)pos;                              \
-                hm[e] = w_ ? h[e] : (_Float16)0; lm[e] = w_ ? l[e] : (_Float16)0;                            \
-                bm_ |= w_ ? (0xffu << (8 * e)) : 0u;                                                         \
-            }                                                                                                \
-            const int o_ = o0_ + (((pos >> 1) && (rm_ & 1)) ? PITCH : 0) + (pos & 1) * PSTRIDE;              \
-            *reinterpret_cast<u32x2_*>(db_ + (wr_ ? o_ : 64)) = u32x2_{pack_f16(hm[0], hm[1]), pack_f16(hm[2], hm[3])};      \
+            const unsigned x_ = amv[u] ^ (0x01010101u * (unsigned)pos);       /* zero byte <=> winner == pos */ \
+            const unsigned eq_ = ((x_ | (x_ >> 1)) & 0x01010101u) ^ 0x01010101u;                             \
+            const unsigned bm_ = (eq_ << 8) - eq_;                            /* 0xff per winner byte */     \
+            const unsigned m01_ = __builtin_amdgcn_perm(bm_, bm_, 0x01010000u);                              \
+            const unsigned m23_ = __builtin_amdgcn_perm(bm_, bm_, 0x03030202u);                              \
+            char* d_ = ldsb + ((pos >> 1) ? rb1_ : rb0_) + (pos & 1) * PSTRIDE;                              \
+            *reinterpret_cast<u32x2_*>(d_) = u32x2_{hw0_ & m01_, hw1_ & m23_};                               \
             if constexpr (F8) {                                                                              \
-                *reinterpret_cast<unsigned*>(db_ + (wr_ ? o_ + 32 - sg4_ : 72)) = w8_ & bm_;                 \
-                *reinterpret_cast<unsigned*>(db_ + (wr_ ? o_ + 48 - sg4_ : 76)) = wl8_ & bm_;                \
+                *reinterpret_cast<unsigned*>(d_ - sg4_ + 32) = w8_ & bm_;                                    \
+                *reinterpret_cast<unsigned*>(d_ - sg4_ + 48) = wl8_ & bm_;                                   \
             } else {                                                                                         \
-                *reinterpret_cast<u32x2_*>(db_ + (wr_ ? o_ + 32 : 72)) = u32x2_{pack_f16(lm[0], lm[1]), pack_f16(lm[2], lm[3])}; \
+                *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{lw0_ & m01_, lw1_ & m23_};                      \
             }                                                                                                \
         }                                                                                                    \
     }
@@ -550,35 +580,37 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #define LRPXH_ISSUE1(u, CHUNK)                                                                               \
     {                                                                                                        \
         int dst_, gp_, amo_;                                                                                 \
-        item(u, dst_, gp_, amo_);                                                                            \
-        const int sg_ = dst_ >= 0 ? ((dst_ >> 28) & 3) * 4 : 0;                                              \
-        const unsigned e_ = __umul24((unsigned)(gp_ >= 0 ? gp_ : W), in_pix_stride) + (unsigned)sg_;         \
+        unsigned e_;                                                                                         \
+        if constexpr (AL && ROWMAP && !POOL) {                                                               \
+            e_ = item_e(u);                                                                                  \
+        } else {                                                                                             \
+            item(u, dst_, gp_, amo_);                                                                        \
+            const int sg_ = dst_ >= 0 ? ((dst_ >> 28) & 3) * 4 : 0;                                          \
+            e_ = __umul24((unsigned)(gp_ >= 0 ? gp_ : W), in_pix_stride) + (unsigned)sg_;                    \
+        }                                                                                                    \
         sv[u] = *reinterpret_cast<const f32x4*>(in_tile + (CHUNK) * in_chunk_step + e_);                     \
     }
 #define LRPXH_COMMIT1(u, BUFIDX)                                                                             \
     {                                                                                                        \
         int dst_, gp_, amo_;                                                                                 \
         item(u, dst_, gp_, amo_);                                                                            \
-        const bool okl_ = gp_ >= 0;                                                                          \
+        /* (an item with nothing to write converts whatever its registers hold into the scratch bytes) */    \
+        const f32x2_ sc2_ = {ssc[AL ? 0 : u], ssc[AL ? 0 : u]};                                              \
+        const f32x2_ xa_ = f32x2_{sv[u][0], sv[u][1]} * sc2_, xb_ = f32x2_{sv[u][2], sv[u][3]} * sc2_;       \
+        const float xs_[4] = {xa_[0], xa_[1], xb_[0], xb_[1]};                                               \
         _Float16 h[4], l[4];                                                                                 \
-        float xs_[4];                                                                                        \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
-            xs_[e] = okl_ ? sv[u][e] * ssc[AL ? 0 : u] : 0.f;                                                \
-            split2(xs_[e], h[e], l[e]);                                                                      \
-        }                                                                                                    \
-        char* db_ = ldsb + (BUFIDX) * BUFB;                                                                  \
-        *reinterpret_cast<u32x2_*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) : 64)) =                           \
-            u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};                                              \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(xs_[e], h[e], l[e]);                            \
+        char* d_ = ldsb + (dst_ >= 0 ? (BUFIDX) * BUFB + (dst_ & 0x03ffffff) : STAGE_SCRATCH);               \
+        *reinterpret_cast<u32x2_*>(d_) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};                 \
         if constexpr (F8) {                                                                                  \
-            const int sg4_ = dst_ >= 0 ? ((dst_ >> 28) & 3) * 4 : 0;                                         \
-            *reinterpret_cast<unsigned*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) + 32 - sg4_ : 72)) =         \
-                pack_fp8x4(xs_[0] * 0.0625f, xs_[1] * 0.0625f, xs_[2] * 0.0625f, xs_[3] * 0.0625f);          \
-            *reinterpret_cast<unsigned*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) + 48 - sg4_ : 76)) =         \
-                pack_fp8x4((xs_[0] - (float)h[0]) * 16.f, (xs_[1] - (float)h[1]) * 16.f,                     \
-                           (xs_[2] - (float)h[2]) * 16.f, (xs_[3] - (float)h[3]) * 16.f);                    \
+            const int sg4_ = ((dst_ >> 28) & 3) * 4;                                                         \
+            const f32x2_ ya_ = xa_ * f32x2_{0.0625f, 0.0625f}, yb_ = xb_ * f32x2_{0.0625f, 0.0625f};         \
+            const f32x2_ ra_ = (xa_ - f32x2_{(float)h[0], (float)h[1]}) * f32x2_{16.f, 16.f};                \
+            const f32x2_ rb_ = (xb_ - f32x2_{(float)h[2], (float)h[3]}) * f32x2_{16.f, 16.f};                \
+            *reinterpret_cast<unsigned*>(d_ - sg4_ + 32) = pack_fp8x4(ya_[0], ya_[1], yb_[0], yb_[1]);       \
+            *reinterpret_cast<unsigned*>(d_ - sg4_ + 48) = pack_fp8x4(ra_[0], ra_[1], rb_[0], rb_[1]);       \
         } else {                                                                                             \
-            *reinterpret_cast<u32x2_*>(db_ + (dst_ >= 0 ? (dst_ & 0x03ffffff) + 32 : 72)) =                  \
-                u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};                                          \
+            *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};        \
         }                                                                                                    \
     }
 
@@ -594,6 +626,9 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // after barrier c - 2 (group 1, chunk c: right behind that barrier; group 0: at the end of interval c - 1).
 #ifndef LRPXH_STAGGER
 #define LRPXH_STAGGER 1
+#endif
+#ifndef LRPXH_EXP
+#define LRPXH_EXP 0       // timing experiments (wrong results): 1 = no staging commits in the K loop
 #endif
     constexpr bool STAG = DB && (LRPXH_STAGGER != 0) && (MT * NWN >= 8);
 #ifdef LRPXH_ISSUE_LATE
@@ -663,6 +698,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     LRPXH_T(t_loop);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = chunk + 1 < nchunk;
+        LRPXH_REFRESH
         LRPXH_T(ta);
         // PRECISE: the K loop has NO branch around a memory instruction.  `s_waitcnt vmcnt` counts in order, and at a
         // control-flow merge the compiler must assume the path with the fewest younger loads: with `if (next chunk
@@ -701,9 +737,18 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #ifndef LRPXH_F8_PIPE
 #define LRPXH_F8_PIPE 3
 #endif
-                // (8-wave workgroups only: their staging needs half the registers per thread; the 4-wave kernels spill with the
-                // extra operand sets and run 27-38 % slower with the pipeline - measured per layer, tools/ab_chain.sh)
-                if constexpr (LRPXH_F8_PIPE != 0 && MT * NWN >= 8) {
+                                // 4-wave workgroups (twice the staging registers per thread): depth 1 pays on the pooled-input 224x224 kernel
+                // only (conv1_2 2.94 -> 2.83 ms with 5 spilled registers; conv2_1 +15 %, conv2_2 +2 %, conv3_1 +-0 with depth 1
+                // or 2 and their 10-25 spills - same-box A/B)
+#ifndef LRPXH_F8_PIPE_TALL
+#define LRPXH_F8_PIPE_TALL 1      // 8-wave workgroups with MT >= 2 (tall tiles of the <= 128-channel layers)
+#endif
+#ifdef LRPXH_F8_PIPE4
+                constexpr int PIPE_D = (MT * NWN >= 8) ? (MT >= 2 ? LRPXH_F8_PIPE_TALL : LRPXH_F8_PIPE) : LRPXH_F8_PIPE4;
+#else
+                constexpr int PIPE_D = (MT * NWN >= 8) ? (MT >= 2 ? LRPXH_F8_PIPE_TALL : LRPXH_F8_PIPE) : ((HW == 224 && POOL) ? 1 : 0);
+#endif
+                if constexpr (PIPE_D != 0) {
                 // Operand pipeline of depth D = LRPXH_F8_PIPE.  Left to itself the compiler (at 240+ VGPRs) keeps ONE set of
                 // A-fragment registers and emits read -> s_waitcnt lgkmcnt(0) -> MFMA for every MFMA: each one waits for its
                 // own LDS round trip and only the partner wave fills the pipe (busy 79 % of the phase).  Here the 98 MFMAs
@@ -711,7 +756,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 // before MFMA k is issued (D operand sets in a ring); `sched_barrier(0)` fences keep the compiler's scheduler
                 // from sinking the reads back to their uses (scheduling groups alone did not hold the order).  Measured
                 // (chain of 320 maps): 56x56 -10 %, 28x28 -7 %, 14x14 -9 % per launch at D = 2 (D = 3: the same).
-                constexpr int D = LRPXH_F8_PIPE != 0 ? LRPXH_F8_PIPE : 1;
+                constexpr int D = PIPE_D != 0 ? PIPE_D : 1;
                 constexpr int TPX[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 8};
                 // op k -> (g, j, m): tap rows 0 and 1 have 5 MFMAs per tile (2 fp8 + 3 fp16), row 2 has 4 (1 fp8 + 3 fp16)
                 auto og = [](const int k) constexpr { return k < 35 ? 0 : (k < 70 ? 1 : 2); };
@@ -885,11 +930,11 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         }
         LRPXH_T(tc);
         if constexpr (DB) {
-            if (more && grp == 0) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
+            if (more && grp == 0 && !(LRPXH_EXP & 1)) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
             LRPXH_T(td);
             __syncthreads();
             if constexpr (STAG) {     // group 1: chunk + 2 into the buffer everyone has just finished reading
-                if (grp == 1 && chunk + 2 < nchunk) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(chunk & 1) } else { LRPXH_COMMIT(chunk & 1) } }
+                if (grp == 1 && chunk + 2 < nchunk && !(LRPXH_EXP & 1)) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(chunk & 1) } else { LRPXH_COMMIT(chunk & 1) } }
             }
             LRPXH_T(te);
 #ifdef LRPX_STAMP
@@ -898,7 +943,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         } else {
             __syncthreads();                       // every wave is done reading the single buffer
             LRPXH_T(td0);
-            if (more) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(0) } else { LRPXH_COMMIT(0) } }
+            if (more && !(LRPXH_EXP & 1)) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(0) } else { LRPXH_COMMIT(0) } }
             LRPXH_T(td);
             __syncthreads();
             LRPXH_T(te);
@@ -908,6 +953,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         }
     }
 #undef LRPXH_ISSUE_NEXT
+#undef LRPXH_REFRESH
 #undef LRPXH_ISSUE
 #undef LRPXH_COMMIT
 #undef LRPXH_ISSUE_LO
@@ -1051,7 +1097,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
 int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
     using C = ConvCfg<HW, 16, MT, NWN, 9>;
-    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 80 + 256);
+    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 80 + 256) + 256;
     const long m_tiles = ceil_div((long)a.n_maps * HW, C::R);
     const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
     long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;

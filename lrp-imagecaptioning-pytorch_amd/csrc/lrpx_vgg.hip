@@ -624,6 +624,10 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
             static const int fl_chunk = getenv("LRPX_FIRST_VALU") ? 16 : 32;
             if (h3 && l == 1) d.out_chunk = fl_chunk;
             else { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
+            // conv2_2 -> conv2_1: S in 16-channel chunks, the K-chunk of the consumer (64-byte slices of 512-byte NHWC pixels
+            // drag every 128-byte line through the fabric twice: FETCH 3.1x the tensor; chunked: conv2_1 1.44 -> 1.37 ms)
+            static const int s21_chunk = getenv("LRPX_S21_NHWC") ? 0 : 16;
+            if (h3 && l == 4 && s21_chunk) { d.out_chunk = s21_chunk; cur_chunked = 1; }
             LRPX_TIMED_DISPATCH(l, &d);
         } else {
             if (h3) {
