@@ -252,20 +252,28 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     const int wm = wave / NWN, wn = wave % NWN;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
+    // Workgroup ids go round-robin over the 8 XCDs (each with its own L2): XCD x walks a CONTIGUOUS range of tiles, so the
+    // halo rows that neighbouring tiles share and the multiplicand tiles of an image's words are re-read from one L2
+    // (round-robin tiles, mtile = (idx / n_blocks) * 8 + xcd: 28x28 layers +6 %, conv1_2 +4 %, chain 18.4 vs 18.1 ms)
+#ifndef LRPXH_XCD_BLOCKED
+#define LRPXH_XCD_BLOCKED 1
+#endif
     int mtile = (idx / n_blocks) * 8 + xcd;
+    if constexpr (LRPXH_XCD_BLOCKED != 0) mtile = xcd * ((m_tiles + 7) / 8) + idx / n_blocks;
     const int nblk = idx % n_blocks;
 #ifndef LRPXH_TILE_GROUP
 #define LRPXH_TILE_GROUP 1
 #endif
     if constexpr (AL && (LRPXH_TILE_GROUP != 0)) {
         // a.tile_group maps per image: the tiles (image row block r) of the words w of one image run back to back on ONE
-        // XCD (workgroup ids go round-robin over the 8 XCDs), so the image's multiplicand tile stays in that L2 for all
-        // of them instead of being fetched from HBM once per word
+        // XCD, so the image's multiplicand tile stays in that L2 for all of them instead of being fetched from HBM once
+        // per word; an XCD walks a contiguous range of (image, row block) groups - consecutive row blocks of an image
         if (a.tile_group > 1) {
             constexpr int TPM = H / C::R;                          // tiles per map
             const int q = idx / n_blocks;                          // position in this XCD's sequence
             const int gl = q / a.tile_group, w = q - gl * a.tile_group;
-            const int G = gl * 8 + xcd;                            // (image, row block) group
+            int G = gl * 8 + xcd;                                  // (image, row block) group
+            if constexpr (LRPXH_XCD_BLOCKED != 0) G = xcd * (((a.n_maps / a.tile_group) * TPM + 7) / 8) + gl;
             const int i = G / TPM, r = G - i * TPM;
             mtile = (i * a.tile_group + w) * TPM + r;
             if (G >= (a.n_maps / a.tile_group) * TPM) return;
@@ -554,8 +562,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         const unsigned lw0_ = pack_f16(l[0], l[1]), lw1_ = pack_f16(l[2], l[3]);                             \
         const int o0_ = (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                               \
         const int sg4_ = ((dst_ >> 28) & 3) * 4;                                                             \
-        const int rb0_ = (rm_ & 1) ? o0_ : POOL_SCRATCH;              /* window row dy = 0 */                \
-        const int rb1_ = (rm_ & 2) ? o0_ + ((rm_ & 1) ? PITCH : 0) : POOL_SCRATCH;      /* dy = 1 */         \
+        const int rb0_ = ((rm_ & 1) && !(LRPXH_EXP & 4)) ? o0_ : POOL_SCRATCH;   /* window row dy = 0 */    \
+        const int rb1_ = ((rm_ & 2) && !(LRPXH_EXP & 4)) ? o0_ + ((rm_ & 1) ? PITCH : 0) : POOL_SCRATCH;     \
         _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                                \
             const unsigned x_ = amv[u] ^ (0x01010101u * (unsigned)pos);       /* zero byte <=> winner == pos */ \
             const unsigned eq_ = ((x_ | (x_ >> 1)) & 0x01010101u) ^ 0x01010101u;                             \
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         const float xs_[4] = {xa_[0], xa_[1], xb_[0], xb_[1]};                                               \
         _Float16 h[4], l[4];                                                                                 \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(xs_[e], h[e], l[e]);                            \
-        char* d_ = ldsb + (dst_ >= 0 ? (BUFIDX) * BUFB + (dst_ & 0x03ffffff) : STAGE_SCRATCH);               \
+        char* d_ = ldsb + ((dst_ >= 0 && !(LRPXH_EXP & 4)) ? (BUFIDX) * BUFB + (dst_ & 0x03ffffff) : STAGE_SCRATCH); \
         *reinterpret_cast<u32x2_*>(d_) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};                 \
         if constexpr (F8) {                                                                                  \
             const int sg4_ = ((dst_ >> 28) & 3) * 4;                                                         \
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         // spilled registers elsewhere, so only that kernel does it)
         // group 0 loads the next chunk, group 1 (which has already committed the next chunk) the one after it
 #define LRPXH_ISSUE_NEXT                                                                        \
-        {                                                                                       \
+        if constexpr (!(LRPXH_EXP & 2)) {                                                       \
             const int cn_ = min(chunk + 1 + grp, nchunk - 1);                                   \
             if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(cn_) } else { LRPXH_ISSUE(cn_) }            \
             __builtin_amdgcn_sched_barrier(0);                                                  \
