@@ -408,7 +408,7 @@ def chain_ms(eng, r_feat, row2img, out, reps):
         e1.record()
         e1.synchronize()
         ms.append(e0.elapsed_time(e1))
-    return sum(ms) / len(ms)
+    return sorted(ms)[len(ms) // 2]          # median: one repetition now and then takes twice as long (clock / power event)
 
 
 def roofline(a, lib, eng, state, maps, B, T, mode):
@@ -466,7 +466,7 @@ def roofline(a, lib, eng, state, maps, B, T, mode):
 
 def mode_sweep(lib, engines, streams, one_step, state, B, T, mode_now):
     """The same step (and the chain alone) in every matrix-core mode, measured in this process: 2 warm-up + 6 timed steps
-    with the batches in flight of the headline; chain = HIP events around lrpx_vgg16_relevance, 3 repetitions."""
+    with the batches in flight of the headline; chain = HIP events around lrpx_vgg16_relevance, median of 5 repetitions."""
     res = {}
     n_pipe = len(engines)
     for m in (0, 1, 2, 3):
@@ -488,7 +488,7 @@ def mode_sweep(lib, engines, streams, one_step, state, B, T, mode_now):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 6
         r_feat, row2img = state["chain_in"]
-        c_ms = chain_ms(engines[0], r_feat, row2img, state["maps0"], 3)
+        c_ms = chain_ms(engines[0], r_feat, row2img, state["maps0"], 5)
         res[str(m)] = {"maps_per_s": round(B * T / dt, 1), "ms_per_step": round(dt * 1e3, 3), "chain_ms": round(c_ms, 3),
                        "dtype": MODE_DTYPE[m]}
         log(f"mode {m}: {B * T / dt:.0f} maps/s, chain {c_ms:.2f} ms")

@@ -259,7 +259,12 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #define LRPXH_XCD_BLOCKED 1
 #endif
     int mtile = (idx / n_blocks) * 8 + xcd;
-    if constexpr (LRPXH_XCD_BLOCKED != 0) mtile = xcd * ((m_tiles + 7) / 8) + idx / n_blocks;
+    if constexpr (LRPXH_XCD_BLOCKED != 0) {
+        // balanced ranges: XCD x owns tiles [x * m / 8, (x + 1) * m / 8) (small grids - the forward trace - stay spread)
+        const int t0 = (int)(((long)xcd * m_tiles) >> 3), t1 = (int)(((long)(xcd + 1) * m_tiles) >> 3);
+        mtile = t0 + idx / n_blocks;
+        if (mtile >= t1 && !(AL && a.tile_group > 1)) return;       // (grouped order: decided below)
+    }
     const int nblk = idx % n_blocks;
 #ifndef LRPXH_TILE_GROUP
 #define LRPXH_TILE_GROUP 1
@@ -273,10 +278,15 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             const int q = idx / n_blocks;                          // position in this XCD's sequence
             const int gl = q / a.tile_group, w = q - gl * a.tile_group;
             int G = gl * 8 + xcd;                                  // (image, row block) group
-            if constexpr (LRPXH_XCD_BLOCKED != 0) G = xcd * (((a.n_maps / a.tile_group) * TPM + 7) / 8) + gl;
+            const int n_groups = (a.n_maps / a.tile_group) * TPM;
+            if constexpr (LRPXH_XCD_BLOCKED != 0) {
+                const int g0x = (int)(((long)xcd * n_groups) >> 3), g1x = (int)(((long)(xcd + 1) * n_groups) >> 3);
+                G = g0x + gl;
+                if (G >= g1x) return;
+            }
             const int i = G / TPM, r = G - i * TPM;
             mtile = (i * a.tile_group + w) * TPM + r;
-            if (G >= (a.n_maps / a.tile_group) * TPM) return;
+            if (G >= n_groups) return;
         }
     }
     if (mtile >= m_tiles) return;
