@@ -686,7 +686,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #ifdef LRPXH_NBQ8
     constexpr int NQ = F8 ? LRPXH_NBQ8 : NBQ;
 #else
-    constexpr int NQ = F8 ? ((POOL && AL && HW <= 112) ? 3 : 2) : NBQ;
+#ifndef LRPXH_NQ_112P
+#define LRPXH_NQ_112P 3
+#endif
+    constexpr int NQ = F8 ? ((POOL && AL && HW <= 112) ? ((HW == 112 && MT * NWN == 4) ? LRPXH_NQ_112P : 3) : 2) : NBQ;
 #endif
     // (a wave without a channel block of its own - n_oc not a multiple of the workgroup's channels - multiplies the last
     // valid block again and drops the result: one code path, see PRECISE below)
@@ -764,7 +767,14 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #ifdef LRPXH_F8_PIPE4
                 constexpr int PIPE_D = (MT * NWN >= 8) ? (MT >= 2 ? LRPXH_F8_PIPE_TALL : LRPXH_F8_PIPE) : LRPXH_F8_PIPE4;
 #else
-                constexpr int PIPE_D = (MT * NWN >= 8) ? (MT >= 2 ? LRPXH_F8_PIPE_TALL : LRPXH_F8_PIPE) : ((HW == 224 && POOL) ? 1 : 0);
+#ifndef LRPXH_PIPE_4W
+#define LRPXH_PIPE_4W 0        // the other 4-wave kernels
+#endif
+#ifndef LRPXH_PIPE_112P
+#define LRPXH_PIPE_112P 1      // conv2_2: 2.26 -> 2.12 ms (depth 3 with a B queue of 2: the same)
+#endif
+                constexpr int PIPE_D = (MT * NWN >= 8) ? (MT >= 2 ? LRPXH_F8_PIPE_TALL : LRPXH_F8_PIPE)
+                                                       : ((HW == 224 && POOL) ? 1 : ((HW == 112 && POOL) ? LRPXH_PIPE_112P : LRPXH_PIPE_4W));
 #endif
                 if constexpr (PIPE_D != 0) {
                 // Operand pipeline of depth D = LRPXH_F8_PIPE.  Left to itself the compiler (at 240+ VGPRs) keeps ONE set of
