@@ -112,7 +112,7 @@ __host__ __device__ constexpr int f8_slot_tap(int m, int i) { return 2 * m + i; 
 // comes back as float4 along the channels: lane L owns the channel quad L % 8 of pixel rows L / 8 + 8k, k = 0..3 - 4
 // loads + 4 stores of 16 bytes per lane and tile, 4x fewer memory instructions, whole 128-byte runs per 8 lanes.
 // Arithmetic, results and the per-map maxima are the same as in epi_gather / epi_finish (bit-identical outputs).
-template <int HW, bool AL>
+template <int HW, bool AL, int EPI>
 __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc)[7], float* __restrict__ scr, const int wm,
                                                  const int ocb, const int lane, const long g0, const long total_pix,
                                                  unsigned* __restrict__ oamax) {
@@ -182,7 +182,13 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const f32x4 xk = xv[j % RING][k];
-            const f32x4 r = {v[k][0] * xk[0], v[k][1] * xk[1], v[k][2] * xk[2], v[k][3] * xk[3]};
+            f32x4 r;
+            if constexpr (EPI == EPI_GUIDED) {     // ReLU hook of the layer below (a.relu == 2: the plain autograd mask)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r[c] = (xk[c] > 0.f && (a.relu == 2 || v[k][c] > 0.f)) ? v[k][c] : 0.f;
+            } else {
+                r = f32x4{v[k][0] * xk[0], v[k][1] * xk[1], v[k][2] * xk[2], v[k][3] * xk[3]};
+            }
             const int dq = r0 + 8 * k;
             const long gp = pix0 + wm * 224 + 32 * j + dq;
             if (col_ok && (AL || gp < total_pix)) {
@@ -1034,7 +1040,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     }
 
     // ---- epilogue (software-pipelined per tile); max|out1| per map goes to a.out1_amax for the next f16x3 consumer ----
-    unsigned* __restrict__ oamax = (EPI == EPI_FWD_DUAL) ? a.out0_amax
+    unsigned* __restrict__ oamax = (EPI == EPI_FWD_DUAL || EPI == EPI_GUIDED) ? a.out0_amax
                                    : (((EPI == EPI_REL || EPI == EPI_REL_MUL) && a.out1) ? a.out1_amax : nullptr);
     EpiMax mx0 = {0.f, 0.f}, mx1 = mx0, mx2 = mx0, mx3 = mx0, mx4 = mx0, mx5 = mx0, mx6 = mx0;   // (scalars: an array
 #ifndef LRPXH_WIDE_EPI
@@ -1044,13 +1050,13 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // lose their 11-13 spilled VGPRs: the two-map dword epilogue held two candidate addresses per element); the aligned
     // 56 / 112 / 224 kernels are 1-5 % SLOWER with it (their dword epilogue has compile-time offsets from one base), so
     // LRPXH_WIDE_EPI = 1 selects it for the straddling kernels only, 2 everywhere
-    if constexpr (EPI == EPI_REL_MUL && ((LRPXH_WIDE_EPI == 1 && !AL) || LRPXH_WIDE_EPI == 2)) {
+    if constexpr ((EPI == EPI_REL_MUL || EPI == EPI_GUIDED) && ((LRPXH_WIDE_EPI == 1 && !AL) || LRPXH_WIDE_EPI == 2)) {
         // (the K loop ends with a barrier: nobody reads the staging buffers any more; 32 x 36 floats per wave)
         float* scr = reinterpret_cast<float*>(ldsb) + wave * (32 * 36);
-        epi_rel_mul_wide<HW, AL>(a, acc, scr, wm, ocb, lane, g0, total_pix, oamax);
+        epi_rel_mul_wide<HW, AL, EPI>(a, acc, scr, wm, ocb, lane, g0, total_pix, oamax);
         return;
     }
-    if constexpr (EPI == EPI_REL_MUL) {                                                  //  would live in scratch)
+    if constexpr (EPI == EPI_REL_MUL || EPI == EPI_GUIDED) {                             //  would live in scratch)
         // one multiplicand per element: all 112 loads are issued before the first store (stores share the in-order
         // vmcnt with loads - a load behind a store waits for the store's write acknowledgement)
         EpiRegs r0, r1, r2, r3, r4, r5, r6;

@@ -207,9 +207,10 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
     const unsigned P = (unsigned)a.pix_per_map;
     float bias = 0.f;
     if (EPI == EPI_FWD_DUAL || EPI == EPI_PLAIN) bias = (a.bias && oc < ncol) ? a.bias[oc] : 0.f;
-    if constexpr (EPI == EPI_REL_MUL) {
+    if constexpr (EPI == EPI_REL_MUL || EPI == EPI_GUIDED) {
         // one output (out1 if given, else out0), one base pointer per tile, compile-time pixel offsets: ~3 VALU per
-        // element instead of a 64-bit multiply-add and two uniform branches
+        // element instead of a 64-bit multiply-add and two uniform branches.  GUIDED (the ReLU hook of the layer below,
+        // out = max(g,0) * [y > 0]; a.relu == 2: the plain autograd mask) moves the same data: one multiplicand, one output
         if (oc >= ncol) return;
         // pixel stride / channel base of the output: NHWC, or channel-chunked [C/ch][pixels][ch] (whole 64-byte runs per
         // pixel for a consumer that walks the channels chunk by chunk: the first-layer kernel)
@@ -228,7 +229,8 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
         for (int e = 0; e < 16; ++e) {
             const int dq = (e & 3) + 8 * (e >> 2);
             if (!ALIGNED && cx.pix0 + cx.q0 + 32 * j + dq >= cx.total_pix) continue;
-            const float rel = r.xv[e] * accj[e];
+            const float rel = EPI == EPI_GUIDED ? ((r.xv[e] > 0.f && (a.relu == 2 || accj[e] > 0.f)) ? accj[e] : 0.f)
+                                                : r.xv[e] * accj[e];
             // streaming store: the S tensors (0.5 - 4 GB) are read back a whole kernel later, keeping them out of the way
             // of the weights and multiplicands in L2 is worth 2 % on the wide layers (chain 21.23 -> 21.06 ms)
             __builtin_nontemporal_store(rel, &ob[dq * ostr]);
@@ -311,7 +313,15 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
         } else {   // EPI_GUIDED: ReLU hook of the layer below, out = max(g,0) * [y > 0]
             static_assert(EPI == EPI_FWD_DUAL || EPI == EPI_REL || EPI == EPI_FIRST || EPI == EPI_PLAIN || EPI == EPI_GUIDED || EPI == EPI_REL_MUL, "unknown epilogue");
             // a.relu == 2: plain autograd ReLU backward (mask only), else the guided rule (mask and clamp)
-            if (oc < ncol) o0[gp * ncol + oc] = (r.xv[e] > 0.f && (a.relu == 2 || v > 0.f)) ? v : 0.f;
+            if (oc < ncol) {
+                const float g = (r.xv[e] > 0.f && (a.relu == 2 || v > 0.f)) ? v : 0.f;
+                o0[gp * ncol + oc] = g;
+                if (mx) {     // the gradient is the next layer's operand: per-map maximum for its fp16 scale
+                    const bool past = !ALIGNED && TAPS == 9 && p0_tile + (e & 3) + 8 * (e >> 2) >= (int)P;
+                    mx->m0 = fmaxf(mx->m0, past ? 0.f : fabsf(g));
+                    mx->m1 = fmaxf(mx->m1, past ? fabsf(g) : 0.f);
+                }
+            }
         }
     }
 }

@@ -565,35 +565,48 @@ __global__ void guided_gate_kernel(const float* __restrict__ g, const float* __r
 }
 
 // max_pool2d backward (gradient to the arg-max, first maximum wins) followed by the guided ReLU hook of the conv
-// below: out = [this pixel is the window's arg-max and a > 0] * max(g, 0)
+// below: out = [this pixel is the window's arg-max and a > 0] * max(g, 0).  AMAX: max|out| per map for the fp16 scale of
+// the conv below (whole blocks of 256 threads, host-checked).  (One thread per OUTPUT pixel: a variant with one thread per
+// window - the window read once, four scattered stores - was 2.3x slower.)
+template <bool AMAX, int ITER>
 __global__ void maxpool_guided_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g_out,
                                           const int* __restrict__ map2img, float* __restrict__ g_in, int ho, int wo,
-                                          int c4, long total, int plain) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n_maps*(2ho)*(2wo)*c4
-    if (idx >= total) return;
-    int cc = idx % c4;
-    long r = idx / c4;
+                                          int c4, long total, int plain, unsigned* __restrict__ amax) {
+    // ITER items per thread at block stride (AMAX: 256 * ITER divides a map, one amax update per block - one per 256
+    // items made the updates of a map's single word the bottleneck: 5.9 instead of 1.8 ms per launch)
+    const long base = (long)blockIdx.x * (blockDim.x * ITER) + threadIdx.x;   // over n_maps*(2ho)*(2wo)*c4
     const int wi = 2 * wo, hi = 2 * ho;
-    int xi = r % wi; r /= wi;
-    int yi = r % hi;
-    long n = r / hi;
-    long img = map2img ? map2img[n] : n;
-    const int yo = yi >> 1, xo = xi >> 1;
-    const int pos = (yi & 1) * 2 + (xi & 1);
-    const f32x4* xb = reinterpret_cast<const f32x4*>(x) + ((img * hi + 2 * yo) * wi + 2 * xo) * c4 + cc;
-    f32x4 w4[4] = {xb[0], xb[c4], xb[(long)wi * c4], xb[(long)wi * c4 + c4]};
-    f32x4 go = reinterpret_cast<const f32x4*>(g_out)[((n * ho + yo) * wo + xo) * c4 + cc];
-    f32x4 o;
+    float mabs = 0.f;
+    long n = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float m = w4[0][e];
-        int am = 0;
-        if (w4[1][e] > m) { m = w4[1][e]; am = 1; }
-        if (w4[2][e] > m) { m = w4[2][e]; am = 2; }
-        if (w4[3][e] > m) { m = w4[3][e]; am = 3; }
-        o[e] = (am == pos && m > 0.f && (plain || go[e] > 0.f)) ? go[e] : 0.f;
+    for (int it = 0; it < ITER; ++it) {
+        const long idx = base + (long)it * blockDim.x;
+        if (idx >= total) break;
+        int cc = idx % c4;
+        long r = idx / c4;
+        int xi = r % wi; r /= wi;
+        int yi = r % hi;
+        n = r / hi;
+        long img = map2img ? map2img[n] : n;
+        const int yo = yi >> 1, xo = xi >> 1;
+        const int pos = (yi & 1) * 2 + (xi & 1);
+        const f32x4* xb = reinterpret_cast<const f32x4*>(x) + ((img * hi + 2 * yo) * wi + 2 * xo) * c4 + cc;
+        f32x4 w4[4] = {xb[0], xb[c4], xb[(long)wi * c4], xb[(long)wi * c4 + c4]};
+        f32x4 go = reinterpret_cast<const f32x4*>(g_out)[((n * ho + yo) * wo + xo) * c4 + cc];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float m = w4[0][e];
+            int am = 0;
+            if (w4[1][e] > m) { m = w4[1][e]; am = 1; }
+            if (w4[2][e] > m) { m = w4[2][e]; am = 2; }
+            if (w4[3][e] > m) { m = w4[3][e]; am = 3; }
+            o[e] = (am == pos && m > 0.f && (plain || go[e] > 0.f)) ? go[e] : 0.f;
+            mabs = fmaxf(mabs, fabsf(o[e]));
+        }
+        reinterpret_cast<f32x4*>(g_in)[idx] = o;
     }
-    reinterpret_cast<f32x4*>(g_in)[idx] = o;
+    if constexpr (AMAX) amax_commit(amax, n, mabs);
 }
 
 __global__ void accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, long n4) {
@@ -848,11 +861,19 @@ int guided_gate(const float* g, const float* y, const int* map2img, float* out, 
     return check_launch("guided_gate");
 }
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
-                       int c, int plain, hipStream_t s) {
-    long total = (long)n_maps * (2 * ho) * (2 * wo) * (c / 4);
-    hipLaunchKernelGGL(maxpool_guided_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, g_out, map2img, g_in, ho,
-                       wo, c / 4, total, plain);
-    return check_launch("maxpool_guided_bwd");
+                       int c, int plain, unsigned* amax, hipStream_t s) {
+    const long per = (long)4 * ho * wo * (c / 4);       // float4 items per map of the unpooled tensor
+    const long total = (long)n_maps * per;
+    const bool fused = amax && per % 2048 == 0;          // whole blocks of 8 x 256 items inside one map
+    if (fused)
+        hipLaunchKernelGGL((maxpool_guided_bwd_kernel<true, 8>), dim3(grid_for(total, 2048)), dim3(256), 0, s, x, g_out, map2img,
+                           g_in, ho, wo, c / 4, total, plain, amax);
+    else
+        hipLaunchKernelGGL((maxpool_guided_bwd_kernel<false, 1>), dim3(grid_for(total)), dim3(256), 0, s, x, g_out, map2img, g_in,
+                           ho, wo, c / 4, total, plain, amax);
+    LRPX_TRY(check_launch("maxpool_guided_bwd"));
+    if (amax && !fused) return lrpx_amax_maps(g_in, n_maps, per * 4, amax, s);   // (odd sizes: one streaming read)
+    return LRPX_OK;
 }
 }  // namespace lrpx
 }  // extern "C++"

@@ -66,7 +66,11 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
                      "or bias-free PLAIN epilogue");
         LRPX_REQUIRE(d->f16x3 != 2 || d->epi == EPI_REL_MUL || d->epi == EPI_GUIDED || d->epi == EPI_PLAIN,
                      "conv_mfma: the f16+f8 kernels (f16x3 = 2) are built for the REL_MUL, GUIDED and PLAIN epilogues");
+        static const int wide_g = getenv("LRPX_WIDE") ? atoi(getenv("LRPX_WIDE")) : 7;
         if (d->f16x3 == 2 && d->epi == EPI_GUIDED) {
+            if ((wide_g & 1) && d->n_oc >= 256 && d->hw == 56) return launch_h8_56w_guided(a, s);
+            if ((wide_g & 1) && d->n_oc >= 256 && d->hw == 28) return launch_h8_28w_guided(a, s);
+            if ((wide_g & 2) && d->n_oc >= 256 && d->hw == 14) return launch_h8_14w_guided(a, s);
             if (d->hw == 224 && d->n_oc <= 64) return launch_h8_224_guided(a, s);
             if (d->hw == 112 && d->n_oc > 64) return launch_h8_112_guided(a, s);
             if (d->hw == 56) return launch_h8_56_guided(a, s);
@@ -75,6 +79,8 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
             LRPX_REQUIRE(false, "conv_mfma: no f16+f8 GUIDED kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
         }
         if (d->f16x3 == 2 && d->epi == EPI_PLAIN) {
+            if ((wide_g & 1) && d->n_oc >= 256 && d->hw == 28) return launch_h8_28w_plain(a, s);
+            if ((wide_g & 2) && d->n_oc >= 256 && d->hw == 14) return launch_h8_14w_plain(a, s);
             if (d->hw == 112 && d->n_oc <= 64) return launch_h8_112n_plain(a, s);
             if (d->hw == 56) return launch_h8_56_plain(a, s);
             if (d->hw == 28) return launch_h8_28_plain(a, s);
@@ -227,7 +233,7 @@ int first_layer_relevance_mfma(const float* S, const float* packed, const float*
 int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, int plain,
                 hipStream_t s);
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
-                       int c, int plain, hipStream_t s);
+                       int c, int plain, unsigned* amax, hipStream_t s);
 
 // PROCESS DEFAULTS of the matrix-core mode of the fused chains (lrpx_set_conv_mode: 0 fp32 MFMA, 1 bf16x6 (conv_bf16x6.h),
 // 2 f16x3 (conv_f16x3.h), 3 = 2 with fp8 cross products in the relevance pass) and of the forward-trace switch
@@ -257,7 +263,7 @@ static thread_local int tl_timing = 0;
 static thread_local float tl_ms[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], first6, first6p, first16, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], first6, first6p, first16, first16p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
@@ -283,6 +289,7 @@ static VggPacked vgg_packed_layout() {
     p.first6 = off; off += (size_t)64 * 9 * 6;   // direct-conv weights of the first layer's rule
     p.first6p = off; off += (size_t)64 * 9 * 6;  // ... and of its plain transposed conv (guided backprop)
     p.first16 = off; off += (size_t)16 + 2 * 9 * 64 * 4;   // first layer's rule on the matrix cores (header + A fragments)
+    p.first16p = off; off += (size_t)16 + 2 * 9 * 64 * 4;  // ... and its plain transposed conv
     p.total = off;
     return p;
 }
@@ -392,6 +399,7 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
             LRPX_TRY(first_layer_pack(w[ci], base + p.first6, L.cout, 0, (hipStream_t)stream));
             LRPX_TRY(first_layer_pack(w[ci], base + p.first6p, L.cout, 1, (hipStream_t)stream));
             LRPX_TRY(first_layer_pack_mfma(w[ci], base + p.first16, 0, (hipStream_t)stream));
+            LRPX_TRY(first_layer_pack_mfma(w[ci], base + p.first16p, 1, (hipStream_t)stream));
         } else {
             LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, lrpx_conv_kc(L.hw, 9, L.cout),
                                        base + p.bwdp[l], stream));
@@ -689,32 +697,48 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
     int cur = 0;
     // hook of the last ReLU (the encoder ends with one): clamp(d,0) * [features > 0]
     LRPX_TRY(guided_gate(d_feat_nhwc, tr + t.act[kNL], map2img, G[cur], n_maps, (long)196 * 512, plain, st));
+    // fp16 split-product kernels: operand scale = per-map maximum of the incoming gradient, gam[l*n_maps + n] for the
+    // tensor conv layer l consumes - recorded by whoever writes that tensor (the GUIDED epilogue of the conv above, the
+    // pool backward kernel); only the first tensor costs a streaming read of its own
+    const bool h3 = mode >= 2;
+    unsigned* gam = reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps);
+    if (h3) {
+        if (hipMemsetAsync(gam, 0, (size_t)kNL * n_maps * sizeof(unsigned), st) != hipSuccess) {
+            set_error("vgg16_guided_backprop: cannot zero the amax words");
+            return LRPX_ELAUNCH;
+        }
+        LRPX_TRY(lrpx_amax_maps(G[cur], n_maps, (long)196 * 512, gam + (size_t)16 * n_maps, st));
+    }
     for (int l = kNL - 1; l >= 0; --l) {
         const VggLayer& L = kVgg[l];
         if (!L.conv) continue;
         if (l == 0) {
-            LRPX_TRY(first_layer_relevance(G[cur], pk + p.first6p, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 1, 0, st));
+            static const int fl_mfma = getenv("LRPX_FIRST_VALU") ? 0 : 1;
+            if (h3 && fl_mfma)
+                LRPX_TRY(first_layer_relevance_mfma(G[cur], pk + p.first16p, tr + t.act[0], map2img, gam, out_nchw, n_maps, 1, 0, st));
+            else
+                LRPX_TRY(first_layer_relevance(G[cur], pk + p.first6p, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 1, 0, st));
             break;
         }
         lrpx_conv_desc d = {};
         d.in = G[cur]; d.wpacked = pk + p.bwdp[l];
         d.n_maps = n_maps; d.hw = L.hw; d.cin = L.cout; d.taps = 9; d.map2img = map2img;
         d.n_oc = L.cin; d.oc_split = L.cin;
-        if (mode >= 2) {
-            // fp16 split-product kernels: operand scale = per-map maximum of the incoming gradient (one streaming read)
-            unsigned* gam = reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps) + (size_t)l * n_maps;
-            LRPX_TRY(lrpx_amax_maps(G[cur], n_maps, (long)L.hw * L.hw * L.cout, gam, st));
-            d.f16x3 = 1; d.wpacked = pk + p.bwdph[l]; d.in_amax = gam;
+        if (h3) {
+            d.f16x3 = 1; d.wpacked = pk + p.bwdph[l]; d.in_amax = gam + (size_t)l * n_maps;
+            d.tile_group = (n_maps % n_img == 0) ? n_maps / n_img : 0;        // (tile-order hint, as in the relevance chain)
             if (mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwdp8[l]; }      // cross products on the fp8 matrix cores
         }
         if (kVgg[l - 1].conv) {
             d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];      // ReLU hook of conv l-1 fused
             d.relu = plain ? 2 : 0;
+            if (h3) d.out0_amax = gam + (size_t)(l - 1) * n_maps;
             LRPX_TRY(conv_dispatch(&d, st));
         } else {
             d.epi = EPI_PLAIN; d.out0 = R;
             LRPX_TRY(conv_dispatch(&d, st));
-            LRPX_TRY(maxpool_guided_bwd(tr + t.act[l - 1], R, map2img, G[cur ^ 1], n_maps, L.hw, L.hw, L.cin, plain, st));
+            LRPX_TRY(maxpool_guided_bwd(tr + t.act[l - 1], R, map2img, G[cur ^ 1], n_maps, L.hw, L.hw, L.cin, plain,
+                                        h3 ? gam + (size_t)(l - 2) * n_maps : nullptr, st));
         }
         cur ^= 1;
     }
