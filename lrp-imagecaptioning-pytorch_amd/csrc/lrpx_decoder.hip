@@ -186,8 +186,11 @@ __global__ void gridtd_fwd_lstm_kernel(GridFwd g, int t, const float* __restrict
 //      att_img = W_v_proj(V)+b_v is time-invariant and precomputed.
 //  (2) context: grid (B, channel blocks): sentinel score, both softmaxes, context, c_hat and
 //      xh2[b,t] = [ctx_hat | h1_new | h2_old].
-constexpr int ATT_PB = 28;    // pixels per block in (1)
-constexpr int ATT_CB = 128;   // channels per block in (2)
+// (latency-bound at B = 16: with 28 pixels / 128 channels per block the two kernels ran 30 + 29 us per time step on 112 / 64
+// workgroups, each wave walking 7 pixels or each thread 98 pixels in sequence; now one pixel per wave and 8 pixel
+// slices per channel)
+constexpr int ATT_PB = 4;     // pixels per block in (1): one per wave
+constexpr int ATT_CB = 32;    // channels per block in (2): 8 pixel slices x 32 channels per block
 
 __global__ __launch_bounds__(256) void gridtd_fwd_att_scores_kernel(
     GridFwd g, int t, const float* __restrict__ att_img, const float* __restrict__ Wg, const float* __restrict__ Ws,
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void gridtd_fwd_att_context_kernel(GridFwd g, 
     const int b = blockIdx.x, H = g.H, P = g.P, tid = threadIdx.x;
     float* zsc = sm;            // P+1
     float* alpha = zsc + P + 1; // P
-    float* red = alpha + P;     // 8
+    float* red = zsc + (2 * P + 1 > 256 ? 2 * P + 1 : 256);     // 8 (behind the 256 partial sums that reuse zsc / alpha)
     const float* sc = scr + (long)b * 3 * P;
     for (int k = tid; k < P; k += 256) zsc[k] = sc[k];
     {   // sentinel score = w_h . tanh(s_proj + h_proj)   (:94)
@@ -248,13 +251,22 @@ __global__ __launch_bounds__(256) void gridtd_fwd_att_context_kernel(GridFwd g, 
     }
     if (tid == 0 && blockIdx.y == 0) g.beta[(long)b * g.T + t] = beta;
     __syncthreads();
-    // context for this block's channels: 2 threads per channel split the pixels
-    const int c = blockIdx.y * ATT_CB + (tid >> 1), half = tid & 1;
+    // context for this block's 32 channels: thread = (pixel slice tid / 32, channel tid % 32) - 128-byte runs per slice -
+    // partial sums through LDS, summed in slice order
+    const int c = blockIdx.y * ATT_CB + (tid & 31), part = tid >> 5;
     float a = 0.f;
     if (c < H)
-        for (int k = half; k < P; k += 2) a += Vp[((long)b * P + k) * H + c] * alpha[k];
-    a += __shfl_xor(a, 1, 64);
-    if (c < H && half == 0) {
+        for (int k = part; k < P; k += 8) a += Vp[((long)b * P + k) * H + c] * alpha[k];
+    float* psum = zsc;                     // (P + 1 >= 8 * 32 floats are not needed any more: alpha is its own array)
+    __syncthreads();
+    psum[tid] = a;
+    __syncthreads();
+    if (part == 0) {
+        a = psum[tid];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) a += psum[q * 32 + tid];
+    }
+    if (c < H && part == 0) {
         const long tr = ((long)b * g.T + t) * H, st0 = ((long)b * (g.T + 1) + t) * H;
         const float sv = g.s[tr + c], h1n = g.h1[st0 + H + c];
         const float ch = beta * sv + (1.f - beta) * a;
@@ -1169,7 +1181,8 @@ int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* V
                        (size_t)2 * tr->H * sizeof(float), (hipStream_t)stream, g, t, att_img, Wg, Ws, bs, wh, scratch);
     LRPX_TRY(check_launch("gridtd_fwd_att_scores"));
     hipLaunchKernelGGL(gridtd_fwd_att_context_kernel, dim3(tr->B, (tr->H + ATT_CB - 1) / ATT_CB), dim3(256),
-                       (size_t)(2 * tr->P + 1 + 8) * sizeof(float), (hipStream_t)stream, g, t, Vp, wh, scratch);
+                       (size_t)((2 * tr->P + 1 > 256 ? 2 * tr->P + 1 : 256) + 8) * sizeof(float), (hipStream_t)stream, g, t, Vp,
+                       wh, scratch);
     return check_launch("gridtd_fwd_att_context");
 }
 
