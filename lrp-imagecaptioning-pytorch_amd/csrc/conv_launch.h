@@ -75,6 +75,7 @@ int launch_h8_56w_rel(const ConvArgs& a, hipStream_t s);      // 8-wave workgrou
 int launch_h8_28w_rel(const ConvArgs& a, hipStream_t s);
 int launch_h8_14w_rel(const ConvArgs& a, hipStream_t s);
 int launch_h8_56w_pool(const ConvArgs& a, hipStream_t s);
+int launch_h8_28w_pool(const ConvArgs& a, hipStream_t s);
 int launch_h8_112_rel(const ConvArgs& a, hipStream_t s);
 int launch_h8_112n_rel(const ConvArgs& a, hipStream_t s);
 int launch_h8_224_rel(const ConvArgs& a, hipStream_t s);

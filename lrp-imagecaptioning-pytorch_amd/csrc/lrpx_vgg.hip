@@ -118,6 +118,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
             if (f8) {
                 static const int widep = getenv("LRPX_WIDE") ? atoi(getenv("LRPX_WIDE")) : 7;
                 if ((widep & 4) && d->hw == 56 && d->n_oc >= 256) return launch_h8_56w_pool(a, s);
+                if ((widep & 4) && d->hw == 28 && d->n_oc >= 256) return launch_h8_28w_pool(a, s);
                 if (d->hw == 224 && d->n_oc <= 64) return launch_h8_224_pool(a, s);
                 if (d->hw == 112 && d->n_oc > 64) return launch_h8_112_pool(a, s);
                 if (d->hw == 56) return launch_h8_56_pool(a, s);
@@ -612,10 +613,12 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
             if (mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
             // under a pool: S[cur] is the low-resolution tensor the conv above the pool wrote, unpooled while staged
             if (pooled_in) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
+            // conv4_3 in mode 3 used to unpool S with a scatter kernel (0.5 GB written) and run the plain 28x28 kernel: the
+            // map-straddling pooled-input kernel spilled 40 VGPRs with the fp8 operands.  With the SWAR commit it fits (8-wave
+            // version: 3 spills, as fast as the plain kernel), so the scatter is gone; LRPX_POOL28=0 brings it back (A/B)
+            static const int pool28 = getenv("LRPX_POOL28") ? atoi(getenv("LRPX_POOL28")) : 1;
+            if (!pool28)
 #ifndef LRPX_F8_POOL28
-            // ... except conv4_3 in mode 3: the map-straddling pooled-input 28x28 kernel spills 40 VGPRs with the fp8
-            // operands (2.98 ms; with fp16 cross products 2.75 ms), so S is unpooled by a scatter kernel (0.5 GB written)
-            // and the conv runs on the plain 28x28 F8 kernel (2.13 ms)
             if (mode == 3 && pooled_in && L.hw == 28) {
                 LRPX_TRY(lrpx_unpool_winner(S[cur], d.pool_am, map2img, S[cur ^ 1], n_maps, L.hw / 2, L.hw / 2, L.cout, stream));
                 cur ^= 1;
