@@ -47,7 +47,7 @@ PEAK_16BIT_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA pea
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E
 # The dominant kernel: the relevance step of a 256->256 conv on 56x56 maps (conv3_x) or of a 512->512 conv on 28x28 maps
 # (conv4_x) - the same work; the three conv3 and three conv4 launches are 55 % of the chain, and in the default mode the
-# 28x28 kernel has the largest total time (3 launches).  Algorithmic work per launch and map: one transposed 3x3 conv =
+# 28x28 kernel has the largest total time (conv4_1 / conv4_2; conv4_3 is its pooled-input instantiation).  Algorithmic work per launch and map: one transposed 3x3 conv =
 # 2*9*256*256*56*56 = 2*9*512*512*28*28 flop.  The matrix cores execute PRODUCTS[mode] 16-bit MFMA products per fp32 product (operand
 # splits, csrc/conv_f16x3.h / conv_bf16x6.h), so `achieved` counts executed MFMA flop against the 16-bit dense peak;
 # `algorithmic_tflops` is the fp32-equivalent rate.
@@ -422,10 +422,10 @@ def roofline(a, lib, eng, state, maps, B, T, mode):
     r_feat, row2img = state["chain_in"]
     out = state["maps0"]
     reps = max(3, min(a.steps, 10))
-    # (1) the whole VGG16 relevance chain (12 conv launches + first-layer kernel + unpool scatter), HIP events
+    # (1) the whole VGG16 relevance chain (12 conv launches + first-layer kernel), HIP events
     c_ms = chain_ms(eng, r_feat, row2img, out, reps)
-    # (2) roofline of the dominant kernel (default mode: the 28x28 relevance conv kernel, 3 launches per pass: conv4_3,
-    # conv4_2 with 512 and conv4_1 with 256 output channels), HIP events recorded by the library on the launch
+    # (2) roofline of the dominant kernel (default mode: the 28x28 relevance conv kernel, 2 launches per pass: conv4_2
+    # with 512 and conv4_1 with 256 output channels), HIP events recorded by the library on the launch
     # stream around every conv launch of the same chain on the same inputs
     per_layer = [0.0] * 17
     lib.lrpx_vgg16_layer_timing(1, None)
@@ -436,11 +436,12 @@ def roofline(a, lib, eng, state, maps, B, T, mode):
         per_layer = [p + float(v) for p, v in zip(per_layer, buf)]
     lib.lrpx_vgg16_layer_timing(0, None)
     per_layer = [p / reps for p in per_layer]
-    # launches of that kernel NAME per pass: mode 3: the kernel with the largest total time is the 28x28 one (conv4_1 with
-    # 256 output channels, conv4_2, conv4_3 behind the unpool scatter): same flop per full launch as the 56x56 layers
-    # (2*9*512*512*28*28); mode 2: conv3_1 / conv3_2 (conv3_3 is the pooled-input variant, own name in rocprof)
-    dom_layers, dom_w = ([10, 11, 12], [0.5, 1.0, 1.0]) if mode == 3 else (([6, 7], [0.5, 1.0]) if mode == 2 else ([6, 7, 8], [0.5, 1.0, 1.0]))
-    dom_desc = ("conv4_1/conv4_2/conv4_3 on 28x28 maps" if mode == 3 else
+    # launches of that kernel NAME per pass: mode 3: the kernel with the largest total time in the serial rocprof summary
+    # is the 28x28 one (conv4_1 with 256 output channels and conv4_2; conv4_3 runs the pooled-input instantiation of the
+    # same template, own name in rocprof): same flop per full launch as the 56x56 layers (2*9*512*512*28*28); mode 2:
+    # conv3_1 / conv3_2 (conv3_3 is the pooled-input variant)
+    dom_layers, dom_w = ([10, 11], [0.5, 1.0]) if mode == 3 else (([6, 7], [0.5, 1.0]) if mode == 2 else ([6, 7, 8], [0.5, 1.0, 1.0]))
+    dom_desc = ("conv4_1/conv4_2 on 28x28 maps" if mode == 3 else
                 ("conv3_1/conv3_2 on 56x56 maps" if mode == 2 else "conv3_1/conv3_2/conv3_3 on 56x56 maps"))
     dom_ms = sum(per_layer[l] for l in dom_layers) / len(dom_layers)          # average launch of that kernel
     flop = DOM_FLOP_PER_MAP * B * T * sum(dom_w) / len(dom_w)                 # average algorithmic flop / launch
