@@ -167,7 +167,11 @@ def test_conv_rule_f16x3_is_fp32_grade(ops, hw, cin, cout, n_img, n_maps):
 
 @pytest.mark.parametrize("hw,cin,cout,n_img,n_maps", [
     (14, 64, 96, 3, 5), (28, 32, 64, 2, 3), (56, 64, 128, 1, 2), (112, 64, 128, 1, 2), (112, 128, 128, 1, 1),
-    (224, 64, 64, 1, 2)])
+    (224, 64, 64, 1, 2),
+    # >= 256 output channels of the relevance pass: the 8-wave workgroups (operand pipeline, wave-group skew, float4
+    # epilogue); 320 = one full workgroup + one with two waves that have no channel block of their own; 9 and 11 maps:
+    # tile ranges per XCD that do not divide
+    (14, 256, 32, 3, 5), (28, 320, 32, 2, 3), (56, 256, 32, 1, 2), (14, 320, 16, 2, 11), (28, 256, 16, 3, 9)])
 def test_conv_rule_f16f8(ops, hw, cin, cout, n_img, n_maps):
     """f16x3 = 2: the hi.hi product on the fp16 matrix cores, the two cross products (2^-11 of the result) on the fp8
     ones with both factors rounded to e4m3.  Same 1e-4 contract against the oracle per map on maps whose scales differ
@@ -202,7 +206,9 @@ def test_conv_rule_f16f8(ops, hw, cin, cout, n_img, n_maps):
 
 @pytest.mark.parametrize("f8", [False, True])
 @pytest.mark.parametrize("hw,cpool,cin,n_img,n_maps", [(28, 64, 32, 2, 3), (56, 32, 64, 1, 2), (112, 32, 128, 1, 2),
-                                                        (224, 16, 64, 1, 1)])
+                                                        (224, 16, 64, 1, 1),
+                                                        # 8-wave pooled-input kernels (conv3_3 / conv4_3 of the chain)
+                                                        (28, 32, 256, 2, 5), (56, 32, 256, 1, 2)])
 def test_pooled_input_conv_rule(ops, hw, cpool, cin, n_img, n_maps, f8):
     """Pool2d rule (lrp_modules.py:182-195) + the conv rule under the pool in ONE kernel: the conv receives the
     relevance at the pool's OUTPUT and the winner positions (lrpx_pool_winner) and unpools while staging.
