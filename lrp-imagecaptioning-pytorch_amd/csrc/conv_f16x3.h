@@ -661,7 +661,11 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     constexpr bool ISSUE_LATE = (HW == 112 && MT == 2);
 #endif
     const int grp = STAG ? (wave >= MT * NWN / 2 ? 1 : 0) : 0;     // wave-uniform (waves w and w + 4 share a SIMD)
-    if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(0) } else { LRPXH_ISSUE(0) }
+    if constexpr (!(LRPXH_EXP & 8)) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(0) } else { LRPXH_ISSUE(0) } }
+    else {      // (EXP 8: what the exposed first load of a tile costs - zeros instead)
+#pragma unroll
+        for (int u = 0; u < (LOSTAGE ? UL : U); ++u) { sv[u] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (POOL) amv[u] = 0; }
+    }
     for (int i = tid; i < NBUF * BUFB / 16; i += NT) reinterpret_cast<u32x4_*>(ldsb)[i] = u32x4_{0, 0, 0, 0};
     __syncthreads();
     if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(0) } else { LRPXH_COMMIT(0) }
