@@ -104,6 +104,56 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
     }
 }
 
+// The same skinny linear on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products): M = 16 rows b per row tile,
+// N = 16 output features per workgroup, the 4 waves split K.  A lane loads ONE float4 of its weight row and one of its x
+// row per 16 k (lane = (feature or row) lane & 15, k quad lane >> 4: component j of the two float4s is the operand pair of
+// MFMA j) - no cross-lane reduction at all: the VALU version spends 64 wave reductions (384 ds_bpermute) per wave and
+// ran 22 us for a 16 x 1536 x 2560 problem (0.7 TB/s of weights).  The four K-slices meet in LDS, summed in wave order.
+template <int RT>
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, long ldo,
+                                                          int B, int K, int N, int act) {
+    __shared__ float red[4][RT][16][17];
+    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    const int nl = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kslice = ((K / 16 + 3) / 4) * 16;                        // K % 16 == 0 (host-checked)
+    const int k_lo = wv_ * kslice, k_hi = min(K, k_lo + kslice);
+    const float* __restrict__ wrow = w + (long)min(n0 + nl, N - 1) * K + kq * 4;
+    const float* __restrict__ xrow[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) xrow[r] = x + (long)min(r * 16 + nl, B - 1) * ldx + kq * 4;
+    f32x4 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+        const f32x4 wq = *reinterpret_cast<const f32x4*>(wrow + k0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const f32x4 xq = *reinterpret_cast<const f32x4*>(xrow[r] + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[j], wq[j], acc[r], 0, 0, 0);
+        }
+    }
+    // result layout: column (feature) lane & 15, rows 4 * (lane >> 4) + i
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wv_][r][4 * kq + i][nl] = acc[r][i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < RT * 256; e += 256) {
+        const int r = e >> 8, row = (e >> 4) & 15, col = e & 15;
+        const int b = r * 16 + row, n = n0 + col;
+        if (b < B && n < N) {
+            float v = (red[0][r][row][col] + red[1][r][row][col]) + (red[2][r][row][col] + red[3][r][row][col]);
+            if (bias) v += bias[n];
+            if (act == 1) v = v > 0.f ? v : 0.f;
+            out[(long)b * ldo + n] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // image-side constants: avg over pixels, relu
 // ------------------------------------------------------------------------------------------------
@@ -1076,6 +1126,16 @@ extern "C" {
 int lrpx_linear_small(const float* x, long ldx, const float* w, const float* bias, float* out, long ldo, int B, int K,
                       int N, int act, void* stream) {
     LRPX_REQUIRE(x && w && out && B > 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0, "linear_small: bad arguments");
+    static const int lin_valu = getenv("LRPX_LINEAR_VALU") ? 1 : 0;     // (A/B switch)
+    if (K % 16 == 0 && B <= 64 && !lin_valu) {
+        const dim3 grid((N + 15) / 16);
+        hipStream_t st = (hipStream_t)stream;
+        if (B <= 16) hipLaunchKernelGGL((linear_mfma_kernel<1>), grid, dim3(256), 0, st, x, ldx, w, bias, out, ldo, B, K, N, act);
+        else if (B <= 32) hipLaunchKernelGGL((linear_mfma_kernel<2>), grid, dim3(256), 0, st, x, ldx, w, bias, out, ldo, B, K, N, act);
+        else if (B <= 48) hipLaunchKernelGGL((linear_mfma_kernel<3>), grid, dim3(256), 0, st, x, ldx, w, bias, out, ldo, B, K, N, act);
+        else hipLaunchKernelGGL((linear_mfma_kernel<4>), grid, dim3(256), 0, st, x, ldx, w, bias, out, ldo, B, K, N, act);
+        return check_launch("linear_small");
+    }
     hipLaunchKernelGGL((linear_small_kernel<4, 16>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
                        bias, out, ldo, B, K, N, act);
     return check_launch("linear_small");
