@@ -99,7 +99,7 @@ typedef struct lrpx_conv_desc {
                              2: as 1, but the two cross products hi*lo + lo*hi (2^-11 of the result) run on the fp8 matrix
                              cores with both factors rounded to e4m3 (error 2^-15 of a product, random sign: the maps
                              move by < 1e-5 of their maximum); wpacked from lrpx_pack_weights_f16f8; REL_MUL, GUIDED or PLAIN epilogue */
-    int out_chunk;        /* REL_MUL: > 0 writes the output channel-chunked [C/out_chunk][n_maps*pixels][out_chunk] (16) */
+    int out_chunk;        /* REL_MUL: > 0 writes the output channel-chunked [C/out_chunk][n_maps*pixels][out_chunk] (16 / 32) */
     const uint32_t* in_amax;  /* f16x3: [n_maps] float bits of max|in| per map (lrpx_amax_maps, or a producer's out1_amax) */
     uint32_t* out1_amax;      /* f16x3 + out1: max|out1| per map is atomicMax-ed into it (zero it first); may be null */
     uint32_t* out0_amax;      /* f16x3 + FWD_DUAL: max of out0 (the activations) per map is atomicMax-ed into it; may be null */

@@ -123,7 +123,7 @@ constexpr int FM_TH = 8, FM_TW = 32, FM_HP = FM_TH + 2, FM_WP = FM_TW + 2, FM_PI
 constexpr int FM_NPIX = FM_HP * FM_WP;                       // 340 halo pixels
 constexpr int FM_NIT = (FM_NPIX * 8 + 255) / 256;            // float4 items per thread and K-chunk (11)
 constexpr int FM_BANDS = 224 / FM_TH, FM_TILES = 224 / FM_TW;
-constexpr int FM_FRAG_FLOATS = 2 * 9 * 64 * 4;               // [chunk 2][tap 9][lane 64][8 fp16]
+
 
 typedef _Float16 fm_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned fm_u32x4 __attribute__((ext_vector_type(4)));
