@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
     f32x4 acc[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+    // (four k-steps of loads ahead of their MFMAs by hand: 9.0 instead of 9.3 us at B = 16, 23 instead of 17 at B = 64)
     for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
         const f32x4 wq = *reinterpret_cast<const f32x4*>(wrow + k0);
 #pragma unroll
