@@ -298,8 +298,20 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     if (mtile >= m_tiles) return;
     const int ocb = nblk * NWN + wn;
     const bool wave_active = ocb * 32 < a.n_oc;
-    const int nchunk = a.cin / KC;
     const long total_pix = (long)a.n_maps * a.pix_per_map;
+    // PLAIN epilogue with a.ksplit > 1 (forward trace of the 14x14 layers at small batches: 112 workgroups with 32
+    // K-chunks each on a chip of 256 CUs): blockIdx.y takes a contiguous range of the K-chunks and writes its partial
+    // sums to out0 + blockIdx.y * (pixels x columns); lrpx_fwd_dual_finish adds them in split order
+    const int nchunk_all = a.cin / KC;
+    int nchunk = nchunk_all, c_begin = 0;
+    if constexpr (EPI == EPI_PLAIN) {
+        if (a.ksplit > 1) {
+            c_begin = (int)blockIdx.y * nchunk_all / a.ksplit;
+            nchunk = ((int)blockIdx.y + 1) * nchunk_all / a.ksplit - c_begin;
+            a.out0 += (long)blockIdx.y * total_pix * a.oc_split;
+            a.ksplit = 1;            // (the epilogue stores its partial sums: conv_mfma.h adds atomically when ksplit > 1)
+        }
+    }
     const int li = lane & 31, lh = lane >> 5;
     const unsigned* __restrict__ in_amax = a.in_amax;
 
@@ -527,7 +539,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // so offsets are never negative; an item with nothing to load reads the tile's first pixel (always inside the tensor).
     const unsigned in_pix_stride = a.in_chunk_stride ? KC : a.cin;
     const long in_chunk_step = a.in_chunk_stride ? a.in_chunk_stride : KC;
-    const float* __restrict__ in_tile = a.in + (g0 - 1) * W * (long)in_pix_stride;
+    const float* __restrict__ in_tile = a.in + (g0 - 1) * W * (long)in_pix_stride + c_begin * in_chunk_step;
     const unsigned char* __restrict__ am_tile = a.pool_am;
     if constexpr (LOSTAGE && AL) {
         const long lo_row = (long)(y_al >> 1) - 1;
@@ -670,7 +682,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     __syncthreads();
     if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(0) } else { LRPXH_COMMIT(0) }
     if constexpr (STAG) {
-        if (grp == 1 && a.cin / 16 > 1) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(1) } else { LRPXH_ISSUE(1) } }
+        if (grp == 1 && nchunk > 1) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(1) } else { LRPXH_ISSUE(1) } }
     }
     f32x16 acc[7];
 #pragma unroll
@@ -705,7 +717,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // valid block again and drops the result: one code path, see PRECISE below)
     const int ocb_w = wave_active ? ocb : (a.n_oc - 1) / 32;
     const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
-                       (long)ocb_w * nchunk * (BSTEPS * BP * 64) + lane;
+                       ((long)ocb_w * nchunk_all + c_begin) * (BSTEPS * BP * 64) + lane;
     const int last_step = nchunk * BSTEPS - 1;
     u32x4_ bq[NQ][BP];
 #pragma unroll
@@ -1148,7 +1160,8 @@ int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
     static std::once_flag attr_once;
     static hipError_t attr_res = hipSuccess;
     LRPX_TRY(reserve_lds_once(attr_once, attr_res, kern, LDS, "conv_f16x3"));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MT * NWN), LDS, stream, a, (int)m_tiles, n_blocks);
+    const unsigned ks = (EPI == EPI_PLAIN && a.ksplit > 1) ? (unsigned)a.ksplit : 1u;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, ks), dim3(64 * MT * NWN), LDS, stream, a, (int)m_tiles, n_blocks);
     return check_launch("conv_f16x3");
 }
 

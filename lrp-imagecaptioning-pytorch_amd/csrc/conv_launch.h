@@ -121,6 +121,6 @@ bool dense_small_fits(const ConvArgs& a);
 int launch_dense_small(const ConvArgs& a, hipStream_t s);
 
 // host-side entry used by the C ABI and by the VGG16 / decoder chains
-int conv_dispatch(const lrpx_conv_desc* d, hipStream_t stream);
+int conv_dispatch(const lrpx_conv_desc* d, hipStream_t stream, int f16_ksplit = 1);
 
 }  // namespace lrpx

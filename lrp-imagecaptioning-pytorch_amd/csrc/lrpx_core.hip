@@ -133,6 +133,13 @@ __global__ void amax_flat_kernel(const float* __restrict__ x, long n, unsigned* 
     if ((threadIdx.x & 63) == 0) amax_update(out, m);
 }
 
+// End of a K-split forward conv (conv_f16x3.h, PLAIN epilogue with ksplit): part[s][pixel][2*cout] partial sums of
+// [conv(x, W) | conv(x, W+)] -> act = ReLU(sum + bias) [pixel][cout], zpos [pixel][cout], max of act per image.  The splits
+// are added in order (deterministic).  Whole blocks of 256 float4 items inside one image (host-checked).
+__global__ void fwd_dual_finish_kernel(const float* __restrict__ part, int nsplit, long split_stride,
+                                       const float* __restrict__ bias, float* __restrict__ act, float* __restrict__ zpos,
+                                       int cout, long per_img4, unsigned* __restrict__ amax);
+
 int amax_flat(const float* x, long n, unsigned* out, hipStream_t s) {
     hipLaunchKernelGGL(amax_flat_kernel, dim3(256), dim3(256), 0, s, x, n, out);
     return check_launch("amax_flat");
@@ -158,6 +165,27 @@ __device__ __forceinline__ void amax_commit(unsigned* __restrict__ amax, long n,
             for (int i = 0; i < 4; ++i) amax_update(&amax[redn[i]], red[i]);
         }
     }
+}
+
+__global__ void fwd_dual_finish_kernel(const float* __restrict__ part, int nsplit, long split_stride,
+                                       const float* __restrict__ bias, float* __restrict__ act, float* __restrict__ zpos,
+                                       int cout, long per_img4, unsigned* __restrict__ amax) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // float4 items over [pixel][2*cout]
+    const int c4n = cout / 2;                                          // float4 per pixel
+    const long pix = idx / c4n;
+    const int c = (int)(idx - pix * c4n) * 4;                          // column in [0, 2*cout)
+    f32x4 v = reinterpret_cast<const f32x4*>(part)[idx];
+    for (int s = 1; s < nsplit; ++s) v += reinterpret_cast<const f32x4*>(part + s * split_stride)[idx];
+    float m = 0.f;
+    if (c < cout) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = fmaxf(v[e] + b[e], 0.f); m = fmaxf(m, v[e]); }
+        *reinterpret_cast<f32x4*>(act + pix * cout + c) = v;
+    } else {
+        *reinterpret_cast<f32x4*>(zpos + pix * cout + (c - cout)) = v;
+    }
+    if (amax) amax_commit(amax, idx / per_img4, m);
 }
 
 // ITER float4 per thread at block stride (ITER > 1 only when 256*ITER divides a map: one amax update per block of
@@ -859,6 +887,14 @@ int guided_gate(const float* g, const float* y, const int* map2img, float* out, 
     hipLaunchKernelGGL(guided_gate_kernel, dim3(grid_for(total)), dim3(256), 0, s, g, y, map2img, out, per / 4, total,
                        plain);
     return check_launch("guided_gate");
+}
+int fwd_dual_finish(const float* part, int nsplit, const float* bias, float* act, float* zpos, int n_img, long pix_per_img,
+                    int cout, unsigned* amax, hipStream_t s) {
+    const long per_img4 = pix_per_img * (cout / 2), total4 = (long)n_img * per_img4;
+    LRPX_REQUIRE(cout % 4 == 0 && per_img4 % 256 == 0, "fwd_dual_finish: %ld float4 items per image are not whole blocks", per_img4);
+    hipLaunchKernelGGL(fwd_dual_finish_kernel, dim3((unsigned)(total4 / 256)), dim3(256), 0, s, part, nsplit,
+                       (long)n_img * pix_per_img * 2 * cout, bias, act, zpos, cout, per_img4, amax);
+    return check_launch("fwd_dual_finish");
 }
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
                        int c, int plain, unsigned* amax, hipStream_t s) {

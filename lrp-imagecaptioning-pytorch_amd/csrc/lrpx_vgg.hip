@@ -13,7 +13,7 @@
 
 namespace lrpx {
 
-int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
+int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
     LRPX_REQUIRE(d && d->in && d->wpacked && (d->out0 || d->out1), "conv_mfma: null pointer");
     LRPX_REQUIRE(d->taps == 9 || d->taps == 1, "conv_mfma: taps must be 9 or 1");
     LRPX_REQUIRE(d->n_maps > 0 && d->cin > 0 && d->n_oc > 0 && d->n_oc % 32 == 0, "conv_mfma: bad sizes (n_oc %% 32)");
@@ -59,6 +59,8 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s) {
         default: LRPX_REQUIRE(false, "conv_mfma: epilogue %d not built", d->epi);
     }
     if (d->f16x3) {
+        // (internal: K split of the PLAIN epilogue, partial sums per split behind each other in out0)
+        a.ksplit = (d->epi == EPI_PLAIN && f16_ksplit > 1 && (d->cin / 16) % f16_ksplit == 0) ? f16_ksplit : 1;
         LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0 && d->in_amax && !d->bf16x6 &&
                          ((d->epi == EPI_REL_MUL && d->x) || ((d->epi == EPI_FWD_DUAL || d->epi == EPI_GUIDED ||
                                                                (d->epi == EPI_PLAIN && !d->relu && !d->bias)) && !d->pool_am)),
@@ -228,6 +230,8 @@ static inline int cin_pad(int l) { return l == 0 ? 8 : kVgg[l].cin; }   // image
 int first_layer_pack(const float* w, float* w6, int cout, int plain, hipStream_t s);
 int first_layer_relevance(const float* S, const float* w6, const float* X8, const int* map2img, float* out, int n_maps,
                           int cin, int plain, int s_chunked, hipStream_t s);
+int fwd_dual_finish(const float* part, int nsplit, const float* bias, float* act, float* zpos, int n_img, long pix_per_img,
+                    int cout, unsigned* amax, hipStream_t s);
 int first_layer_pack_mfma(const float* w, float* packed, int plain, hipStream_t s);
 int first_layer_relevance_mfma(const float* S, const float* packed, const float* X8, const int* map2img,
                                const unsigned* s_amax, float* out, int n_maps, int plain, int chunked32, hipStream_t s);
@@ -487,6 +491,22 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
                 if (l == 1) LRPX_TRY(lrpx_amax_maps(tr + t.act[1], n_img, (long)L.hw * L.hw * L.cin, fam + (size_t)1 * n_img, stream));
                 d.f16x3 = 1; d.wpacked = pk + p.fwdh[l];
                 d.in_amax = fam + (size_t)in_l * n_img; d.out0_amax = fam + (size_t)(l + 1) * n_img;
+                // 14x14 layers of a small batch: ceil(n_img * 196 / 224) x 8 workgroups walk 32 K-chunks each on a chip of 256
+                // CUs (207 us per layer at 16 images).  Four K ranges per tile instead (PLAIN epilogue, partial sums into the
+                // - still unused - xz[1] region of the trace), then one pass adds them, applies bias / ReLU and records the
+                // per-image maximum: what the FWD_DUAL epilogue does.  Deterministic (the splits are added in order).
+                static const int fwd_ks = getenv("LRPX_FWD_KSPLIT") ? atoi(getenv("LRPX_FWD_KSPLIT")) : 4;
+                const long tiles14 = ((long)n_img * 196 + 223) / 224 * 8;
+                if (L.hw == 14 && fwd_ks > 1 && tiles14 * fwd_ks <= 1024 && (L.cin / 16) % fwd_ks == 0 &&
+                    (size_t)fwd_ks * 196 * 2 * L.cout <= (size_t)224 * 224 * 64) {
+                    float* part = tr + t.xz[1];
+                    d.epi = EPI_PLAIN; d.bias = nullptr; d.oc_split = 2 * L.cout;
+                    d.out0 = part; d.out1 = nullptr; d.out0_amax = nullptr;
+                    LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream, fwd_ks));
+                    LRPX_TRY(fwd_dual_finish(part, fwd_ks, pk + p.bias[l], tr + t.act[l + 1], tr + t.zpos[l], n_img, 196, L.cout,
+                                             fam + (size_t)(l + 1) * n_img, (hipStream_t)stream));
+                    continue;
+                }
             } else if (use_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
             LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
         } else {
