@@ -97,6 +97,11 @@ int launch_h8_28w_guided(const ConvArgs& a, hipStream_t s);
 int launch_h8_14w_guided(const ConvArgs& a, hipStream_t s);
 int launch_h8_28w_plain(const ConvArgs& a, hipStream_t s);
 int launch_h8_14w_plain(const ConvArgs& a, hipStream_t s);
+int launch_h8_112n_guided(const ConvArgs& a, hipStream_t s);
+int launch_h8_224_pool_guided(const ConvArgs& a, hipStream_t s);   // ... under a pool: pooled-input staging
+int launch_h8_112_pool_guided(const ConvArgs& a, hipStream_t s);
+int launch_h8_56w_pool_guided(const ConvArgs& a, hipStream_t s);
+int launch_h8_28w_pool_guided(const ConvArgs& a, hipStream_t s);
 int launch_h3_224_fwd(const ConvArgs& a, hipStream_t s);    // forward trace (ReLU(conv+b) and Z+) on the fp16 matrix cores
 int launch_h3_112_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_fwd(const ConvArgs& a, hipStream_t s);

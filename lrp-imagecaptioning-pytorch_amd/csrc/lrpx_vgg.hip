@@ -62,19 +62,30 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
         // (internal: K split of the PLAIN epilogue, partial sums per split behind each other in out0)
         a.ksplit = (d->epi == EPI_PLAIN && f16_ksplit > 1 && (d->cin / 16) % f16_ksplit == 0) ? f16_ksplit : 1;
         LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0 && d->in_amax && !d->bf16x6 &&
-                         ((d->epi == EPI_REL_MUL && d->x) || ((d->epi == EPI_FWD_DUAL || d->epi == EPI_GUIDED ||
-                                                               (d->epi == EPI_PLAIN && !d->relu && !d->bias)) && !d->pool_am)),
+                         ((d->epi == EPI_REL_MUL && d->x) || (d->epi == EPI_GUIDED && d->f16x3 == 2 && d->x) ||
+                          ((d->epi == EPI_FWD_DUAL || d->epi == EPI_GUIDED || (d->epi == EPI_PLAIN && !d->relu && !d->bias)) &&
+                           !d->pool_am)),
                      "conv_mfma: f16x3 needs a 3x3 conv, cin %% 16 == 0, in_amax and the REL_MUL (with x), FWD_DUAL, GUIDED "
                      "or bias-free PLAIN epilogue");
         LRPX_REQUIRE(d->f16x3 != 2 || d->epi == EPI_REL_MUL || d->epi == EPI_GUIDED || d->epi == EPI_PLAIN,
                      "conv_mfma: the f16+f8 kernels (f16x3 = 2) are built for the REL_MUL, GUIDED and PLAIN epilogues");
         static const int wide_g = getenv("LRPX_WIDE") ? atoi(getenv("LRPX_WIDE")) : 7;
+        if (d->f16x3 == 2 && d->epi == EPI_GUIDED && d->pool_am) {
+            LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
+                         "conv_mfma: too many (image, pooled pixel, channel) elements for the pooled-input kernel");
+            if (d->hw == 224 && d->n_oc <= 64) return launch_h8_224_pool_guided(a, s);
+            if (d->hw == 112 && d->n_oc > 64 && d->n_oc <= 128) return launch_h8_112_pool_guided(a, s);
+            if (d->hw == 56 && d->n_oc >= 256) return launch_h8_56w_pool_guided(a, s);
+            if (d->hw == 28 && d->n_oc >= 256) return launch_h8_28w_pool_guided(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no pooled-input f16+f8 GUIDED kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
         if (d->f16x3 == 2 && d->epi == EPI_GUIDED) {
             if ((wide_g & 1) && d->n_oc >= 256 && d->hw == 56) return launch_h8_56w_guided(a, s);
             if ((wide_g & 1) && d->n_oc >= 256 && d->hw == 28) return launch_h8_28w_guided(a, s);
             if ((wide_g & 2) && d->n_oc >= 256 && d->hw == 14) return launch_h8_14w_guided(a, s);
             if (d->hw == 224 && d->n_oc <= 64) return launch_h8_224_guided(a, s);
             if (d->hw == 112 && d->n_oc > 64) return launch_h8_112_guided(a, s);
+            if (d->hw == 112) return launch_h8_112n_guided(a, s);
             if (d->hw == 56) return launch_h8_56_guided(a, s);
             if (d->hw == 28) return launch_h8_28_guided(a, s);
             if (d->hw == 14) return launch_h8_14_guided(a, s);
@@ -752,10 +763,22 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
             d.tile_group = (n_maps % n_img == 0) ? n_maps / n_img : 0;        // (tile-order hint, as in the relevance chain)
             if (mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwdp8[l]; }      // cross products on the fp8 matrix cores
         }
+        // mode 3: a conv under a pool receives the gradient at the pool's OUTPUT resolution and routes it to the windows'
+        // arg-max while staging (the winner bytes of the trace, as the relevance chain): no pool-backward kernel, no 4x tensor
+        static const int gpool = getenv("LRPX_GUIDED_POOLBWD") ? 0 : 1;
+        const bool lowres_in = gpool && mode == 3 && l + 1 < kNL && !kVgg[l + 1].conv && l + 2 < kNL;
+        if (lowres_in) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
         if (kVgg[l - 1].conv) {
             d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];      // ReLU hook of conv l-1 fused
             d.relu = plain ? 2 : 0;
             if (h3) d.out0_amax = gam + (size_t)(l - 1) * n_maps;
+            LRPX_TRY(conv_dispatch(&d, st));
+        } else if (gpool && mode == 3 && l >= 2) {
+            // a pool lies below: the pool backward's gate [max > 0] (and the guided clamp) is the GUIDED hook on the pool's
+            // OUTPUT (= this conv's input, act[l]); the conv under the pool unpools while staging
+            d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];
+            d.relu = plain ? 2 : 0;
+            d.out0_amax = gam + (size_t)(l - 2) * n_maps;
             LRPX_TRY(conv_dispatch(&d, st));
         } else {
             d.epi = EPI_PLAIN; d.out0 = R;
