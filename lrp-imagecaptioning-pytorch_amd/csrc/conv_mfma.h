@@ -510,21 +510,38 @@ __global__ __launch_bounds__(64 * MT * NWN, 2) void conv_mfma_kernel(ConvArgs a,
         const long img = a.map2img ? a.map2img[n] : n;
         cx.xi_base = (img * a.pix_per_map + (long)((g - n * HW) * HW + cc)) * a.oc_split + cx.oc;
     }
+    // FWD_DUAL on map-aligned tiles (conv1_1 of the forward trace): the activations' maximum per image for the fp16 scale of
+    // the next layer, recorded here instead of by a streaming read of the 205 MB tensor afterwards
+    constexpr bool AMX = (EPI == EPI_FWD_DUAL) && AL;
+    EpiMax mx = {0.f, 0.f};
+    EpiMax* mxp = (AMX && a.out0_amax) ? &mx : nullptr;
     EpiRegs ra, rb;
     epi_gather<EPI, HW, TAPS, AL>(a, cx, 0, ra);
     epi_gather<EPI, HW, TAPS, AL>(a, cx, 1, rb);
-    epi_finish<EPI, HW, TAPS, AL>(a, cx, 0, acc[0], ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 0, acc[0], ra, mxp);
     epi_gather<EPI, HW, TAPS, AL>(a, cx, 2, ra);
-    epi_finish<EPI, HW, TAPS, AL>(a, cx, 1, acc[1], rb);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 1, acc[1], rb, mxp);
     epi_gather<EPI, HW, TAPS, AL>(a, cx, 3, rb);
-    epi_finish<EPI, HW, TAPS, AL>(a, cx, 2, acc[2], ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 2, acc[2], ra, mxp);
     epi_gather<EPI, HW, TAPS, AL>(a, cx, 4, ra);
-    epi_finish<EPI, HW, TAPS, AL>(a, cx, 3, acc[3], rb);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 3, acc[3], rb, mxp);
     epi_gather<EPI, HW, TAPS, AL>(a, cx, 5, rb);
-    epi_finish<EPI, HW, TAPS, AL>(a, cx, 4, acc[4], ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 4, acc[4], ra, mxp);
     epi_gather<EPI, HW, TAPS, AL>(a, cx, 6, ra);
-    epi_finish<EPI, HW, TAPS, AL>(a, cx, 5, acc[5], rb);
-    epi_finish<EPI, HW, TAPS, AL>(a, cx, 6, acc[6], ra);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 5, acc[5], rb, mxp);
+    epi_finish<EPI, HW, TAPS, AL>(a, cx, 6, acc[6], ra, mxp);
+    if constexpr (AMX) {
+        if (mxp) {
+            float m = mx.m0;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const unsigned n = (unsigned)g0 / (unsigned)H;
+            if (lane == 0 && m > 0.f && (int)n < a.n_maps) {
+                const unsigned b = __builtin_bit_cast(unsigned, m);
+                if (b > *reinterpret_cast<const volatile unsigned*>(&a.out0_amax[n])) atomicMax(&a.out0_amax[n], b);
+            }
+        }
+    }
 }
 
 }  // namespace lrpx

@@ -499,7 +499,7 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
                 // fp16 split products (conv_f16x3.h): operand scale = max of the layer input per image; a max-pool keeps it
                 unsigned* fam = reinterpret_cast<unsigned*>(tr + t.famax);
                 const int in_l = kVgg[l - 1].conv ? l : l - 1;
-                if (l == 1) LRPX_TRY(lrpx_amax_maps(tr + t.act[1], n_img, (long)L.hw * L.hw * L.cin, fam + (size_t)1 * n_img, stream));
+                // (the maximum of act[1] is recorded by conv1_1's epilogue below: l == 0)
                 d.f16x3 = 1; d.wpacked = pk + p.fwdh[l];
                 d.in_amax = fam + (size_t)in_l * n_img; d.out0_amax = fam + (size_t)(l + 1) * n_img;
                 // 14x14 layers of a small batch: ceil(n_img * 196 / 224) x 8 workgroups walk 32 K-chunks each on a chip of 256
@@ -519,6 +519,8 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
                     continue;
                 }
             } else if (use_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
+            // conv1_1 (fp32 MFMA kernel) records the per-image maximum of its activations for conv1_2's fp16 scale
+            if (fwd_f16 && mode >= 2 && l == 0) d.out0_amax = reinterpret_cast<unsigned*>(tr + t.famax) + (size_t)1 * n_img;
             LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
         } else {
             LRPX_TRY(lrpx_maxpool2x2_fwd(tr + t.act[l], tr + t.act[l + 1], n_img, L.hw, L.hw, L.cin, stream));
