@@ -193,7 +193,11 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
             const long gp = pix0 + wm * 224 + 32 * j + dq;
             if (col_ok && (AL || gp < total_pix)) {
                 float* op = O + gp * (long)ostr + obase;
+#if LRPXH_NT_STORE & 1
                 __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(op));
+#else
+                *reinterpret_cast<f32x4*>(op) = r;
+#endif
                 const float m = fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3])));
                 if (AL || p0 + dq < (int)P) m0 = fmaxf(m0, m); else m1 = fmaxf(m1, m);
             }
@@ -1070,6 +1074,22 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         // (the K loop ends with a barrier: nobody reads the staging buffers any more; 32 x 36 floats per wave)
         float* scr = reinterpret_cast<float*>(ldsb) + wave * (32 * 36);
         epi_rel_mul_wide<HW, AL, EPI>(a, acc, scr, wm, ocb, lane, g0, total_pix, oamax);
+#ifdef LRPX_STAMP
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LRPXH_T(t_endw);
+            if (lane == 0 && HW == LRPX_STAMP_HW) {
+                atomicAdd(&g_stamp_h3[0], t_loop - t_start);
+                atomicAdd(&g_stamp_h3[1], s_issue);
+                atomicAdd(&g_stamp_h3[2], s_mfma);
+                atomicAdd(&g_stamp_h3[3], s_commit);
+                atomicAdd(&g_stamp_h3[4], s_barrier);
+                atomicAdd(&g_stamp_h3[5], t_endw - t_epi);
+                atomicAdd(&g_stamp_h3[6], t_endw - t_start);
+                atomicAdd(&g_stamp_h3[7], 1ull);
+            }
+        }
+#endif
         return;
     }
     if constexpr (EPI == EPI_REL_MUL || EPI == EPI_GUIDED) {                             //  would live in scratch)

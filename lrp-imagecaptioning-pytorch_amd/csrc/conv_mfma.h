@@ -19,6 +19,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef LRPXH_NT_STORE
+#define LRPXH_NT_STORE 3      // bit 0: float4 (wide) REL_MUL epilogue, bit 1: dword epilogue: streaming stores
+#endif
+
 namespace lrpx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -233,7 +237,11 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
                                                 : r.xv[e] * accj[e];
             // streaming store: the S tensors (0.5 - 4 GB) are read back a whole kernel later, keeping them out of the way
             // of the weights and multiplicands in L2 is worth 2 % on the wide layers (chain 21.23 -> 21.06 ms)
+#if LRPXH_NT_STORE & 2
             __builtin_nontemporal_store(rel, &ob[dq * ostr]);
+#else
+            ob[dq * ostr] = rel;
+#endif
             if (mx) {
                 const bool past = !ALIGNED && TAPS == 9 && p0t + dq >= (int)P;
                 mx->m0 = fmaxf(mx->m0, past ? 0.f : fabsf(rel));
