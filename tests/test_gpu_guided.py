@@ -150,3 +150,37 @@ def test_guided_gradcam_vs_reference_fixture():
     # explain_cnn of the drop-in: one word's decoder gradient -> the same map
     d_feat, _ = ex.explain_caption_wordt(2)
     assert torch.equal(ex.explain_cnn(d_feat)[0], maps[0, 2])
+
+
+@pytest.mark.parametrize("plain", [False, True])
+def test_image_gradient_chain_agrees_across_conv_modes(case, plain):
+    """guided backprop / plain gradient through VGG16 on the same trace in the bf16x6 kernels (mode 1, fp32-grade), the
+    f16x3 kernels (mode 2: pool-backward kernels, operand maxima recorded by the producers) and the default fp16 + fp8
+    kernels (mode 3: pooled-input staging under the pools, 8-wave workgroups, matrix-core first layer): 1e-4 per map, on 5
+    maps of 2 images (map counts that do not divide the per-XCD tile ranges) with scales 1e6 apart"""
+    from test_gpu_vgg import to_nhwc
+    from lrp_amd import weights
+    g, sd, eng, img, cap = case
+    vgg = eng.vgg
+    imgs = torch.from_numpy(weights.make_images(77, 2)).cuda()
+    gen = torch.Generator().manual_seed(5)
+    d = torch.randn(5, 512, 14, 14, generator=gen) * torch.exp(2 * torch.randn(5, 512, 14, 14, generator=gen))
+    d = (d * torch.logspace(0, -6, 5).view(-1, 1, 1, 1)).contiguous()
+    m2i = torch.tensor([0, 1, 1, 0, 1], dtype=torch.int32, device="cuda")
+    fn = vgg.gradient if plain else vgg.guided_backprop
+    keep = vgg.conv_mode
+    outs = {}
+    try:
+        for mode in (1, 2, 3):
+            vgg.conv_mode = mode
+            vgg.forward(imgs)
+            if mode == 1:
+                trace1 = vgg.trace.clone()
+            else:
+                vgg.trace.copy_(trace1)          # the same activations / pool winners / ReLU masks for every mode
+            outs[mode] = fn(to_nhwc(d).cuda(), m2i).cpu()
+    finally:
+        vgg.conv_mode = keep
+    for mode in (2, 3):
+        for i in range(5):
+            assert rel_err(outs[mode][i], outs[1][i]) < 1e-4, (mode, i, rel_err(outs[mode][i], outs[1][i]))
