@@ -26,6 +26,10 @@ Rank 0 prints ONE JSON line.  At N=1 it also carries
   sustained    : the same step repeated for >= --sustain seconds (power-limited clocks show here, not in 20 steps)
   median_ms    : median interval between step completions (HIP events) inside the timed region
   cpu_baseline : the reference-equivalent CPU mode (oracle/ref_equiv.py, kind "port") on a bounded sample.
+  configs      : the other BASELINE configs measured in the SAME invocation after the headline (driver-witnessed):
+                 "3" AoA B=64 head 0 (+ `all_heads`: the 8 heads of every word, 10 240 maps per step), "4" LRP + Guided-
+                 Backprop B=32, "5" bottom-up B=32, and "b64": the headline model at the 64-image batch north_star's
+                 target names; each with value, ms_per_step and the dominant kernel's roofline fraction (--no-configs skips)
 """
 import argparse
 import json
@@ -135,7 +139,7 @@ def read_traffic(mode, n_maps):
     return None, None
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -149,6 +153,8 @@ def parse():
     ap.add_argument("--gather", action="store_true", help="gather the maps to rank 0 over RCCL inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the roofline.modes sweep (every conv mode, same process)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 3 / 4 / 5 and the B=64 line, same process)")
+    ap.add_argument("--all-heads", action="store_true", help="config 3: explain all 8 heads of every word in the step (8 x B x T maps)")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained sub-measurement (0 = off)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph per batch in flight (config 2, LRP)")
     ap.add_argument("--pipeline", type=int, default=None,
@@ -158,7 +164,7 @@ def parse():
     ap.add_argument("--fp32-mfma", action="store_true", help="same as --conv-mode 0")
     ap.add_argument("--conv-mode", type=int, default=3, choices=[0, 1, 2, 3],
                     help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp8 cross products (default)")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     if a.explainer is None:
         a.explainer = "lrp+guided" if a.config == 4 else "lrp"
     if a.batch is None:
@@ -198,6 +204,47 @@ def main():
         dist = None
         torch.cuda.set_device(0)
 
+    out = run_config(a, dist, rank, world)
+    if rank == 0:
+        if world == 1 and a.config == 2 and a.explainer == "lrp" and not a.no_configs and not a.graph and a.batch == 16:
+            out["configs"] = other_configs(a)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def other_configs(a):
+    """BASELINE configs 3 / 4 / 5 and the 64-image gridTD batch, measured in this process after the headline: 2 warm-up +
+    `n` timed steps each with that config's own batches in flight, no sustained leg, no mode sweep, no CPU baseline."""
+    import gc
+    res = {}
+    todo = [("3", ["--config", "3"], 6), ("3_all_heads", ["--config", "3", "--all-heads"], 2),
+            ("4", ["--config", "4"], 6), ("5", ["--config", "5"], 40), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 6)]
+    for key, argv, n in todo:
+        gc.collect()
+        torch.cuda.empty_cache()
+        b = parse(argv + ["--steps", str(n), "--warmup", "2", "--sustain", "0", "--no-modes", "--no-cpu-baseline", "--no-configs",
+                          "--conv-mode", str(a.conv_mode)])
+        o = run_config(b, None, 0, 1)
+        r = o.get("roofline") or {}
+        line = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": n, "maps_per_step": o["config"]["maps_per_step"],
+                "batches_in_flight": o["config"]["batches_in_flight"], "workload": o["config"]["workload"],
+                "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "ms_per_launch") if k in r}}
+        if "chain" in r:
+            line["roofline"]["chain_ms"] = r["chain"]["ms_per_step"]
+        log(f"configs[{key}]: {o['value']:.0f} maps/s, {o['ms_per_step']:.2f} ms/step")
+        if key == "3_all_heads":
+            res["3"]["all_heads"] = {k: line[k] for k in ("value", "unit", "ms_per_step", "steps", "maps_per_step")}
+            res["3"]["all_heads"]["note"] = "encoder + decoder trace once per batch, decoder relevance + CNN relevance + running sums for each of the 8 heads"
+        else:
+            res[key] = line
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_config(a, dist, rank, world):
+    """one measurement (the contract's timed region + the roofline of its dominant kernel) -> the dict of the JSON line"""
     import lrp_amd  # noqa: F401
     from lrp_amd import _lib, ops, weights
 
@@ -213,7 +260,8 @@ def main():
     caps = torch.from_numpy(weights.make_captions(200 + rank, B, T, V)).cuda()
     state = {"caps": caps}
     guided = a.explainer == "lrp+guided"
-    maps_per_gpu = B * T * (2 if guided else 1)
+    heads = list(range(8)) if (a.all_heads and a.config == 3) else [a.head]
+    maps_per_gpu = B * T * (2 if guided else 1) * len(heads)
     has_vgg = a.config != 5
 
     def buf(name, k, *shape):
@@ -251,14 +299,15 @@ def main():
         def one_step(e, k):
             enc = e.encode(images)
             tr = e.trace(enc, caps, predictions=True)
-            r_feat, r_words, row2img = e.relevance(enc, tr, a.head)
-            maps = e.vgg.relevance(r_feat, row2img, out=buf("maps", k, B * T, 3, 224, 224))
-            cum = ops.cumsum_maps(maps, B, T, out=buf("cum", k, B * T, 3, 224, 224))
+            for hd in heads:          # (--all-heads: the heads share the traces, everything behind `lrp_mha` is per head)
+                r_feat, r_words, row2img = e.relevance(enc, tr, hd)
+                maps = e.vgg.relevance(r_feat, row2img, out=buf("maps", k, B * T, 3, 224, 224))
+                cum = ops.cumsum_maps(maps, B, T, out=buf(f"cum{hd}_", k, B * T, 3, 224, 224))
             if k == 0:
                 state["chain_in"] = (r_feat, row2img)
             return cum, r_words
         workload = (f"BASELINE configs[2]: batch-{B} 224x224 images x {T}-word captions per GPU, VGG16 + AoA 8-head decoder, "
-                    f"LRP through multi-head attention (head {a.head}) + FC predictor, V={V}, random-init")
+                    f"LRP through multi-head attention ({'all 8 heads' if len(heads) > 1 else f'head {a.head}'}) + FC predictor, V={V}, random-init")
     else:
         from lrp_amd.explainers.aoa import AOAEngine
         eng = AOAEngine(weights.make_aoa_state(seed=0, vocab_size=V, feat_dim=2048, with_encoder=False))
@@ -390,9 +439,8 @@ def main():
                                "traffic": None}
         if world == 1 and a.config == 2 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(V, T, sorted({round(i * (T - 1) / 9) for i in range(10)}))   # 10 words, mean index (T-1)/2
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 def e_images(state):

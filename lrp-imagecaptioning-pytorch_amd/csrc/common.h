@@ -45,20 +45,48 @@ int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, flo
 // max|x| over a flat tensor, atomically max-ed into *out as float bits (lrpx_core.hip)
 int amax_flat(const float* x, long n, unsigned* out, hipStream_t stream);
 
-// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel instantiation, set exactly once even when several host threads
-// make their first launch of it at the same time (no globals except an init-once cache behind a mutex).
-// `once` / `res` are the caller's function-local statics (one pair per template instantiation).
+// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel instantiation.  HIP function attributes are PER DEVICE, and one
+// host process may drive several GPUs from several threads (include/lrpx.h THREADING), so the attribute is set exactly once
+// per (instantiation, device ordinal) even when several host threads make their first launch of it at the same time
+// (no globals except an init-once cache behind a mutex).  `LdsOnce` is the caller's function-local static
+// (one per template instantiation).
+struct LdsOnce {
+    static constexpr int MAX_DEV = 64;
+    std::once_flag once[MAX_DEV];
+    hipError_t res[MAX_DEV] = {};
+};
 template <typename K>
-inline int reserve_lds_once(std::once_flag& once, hipError_t& res, K kern, int bytes, const char* what) {
-    std::call_once(once, [&] {
-        res = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+inline int reserve_lds_once(LdsOnce& st, K kern, int bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LdsOnce::MAX_DEV) {
+        set_error("%s: cannot identify the current device", what);
+        return LRPX_ELAUNCH;
+    }
+    std::call_once(st.once[dev], [&] {
+        st.res[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     });
-    if (res != hipSuccess) {
-        set_error("%s: cannot reserve %d bytes of LDS", what, bytes);
+    if (st.res[dev] != hipSuccess) {
+        set_error("%s: cannot reserve %d bytes of LDS on device %d", what, bytes, dev);
         return LRPX_ELAUNCH;
     }
     return LRPX_OK;
 }
+
+// A/B switches of the shipped dispatch paths: ONE getenv pass per process, latched on first use, so that paired decisions
+// (LRPX_FIRST_VALU picks both the first-layer kernel and the chunk width its producer writes) cannot diverge.  Defaults are
+// what every number in DESIGN.md is measured with; the non-default values are exercised by tests/test_gpu_switches.py.
+struct Switches {
+    int wide;            // LRPX_WIDE (bit mask, default 7): 8-wave relevance kernels for 56/28 (1), 14 (2), pooled-input 56/28 (4)
+    int fwd_ksplit14;    // LRPX_FWD_KSPLIT (default 8): K ranges per tile of the 14x14 forward layers (1 = unsplit)
+    int fwd_ksplit28;    // LRPX_FWD_KSPLIT28 (default 4): ... of the 28x28 forward layers
+    int first_valu;      // LRPX_FIRST_VALU: first-layer rule on the VALU kernel (and S from conv1_2 in 16-channel chunks)
+    int pool28;          // LRPX_POOL28 (default 1): conv4_3 unpools while staging; 0 = scatter kernel + plain 28x28 kernel
+    int s21_nhwc;        // LRPX_S21_NHWC: S between conv2_2 and conv2_1 as NHWC instead of 16-channel chunks
+    int guided_poolbwd;  // LRPX_GUIDED_POOLBWD: image-gradient chain with pool-backward kernels
+    int dense_1wave;     // LRPX_DENSE_1WAVE: PLAIN few-row GEMMs without the 4-wave K split
+    int linear_valu;     // LRPX_LINEAR_VALU: the VALU skinny linear instead of the fp32-MFMA one
+};
+const Switches& switches();      // (lrpx_core.hip)
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline long ceil_div(long a, long b) { return (a + b - 1) / b; }

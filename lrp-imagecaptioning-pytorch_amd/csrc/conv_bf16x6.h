@@ -305,9 +305,8 @@ int launch_conv_bf16x6(const ConvArgs& a, hipStream_t stream) {
     const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
     const long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
     auto kern = conv_bf16x6_kernel<HW, MT, NWN, DB, EPI>;
-    static std::once_flag attr_once;
-    static hipError_t attr_res = hipSuccess;
-    LRPX_TRY(reserve_lds_once(attr_once, attr_res, kern, LDS, "conv_bf16x6"));
+    static LdsOnce attr_once;
+    LRPX_TRY(reserve_lds_once(attr_once, kern, LDS, "conv_bf16x6"));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MT * NWN), LDS, stream, a, (int)m_tiles, n_blocks);
     return check_launch("conv_bf16x6");
 }

@@ -1177,9 +1177,8 @@ int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
         grid = ceil_div(n_groups, 8) * 8 * a.tile_group * n_blocks;
     }
     auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI, POOL, F8>;
-    static std::once_flag attr_once;
-    static hipError_t attr_res = hipSuccess;
-    LRPX_TRY(reserve_lds_once(attr_once, attr_res, kern, LDS, "conv_f16x3"));
+    static LdsOnce attr_once;
+    LRPX_TRY(reserve_lds_once(attr_once, kern, LDS, "conv_f16x3"));
     const unsigned ks = (EPI == EPI_PLAIN && a.ksplit > 1) ? (unsigned)a.ksplit : 1u;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, ks), dim3(64 * MT * NWN), LDS, stream, a, (int)m_tiles, n_blocks);
     return check_launch("conv_f16x3");

@@ -18,9 +18,8 @@ int launch_conv_cfg(const ConvArgs& a, hipStream_t stream) {
         return LRPX_EINVAL;
     }
     auto kern = conv_mfma_kernel<HW, KC, MT, NWN, TAPS, EPI>;
-    static std::once_flag attr_once;
-    static hipError_t attr_res = hipSuccess;
-    LRPX_TRY(reserve_lds_once(attr_once, attr_res, kern, C::LDS_BYTES, "conv_mfma"));
+    static LdsOnce attr_once;
+    LRPX_TRY(reserve_lds_once(attr_once, kern, C::LDS_BYTES, "conv_mfma"));
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, ks), dim3(C::NT), C::LDS_BYTES, stream, a, (int)m_tiles, n_blocks);
     return check_launch("conv_mfma");

@@ -317,16 +317,15 @@ static int launch_dense_small_t(const ConvArgs& a, hipStream_t stream) {
     const int m_tiles = (int)ceil_div(rows, 32);
     const int n_blocks = (int)ceil_div(a.n_oc, 128);
     const int lds = 32 * ((a.cin < 1024 ? a.cin : 1024) + 4) * (int)sizeof(float);
-    static const int dense_ks = getenv("LRPX_DENSE_1WAVE") ? 0 : 1;      // (A/B switch)
+    const int dense_ks = switches().dense_1wave ? 0 : 1;      // (A/B switch)
     if constexpr (EPI == EPI_PLAIN) {
         if (dense_ks && a.cin >= 512) {
             // K split over four waves per column block (16-wave workgroups)
             constexpr int RED = 16 * 32 * 33 * (int)sizeof(float);
             const int lds_ks = lds > RED ? lds : RED;
             constexpr int LDS_KS_MAX = 32 * (1024 + 4) * (int)sizeof(float);
-            static std::once_flag once_ks;
-            static hipError_t res_ks = hipSuccess;
-            LRPX_TRY(reserve_lds_once(once_ks, res_ks, dense_ks_kernel<EPI>, LDS_KS_MAX, "dense_ks"));
+            static LdsOnce once_ks;
+            LRPX_TRY(reserve_lds_once(once_ks, dense_ks_kernel<EPI>, LDS_KS_MAX, "dense_ks"));
             hipLaunchKernelGGL(dense_ks_kernel<EPI>, dim3((unsigned)(m_tiles * n_blocks)), dim3(1024), lds_ks, stream, a, m_tiles,
                                n_blocks);
             return check_launch("dense_ks");
@@ -336,9 +335,8 @@ static int launch_dense_small_t(const ConvArgs& a, hipStream_t stream) {
     auto kern = slabs ? dense_slab_kernel<EPI> : dense_small_kernel<EPI>;
     // the largest LDS image either kernel ever asks for (32 rows x (1024 + 4) floats), reserved once per kernel
     constexpr int LDS_MAX = 32 * (1024 + 4) * (int)sizeof(float);
-    static std::once_flag once[2];
-    static hipError_t res[2] = {hipSuccess, hipSuccess};
-    LRPX_TRY(reserve_lds_once(once[slabs], res[slabs], kern, LDS_MAX, "dense_small"));
+    static LdsOnce once[2];
+    LRPX_TRY(reserve_lds_once(once[slabs], kern, LDS_MAX, "dense_small"));
     hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks);
     return check_launch("dense_small");
 }

@@ -1,5 +1,6 @@
 // liblrpx core: error state, weight packing, layout / pooling / elementwise kernels of the LRP path.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -18,6 +19,25 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+const Switches& switches() {
+    static const Switches sw = [] {
+        auto num = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+        auto set = [](const char* name) { return getenv(name) ? 1 : 0; };
+        Switches w;
+        w.wide = num("LRPX_WIDE", 7);
+        w.fwd_ksplit14 = num("LRPX_FWD_KSPLIT", 8);
+        w.fwd_ksplit28 = num("LRPX_FWD_KSPLIT28", 4);
+        w.first_valu = set("LRPX_FIRST_VALU");
+        w.pool28 = num("LRPX_POOL28", 1);
+        w.s21_nhwc = set("LRPX_S21_NHWC");
+        w.guided_poolbwd = set("LRPX_GUIDED_POOLBWD");
+        w.dense_1wave = set("LRPX_DENSE_1WAVE");
+        w.linear_valu = set("LRPX_LINEAR_VALU");
+        return w;
+    }();
+    return sw;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -174,10 +194,19 @@ __global__ void fwd_dual_finish_kernel(const float* __restrict__ part, int nspli
     const int c4n = cout / 2;                                          // float4 per pixel
     const long pix = idx / c4n;
     const int c = (int)(idx - pix * c4n) * 4;                          // column in [0, 2*cout)
+    // Pairwise (binary-tree) order over the splits, the same for every element and every launch: deterministic, and the
+    // last additions meet partial sums of equal length (a running sum over 8 splits would round the nearly complete sum
+    // seven times).  One split after the other: all loads of a thread in flight at once ran 73 instead of 43 us - the
+    // partial tensors lie 12.8 MB apart.
+    f32x4 lvl[5];
     f32x4 v = reinterpret_cast<const f32x4*>(part)[idx];
-    // (one split after the other: all four loads of a thread in flight at once ran 73 instead of 43 us - the partial tensors
-    // lie 12.8 MB apart)
-    for (int s = 1; s < nsplit; ++s) v += reinterpret_cast<const f32x4*>(part + s * split_stride)[idx];
+    for (int s = 0; s < nsplit; ++s) {
+        if (s) v = reinterpret_cast<const f32x4*>(part + s * split_stride)[idx];
+        int k = s, l = 0;
+        while (k & 1) { v = lvl[l] + v; k >>= 1; ++l; }
+        lvl[l] = v;
+    }
+    // (nsplit is a power of two <= 16, host-checked: the total sits in `v`)
     float m = 0.f;
     if (c < cout) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
@@ -894,6 +923,7 @@ int fwd_dual_finish(const float* part, int nsplit, const float* bias, float* act
                     int cout, unsigned* amax, hipStream_t s) {
     const long per_img4 = pix_per_img * (cout / 2), total4 = (long)n_img * per_img4;
     LRPX_REQUIRE(cout % 4 == 0 && per_img4 % 256 == 0, "fwd_dual_finish: %ld float4 items per image are not whole blocks", per_img4);
+    LRPX_REQUIRE(nsplit >= 1 && nsplit <= 16 && (nsplit & (nsplit - 1)) == 0, "fwd_dual_finish: %d splits (a power of two <= 16)", nsplit);
     hipLaunchKernelGGL(fwd_dual_finish_kernel, dim3((unsigned)(total4 / 256)), dim3(256), 0, s, part, nsplit,
                        (long)n_img * pix_per_img * 2 * cout, bias, act, zpos, cout, per_img4, amax);
     return check_launch("fwd_dual_finish");

@@ -1126,7 +1126,7 @@ extern "C" {
 int lrpx_linear_small(const float* x, long ldx, const float* w, const float* bias, float* out, long ldo, int B, int K,
                       int N, int act, void* stream) {
     LRPX_REQUIRE(x && w && out && B > 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0, "linear_small: bad arguments");
-    static const int lin_valu = getenv("LRPX_LINEAR_VALU") ? 1 : 0;     // (A/B switch)
+    const int lin_valu = switches().linear_valu;     // (A/B switch)
     if (K % 16 == 0 && B <= 64 && !lin_valu) {
         const dim3 grid((N + 15) / 16);
         hipStream_t st = (hipStream_t)stream;

@@ -69,7 +69,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
                      "or bias-free PLAIN epilogue");
         LRPX_REQUIRE(d->f16x3 != 2 || d->epi == EPI_REL_MUL || d->epi == EPI_GUIDED || d->epi == EPI_PLAIN,
                      "conv_mfma: the f16+f8 kernels (f16x3 = 2) are built for the REL_MUL, GUIDED and PLAIN epilogues");
-        static const int wide_g = getenv("LRPX_WIDE") ? atoi(getenv("LRPX_WIDE")) : 7;
+        const int wide_g = switches().wide;
         if (d->f16x3 == 2 && d->epi == EPI_GUIDED && d->pool_am) {
             LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
                          "conv_mfma: too many (image, pooled pixel, channel) elements for the pooled-input kernel");
@@ -129,7 +129,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
             LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
                          "conv_mfma: too many (image, pooled pixel, channel) elements for the pooled-input kernel");
             if (f8) {
-                static const int widep = getenv("LRPX_WIDE") ? atoi(getenv("LRPX_WIDE")) : 7;
+                const int widep = switches().wide;
                 if ((widep & 4) && d->hw == 56 && d->n_oc >= 256) return launch_h8_56w_pool(a, s);
                 if ((widep & 4) && d->hw == 28 && d->n_oc >= 256) return launch_h8_28w_pool(a, s);
                 if (d->hw == 224 && d->n_oc <= 64) return launch_h8_224_pool(a, s);
@@ -149,7 +149,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
             // alone is as fast as with two 4-wave workgroups per CU (20.9 ms either way), but the step with batches in
             // flight is 2 % faster (12 410 -> 12 690 maps/s sustained, tools/ab_bench.sh): one double-buffered tile per CU
             // instead of two leaves LDS for the other batches' kernels.  LRPX_WIDE=0 switches back (A/B only).
-            static const int wide = getenv("LRPX_WIDE") ? atoi(getenv("LRPX_WIDE")) : 7;
+            const int wide = switches().wide;
             if ((wide & 1) && d->n_oc >= 256 && d->hw == 56) return launch_h8_56w_rel(a, s);
             if ((wide & 1) && d->n_oc >= 256 && d->hw == 28) return launch_h8_28w_rel(a, s);
             if ((wide & 2) && d->n_oc >= 256 && d->hw == 14) return launch_h8_14w_rel(a, s);
@@ -314,6 +314,8 @@ struct VggTrace {   // offsets in floats; act[l] = input of layer l, act[17] = e
     size_t act[18], zpos[17], xz[17], am[17], famax, total;   // famax: [18][n_img] max of act[l] per image (f16x3 forward)
     // xz[l]: multiplicand of conv l's fused relevance step = act[l] / safe(Z+ of the conv below): directly below
     //        (zpos[l-1]) or under a pool (zpos[l-2] at the window's winner, lrpx_pool_winner);
+    //        xz[1] (n_img x 224*224*64 floats, the largest) doubles as the SCRATCH of the K-split forward layers while
+    //        lrpx_vgg16_forward runs: the xz tensors are only valid after lrpx_vgg16_trace_derive, its last step;
     // am[lp]: winner positions of pool lp (bytes, stored in a float-aligned region)
 };
 static VggTrace vgg_trace_layout(int n_img) {
@@ -502,20 +504,25 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
                 // (the maximum of act[1] is recorded by conv1_1's epilogue below: l == 0)
                 d.f16x3 = 1; d.wpacked = pk + p.fwdh[l];
                 d.in_amax = fam + (size_t)in_l * n_img; d.out0_amax = fam + (size_t)(l + 1) * n_img;
-                // 14x14 layers of a small batch: ceil(n_img * 196 / 224) x 8 workgroups walk 32 K-chunks each on a chip of 256
-                // CUs (207 us per layer at 16 images).  Four K ranges per tile instead (PLAIN epilogue, partial sums into the
-                // - still unused - xz[1] region of the trace), then one pass adds them, applies bias / ReLU and records the
-                // per-image maximum: what the FWD_DUAL epilogue does.  Deterministic (the splits are added in order).
-                static const int fwd_ks = getenv("LRPX_FWD_KSPLIT") ? atoi(getenv("LRPX_FWD_KSPLIT")) : 4;
-                const long tiles14 = ((long)n_img * 196 + 223) / 224 * 8;
-                if (L.hw == 14 && fwd_ks > 1 && tiles14 * fwd_ks <= 1024 && (L.cin / 16) % fwd_ks == 0 &&
-                    (size_t)fwd_ks * 196 * 2 * L.cout <= (size_t)224 * 224 * 64) {
+                // The deep layers run K-SPLIT: blockIdx.y takes one of `ks` contiguous K ranges per tile through the PLAIN
+                // epilogue (partial sums behind each other in the xz[1] region of the trace - SCRATCH during the forward pass:
+                // lrpx_vgg16_trace_derive below rewrites it after the last layer), then one pass adds the splits pairwise in a
+                // fixed order, applies bias / ReLU and records the per-image maximum: what the FWD_DUAL epilogue does.
+                //  * accuracy: one accumulator then carries 36 (14x14: K = 4608 in 8 ranges) or 72 (28x28: 4 ranges) k-steps
+                //    instead of 288 - the rounding of a sequential fp32 chain grows with its length, and the features moved
+                //    from 3e-6 to <2e-6 of their maximum against an fp64 forward (tests/test_gpu_t20.py);
+                //  * the grids fill the chip: 16 images are 112 (14x14) / 448 (28x28) workgroups of 32 K-chunks each;
+                //  * the decision depends on the LAYER only, never on the batch size: an image gets the same activations,
+                //    pool winners and maps whatever batch it sits in.
+                const int fwd_ks = L.hw == 14 ? switches().fwd_ksplit14 : (L.hw == 28 ? switches().fwd_ksplit28 : 1);
+                if (fwd_ks > 1 && (fwd_ks & (fwd_ks - 1)) == 0 && fwd_ks <= 16 && (L.cin / 16) % fwd_ks == 0 &&
+                    (size_t)fwd_ks * L.hw * L.hw * 2 * L.cout <= (size_t)224 * 224 * 64) {
                     float* part = tr + t.xz[1];
                     d.epi = EPI_PLAIN; d.bias = nullptr; d.oc_split = 2 * L.cout;
                     d.out0 = part; d.out1 = nullptr; d.out0_amax = nullptr;
                     LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream, fwd_ks));
-                    LRPX_TRY(fwd_dual_finish(part, fwd_ks, pk + p.bias[l], tr + t.act[l + 1], tr + t.zpos[l], n_img, 196, L.cout,
-                                             fam + (size_t)(l + 1) * n_img, (hipStream_t)stream));
+                    LRPX_TRY(fwd_dual_finish(part, fwd_ks, pk + p.bias[l], tr + t.act[l + 1], tr + t.zpos[l], n_img,
+                                             (long)L.hw * L.hw, L.cout, fam + (size_t)(l + 1) * n_img, (hipStream_t)stream));
                     continue;
                 }
             } else if (use_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
@@ -626,7 +633,7 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
         if (l == 0) {
             // 3 output channels (first_layer.hip): 16x16x32 MFMAs on the split halves of S in the split-product modes (S
             // comes with its per-map maximum, in 32-channel chunks), the direct fp32 VALU conv otherwise
-            static const int fl_mfma = getenv("LRPX_FIRST_VALU") ? 0 : 1;
+            const int fl_mfma = switches().first_valu ? 0 : 1;
             if (h3 && fl_mfma)
                 LRPX_TRY(first_layer_relevance_mfma(S[cur], pk + p.first16, tr + t.act[0], map2img, amax, out_nchw, n_maps,
                                                     0, 1, (hipStream_t)stream));
@@ -649,15 +656,11 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
             // conv4_3 in mode 3 used to unpool S with a scatter kernel (0.5 GB written) and run the plain 28x28 kernel: the
             // map-straddling pooled-input kernel spilled 40 VGPRs with the fp8 operands.  With the SWAR commit it fits (8-wave
             // version: 3 spills, as fast as the plain kernel), so the scatter is gone; LRPX_POOL28=0 brings it back (A/B)
-            static const int pool28 = getenv("LRPX_POOL28") ? atoi(getenv("LRPX_POOL28")) : 1;
-            if (!pool28)
-#ifndef LRPX_F8_POOL28
-            if (mode == 3 && pooled_in && L.hw == 28) {
+            if (!switches().pool28 && mode == 3 && pooled_in && L.hw == 28) {
                 LRPX_TRY(lrpx_unpool_winner(S[cur], d.pool_am, map2img, S[cur ^ 1], n_maps, L.hw / 2, L.hw / 2, L.cout, stream));
                 cur ^= 1;
                 d.in = S[cur]; d.pool_am = nullptr;
             }
-#endif
         }
         else if (use_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
         if (kVgg[l - 1].conv) {
@@ -665,12 +668,12 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
             d.out1 = S[cur ^ 1];
             if (h3) { d.x = tr + t.xz[l]; d.out1_amax = amax + (size_t)(l - 1) * n_maps; }   // x / safe(Z+) precomputed
             // the first-layer kernel walks S in channel chunks (MFMA version: 32 = whole 128-byte lines per pixel; VALU: 16)
-            static const int fl_chunk = getenv("LRPX_FIRST_VALU") ? 16 : 32;
+            const int fl_chunk = switches().first_valu ? 16 : 32;
             if (h3 && l == 1) d.out_chunk = fl_chunk;
             else { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
             // conv2_2 -> conv2_1: S in 16-channel chunks, the K-chunk of the consumer (64-byte slices of 512-byte NHWC pixels
             // drag every 128-byte line through the fabric twice: FETCH 3.1x the tensor; chunked: conv2_1 1.44 -> 1.37 ms)
-            static const int s21_chunk = getenv("LRPX_S21_NHWC") ? 0 : 16;
+            const int s21_chunk = switches().s21_nhwc ? 0 : 16;
             if (h3 && l == 4 && s21_chunk) { d.out_chunk = s21_chunk; cur_chunked = 1; }
             LRPX_TIMED_DISPATCH(l, &d);
         } else {
@@ -749,7 +752,7 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
         const VggLayer& L = kVgg[l];
         if (!L.conv) continue;
         if (l == 0) {
-            static const int fl_mfma = getenv("LRPX_FIRST_VALU") ? 0 : 1;
+            const int fl_mfma = switches().first_valu ? 0 : 1;
             if (h3 && fl_mfma)
                 LRPX_TRY(first_layer_relevance_mfma(G[cur], pk + p.first16p, tr + t.act[0], map2img, gam, out_nchw, n_maps, 1, 0, st));
             else
@@ -767,7 +770,7 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
         }
         // mode 3: a conv under a pool receives the gradient at the pool's OUTPUT resolution and routes it to the windows'
         // arg-max while staging (the winner bytes of the trace, as the relevance chain): no pool-backward kernel, no 4x tensor
-        static const int gpool = getenv("LRPX_GUIDED_POOLBWD") ? 0 : 1;
+        const int gpool = switches().guided_poolbwd ? 0 : 1;
         const bool lowres_in = gpool && mode == 3 && l + 1 < kNL && !kVgg[l + 1].conv && l + 2 < kNL;
         if (lowres_in) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
         if (kVgg[l - 1].conv) {

@@ -631,6 +631,147 @@ def gen_t20(out, weights, T=20, seed=0, n_img=2):
     print("t20.npz written:", sum(v.nbytes for v in g.values() if hasattr(v, "nbytes")) / 1e6, "MB")
 
 
+def gen_t20_f64(out, weights, T=20, seed=0, n_img=2):
+    """The rows of t20.npz once more with the reference's classes in DOUBLE precision (weights, image, every tensor the
+    explainers allocate: `torch.set_default_dtype(float64)` for the call): the fp64 value of the reference's own formula,
+    forward included.  |ref32 - fp64| of a row is the reference's own rounding noise there; tests/test_gpu_t20.py bounds
+    |GPU - fp64| by 3 x that (floor 1e-5) instead of a flat tolerance.  Stored: r_words (float64) and
+    r_feat statistics [sum, absmax, L2, L1] per (model, image, head, word), and the fp64 VGG16 features of both images
+    (every 4th channel, as float32) so the GPU forward can be placed against fp64 on the GPU box."""
+    import models.gridTDmodel as gtd
+    import models.aoamodel as aoa
+    g32 = np.load(os.path.join(out, "t20.npz"))
+    g = dict(seed=np.int64(seed), T=np.int64(T), n_img=np.int64(n_img), img_seed=np.int64(50))
+    imgs = weights.make_images(50, n_img).astype(np.float64)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        V = 9586
+        sd = weights.make_gridtd_state(seed=seed, vocab_size=V)
+        model = gtd.GridTDModel(512, 512, V, 'vgg16')
+        model.load_state_dict(to_torch_sd(sd))
+        model = model.double()
+        wm = weights.make_word_map(V)
+        caps = g32["grid_caption"]
+        for b in range(n_img):
+            with tempfile.TemporaryDirectory() as tmp:
+                ex = gtd.ExplainGridTDAttention(make_args(tmp), wm, model=model)
+                _patch_explainer(ex, imgs[b:b + 1], caps[b])
+                ex.get_hidden_parameters("synthetic.jpg")
+                assert ex.image_features.dtype == torch.float64
+                g[f"features64_{b}"] = ex.image_features.detach()[0, ::4].reshape(128, 196).float().numpy()
+                g[f"features64_absmax_{b}"] = np.float64(ex.image_features.abs().max().item())
+                for t in range(T):
+                    with torch.no_grad():
+                        rf, rw = ex.explain_caption_wordt(t)
+                    assert rw.dtype == torch.float64
+                    g[f"grid{b}_r_feat_stats64_{t}"] = stats4(rf.detach()[0])
+                    g[f"grid{b}_r_words64_{t}"] = rw.detach().numpy()
+            print("t20_f64 gridTD image", b, "done", flush=True)
+        V = 11027
+        sd = weights.make_aoa_state(seed=seed, vocab_size=V)
+        model = aoa.AOAModel(512, 512, 8, V, 'vgg16')
+        model.load_state_dict(to_torch_sd(sd))
+        model = model.double()
+        wm = weights.make_word_map(V)
+        caps = g32["aoa_caption"]
+        for b in range(n_img):
+            with tempfile.TemporaryDirectory() as tmp:
+                ex = aoa.ExplainAOAAttention(make_args(tmp), wm, model=model)
+                _patch_explainer(ex, imgs[b:b + 1], caps[b])
+                ex.get_hidden_parameters("synthetic.jpg")
+                for hd in ((0,) if b == 0 else (0, 3)):
+                    for t in range(T):
+                        with torch.no_grad():
+                            rf, rw = ex.explain_caption_wordt(t, hd)
+                        g[f"aoa{b}_h{hd}_r_feat_stats64_{t}"] = stats4(rf.detach()[0])
+                        g[f"aoa{b}_h{hd}_r_words64_{t}"] = rw.detach().numpy()
+            print("t20_f64 AoA image", b, "done", flush=True)
+        sd = weights.make_aoa_state(seed=seed, vocab_size=V, feat_dim=2048, with_encoder=False)
+        feats_np = weights.make_bu_features(50, n_img).astype(np.float64)
+        caps = g32["bu_caption"]
+        for b in range(n_img):
+            class StubEnc(nn.Module):
+                feat_dim = 2048
+
+                def forward(self, img, _f=feats_np[b]):
+                    f = torch.from_numpy(_f.T.copy()).reshape(1, 2048, 6, 6)
+                    return f, f.mean(dim=(2, 3)).squeeze()
+            model = aoa.AOAModel(512, 512, 8, V, 'vgg16')
+            model.img_encoder = StubEnc()
+            model.encoder_raw_dim = 2048
+            model.img_projector = nn.Conv2d(2048, 512, 1)
+            model.load_state_dict(to_torch_sd(sd))
+            model = model.double()
+            with tempfile.TemporaryDirectory() as tmp:
+                ex = aoa.ExplainAOAAttention(make_args(tmp), wm, model=model)
+                _patch_explainer(ex, np.zeros((1, 3, 8, 8), np.float64), caps[b])
+                ex.get_hidden_parameters("synthetic")
+                for t in range(T):
+                    with torch.no_grad():
+                        rf, rw = ex.explain_caption_wordt(t, 0)
+                    g[f"bu{b}_r_feat_stats64_{t}"] = stats4(rf.detach().reshape(2048, 36).t())
+                    g[f"bu{b}_r_words64_{t}"] = rw.detach().numpy()
+            print("t20_f64 BU image", b, "done", flush=True)
+    finally:
+        torch.set_default_dtype(old)
+    np.savez(os.path.join(out, "t20_f64.npz"), **g)
+    print("t20_f64.npz written:", sum(v.nbytes for v in g.values() if hasattr(v, "nbytes")) / 1e6, "MB")
+
+def gen_t20_guided(out, weights, T=20, seed=0, n_img=2):
+    """Guided-Backprop decoder BPTT at the headline caption length (BASELINE config 4 is LRP + Guided-Backprop at T = 20):
+    `ExplainiGridTDGuidedGradient.explain_caption_wordt` (models/gridTDmodel.py:1588-1675) for every word of the two
+    images / captions of t20.npz.  Stored per (image, word): statistics of d_feat [sum, absmax, L2, L1], the channel
+    subsample (t % 32)::32, r_words; two full d_feat rows; for image 0 the pixel maps of the whole `explain_caption`
+    (every 8th pixel + statistics)."""
+    import models.gridTDmodel as gtd
+    g32 = np.load(os.path.join(out, "t20.npz"))
+    V = int(g32["grid_V"])
+    g = dict(seed=np.int64(seed), T=np.int64(T), n_img=np.int64(n_img), img_seed=np.int64(50), V=np.int64(V))
+    imgs = weights.make_images(50, n_img)
+    caps = g32["grid_caption"]
+    g["caption"] = caps
+    sd = weights.make_gridtd_state(seed=seed, vocab_size=V)
+    wm = weights.make_word_map(V)
+    for b in range(n_img):
+        with tempfile.TemporaryDirectory() as tmp:
+            real_load = torch.load
+            torch.load = lambda *a, **k: {"state_dict": to_torch_sd(sd)}
+            try:
+                ex = gtd.ExplainiGridTDGuidedGradient(make_args(tmp), wm)
+            finally:
+                torch.load = real_load
+            _patch_explainer(ex, imgs[b:b + 1], caps[b])
+            feats, rws = [], []
+            if b == 0:
+                orig = ex.explain_caption_wordt
+
+                def wrapped(t, _orig=orig, _feats=feats):
+                    rf, rw = _orig(t)
+                    _feats.append(rf.clone())
+                    return rf, rw
+                ex.explain_caption_wordt = wrapped
+                maps, rws = ex.explain_caption("synthetic.jpg")
+                for t in range(T):
+                    g[f"gb0_map_stats_{t}"] = stats4(maps[t])
+                    g[f"gb0_map_sub8_{t}"] = maps[t][..., ::8, ::8].contiguous().numpy()
+            else:
+                ex.get_hidden_parameters("synthetic.jpg")
+                ex.image_feature_proj = ex.image_feature_proj.transpose(1, 2)       # as explain_caption does (:1528)
+                for t in range(T):
+                    with torch.no_grad():
+                        rf, rw = ex.explain_caption_wordt(t)
+                    feats.append(rf.clone()); rws.append(rw.clone())
+        for t in range(T):
+            rf = feats[t].detach()[0]                                   # (512,14,14)
+            g[f"gb{b}_d_feat_stats_{t}"] = stats4(rf)
+            g[f"gb{b}_d_feat_sub_{t}"] = rf[(t % 32)::32].contiguous().numpy()
+            g[f"gb{b}_r_words_{t}"] = rws[t].detach().numpy()
+        g[f"gb{b}_d_feat_full_{T - 1 - 9 * b}"] = feats[T - 1 - 9 * b].detach()[0].numpy()
+        print("t20_guided image", b, "done", flush=True)
+    np.savez(os.path.join(out, "t20_guided.npz"), **g)
+    print("t20_guided.npz written:", sum(v.nbytes for v in g.values() if hasattr(v, "nbytes")) / 1e6, "MB")
+
 
 def gen_m4(out):
     """The rule classes the VGG16 path never reaches (ResNet encoders): Linear epsilon rule with the
@@ -864,7 +1005,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,m4,forwardlrp,guided_gradcam,beam")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,t20_f64,t20_guided,m4,forwardlrp,guided_gradcam,beam")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -884,6 +1025,10 @@ def main():
         gen_greedy(HERE, weights)
     if "t20" in todo:
         gen_t20(HERE, weights)
+    if "t20_f64" in todo:
+        gen_t20_f64(HERE, weights)
+    if "t20_guided" in todo:
+        gen_t20_guided(HERE, weights)
     if "m4" in todo:
         gen_m4(HERE)
     if "forwardlrp" in todo:

@@ -587,15 +587,21 @@ def test_full_size_chain_hostile_relevance_all_modes(ops, gridtd_case):
     hostile relevance at the encoder output: signed heavy-tailed randn*exp(4 randn), per-map scales 1e-6..1e6,
     sparse maps dominated by one entry, and the reference's own signed decoder relevance.  Contract (BASELINE
     north_star): max|dR| / max|R| < 1e-4 per map.  Prints the worst map of every family and mode; the fp32-MFMA
-    column is the floor two fp32-grade evaluations differ by on the same data."""
+    column is the floor two fp32-grade evaluations differ by on the same data.
+    The launch also meets the CPU ORACLE, not only another HIP mode: the trace of all 16 images is the
+    oracle's own forward (injected), and the worst map of every family in the default mode 3 - plus that family's first map -
+    is recomputed by `O.vgg_lrp` (LRPtools/lrp_modules.py:124-195 restated) on that image's activations: < 1e-4 of max|R|
+    in every mode."""
     from lrp_amd import _lib, weights
     lib = _lib.load()
     g, _, _ = gridtd_case
     sd = weights.make_gridtd_state(seed=5, vocab_size=32)
     vgg = _vgg(ops, sd)
     n_img, n_maps = 16, 320
-    img = torch.from_numpy(weights.make_images(7, n_img)).cuda()
+    img_cpu = torch.from_numpy(weights.make_images(7, n_img))
+    img = img_cpu.cuda()
     feats = vgg.forward(img)
+    _inject_oracle_trace(vgg, sd, img_cpu)        # identical activations / pool winners for the HIP chain and the oracle
     m2i = (torch.arange(n_maps, device="cuda") * n_img // n_maps).to(torch.int32)
     r_feat, names = _hostile_targets(feats, m2i, n_maps, g)
     out = {}
@@ -624,6 +630,22 @@ def test_full_size_chain_hostile_relevance_all_modes(ops, gridtd_case):
             "mode %d: max %.2e mean %.2e (map %d)" % ((m,) + worst[(m, fam)]) for m in (0, 2, 3)))
     for (mode, fam), (mx, _, k) in worst.items():
         assert mx < TOL, (mode, fam, mx, k)
+    # ---- the CPU oracle on maps of this very launch
+    from oracle import lrp_oracle as O
+    sdt = O.state_to_torch(sd)
+    _, _, saved = O.vgg_forward(sdt, img_cpu)
+    picks = []
+    for fam in ("heavy", "scaled", "sparse", "reference"):
+        picks += [worst[(3, fam)][2], names.index(fam)]
+    for k in sorted(set(picks)):
+        b = int(m2i[k])
+        want = O.vgg_lrp(sdt, [x[b:b + 1] for x in saved], from_nhwc(r_feat[k:k + 1].cpu(), 512, 14, 14)).double()
+        sc = want.abs().max()
+        errs = {mode: ((out[mode][k:k + 1].cpu().double() - want).abs().max() / sc).item() for mode in (3, 2, 1, 0)}
+        print("hostile map %3d (%-9s, image %2d) vs the CPU oracle: " % (k, names[k], b) +
+              "  ".join("mode %d %.2e" % (m, e) for m, e in errs.items()))
+        for m, e in errs.items():
+            assert e < TOL, ("oracle", k, names[k], m, e)
 
 
 def test_rel_mul_rejects_two_outputs_and_never_writes_past_the_last_map(ops):
