@@ -325,6 +325,21 @@ def run_config(a, dist, rank, world):
     if a.gather and world > 1 and rank == 0:
         gathered = [torch.empty(B * T, 3, 224, 224, device="cuda") for _ in range(world)]
 
+    gloo = dist is not None and dist.get_backend() == "gloo"
+    if a.gather and gloo:          # rehearsal backend: gloo gathers host tensors only, so the maps are staged through pinned memory
+        state["host_maps"] = torch.empty(B * T, 3, 224, 224).pin_memory()
+        if rank == 0:
+            gathered = [torch.empty(B * T, 3, 224, 224) for _ in range(world)]
+
+    def gather_maps(m):
+        """the terminal collective of north_star: every rank's maps to rank 0 (RCCL over xGMI; device tensors end to end)"""
+        if gloo:
+            state["host_maps"].copy_(m.view(B * T, 3, 224, 224), non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            dist.gather(state["host_maps"], gathered, dst=0)
+        else:
+            dist.gather(m.view(B * T, 3, 224, 224), gathered, dst=0)
+
     step_no = [0]
 
     def step(end_events=None):
@@ -337,7 +352,7 @@ def run_config(a, dist, rank, world):
                 out = engines[k].explain_batch_graph(images, caps, accumulate=True, predictions=True) if use_graph \
                     else one_step(engines[k], k)
                 if a.gather and world > 1 and has_vgg:
-                    dist.gather(out[0], gathered, dst=0)
+                    gather_maps(out[0])
                 if end_events is not None:
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record()
@@ -348,7 +363,7 @@ def run_config(a, dist, rank, world):
         else:
             out = one_step(eng, 0)
         if a.gather and world > 1 and has_vgg:
-            dist.gather(out[0].view(B * T, 3, 224, 224), gathered, dst=0)
+            gather_maps(out[0].view(B * T, 3, 224, 224))
         if end_events is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()

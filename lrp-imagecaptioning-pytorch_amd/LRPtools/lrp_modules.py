@@ -6,8 +6,8 @@ lrp_params)` returns a tuple with the arity of `relevance_input` (:157-170).  `m
 layer input, as the reference's `save_input_hook` leaves it (lrp_wrapper.py:24-25).  Tensors are NCHW on the
 device, as in the reference; layouts are converted at this boundary.
 
-Conv2d 3x3/pad 1, MaxPool2d(2,2) and ReLU are the layers VGG16 exercises (square maps of 224/112/56/28/14 pixels;
-other shapes raise ValueError).  Linear / BatchNorm2d / BatchNorm1d / Dropout / Add / Flatten (only
+Conv2d 3x3/pad 1, MaxPool2d(2,2) and ReLU are the layers VGG16 exercises (kernels for square maps of 224/112/56/28/14
+pixels; any other H x W <= 224 runs zero-embedded in the next larger of those; other kernel sizes / strides raise ValueError).  Linear / BatchNorm2d / BatchNorm1d / Dropout / Add / Flatten (only
 reached with the reference's ResNet encoders) are HBM-bound streaming kernels (csrc/lrpx_rules.hip), any shape."""
 import torch
 import torch.nn as nn
@@ -47,10 +47,21 @@ class Conv2d:
         r_out = relevance_output[0].detach()
         _require(isinstance(module, nn.Conv2d) and module.kernel_size == (3, 3) and module.padding == (1, 1)
                  and module.stride == (1, 1) and module.groups == 1, "lrpx Conv2d rule: 3x3 / pad 1 / stride 1 only")
-        n, cin, h, w = x.shape
+        n, cin, h0, w0 = x.shape
         cout = module.out_channels
-        _require(h == w and h in _SIZES, f"lrpx Conv2d rule: square maps of {_SIZES} pixels only, got {h}x{w}")
-        _require(r_out.shape == (n, cout, h, w), "relevance_output shape mismatch")
+        _require(r_out.shape == (n, cout, h0, w0), "relevance_output shape mismatch")
+        _require(max(h0, w0) <= _SIZES[0], f"lrpx Conv2d rule: maps of at most {_SIZES[0]}x{_SIZES[0]} pixels, got {h0}x{w0}")
+        # The kernels are built for the five square map sizes of VGG16.  Any other H x W runs on the next larger one with
+        # the map in the top-left corner of a zero canvas: a zero-padded 3x3 conv sees the same zeros beyond the map's
+        # edge as beyond the canvas', R_out is zero outside the map, so S = R_out / Z is too, and the rows / columns
+        # [0,H) x [0,W) of the result are the rule's output exactly (tests: the 16x16 / 8x8 fixture net of layers.npz).
+        h = w = min(sz for sz in _SIZES if sz >= max(h0, w0))
+        if (h0, w0) != (h, w):
+            xe = torch.zeros(n, cin, h, w, device=x.device, dtype=x.dtype)
+            xe[:, :, :h0, :w0] = x
+            re = torch.zeros(n, cout, h, w, device=r_out.device, dtype=r_out.dtype)
+            re[:, :, :h0, :w0] = r_out
+            x, r_out = xe, re
         lib = _lib.load()
         st = stream_ptr()
         dev = x.device
@@ -93,6 +104,8 @@ class Conv2d:
         r_half = torch.empty(n, h * w, half, device=dev)
         check(lib.lrpx_fold_halves(ptr(r_split), ptr(r_half), n * h * w, half, st))
         R = ops.nhwc_to_nchw(r_half, cin, h, w)
+        if (h0, w0) != (h, w):
+            R = R[:, :, :h0, :w0].contiguous()
         ops.check_relevance(R)                                      # lrp_modules.py:154-155
         if relevance_input is not None and len(relevance_input) == 3:
             return R, relevance_input[1], relevance_input[2]

@@ -1,9 +1,15 @@
 """Mirror of the reference's LRPtools/lrp_wrapper.py: `add_lrp(model)` + `model.compute_lrp(sample, target=...)`.
 
 The reference installs a forward hook and a legacy backward hook on every leaf and lets autograd drive the
-relevance pass (lrp_wrapper.py:37-87).  Here `add_lrp` validates the same leaf -> rule table, packs the weights
-once and attaches a `compute_lrp` with the same signature and return value; the pass itself is the fused HIP
-chain `lrpx_vgg16_forward` + `lrpx_vgg16_relevance` (no autograd, no per-word forward with dead wgrad work).
+relevance pass (lrp_wrapper.py:37-87).  Here `add_lrp` validates the same leaf -> rule table and attaches a
+`compute_lrp` with the same signature and return value.  Two drivers behind it:
+  * the VGG16 encoder (features[0:-1], what every explainer of the reference passes): weights packed once, the pass
+    is the fused HIP chain `lrpx_vgg16_forward` + `lrpx_vgg16_relevance` (no autograd, no per-word forward with dead
+    wgrad work);
+  * ANY other leaf sequence (the reference's ResNet-style stacks with BatchNorm / Add / Flatten / Linear, small test
+    nets): the model's own forward runs once under forward hooks that keep `module.input` (lrp_wrapper.py:24-25) and
+    record the call order; the relevance then walks the recorded calls in reverse through this repo's rule classes
+    (lrp_modules.py, HIP kernels), summing where a tensor feeds several modules - what autograd does for the reference.
 Improvement over the reference: `add_lrp` is idempotent (the reference stacks hooks on every call, which
 multiplies its cost without changing the result)."""
 import torch
@@ -55,8 +61,7 @@ def add_lrp(model):
     for m in leaves:
         lrp_modules.get_lrp_module(m)                     # ValueError("Layer type ... not known.")
     if not _match_vgg16(leaves):
-        raise ValueError("lrpx add_lrp: only the VGG16 encoder (features[0:-1]) is built as a fused chain; "
-                         "use the per-layer rules in lrp_modules for other stacks")
+        return _add_lrp_generic(model, leaves)
     convs = [m for m in leaves if isinstance(m, nn.Conv2d)]
     dev = convs[0].weight.device
     if dev.type != "cuda":
@@ -76,13 +81,16 @@ def compute_lrp(model, sample, target=None, return_output=False, rectify_logits=
     lib = _lib.load()
     if sample.requires_grad is False:
         sample.requires_grad = True
-    x = sample.detach().to(torch.float32).contiguous()
-    feats = ctx.forward(x)                                       # (N,196,512) NHWC
-    n = x.shape[0]
     if target is None:
         raise ValueError("compute_lrp needs `target` (the reference passes the anchor to backward(), :80)")
-    t_nhwc = ops.nchw_to_nhwc(target.detach().to(torch.float32))
-    r = ctx.relevance(t_nhwc, None)
+    if ctx is None:                                              # any leaf sequence: recorded forward + reverse walk
+        r, logits_g = _compute_lrp_generic(model, sample, target, return_output)
+        feats = None
+    else:
+        x = sample.detach().to(torch.float32).contiguous()
+        feats = ctx.forward(x)                                   # (N,196,512) NHWC
+        t_nhwc = ops.nchw_to_nhwc(target.detach().to(torch.float32))
+        r = ctx.relevance(t_nhwc, None)
     if sample.grad is None:
         sample.grad = r
     else:
@@ -90,6 +98,97 @@ def compute_lrp(model, sample, target=None, return_output=False, rectify_logits=
     ops.check_relevance(sample.grad, finite=True, nonzero=True)  # `assert sample.grad.sum()!=0` (:81)
     output = sample.grad.clone().detach()
     if return_output:
-        logits = ops.nhwc_to_nchw(feats.contiguous(), 512, 14, 14)
+        logits = logits_g if feats is None else ops.nhwc_to_nchw(feats.contiguous(), 512, 14, 14)
         return output, logits
     return output
+
+
+# ------------------------------------------------------------------------------------------------
+# generic driver: any leaf sequence the rule table knows (lrp_wrapper.py:37-59 hooks every leaf of any model)
+# ------------------------------------------------------------------------------------------------
+def _rule_name(module):
+    """lrp_wrapper.py:42-56: Linear / BatchNorm -> 'epsilon', ReLU -> 'identity', everything else 'alpha_beta'"""
+    if type(module) in (nn.Linear, nn.BatchNorm2d, nn.BatchNorm1d):
+        return 'epsilon'
+    if type(module) == nn.ReLU:
+        return 'identity'
+    return 'alpha_beta'
+
+
+def _key(t):
+    """Tensors are matched between a producer's output and a consumer's input by their memory: an in-place ReLU returns
+    its input, `x.view(...)` between two modules shares the storage - both keep the relevance flowing, as autograd's view /
+    in-place tracking does for the reference."""
+    return (t.data_ptr(), t.numel())
+
+
+def _add_lrp_generic(model, leaves):
+    for t in list(model.parameters()) + list(model.buffers()):
+        if t.device.type != "cuda":
+            raise _lib.LrpxError("add_lrp: the model must live on the GPU (no CPU path)")
+    old = model.__dict__.pop("_lrpx_hooks", None)
+    for h in old or ():
+        h.remove()                                        # idempotent: never two hooks per leaf
+    tape = []
+
+    def save_input_hook(module, input_, output):          # lrp_wrapper.py:24-25 (+ the call order)
+        module.input = input_
+        tape.append((module, input_, output))
+    model._lrpx_hooks = [m.register_forward_hook(save_input_hook) for m in leaves]
+    model._lrpx_tape = tape
+    model._lrpx_ctx = None
+    model.compute_lrp = lambda sample, **kwargs: compute_lrp(model, sample, **kwargs)
+
+
+def _compute_lrp_generic(model, sample, target, return_output):
+    lib = _lib.load()
+    if sample.device.type != "cuda":
+        raise _lib.LrpxError("compute_lrp: the sample must live on the GPU (no CPU path)")
+    preset = SequentialPresetA()
+    tape = model._lrpx_tape
+    del tape[:]
+    with torch.no_grad():
+        logits = model(sample.detach())                   # the model's own forward; the hooks record it
+    if not isinstance(logits, torch.Tensor):
+        raise ValueError("compute_lrp: the model must return one tensor (the anchor of the relevance pass, :69-80)")
+    target = target.detach().to(device=logits.device, dtype=torch.float32)
+    if target.shape != logits.shape:
+        raise RuntimeError("Mismatch in shape: grad_output[0] has a shape of {} and output[0] has a shape of {}."
+                           .format(target.shape, logits.shape))                      # what backward(anchor) raises
+    rel = {_key(logits): target.contiguous().clone()}
+    r_sample = None
+    for module, inputs, output in reversed(tape):
+        if not isinstance(output, torch.Tensor):
+            raise ValueError("compute_lrp: leaf {} returned {}, not a tensor".format(type(module).__name__, type(output)))
+        r_out = rel.pop(_key(output), None)
+        if r_out is None:
+            continue                                      # a leaf whose output does not reach the anchor
+        r_out = r_out.view(output.shape)
+        rule = lrp_modules.get_lrp_module(module)
+        # `relevance_input` only fixes the arity of the rule's result (lrp_modules.py:157-170): one entry per module input,
+        # the incoming relevance first (the identity gradient of Dropout in eval mode, :248-254)
+        r_in = rule.propagate_relevance(module, (r_out,) + (None,) * 2, (r_out,), _rule_name(module), lrp_params=preset.lrp_params)
+        tensors_in = [t for t in inputs if isinstance(t, torch.Tensor)]
+        if isinstance(rule, lrp_modules.Linear):          # the reference's Linear returns (grad_bias slot, R, grad_weight slot)
+            r_in = (r_in[1],)
+        for t, r in zip(tensors_in, r_in[:len(tensors_in)]):
+            r = r.detach().to(torch.float32).reshape(t.shape).contiguous()
+            if _key(t) == _key(sample) or t is sample:
+                if r_sample is None:
+                    r_sample = r.clone()
+                else:
+                    check(lib.lrpx_accumulate(ptr(r_sample), ptr(r), r.numel(), stream_ptr()))
+                continue
+            k = _key(t)
+            if k in rel:                                  # the tensor feeds several modules: relevance adds up
+                acc = rel[k]
+                check(lib.lrpx_accumulate(ptr(acc), ptr(r), r.numel(), stream_ptr()))
+            else:
+                rel[k] = r.clone() if r.data_ptr() == r_out.data_ptr() else r
+    if rel:
+        raise ValueError("compute_lrp: {} tensor(s) between the leaf modules were produced by functional code (x + y, "
+                         "torch.flatten, F.relu ...): the rules see leaf modules only - use explicit Add / Flatten modules as "
+                         "the reference's models/resnet.py:25-38 does".format(len(rel)))
+    if r_sample is None:
+        raise ValueError("compute_lrp: no recorded leaf consumes the sample tensor")
+    return r_sample, logits

@@ -120,6 +120,9 @@ int launch_h3_112_pool(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_pool(const ConvArgs& a, hipStream_t s);
 int launch_h3_28_pool(const ConvArgs& a, hipStream_t s);
 
+// dense relevance GEMMs with many rows on the fp16 matrix cores (dense_f16x3.hip)
+int launch_dense_f16x3(const ConvArgs& a, hipStream_t s);
+
 // few-row dense GEMMs (dense_small.hip)
 bool dense_small_fits(const ConvArgs& a);
 int launch_dense_small(const ConvArgs& a, hipStream_t s);

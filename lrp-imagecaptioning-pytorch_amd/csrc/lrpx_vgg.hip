@@ -30,6 +30,14 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
     a.out_chunk = d->epi == EPI_REL_MUL ? d->out_chunk : 0;
     a.tile_group = (d->f16x3 && d->tile_group > 1 && d->n_maps % d->tile_group == 0) ? d->tile_group : 0;
     a.ksplit = 1;
+    // many rows (the (word, pixel) rules of the decoders): split products on the fp16 matrix cores (dense_f16x3.hip);
+    // `wpacked` is then an lrpx_pack_weights_f16x2 blob (taps = 1) and `in_amax` holds max|in| per map
+    if (d->taps == 1 && d->f16x3) {
+        LRPX_REQUIRE(d->f16x3 == 1 && d->epi == EPI_REL && d->x && d->in_amax && d->pix_per_map > 0,
+                     "conv_mfma: the dense f16x3 GEMM is built for the REL epilogue (needs x, in_amax, pix_per_map)");
+        LRPX_REQUIRE(!d->out1 || d->zdiv || d->stab == STAB_NONE, "conv_mfma: REL out1 needs zdiv");
+        return launch_dense_f16x3(a, s);
+    }
     // few rows (the decoder's lock-step rules): 32-row tiles, whole K per workgroup (dense_small.hip)
     if (d->taps == 1 && !d->bf16x6 && !d->f16x3 && dense_small_fits(a)) {
         LRPX_REQUIRE(d->epi != EPI_REL || d->x, "conv_mfma: REL needs x");

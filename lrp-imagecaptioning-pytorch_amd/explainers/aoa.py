@@ -54,6 +54,12 @@ class AOAEngine:
         self.p_lin_rel = ops.pack_weights(sd["decoder_aoa_linear.weight"], H, H, 1, PACK_DENSE_T, kc)
         self.p_v_rel = ops.pack_weights(sd["decoder_v_proj.weight"], H, H, 1, PACK_DENSE_T, kc)
         self.p_proj_rel = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE_T, kc)
+        # the v_proj / projector rules run over every (word, pixel) row: split products on the fp16 matrix cores
+        # (csrc/dense_f16x3.hip)
+        self.p_v_rel_h = self.p_proj_rel_h = None
+        if H % 64 == 0:
+            self.p_v_rel_h = ops.pack_weights_f16x2(sd["decoder_v_proj.weight"], H, H, _lib.PACK_BWD_PLAIN, taps=1)
+            self.p_proj_rel_h = ops.pack_weights_f16x2(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1)
         # gradient explainers (:1435-1499): contraction over the 4H gate rows / over the outputs of the two aoa linears
         self.p_gates_grad = ops.pack_weights(self.Wcat, 4 * H, E + 2 * H, 1, PACK_DENSE_T, kc)
         self.p_gate_grad = ops.pack_weights(sd["decoder_aoa_linear_gate.weight"], H, H, 1, PACK_DENSE_T, kc)
@@ -364,11 +370,19 @@ class AOAEngine:
         U = e(rows, H)
         check(lib.lrpx_rel_avg_u(ptr(rs["r_glob"]), ptr(enc["glob"]), ptr(U), rows, T, H, P, st))
         a_proj = e(rows, P, H)
-        ops.conv_mfma(a_val, self.p_v_rel, rows, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
-                      zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img, out1=a_proj)
         r_feat = e(rows, P, Cc)
-        ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=enc["feats"],
-                      map2img=row2img, out0=r_feat)                                   # :1145-1148
+        if self.p_v_rel_h is not None and P >= 32:
+            amax2 = torch.zeros(rows, dtype=torch.int32, device=self.device)         # max|a_proj| per row: recorded by the first GEMM
+            ops.conv_mfma(a_val, self.p_v_rel_h, rows, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
+                          zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img, out1=a_proj, f16x3=1,
+                          in_amax=ops.amax_maps(a_val, rows), out1_amax=amax2)
+            ops.conv_mfma(a_proj, self.p_proj_rel_h, rows, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
+                          x=enc["feats"], map2img=row2img, out0=r_feat, f16x3=1, in_amax=amax2)       # :1145-1148
+        else:
+            ops.conv_mfma(a_val, self.p_v_rel, rows, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
+                          zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img, out1=a_proj)
+            ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=enc["feats"],
+                          map2img=row2img, out0=r_feat)                                   # :1145-1148
         check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
         return r_feat, rs["r_words"], row2img
 

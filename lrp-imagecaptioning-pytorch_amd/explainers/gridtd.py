@@ -68,6 +68,8 @@ class GridTDEngine:
         self.p_wg2 = ops.pack_weights(wg2, H, 3 * H, 1, PACK_DENSE_T, kc)
         self.p_gp_rel = ops.pack_weights(sd["global_img_feature_proj.weight"], E, Cc, 1, PACK_DENSE_T, kc)
         self.p_proj_rel = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE_T, kc)
+        # the projector rule runs over every (word, pixel) row: split products on the fp16 matrix cores (csrc/dense_f16x3.hip)
+        self.p_proj_rel_h = ops.pack_weights_f16x2(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1) if H % 64 == 0 else None
         torch.cuda.synchronize()
         self._idx_cache = {}
 
@@ -358,8 +360,12 @@ class GridTDEngine:
         a_proj = e(rows, P, H)
         check(lib.lrpx_gridtd_rel_pix(ctr, crs, ptr(enc["Vp"]), ptr(enc["proj_pre"]), ptr(a_proj), st))
         r_feat = e(rows, P, Cc)
-        ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
-                      x=enc["feats"], u=U, map2img=row2img, out0=r_feat)
+        if self.p_proj_rel_h is not None:
+            ops.conv_mfma(a_proj, self.p_proj_rel_h, rows, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
+                          x=enc["feats"], u=U, map2img=row2img, out0=r_feat, f16x3=1, in_amax=ops.amax_maps(a_proj, rows))
+        else:
+            ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
+                          x=enc["feats"], u=U, map2img=row2img, out0=r_feat)
         check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
         return r_feat, rs["r_words"], row2img
 

@@ -49,12 +49,14 @@ def pack_weights_bf16x3(w, cout, cin, mode):
     return out
 
 
-def pack_weights_f16x2(w, cout, cin, mode):
-    """3x3 conv weights -> layer-scaled fp16 hi/lo planes in fragment layout (for conv_mfma(..., f16x3=1))."""
+def pack_weights_f16x2(w, cout, cin, mode, taps=9):
+    """3x3 conv weights (taps = 9) or a dense (cout, cin) matrix (taps = 1) -> layer-scaled fp16 hi/lo planes in fragment
+    layout (for conv_mfma(..., f16x3=1)).  Dense: PACK_BWD_PLAIN = the transposed product  out[m, i] = sum_o a[m, o] w[o, i]
+    of the epsilon rules (what PACK_DENSE_T is for the fp32 kernels)."""
     lib = _lib.load()
     n_oc, k = (cout, cin) if mode == _lib.PACK_FWD else (cin, cout)
-    out = torch.empty(lib.lrpx_packed_f16x2_bytes(n_oc, k, 9) // 4, dtype=torch.float32, device=w.device)
-    check(lib.lrpx_pack_weights_f16x2(ptr(w.contiguous()), cout, cin, 9, mode, ptr(out), stream_ptr()))
+    out = torch.empty(lib.lrpx_packed_f16x2_bytes(n_oc, k, taps) // 4, dtype=torch.float32, device=w.device)
+    check(lib.lrpx_pack_weights_f16x2(ptr(w.contiguous()), cout, cin, taps, mode, ptr(out), stream_ptr()))
     return out
 
 

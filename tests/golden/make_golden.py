@@ -772,6 +772,59 @@ def gen_t20_guided(out, weights, T=20, seed=0, n_img=2):
     np.savez(os.path.join(out, "t20_guided.npz"), **g)
     print("t20_guided.npz written:", sum(v.nbytes for v in g.values() if hasattr(v, "nbytes")) / 1e6, "MB")
 
+def toy_resnet(rs, add_cls, flatten_cls):
+    """Conv-BN-ReLU -> [Conv-BN-ReLU] + skip (explicit Add module) -> MaxPool -> Flatten -> Linear, weights drawn from `rs`.
+    Shared by make_golden.py (reference side: models.resnet.Add / Flatten) and tests/test_gpu_hooks.py (this repo's classes)."""
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 8, 3, padding=1); self.bn1 = nn.BatchNorm2d(8); self.relu1 = nn.ReLU()
+            self.conv2 = nn.Conv2d(8, 8, 3, padding=1, bias=False); self.bn2 = nn.BatchNorm2d(8); self.relu2 = nn.ReLU()
+            self.add = add_cls(); self.pool = nn.MaxPool2d(2, 2); self.flat = flatten_cls()
+            self.fc = nn.Linear(8 * 7 * 7, 10)
+
+        def forward(self, x):
+            x = self.relu1(self.bn1(self.conv1(x)))
+            y = self.relu2(self.bn2(self.conv2(x)))
+            z = self.pool(self.add(x, y))
+            return self.fc(self.flat(z))
+    net = Toy()
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            m.weight.data = torch.from_numpy(rs.standard_normal(m.weight.shape).astype(np.float32) * 0.2)
+            if m.bias is not None:
+                m.bias.data = torch.from_numpy(rs.standard_normal(m.bias.shape).astype(np.float32) * 0.1)
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data = torch.from_numpy(rs.uniform(0.5, 1.5, m.weight.shape).astype(np.float32))
+            m.bias.data = torch.from_numpy(rs.standard_normal(m.bias.shape).astype(np.float32) * 0.2)
+            m.running_mean = torch.from_numpy(rs.standard_normal(m.bias.shape).astype(np.float32) * 0.2)
+            m.running_var = torch.from_numpy(rs.uniform(0.5, 1.5, m.bias.shape).astype(np.float32))
+    return net.eval()
+
+
+def gen_toy(out):
+    """The reference's `add_lrp` / `compute_lrp` (LRPtools/lrp_wrapper.py:37-87) on a NON-VGG leaf sequence with a residual
+    branch: Conv2d alpha1beta0, BatchNorm2d, ReLU, the explicit Add / Flatten modules of models/resnet.py:25-38, MaxPool2d
+    and the Linear epsilon rule, driven by autograd + the reference's hooks.  Two calls on the same sample tensor: the second
+    result carries the `.grad` running sum (:64-82).  (nn.Dropout in eval mode is an alias of its input under this PyTorch:
+    the reference's own hook then fires on the Flatten view's node and its assert fails - not part of the fixture.)"""
+    from LRPtools import lrp_wrapper
+    import models.resnet as rn
+    rs = np.random.RandomState(5)
+    net = toy_resnet(rs, rn.Add, rn.Flatten)
+    lrp_wrapper.add_lrp(net)
+    x = torch.from_numpy(rs.standard_normal((2, 3, 14, 14)).astype(np.float32))
+    x[1, :, 5, 6] = 0.0
+    target = torch.from_numpy(rs.standard_normal((2, 10)).astype(np.float32))
+    target2 = torch.from_numpy(rs.standard_normal((2, 10)).astype(np.float32))
+    xs = x.clone()
+    r1, logits = net.compute_lrp(xs, target=target.clone(), return_output=True)
+    r2 = net.compute_lrp(xs, target=target2.clone())
+    g = dict(x=x.numpy(), target=target.numpy(), target2=target2.numpy(), r1=r1.numpy(), r2=r2.numpy(),
+             logits=logits.detach().numpy(), seed=np.int64(5))
+    np.savez(os.path.join(out, "toy_resnet.npz"), **g)
+    print("toy_resnet.npz: r1 absmax %.4f sum %.4f; r2 - r1 absmax %.4f" % (r1.abs().max(), r1.sum(), (r2 - r1).abs().max()))
+
 
 def gen_m4(out):
     """The rule classes the VGG16 path never reaches (ResNet encoders): Linear epsilon rule with the
@@ -1005,7 +1058,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,t20_f64,t20_guided,m4,forwardlrp,guided_gradcam,beam")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,t20_f64,t20_guided,toy,m4,forwardlrp,guided_gradcam,beam")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -1029,6 +1082,8 @@ def main():
         gen_t20_f64(HERE, weights)
     if "t20_guided" in todo:
         gen_t20_guided(HERE, weights)
+    if "toy" in todo:
+        gen_toy(HERE)
     if "m4" in todo:
         gen_m4(HERE)
     if "forwardlrp" in todo:

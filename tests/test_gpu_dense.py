@@ -55,3 +55,55 @@ def test_dense_plain_few_rows(ops, rows, k, n, relu):
     if relu:
         want = want.clamp(min=0)
     assert rel_err(out.cpu(), want) < 2e-6
+
+
+@pytest.mark.parametrize("n_maps,P,k,n,n_img", [(40, 196, 512, 512, 4), (23, 36, 512, 2048, 5), (3, 36, 64, 96, 2), (320, 196, 512, 512, 16)])
+def test_dense_f16x3_rel_many_rows(ops, n_maps, P, k, n, n_img):
+    """The (word, pixel) epsilon rules of the decoders on the fp16 matrix cores (csrc/dense_f16x3.hip):
+        r = X[img(map), p] * (sum_i A[map, p, i] W[i, :] + U[map]),  out0 = r,  out1 = r / z~(Zdiv[img(map), p])
+    (models/gridTDmodel.py:1125-1128, models/aoamodel.py:1135-1148) against fp64: per map <= 2e-6 of max|r| although the maps'
+    magnitudes are spread over 1e-12 .. 1e12 and their entries over e^+-6 (per-map power-of-two operand scale); row counts that
+    are no multiple of the 128-row tile, maps that straddle tiles, 96 / 2048 columns; nothing is written behind the outputs;
+    out1_amax = the exact per-map maximum of out1."""
+    from lrp_amd import _lib
+    g = torch.Generator().manual_seed(n_maps * 7 + P)
+    a = torch.randn(n_maps, P, k, generator=g) * torch.exp(1.5 * torch.randn(n_maps, P, k, generator=g))
+    a = a * torch.logspace(-12, 12, n_maps).view(-1, 1, 1)
+    a[n_maps // 2] = 0.0                                                       # an all-zero map (amax = 0)
+    w = torch.randn(k, n, generator=g) * 0.05
+    x = torch.randn(n_img, P, n, generator=g)
+    u = torch.randn(n_maps, n, generator=g) * a.abs().amax(dim=(1, 2)).view(-1, 1) * 0.3
+    z = torch.randn(n_img, P, n, generator=g)
+    z[0, 0, :5] = 0.0                                                          # z == 0 -> 0.01 (epsilon stabiliser)
+    m2i = torch.randint(0, n_img, (n_maps,), generator=g).to(torch.int32)
+    n_pad = -(-n // 32) * 32
+    wp = ops.pack_weights_f16x2(w.cuda(), k, n, _lib.PACK_BWD_PLAIN, taps=1)
+    rows = n_maps * P
+    guard = 128 * n
+    buf0 = torch.full((rows * n + guard,), 777.0, device="cuda")
+    buf1 = torch.full((rows * n + guard,), 777.0, device="cuda")
+    amax_in = ops.amax_maps(a.cuda(), n_maps)
+    amax_out = torch.zeros(n_maps, dtype=torch.int32, device="cuda")
+    ops.conv_mfma(a.cuda(), wp, n_maps, 0, k, n_pad, 1, _lib.EPI_REL, pix_per_map=P, oc_split=n, x=x.cuda(), u=u.cuda(),
+                  zdiv=z.cuda(), stab=_lib.STAB_EPS, map2img=m2i.cuda(), out0=buf0[:rows * n], out1=buf1[:rows * n], f16x3=1,
+                  in_amax=amax_in, out1_amax=amax_out)
+    torch.cuda.synchronize()
+    assert (buf0[rows * n:] == 777.0).all() and (buf1[rows * n:] == 777.0).all()
+    got0, got1 = buf0[:rows * n].view(n_maps, P, n).cpu().double(), buf1[:rows * n].view(n_maps, P, n).cpu().double()
+    xs, zs = x[m2i.long()].double(), z[m2i.long()].double()
+    want0 = xs * (a.double() @ w.double() + u.double().unsqueeze(1))
+    zt = zs + 0.01 * torch.sign(zs)
+    zt[zt == 0] = 0.01
+    want1 = want0 / zt
+    worst = 0.0
+    for m in range(n_maps):
+        s0 = want0[m].abs().max().item()
+        if s0 == 0:
+            assert got0[m].abs().max().item() == 0 and got1[m].abs().max().item() == 0
+            continue
+        e0 = ((got0[m] - want0[m]).abs().max() / s0).item()
+        e1 = ((got1[m] - want1[m]).abs().max() / want1[m].abs().max()).item()
+        worst = max(worst, e0, e1)
+        assert e0 < 2e-6 and e1 < 4e-6, (m, e0, e1)
+        assert amax_out[m:m + 1].view(torch.float32).item() == buf1[:rows * n].view(n_maps, P, n)[m].abs().max().item()
+    print(f"dense f16x3 ({n_maps} maps x {P} rows, {k} -> {n}): worst map {worst:.2e} of its maximum")

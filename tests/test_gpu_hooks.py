@@ -111,6 +111,72 @@ def test_mini_network_layer_by_layer(gold):
     assert rel_err(r[:, :, :16, :16].cpu(), G["mini_r"]) < 1e-4
 
 
+def _fixture_net(G):
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(inplace=True),
+                        nn.MaxPool2d(2, 2), nn.Conv2d(8, 16, 3, padding=1), nn.ReLU(inplace=True))
+    for i in (0, 2, 5):
+        net[i].weight.data = torch.from_numpy(G[f"mini_w{i}"])
+        net[i].bias.data = torch.from_numpy(G[f"mini_b{i}"])
+    return net.cuda().eval()
+
+
+def test_generic_add_lrp_on_the_reference_fixture_net():
+    """`add_lrp(net)` + `net.compute_lrp(x, target=...)` on the reference's own 7-layer fixture net
+    (make_golden.py:gen_layers, 16x16 / 8x8 maps, in-place ReLUs) - a NON-VGG leaf sequence - reproduces the reference's
+    result `mini_r` (layers.npz) through the generic driver (recorded forward + reverse walk over the rule classes)."""
+    from lrp_amd.LRPtools import lrp_wrapper
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    G = np.load(os.path.join(GOLDEN, "layers.npz"))
+    net = _fixture_net(G)
+    lrp_wrapper.add_lrp(net)
+    lrp_wrapper.add_lrp(net)
+    x = torch.from_numpy(G["mini_x"]).cuda()
+    r = net.compute_lrp(x, target=torch.from_numpy(G["mini_target"]).cuda())
+    assert r.shape == x.shape and r.device.type == "cuda"
+    e = rel_err(r.cpu(), G["mini_r"])
+    print(f"generic add_lrp, fixture net: {e:.2e}")
+    assert e < 1e-4
+    with pytest.raises(RuntimeError, match="Mismatch in shape"):
+        net.compute_lrp(x, target=torch.zeros(1, 16, 4, 4).cuda())
+
+
+def test_generic_add_lrp_on_a_residual_toy_net():
+    """Conv-BN-ReLU, a skip connection through the explicit Add module, MaxPool, Flatten, Linear: every M4 rule reached
+    through `add_lrp` / `compute_lrp`, against the reference's own add_lrp on the same net (toy_resnet.npz).  The output of
+    relu1 feeds conv2 AND the Add: its relevance is the sum of both (autograd's accumulation in the reference); two calls
+    on the same sample return the `.grad` running sum (lrp_wrapper.py:64-82)."""
+    import sys
+    from lrp_amd.LRPtools import lrp_wrapper, lrp_modules
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, GOLDEN)
+    from make_golden import toy_resnet
+    G = np.load(os.path.join(GOLDEN, "toy_resnet.npz"))
+    net = toy_resnet(np.random.RandomState(int(G["seed"])), lrp_modules.resAdd, lrp_modules.resFlatten).cuda()
+    lrp_wrapper.add_lrp(net)
+    xs = torch.from_numpy(G["x"]).cuda()
+    r1, logits = net.compute_lrp(xs, target=torch.from_numpy(G["target"]).cuda(), return_output=True)
+    assert rel_err(logits.cpu(), G["logits"]) < 1e-5
+    r2 = net.compute_lrp(xs, target=torch.from_numpy(G["target2"]).cuda())
+    e1, e2 = rel_err(r1.cpu(), G["r1"]), rel_err(r2.cpu(), G["r2"])
+    print(f"generic add_lrp, residual toy net: {e1:.2e} (first call), {e2:.2e} (running sum of two calls)")
+    assert e1 < 1e-4 and e2 < 1e-4
+    assert cosine(r1.cpu(), G["r1"]) > 0.99999
+
+    class Functional(nn.Module):                 # a functional `+` between leaves: the rules cannot see it -> refused, not dropped
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.relu = nn.Conv2d(3, 8, 3, padding=1), nn.Conv2d(3, 8, 3, padding=1), nn.ReLU()
+
+        def forward(self, x):
+            return self.relu(self.a(x) + self.b(x))
+    f = Functional().cuda().eval()
+    lrp_wrapper.add_lrp(f)
+    with pytest.raises(ValueError, match="functional"):
+        f.compute_lrp(xs, target=torch.rand(2, 8, 14, 14).cuda())
+
+
 def test_explainer_class_drop_in(gold):
     from lrp_amd import weights
     from lrp_amd.explainers.gridtd import ExplainGridTDAttention

@@ -79,8 +79,25 @@ def test_no_cpu_fallback():
     with pytest.raises(ValueError):
         ops.conv_mfma(torch.zeros(4), torch.zeros(4), 1, 14, 32, 32, 9, 1)
     cpu_vgg = nn.Sequential(*[m for v in [64] for m in (nn.Conv2d(3, 64, 3, padding=1), nn.ReLU())])
-    with pytest.raises((ValueError, _lib.LrpxError)):
+    with pytest.raises(_lib.LrpxError, match="no CPU path"):      # generic driver: refuses a model on the CPU
         lrp_wrapper.add_lrp(cpu_vgg)
+    pools = nn.Sequential(nn.MaxPool2d(2, 2), nn.ReLU())          # nothing to tell the device from: refused at the call
+    lrp_wrapper.add_lrp(pools)
+    with pytest.raises(_lib.LrpxError, match="no CPU path"):
+        pools.compute_lrp(torch.zeros(1, 2, 4, 4), target=torch.ones(1, 2, 2, 2))
+
+
+def test_generic_add_lrp_hooks_every_leaf_once():
+    """lrp_wrapper.py:37-59 hooks every leaf of ANY model; a second add_lrp must not stack hooks (the reference does)"""
+    net = nn.Sequential(nn.MaxPool2d(2, 2), nn.ReLU(), nn.Dropout())
+    lrp_wrapper.add_lrp(net)
+    lrp_wrapper.add_lrp(net)
+    assert all(len(m._forward_hooks) == 1 for m in net) and callable(net.compute_lrp)
+    x = torch.rand(1, 2, 4, 4)
+    net.eval()(x)
+    assert net[0].input[0] is x and len(net._lrpx_tape) == 3      # save_input_hook (:24-25) + the call order
+    assert [lrp_wrapper._rule_name(m) for m in (nn.Linear(2, 2), nn.BatchNorm2d(2), nn.ReLU(), nn.Conv2d(2, 2, 3), nn.MaxPool2d(2))] == \
+        ["epsilon", "epsilon", "identity", "alpha_beta", "alpha_beta"]
 
 
 def test_bench_host_cores_respects_cgroup():
