@@ -156,7 +156,8 @@ def parse(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 3 / 4 / 5 and the B=64 line, same process)")
     ap.add_argument("--all-heads", action="store_true", help="config 3: explain all 8 heads of every word in the step (8 x B x T maps)")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained sub-measurement (0 = off)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph per batch in flight (config 2, LRP)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph per batch in flight (config 2 LRP; config 5: the default)")
+    ap.add_argument("--no-graph", action="store_true", help="config 5: eager launches instead of the HIP-graph replay")
     ap.add_argument("--pipeline", type=int, default=None,
                     help="independent batches in flight on separate HIP streams (1 = serial steps; default 3, 2 for the "
                          "large configs 3 / 4); every step is still one full pass over one batch, the decoder's "
@@ -173,6 +174,8 @@ def parse(argv=None):
         a.vocab = 9586 if a.config in (2, 4) else 11027
     if a.pipeline is None:
         a.pipeline = 3 if a.config in (2, 5) else 2
+    if a.config == 5 and not a.no_graph:
+        a.graph = True
     return a
 
 
@@ -314,6 +317,8 @@ def run_config(a, dist, rank, world):
         feats = torch.from_numpy(weights.make_bu_features(100 + rank, B)).cuda()
 
         def one_step(e, k):
+            if a.graph:          # the step replayed from a HIP graph per batch in flight (the path is host-launch-bound eagerly)
+                return e.explain_batch_graph(caps, a.head, features=feats, predictions=True)
             enc = e.encode(features=feats)
             tr = e.trace(enc, caps, predictions=True)
             r_feat, r_words, _ = e.relevance(enc, tr, a.head)
@@ -436,7 +441,7 @@ def run_config(a, dist, rank, world):
                           "unit_of_work": "trace (VGG16 forward + decoder, predictions kept) + decoder relevance + CNN relevance + "
                                           "running sums of the maps" if has_vgg else "decoder trace (predictions kept) + decoder relevance",
                           "sharding": f"images x{world}, no data-path collective" + (" + gather" if a.gather else ""),
-                          "batches_in_flight": n_pipe},
+                          "batches_in_flight": n_pipe, "launch": "HIP graph replay per batch in flight" if a.graph else "eager"},
                "median_ms": round(median_ms, 3), "hip_event_ms_per_step": round(ends[-1] / a.steps, 3), "sustained": sustained}
         out["median_ms_note"] = (f"median over the timed region of (completion[i] - completion[i-{w}]) / {w} by HIP events "
                                  f"({w} batches in flight complete in bursts); hip_event_ms_per_step = last completion / steps")

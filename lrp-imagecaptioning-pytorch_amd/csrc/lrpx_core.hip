@@ -29,6 +29,7 @@ const Switches& switches() {
         w.wide = num("LRPX_WIDE", 7);
         w.fwd_ksplit14 = num("LRPX_FWD_KSPLIT", 8);
         w.fwd_ksplit28 = num("LRPX_FWD_KSPLIT28", 4);
+        w.conv11_f16 = num("LRPX_CONV11_F16", 1);
         w.first_valu = set("LRPX_FIRST_VALU");
         w.pool28 = num("LRPX_POOL28", 1);
         w.s21_nhwc = set("LRPX_S21_NHWC");
@@ -270,6 +271,14 @@ __global__ void pack_weights_f16x2_kernel(const float* __restrict__ w, float* __
                 const int co = oc < cout ? oc : oc - cout;
                 const float x = w[((long)co * cin + k) * taps + tap];
                 v = oc < cout ? x : fmaxf(x, 0.f);
+            }
+            break;
+        case LRPX_PACK_FWD_DUAL_FIRST:   // input channels [0,cin) = x+, [cin,2cin) = x- (the signed image): Z = x+ W+ + x- W-
+            if (k < 2 * cin && oc < 2 * cout) {
+                const int co = oc < cout ? oc : oc - cout;
+                const int ci = k < cin ? k : k - cin;
+                const float x = w[((long)co * cin + ci) * taps + tap];
+                v = oc < cout ? x : (k < cin ? fmaxf(x, 0.f) : fminf(x, 0.f));
             }
             break;
     }
@@ -878,9 +887,9 @@ int lrpx_pack_weights_f16f8(const float* w, int cout, int cin, int mode, void* p
 }
 
 int lrpx_pack_weights_f16x2(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream) {
-    LRPX_REQUIRE(w && packed && taps == 9, "pack_weights_f16x2: bad arguments (3x3 kernels only)");
+    LRPX_REQUIRE(w && packed && (taps == 9 || taps == 1), "pack_weights_f16x2: bad arguments (3x3 kernels or dense matrices)");
     LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN || mode == LRPX_PACK_FWD ||
-                     mode == LRPX_PACK_FWD_DUAL, "pack_weights_f16x2: mode %d not supported", mode);
+                     mode == LRPX_PACK_FWD_DUAL || mode == LRPX_PACK_FWD_DUAL_FIRST, "pack_weights_f16x2: mode %d not supported", mode);
     int n_oc_pad, k_pad;
     pack_dims(cout, cin, mode, 16, &n_oc_pad, &k_pad);
     hipStream_t st = (hipStream_t)stream;

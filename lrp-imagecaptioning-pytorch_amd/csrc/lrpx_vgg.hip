@@ -287,7 +287,7 @@ static thread_local int tl_timing = 0;
 static thread_local float tl_ms[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], first6, first6p, first16, first16p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], fwdh0, first6, first6p, first16, first16p, total;
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
@@ -310,6 +310,7 @@ static VggPacked vgg_packed_layout() {
             p.fwd6[l] = off; off += lrpx_packed_bf16x3_bytes(2 * L.cout, L.cin, 9) / sizeof(float);
         }
     }
+    p.fwdh0 = off; off += lrpx_packed_f16x2_bytes(2 * 64, 16, 9) / sizeof(float);   // conv1_1 forward on the fp16 matrix cores
     p.first6 = off; off += (size_t)64 * 9 * 6;   // direct-conv weights of the first layer's rule
     p.first6p = off; off += (size_t)64 * 9 * 6;  // ... and of its plain transposed conv (guided backprop)
     p.first16 = off; off += (size_t)16 + 2 * 9 * 64 * 4;   // first layer's rule on the matrix cores (header + A fragments)
@@ -422,6 +423,7 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
             return LRPX_ELAUNCH;
         }
         if (l == 0) {
+            LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL_FIRST, base + p.fwdh0, stream));
             LRPX_TRY(first_layer_pack(w[ci], base + p.first6, L.cout, 0, (hipStream_t)stream));
             LRPX_TRY(first_layer_pack(w[ci], base + p.first6p, L.cout, 1, (hipStream_t)stream));
             LRPX_TRY(first_layer_pack_mfma(w[ci], base + p.first16, 0, (hipStream_t)stream));
@@ -534,8 +536,19 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
                     continue;
                 }
             } else if (use_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
-            // conv1_1 (fp32 MFMA kernel) records the per-image maximum of its activations for conv1_2's fp16 scale
-            if (fwd_f16 && mode >= 2 && l == 0) d.out0_amax = reinterpret_cast<unsigned*>(tr + t.famax) + (size_t)1 * n_img;
+            if (fwd_f16 && mode >= 2 && l == 0) {
+                unsigned* fam = reinterpret_cast<unsigned*>(tr + t.famax);
+                d.out0_amax = fam + (size_t)1 * n_img;       // per-image maximum of the activations: conv1_2's fp16 scale
+                if (switches().conv11_f16) {
+                    // conv1_1 on the fp16 matrix cores too (the fp32 MFMA kernel: 0.67 ms per 16 images for 15 GFLOP and 0.4 GB -
+                    // neither its matrix nor its memory time): the signed image [x+ | x- | 0] padded to one 16-channel
+                    // K-chunk (51 MB per 16 images, in the scratch region of the trace), scale = max|pixel| per image
+                    float* img16 = tr + t.xz[1];
+                    LRPX_TRY(lrpx_nchw_to_nhwc_posneg(img_nchw, img16, n_img, 3, 224 * 224, 16, stream));
+                    LRPX_TRY(lrpx_amax_maps(img16, n_img, (long)224 * 224 * 16, fam, stream));
+                    d.in = img16; d.cin = 16; d.f16x3 = 1; d.wpacked = pk + p.fwdh0; d.in_amax = fam;
+                }
+            }
             LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
         } else {
             LRPX_TRY(lrpx_maxpool2x2_fwd(tr + t.act[l], tr + t.act[l + 1], n_img, L.hw, L.hw, L.cin, stream));

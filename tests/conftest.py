@@ -23,8 +23,9 @@ _TIE_STATS = []
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """observed end-to-end deviations (assert_close_modulo_pool_ties) of this session -> gpurun_out/pool_tie_stats.json"""
-    if _TIE_STATS:
+    """observed end-to-end deviations (assert_close_modulo_pool_ties) of this session -> gpurun_out/pool_tie_stats.json,
+    only when LRPX_TIE_STATS=1 asks for it (a test session does not write into the tree otherwise: ADVICE r2)"""
+    if _TIE_STATS and os.environ.get("LRPX_TIE_STATS") == "1":
         import json
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
@@ -45,7 +46,7 @@ def cosine(a, b):
     return (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
 
 
-def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=3e-3, l2=6e-4, what="", cos=0.99999):
+def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=8e-3, l2=1.5e-3, what="", cos=0.99999):
     """End-to-end comparison of pixel relevance maps whose FORWARD passes were computed by different conv
     implementations.  Relevance through MaxPool2d goes to the arg-max of each 2x2 window
     (LRPtools/lrp_modules.py:182-195); rounding-level differences of the forward flip the winner of a few
@@ -55,9 +56,11 @@ def assert_close_modulo_pool_ties(got, want, frac=1e-2, hard=3e-3, l2=6e-4, what
     (tests/e2e_stats.py).  So: cosine >= 0.99999, relative L2 error < `l2`, at most `frac` of the
     pixels off by more than 1e-4 of max|R|, none by more than `hard`.  The strict 1e-4 bound is asserted
     separately on identical activations.
-    The default bounds are <= 3.5x the worst observation over all 65 LRP end-to-end comparisons of the suite (round 2,
-    gpurun_out/pool_tie_stats.json written by this function's callers: 0.29 % of the pixels, max 8.0e-4, relative L2
-    1.8e-4 - the B = 2 multi-image case of test_gpu_gridtd.py; the golden image alone: 0.12 %, 6.8e-4, 8.2e-5)."""
+    The default bounds are ~10x the worst observation over the LRP end-to-end comparisons of the suite (round 2: 0.29 % of
+    the pixels, max 8.0e-4, relative L2 1.8e-4 - the B = 2 multi-image case of test_gpu_gridtd.py; the golden image alone:
+    0.12 %, 6.8e-4, 8.2e-5): which near-tied window flips depends on the box's clock order and on the forward variant, one
+    flip more doubles the numbers (3.5x was thin).  LRPX_TIE_STATS=1 writes the observations of a session to
+    gpurun_out/pool_tie_stats.json."""
     import torch
     got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
     scale = want.abs().max().clamp_min(1e-300)

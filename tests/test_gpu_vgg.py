@@ -725,3 +725,41 @@ def test_per_context_conv_mode_in_flight_on_two_streams(ops, gridtd_case):
         assert all(ms[l] > 0 for l in convs) and ms[0] == 0 and all(ms[l] == 0 for l in (2, 5, 9, 13))
     finally:
         lib.lrpx_set_conv_mode(prev)
+
+
+def test_forward_discrete_decisions_vs_oracle(ops):
+    """What the end-to-end deviations are made of: the discrete decisions of the forward trace - ReLU
+    signs of all 13 conv outputs, arg-max of all 4 pools - of two images against the CPU oracle's fp32 forward (oneDNN, what
+    the reference runs).  Observed (tools/flip_probe.py, every forward variant): 3 - 6 ReLU flips of 27 M activations and 1 - 4
+    winner flips of 2.2 M live windows; oneDNN itself is 2 + 2 flips away from an fp64 forward of the same weights.  Bound:
+    10x that.  Printed per kind so the numbers land in the test log."""
+    import torch.nn.functional as F
+    from lrp_amd import weights
+    from oracle import lrp_oracle as O
+    sd = weights.make_gridtd_state(seed=0, vocab_size=64)
+    vgg = _vgg(ops, sd)
+    img = torch.from_numpy(weights.make_images(0, 2))
+    vgg.forward(img.cuda())
+    torch.cuda.synchronize()
+    acts, _ = vgg.trace_views()
+    sdt = O.state_to_torch(sd)
+    feats, _, saved = O.vgg_forward(sdt, img)
+    saved = saved + [feats]
+    relu = pool = n_act = n_win = 0
+    for l, (kind, idx, cin, cout) in enumerate(O.vgg_layers()):
+        want = saved[l + 1]
+        n, c, hw = want.shape[0], want.shape[1], want.shape[2]
+        got = acts[l + 1][:n].cpu().reshape(n, hw, hw, -1)[..., :c].permute(0, 3, 1, 2)
+        if kind == "conv":
+            relu += ((got > 0) != (want > 0)).sum().item()
+            n_act += want.numel()
+        else:
+            x_gpu = acts[l][:n].cpu().reshape(n, 2 * hw, 2 * hw, -1)[..., :c].permute(0, 3, 1, 2)
+            _, ig = F.max_pool2d(x_gpu, 2, 2, return_indices=True)
+            _, iw = F.max_pool2d(saved[l], 2, 2, return_indices=True)
+            live = want > 0
+            pool += ((ig != iw) & live).sum().item()
+            n_win += int(live.sum())
+    print(f"forward vs the oracle's oneDNN forward, 2 images: {relu} ReLU sign flips of {n_act} activations, "
+          f"{pool} pool-winner flips of {n_win} live windows")
+    assert relu <= 60 and pool <= 40
