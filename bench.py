@@ -156,12 +156,13 @@ def parse(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 3 / 4 / 5 and the B=64 line, same process)")
     ap.add_argument("--all-heads", action="store_true", help="config 3: explain all 8 heads of every word in the step (8 x B x T maps)")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained sub-measurement (0 = off)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph per batch in flight (config 2 LRP; config 5: the default)")
-    ap.add_argument("--no-graph", action="store_true", help="config 5: eager launches instead of the HIP-graph replay")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph per batch in flight (config 2 LRP, config 5); measured slower than eager launches with batches in flight in both (DESIGN.md)")
     ap.add_argument("--pipeline", type=int, default=None,
                     help="independent batches in flight on separate HIP streams (1 = serial steps; default 3, 2 for the "
                          "large configs 3 / 4); every step is still one full pass over one batch, the decoder's "
                          "latency-bound kernels of one batch overlap the MFMA-bound CNN chain of another")
+    ap.add_argument("--host-threads", action="store_true", help="one host thread per batch in flight issues that batch's launches (A/B: config 5 is "
+                    "bound by the GPU's dispatch rate of dependent small kernels, not by the host: 430 000 against 480 000 maps/s)")
     ap.add_argument("--fp32-mfma", action="store_true", help="same as --conv-mode 0")
     ap.add_argument("--conv-mode", type=int, default=3, choices=[0, 1, 2, 3],
                     help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp8 cross products (default)")
@@ -174,8 +175,6 @@ def parse(argv=None):
         a.vocab = 9586 if a.config in (2, 4) else 11027
     if a.pipeline is None:
         a.pipeline = 3 if a.config in (2, 5) else 2
-    if a.config == 5 and not a.no_graph:
-        a.graph = True
     return a
 
 
@@ -380,12 +379,49 @@ def run_config(a, dist, rank, world):
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_threads = a.host_threads and n_pipe > 1 and not a.gather
+
+    def run_steps(n, events):
+        """n steps in issue order: one host thread round-robin over the streams, or (--host-threads) one host thread per
+        batch in flight - thread k issues steps k, k + n_pipe, ... on its own stream and replica (the native step loops
+        release the interpreter lock while they issue their launches).  Measured on config 5 (~330 small launches per
+        step): no gain - three dependent chains of 4 - 25 us kernels overlap 1.7x whoever issues them, the ceiling is
+        the GPU's dispatch rate (~250 000 launches/s), so the default stays one thread."""
+        if not host_threads:
+            out = None
+            for _ in range(n):
+                out = step(events)
+            return out
+        import threading
+        base = step_no[0]
+        step_no[0] += n
+        outs = [None] * n_pipe
+
+        def worker(k):
+            torch.cuda.set_device(torch.cuda.current_device())
+            with torch.cuda.stream(streams[k]):
+                for i in range(base, base + n):
+                    if i % n_pipe == k:
+                        outs[k] = one_step(engines[k], k)
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(n_pipe)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        last = (base + n - 1) % n_pipe
+        if events is not None:          # (per-step completion events are not taken in this mode: one end event)
+            ev = torch.cuda.Event(enable_timing=True)
+            for st_ in streams:
+                torch.cuda.current_stream().wait_stream(st_)
+            ev.record()
+            events.append(ev)
+        return outs[last]
+
     def timed(n, events=None):
         """n steps bracketed by barrier + synchronize on both sides; MAX over ranks"""
         barrier()
         t0 = time.perf_counter()
-        for _ in range(n):
-            out = step(events)
+        out = run_steps(n, events)
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -394,8 +430,7 @@ def run_config(a, dist, rank, world):
             dt = tmax.item()
         return dt, out
 
-    for _ in range(a.warmup):
-        step()
+    run_steps(a.warmup, None)
     barrier()
     if rank == 0:
         log("warm-up done, timing")
@@ -410,8 +445,12 @@ def run_config(a, dist, rank, world):
     # taken over windows of n_pipe consecutive completions: (end[i] - end[i - n_pipe]) / n_pipe, median over the region
     ends = [0.0] + [ev0.elapsed_time(e) for e in events[1:]]
     w = min(n_pipe, a.steps)
-    gaps = sorted((ends[i] - ends[i - w]) / w for i in range(w, len(ends)))
-    median_ms = gaps[len(gaps) // 2] if len(gaps) % 2 else 0.5 * (gaps[len(gaps) // 2 - 1] + gaps[len(gaps) // 2])
+    if host_threads:                   # one end event for the whole region in this mode
+        ends = [0.0] * a.steps + [ends[-1]]
+        median_ms = ends[-1] / a.steps
+    else:
+        gaps = sorted((ends[i] - ends[i - w]) / w for i in range(w, len(ends)))
+        median_ms = gaps[len(gaps) // 2] if len(gaps) % 2 else 0.5 * (gaps[len(gaps) // 2 - 1] + gaps[len(gaps) // 2])
     if rank == 0:
         log(f"timed region done: {dt / a.steps * 1e3:.2f} ms/step (median step interval by HIP events {median_ms:.2f} ms)")
     sustained = None
@@ -441,7 +480,7 @@ def run_config(a, dist, rank, world):
                           "unit_of_work": "trace (VGG16 forward + decoder, predictions kept) + decoder relevance + CNN relevance + "
                                           "running sums of the maps" if has_vgg else "decoder trace (predictions kept) + decoder relevance",
                           "sharding": f"images x{world}, no data-path collective" + (" + gather" if a.gather else ""),
-                          "batches_in_flight": n_pipe, "launch": "HIP graph replay per batch in flight" if a.graph else "eager"},
+                          "batches_in_flight": n_pipe, "launch": ("HIP graph replay per batch in flight" if a.graph else "eager") + (", one host thread per batch in flight" if host_threads else "")},
                "median_ms": round(median_ms, 3), "hip_event_ms_per_step": round(ends[-1] / a.steps, 3), "sustained": sustained}
         out["median_ms_note"] = (f"median over the timed region of (completion[i] - completion[i-{w}]) / {w} by HIP events "
                                  f"({w} batches in flight complete in bursts); hip_event_ms_per_step = last completion / steps")

@@ -351,6 +351,19 @@ int lrpx_aoa_fwd_lstm(const lrpx_aoa_trace* tr, int t, const float* zz, int ldz,
 int lrpx_aoa_fwd_attention(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* key,
                            const float* value, void* stream);
 int lrpx_aoa_fwd_post(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* lin, void* stream);
+/* decoder steps t0 <= t < t1 of get_hidden_parameters (models/aoamodel.py:1020-1052) in ONE call: per step fwd_pre, LSTM gate
+ * linear, fwd_lstm, [q | aoa gate] linear, fwd_attention, decoder_aoa_linear, fwd_post - the `for t in range(...)` loop of
+ * the reference (:1019) with its host side in native code */
+typedef struct lrpx_aoa_step_args {
+    const float *glob, *emb;            /* global image feature [B][H], embedding table */
+    const long long* tok; int tok_ld;   /* token ids [B][tok_ld] (teacher forcing: the caption incl. <start>) */
+    const float *w_cat, *b_cat;         /* LSTM [W_ih | W_hh] (4H x (E+2H)) and its bias (the explainers' quirk or the model's) */
+    const float *w_qg, *b_qg;           /* [q_proj ; decoder_aoa_linear_gate] (2H x H) */
+    const float *w_lin, *b_lin;         /* decoder_aoa_linear (H x H) */
+    const float *key, *value;           /* [B][P][H] */
+    float *zz, *qg, *lin;               /* scratch [B][4H], [B][2H], [B][H] */
+} lrpx_aoa_step_args;
+int lrpx_aoa_fwd_steps(const lrpx_aoa_trace* tr, int t0, int t1, const lrpx_aoa_step_args* a, void* stream);
 
 /* ---- AoA decoder: gradient explainers (ExplainAOAGradient.explain_caption_wordt, models/aoamodel.py:1435-1499;
  *      inherited unchanged by the guided / Grad-CAM variants) --------------------------------------------------- */
@@ -387,6 +400,11 @@ int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, co
                        int head, float* a_val, void* stream);
 /* lock-step s: phase 0 g-gate split (:1116-1120) -> A ; phase 1 after the LSTM dense rule (:1129-1133) */
 int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int s, int phase, void* stream);
+/* lock-steps 0 <= s < n_steps of explain_caption_wordt's `for i in range(t+1)[::-1]` (models/aoamodel.py:1114-1134) in ONE
+ * call: phase 0, the LSTM dense rule `dense` (an lrpx_conv_mfma descriptor whose map2img is replaced by idx + s * idx_ld:
+ * row -> source row of its multiplicand), phase 1 */
+int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int n_steps, const lrpx_conv_desc* dense,
+                       const int32_t* idx, int idx_ld, void* stream);
 
 /* ---- gridTD guided backprop, decoder side (ExplainiGridTDGuidedGradient.explain_caption_wordt,
  *      models/gridTDmodel.py:1588-1675): BPTT with alpha/beta constant ------------------------------------ */

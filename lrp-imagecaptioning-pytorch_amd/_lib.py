@@ -42,6 +42,12 @@ class AoaTrace(C.Structure):
         "xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha", "o", "sg")]
 
 
+class AoaStepArgs(C.Structure):
+    """lrpx_aoa_step_args"""
+    _fields_ = [("glob", _f), ("emb", _f), ("tok", _f), ("tok_ld", _i)] + [(k, _f) for k in (
+        "w_cat", "b_cat", "w_qg", "b_qg", "w_lin", "b_lin", "key", "value", "zz", "qg", "lin")]
+
+
 class AoaGradState(C.Structure):
     _fields_ = [(k, _f) for k in ("lens", "d_h", "d_c", "dA", "dB", "gates", "dx", "d_glob", "r_words")]
 
@@ -127,9 +133,11 @@ SIGNATURES = {
     "lrpx_aoa_fwd_lstm": (_i, [C.POINTER(AoaTrace), _i, _f, _i, _f]),
     "lrpx_aoa_fwd_attention": (_i, [C.POINTER(AoaTrace), _i, _f, _i, _f, _f, _f]),
     "lrpx_aoa_fwd_post": (_i, [C.POINTER(AoaTrace), _i, _f, _i, _f, _f]),
+    "lrpx_aoa_fwd_steps": (_i, [C.POINTER(AoaTrace), _i, _i, C.POINTER(AoaStepArgs), _f]),
     "lrpx_aoa_rel_init": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _f, _i, _f]),
     "lrpx_aoa_rel_value": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _i, _f, _f]),
     "lrpx_aoa_rel_step": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _i, _i, _f]),
+    "lrpx_aoa_rel_steps": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _i, C.POINTER(ConvDesc), _f, _i, _f]),
     "lrpx_gridtd_grad_init": (_i, [C.POINTER(GridTrace), C.POINTER(GridGradState), _f, _f, _i, _f]),
     "lrpx_gridtd_grad_step": (_i, [C.POINTER(GridTrace), C.POINTER(GridGradState), _i, _i, _f]),
     "lrpx_spread_pixels": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),

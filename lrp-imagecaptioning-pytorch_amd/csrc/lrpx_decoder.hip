@@ -1543,4 +1543,38 @@ int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int
     return check_launch("aoa_rel_step");
 }
 
+// The host loops of the AoA decoder in native code.  Every launch is one of the entry points above; what goes away is the
+// interpreter between them: ~4 us per call through ctypes against ~1.5 us for a launch issued from here.  With a CNN stage
+// behind it that is noise; the bottom-up path (no CNN, ~330 launches of 4 - 25 us per step of 640 maps) was bound by it.
+int lrpx_aoa_fwd_steps(const lrpx_aoa_trace* tr, int t0, int t1, const lrpx_aoa_step_args* a, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(a && a->glob && a->emb && a->tok && a->w_cat && a->w_qg && a->w_lin && a->key && a->value && a->zz && a->qg &&
+                     a->lin && t0 >= 0 && t0 <= t1 && t1 <= tr->T, "aoa_fwd_steps: bad arguments");
+    const int B = tr->B, T = tr->T, H = tr->H, W = tr->E + 2 * tr->H;
+    for (int t = t0; t < t1; ++t) {
+        LRPX_TRY(lrpx_aoa_fwd_pre(tr, t, a->glob, a->emb, a->tok, a->tok_ld, stream));
+        LRPX_TRY(lrpx_linear_small(tr->xh + (long)t * W, (long)T * W, a->w_cat, a->b_cat, a->zz, 4 * H, B, W, 4 * H, 0, stream));
+        LRPX_TRY(lrpx_aoa_fwd_lstm(tr, t, a->zz, 4 * H, stream));
+        LRPX_TRY(lrpx_linear_small(tr->h + (long)(t + 1) * H, (long)(T + 1) * H, a->w_qg, a->b_qg, a->qg, 2 * H, B, H, 2 * H, 0, stream));
+        LRPX_TRY(lrpx_aoa_fwd_attention(tr, t, a->qg, 2 * H, a->key, a->value, stream));
+        LRPX_TRY(lrpx_linear_small(tr->ctx + (long)t * H, (long)T * H, a->w_lin, a->b_lin, a->lin, H, B, H, H, 0, stream));
+        LRPX_TRY(lrpx_aoa_fwd_post(tr, t, a->qg, 2 * H, a->lin, stream));
+    }
+    return LRPX_OK;
+}
+
+int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int n_steps, const lrpx_conv_desc* dense,
+                       const int32_t* idx, int idx_ld, void* stream) {
+    LRPX_TRY(check_arel(tr, rs));
+    LRPX_REQUIRE(dense && idx && n_steps >= 0 && n_steps <= tr->T && idx_ld >= tr->B * tr->T, "aoa_rel_steps: bad arguments");
+    lrpx_conv_desc d = *dense;
+    for (int s = 0; s < n_steps; ++s) {
+        LRPX_TRY(lrpx_aoa_rel_step(tr, rs, s, 0, stream));
+        d.map2img = idx + (long)s * idx_ld;          // row -> source row of the multiplicand at lock-step s
+        LRPX_TRY(lrpx_conv_mfma(&d, stream));
+        LRPX_TRY(lrpx_aoa_rel_step(tr, rs, s, 1, stream));
+    }
+    return LRPX_OK;
+}
+
 }  // extern "C"

@@ -514,16 +514,19 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
                 // (the maximum of act[1] is recorded by conv1_1's epilogue below: l == 0)
                 d.f16x3 = 1; d.wpacked = pk + p.fwdh[l];
                 d.in_amax = fam + (size_t)in_l * n_img; d.out0_amax = fam + (size_t)(l + 1) * n_img;
-                // The deep layers run K-SPLIT: blockIdx.y takes one of `ks` contiguous K ranges per tile through the PLAIN
-                // epilogue (partial sums behind each other in the xz[1] region of the trace - SCRATCH during the forward pass:
+                // The 14x14 layers run K-SPLIT: blockIdx.y takes one of 8 contiguous K ranges per tile through the PLAIN epilogue
+                // (partial sums behind each other in the xz[1] region of the trace - SCRATCH during the forward pass:
                 // lrpx_vgg16_trace_derive below rewrites it after the last layer), then one pass adds the splits pairwise in a
                 // fixed order, applies bias / ReLU and records the per-image maximum: what the FWD_DUAL epilogue does.
-                //  * accuracy: one accumulator then carries 36 (14x14: K = 4608 in 8 ranges) or 72 (28x28: 4 ranges) k-steps
-                //    instead of 288 - the rounding of a sequential fp32 chain grows with its length, and the features moved
-                //    from 3e-6 to <2e-6 of their maximum against an fp64 forward (tests/test_gpu_t20.py);
-                //  * the grids fill the chip: 16 images are 112 (14x14) / 448 (28x28) workgroups of 32 K-chunks each;
+                //  * the grid fills the chip: 16 images are 112 workgroups of 32 K-chunks each (207 -> 112 + 45 us per layer);
+                //  * accuracy: an accumulator carries 36 k-steps instead of 288.  A chain of N MFMA accumulations rounds like a
+                //    sequential fp32 sum (tools/micro/mfma_round.hip, profiles/r03_mfma_round.txt: rms 3.6e-7 of the result at
+                //    N = 288, 6.5e-8 in 8 blocks): features 2.9e-6 -> 2.0e-6 of their maximum from an fp64 forward;
                 //  * the decision depends on the LAYER only, never on the batch size: an image gets the same activations,
-                //    pool winners and maps whatever batch it sits in.
+                //    pool winners and maps whatever batch it sits in (test_forward_features_vs_fp64_...).
+                // The 28x28 layers can split too (LRPX_FWD_KSPLIT28=4: features 1.6e-6 from fp64), but their partial sums are 4 x
+                // 51 MB per layer and 16 images: +0.3 ms per forward pass for a gain that no parity test can see (the AoA
+                // r_words rows sit at 1.0 - 1.2 of the reference's own fp64 distance either way, bound 3) - off by default.
                 const int fwd_ks = L.hw == 14 ? switches().fwd_ksplit14 : (L.hw == 28 ? switches().fwd_ksplit28 : 1);
                 if (fwd_ks > 1 && (fwd_ks & (fwd_ks - 1)) == 0 && fwd_ks <= 16 && (L.cin / 16) % fwd_ks == 0 &&
                     (size_t)fwd_ks * L.hw * L.hw * 2 * L.cout <= (size_t)224 * 224 * 64) {

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
-from .._lib import (AoaGradState, AoaRelState, AoaTrace, EPI_PLAIN, EPI_REL, PACK_DENSE, PACK_DENSE_T, STAB_EPS, check, ptr, ptr_at,
+from .._lib import (AoaGradState, AoaRelState, AoaStepArgs, AoaTrace, EPI_PLAIN, EPI_REL, PACK_DENSE, PACK_DENSE_T, STAB_EPS, check, ptr, ptr_at,
                     stream_ptr)
 from .gridtd import VGG_PREFIX, _t
 
@@ -238,8 +238,15 @@ class AOAEngine:
         W = E + 2 * H
         bias = self.bcat_model if model_bias else self.bcat_explainer
         sd = self.sd
-        for t in range(T):
-            self._step(tr, enc, t, captions, bias)
+        # the T decoder steps (:1019-1052) in one native call (the host loop of `_step` in C: the bottom-up path is bound by the
+        # launch rate of the interpreter otherwise)
+        tr["_zz"], tr["_qg"], tr["_lin"] = (torch.empty(B, n * H, device=self.device) for n in (4, 2, 1))
+        sa = AoaStepArgs()
+        sa.glob, sa.emb, sa.tok, sa.tok_ld = ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), captions.shape[1]
+        sa.w_cat, sa.b_cat, sa.w_qg, sa.b_qg = ptr(self.Wcat), ptr(bias), ptr(self.Wqg), ptr(self.bqg)
+        sa.w_lin, sa.b_lin = ptr(sd["decoder_aoa_linear.weight"]), ptr(sd["decoder_aoa_linear.bias"])
+        sa.key, sa.value, sa.zz, sa.qg, sa.lin = ptr(enc["key"]), ptr(enc["value"]), ptr(tr["_zz"]), ptr(tr["_qg"]), ptr(tr["_lin"])
+        check(lib.lrpx_aoa_fwd_steps(c, 0, T, C.byref(sa), st))
         tr["captions"] = captions
         tr["logit"] = torch.empty(B * T, device=self.device)
         check(lib.lrpx_target_logit(ptr(tr["hc"]), ptr(sd["fc.weight"]), ptr(sd["fc.bias"]), ptr(captions), T + 1,
@@ -361,11 +368,10 @@ class AOAEngine:
         a_val = e(rows, P, H)
         check(lib.lrpx_aoa_rel_value(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), st))
         W = E + 2 * H
-        for s in range(T):
-            check(lib.lrpx_aoa_rel_step(ctr, crs, s, 0, st))
-            ops.conv_mfma(rs["A"], self.p_wg, rows, 0, H, W, 1, EPI_REL, pix_per_map=1, oc_split=W, x=tr["xh"],
-                          map2img=idx[s], out0=rs["rx"])
-            check(lib.lrpx_aoa_rel_step(ctr, crs, s, 1, st))
+        # the lock-steps s = 0..T-1 (:1114-1134) in one native call: phase 0, the LSTM dense rule with map2img = idx[s], phase 1
+        dense = ops.conv_desc(rs["A"], self.p_wg, rows, 0, H, W, 1, EPI_REL, pix_per_map=1, oc_split=W, x=tr["xh"],
+                              map2img=idx[0], out0=rs["rx"])
+        check(lib.lrpx_aoa_rel_steps(ctr, crs, T, C.byref(dense), ptr(idx), idx.shape[1], st))
         # :1136-1144  r_proj = eye rule on the mean (U) + v_proj dense rule; fused division for the projector rule
         U = e(rows, H)
         check(lib.lrpx_rel_avg_u(ptr(rs["r_glob"]), ptr(enc["glob"]), ptr(U), rows, T, H, P, st))
@@ -408,11 +414,12 @@ class AOAEngine:
 
 
     def explain_batch_graph(self, captions, head_idx, images=None, features=None, accumulate=False, predictions=False):
-        """`explain_batch` replayed from a captured HIP graph (one per input shape / head): the bottom-up path has no CNN
-        stage, its ~330 launches of 4 - 25 us per step are bound by the HOST's launch rate (one Python thread feeding
-        the streams: 1.4 ms per step of 640 maps against 0.8 ms of GPU work), one hipGraphLaunch per step is not.  Inputs
-        are copied into the graph's static buffers; the returned tensors are the graph's static outputs (overwritten by
-        the next call with the same shapes)."""
+        """`explain_batch` replayed from a captured HIP graph (one per input shape / head), as GridTDEngine.explain_batch_graph:
+        one hipGraphLaunch instead of the ~330 launches of a bottom-up step.  Worth it for a SINGLE batch in flight (the host
+        issues ~4 us per launch); with batches in flight on several streams eager launches are faster (config 5, B = 32:
+        442 000 maps/s eager against 343 000 - 391 000 replayed, gpurun_out/r3g) - a replayed graph does not overlap with its
+        neighbours the way independent kernels do.  Inputs are copied into the graph's static buffers; the returned tensors
+        are the graph's static outputs (overwritten by the next call with the same shapes)."""
         src = features if features is not None else images
         src = src.to(self.device, torch.float32)
         captions = captions.to(self.device, torch.int64)

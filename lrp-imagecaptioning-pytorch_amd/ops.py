@@ -77,9 +77,10 @@ def amax_maps(s, n_maps):
     return out
 
 
-def conv_mfma(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, *, pix_per_map=0, stab=STAB_NONE, oc_split=0,
+def conv_desc(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, *, pix_per_map=0, stab=STAB_NONE, oc_split=0,
               relu=0, bias=None, x=None, u=None, zdiv=None, map2img=None, out0=None, out1=None, bf16x6=0,
               f16x3=0, in_amax=None, out1_amax=None, pool_am=None, out0_amax=None):
+    """the lrpx_conv_desc of one contraction (the tensors must outlive its use: the descriptor holds raw pointers)"""
     d = ConvDesc()
     d.in_, d.wpacked = ptr(_dev(inp)), ptr(_dev(wpacked))
     d.n_maps, d.hw, d.cin, d.n_oc, d.taps, d.pix_per_map = n_maps, hw, cin, n_oc, taps, pix_per_map
@@ -88,6 +89,11 @@ def conv_mfma(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, *, pix_per_map=0, 
     d.in_amax, d.out1_amax, d.pool_am, d.out0_amax = ptr(in_amax), ptr(out1_amax), ptr(pool_am), ptr(out0_amax)
     d.bias, d.x, d.u, d.zdiv, d.map2img = ptr(bias), ptr(x), ptr(u), ptr(zdiv), ptr(map2img)
     d.out0, d.out1 = ptr(out0), ptr(out1)
+    return d
+
+
+def conv_mfma(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, **kw):
+    d = conv_desc(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, **kw)
     check(_lib.load().lrpx_conv_mfma(C.byref(d), stream_ptr()))
 
 

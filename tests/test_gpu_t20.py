@@ -208,7 +208,7 @@ def test_forward_features_vs_fp64_and_batch_independence(g20, g64):
     assert worst < FWD_FP64_BOUND, worst
 
 
-FWD_FP64_BOUND = 4e-6
+FWD_FP64_BOUND = 2.6e-6      # observed 2.04e-6 (round 2: 2.93e-6; with LRPX_FWD_KSPLIT28=4: 1.57e-6)
 
 
 def test_guided_t20_rows_inside_b32_batch_with_lrp_side_by_side(g20, g64):
