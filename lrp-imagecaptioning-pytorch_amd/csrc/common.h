@@ -79,6 +79,7 @@ struct Switches {
     int wide;            // LRPX_WIDE (bit mask, default 7): 8-wave relevance kernels for 56/28 (1), 14 (2), pooled-input 56/28 (4)
     int fwd_ksplit14;    // LRPX_FWD_KSPLIT (default 8): K ranges per tile of the 14x14 forward layers (1 = unsplit)
     int fwd_ksplit28;    // LRPX_FWD_KSPLIT28 (default 1 = unsplit; 2 / 4 built and tested): ... of the 28x28 forward layers
+    int fwd_wide;        // LRPX_FWD_WIDE (bit mask, default 0): 8-wave forward kernels for 112 (1), 56 (2), 28 (4), K-split 14 (8)
     int conv11_f16;      // LRPX_CONV11_F16 (default 1): conv1_1 of the forward trace on the f16x3 kernel; 0 = fp32 MFMA kernel
     int first_valu;      // LRPX_FIRST_VALU: first-layer rule on the VALU kernel (and S from conv1_2 in 16-channel chunks)
     int pool28;          // LRPX_POOL28 (default 1): conv4_3 unpools while staging; 0 = scatter kernel + plain 28x28 kernel

@@ -106,6 +106,10 @@ int launch_h3_112_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_28_fwd(const ConvArgs& a, hipStream_t s);
 int launch_h3_14_fwd(const ConvArgs& a, hipStream_t s);
+int launch_h3_112w_fwd(const ConvArgs& a, hipStream_t s);   // ... 8-wave workgroups (A/B: LRPX_FWD_WIDE)
+int launch_h3_56w_fwd(const ConvArgs& a, hipStream_t s);
+int launch_h3_28w_fwd(const ConvArgs& a, hipStream_t s);
+int launch_h3_14w_plain(const ConvArgs& a, hipStream_t s);
 int launch_h3_224_guided(const ConvArgs& a, hipStream_t s);   // image-gradient chains (guided backprop / plain gradient)
 int launch_h3_112_guided(const ConvArgs& a, hipStream_t s);
 int launch_h3_56_guided(const ConvArgs& a, hipStream_t s);
@@ -122,6 +126,7 @@ int launch_h3_28_pool(const ConvArgs& a, hipStream_t s);
 
 // dense relevance GEMMs with many rows on the fp16 matrix cores (dense_f16x3.hip)
 int launch_dense_f16x3(const ConvArgs& a, hipStream_t s);
+int launch_dense_small_f16x3(const ConvArgs& a, hipStream_t s);     // few rows: whole K per workgroup, row scales found in-kernel
 
 // few-row dense GEMMs (dense_small.hip)
 bool dense_small_fits(const ConvArgs& a);

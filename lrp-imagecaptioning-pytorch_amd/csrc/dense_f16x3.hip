@@ -186,6 +186,145 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_t
     }
 }
 
+
+// ---- few rows (the lock-step gate rules of the decoders: rows = images x words, 320 .. 1280; K = 512) -------------------
+// dense_small.hip on the fp16 matrix cores: one workgroup = 32 rows x 128 columns, the whole 32 x K slab of A staged ONCE
+// into LDS - scaled per ROW by 2^kA from the row's own maximum (found while staging: the slab passes through registers) and
+// split a = a0 + a1 - then 3 MFMAs (32 cycles each) per 16 of K instead of 8 fp32 MFMAs (64 cycles each): the serial chain
+// of one wave drops from 16 k to 3 k matrix cycles.  B fragments stream from the f16x2 pack through a register queue.
+// Epilogue REL (out0 only): out = X[src(row)] * (acc + U).  K <= 1024, K % 16 == 0.
+constexpr int DS_NB = 6;
+__global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mtile = blockIdx.x / n_blocks, nblk = blockIdx.x % n_blocks;
+    const int K = a.cin, nks = K / 16, k4 = K / 4;
+    const int pitch = nks * 64 + 16;
+    unsigned* rowmax = reinterpret_cast<unsigned*>(ldsb + 32 * pitch);        // [32] float bits of max|A[row]|
+    const long rows = (long)a.n_maps * a.pix_per_map;
+    const long row0 = (long)mtile * 32;
+    const int ocb = nblk * 4 + wave;
+    const int ocb_last = (a.n_oc - 1) / 32;
+    const bool wave_active = ocb <= ocb_last;
+    const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) + (long)min(ocb, ocb_last) * nks * 128 + lane;
+    u32x4_ bq[DS_NB][2];
+#pragma unroll
+    for (int i = 0; i < DS_NB - 1; ++i) { bq[i][0] = wp[(long)min(i, nks - 1) * 128]; bq[i][1] = wp[(long)min(i, nks - 1) * 128 + 64]; }
+    if (tid < 32) rowmax[tid] = 0u;
+    __syncthreads();
+    // pass 1: the slab through registers (<= 32 float4 per thread), row maxima into LDS
+    constexpr int MAXU = 32;                       // 32 rows x 1024 / 4 / 256
+    f32x4 sv[MAXU];
+    const int nu = (32 * k4 + 255) / 256;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+        sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < nu) {
+            const int it = tid + 256 * u;
+            const int r = it / k4, c4 = it - r * k4;
+            if (it < 32 * k4 && row0 + r < rows) sv[u] = *reinterpret_cast<const f32x4*>(a.in + (row0 + r) * K + c4 * 4);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+        if (u < nu) {
+            const int it = tid + 256 * u;
+            const int r = it / k4;
+            float m = fmaxf(fmaxf(fabsf(sv[u][0]), fabsf(sv[u][1])), fmaxf(fabsf(sv[u][2]), fabsf(sv[u][3])));
+            if ((k4 & 63) == 0) {                  // a wave's 64 items lie in one row: one LDS atomic per wave
+                m = wave_max(m);
+                if (lane == 0 && it < 32 * k4) atomicMax(&rowmax[r], __builtin_bit_cast(unsigned, m));
+            } else if (it < 32 * k4) {
+                atomicMax(&rowmax[r], __builtin_bit_cast(unsigned, m));
+            }
+        }
+    }
+    __syncthreads();
+    // pass 2: scale, split, LDS.  Row layout: [k-step][hi: lane group 0, 1 | lo: lane group 0, 1] x 16 B
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+        if (u < nu) {
+            const int it = tid + 256 * u;
+            if (it < 32 * k4) {
+                const int r = it / k4, c4 = it - r * k4;
+                const float sc = exp2i(f16_scale_exp(rowmax[r]));
+                _Float16 h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(sv[u][e] * sc, h[e], l[e]);
+                char* d_ = ldsb + r * pitch + (c4 >> 2) * 64 + ((c4 >> 1) & 1) * 16 + (c4 & 1) * 8;
+                *reinterpret_cast<u32x2_*>(d_) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};
+                *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};
+            }
+        }
+    }
+    __syncthreads();
+    if (!wave_active) return;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const char* ap = ldsb + li * pitch + lh * 16;
+    for (int ks = 0; ks < nks; ks += DS_NB) {
+#pragma unroll
+        for (int u = 0; u < DS_NB; ++u) {
+            const int step = ks + u;
+            const long nxt = (long)min(step + DS_NB - 1, nks - 1) * 128;
+            bq[DS_NB - 1][0] = wp[nxt]; bq[DS_NB - 1][1] = wp[nxt + 64];
+            if (step < nks) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(ap + step * 64);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(ap + step * 64 + 32);
+                const f16x8 bh = __builtin_bit_cast(f16x8, bq[0][0]), bl = __builtin_bit_cast(f16x8, bq[0][1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);      // small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < DS_NB - 1; ++i) { bq[i][0] = bq[i + 1][0]; bq[i][1] = bq[i + 1][1]; }
+        }
+    }
+    const int oc = ocb * 32 + li;
+    const int ncol = a.oc_split;
+    if (oc >= ncol) return;
+    const unsigned P = (unsigned)a.pix_per_map;
+    const float inv_w = a.wp[0];
+    float xv[16];
+    long nn[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const long row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        xv[e] = 0.f; nn[e] = 0;
+        if (row < rows) {
+            const long n = row / P, p = row - n * P;
+            const long img = a.map2img ? a.map2img[n] : n;
+            nn[e] = n;
+            xv[e] = a.X[(img * P + p) * ncol + oc];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int rl = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const long row = row0 + rl;
+        if (row >= rows) continue;
+        float v = acc[e] * (exp2i(-f16_scale_exp(rowmax[rl])) * inv_w);
+        if (a.U) v += a.U[nn[e] * ncol + oc];
+        a.out0[row * ncol + oc] = xv[e] * v;
+    }
+}
+
+int launch_dense_small_f16x3(const ConvArgs& a, hipStream_t stream) {
+    const long rows = (long)a.n_maps * a.pix_per_map;
+    LRPX_REQUIRE(a.cin % 16 == 0 && a.cin >= 16 && a.cin <= 1024, "dense_small_f16x3: K = %d (a multiple of 16, <= 1024)", a.cin);
+    LRPX_REQUIRE(a.X && a.out0 && !a.out1 && rows > 0, "dense_small_f16x3: REL epilogue with x and out0 only");
+    const int m_tiles = (int)ceil_div(rows, 32);
+    const int n_blocks = (int)ceil_div(a.n_oc, 128);
+    const int lds = 32 * ((a.cin / 16) * 64 + 16) + 128;
+    constexpr int LDS_MAX = 32 * (64 * 64 + 16) + 128;
+    static LdsOnce once;
+    LRPX_TRY(reserve_lds_once(once, dense_small_f16x3_kernel, LDS_MAX, "dense_small_f16x3"));
+    hipLaunchKernelGGL(dense_small_f16x3_kernel, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks);
+    return check_launch("dense_small_f16x3");
+}
+
 int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
     const long M = (long)a.n_maps * a.pix_per_map;
     LRPX_REQUIRE(a.cin % DH_KC == 0 && a.cin >= DH_KC, "dense_f16x3: K = %d is not a multiple of %d", a.cin, DH_KC);

@@ -29,6 +29,7 @@ const Switches& switches() {
         w.wide = num("LRPX_WIDE", 7);
         w.fwd_ksplit14 = num("LRPX_FWD_KSPLIT", 8);
         w.fwd_ksplit28 = num("LRPX_FWD_KSPLIT28", 1);
+        w.fwd_wide = num("LRPX_FWD_WIDE", 0);
         w.conv11_f16 = num("LRPX_CONV11_F16", 1);
         w.first_valu = set("LRPX_FIRST_VALU");
         w.pool28 = num("LRPX_POOL28", 1);

@@ -33,8 +33,11 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
     // many rows (the (word, pixel) rules of the decoders): split products on the fp16 matrix cores (dense_f16x3.hip);
     // `wpacked` is then an lrpx_pack_weights_f16x2 blob (taps = 1) and `in_amax` holds max|in| per map
     if (d->taps == 1 && d->f16x3) {
-        LRPX_REQUIRE(d->f16x3 == 1 && d->epi == EPI_REL && d->x && d->in_amax && d->pix_per_map > 0,
-                     "conv_mfma: the dense f16x3 GEMM is built for the REL epilogue (needs x, in_amax, pix_per_map)");
+        LRPX_REQUIRE(d->f16x3 == 1 && d->epi == EPI_REL && d->x && d->pix_per_map > 0,
+                     "conv_mfma: the dense f16x3 GEMMs are built for the REL epilogue (need x, pix_per_map)");
+        // few rows (the lock-step gate rules): whole K per workgroup, per-row operand scales found while staging
+        if ((long)d->n_maps * d->pix_per_map <= 4096 && d->cin <= 1024 && !d->out1) return launch_dense_small_f16x3(a, s);
+        LRPX_REQUIRE(d->in_amax, "conv_mfma: the many-row dense f16x3 GEMM needs in_amax (max|in| per map)");
         LRPX_REQUIRE(!d->out1 || d->zdiv || d->stab == STAB_NONE, "conv_mfma: REL out1 needs zdiv");
         return launch_dense_f16x3(a, s);
     }
@@ -117,6 +120,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
             LRPX_REQUIRE(false, "conv_mfma: no f16x3 GUIDED kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
         }
         if (d->epi == EPI_PLAIN) {
+            if ((switches().fwd_wide & 8) && d->hw == 14 && d->n_oc >= 256 && a.ksplit > 1) return launch_h3_14w_plain(a, s);
             if (d->hw == 112 && d->n_oc <= 64) return launch_h3_112n_plain(a, s);
             if (d->hw == 56) return launch_h3_56_plain(a, s);
             if (d->hw == 28) return launch_h3_28_plain(a, s);
@@ -124,6 +128,10 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
             LRPX_REQUIRE(false, "conv_mfma: no f16x3 PLAIN kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
         }
         if (d->epi == EPI_FWD_DUAL) {
+            const int fw = switches().fwd_wide;
+            if ((fw & 1) && d->hw == 112 && d->n_oc >= 256) return launch_h3_112w_fwd(a, s);
+            if ((fw & 2) && d->hw == 56 && d->n_oc >= 256) return launch_h3_56w_fwd(a, s);
+            if ((fw & 4) && d->hw == 28 && d->n_oc >= 256) return launch_h3_28w_fwd(a, s);
             if (d->hw == 224) return launch_h3_224_fwd(a, s);
             if (d->hw == 112) return launch_h3_112_fwd(a, s);
             if (d->hw == 56) return launch_h3_56_fwd(a, s);

@@ -60,6 +60,10 @@ class AOAEngine:
         if H % 64 == 0:
             self.p_v_rel_h = ops.pack_weights_f16x2(sd["decoder_v_proj.weight"], H, H, _lib.PACK_BWD_PLAIN, taps=1)
             self.p_proj_rel_h = ops.pack_weights_f16x2(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1)
+        # ... and the lock-step gate rule / the aoa_linear rule (rows = images x words): the few-row kernel of the same file
+        self.lockstep_f16 = H % 16 == 0 and E % 16 == 0
+        self.p_wg_h = ops.pack_weights_f16x2(wg, H, E + 2 * H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
+        self.p_lin_rel_h = ops.pack_weights_f16x2(sd["decoder_aoa_linear.weight"], H, H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
         # gradient explainers (:1435-1499): contraction over the 4H gate rows / over the outputs of the two aoa linears
         self.p_gates_grad = ops.pack_weights(self.Wcat, 4 * H, E + 2 * H, 1, PACK_DENSE_T, kc)
         self.p_gate_grad = ops.pack_weights(sd["decoder_aoa_linear_gate.weight"], H, H, 1, PACK_DENSE_T, kc)
@@ -363,14 +367,15 @@ class AOAEngine:
         check(lib.lrpx_aoa_rel_init(ctr, crs, ptr(self.sd["fc.weight"]), ptr(tr["logit"]), ptr(tr["captions"]), T + 1, st))
         # decoder_aoa_linear dense rule (:1107-1110): r_ctx = ctx * (W^T (r_caoa / z~(lin)))
         r_ctx = e(rows, H)
-        ops.conv_mfma(rs["A"], self.p_lin_rel, rows, 0, H, H, 1, EPI_REL, pix_per_map=1, oc_split=H, x=tr["ctx"],
-                      map2img=rowid, out0=r_ctx)
+        f16 = 1 if self.lockstep_f16 else 0
+        ops.conv_mfma(rs["A"], self.p_lin_rel_h if f16 else self.p_lin_rel, rows, 0, H, H, 1, EPI_REL, pix_per_map=1, oc_split=H,
+                      x=tr["ctx"], map2img=rowid, out0=r_ctx, f16x3=f16)
         a_val = e(rows, P, H)
         check(lib.lrpx_aoa_rel_value(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), st))
         W = E + 2 * H
         # the lock-steps s = 0..T-1 (:1114-1134) in one native call: phase 0, the LSTM dense rule with map2img = idx[s], phase 1
-        dense = ops.conv_desc(rs["A"], self.p_wg, rows, 0, H, W, 1, EPI_REL, pix_per_map=1, oc_split=W, x=tr["xh"],
-                              map2img=idx[0], out0=rs["rx"])
+        dense = ops.conv_desc(rs["A"], self.p_wg_h if f16 else self.p_wg, rows, 0, H, W, 1, EPI_REL, pix_per_map=1, oc_split=W,
+                              x=tr["xh"], map2img=idx[0], out0=rs["rx"], f16x3=f16)
         check(lib.lrpx_aoa_rel_steps(ctr, crs, T, C.byref(dense), ptr(idx), idx.shape[1], st))
         # :1136-1144  r_proj = eye rule on the mean (U) + v_proj dense rule; fused division for the projector rule
         U = e(rows, H)

@@ -70,6 +70,12 @@ class GridTDEngine:
         self.p_proj_rel = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE_T, kc)
         # the projector rule runs over every (word, pixel) row: split products on the fp16 matrix cores (csrc/dense_f16x3.hip)
         self.p_proj_rel_h = ops.pack_weights_f16x2(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1) if H % 64 == 0 else None
+        # ... and the lock-step gate rules (rows = images x words): the few-row kernel of the same file.  `lockstep_f16 = False`
+        # puts them back on the fp32 MFMA (csrc/dense_small.hip; A/B: tools/phase_times.py --lockstep-fp32)
+        self.lockstep_f16 = H % 16 == 0 and E % 16 == 0
+        self.p_wg1_h = ops.pack_weights_f16x2(wg1, H, 2 * E + 2 * H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
+        self.p_wg2_h = ops.pack_weights_f16x2(wg2, H, 3 * H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
+        self.p_gp_rel_h = ops.pack_weights_f16x2(sd["global_img_feature_proj.weight"], E, Cc, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
         torch.cuda.synchronize()
         self._idx_cache = {}
 
@@ -341,20 +347,21 @@ class GridTDEngine:
         check(lib.lrpx_gridtd_rel_init(ctr, crs, ptr(self.sd["fc.weight"]), ptr(tr["logit"]), ptr(tr["captions"]),
                                        T + 1, st))
         W1 = 2 * E + 2 * H
+        f16 = 1 if self.lockstep_f16 else 0
         for s in range(T):
             check(lib.lrpx_gridtd_rel_step(ctr, crs, s, 0, st))
-            ops.conv_mfma(rs["A"], self.p_wg2, rows, 0, H, 3 * H, 1, EPI_REL, pix_per_map=1, oc_split=3 * H,
-                          x=tr["xh2"], map2img=idx[s], out0=rs["rx"])
+            ops.conv_mfma(rs["A"], self.p_wg2_h if f16 else self.p_wg2, rows, 0, H, 3 * H, 1, EPI_REL, pix_per_map=1, oc_split=3 * H,
+                          x=tr["xh2"], map2img=idx[s], out0=rs["rx"], f16x3=f16)
             check(lib.lrpx_gridtd_rel_step(ctr, crs, s, 1, st))
-            ops.conv_mfma(rs["A"], self.p_wg1, rows, 0, H, W1, 1, EPI_REL, pix_per_map=1, oc_split=W1,
-                          x=tr["xh1"], map2img=idx[s], out0=rs["rx"])
+            ops.conv_mfma(rs["A"], self.p_wg1_h if f16 else self.p_wg1, rows, 0, H, W1, 1, EPI_REL, pix_per_map=1, oc_split=W1,
+                          x=tr["xh1"], map2img=idx[s], out0=rs["rx"], f16x3=f16)
             check(lib.lrpx_gridtd_rel_step(ctr, crs, s, 2, st))
         # global feature path (:1116-1124) and projector (:1125-1128)
         a_glob = e(rows, E)
         check(lib.lrpx_gridtd_rel_glob(ctr, crs, ptr(enc["glob_pre"]), ptr(a_glob), st))
         r_avg = e(rows, Cc)
-        ops.conv_mfma(a_glob, self.p_gp_rel, rows, 0, E, Cc, 1, EPI_REL, pix_per_map=1, oc_split=Cc, x=enc["avg"],
-                      map2img=row2img, out0=r_avg)
+        ops.conv_mfma(a_glob, self.p_gp_rel_h if f16 else self.p_gp_rel, rows, 0, E, -(-Cc // 32) * 32 if f16 else Cc, 1, EPI_REL,
+                      pix_per_map=1, oc_split=Cc, x=enc["avg"], map2img=row2img, out0=r_avg, f16x3=f16)
         U = e(rows, Cc)
         check(lib.lrpx_rel_avg_u(ptr(r_avg), ptr(enc["avg"]), ptr(U), rows, T, Cc, P, st))
         a_proj = e(rows, P, H)

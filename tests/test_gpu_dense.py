@@ -107,3 +107,32 @@ def test_dense_f16x3_rel_many_rows(ops, n_maps, P, k, n, n_img):
         assert e0 < 2e-6 and e1 < 4e-6, (m, e0, e1)
         assert amax_out[m:m + 1].view(torch.float32).item() == buf1[:rows * n].view(n_maps, P, n)[m].abs().max().item()
     print(f"dense f16x3 ({n_maps} maps x {P} rows, {k} -> {n}): worst map {worst:.2e} of its maximum")
+
+
+@pytest.mark.parametrize("rows,k,n,n_src", [(320, 512, 1536, 16), (1280, 512, 2048, 64), (37, 96, 64, 5), (640, 1024, 160, 640)])
+def test_dense_f16x3_rel_few_rows(ops, rows, k, n, n_src):
+    """the lock-step gate rules on the fp16 matrix cores (dense_small_f16x3_kernel): out[row] = X[src(row)] * (A[row] W + U[row]),
+    row scales found in-kernel - rows 1e-12 .. 1e12 apart, an all-zero row, row counts off the 32-row tile - against fp64"""
+    from lrp_amd import _lib
+    g = torch.Generator().manual_seed(rows + k)
+    a = torch.randn(rows, k, generator=g) * torch.exp(1.5 * torch.randn(rows, k, generator=g)) * torch.logspace(-12, 12, rows).view(-1, 1)
+    a[rows // 3] = 0.0
+    w = torch.randn(k, n, generator=g) * 0.05
+    x = torch.randn(n_src, n, generator=g)
+    u = torch.randn(rows, n, generator=g) * a.abs().amax(dim=1, keepdim=True) * 0.2
+    src = torch.randint(0, n_src, (rows,), generator=g).to(torch.int32)
+    n_pad = -(-n // 32) * 32
+    wp = ops.pack_weights_f16x2(w.cuda(), k, n, _lib.PACK_BWD_PLAIN, taps=1)
+    buf = torch.full((rows * n + 4096,), 555.0, device="cuda")
+    ops.conv_mfma(a.cuda(), wp, rows, 0, k, n_pad, 1, _lib.EPI_REL, pix_per_map=1, oc_split=n, x=x.cuda(), u=u.cuda(),
+                  map2img=src.cuda(), out0=buf[:rows * n], f16x3=1)
+    torch.cuda.synchronize()
+    assert (buf[rows * n:] == 555.0).all()
+    got = buf[:rows * n].view(rows, n).cpu().double()
+    want = x[src.long()].double() * (a.double() @ w.double() + u.double())
+    scale = want.abs().amax(dim=1)
+    live = scale > 0
+    err = ((got - want).abs().amax(dim=1)[live] / scale[live]).max().item()
+    assert got[~live].abs().max().item() == 0 if (~live).any() else True
+    print(f"dense f16x3, few rows ({rows} x {k} -> {n}): worst row {err:.2e} of its maximum")
+    assert err < 2e-6

@@ -48,7 +48,7 @@ def default_run(tmp_path_factory):
     return _run(tmp_path_factory.mktemp("sw"), "default", {})
 
 
-SWITCHES = [("LRPX_CONV11_F16", "0"), ("LRPX_WIDE", "0"), ("LRPX_FWD_KSPLIT", "1"), ("LRPX_FWD_KSPLIT28", "4"), ("LRPX_FIRST_VALU", "1"), ("LRPX_POOL28", "0"),
+SWITCHES = [("LRPX_FWD_WIDE", "15"), ("LRPX_CONV11_F16", "0"), ("LRPX_WIDE", "0"), ("LRPX_FWD_KSPLIT", "1"), ("LRPX_FWD_KSPLIT28", "4"), ("LRPX_FIRST_VALU", "1"), ("LRPX_POOL28", "0"),
             ("LRPX_S21_NHWC", "1"), ("LRPX_GUIDED_POOLBWD", "1"), ("LRPX_DENSE_1WAVE", "1"), ("LRPX_LINEAR_VALU", "1")]
 
 

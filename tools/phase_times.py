@@ -8,6 +8,8 @@ from lrp_amd import weights, ops
 from lrp_amd.explainers.gridtd import GridTDEngine
 B, T, V = 16, 20, 9586
 eng = GridTDEngine(weights.make_gridtd_state(seed=0, vocab_size=V))
+if "--lockstep-fp32" in sys.argv:
+    eng.lockstep_f16 = False
 images = torch.from_numpy(weights.make_images(100, B)).cuda()
 caps = torch.from_numpy(weights.make_captions(200, B, T, V)).cuda()
 names = ["encode", "trace", "relevance", "chain", "cumsum"]
