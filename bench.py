@@ -163,6 +163,7 @@ def parse(argv=None):
                          "latency-bound kernels of one batch overlap the MFMA-bound CNN chain of another")
     ap.add_argument("--host-threads", action="store_true", help="one host thread per batch in flight issues that batch's launches (A/B: config 5 is "
                     "bound by the GPU's dispatch rate of dependent small kernels, not by the host: 430 000 against 480 000 maps/s)")
+    ap.add_argument("--chain-streams", type=int, default=1, help="HIP streams the maps of one VGG16 relevance pass are split over (maps are independent)")
     ap.add_argument("--fp32-mfma", action="store_true", help="same as --conv-mode 0")
     ap.add_argument("--conv-mode", type=int, default=3, choices=[0, 1, 2, 3],
                     help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp8 cross products (default)")
@@ -282,7 +283,7 @@ def run_config(a, dist, rank, world):
             enc = e.encode(images)
             tr = e.trace(enc, caps, predictions=True)
             r_feat, r_words, row2img = e.relevance(enc, tr)
-            maps = e.vgg.relevance(r_feat, row2img, out=buf("maps", k, B * T, 3, 224, 224))
+            maps = e.vgg.relevance(r_feat, row2img, out=buf("maps", k, B * T, 3, 224, 224), streams=a.chain_streams)
             cum = ops.cumsum_maps(maps, B, T, out=buf("cum", k, B * T, 3, 224, 224))   # explain_caption's running sums
             if k == 0:
                 state["chain_in"] = (r_feat, row2img)
@@ -303,7 +304,7 @@ def run_config(a, dist, rank, world):
             tr = e.trace(enc, caps, predictions=True)
             for hd in heads:          # (--all-heads: the heads share the traces, everything behind `lrp_mha` is per head)
                 r_feat, r_words, row2img = e.relevance(enc, tr, hd)
-                maps = e.vgg.relevance(r_feat, row2img, out=buf("maps", k, B * T, 3, 224, 224))
+                maps = e.vgg.relevance(r_feat, row2img, out=buf("maps", k, B * T, 3, 224, 224), streams=a.chain_streams)
                 cum = ops.cumsum_maps(maps, B, T, out=buf(f"cum{hd}_", k, B * T, 3, 224, 224))
             if k == 0:
                 state["chain_in"] = (r_feat, row2img)

@@ -78,13 +78,15 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_t
     const u32x4_* wp0 = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) + (long)min(ocb0, ocb_last) * nks * 128 + lane;
     const u32x4_* wp1 = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) + (long)min(ocb0 + 1, ocb_last) * nks * 128 + lane;
     const float inv_w = a.wp[0];
-    u32x4_ bq[2][4];                 // [current / next k-step][tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo]
-    auto load_b = [&](const int ks, u32x4_ (&b)[4]) {
+    constexpr int DH_NBQ = 4;        // B queue: k-step s + 3 is loaded while k-step s multiplies (12 MFMAs = 384 matrix cycles per
+    u32x4_ bq[DH_NBQ][4];            // k-step against an L2 round trip of ~1000: one step ahead left the pipe waiting - 278 us)
+    auto load_b = [&](const int ks, u32x4_ (&b)[4]) {        // [tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo]
         const int k = min(ks, nks - 1);
         b[0] = wp0[(long)k * 128]; b[1] = wp0[(long)k * 128 + 64];
         b[2] = wp1[(long)k * 128]; b[3] = wp1[(long)k * 128 + 64];
     };
-    load_b(0, bq[0]);
+#pragma unroll
+    for (int i = 0; i < DH_NBQ - 1; ++i) load_b(i, bq[i]);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -105,12 +107,12 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_t
         const char* abuf = ldsb + (chunk & 1) * DH_BUF + a_off;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            load_b(chunk * 4 + s + 1, bq[(s + 1) & 1]);
+            load_b(chunk * 4 + s + DH_NBQ - 1, bq[(s + DH_NBQ - 1) % DH_NBQ]);
             const f16x8 a0h = *reinterpret_cast<const f16x8*>(abuf + s * 64);
             const f16x8 a0l = *reinterpret_cast<const f16x8*>(abuf + s * 64 + 32);
             const f16x8 a1h = *reinterpret_cast<const f16x8*>(abuf + 32 * DH_ROWB + s * 64);
             const f16x8 a1l = *reinterpret_cast<const f16x8*>(abuf + 32 * DH_ROWB + s * 64 + 32);
-            const u32x4_(&b)[4] = bq[s & 1];
+            const u32x4_(&b)[4] = bq[s % DH_NBQ];
             const f16x8 b0h = __builtin_bit_cast(f16x8, b[0]), b0l = __builtin_bit_cast(f16x8, b[1]);
             const f16x8 b1h = __builtin_bit_cast(f16x8, b[2]), b1l = __builtin_bit_cast(f16x8, b[3]);
             // small terms first
@@ -151,28 +153,44 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_t
         const long rt = row0 + wm * 64 + 32 * i;
         const unsigned nt0 = (unsigned)(rt < M ? rt : M - 1) / P;
         float m0 = 0.f, m1 = 0.f;
+        // Three phases so that the loads of a phase are issued back to back (one dependent chain per element - row -> map ->
+        // image -> multiplicand - made the epilogue the longest part of the kernel: 278 us for 62 720 x 512 x 512):
+        // (1) per row: map, image, operand scale; (2) all multiplicands / addends / denominators; (3) arithmetic and stores.
+        unsigned nn[16], xb[16];
+        float sc[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const long r = rt + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (r >= M) continue;
-            const unsigned n = (unsigned)r / P, p = (unsigned)r - n * P;
-            const long img = m2i ? m2i[n] : (long)n;
-            const float inv_a = exp2i(-f16_scale_exp(in_amax[n])) * inv_w;
+            const long rc = r < M ? r : M - 1;
+            const unsigned n = (unsigned)rc / P, p = (unsigned)rc - n * P;
+            nn[e] = n;
+            const unsigned img = m2i ? (unsigned)m2i[n] : n;
+            xb[e] = (img * P + p) * (unsigned)ncol;               // (< 2^31: host-checked)
+            sc[e] = exp2i(-f16_scale_exp(in_amax[n])) * inv_w;
+        }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int oc = (ocb0 + j) * 32 + li;
-                if (oc >= ncol) continue;
-                float v = acc[i][j][e] * inv_a;
-                if (Uu) v += Uu[(long)n * ncol + oc];
-                const long xi = (img * P + p) * ncol + oc;
-                const float rel = X[xi] * v;
+        for (int j = 0; j < 2; ++j) {
+            const int oc = (ocb0 + j) * 32 + li;
+            if (oc >= ncol) continue;
+            float xv[16], uv[16], zv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                xv[e] = X[xb[e] + oc];
+                uv[e] = Uu ? Uu[(long)nn[e] * ncol + oc] : 0.f;
+                zv[e] = (o1 && Zd) ? Zd[xb[e] + oc] : 1.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long r = rt + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (r >= M) continue;
+                const float rel = xv[e] * (acc[i][j][e] * sc[e] + uv[e]);
                 if (o0) o0[r * ncol + oc] = rel;
                 if (o1) {
-                    float z = Zd ? Zd[xi] : 1.f;
+                    float z = zv[e];
                     z = (a.stab == STAB_SAFE) ? stab_safe(z) : ((a.stab == STAB_EPS) ? stab_eps(z) : z);
                     const float sv_ = fast_div(rel, z);
                     o1[r * ncol + oc] = sv_;
-                    if (n == nt0) m0 = fmaxf(m0, fabsf(sv_)); else m1 = fmaxf(m1, fabsf(sv_));
+                    if (nn[e] == nt0) m0 = fmaxf(m0, fabsf(sv_)); else m1 = fmaxf(m1, fabsf(sv_));
                 }
             }
         }
@@ -186,14 +204,16 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_t
     }
 }
 
-
 // ---- few rows (the lock-step gate rules of the decoders: rows = images x words, 320 .. 1280; K = 512) -------------------
 // dense_small.hip on the fp16 matrix cores: one workgroup = 32 rows x 128 columns, the whole 32 x K slab of A staged ONCE
 // into LDS - scaled per ROW by 2^kA from the row's own maximum (found while staging: the slab passes through registers) and
 // split a = a0 + a1 - then 3 MFMAs (32 cycles each) per 16 of K instead of 8 fp32 MFMAs (64 cycles each): the serial chain
 // of one wave drops from 16 k to 3 k matrix cycles.  B fragments stream from the f16x2 pack through a register queue.
 // Epilogue REL (out0 only): out = X[src(row)] * (acc + U).  K <= 1024, K % 16 == 0.
-constexpr int DS_NB = 6;
+// B queue: 11 k-steps ahead (a k-step is 3 MFMAs = 96 matrix cycles, an L2 round trip ~1000: 5 ahead left the K loop bound by
+// the load latency - 28 us per GEMM against 25 for the fp32 kernel it replaces)
+constexpr int DS_NB = 12;
+template <int MAXU>        // float4 items of the A slab per thread: 16 for K <= 512, 32 for K <= 1024
 __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -214,7 +234,6 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
     if (tid < 32) rowmax[tid] = 0u;
     __syncthreads();
     // pass 1: the slab through registers (<= 32 float4 per thread), row maxima into LDS
-    constexpr int MAXU = 32;                       // 32 rows x 1024 / 4 / 256
     f32x4 sv[MAXU];
     const int nu = (32 * k4 + 255) / 256;
 #pragma unroll
@@ -319,9 +338,11 @@ int launch_dense_small_f16x3(const ConvArgs& a, hipStream_t stream) {
     const int n_blocks = (int)ceil_div(a.n_oc, 128);
     const int lds = 32 * ((a.cin / 16) * 64 + 16) + 128;
     constexpr int LDS_MAX = 32 * (64 * 64 + 16) + 128;
-    static LdsOnce once;
-    LRPX_TRY(reserve_lds_once(once, dense_small_f16x3_kernel, LDS_MAX, "dense_small_f16x3"));
-    hipLaunchKernelGGL(dense_small_f16x3_kernel, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks);
+    const bool big = a.cin > 512;
+    auto kern = big ? dense_small_f16x3_kernel<32> : dense_small_f16x3_kernel<16>;
+    static LdsOnce once[2];
+    LRPX_TRY(reserve_lds_once(once[big], kern, LDS_MAX, "dense_small_f16x3"));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks);
     return check_launch("dense_small_f16x3");
 }
 
@@ -330,6 +351,7 @@ int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
     LRPX_REQUIRE(a.cin % DH_KC == 0 && a.cin >= DH_KC, "dense_f16x3: K = %d is not a multiple of %d", a.cin, DH_KC);
     LRPX_REQUIRE(a.in_amax && a.X && (a.out0 || a.out1), "dense_f16x3: needs in_amax, x and an output");
     LRPX_REQUIRE(M > 0 && M < 0x7fffffffL, "dense_f16x3: %ld rows out of range", M);
+    LRPX_REQUIRE((long)a.n_maps * a.pix_per_map * a.oc_split < 0x7fffffffL, "dense_f16x3: too many multiplicand elements for 32-bit offsets");
     LRPX_REQUIRE(!(a.out1 && a.out1_amax) || a.pix_per_map >= 32, "dense_f16x3: out1_amax needs at least 32 rows per map");
     const long m_tiles = ceil_div(M, DH_BM);
     const int n_blocks = (int)ceil_div(a.n_oc, DH_BN);

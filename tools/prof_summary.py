@@ -3,7 +3,8 @@
    prof_summary.py stats <dir>            kernel table (calls, total ms, avg us, %) from *_kernel_stats.csv
    prof_summary.py traffic <dirB> <dirC>  per kernel FETCH_SIZE / WRITE_SIZE sums (GB) and L2 hit rate from two --pmc passes
    prof_summary.py traffic-json <maps_per_launch> <dirB> <dirC>   the same as JSON (read by bench.py for roofline.traffic)
-   prof_summary.py sq <dir> [<dir>...]    per kernel means of every SQ counter found (per launch)"""
+   prof_summary.py sq <dir> [<dir>...]    per kernel means of every SQ counter found (per launch)
+   prof_summary.py pipe <dir> [<dir>...]  matrix-pipe utilisation per kernel (MFMA busy cycles / GPU cycles), MFMA op mix"""
 import collections, csv, glob, os, re, sys
 
 
@@ -73,5 +74,20 @@ def sq(dirs):
             print(f"   {name:36s} {sum(v)/len(v):16.0f}")
 
 
+def pipe(dirs):
+    """matrix-pipe utilisation per kernel from the counters: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / 1024 against
+    GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs), per-launch means; MFMA operations by type; LDS bank-conflict share"""
+    data = counters(dirs)
+    print(f"{'kernel':64s} {'launches':>8s} {'Mcycles':>9s} {'pipe busy':>10s} {'MOPS f16':>10s} {'MOPS f8':>10s} {'MOPS f32':>10s} {'LDS confl':>10s}")
+    for k, c in sorted(data.items()):
+        if "GRBM_GUI_ACTIVE" not in c or "SQ_VALU_MFMA_BUSY_CYCLES" not in c:
+            continue
+        m = lambda n: sum(c[n]) / len(c[n]) if n in c else 0.0
+        gui = m("GRBM_GUI_ACTIVE") / 8
+        print(f"{k[:64]:64s} {len(c['SQ_VALU_MFMA_BUSY_CYCLES']):8d} {gui/1e6:9.3f} {m('SQ_VALU_MFMA_BUSY_CYCLES')/1024/max(gui,1):10.3f} "
+              f"{m('SQ_INSTS_VALU_MFMA_MOPS_F16')/1e9:10.2f} {m('SQ_INSTS_VALU_MFMA_MOPS_F8')/1e9:10.2f} {m('SQ_INSTS_VALU_MFMA_MOPS_F32')/1e9:10.2f} "
+              f"{m('SQ_LDS_BANK_CONFLICT')/max(m('SQ_LDS_IDX_ACTIVE'),1):10.3f}")
+
+
 if __name__ == "__main__":
-    {"stats": lambda a: stats(a[0]), "traffic": traffic, "traffic-json": traffic_json, "sq": sq}[sys.argv[1]](sys.argv[2:])
+    {"stats": lambda a: stats(a[0]), "traffic": traffic, "traffic-json": traffic_json, "sq": sq, "pipe": pipe}[sys.argv[1]](sys.argv[2:])
