@@ -70,7 +70,7 @@ MODE_DTYPE = {0: "f32", 1: "bf16x6 split products, f32 accumulate", 2: "f16x3 sp
 # HBM traffic of the dominant kernel per launch: tools/prof_summary.py traffic --json writes this file from the two --pmc
 # passes (FETCH_SIZE / WRITE_SIZE, separate from any tracing); bytes = 2 x FETCH_SIZE raw [gfx950 reports half of wide
 # streaming reads, MI355X_MICROARCH.md §HBM] + WRITE_SIZE, divided by the launches and scaled to the maps of this run
-TRAFFIC_FILES = ["profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
+TRAFFIC_FILES = ["profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
 TRAFFIC_KERNEL = {0: "conv_mfma_kernel<56, 16, 1, 4, 9, 1>", 1: "conv_bf16x6_kernel<56, 1, 4, true, 1>",
                   2: "conv_f16x3_kernel<56, 1, 4, true, 5, false, false>", 3: "conv_f16x3_kernel<28, 1, 8, true, 5, false, true>"}
 

@@ -928,11 +928,20 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 }
                 }
             } else {
-            f16x8 n0, n1;
+#ifndef LRPXH_APIPE_D
+#define LRPXH_APIPE_D 1       // A fragments read this many accumulator tiles ahead of their MFMAs (non-F8 path: forward trace, mode 2)
+#endif
+            constexpr int AD = LRPXH_APIPE_D;
+            f16x8 nq[AD][2];          // ring: nq[t % AD] = fragments (hi, lo) of op t = tap * 7 + j
             if constexpr (APIPE) {
-                n0 = *reinterpret_cast<const f16x8*>(abuf + abase[0]);
-                n1 = *reinterpret_cast<const f16x8*>(abuf + abase[0] + 32);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int d = 0; d < AD; ++d) {
+                    const int jn = d % 7, tn = d / 7;
+                    const char* apn = abuf + abase[jn] + (tn / 3) * PITCH + (tn % 3) * PSTRIDE;
+                    nq[d][0] = *reinterpret_cast<const f16x8*>(apn);
+                    nq[d][1] = *reinterpret_cast<const f16x8*>(apn + 32);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * AD, 0);
             }
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
@@ -947,12 +956,13 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 for (int j = 0; j < 7; ++j) {
                     f16x8 a0, a1;
                     if constexpr (APIPE) {
-                        a0 = n0; a1 = n1;
-                        if (!(tap == TAPS - 1 && j == 6)) {
-                            const int jn = (j + 1) % 7, tn = tap + (j == 6 ? 1 : 0);
+                        const int t = tap * 7 + j;
+                        a0 = nq[t % AD][0]; a1 = nq[t % AD][1];
+                        if (t + AD < TAPS * 7) {
+                            const int jn = (t + AD) % 7, tn = (t + AD) / 7;
                             const char* apn = abuf + abase[jn] + (tn / 3) * PITCH + (tn % 3) * PSTRIDE;
-                            n1 = *reinterpret_cast<const f16x8*>(apn + 32);
-                            n0 = *reinterpret_cast<const f16x8*>(apn);
+                            nq[t % AD][1] = *reinterpret_cast<const f16x8*>(apn + 32);
+                            nq[t % AD][0] = *reinterpret_cast<const f16x8*>(apn);
                         }
                     } else {
                         const char* ap = abuf + abase[j] + tapoff;
@@ -964,7 +974,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[j], 0, 0, 0);
                     if constexpr (APIPE) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the 2 reads of the NEXT tile ...
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the 2 reads of a LATER tile ...
                         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the 3 MFMAs of this one
                     }
                 }
