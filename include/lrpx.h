@@ -358,6 +358,9 @@ typedef struct lrpx_aoa_step_args {
     const float *glob, *emb;            /* global image feature [B][H], embedding table */
     const long long* tok; int tok_ld;   /* token ids [B][tok_ld] (teacher forcing: the caption incl. <start>) */
     const float *w_cat, *b_cat;         /* LSTM [W_ih | W_hh] (4H x (E+2H)) and its bias (the explainers' quirk or the model's) */
+    const float *w_cat_il, *b_cat_il;   /* optional: the same with the gate rows interleaved (row 16 j + 4 gate + u = row gate * H + 4 j + u):
+                                           the steps then run fused, 4 launches instead of 7 (gate linear + LSTM cell; aoa_linear + gated
+                                           sum + the next step's input row); results are bit-identical */
     const float *w_qg, *b_qg;           /* [q_proj ; decoder_aoa_linear_gate] (2H x H) */
     const float *w_lin, *b_lin;         /* decoder_aoa_linear (H x H) */
     const float *key, *value;           /* [B][P][H] */

@@ -45,7 +45,7 @@ class AoaTrace(C.Structure):
 class AoaStepArgs(C.Structure):
     """lrpx_aoa_step_args"""
     _fields_ = [("glob", _f), ("emb", _f), ("tok", _f), ("tok_ld", _i)] + [(k, _f) for k in (
-        "w_cat", "b_cat", "w_qg", "b_qg", "w_lin", "b_lin", "key", "value", "zz", "qg", "lin")]
+        "w_cat", "b_cat", "w_cat_il", "b_cat_il", "w_qg", "b_qg", "w_lin", "b_lin", "key", "value", "zz", "qg", "lin")]
 
 
 class AoaGradState(C.Structure):

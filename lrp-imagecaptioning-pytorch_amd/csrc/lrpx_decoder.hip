@@ -939,6 +939,108 @@ __global__ void aoa_fwd_post_kernel(AoaFwd g, int t, const float* __restrict__ q
     }
 }
 
+// ---- the skinny linears of the AoA step with their point-wise neighbours in the epilogue ---------------------------------
+// The bottom-up path is bound by the GPU's dispatch rate of dependent small kernels (~330 launches of 4 - 28 us per step of 640
+// maps), so the seven launches of a decoder step become four: the gate linear applies the LSTM cell (its weight
+// ROWS are interleaved - workgroup j holds the i, f, g, o rows of the hidden units 4j .. 4j+3 - so the four pre-activations of
+// a unit meet in the workgroup's LDS reduction), decoder_aoa_linear applies the gated sum (fwd_post) and gathers the NEXT
+// step's LSTM input row (fwd_pre).  The dot products run in the same order as in linear_mfma_kernel and the point-wise code is
+// that of aoa_fwd_lstm / _post / _pre: results are bit-identical to the unfused step (token ids of the sampling goldens, traces).
+template <int RT>
+__device__ __forceinline__ void linear_mfma_core(const float* __restrict__ x, long ldx, const float* __restrict__ w, int B, int K,
+                                                 int N, float (&red)[4][RT][16][17]) {
+    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    const int nl = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kslice = ((K / 16 + 3) / 4) * 16;
+    const int k_lo = wv_ * kslice, k_hi = min(K, k_lo + kslice);
+    const float* __restrict__ wrow = w + (long)min(n0 + nl, N - 1) * K + kq * 4;
+    const float* __restrict__ xrow[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) xrow[r] = x + (long)min(r * 16 + nl, B - 1) * ldx + kq * 4;
+    f32x4 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+        const f32x4 wq = *reinterpret_cast<const f32x4*>(wrow + k0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const f32x4 xq = *reinterpret_cast<const f32x4*>(xrow[r] + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[j], wq[j], acc[r], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wv_][r][4 * kq + i][nl] = acc[r][i];
+    __syncthreads();
+}
+
+// gate linear + LSTM cell (aoa_fwd_lstm_kernel).  w / bias: rows interleaved, row 16 j + 4 gate + u = original row gate * H + 4 j + u
+template <int RT>
+__global__ __launch_bounds__(256) void aoa_linear_lstm_kernel(AoaFwd g, int t, const float* __restrict__ w,
+                                                              const float* __restrict__ bias) {
+    __shared__ float red[4][RT][16][17];
+    const int H = g.H, W = g.E + 2 * H;
+    linear_mfma_core<RT>(g.xh + (long)t * W, (long)g.T * W, w, g.B, W, 4 * H, red);
+    for (int e = threadIdx.x; e < RT * 64; e += 256) {
+        const int r = e >> 6, row = (e >> 2) & 15, u = e & 3;
+        const int b = r * 16 + row, c = blockIdx.x * 4 + u;
+        if (b >= g.B || c >= H) continue;
+        float z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 4 * q + u;
+            z[q] = (red[0][r][row][col] + red[1][r][row][col]) + (red[2][r][row][col] + red[3][r][row][col]);
+            if (bias) z[q] += bias[blockIdx.x * 16 + col];
+        }
+        const long st0 = ((long)b * (g.T + 1) + t) * H, st1 = st0 + H, tr = ((long)b * g.T + t) * H;
+        const float i = sigmoidf_(z[0]), f = sigmoidf_(z[1]), zg = z[2], o = sigmoidf_(z[3]);
+        const float cn = f * g.c[st0 + c] + i * tanhf(zg);
+        g.c[st1 + c] = cn; g.h[st1 + c] = o * tanhf(cn);
+        g.g[tr + c] = zg; g.i[tr + c] = i; g.f[tr + c] = f;
+        if (g.o) g.o[tr + c] = o;
+    }
+}
+
+// decoder_aoa_linear + gated sum (aoa_fwd_post_kernel) + the next step's input row (aoa_fwd_pre_kernel for t + 1)
+template <int RT>
+__global__ __launch_bounds__(256) void aoa_linear_post_kernel(AoaFwd g, int t, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const float* __restrict__ qg, int ldq,
+                                                              const float* __restrict__ glob, const float* __restrict__ emb,
+                                                              const long long* __restrict__ tok, int tok_ld) {
+    __shared__ float red[4][RT][16][17];
+    const int H = g.H, W = g.E + 2 * H;
+    linear_mfma_core<RT>(g.ctx + (long)t * H, (long)g.T * H, w, g.B, H, H, red);
+    for (int e = threadIdx.x; e < RT * 256; e += 256) {
+        const int r = e >> 8, row = (e >> 4) & 15, col = e & 15;
+        const int b = r * 16 + row, c = blockIdx.x * 16 + col;
+        if (b >= g.B || c >= H) continue;
+        float l = (red[0][r][row][col] + red[1][r][row][col]) + (red[2][r][row][col] + red[3][r][row][col]);
+        if (bias) l += bias[c];
+        const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = ((long)b * g.T + t) * H;
+        const float sgv = sigmoidf_(qg[(long)b * ldq + H + c]);
+        const float ca = sgv * l;
+        g.lin[tr + c] = l; g.c_aoa[tr + c] = ca; g.hc[tr + c] = ca + g.h[st1 + c];
+        if (g.sg) g.sg[tr + c] = sgv;
+    }
+    if (t + 1 < g.T) {        // xh[b, t+1] = [emb[tok[b, t+1]] | glob[b] | h[b, t+1]]: this workgroup's slice of the columns, every image
+        const int per = (W + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int c0 = blockIdx.x * per, c1 = min(W, c0 + per);
+        for (int e = threadIdx.x; e < g.B * per; e += 256) {
+            const int b = e / per, c = c0 + e - b * per;
+            if (c >= c1) continue;
+            const long long k = tok[(long)b * tok_ld + t + 1];
+            float v;
+            if (c < g.E) v = emb[k * g.E + c];
+            else if (c < g.E + H) v = glob[(long)b * H + (c - g.E)];
+            else v = g.h[((long)b * (g.T + 1) + t + 1) * H + (c - g.E - H)];
+            g.xh[((long)b * g.T + t + 1) * W + c] = v;
+        }
+    }
+}
+
 // ---- AoA gradient explainers (models/aoamodel.py:1435-1499), all (image, word) rows in lock-step -------------------
 struct AoaGrad {
     int B, T, H, E, P, NH;
@@ -1115,6 +1217,37 @@ __global__ __launch_bounds__(256) void aoa_rel_c_kernel(AoaRel g, int s) {
     }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) g.r_words[(long)row * g.T + i] = acc;
+}
+
+// rel_c of lock-step s followed by rel_a of lock-step s + 1 for the same row (one launch instead of two; the same code, the
+// element -> thread map of both parts is the same, so a thread reads back the r_hn it has just written)
+__global__ __launch_bounds__(256) void aoa_rel_ca_kernel(AoaRel g, int s) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, E = g.E;
+    const long tr = (long)row * H;
+    if (aoa_row_active(g, b, t, s)) {
+        const int i = t - s;
+        const float* rx = g.rx + (long)row * (E + 2 * H);
+        float acc = 0.f;
+        for (int c = threadIdx.x; c < E; c += 256) acc += rx[c];
+        for (int c = threadIdx.x; c < H; c += 256) {
+            g.r_glob[tr + c] += rx[E + c];
+            g.r_hn[tr + c] = rx[E + H + c];
+        }
+        acc = block_sum(acc, red);
+        if (threadIdx.x == 0) g.r_words[(long)row * g.T + i] = acc;
+    }
+    if (s + 1 >= g.T) return;
+    if (!aoa_row_active(g, b, t, s + 1)) {
+        for (int c = threadIdx.x; c < H; c += 256) g.A[tr + c] = 0.f;
+        return;
+    }
+    const int i = t - s - 1;
+    const long ti = ((long)b * g.T + i) * H, sc1 = ((long)b * (g.T + 1) + i + 1) * H;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float rg = eps_id(g.r_hn[tr + c], g.i[ti + c] * tanhf(g.g[ti + c]), g.c[sc1 + c]);
+        g.A[tr + c] = rg / stab_eps(g.g[ti + c]);
+    }
 }
 
 }  // namespace lrpx
@@ -1546,11 +1679,38 @@ int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int
 // The host loops of the AoA decoder in native code.  Every launch is one of the entry points above; what goes away is the
 // interpreter between them: ~4 us per call through ctypes against ~1.5 us for a launch issued from here.  With a CNN stage
 // behind it that is noise; the bottom-up path (no CNN, ~330 launches of 4 - 25 us per step of 640 maps) was bound by it.
+}  // extern "C"
+template <int RT>
+static int aoa_fused_steps(const lrpx_aoa_trace* tr, int t0, int t1, const lrpx_aoa_step_args* a, hipStream_t st) {
+    const AoaFwd g = to_afwd(tr);
+    const int H = tr->H, T = tr->T, B = tr->B;
+    for (int t = t0; t < t1; ++t) {
+        hipLaunchKernelGGL((aoa_linear_lstm_kernel<RT>), dim3(4 * H / 16), dim3(256), 0, st, g, t, a->w_cat_il, a->b_cat_il);
+        LRPX_TRY(check_launch("aoa_linear_lstm"));
+        LRPX_TRY(lrpx_linear_small(tr->h + (long)(t + 1) * H, (long)(T + 1) * H, a->w_qg, a->b_qg, a->qg, 2 * H, B, H, 2 * H, 0, st));
+        LRPX_TRY(lrpx_aoa_fwd_attention(tr, t, a->qg, 2 * H, a->key, a->value, st));
+        hipLaunchKernelGGL((aoa_linear_post_kernel<RT>), dim3(H / 16), dim3(256), 0, st, g, t, a->w_lin, a->b_lin, a->qg, 2 * H, a->glob,
+                           a->emb, a->tok, a->tok_ld);
+        LRPX_TRY(check_launch("aoa_linear_post"));
+    }
+    return LRPX_OK;
+}
+
+extern "C" {
 int lrpx_aoa_fwd_steps(const lrpx_aoa_trace* tr, int t0, int t1, const lrpx_aoa_step_args* a, void* stream) {
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(a && a->glob && a->emb && a->tok && a->w_cat && a->w_qg && a->w_lin && a->key && a->value && a->zz && a->qg &&
                      a->lin && t0 >= 0 && t0 <= t1 && t1 <= tr->T, "aoa_fwd_steps: bad arguments");
     const int B = tr->B, T = tr->T, H = tr->H, W = tr->E + 2 * tr->H;
+    // fused steps (4 launches instead of 7): needs the interleaved gate rows, <= 64 images, dims the matrix-core linear takes
+    if (a->w_cat_il && B <= 64 && W % 16 == 0 && H % 16 == 0 && t0 < t1) {
+        LRPX_TRY(lrpx_aoa_fwd_pre(tr, t0, a->glob, a->emb, a->tok, a->tok_ld, stream));      // (later rows: gathered by the step before)
+        hipStream_t st = (hipStream_t)stream;
+        if (B <= 16) return aoa_fused_steps<1>(tr, t0, t1, a, st);
+        if (B <= 32) return aoa_fused_steps<2>(tr, t0, t1, a, st);
+        if (B <= 48) return aoa_fused_steps<3>(tr, t0, t1, a, st);
+        return aoa_fused_steps<4>(tr, t0, t1, a, st);
+    }
     for (int t = t0; t < t1; ++t) {
         LRPX_TRY(lrpx_aoa_fwd_pre(tr, t, a->glob, a->emb, a->tok, a->tok_ld, stream));
         LRPX_TRY(lrpx_linear_small(tr->xh + (long)t * W, (long)T * W, a->w_cat, a->b_cat, a->zz, 4 * H, B, W, 4 * H, 0, stream));
@@ -1568,11 +1728,17 @@ int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, in
     LRPX_TRY(check_arel(tr, rs));
     LRPX_REQUIRE(dense && idx && n_steps >= 0 && n_steps <= tr->T && idx_ld >= tr->B * tr->T, "aoa_rel_steps: bad arguments");
     lrpx_conv_desc d = *dense;
+    const AoaRel g = to_arel(tr, rs);
+    if (n_steps > 0) LRPX_TRY(lrpx_aoa_rel_step(tr, rs, 0, 0, stream));
     for (int s = 0; s < n_steps; ++s) {
-        LRPX_TRY(lrpx_aoa_rel_step(tr, rs, s, 0, stream));
         d.map2img = idx + (long)s * idx_ld;          // row -> source row of the multiplicand at lock-step s
         LRPX_TRY(lrpx_conv_mfma(&d, stream));
-        LRPX_TRY(lrpx_aoa_rel_step(tr, rs, s, 1, stream));
+        if (s + 1 < n_steps) {                       // phase 1 of step s and phase 0 of step s + 1 in one launch
+            hipLaunchKernelGGL(aoa_rel_ca_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, g, s);
+            LRPX_TRY(check_launch("aoa_rel_ca"));
+        } else {
+            LRPX_TRY(lrpx_aoa_rel_step(tr, rs, s, 1, stream));
+        }
     }
     return LRPX_OK;
 }

@@ -41,6 +41,12 @@ class AOAEngine:
         self.Wcat = torch.cat([sd[l + "weight_ih"], sd[l + "weight_hh"]], 1).contiguous()          # (4H, E+2H)
         self.bcat_explainer = (sd[l + "bias_ih"] + sd[l + "bias_ih"]).contiguous()                  # quirk :873
         self.bcat_model = (sd[l + "bias_ih"] + sd[l + "bias_hh"]).contiguous()
+        # gate rows interleaved for the fused decoder step (lrpx_aoa_fwd_steps): row 16 j + 4 gate + u = row gate * H + 4 j + u, so
+        # that one workgroup of the gate linear holds the i, f, g, o pre-activations of the hidden units 4j .. 4j+3
+        jj, qq, uu = torch.meshgrid(torch.arange(H // 4), torch.arange(4), torch.arange(4), indexing="ij")
+        il = (qq * H + 4 * jj + uu).reshape(-1).to(self.device)
+        self.Wcat_il = self.Wcat[il].contiguous()
+        self.bcat_model_il, self.bcat_explainer_il = self.bcat_model[il].contiguous(), self.bcat_explainer[il].contiguous()
         self.Wqg = torch.cat([sd["decoder_multihead_attention.q_proj.weight"], sd["decoder_aoa_linear_gate.weight"]], 0).contiguous()
         self.bqg = torch.cat([sd["decoder_multihead_attention.q_proj.bias"], sd["decoder_aoa_linear_gate.bias"]]).contiguous()
         self.w_proj2d = w_proj.reshape(H, Cc).contiguous()
@@ -61,6 +67,7 @@ class AOAEngine:
             self.p_v_rel_h = ops.pack_weights_f16x2(sd["decoder_v_proj.weight"], H, H, _lib.PACK_BWD_PLAIN, taps=1)
             self.p_proj_rel_h = ops.pack_weights_f16x2(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1)
         # ... and the lock-step gate rule / the aoa_linear rule (rows = images x words): the few-row kernel of the same file
+        self.fused_steps = True          # decoder steps as 4 launches instead of 7 (False: the unfused kernels; A/B and tests)
         self.lockstep_f16 = H % 16 == 0 and E % 16 == 0
         self.p_wg_h = ops.pack_weights_f16x2(wg, H, E + 2 * H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
         self.p_lin_rel_h = ops.pack_weights_f16x2(sd["decoder_aoa_linear.weight"], H, H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
@@ -248,6 +255,8 @@ class AOAEngine:
         sa = AoaStepArgs()
         sa.glob, sa.emb, sa.tok, sa.tok_ld = ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), captions.shape[1]
         sa.w_cat, sa.b_cat, sa.w_qg, sa.b_qg = ptr(self.Wcat), ptr(bias), ptr(self.Wqg), ptr(self.bqg)
+        if self.fused_steps:
+            sa.w_cat_il, sa.b_cat_il = ptr(self.Wcat_il), ptr(self.bcat_model_il if model_bias else self.bcat_explainer_il)
         sa.w_lin, sa.b_lin = ptr(sd["decoder_aoa_linear.weight"]), ptr(sd["decoder_aoa_linear.bias"])
         sa.key, sa.value, sa.zz, sa.qg, sa.lin = ptr(enc["key"]), ptr(enc["value"]), ptr(tr["_zz"]), ptr(tr["_qg"]), ptr(tr["_lin"])
         check(lib.lrpx_aoa_fwd_steps(c, 0, T, C.byref(sa), st))
