@@ -104,3 +104,17 @@ def test_bench_host_cores_respects_cgroup():
     import bench
     n = bench.host_cores()
     assert 1 <= n <= 16
+
+
+def test_bench_arguments_of_every_baseline_config():
+    """bench.py: the defaults of every BASELINE config line and of the `configs` block the default run appends"""
+    import bench
+    a = bench.parse([])
+    assert (a.config, a.batch, a.words, a.vocab, a.pipeline, a.explainer, a.gpus) == (2, 16, 20, 9586, 3, "lrp", 1)
+    assert (a.steps, a.warmup) == (20, 4) and not a.no_configs
+    for cfg, want in ((3, (64, 11027, 2, "lrp")), (4, (32, 9586, 2, "lrp+guided")), (5, (32, 11027, 3, "lrp"))):
+        b = bench.parse(["--config", str(cfg)])
+        assert (b.batch, b.vocab, b.pipeline, b.explainer) == want
+    b64 = bench.parse(["--config", "2", "--batch", "64", "--pipeline", "2"])
+    assert (b64.batch, b64.pipeline, b64.vocab) == (64, 2, 9586)
+    assert bench.parse(["--config", "3", "--all-heads"]).all_heads
