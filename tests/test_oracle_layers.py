@@ -92,3 +92,41 @@ def test_m4_add_flatten_dropout_rules():
     assert torch.equal(r1[0, 1], 0.5 * M("add_rout")[0, 1])                  # zero sums: half each (:262-272)
     assert torch.equal(M("flat_rin").reshape(3, 16), M("flat_rout"))         # Flatten: a view (:282-291)
     assert torch.equal(M("drop_rin"), M("drop_r"))                           # Dropout: passes relevance_input (:248-254)
+
+
+def test_toy_residual_net_through_the_rules():
+    # tests/golden/toy_resnet.npz: the reference's add_lrp / compute_lrp on Conv-BN-ReLU, a skip through the explicit Add
+    # module, MaxPool, Flatten, Linear (make_golden.py:gen_toy).  The oracle's rule restatements walked by hand in the order
+    # autograd drives the reference's hooks; the relevance of relu1's output is the SUM of its two consumers' (Add and conv2)
+    import sys
+    import torch.nn as nn
+    sys.path.insert(0, GOLDEN)
+    from make_golden import toy_resnet
+
+    class _Add(nn.Module):
+        def forward(self, x, y):
+            return x + y
+
+    class _Flat(nn.Module):
+        def forward(self, x):
+            return x.view(x.size(0), -1)
+    g = np.load(os.path.join(GOLDEN, "toy_resnet.npz"))
+    net = toy_resnet(np.random.RandomState(int(g["seed"])), _Add, _Flat)
+    x = torch.from_numpy(g["x"])
+    bn = lambda m, r, xin: O.batchnorm_rule(xin, r, m.weight.data, m.bias.data, m.running_mean, m.running_var, m.eps)
+    with torch.no_grad():
+        c1 = net.conv1(x); b1 = net.bn1(c1); x1 = net.relu1(b1)
+        c2 = net.conv2(x1); b2 = net.bn2(c2); y = net.relu2(b2)
+        z = x1 + y; p = net.pool(z); f = p.view(p.size(0), -1)
+        logits = net.fc(f)
+    assert rel_err(logits, g["logits"]) < 1e-6
+    total = 0
+    for key, want in (("target", "r1"), ("target2", "r2")):
+        r, _ = O.linear_eps_rule(f.clone(), net.fc.weight.data, torch.from_numpy(g[key]))
+        r = O.maxpool_rule(z, r.view(p.shape))
+        r_x1, r_y = O.add_rule(x1, y, r)
+        r = bn(net.bn2, r_y, c2)
+        r_x1 = r_x1 + O.conv_alpha1beta0(x1, net.conv2.weight.data, r)
+        r = bn(net.bn1, r_x1, c1)
+        total = total + O.conv_alpha1beta0(x, net.conv1.weight.data, r)
+        assert rel_err(total, g[want]) < 1e-5, want          # the second call returns the `.grad` running sum
