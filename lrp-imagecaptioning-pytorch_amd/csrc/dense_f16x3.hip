@@ -21,12 +21,29 @@
 
 namespace lrpx {
 
-constexpr int DH_BM = 128, DH_BN = 128, DH_KC = 64;
-constexpr int DH_ROWB = 4 * 2 * 2 * 16 + 16;        // LDS bytes per A row: [k-step 4][plane 2][lane group 2][16 B] + pad
-constexpr int DH_BUF = DH_BM * DH_ROWB;
-constexpr int DH_LDS = 2 * DH_BUF;
+constexpr int DH_BN = 128;
+#ifndef LRPXB_SCHED
+#define LRPXB_SCHED 1       // 1: fences around the A-fragment prefetch and the k-steps; 0: the compiler's own schedule; 2: commit spread over the k-steps
+#endif
+#ifndef LRPXB_EXP
+#define LRPXB_EXP 0       // timing experiments (wrong results): 1 no epilogue, 2 no MFMAs, 4 no staging loads / commits, 8 no B loads
+#endif
+// WM wave rows x 2 wave columns; a wave owns 64 rows x 64 columns.  WM = 2: 128-row tiles, K chunks of 64, two workgroups per CU.
+// WM = 4 (many rows): 256-row tiles, 8 waves, K chunks of 32 (the two A buffers stay at 74 KB), one workgroup per CU - every B
+// fragment streamed from L2 now serves 256 rows: the 62 720 x 512 x 512 rule moved 1.0 GB of weights from L2 to the CUs with
+// 128-row tiles (1960 workgroups x 512 KB), the dominant term of its 186 us.
+template <int WM>
+struct DenseCfg {
+    static constexpr int NT = WM * 128, BM = WM * 64, KC = WM == 2 ? 64 : 32, KS = KC / 16, SEGS = KC / 4;
+    static constexpr int RP = NT / SEGS, NU = BM / RP;              // rows per staging pass, float4 items per thread and chunk
+    static constexpr int ROWB = KS * 64 + 16;                       // LDS bytes per A row: [k-step][hi | lo][lane group 2][16 B] + pad
+    static constexpr int BUF = BM * ROWB, LDS = 2 * BUF;
+    static constexpr int CPI = 4 / KS;                              // chunks per loop iteration (4 k-steps: static B ring indices)
+};
 
-__global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+template <int EPI, int WM>      // EPI_REL, or EPI_PLAIN: out0 = acc + bias (optional ReLU) - the (T,V) scores of a trace
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void dense_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+    using C = DenseCfg<WM>;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -39,32 +56,40 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_t
     if (lin >= t1) return;
     const int mtile = (int)(lin / n_blocks), nblk = (int)(lin - (long)mtile * n_blocks);
     const long M = (long)a.n_maps * a.pix_per_map;
-    const long row0 = (long)mtile * DH_BM;
-    const int K = a.cin, nchunk = K / DH_KC;
+    const long row0 = (long)mtile * C::BM;
+    const int K = a.cin, nchunk = K / C::KC;
     const unsigned P = (unsigned)a.pix_per_map;
     const unsigned* __restrict__ in_amax = a.in_amax;
 
-    // ---- staging: thread -> 8 items (row = tid / 16 + 16 u, 16-byte segment tid % 16 of the 64-float chunk row)
-    const int s_row = tid >> 4, s_seg = tid & 15;
-    float ssc[8];
-    long srow[8];
+    // ---- staging: thread -> NU items (row = tid / SEGS + RP u, 16-byte segment tid % SEGS of the chunk row)
+    const int s_row = tid / C::SEGS, s_seg = tid % C::SEGS;
+    float ssc[C::NU];
+    long srow[C::NU];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const long r = row0 + s_row + 16 * u;
+    for (int u = 0; u < C::NU; ++u) {
+        const long r = row0 + s_row + C::RP * u;
         const long rc = r < M ? r : M - 1;               // rows past the end re-read the last row (results dropped)
         srow[u] = rc * K;
         ssc[u] = exp2i(f16_scale_exp(in_amax[(unsigned)rc / P]));
     }
     // LDS offset of the item inside a row: k-step = seg / 4, lane group = (seg / 2) & 1, half = seg & 1 (8 bytes)
     const int s_off = (s_seg >> 2) * 64 + ((s_seg >> 1) & 1) * 16 + (s_seg & 1) * 8;
-    f32x4 sv[8];
+    f32x4 sv[C::NU];
     const float* __restrict__ A = a.in;
-#define DH_ISSUE(CHUNK) _Pragma("unroll") for (int u = 0; u < 8; ++u) sv[u] = *reinterpret_cast<const f32x4*>(A + srow[u] + (CHUNK) * DH_KC + s_seg * 4);
-#define DH_COMMIT(BUF)                                                                                     \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
+#define DH_ISSUE(CHUNK) if constexpr (!(LRPXB_EXP & 4)) { _Pragma("unroll") for (int u = 0; u < C::NU; ++u) sv[u] = *reinterpret_cast<const f32x4*>(A + srow[u] + (CHUNK) * C::KC + s_seg * 4); }
+#define DH_COMMIT(BUFI)                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < C::NU; ++u) {                                                    \
         _Float16 h[4], l[4];                                                                               \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * ssc[u], h[e], l[e]);                \
-        char* d_ = ldsb + (BUF) * DH_BUF + (s_row + 16 * u) * DH_ROWB + s_off;                             \
+        char* d_ = ldsb + (BUFI) * C::BUF + (s_row + C::RP * u) * C::ROWB + s_off;                         \
+        *reinterpret_cast<u32x2_*>(d_) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};               \
+        *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};          \
+    }
+#define DH_COMMIT_PART(BUFI, U0, NUM)                                                                     \
+    _Pragma("unroll") for (int u = (U0); u < (U0) + (NUM); ++u) {                                          \
+        _Float16 h[4], l[4];                                                                               \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * ssc[u], h[e], l[e]);                \
+        char* d_ = ldsb + (BUFI) * C::BUF + (s_row + C::RP * u) * C::ROWB + s_off;                         \
         *reinterpret_cast<u32x2_*>(d_) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};               \
         *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};          \
     }
@@ -98,43 +123,72 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_t
 
     DH_COMMIT(0)
     __syncthreads();
-    const int a_off = (wm * 64 + li) * DH_ROWB + lh * 16;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        {
-            const int cn = min(chunk + 1, nchunk - 1);     // (past the last chunk: re-read it, nobody commits it)
-            DH_ISSUE(cn)
-        }
-        const char* abuf = ldsb + (chunk & 1) * DH_BUF + a_off;
+    const int a_off = (wm * 64 + li) * C::ROWB + lh * 16;
+    for (int c0 = 0; c0 < nchunk; c0 += C::CPI) {           // (nchunk % CPI == 0: K % 64 == 0, host-checked)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            load_b(chunk * 4 + s + DH_NBQ - 1, bq[(s + DH_NBQ - 1) % DH_NBQ]);
-            const f16x8 a0h = *reinterpret_cast<const f16x8*>(abuf + s * 64);
-            const f16x8 a0l = *reinterpret_cast<const f16x8*>(abuf + s * 64 + 32);
-            const f16x8 a1h = *reinterpret_cast<const f16x8*>(abuf + 32 * DH_ROWB + s * 64);
-            const f16x8 a1l = *reinterpret_cast<const f16x8*>(abuf + 32 * DH_ROWB + s * 64 + 32);
-            const u32x4_(&b)[4] = bq[s % DH_NBQ];
-            const f16x8 b0h = __builtin_bit_cast(f16x8, b[0]), b0l = __builtin_bit_cast(f16x8, b[1]);
-            const f16x8 b1h = __builtin_bit_cast(f16x8, b[2]), b1l = __builtin_bit_cast(f16x8, b[3]);
-            // small terms first
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0l, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1l, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0l, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1l, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, acc[1][1], 0, 0, 0);
+        for (int cc = 0; cc < C::CPI; ++cc) {
+            const int chunk = c0 + cc;
+            {
+                const int cn = min(chunk + 1, nchunk - 1);     // (past the last chunk: re-read it, nobody commits it)
+                DH_ISSUE(cn)
+                // keep the loads HERE: left alone the scheduler sinks them to their use (the commit at the end of the chunk)
+                // and the whole global-load latency sits between the matrix phases of two chunks
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int bufi = C::CPI == 1 ? (chunk & 1) : cc;   // (two chunks per iteration: the buffer index is the position)
+            const char* abuf = ldsb + bufi * C::BUF + a_off;
+            // A fragments one k-step ahead of their MFMAs (two register sets; the compiler's own schedule reads a fragment,
+            // waits for it - lgkmcnt(0) - and multiplies, one LDS round trip per pair of MFMAs)
+            f16x8 af[2][4];
+            auto read_a = [&](const int s_, f16x8 (&f)[4]) {
+                f[0] = *reinterpret_cast<const f16x8*>(abuf + s_ * 64);
+                f[1] = *reinterpret_cast<const f16x8*>(abuf + s_ * 64 + 32);
+                f[2] = *reinterpret_cast<const f16x8*>(abuf + 32 * C::ROWB + s_ * 64);
+                f[3] = *reinterpret_cast<const f16x8*>(abuf + 32 * C::ROWB + s_ * 64 + 32);
+            };
+            read_a(0, af[0]);
+            if constexpr (LRPXB_SCHED == 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+                const int q = cc * C::KS + s;                  // position in the iteration's 4 k-steps: static ring indices
+                if constexpr (!(LRPXB_EXP & 8)) load_b(chunk * C::KS + s + DH_NBQ - 1, bq[(q + DH_NBQ - 1) % DH_NBQ]);
+                if (s + 1 < C::KS) read_a(s + 1, af[(s + 1) & 1]);
+                if constexpr (LRPXB_SCHED == 1) __builtin_amdgcn_sched_barrier(0);
+                const f16x8 a0h = af[s & 1][0], a0l = af[s & 1][1], a1h = af[s & 1][2], a1l = af[s & 1][3];
+                const u32x4_(&b)[4] = bq[q % DH_NBQ];
+                const f16x8 b0h = __builtin_bit_cast(f16x8, b[0]), b0l = __builtin_bit_cast(f16x8, b[1]);
+                const f16x8 b1h = __builtin_bit_cast(f16x8, b[2]), b1l = __builtin_bit_cast(f16x8, b[3]);
+                // small terms first
+                if constexpr (LRPXB_EXP & 2) { acc[0][0][0] += a0h[0] + a1l[1] + b0l[0] + b1h[2] + a0l[0] + a1h[0] + b0h[0] + b1l[0]; continue; }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0l, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1l, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0l, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1l, acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, acc[1][1], 0, 0, 0);
+                if constexpr (LRPXB_SCHED == 1) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (LRPXB_SCHED == 2 && !(LRPXB_EXP & 4)) {
+                    // a quarter (half) of the next chunk's commit behind every k-step: conversions and LDS writes in the shadow of
+                    // the 12 MFMAs just issued (the last chunk commits into the idle buffer: harmless, no branch)
+                    constexpr int PER = C::NU / C::KS;
+                    DH_COMMIT_PART(C::CPI == 1 ? ((chunk + 1) & 1) : (1 - cc), s * PER, PER)
+                }
+            }
+            if constexpr (LRPXB_SCHED != 2) { if (chunk + 1 < nchunk && !(LRPXB_EXP & 4)) { DH_COMMIT(C::CPI == 1 ? ((chunk + 1) & 1) : (1 - cc)) } }
+            __syncthreads();
         }
-        if (chunk + 1 < nchunk) { DH_COMMIT((chunk + 1) & 1) }
-        __syncthreads();
     }
 #undef DH_ISSUE
 #undef DH_COMMIT
+#undef DH_COMMIT_PART
 
+    if constexpr (LRPXB_EXP & 1) { if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) a.out0[0] = 1.f; return; }
     // ---- epilogue (EPI_REL of conv_mfma.h): element e of tile (i, j): row = row0 + wm*64 + 32 i + (e&3) + 8 (e>>2) + 4 lh,
     // column = 32 (ocb0 + j) + li
     const float* __restrict__ X = a.X;
@@ -164,9 +218,26 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_t
             const long rc = r < M ? r : M - 1;
             const unsigned n = (unsigned)rc / P, p = (unsigned)rc - n * P;
             nn[e] = n;
-            const unsigned img = m2i ? (unsigned)m2i[n] : n;
+            const unsigned img = EPI == EPI_PLAIN ? n : (unsigned)m2i[n];      // (REL: map2img is required - no branch around the load)
             xb[e] = (img * P + p) * (unsigned)ncol;               // (< 2^31: host-checked)
             sc[e] = exp2i(-f16_scale_exp(in_amax[n])) * inv_w;
+        }
+        if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oc = (ocb0 + j) * 32 + li;
+                if (oc >= ncol) continue;
+                const float bv = a.bias ? a.bias[oc] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long r = rt + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (r >= M) continue;
+                    float v = acc[i][j][e] * sc[e] + bv;
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    o0[r * ncol + oc] = v;
+                }
+            }
+            continue;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -213,13 +284,17 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_kernel(ConvArgs a, int m_t
 // B queue: 11 k-steps ahead (a k-step is 3 MFMAs = 96 matrix cycles, an L2 round trip ~1000: 5 ahead left the K loop bound by
 // the load latency - 28 us per GEMM against 25 for the fp32 kernel it replaces)
 constexpr int DS_NB = 12;
-template <int MAXU>        // float4 items of the A slab per thread: 16 for K <= 512, 32 for K <= 1024
+#ifndef LRPXD_EXP
+#define LRPXD_EXP 0       // timing experiments (wrong results): 1 no multiplicand / addend loads in the epilogue, 2 no K loop, 4 no A staging, 8 no stores
+#endif
+template <int MAXU, bool EXACT>   // float4 items of the A slab per thread: 16 for K = 512, 32 for K = 1024 (EXACT: no tail); else guarded
 __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mtile = blockIdx.x / n_blocks, nblk = blockIdx.x % n_blocks;
-    const int K = a.cin, nks = K / 16, k4 = K / 4;
+    const int K = EXACT ? MAXU * 32 : a.cin;      // (EXACT: a compile-time constant - the item -> (row, segment) maps become shifts)
+    const int nks = K / 16, k4 = K / 4;
     const int pitch = nks * 64 + 16;
     unsigned* rowmax = reinterpret_cast<unsigned*>(ldsb + 32 * pitch);        // [32] float bits of max|A[row]|
     const long rows = (long)a.n_maps * a.pix_per_map;
@@ -233,27 +308,28 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
     for (int i = 0; i < DS_NB - 1; ++i) { bq[i][0] = wp[(long)min(i, nks - 1) * 128]; bq[i][1] = wp[(long)min(i, nks - 1) * 128 + 64]; }
     if (tid < 32) rowmax[tid] = 0u;
     __syncthreads();
-    // pass 1: the slab through registers (<= 32 float4 per thread), row maxima into LDS
+    // pass 1: the slab through registers, row maxima into LDS.  BRANCH-FREE: every load is issued unconditionally (rows past the
+    // end re-read the last row and are zeroed by a select) - with `if (row < rows) load` the compiler waits for each of the 16
+    // loads before it issues the next (s_waitcnt vmcnt(0) at every control-flow merge): 7 of the kernel's 25 us
     f32x4 sv[MAXU];
-    const int nu = (32 * k4 + 255) / 256;
+    const int nu = EXACT ? MAXU : (32 * k4 + 255) / 256;
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
-        sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (u < nu) {
-            const int it = tid + 256 * u;
-            const int r = it / k4, c4 = it - r * k4;
-            if (it < 32 * k4 && row0 + r < rows) sv[u] = *reinterpret_cast<const f32x4*>(a.in + (row0 + r) * K + c4 * 4);
-        }
+        const int it = EXACT ? tid + 256 * u : min(tid + 256 * u, 32 * k4 - 1);
+        const int r = it / k4, c4 = it - r * k4;
+        const long rr = min(row0 + r, rows - 1);
+        sv[u] = *reinterpret_cast<const f32x4*>(a.in + rr * K + c4 * 4);
+        if ((LRPXD_EXP & 4) || row0 + r >= rows || (!EXACT && (u >= nu || tid + 256 * u >= 32 * k4))) sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
-        if (u < nu) {
+        if (EXACT || u < nu) {
             const int it = tid + 256 * u;
-            const int r = it / k4;
+            const int r = min(it / k4, 31);
             float m = fmaxf(fmaxf(fabsf(sv[u][0]), fabsf(sv[u][1])), fmaxf(fabsf(sv[u][2]), fabsf(sv[u][3])));
             if ((k4 & 63) == 0) {                  // a wave's 64 items lie in one row: one LDS atomic per wave
                 m = wave_max(m);
-                if (lane == 0 && it < 32 * k4) atomicMax(&rowmax[r], __builtin_bit_cast(unsigned, m));
+                if (lane == 0) atomicMax(&rowmax[r], __builtin_bit_cast(unsigned, m));
             } else if (it < 32 * k4) {
                 atomicMax(&rowmax[r], __builtin_bit_cast(unsigned, m));
             }
@@ -263,9 +339,9 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
     // pass 2: scale, split, LDS.  Row layout: [k-step][hi: lane group 0, 1 | lo: lane group 0, 1] x 16 B
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
-        if (u < nu) {
+        if (EXACT || u < nu) {
             const int it = tid + 256 * u;
-            if (it < 32 * k4) {
+            if (EXACT || it < 32 * k4) {
                 const int r = it / k4, c4 = it - r * k4;
                 const float sc = exp2i(f16_scale_exp(rowmax[r]));
                 _Float16 h[4], l[4];
@@ -283,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const char* ap = ldsb + li * pitch + lh * 16;
-    for (int ks = 0; ks < nks; ks += DS_NB) {
+    for (int ks = 0; ks < ((LRPXD_EXP & 2) ? 0 : nks); ks += DS_NB) {
 #pragma unroll
         for (int u = 0; u < DS_NB; ++u) {
             const int step = ks + u;
@@ -306,61 +382,83 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
     if (oc >= ncol) return;
     const unsigned P = (unsigned)a.pix_per_map;
     const float inv_w = a.wp[0];
-    float xv[16];
-    long nn[16];
+    // (branch-free as the staging: all 16 row -> source-row lookups, then all 16 multiplicands / addends, then the stores;
+    // 32-bit index arithmetic - rows < 2^31 host-checked - and no division at all for the lock-step rules' pix_per_map = 1)
+    float xv[16], uv[16];
+    long src[16];
+    unsigned nn[16];
+    const int* __restrict__ m2i = a.map2img;
+    const float* __restrict__ X = a.X;
+    const float* __restrict__ Uu = a.U;
+    const unsigned last = (unsigned)(rows - 1);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const long row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        xv[e] = 0.f; nn[e] = 0;
-        if (row < rows) {
-            const long n = row / P, p = row - n * P;
-            const long img = a.map2img ? a.map2img[n] : n;
-            nn[e] = n;
-            xv[e] = a.X[(img * P + p) * ncol + oc];
-        }
+        const unsigned row = min((unsigned)row0 + (unsigned)((e & 3) + 8 * (e >> 2) + 4 * lh), last);
+        const unsigned n = P == 1u ? row : row / P, p = P == 1u ? 0u : row - n * P;
+        nn[e] = n;
+        const long img = (m2i && !(LRPXD_EXP & 1)) ? (long)m2i[n] : (long)n;
+        src[e] = (img * P + p) * ncol + oc;
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        xv[e] = (LRPXD_EXP & 1) ? 1.f : X[src[e]];
+        uv[e] = (Uu && !(LRPXD_EXP & 1)) ? Uu[(long)nn[e] * ncol + oc] : 0.f;
+    }
+    float* __restrict__ O0 = a.out0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int rl = (e & 3) + 8 * (e >> 2) + 4 * lh;
         const long row = row0 + rl;
         if (row >= rows) continue;
-        float v = acc[e] * (exp2i(-f16_scale_exp(rowmax[rl])) * inv_w);
-        if (a.U) v += a.U[nn[e] * ncol + oc];
-        a.out0[row * ncol + oc] = xv[e] * v;
+        const float v = acc[e] * (exp2i(-f16_scale_exp(rowmax[rl])) * inv_w) + uv[e];
+        if (!(LRPXD_EXP & 8) || v == 12345.f) O0[row * ncol + oc] = xv[e] * v;
     }
 }
 
 int launch_dense_small_f16x3(const ConvArgs& a, hipStream_t stream) {
     const long rows = (long)a.n_maps * a.pix_per_map;
     LRPX_REQUIRE(a.cin % 16 == 0 && a.cin >= 16 && a.cin <= 1024, "dense_small_f16x3: K = %d (a multiple of 16, <= 1024)", a.cin);
-    LRPX_REQUIRE(a.X && a.out0 && !a.out1 && rows > 0, "dense_small_f16x3: REL epilogue with x and out0 only");
+    LRPX_REQUIRE(a.X && a.out0 && !a.out1 && rows > 0 && rows < 0x7fffffffL, "dense_small_f16x3: REL epilogue with x and out0 only");
     const int m_tiles = (int)ceil_div(rows, 32);
     const int n_blocks = (int)ceil_div(a.n_oc, 128);
     const int lds = 32 * ((a.cin / 16) * 64 + 16) + 128;
     constexpr int LDS_MAX = 32 * (64 * 64 + 16) + 128;
-    const bool big = a.cin > 512;
-    auto kern = big ? dense_small_f16x3_kernel<32> : dense_small_f16x3_kernel<16>;
-    static LdsOnce once[2];
-    LRPX_TRY(reserve_lds_once(once[big], kern, LDS_MAX, "dense_small_f16x3"));
+    // instantiations: K = 512 and K = 1024 exactly (no tail item, no guard in the staging loops), any other K guarded
+    const int which = a.cin == 512 ? 0 : (a.cin == 1024 ? 1 : (a.cin < 512 ? 2 : 3));
+    auto kern = which == 0 ? dense_small_f16x3_kernel<16, true> : (which == 1 ? dense_small_f16x3_kernel<32, true>
+                : (which == 2 ? dense_small_f16x3_kernel<16, false> : dense_small_f16x3_kernel<32, false>));
+    static LdsOnce once[4];
+    LRPX_TRY(reserve_lds_once(once[which], kern, LDS_MAX, "dense_small_f16x3"));
     hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks);
     return check_launch("dense_small_f16x3");
 }
 
 int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
     const long M = (long)a.n_maps * a.pix_per_map;
-    LRPX_REQUIRE(a.cin % DH_KC == 0 && a.cin >= DH_KC, "dense_f16x3: K = %d is not a multiple of %d", a.cin, DH_KC);
-    LRPX_REQUIRE(a.in_amax && a.X && (a.out0 || a.out1), "dense_f16x3: needs in_amax, x and an output");
+    LRPX_REQUIRE(a.cin % 64 == 0 && a.cin >= 64, "dense_f16x3: K = %d is not a multiple of 64", a.cin);
+    const bool plain = a.epi == EPI_PLAIN;
+    LRPX_REQUIRE(a.in_amax && (plain ? (a.out0 && !a.out1) : (a.X && a.map2img && (a.out0 || a.out1))),
+                 "dense_f16x3: needs in_amax, an output (and x, map2img for REL)");
     LRPX_REQUIRE(M > 0 && M < 0x7fffffffL, "dense_f16x3: %ld rows out of range", M);
-    LRPX_REQUIRE((long)a.n_maps * a.pix_per_map * a.oc_split < 0x7fffffffL, "dense_f16x3: too many multiplicand elements for 32-bit offsets");
+    LRPX_REQUIRE(plain || (long)a.n_maps * a.pix_per_map * a.oc_split < 0x7fffffffL, "dense_f16x3: too many multiplicand elements for 32-bit offsets");
     LRPX_REQUIRE(!(a.out1 && a.out1_amax) || a.pix_per_map >= 32, "dense_f16x3: out1_amax needs at least 32 rows per map");
-    const long m_tiles = ceil_div(M, DH_BM);
+    const bool wide = switches().dense_wide && M >= 8192;      // 256-row tiles (8 waves) for many rows: measured slower, off (A/B)
+    const long m_tiles = ceil_div(M, wide ? 256 : 128);
     const int n_blocks = (int)ceil_div(a.n_oc, DH_BN);
     const long total = m_tiles * n_blocks;
     const long grid = ceil_div(total, 8) * 8;
     LRPX_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "dense_f16x3: grid %ld out of range", grid);
-    static LdsOnce attr_once;
-    LRPX_TRY(reserve_lds_once(attr_once, dense_f16x3_kernel, DH_LDS, "dense_f16x3"));
-    hipLaunchKernelGGL(dense_f16x3_kernel, dim3((unsigned)grid), dim3(256), DH_LDS, stream, a, (int)m_tiles, n_blocks);
+    static LdsOnce attr_once[4];
+    const int which = (plain ? 2 : 0) + (wide ? 1 : 0);
+    if (wide) {
+        auto kern = plain ? dense_f16x3_kernel<EPI_PLAIN, 4> : dense_f16x3_kernel<EPI_REL, 4>;
+        LRPX_TRY(reserve_lds_once(attr_once[which], kern, DenseCfg<4>::LDS, "dense_f16x3"));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), DenseCfg<4>::LDS, stream, a, (int)m_tiles, n_blocks);
+    } else {
+        auto kern = plain ? dense_f16x3_kernel<EPI_PLAIN, 2> : dense_f16x3_kernel<EPI_REL, 2>;
+        LRPX_TRY(reserve_lds_once(attr_once[which], kern, DenseCfg<2>::LDS, "dense_f16x3"));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), DenseCfg<2>::LDS, stream, a, (int)m_tiles, n_blocks);
+    }
     return check_launch("dense_f16x3");
 }
 

@@ -35,6 +35,7 @@ const Switches& switches() {
         w.pool28 = num("LRPX_POOL28", 1);
         w.s21_nhwc = set("LRPX_S21_NHWC");
         w.guided_poolbwd = set("LRPX_GUIDED_POOLBWD");
+        w.dense_wide = num("LRPX_DENSE_WIDE", 0);
         w.dense_1wave = set("LRPX_DENSE_1WAVE");
         w.linear_valu = set("LRPX_LINEAR_VALU");
         return w;

@@ -32,9 +32,16 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
     a.ksplit = 1;
     // many rows (the (word, pixel) rules of the decoders): split products on the fp16 matrix cores (dense_f16x3.hip);
     // `wpacked` is then an lrpx_pack_weights_f16x2 blob (taps = 1) and `in_amax` holds max|in| per map
+    if (d->taps == 1 && d->f16x3 && d->epi == EPI_PLAIN) {
+        // out0 = in W^T + bias on the fp16 matrix cores (the (T,V) scores of a trace): weights from lrpx_pack_weights_f16x2(PACK_FWD,
+        // taps = 1), in_amax = max|in| per map (rows of a map share one operand scale; pix_per_map = 1: per row)
+        LRPX_REQUIRE(d->f16x3 == 1 && d->in_amax && d->pix_per_map > 0 && d->out0 && !d->out1,
+                     "conv_mfma: the dense f16x3 PLAIN GEMM needs in_amax, pix_per_map and out0");
+        return launch_dense_f16x3(a, s);
+    }
     if (d->taps == 1 && d->f16x3) {
         LRPX_REQUIRE(d->f16x3 == 1 && d->epi == EPI_REL && d->x && d->pix_per_map > 0,
-                     "conv_mfma: the dense f16x3 GEMMs are built for the REL epilogue (need x, pix_per_map)");
+                     "conv_mfma: the dense f16x3 GEMMs are built for the REL / PLAIN epilogues (REL needs x, pix_per_map)");
         // few rows (the lock-step gate rules): whole K per workgroup, per-row operand scales found while staging
         if ((long)d->n_maps * d->pix_per_map <= 4096 && d->cin <= 1024 && !d->out1) return launch_dense_small_f16x3(a, s);
         LRPX_REQUIRE(d->in_amax, "conv_mfma: the many-row dense f16x3 GEMM needs in_amax (max|in| per map)");

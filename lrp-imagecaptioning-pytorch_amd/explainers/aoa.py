@@ -55,6 +55,7 @@ class AOAEngine:
         self.p_k_fwd = ops.pack_weights(sd["decoder_k_proj.weight"], H, H, 1, PACK_DENSE, kc)
         self.p_v_fwd = ops.pack_weights(sd["decoder_v_proj.weight"], H, H, 1, PACK_DENSE, kc)
         self.p_fc_fwd = ops.pack_weights(sd["fc.weight"], self.V, H, 1, PACK_DENSE, kc)
+        self.p_fc_fwd_h = ops.pack_weights_f16x2(sd["fc.weight"], self.V, H, _lib.PACK_FWD, taps=1) if H % 64 == 0 else None
         wg = torch.cat([sd[l + "weight_ih"][2 * H:3 * H], sd[l + "weight_hh"][2 * H:3 * H]], 1).contiguous()
         self.p_wg = ops.pack_weights(wg, H, E + 2 * H, 1, PACK_DENSE_T, kc)
         self.p_lin_rel = ops.pack_weights(sd["decoder_aoa_linear.weight"], H, H, 1, PACK_DENSE_T, kc)
@@ -265,7 +266,7 @@ class AOAEngine:
         check(lib.lrpx_target_logit(ptr(tr["hc"]), ptr(sd["fc.weight"]), ptr(sd["fc.bias"]), ptr(captions), T + 1,
                                     ptr(tr["logit"]), B, T, H, st))
         if predictions:
-            tr["pred"] = self.logits(tr["hc"].view(B * T, H)).view(B, T, self.V)
+            tr["pred"] = self.logits(tr["hc"].view(B * T, H), fast=True).view(B, T, self.V)
         return tr
 
     def gradient(self, enc, tr, head_idx, lens=None):
@@ -340,9 +341,16 @@ class AOAEngine:
             out = out + (d_feat.view(B, T, enc["P"], self.C), tr, enc)
         return out
 
-    def logits(self, hc_rows):
+    def logits(self, hc_rows, fast=False):
+        """fc scores for R rows -> (R,V).  fast=True (the (T,V) block a trace keeps, not the decisions of a decoding loop): split
+        products on the fp16 matrix cores (csrc/dense_f16x3.hip, fp32-grade: <= 2e-7 of a row's maximum)"""
         R = hc_rows.shape[0]
         out = torch.empty(R, self.V, device=self.device)
+        if fast and R >= 128 and self.p_fc_fwd_h is not None:
+            hc_rows = hc_rows.contiguous()
+            ops.conv_mfma(hc_rows, self.p_fc_fwd_h, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=self.V,
+                          bias=self.sd["fc.bias"], out0=out, f16x3=1, in_amax=ops.amax_maps(hc_rows, R))
+            return out
         ops.conv_mfma(hc_rows, self.p_fc_fwd, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1,
                       oc_split=self.V, bias=self.sd["fc.bias"], out0=out)
         return out

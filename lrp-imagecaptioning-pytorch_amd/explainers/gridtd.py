@@ -57,6 +57,7 @@ class GridTDEngine:
         self.p_proj_fwd = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE, kc)
         self.p_attv_fwd = ops.pack_weights(sd["AdaAttention.W_v_proj.weight"], self.P, H, 1, PACK_DENSE, kc)
         self.p_fc_fwd = ops.pack_weights(sd["fc.weight"], self.V, H, 1, PACK_DENSE, kc)
+        self.p_fc_fwd_h = ops.pack_weights_f16x2(sd["fc.weight"], self.V, H, _lib.PACK_FWD, taps=1) if H % 64 == 0 else None
         # --- guided-backprop weights: full gate matrices, contraction over the 4H gate rows (gridTDmodel.py:1637-1659)
         self.p_g2 = ops.pack_weights(self.Wcat2, 4 * H, 3 * H, 1, PACK_DENSE_T, kc)
         self.p_g1 = ops.pack_weights(sd[a + "weight_ih"].contiguous(), 4 * H, 2 * E + H, 1, PACK_DENSE_T, kc)
@@ -175,13 +176,19 @@ class GridTDEngine:
         check(lib.lrpx_target_logit(ptr(tr["hc"]), ptr(self.sd["fc.weight"]), ptr(self.sd["fc.bias"]), ptr(captions),
                                     T + 1, ptr(tr["logit"]), B, T, self.H, stream_ptr()))
         if predictions:
-            tr["pred"] = self.logits(tr["hc"].view(B * T, self.H)).view(B, T, self.V)
+            tr["pred"] = self.logits(tr["hc"].view(B * T, self.H), fast=True).view(B, T, self.V)
         return tr
 
-    def logits(self, hc_rows):
-        """fc(context_hat + h2) (gridTDmodel.py:990) for R rows -> (R,V)."""
+    def logits(self, hc_rows, fast=False):
+        """fc(context_hat + h2) (gridTDmodel.py:990) for R rows -> (R,V).  fast=True (the (T,V) block a trace keeps, not the
+        decisions of a decoding loop): split products on the fp16 matrix cores (csrc/dense_f16x3.hip, fp32-grade)"""
         R = hc_rows.shape[0]
         out = torch.empty(R, self.V, device=self.device)
+        if fast and R >= 128 and self.p_fc_fwd_h is not None:
+            hc_rows = hc_rows.contiguous()
+            ops.conv_mfma(hc_rows, self.p_fc_fwd_h, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=self.V,
+                          bias=self.sd["fc.bias"], out0=out, f16x3=1, in_amax=ops.amax_maps(hc_rows, R))
+            return out
         ops.conv_mfma(hc_rows, self.p_fc_fwd, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1,
                       oc_split=self.V, bias=self.sd["fc.bias"], out0=out)
         return out

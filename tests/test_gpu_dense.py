@@ -136,3 +136,27 @@ def test_dense_f16x3_rel_few_rows(ops, rows, k, n, n_src):
     assert got[~live].abs().max().item() == 0 if (~live).any() else True
     print(f"dense f16x3, few rows ({rows} x {k} -> {n}): worst row {err:.2e} of its maximum")
     assert err < 2e-6
+
+
+@pytest.mark.parametrize("rows,k,n", [(640, 512, 11027), (320, 512, 9586), (130, 64, 96)])
+def test_dense_f16x3_plain_scores(ops, rows, k, n):
+    """the (T,V) score block of a trace on the fp16 matrix cores (dense_f16x3_kernel<EPI_PLAIN>): out = A W^T + b with a per-row
+    operand scale, rows spread over 1e-6 .. 1e6, against fp64: <= 2e-6 of a row's maximum; nothing written behind the output"""
+    from lrp_amd import _lib
+    g = torch.Generator().manual_seed(rows + n)
+    a = torch.randn(rows, k, generator=g) * torch.logspace(-6, 6, rows).view(-1, 1)
+    w = torch.randn(n, k, generator=g) * 0.05
+    b = torch.randn(n, generator=g) * 0.1
+    wp = ops.pack_weights_f16x2(w.cuda(), n, k, _lib.PACK_FWD, taps=1)
+    n_pad = -(-n // 32) * 32
+    buf = torch.full((rows * n + 4096,), 333.0, device="cuda")
+    ac = a.cuda()
+    ops.conv_mfma(ac, wp, rows, 0, k, n_pad, 1, _lib.EPI_PLAIN, pix_per_map=1, oc_split=n, bias=b.cuda(), out0=buf[:rows * n],
+                  f16x3=1, in_amax=ops.amax_maps(ac, rows))
+    torch.cuda.synchronize()
+    assert (buf[rows * n:] == 333.0).all()
+    got = buf[:rows * n].view(rows, n).cpu().double()
+    want = a.double() @ w.double().t() + b.double()
+    err = ((got - want).abs().amax(dim=1) / want.abs().amax(dim=1)).max().item()
+    print(f"dense f16x3 PLAIN ({rows} x {k} -> {n}): worst row {err:.2e} of its maximum")
+    assert err < 2e-6
