@@ -79,19 +79,23 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void dense_f16x3_kernel(
 #define DH_ISSUE(CHUNK) if constexpr (!(LRPXB_EXP & 4)) { _Pragma("unroll") for (int u = 0; u < C::NU; ++u) sv[u] = *reinterpret_cast<const f32x4*>(A + srow[u] + (CHUNK) * C::KC + s_seg * 4); }
 #define DH_COMMIT(BUFI)                                                                                    \
     _Pragma("unroll") for (int u = 0; u < C::NU; ++u) {                                                    \
-        _Float16 h[4], l[4];                                                                               \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * ssc[u], h[e], l[e]);                \
+        unsigned h0_, h1_, l0_, l1_;                                                                       \
+        f32x2_ f0_, f1_;                                                                                   \
+        split2_pk(f32x2_{sv[u][0], sv[u][1]} * f32x2_{ssc[u], ssc[u]}, h0_, l0_, f0_);                     \
+        split2_pk(f32x2_{sv[u][2], sv[u][3]} * f32x2_{ssc[u], ssc[u]}, h1_, l1_, f1_);                     \
         char* d_ = ldsb + (BUFI) * C::BUF + (s_row + C::RP * u) * C::ROWB + s_off;                         \
-        *reinterpret_cast<u32x2_*>(d_) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};               \
-        *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};          \
+        *reinterpret_cast<u32x2_*>(d_) = u32x2_{h0_, h1_};                                                 \
+        *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{l0_, l1_};                                            \
     }
 #define DH_COMMIT_PART(BUFI, U0, NUM)                                                                     \
     _Pragma("unroll") for (int u = (U0); u < (U0) + (NUM); ++u) {                                          \
-        _Float16 h[4], l[4];                                                                               \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) split2(sv[u][e] * ssc[u], h[e], l[e]);                \
+        unsigned h0_, h1_, l0_, l1_;                                                                       \
+        f32x2_ f0_, f1_;                                                                                   \
+        split2_pk(f32x2_{sv[u][0], sv[u][1]} * f32x2_{ssc[u], ssc[u]}, h0_, l0_, f0_);                     \
+        split2_pk(f32x2_{sv[u][2], sv[u][3]} * f32x2_{ssc[u], ssc[u]}, h1_, l1_, f1_);                     \
         char* d_ = ldsb + (BUFI) * C::BUF + (s_row + C::RP * u) * C::ROWB + s_off;                         \
-        *reinterpret_cast<u32x2_*>(d_) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};               \
-        *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};          \
+        *reinterpret_cast<u32x2_*>(d_) = u32x2_{h0_, h1_};                                                 \
+        *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{l0_, l1_};                                            \
     }
     DH_ISSUE(0)
 
@@ -344,12 +348,13 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
             if (EXACT || it < 32 * k4) {
                 const int r = it / k4, c4 = it - r * k4;
                 const float sc = exp2i(f16_scale_exp(rowmax[r]));
-                _Float16 h[4], l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split2(sv[u][e] * sc, h[e], l[e]);
+                unsigned h0_, h1_, l0_, l1_;
+                f32x2_ f0_, f1_;
+                split2_pk(f32x2_{sv[u][0], sv[u][1]} * f32x2_{sc, sc}, h0_, l0_, f0_);
+                split2_pk(f32x2_{sv[u][2], sv[u][3]} * f32x2_{sc, sc}, h1_, l1_, f1_);
                 char* d_ = ldsb + r * pitch + (c4 >> 2) * 64 + ((c4 >> 1) & 1) * 16 + (c4 & 1) * 8;
-                *reinterpret_cast<u32x2_*>(d_) = u32x2_{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};
-                *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};
+                *reinterpret_cast<u32x2_*>(d_) = u32x2_{h0_, h1_};
+                *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{l0_, l1_};
             }
         }
     }

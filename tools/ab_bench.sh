@@ -2,7 +2,7 @@
 # A/B of the whole pipelined step on ONE box: tools/ab_bench.sh "<env A>" "<env B>" ... ; 20 steps + 5 s sustained, twice
 for rep in 1 2; do
 for v in "$@"; do
-  out=$(env $v timeout -k 10 300 python bench.py --no-cpu-baseline --no-modes 2>/dev/null)
+  out=$(env $v timeout -k 10 300 python bench.py --no-cpu-baseline --no-modes --no-configs 2>/dev/null)
   python - "$v" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[2])

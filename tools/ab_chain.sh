@@ -3,7 +3,7 @@
 # prints chain ms + per-layer ms (HIP events of the library) for every variant, twice (boxes drift by ~1 %)
 for rep in 1 2; do
 for v in "$@"; do
-  out=$(env $v timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-modes --sustain 0 2>/dev/null)
+  out=$(env $v timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-modes --no-configs --sustain 0 2>/dev/null)
   python - "$v" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[2])
