@@ -136,7 +136,7 @@ __host__ __device__ constexpr int f8_slot_tap(int m, int i) { return 2 * m + i; 
 template <int HW, bool AL, int EPI>
 __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc)[7], float* __restrict__ scr, const int wm,
                                                  const int ocb, const int lane, const long g0, const long total_pix,
-                                                 unsigned* __restrict__ oamax) {
+                                                 unsigned* __restrict__ oamax, const int* __restrict__ tab) {
     constexpr int PITCH_F = 36;
     const int li = lane & 31, lh = lane >> 5;
     const int qd = lane & 7, r0 = lane >> 3;
@@ -160,8 +160,12 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
         const unsigned g = (unsigned)g0 + rr;
         n0 = g / (unsigned)HW;
         p0 = (int)((g - n0 * HW) * HW + c0);
-        const long img0 = a.map2img ? a.map2img[min((int)n0, nmax)] : (long)n0;
-        const long img1 = AL ? img0 : (a.map2img ? a.map2img[min((int)n0 + 1, nmax)] : (long)n0 + 1);
+        long img0, img1;
+        if constexpr (AL) {
+            img0 = img1 = a.map2img ? a.map2img[min((int)n0, nmax)] : (long)n0;
+        } else {       // map-straddling tiles: the two images of the tile from the workgroup's table (filled in the prologue)
+            img0 = tab[(wm * 7 + j) * 4 + 2]; img1 = tab[(wm * 7 + j) * 4 + 3];
+        }
         b0 = (img0 * P + p0) * (long)ncol + oc4;
         b1 = (img1 * P + p0 - (long)P) * (long)ncol + oc4;
     };
@@ -339,6 +343,22 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     }
     const int li = lane & 31, lh = lane >> 5;
     const unsigned* __restrict__ in_amax = a.in_amax;
+    // map-straddling tiles (28x28 / 14x14): per accumulator tile (wave row wm, tile j) the operand scales and the images of the
+    // map of its first pixel and of the next map, looked up ONCE by 7 * MT threads while the first staging loads are in flight
+    // and parked in LDS behind the staging buffers: [wm * 7 + j][2^-kA(n0), 2^-kA(n0 + 1), image(n0), image(n0 + 1)]
+    int* tile_tab = reinterpret_cast<int*>(ldsb + NBUF * BUFB + 256 + 16);
+    if constexpr (!AL) {
+        if (tid < 7 * MT) {
+            const unsigned q0t = (unsigned)((tid / 7) * 224 + 32 * (tid % 7));
+            const unsigned g = (unsigned)((long)mtile * C::R) + q0t / (unsigned)HW;
+            const int n0 = (int)(g / (unsigned)HW), nmax_ = a.n_maps - 1;
+            const int na = min(n0, nmax_), nb = min(n0 + 1, nmax_);
+            tile_tab[tid * 4 + 0] = __builtin_bit_cast(int, exp2i(-split_scale_exp<F8>(in_amax[na])));
+            tile_tab[tid * 4 + 1] = __builtin_bit_cast(int, exp2i(-split_scale_exp<F8>(in_amax[nb])));
+            tile_tab[tid * 4 + 2] = a.map2img ? a.map2img[na] : n0;
+            tile_tab[tid * 4 + 3] = a.map2img ? a.map2img[nb] : n0 + 1;
+        }
+    }
 
     const long g0 = (long)mtile * C::R;
     const long v0 = g0 + g0 / H;
@@ -819,7 +839,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #ifndef LRPXH_PIPE_112P
 #define LRPXH_PIPE_112P 1      // conv2_2: 2.26 -> 2.12 ms (depth 3 with a B queue of 2: the same)
 #endif
-                constexpr int PIPE_D = (MT * NWN >= 8) ? (MT >= 2 ? LRPXH_F8_PIPE_TALL : LRPXH_F8_PIPE)
+#ifndef LRPXH_F8_PIPE_POOLS
+#define LRPXH_F8_PIPE_POOLS LRPXH_F8_PIPE      // the map-straddling pooled-input 8-wave kernel (conv4_3): the only one that spills
+#endif
+                constexpr int PIPE_D = (MT * NWN >= 8) ? (MT >= 2 ? LRPXH_F8_PIPE_TALL : ((POOL && !AL) ? LRPXH_F8_PIPE_POOLS : LRPXH_F8_PIPE))
                                                        : ((HW == 224 && POOL) ? 1 : ((HW == 112 && POOL) ? LRPXH_PIPE_112P : LRPXH_PIPE_4W));
 #endif
                 if constexpr (PIPE_D != 0) {
@@ -1073,14 +1096,16 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     } else {
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-            // a 32-pixel accumulator tile is shorter than a map: at most one boundary inside it (cf. epi_gather)
-            const unsigned q0t = (unsigned)(cx.q0 + 32 * j);
+            // a 32-pixel accumulator tile is shorter than a map: at most one boundary inside it (cf. epi_gather).  The two
+            // scales of the tile come from the workgroup's table (the prologue looked them up: 14 dependent global loads per
+            // wave sat here, behind the K loop - conv4_3 -8 %, conv4_2 -2 % in a build without them)
+            const unsigned q0t = (unsigned)(wm * 224 + 32 * j);            // the tile's first pixel (lanes 32-63: 4 pixels on)
             const unsigned rr = q0t / (unsigned)HW, c0 = q0t - rr * HW;
             const unsigned g = (unsigned)cx.g0 + rr;
             const unsigned n0 = g / (unsigned)HW;
-            const int p0 = (int)((g - n0 * HW) * HW + c0);
-            const float i0 = exp2i(-split_scale_exp<F8>(in_amax[min((int)n0, nmax)]));
-            const float i1 = exp2i(-split_scale_exp<F8>(in_amax[min((int)n0 + 1, nmax)]));
+            const int p0 = (int)((g - n0 * HW) * HW + c0) + 4 * lh;
+            const float i0 = __builtin_bit_cast(float, tile_tab[(wm * 7 + j) * 4 + 0]);
+            const float i1 = __builtin_bit_cast(float, tile_tab[(wm * 7 + j) * 4 + 1]);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int dq = (e & 3) + 8 * (e >> 2);
@@ -1103,7 +1128,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     if constexpr ((EPI == EPI_REL_MUL || EPI == EPI_GUIDED) && ((LRPXH_WIDE_EPI == 1 && !AL) || LRPXH_WIDE_EPI == 2)) {
         // (the K loop ends with a barrier: nobody reads the staging buffers any more; 32 x 36 floats per wave)
         float* scr = reinterpret_cast<float*>(ldsb) + wave * (32 * 36);
-        epi_rel_mul_wide<HW, AL, EPI>(a, acc, scr, wm, ocb, lane, g0, total_pix, oamax);
+        epi_rel_mul_wide<HW, AL, EPI>(a, acc, scr, wm, ocb, lane, g0, total_pix, oamax, tile_tab);
 #ifdef LRPX_STAMP
         {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1197,7 +1222,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
 int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
     using C = ConvCfg<HW, 16, MT, NWN, 9>;
-    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 80 + 256) + 256;
+    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 80 + 256) + 256 + 16 + 7 * MT * 16;     // buffers + scratch + tile table
     const long m_tiles = ceil_div((long)a.n_maps * HW, C::R);
     const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
     long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
