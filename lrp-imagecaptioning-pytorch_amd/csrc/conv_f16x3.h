@@ -36,11 +36,17 @@ __host__ __device__ __forceinline__ int f16_scale_exp(unsigned amax_bits) {
     const int k = 14 - (e - 127);
     return k > 120 ? 120 : k;
 }
+// Which narrow format carries the two cross products of the F8 kernels: 1 = block-scaled fp6 e2m3 (v_mfma_scale_f32_32x32x64_f8f6f4
+// at 32 cycles per K = 64, as fast as one fp16 MFMA of K = 16), 0 = fp8 e4m3 (64 cycles; rounds 1-2 of this kernel)
+#ifndef LRPXH_XP6
+#define LRPXH_XP6 1
+#endif
 // F8 variant (cross products on the fp8 matrix cores, see below): operands are scaled into [2^11, 2^12) instead, so
-// that x * 2^-4 fits fp8 e4m3 (max 448) and the fp16 residual * 2^4 does too
+// that x * 2^-4 fits fp8 e4m3 (max 448) and the fp16 residual * 2^4 does too.  (fp6: every 16-channel slice carries its own
+// block exponent, the operands keep the fp16 range.)
 template <bool F8>
 __host__ __device__ __forceinline__ int split_scale_exp(unsigned amax_bits) {
-    if constexpr (!F8) return f16_scale_exp(amax_bits);
+    if constexpr (!F8 || (LRPXH_XP6 != 0)) return f16_scale_exp(amax_bits);
     const int e = (int)((amax_bits >> 23) & 0xff);
     if (e == 0 || e == 255) return 0;
     const int k = 11 - (e - 127);
@@ -245,6 +251,54 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
     }
 }
 
+// ---- fp6 cross products (LRPXH_XP6) ----
+typedef unsigned u32x6_ __attribute__((ext_vector_type(6)));
+typedef unsigned u32x3_ __attribute__((ext_vector_type(3)));
+typedef unsigned u32x16_ __attribute__((ext_vector_type(16)));
+// One 16-channel slice v * sc (scaled into the fp16 range): hw = the fp16 hi halves (8 packed pairs), rw = the residuals
+// (x - hi) * 2^11 as fp16 pairs (|.| <= |x|: the same block serves both), and the slice's block scale bs - a float whose EXPONENT
+// FIELD e is what the conversion and the matrix core use: values / 2^(e-127) lie in [3.75, 7.5] for the largest |x| (e2m3 saturates
+// at 7.5).  The E8M0 byte of the matrix core carries the 2^-11 of the residual scaling: e - 11 (clamped at 0: such a slice is
+// < 2^-116 of the fp16 range).
+__device__ __forceinline__ void x6_split(const f32x4 (&v)[4], const float sc, unsigned (&hw)[8], unsigned (&rw)[8], float& bs, unsigned& sbyte) {
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        const f32x2_ x2 = f32x2_{v[c >> 2][c & 3], v[c >> 2][(c & 3) + 1]} * f32x2_{sc, sc};
+        const f16x2_ h = __builtin_convertvector(x2, f16x2_);
+        const f32x2_ hf = __builtin_convertvector(h, f32x2_);
+        const f16x2_ r = __builtin_convertvector((x2 - hf) * f32x2_{2048.f, 2048.f}, f16x2_);
+        hw[c / 2] = __builtin_bit_cast(unsigned, h);
+        rw[c / 2] = __builtin_bit_cast(unsigned, r);
+        m = fmaxf(m, fmaxf(fabsf(x2[0]), fabsf(x2[1])));
+    }
+    bs = m * (16.f / 15.f * 0.25f);
+    const int e = (int)((__builtin_bit_cast(unsigned, bs) >> 23) & 0xffu);
+    sbyte = (unsigned)max(e - 11, 0);
+}
+// 32 fp16 -> 32 fp6 e2m3, field c = x_c / 2^(e-127), field 16 + c = r_c / 2^(e-127) (v_cvt_scalef32_pk32_fp6_f16: element i ->
+// field i, round to nearest even, saturating).  Inline asm with an EARLY-CLOBBER result: the compiler (ROCm 7.2) lets the 6
+// result registers of the conversion builtins overlap their 16 / 32 source registers, and the multi-pass instruction then reads
+// sources it has already overwritten (seen with __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32 as wrong cross products in exactly
+// those unrolled item copies whose allocation overlapped: v[126:131] <- v[112:127], v[128:143]).
+__device__ __forceinline__ u32x6_ x6_pack(const unsigned (&hw)[8], const unsigned (&rw)[8], const float bs) {
+    const u32x16_ src = {hw[0], hw[1], hw[2], hw[3], hw[4], hw[5], hw[6], hw[7], rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], rw[6], rw[7]};
+    u32x6_ q;
+    asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(q) : "v"(src), "v"(bs));
+    return q;
+}
+// host / pack-time encoder of one e2m3 value (round to nearest even, saturating at 7.5): |v| < 2: steps of 1/8 (subnormals and the
+// first binade), [2, 4): 1/4, [4, 8): 1/2
+__host__ __device__ __forceinline__ unsigned fp6_e2m3_encode(float v) {
+    const unsigned sgn = v < 0.f ? 32u : 0u;
+    const float a = fabsf(v);
+    float c;
+    if (!(a < 2.f)) c = !(a < 4.f) ? rintf(a * 2.f) + 16.f : rintf(a * 4.f) + 8.f;
+    else c = rintf(a * 8.f);
+    if (!(c < 31.f)) c = 31.f;                      // (also NaN)
+    return sgn | (unsigned)c;
+}
+
 // F8 ("f16+f8x2"): the two CROSS products a0*b1 + a1*b0 - 2^-11 of the result - do not need fp16 operands: with both
 // factors rounded to fp8 e4m3 (4 significand bits) their error is 2^-11 * 2^-4 per product, random sign; simulated
 // through all 13 layers the maps move by < 1e-5 of their maximum (tolerance 1e-4; plain f16x3: ~1e-6).  They run on
@@ -279,6 +333,11 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #define LRPXH_APIPE_MIN_HW 14
 #endif
     constexpr bool APIPE = (HW >= LRPXH_APIPE_MIN_HW) && !F8;
+    // X6: the cross products as block-scaled fp6.  LDS pixel: 16 fp16 hi (32 B) | 32 fp6 e2m3 = x_0..x_15, then (x_c - hi_c) * 2^11,
+    // c = 0..15, all divided by the slice's block scale 2^s (24 B) | E8M0 byte s - 11 + 127 (dword at byte 60; byte 56 stays clear so that the 8 + 4 byte reads do not fuse into a slower ds_read_b96) | pad.  A staging item is one
+    // pixel's whole 16-channel slice (4 float4): the block maximum and v_cvt_scalef32_pk32_fp6_f16 need the 16 values in one lane.
+    constexpr bool X6 = F8 && (LRPXH_XP6 != 0);
+    constexpr int NV = X6 ? 4 : 1;                     // float4 loads per staging item
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
     const int tid = threadIdx.x;
@@ -384,7 +443,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // (lrp_modules.py:182-195) is applied while staging - pixel (y, x) receives S_lo[y/2][x/2] if it is the winner of
     // its window, else 0 - so the 4x larger unpooled tensor (75 % zeros) never exists in HBM.  The global pixel is
     // then the LOW-resolution one, the window position rides in bits 26-27 of the LDS offset.
-    constexpr int SEG = KC / 4;
+    constexpr int SEG = X6 ? 1 : KC / 4;
     constexpr int NITEM = C::NSLOT * W * SEG;
     // map-aligned tiles: staging items are laid out ROW-WISE over the threads - item slot u of thread tid is LDS row
     // u*RPS + tid/RI (narrow maps: RPS whole rows per slot) or row u/SPR, part u%SPR (wide maps: SPR slots per row) - so
@@ -591,8 +650,9 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         in_tile = a.in + ((long)n_al * (HO * WO) + lo_row * WO) * a.cin;
         am_tile = a.pool_am + (img_al * (HO * WO) + lo_row * WO) * a.cin;
     }
-    f32x4 sv[LOSTAGE ? UL : U];
-    unsigned amv[POOL ? (LOSTAGE ? UL : U) : 1];
+    f32x4 sv[LOSTAGE ? UL : U][NV];
+    unsigned amv[(POOL && !X6) ? (LOSTAGE ? UL : U) : 1];
+    u32x4_ amv4[(POOL && X6) ? (LOSTAGE ? UL : U) : 1];      // X6: the 16 winner bytes of the item's slice
 #define LRPXH_ISSUE_LO(CHUNK) _Pragma("unroll") for (int u = 0; u < UL; ++u) LRPXH_ISSUE_LO1(u, CHUNK)
 #define LRPXH_COMMIT_LO(BUFIDX) _Pragma("unroll") for (int u = 0; u < UL; ++u) LRPXH_COMMIT_LO1(u, BUFIDX)
 #define LRPXH_ISSUE_LO1(u, CHUNK)                                                                            \
@@ -601,16 +661,21 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         float sc_;                                                                                           \
         item_lo(u, dst_, gp_, amo_, rm_, sc_);                                                               \
         const int sg_ = ((dst_ >> 28) & 3) * 4;                                                              \
+        const float* sp_;                                                                                    \
+        const unsigned char* ap_;                                                                            \
         if constexpr (AL) {                                                                                  \
             const unsigned e_ = __umul24((unsigned)(gp_ >= 0 ? gp_ : WO), (unsigned)a.cin) + (unsigned)sg_;  \
-            sv[u] = *reinterpret_cast<const f32x4*>(in_tile + (CHUNK) * KC + e_);                            \
-            amv[u] = *reinterpret_cast<const unsigned*>(am_tile + (CHUNK) * KC + e_);                        \
+            sp_ = in_tile + (CHUNK) * KC + e_;                                                               \
+            ap_ = am_tile + (CHUNK) * KC + e_;                                                               \
         } else {                                                                                             \
             const long g_ = gp_ >= 0 ? gp_ : 0;                                                              \
             const int am_ = gp_ >= 0 ? amo_ : 0;                                                             \
-            sv[u] = *reinterpret_cast<const f32x4*>(a.in + g_ * a.cin + (CHUNK) * KC + sg_);                  \
-            amv[u] = *reinterpret_cast<const unsigned*>(a.pool_am + am_ + (CHUNK) * KC + sg_);                \
+            sp_ = a.in + g_ * a.cin + (CHUNK) * KC + sg_;                                                    \
+            ap_ = a.pool_am + am_ + (CHUNK) * KC + sg_;                                                      \
         }                                                                                                    \
+        _Pragma("unroll") for (int v_ = 0; v_ < NV; ++v_) sv[u][v_] = reinterpret_cast<const f32x4*>(sp_)[v_]; \
+        if constexpr (X6) amv4[u] = *reinterpret_cast<const u32x4_*>(ap_);                                   \
+        else amv[u] = *reinterpret_cast<const unsigned*>(ap_);                                               \
     }
 // The four window positions of an item differ only in the lanes that are kept: byte masks from one SWAR compare of the
 // four winner bytes (values 0..3) per position, halfword masks by v_perm_b32, row bases selected once per item (an absent
@@ -622,7 +687,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         int dst_, gp_, amo_, rm_;                                                                            \
         float sc_;                                                                                           \
         item_lo(u, dst_, gp_, amo_, rm_, sc_);                                                               \
-        const f32x2_ xa_ = f32x2_{sv[u][0], sv[u][1]} * f32x2_{sc_, sc_}, xb_ = f32x2_{sv[u][2], sv[u][3]} * f32x2_{sc_, sc_}; \
+        if constexpr (X6) { LRPXH_COMMIT_LO1_X6(u, BUFIDX) } else {                                          \
+        const f32x2_ xa_ = f32x2_{sv[u][0][0], sv[u][0][1]} * f32x2_{sc_, sc_}, xb_ = f32x2_{sv[u][0][2], sv[u][0][3]} * f32x2_{sc_, sc_}; \
         unsigned hw0_, hw1_, lw0_, lw1_;                                                                     \
         f32x2_ ha_, hb_;                                                                                     \
         split2_pk(xa_, hw0_, lw0_, ha_); split2_pk(xb_, hw1_, lw1_, hb_);                                    \
@@ -652,6 +718,39 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{lw0_ & m01_, lw1_ & m23_};                      \
             }                                                                                                \
         }                                                                                                    \
+        }                                                                                                    \
+    }
+// X6: the item is the whole 16-channel slice of a pooled pixel.  Split once; per window position the channels that did not win
+// there are zeroed on the fp32 values (bit masks replicated from the SWAR compare of the 16 winner bytes), then hi = cvt_pk of the
+// masked values and one fp6 conversion with the slice's common block scale (the maximum over all 16 channels: a position that
+// keeps only small entries is rounded against the pooled pixel's largest one - the same absolute error as in a layer without pool)
+#define LRPXH_COMMIT_LO1_X6(u, BUFIDX)                                                                       \
+    {                                                                                                        \
+        unsigned hwu_[8], rwu_[8], sb_;                                                                      \
+        float bs_;                                                                                           \
+        x6_split(sv[u], sc_, hwu_, rwu_, bs_, sb_);                                                          \
+        const int o0_ = (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                               \
+        const int rb0_ = ((rm_ & 1) && !(LRPXH_EXP & 4)) ? o0_ : POOL_SCRATCH;   /* window row dy = 0 */    \
+        const int rb1_ = ((rm_ & 2) && !(LRPXH_EXP & 4)) ? o0_ + ((rm_ & 1) ? PITCH : 0) : POOL_SCRATCH;     \
+        _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                                \
+            unsigned hm_[8], rm2_[8];                                                                        \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                               \
+                const unsigned x_ = amv4[u][q_] ^ (0x01010101u * (unsigned)pos);  /* zero byte <=> winner == pos */ \
+                const unsigned eq_ = ((x_ | (x_ >> 1)) & 0x01010101u) ^ 0x01010101u;                         \
+                /* v_perm_b32 selector bytes 0x0c / 0x0d yield the constants 0x00 / 0xff: halfword masks of channels 4q .. 4q + 3 */ \
+                const unsigned sel_ = eq_ + 0x0c0c0c0cu;                                                     \
+                const unsigned m01_ = __builtin_amdgcn_perm(0u, 0u, __builtin_amdgcn_perm(sel_, sel_, 0x01010000u)); \
+                const unsigned m23_ = __builtin_amdgcn_perm(0u, 0u, __builtin_amdgcn_perm(sel_, sel_, 0x03030202u)); \
+                hm_[2 * q_] = hwu_[2 * q_] & m01_; hm_[2 * q_ + 1] = hwu_[2 * q_ + 1] & m23_;                \
+                rm2_[2 * q_] = rwu_[2 * q_] & m01_; rm2_[2 * q_ + 1] = rwu_[2 * q_ + 1] & m23_;              \
+            }                                                                                                \
+            const u32x6_ q6_ = x6_pack(hm_, rm2_, bs_);                                                      \
+            char* d_ = ldsb + ((pos >> 1) ? rb1_ : rb0_) + (pos & 1) * PSTRIDE;                              \
+            *reinterpret_cast<u32x4_*>(d_) = u32x4_{hm_[0], hm_[1], hm_[2], hm_[3]};                         \
+            *reinterpret_cast<u32x4_*>(d_ + 16) = u32x4_{hm_[4], hm_[5], hm_[6], hm_[7]};                    \
+            *reinterpret_cast<u32x4_*>(d_ + 32) = u32x4_{q6_[0], q6_[1], q6_[2], q6_[3]};                    \
+            *reinterpret_cast<u32x4_*>(d_ + 48) = u32x4_{q6_[4], q6_[5], 0u, sb_};                           \
+        }                                                                                                    \
     }
 #define LRPXH_ISSUE(CHUNK) _Pragma("unroll") for (int u = 0; u < U; ++u) LRPXH_ISSUE1(u, CHUNK)
 #define LRPXH_COMMIT(BUFIDX) _Pragma("unroll") for (int u = 0; u < U; ++u) LRPXH_COMMIT1(u, BUFIDX)
@@ -669,19 +768,30 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             const int sg_ = dst_ >= 0 ? ((dst_ >> 28) & 3) * 4 : 0;                                          \
             e_ = __umul24((unsigned)(gp_ >= 0 ? gp_ : W), in_pix_stride) + (unsigned)sg_;                    \
         }                                                                                                    \
-        sv[u] = *reinterpret_cast<const f32x4*>(in_tile + (CHUNK) * in_chunk_step + e_);                     \
+        _Pragma("unroll") for (int v_ = 0; v_ < NV; ++v_)                                                    \
+            sv[u][v_] = reinterpret_cast<const f32x4*>(in_tile + (CHUNK) * in_chunk_step + e_)[v_];          \
     }
 #define LRPXH_COMMIT1(u, BUFIDX)                                                                             \
     {                                                                                                        \
         int dst_, gp_, amo_;                                                                                 \
         item(u, dst_, gp_, amo_);                                                                            \
         /* (an item with nothing to write converts whatever its registers hold into the scratch bytes) */    \
+        char* d_ = ldsb + ((dst_ >= 0 && !(LRPXH_EXP & 4)) ? (BUFIDX) * BUFB + (dst_ & 0x03ffffff) : STAGE_SCRATCH); \
+        if constexpr (X6) {                                                                                  \
+            unsigned hwu_[8], rwu_[8], sb_;                                                                  \
+            float bs_;                                                                                       \
+            x6_split(sv[u], ssc[AL ? 0 : u], hwu_, rwu_, bs_, sb_);                                          \
+            const u32x6_ q6_ = x6_pack(hwu_, rwu_, bs_);                                                     \
+            *reinterpret_cast<u32x4_*>(d_) = u32x4_{hwu_[0], hwu_[1], hwu_[2], hwu_[3]};                     \
+            *reinterpret_cast<u32x4_*>(d_ + 16) = u32x4_{hwu_[4], hwu_[5], hwu_[6], hwu_[7]};                \
+            *reinterpret_cast<u32x4_*>(d_ + 32) = u32x4_{q6_[0], q6_[1], q6_[2], q6_[3]};                    \
+            *reinterpret_cast<u32x4_*>(d_ + 48) = u32x4_{q6_[4], q6_[5], 0u, sb_};                           \
+        } else {                                                                                             \
         const f32x2_ sc2_ = {ssc[AL ? 0 : u], ssc[AL ? 0 : u]};                                              \
-        const f32x2_ xa_ = f32x2_{sv[u][0], sv[u][1]} * sc2_, xb_ = f32x2_{sv[u][2], sv[u][3]} * sc2_;       \
+        const f32x2_ xa_ = f32x2_{sv[u][0][0], sv[u][0][1]} * sc2_, xb_ = f32x2_{sv[u][0][2], sv[u][0][3]} * sc2_; \
         unsigned hw0_, hw1_, lw0_, lw1_;                                                                     \
         f32x2_ ha_, hb_;                                                                                     \
         split2_pk(xa_, hw0_, lw0_, ha_); split2_pk(xb_, hw1_, lw1_, hb_);                                    \
-        char* d_ = ldsb + ((dst_ >= 0 && !(LRPXH_EXP & 4)) ? (BUFIDX) * BUFB + (dst_ & 0x03ffffff) : STAGE_SCRATCH); \
         *reinterpret_cast<u32x2_*>(d_) = u32x2_{hw0_, hw1_};                                                 \
         if constexpr (F8) {                                                                                  \
             const int sg4_ = ((dst_ >> 28) & 3) * 4;                                                         \
@@ -691,6 +801,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             *reinterpret_cast<unsigned*>(d_ - sg4_ + 48) = pack_fp8x4(ra_[0], ra_[1], rb_[0], rb_[1]);       \
         } else {                                                                                             \
             *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{lw0_, lw1_};                                        \
+        }                                                                                                    \
         }                                                                                                    \
     }
 
@@ -720,7 +831,12 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     if constexpr (!(LRPXH_EXP & 8)) { if constexpr (LOSTAGE) { LRPXH_ISSUE_LO(0) } else { LRPXH_ISSUE(0) } }
     else {      // (EXP 8: what the exposed first load of a tile costs - zeros instead)
 #pragma unroll
-        for (int u = 0; u < (LOSTAGE ? UL : U); ++u) { sv[u] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (POOL) amv[u] = 0; }
+        for (int u = 0; u < (LOSTAGE ? UL : U); ++u) {
+#pragma unroll
+            for (int v_ = 0; v_ < NV; ++v_) sv[u][v_] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (POOL && !X6) amv[u] = 0;
+            if constexpr (POOL && X6) amv4[u] = u32x4_{0, 0, 0, 0};
+        }
     }
     for (int i = tid; i < NBUF * BUFB / 16; i += NT) reinterpret_cast<u32x4_*>(ldsb)[i] = u32x4_{0, 0, 0, 0};
     __syncthreads();
@@ -755,7 +871,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #ifndef LRPXH_NQ_112P
 #define LRPXH_NQ_112P 3
 #endif
-    constexpr int NQ = F8 ? ((POOL && AL && HW <= 112) ? ((HW == 112 && MT * NWN == 4) ? LRPXH_NQ_112P : 3) : 2) : NBQ;
+    // X6 (a staging item holds 16 floats): a third entry spills everywhere
+    constexpr int NQ = F8 ? ((!X6 && POOL && AL && HW <= 112) ? ((HW == 112 && MT * NWN == 4) ? LRPXH_NQ_112P : 3) : 2) : NBQ;
 #endif
     // (a wave without a channel block of its own - n_oc not a multiple of the workgroup's channels - multiplies the last
     // valid block again and drops the result: one code path, see PRECISE below)
@@ -763,6 +880,16 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
                        ((long)ocb_w * nchunk_all + c_begin) * (BSTEPS * BP * 64) + lane;
     const int last_step = nchunk * BSTEPS - 1;
+    // plane p of queue entry `e`; X6: planes 4 and 6 hold 8 bytes of fp6 + the block-scale dword - 12 bytes, loaded as such
+    auto ldb = [&](const long e, const int p) -> u32x4_ {
+        if constexpr (X6) {
+            if (p == 4 || p == 6) {
+                const u32x3_ t = *reinterpret_cast<const u32x3_*>(wp + (e * BP + p) * 64);
+                return u32x4_{t[0], t[1], t[2], 0u};
+            }
+        }
+        return wp[(e * BP + p) * 64];
+    };
     u32x4_ bq[NQ][BP];
 #pragma unroll
     for (int i = 0; i < NQ; ++i)
@@ -771,12 +898,16 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #pragma unroll
     for (int i = 0; i < NQ - 1; ++i)
 #pragma unroll
-        for (int p = 0; p < BP; ++p) bq[i][p] = wp[((long)min(i, last_step) * BP + p) * 64];
+        for (int p = 0; p < BP; ++p) bq[i][p] = ldb(min(i, last_step), p);
     // F8: LDS byte offsets of the lane's two fp8 tap slots of a tap row (dx = 0 / 1 for lanes 0-31; dx = 2 / 2 for lanes
     // 32-63, whose second slot carries zero weights)
     // F8: lanes 0-31 read the fp8 plane of x - hi (byte 48 of the pixel), lanes 32-63 that of x (byte 32; abase[] already
     // carries + 16 for them)
     const int c8 = lh ? 16 : 48;
+    // X6: the operand of fp6 MFMA mm = 0..4 is the 32 bytes at byte 32 of ONE pixel per lane: tap 2mm for lanes 0-31, tap 2mm + 1
+    // for lanes 32-63 (mm = 4: tap 8 again, against zero weights) - the lane halves differ by one pixel (mm = 0, 2, 3), by a row
+    // less two pixels (mm = 1) or not at all (mm = 4); abase[] carries + 16 for lanes 32-63
+    const int e6a = 32 - 16 * lh + lh * PSTRIDE, e6b = 32 - 16 * lh + lh * (PITCH - 2 * PSTRIDE), e6c = 32 - 16 * lh;
     __syncthreads();
     if constexpr (STAG) {
         if (grp == 1 && nchunk > 1) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(1) } else { LRPXH_COMMIT(1) } }
@@ -842,8 +973,11 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #ifndef LRPXH_F8_PIPE_POOLS
 #define LRPXH_F8_PIPE_POOLS LRPXH_F8_PIPE      // the map-straddling pooled-input 8-wave kernel (conv4_3): the only one that spills
 #endif
+#ifndef LRPXH_PIPE_4W_X6
+#define LRPXH_PIPE_4W_X6 1     // fp6 build: the explicit operand ring keeps fewer temporaries alive than the compiler's own schedule (35 -> 1..4 spills)
+#endif
                 constexpr int PIPE_D = (MT * NWN >= 8) ? (MT >= 2 ? LRPXH_F8_PIPE_TALL : ((POOL && !AL) ? LRPXH_F8_PIPE_POOLS : LRPXH_F8_PIPE))
-                                                       : ((HW == 224 && POOL) ? 1 : ((HW == 112 && POOL) ? LRPXH_PIPE_112P : LRPXH_PIPE_4W));
+                                                       : ((HW == 224 && POOL) ? 1 : ((HW == 112 && POOL) ? LRPXH_PIPE_112P : (X6 ? LRPXH_PIPE_4W_X6 : LRPXH_PIPE_4W)));
 #endif
                 if constexpr (PIPE_D != 0) {
                 // Operand pipeline of depth D = LRPXH_F8_PIPE.  Left to itself the compiler (at 240+ VGPRs) keeps ONE set of
@@ -862,8 +996,18 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 auto rd = [&](const int k) {
                     const int g = og(k), j = oj(k), m = om(k);
                     if (m < 2) {                                   // fp8 operand: taps 4g + 2m, 4g + 2m + 1
-                        const char* a8 = abuf + abase[j] + c8;
                         const int t = 4 * g + 2 * m;
+                        if constexpr (X6) {
+                            const char* a6 = abuf + abase[j] + (t == 2 ? e6b : (t == 8 ? e6c : e6a)) + (TPX[t] / 3) * PITCH + (TPX[t] % 3) * PSTRIDE;
+                            // 16 + 8 + 4 bytes: every register a read returns is used (a register that is loaded but dead gets
+                            // re-used by the allocator while the read is in flight, and the wait for that write-after-write
+                            // hazard is a full drain of the counter)
+                            const u32x4_ x0 = *reinterpret_cast<const u32x4_*>(a6);
+                            const u32x2_ x1 = *reinterpret_cast<const u32x2_*>(a6 + 16);
+                            const unsigned xs = *reinterpret_cast<const unsigned*>(a6 + 28);
+                            return i32x8_{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)xs, 0};
+                        }
+                        const char* a8 = abuf + abase[j] + c8;
                         const u32x4_ x0 = *reinterpret_cast<const u32x4_*>(a8 + (TPX[t] / 3) * PITCH + (TPX[t] % 3) * PSTRIDE);
                         const u32x4_ x1 = *reinterpret_cast<const u32x4_*>(a8 + (TPX[t + 1] / 3) * PITCH + (TPX[t + 1] % 3) * PSTRIDE);
                         return i32x8_{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
@@ -874,10 +1018,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 i32x8_ ring[D];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step) * BP;
+                    const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step);
 #pragma unroll
                     for (int p = 0; p < BP; ++p)
-                        if (p < 5 || (g + NQ - 1) % 3 != 2) bq[NQ - 1][p] = wp[(nxt + p) * 64];
+                        if (p < 5 || (g + NQ - 1) % 3 != 2) bq[NQ - 1][p] = ldb(nxt, p);
                     if (g == 0) {
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (ISSUE_LATE) { LRPXH_ISSUE_NEXT }
@@ -901,7 +1045,12 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                             __builtin_amdgcn_sched_barrier(0);       // (a fence for the compiler's scheduler, no instruction)
                         }
                         if (m < 2) {
-                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cur, m == 0 ? bm0 : bm1, acc[j], 0, 0, 0, 0, 0, 0);
+                            if constexpr (X6) {      // fp6 x fp6, block scales: dword 6 of either operand (byte 0)
+                                acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cur, m == 0 ? bm0 : bm1, acc[j], 2, 2, 0, cur[6], 0,
+                                                                                         m == 0 ? bm0[6] : bm1[6]);
+                            } else {
+                                acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cur, m == 0 ? bm0 : bm1, acc[j], 0, 0, 0, 0, 0, 0);
+                            }
                         } else {
                             const u32x4_ c4 = {(unsigned)cur[0], (unsigned)cur[1], (unsigned)cur[2], (unsigned)cur[3]};
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, c4), bh[m - 2], acc[j], 0, 0, 0);
@@ -916,11 +1065,11 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 } else {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step) * BP;
+                    const long nxt = (long)min(chunk * 3 + g + NQ - 1, last_step);
                     // (the entry of tap row 2 has one fp8 MFMA: its last two planes are padding and stay out of registers)
 #pragma unroll
                     for (int p = 0; p < BP; ++p)
-                        if (p < 5 || (g + NQ - 1) % 3 != 2) bq[NQ - 1][p] = wp[(nxt + p) * 64];
+                        if (p < 5 || (g + NQ - 1) % 3 != 2) bq[NQ - 1][p] = ldb(nxt, p);
                     if (g == 0 && ISSUE_LATE) { __builtin_amdgcn_sched_barrier(0); LRPXH_ISSUE_NEXT }
                     const f16x8 bh0 = __builtin_bit_cast(f16x8, bq[0][0]);
                     const f16x8 bh1 = __builtin_bit_cast(f16x8, bq[0][1]);
@@ -938,20 +1087,38 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                         // fences the scheduler)
                         constexpr int TP[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 8};
 #define LRPXH_TOFF(t) ((TP[t] / 3) * PITCH + (TP[t] % 3) * PSTRIDE)
-                        const u32x4_ p0 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(4 * g));
-                        const u32x4_ p1 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(4 * g + 1));
+                        u32x4_ p0, p1;
+                        if constexpr (X6) {
+                            const char* a6 = abuf + abase[j] + (g == 2 ? e6c : e6a) + LRPXH_TOFF(4 * g);
+                            p0 = *reinterpret_cast<const u32x4_*>(a6);
+                            const u32x2_ y_ = *reinterpret_cast<const u32x2_*>(a6 + 16);
+                            p1 = u32x4_{y_[0], y_[1], *reinterpret_cast<const unsigned*>(a6 + 28), 0u};
+                        } else {
+                            p0 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(4 * g));
+                            p1 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(4 * g + 1));
+                        }
                         const f16x8 h0 = *reinterpret_cast<const f16x8*>(ap);
                         const f16x8 h1 = *reinterpret_cast<const f16x8*>(ap + PSTRIDE);
                         const f16x8 h2 = *reinterpret_cast<const f16x8*>(ap + 2 * PSTRIDE);
                         const i32x8_ am0 = {(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3], (int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
                         // small terms first: the cross products on the fp8 cores, then hi * hi_W
-                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am0, bm0, acc[j], 0, 0, 0, 0, 0, 0);
+                        if constexpr (X6) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am0, bm0, acc[j], 2, 2, 0, am0[6], 0, bm0[6]);
+                        else acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am0, bm0, acc[j], 0, 0, 0, 0, 0, 0);
                         if (g < 2) {          // (compile-time after unrolling)
-                            const u32x4_ q0 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(g < 2 ? 4 * g + 2 : 0));
-                            const u32x4_ q1 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(g < 2 ? 4 * g + 3 : 0));
+                            u32x4_ q0, q1;
+                            if constexpr (X6) {       // taps 4g + 2 / 4g + 3: g = 0: a row less two pixels apart, g = 1: one pixel
+                                const char* a6 = abuf + abase[j] + (g == 0 ? e6b : e6a) + LRPXH_TOFF(g < 2 ? 4 * g + 2 : 0);
+                                q0 = *reinterpret_cast<const u32x4_*>(a6);
+                                const u32x2_ y_ = *reinterpret_cast<const u32x2_*>(a6 + 16);
+                                q1 = u32x4_{y_[0], y_[1], *reinterpret_cast<const unsigned*>(a6 + 28), 0u};
+                            } else {
+                                q0 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(g < 2 ? 4 * g + 2 : 0));
+                                q1 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(g < 2 ? 4 * g + 3 : 0));
+                            }
 #undef LRPXH_TOFF
                             const i32x8_ am1 = {(int)q0[0], (int)q0[1], (int)q0[2], (int)q0[3], (int)q1[0], (int)q1[1], (int)q1[2], (int)q1[3]};
-                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am1, bm1, acc[j], 0, 0, 0, 0, 0, 0);
+                            if constexpr (X6) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am1, bm1, acc[j], 2, 2, 0, am1[6], 0, bm1[6]);
+                            else acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am1, bm1, acc[j], 0, 0, 0, 0, 0, 0);
                         }
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh0, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh1, acc[j], 0, 0, 0);

@@ -323,6 +323,45 @@ __global__ void pack_weights_f16f8_kernel(const float* __restrict__ w, float* __
         unsigned short* o = reinterpret_cast<unsigned short*>(out + dx * 1024);
         for (int j = 0; j < 8; ++j) o[j] = __builtin_bit_cast(unsigned short, (_Float16)wv(chunk * 16 + 8 * lh + j, dx));
     }
+#if LRPXH_XP6
+    // fp6 cross products: planes 3/4 = B operand of MFMA m = 2g, planes 5/6 = MFMA 2g + 1 (none for g = 2).  A lane's 32 e2m3
+    // values belong to ONE tap - 2m for lanes 0-31, 2m + 1 for lanes 32-63 (tap 9: zeros) - in the field order of the staging
+    // code: field c meets x_c and holds (W_c - hi(W_c)) * 2^11, field 16 + c meets (x_c - hi) * 2^11 and holds W_c; all divided
+    // by the lane's block scale 2^(e-127), e in the dword behind the 24 bytes (conv_f16x3.h, x6_split)
+    for (int mm = 0; mm < 2; ++mm) {
+        const int m = 2 * g + mm, tap = 2 * m + lh;
+        unsigned* o = reinterpret_cast<unsigned*>(out + (3 + 2 * mm) * 1024);       // 16 B here, 16 B one plane on
+        unsigned words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < 5 && tap <= 8) {
+            float ws[16], wr[16], mx = 0.f;
+            for (int c = 0; c < 16; ++c) {
+                const int k = chunk * 16 + c;
+                float v = 0.f;
+                if (mode == LRPX_PACK_BWD_POS) { if (k < cout && oc < cin) v = fmaxf(w[((long)k * cin + oc) * 9 + (8 - tap)], 0.f); }
+                else if (mode == LRPX_PACK_BWD_PLAIN) { if (k < cout && oc < cin) v = w[((long)k * cin + oc) * 9 + (8 - tap)]; }
+                v *= sc;
+                ws[c] = v;
+                wr[c] = (v - (float)(_Float16)v) * 2048.f;
+                mx = fmaxf(mx, fmaxf(fabsf(v), fabsf(wr[c])));
+            }
+            const float bs = mx * (16.f / 15.f * 0.25f);
+            const int e = (int)((__builtin_bit_cast(unsigned, bs) >> 23) & 0xffu);
+            if (e > 0 && e < 255) {
+                const float inv = exp2i(127 - e);
+                for (int c = 0; c < 16; ++c) {
+                    const unsigned f0 = fp6_e2m3_encode(wr[c] * inv), f1 = fp6_e2m3_encode(ws[c] * inv);
+                    const int b0 = 6 * c, b1 = 6 * (16 + c);
+                    words[b0 >> 5] |= f0 << (b0 & 31);
+                    if ((b0 & 31) > 26) words[(b0 >> 5) + 1] |= f0 >> (32 - (b0 & 31));
+                    words[b1 >> 5] |= f1 << (b1 & 31);
+                    if ((b1 & 31) > 26) words[(b1 >> 5) + 1] |= f1 >> (32 - (b1 & 31));
+                }
+                words[6] = (unsigned)e;
+            }
+        }
+        for (int q = 0; q < 4; ++q) { o[q] = words[q]; o[256 + q] = words[4 + q]; }
+    }
+#else
     // planes 3/4: B operand of fp8 MFMA m = 2g (taps 2m, 2m+1; lanes 0-31: "L" slices, lanes 32-63: "S" slices);
     // planes 5/6: MFMA 2g+1 (none for g = 2)
     for (int mm = 0; mm < 2; ++mm) {
@@ -350,6 +389,7 @@ __global__ void pack_weights_f16f8_kernel(const float* __restrict__ w, float* __
             }
         }
     }
+#endif
 }
 
 static void pack_dims(int cout, int cin, int mode, int kc, int* n_oc_pad, int* k_pad) {
