@@ -190,7 +190,7 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
             const bool ok = col_ok && (AL || gp < total_pix);
             const long xi = ((AL || p0 + dq < (int)P) ? b0 : b1) + (long)dq * ncol;
             xv[j % RING][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok) xv[j % RING][k] = *reinterpret_cast<const f32x4*>(X + xi);
+            if (ok && !(LRPX_EPI_EXP & 1)) xv[j % RING][k] = *reinterpret_cast<const f32x4*>(X + xi);
         }
     };
 #pragma unroll
@@ -224,7 +224,9 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
             const long gp = pix0 + wm * 224 + 32 * j + dq;
             if (col_ok && (AL || gp < total_pix)) {
                 float* op = O + gp * (long)ostr + obase;
-#if LRPXH_NT_STORE & 1
+#if LRPX_EPI_EXP & 2
+                if (r[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(op) = r;
+#elif LRPXH_NT_STORE & 1
                 __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(op));
 #else
                 *reinterpret_cast<f32x4*>(op) = r;
@@ -299,6 +301,111 @@ __host__ __device__ __forceinline__ unsigned fp6_e2m3_encode(float v) {
     return sgn | (unsigned)c;
 }
 
+// REL_MUL / GUIDED epilogue for TRANSPOSED accumulators (LRPXH_TR): the MFMAs were issued with the weights as the A operand and the
+// pixels as the B operand - the same fragments, the arguments swapped - so the result tile is channels x pixels: a lane owns ONE
+// pixel (tile pixel lane % 32) and 16 channels, 4 lh + 8 k + (0..3), k = 0..3: four float4 per tile straight from the accumulator
+// registers - no LDS transposition, 4 loads + 4 stores of 16 bytes per lane and tile (the dword epilogue: 16 + 16 of 4 bytes), and
+// everything per pixel (map, image, operand scale, the pixel's address) is per LANE: one value, no per-element selects.
+template <int HW, bool AL, int EPI, bool F8>
+__device__ __forceinline__ void epi_rel_mul_t(const ConvArgs& a, f32x16 (&acc)[7], const int wm, const int ocb, const int lane,
+                                              const long g0, const long total_pix, unsigned* __restrict__ oamax,
+                                              const int* __restrict__ tab, const float inv_w, const unsigned* __restrict__ in_amax) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int ncol = a.oc_split;
+    const int oc0 = ocb * 32 + 4 * lh;                  // the lane's channels: oc0 + 8 k + (0..3)
+    const float* __restrict__ X = a.X;
+    float* __restrict__ O = a.out1 ? a.out1 : a.out0;
+    const int ch = a.out_chunk;
+    const int ostr = ch > 0 ? ch : ncol;
+    const unsigned P = (unsigned)a.pix_per_map;
+    const int nmax = a.n_maps - 1;
+    const long pix0 = g0 * HW;
+    // per tile j: the lane's pixel - global index gp, X row xrow (elements), factor f = 2^-kA(map) * 2^-kW, second-map flag
+    auto pixel = [&](const int j, long& gp, long& xrow, float& f, bool& second, unsigned& n0) {
+        const unsigned q0t = (unsigned)(wm * 224 + 32 * j);
+        const unsigned rr = q0t / (unsigned)HW, c0 = q0t - rr * HW;
+        const unsigned g = (unsigned)g0 + rr;
+        n0 = g / (unsigned)HW;
+        const int p = (int)((g - n0 * HW) * HW + c0) + li;
+        gp = pix0 + q0t + li;
+        if constexpr (AL) {
+            const long img = a.map2img ? a.map2img[min((int)n0, nmax)] : (long)n0;
+            second = false;
+            xrow = (img * P + p) * (long)ncol;
+            f = exp2i(-split_scale_exp<F8>(in_amax[min((int)n0, nmax)])) * inv_w;
+        } else {
+            second = p >= (int)P;
+            const long img = tab[(wm * 7 + j) * 4 + (second ? 3 : 2)];
+            xrow = (img * P + (second ? p - (int)P : p)) * (long)ncol;
+            f = __builtin_bit_cast(float, tab[(wm * 7 + j) * 4 + (second ? 1 : 0)]) * inv_w;
+        }
+    };
+    constexpr int RING = AL ? 7 : 4;
+    f32x4 xv[RING][4];
+    auto load_x = [&](const int j) {
+        long gp, xrow; float f; bool second; unsigned n0;
+        pixel(j, gp, xrow, f, second, n0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oc = oc0 + 8 * k;
+            const bool ok = oc < ncol && (AL || gp < total_pix);
+            xv[j % RING][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok && !(LRPX_EPI_EXP & 1)) xv[j % RING][k] = *reinterpret_cast<const f32x4*>(X + xrow + oc);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < (AL ? 7 : RING - 1); ++j) load_x(j);
+    float m_al = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        if constexpr (!AL) { if (j + RING - 1 < 7) load_x(j + RING - 1); }
+        long gp, xrow; float f; bool second; unsigned n0;
+        pixel(j, gp, xrow, f, second, n0);
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oc = oc0 + 8 * k;
+            const f32x4 xk = xv[j % RING][k];
+            const f32x4 v = f32x4{acc[j][4 * k] * f, acc[j][4 * k + 1] * f, acc[j][4 * k + 2] * f, acc[j][4 * k + 3] * f};
+            f32x4 r;
+            if constexpr (EPI == EPI_GUIDED) {     // ReLU hook of the layer below (a.relu == 2: the plain autograd mask)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r[c] = (xk[c] > 0.f && (a.relu == 2 || v[c] > 0.f)) ? v[c] : 0.f;
+            } else {
+                r = v * xk;
+            }
+            if (oc < ncol && (AL || gp < total_pix)) {
+                const long obase = ch > 0 ? (long)(oc / ch) * total_pix * ch + (oc % ch) : (long)oc;
+                float* op = O + gp * (long)ostr + obase;
+#if LRPX_EPI_EXP & 2
+                if (r[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(op) = r;
+#elif LRPXH_NT_STORE & 1
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(op));
+#else
+                *reinterpret_cast<f32x4*>(op) = r;
+#endif
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
+            }
+        }
+        if (oamax) {
+            if constexpr (AL) {
+                m_al = fmaxf(m_al, m);
+            } else {
+                const float m0 = wave_max(second ? 0.f : m), m1 = wave_max(second ? m : 0.f);
+                if (lane == 0 && (int)n0 <= nmax) amax_update(&oamax[n0], m0);
+                if (lane == 0 && (int)n0 + 1 <= nmax) amax_update(&oamax[n0 + 1], m1);
+            }
+        }
+    }
+    if constexpr (AL) {
+        if (oamax) {
+            m_al = wave_max(m_al);
+            const unsigned n_first = (unsigned)g0 / (unsigned)HW;
+            if (lane == 0 && (int)n_first <= nmax) amax_update(&oamax[n_first], m_al);
+        }
+    }
+}
+
 // F8 ("f16+f8x2"): the two CROSS products a0*b1 + a1*b0 - 2^-11 of the result - do not need fp16 operands: with both
 // factors rounded to fp8 e4m3 (4 significand bits) their error is 2^-11 * 2^-4 per product, random sign; simulated
 // through all 13 layers the maps move by < 1e-5 of their maximum (tolerance 1e-4; plain f16x3: ~1e-6).  They run on
@@ -337,6 +444,14 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // c = 0..15, all divided by the slice's block scale 2^s (24 B) | E8M0 byte s - 11 + 127 (dword at byte 60; byte 56 stays clear so that the 8 + 4 byte reads do not fuse into a slower ds_read_b96) | pad.  A staging item is one
     // pixel's whole 16-channel slice (4 float4): the block maximum and v_cvt_scalef32_pk32_fp6_f16 need the 16 values in one lane.
     constexpr bool X6 = F8 && (LRPXH_XP6 != 0);
+#ifndef LRPXH_TR
+#define LRPXH_TR 0
+#endif
+    // TR (experiment, off): the relevance kernels accumulate channels x pixels (the arguments of every MFMA swapped): see epi_rel_mul_t.
+    // Measured (same box, chain of 320 maps): 17.7 -> 19.9 ms (conv1_2 +35 %, the 56x56 layers +15 %, 28x28 / 14x14 +3 %): a float4
+    // instruction of the transposed layout touches 32 cache lines (32-byte pieces of 32 pixels) where the dword and the LDS-transposed
+    // float4 epilogues touch 2 and 8 WHOLE lines - the epilogue costs by lines touched per instruction, not by instructions.
+    constexpr bool TR = X6 && (LRPXH_TR != 0) && (EPI == EPI_REL_MUL || EPI == EPI_GUIDED);
     constexpr int NV = X6 ? 4 : 1;                     // float4 loads per staging item
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
@@ -384,6 +499,14 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         }
     }
     if (mtile >= m_tiles) return;
+#ifdef LRPXH_START_SKEW
+    // (experiment) the workgroups of the first round start spread over one tile time, so that the epilogues of the CUs - whose tiles
+    // all take the same time - do not store in the same bursts
+    if (idx / n_blocks < LRPXH_START_ROUNDS) {
+        const int phase = (bid >> 3) & 7;
+        for (int i = 0; i < phase * LRPXH_START_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int ocb = nblk * NWN + wn;
     const bool wave_active = ocb * 32 < a.n_oc;
     const long total_pix = (long)a.n_maps * a.pix_per_map;
@@ -819,7 +942,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #define LRPXH_STAGGER 1
 #endif
 #ifndef LRPXH_EXP
-#define LRPXH_EXP 0       // timing experiments (wrong results): 1 = no staging commits in the K loop
+#define LRPXH_EXP 0       // timing experiments (wrong results): 1 = no staging commits in the K loop, 2 = no staging loads, 16 = no A-operand reads,
+                          // 32 = no epilogue, 64 = no barrier in the (double-buffered) K loop
 #endif
     constexpr bool STAG = DB && (LRPXH_STAGGER != 0) && (MT * NWN >= 8);
 #ifdef LRPXH_ISSUE_LATE
@@ -995,6 +1119,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 auto om = [](const int k) constexpr { return k < 70 ? (k % 35) % 5 : ((k - 70) % 4 == 0 ? 0 : (k - 70) % 4 + 1); };   // 0,1: fp8; 2..4: fp16 dx 0..2
                 auto rd = [&](const int k) {
                     const int g = og(k), j = oj(k), m = om(k);
+                    if constexpr ((LRPXH_EXP & 16) != 0) return i32x8_{lane, lane + 1, lane + 2, lane + 3, lane, lane, 0x7f, 0};   // (EXP 16: no LDS reads)
                     if (m < 2) {                                   // fp8 operand: taps 4g + 2m, 4g + 2m + 1
                         const int t = 4 * g + 2 * m;
                         if constexpr (X6) {
@@ -1046,14 +1171,19 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                         }
                         if (m < 2) {
                             if constexpr (X6) {      // fp6 x fp6, block scales: dword 6 of either operand (byte 0)
-                                acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cur, m == 0 ? bm0 : bm1, acc[j], 2, 2, 0, cur[6], 0,
-                                                                                         m == 0 ? bm0[6] : bm1[6]);
+                                if constexpr (TR)
+                                    acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(m == 0 ? bm0 : bm1, cur, acc[j], 2, 2, 0,
+                                                                                             m == 0 ? bm0[6] : bm1[6], 0, cur[6]);
+                                else
+                                    acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cur, m == 0 ? bm0 : bm1, acc[j], 2, 2, 0, cur[6], 0,
+                                                                                             m == 0 ? bm0[6] : bm1[6]);
                             } else {
                                 acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cur, m == 0 ? bm0 : bm1, acc[j], 0, 0, 0, 0, 0, 0);
                             }
                         } else {
                             const u32x4_ c4 = {(unsigned)cur[0], (unsigned)cur[1], (unsigned)cur[2], (unsigned)cur[3]};
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, c4), bh[m - 2], acc[j], 0, 0, 0);
+                            if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[m - 2], __builtin_bit_cast(f16x8, c4), acc[j], 0, 0, 0);
+                            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, c4), bh[m - 2], acc[j], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -1102,7 +1232,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                         const f16x8 h2 = *reinterpret_cast<const f16x8*>(ap + 2 * PSTRIDE);
                         const i32x8_ am0 = {(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3], (int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
                         // small terms first: the cross products on the fp8 cores, then hi * hi_W
-                        if constexpr (X6) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am0, bm0, acc[j], 2, 2, 0, am0[6], 0, bm0[6]);
+                        if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bm0, am0, acc[j], 2, 2, 0, bm0[6], 0, am0[6]);
+                        else if constexpr (X6) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am0, bm0, acc[j], 2, 2, 0, am0[6], 0, bm0[6]);
                         else acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am0, bm0, acc[j], 0, 0, 0, 0, 0, 0);
                         if (g < 2) {          // (compile-time after unrolling)
                             u32x4_ q0, q1;
@@ -1117,12 +1248,19 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                             }
 #undef LRPXH_TOFF
                             const i32x8_ am1 = {(int)q0[0], (int)q0[1], (int)q0[2], (int)q0[3], (int)q1[0], (int)q1[1], (int)q1[2], (int)q1[3]};
-                            if constexpr (X6) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am1, bm1, acc[j], 2, 2, 0, am1[6], 0, bm1[6]);
+                            if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bm1, am1, acc[j], 2, 2, 0, bm1[6], 0, am1[6]);
+                            else if constexpr (X6) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am1, bm1, acc[j], 2, 2, 0, am1[6], 0, bm1[6]);
                             else acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am1, bm1, acc[j], 0, 0, 0, 0, 0, 0);
                         }
+                        if constexpr (TR) {
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, h0, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, h1, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh2, h2, acc[j], 0, 0, 0);
+                        } else {
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh0, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh1, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, bh2, acc[j], 0, 0, 0);
+                        }
                         if constexpr (LRPXH_F8_SGB != 0) {
                             const int gn = (j == 6) ? g + 1 : g;                     // tap row of the next tile
                             if (gn < 2) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
@@ -1206,7 +1344,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         if constexpr (DB) {
             if (more && grp == 0 && !(LRPXH_EXP & 1)) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO((chunk + 1) & 1) } else { LRPXH_COMMIT((chunk + 1) & 1) } }
             LRPXH_T(td);
-            __syncthreads();
+            if constexpr (!(LRPXH_EXP & 64)) __syncthreads();      // (EXP 64: no barrier in the K loop)
             if constexpr (STAG) {     // group 1: chunk + 2 into the buffer everyone has just finished reading
                 if (grp == 1 && chunk + 2 < nchunk && !(LRPXH_EXP & 1)) { if constexpr (LOSTAGE) { LRPXH_COMMIT_LO(chunk & 1) } else { LRPXH_COMMIT(chunk & 1) } }
             }
@@ -1233,7 +1371,40 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #undef LRPXH_ISSUE_LO
 #undef LRPXH_COMMIT_LO
     if (!wave_active) return;
+    if constexpr ((LRPXH_EXP & 32) != 0) {        // (EXP 32: no epilogue)
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc += acc[j][e];
+        if (sacc == 1.2345e-30f) a.out0[0] = sacc;
+        return;
+    }
     LRPXH_T(t_epi);
+    if constexpr (TR) {
+        unsigned* __restrict__ oamax_t = (EPI == EPI_GUIDED) ? a.out0_amax : (a.out1 ? a.out1_amax : nullptr);
+        epi_rel_mul_t<HW, AL, EPI, F8>(a, acc, wm, ocb, lane, g0, total_pix, oamax_t, tile_tab, inv_w, in_amax);
+#ifdef LRPXH_END_SLEEP
+        for (int i = 0; i < LRPXH_END_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+#ifdef LRPX_STAMP
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LRPXH_T(t_endt);
+            if (lane == 0 && HW == LRPX_STAMP_HW) {
+                atomicAdd(&g_stamp_h3[0], t_loop - t_start);
+                atomicAdd(&g_stamp_h3[1], s_issue);
+                atomicAdd(&g_stamp_h3[2], s_mfma);
+                atomicAdd(&g_stamp_h3[3], s_commit);
+                atomicAdd(&g_stamp_h3[4], s_barrier);
+                atomicAdd(&g_stamp_h3[5], t_endt - t_epi);
+                atomicAdd(&g_stamp_h3[6], t_endt - t_start);
+                atomicAdd(&g_stamp_h3[7], 1ull);
+            }
+        }
+#endif
+        return;
+    }
 
     EpiCtx cx;
     cx.oc = ocb * 32 + li;
@@ -1296,6 +1467,9 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         // (the K loop ends with a barrier: nobody reads the staging buffers any more; 32 x 36 floats per wave)
         float* scr = reinterpret_cast<float*>(ldsb) + wave * (32 * 36);
         epi_rel_mul_wide<HW, AL, EPI>(a, acc, scr, wm, ocb, lane, g0, total_pix, oamax, tile_tab);
+#ifdef LRPXH_END_SLEEP
+        for (int i = 0; i < LRPXH_END_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);      // (experiment: is the store drain at wave end exposed?)
+#endif
 #ifdef LRPX_STAMP
         {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1369,6 +1543,9 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #undef LRPXH_AMAX
         }
     }
+#ifdef LRPXH_END_SLEEP
+    for (int i = 0; i < LRPXH_END_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 #ifdef LRPX_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LRPXH_T(t_end);

@@ -23,6 +23,9 @@
 #define LRPXH_NT_STORE 3      // bit 0: float4 (wide) REL_MUL epilogue, bit 1: dword epilogue: streaming stores
 #endif
 
+#ifndef LRPX_EPI_EXP
+#define LRPX_EPI_EXP 0      // timing experiments on the epilogues (wrong results): 1 = no multiplicand loads, 2 = no stores
+#endif
 namespace lrpx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -140,7 +143,11 @@ __device__ __forceinline__ void epi_gather(const ConvArgs& a, const EpiCtx& cx, 
             r.xv[e] = 0.f; r.zv[e] = 1.f;
             if (NEEDS_X && oc < ncol) {
                 const int xo = ((e & 3) + 8 * (e >> 2)) * ncol;
+#if LRPX_EPI_EXP & 1
+                r.xv[e] = 1.f;
+#else
                 r.xv[e] = (X + xb)[xo];
+#endif
                 if (EPI == EPI_REL && Zd && a.out1) r.zv[e] = (Zd + xb)[xo];
             }
         }
@@ -221,7 +228,11 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
         const int ch = a.out_chunk;
         const int ostr = ch > 0 ? ch : ncol;
         const long obase = ch > 0 ? (long)(oc / ch) * cx.total_pix * ch + (oc % ch) : (long)oc;
+#if LRPX_EPI_EXP & 4        // (same store instructions into a 1 MB window: no HBM write traffic)
+        float* __restrict__ ob = (o1 ? o1 : o0) + ((((cx.pix0 + cx.q0 + 32 * j) * (long)ostr + obase) & 0x3ffffL) & ~31L) + (oc & 31);
+#else
         float* __restrict__ ob = (o1 ? o1 : o0) + (cx.pix0 + cx.q0 + 32 * j) * (long)ostr + obase;
+#endif
         int p0t = 0;
         if (mx && !ALIGNED && TAPS == 9) {
             const unsigned q0t = (unsigned)(cx.q0 - 4 * (cx.lane >> 5) + 32 * j);
@@ -237,7 +248,9 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& cx, 
                                                 : r.xv[e] * accj[e];
             // streaming store: the S tensors (0.5 - 4 GB) are read back a whole kernel later, keeping them out of the way
             // of the weights and multiplicands in L2 is worth 2 % on the wide layers (chain 21.23 -> 21.06 ms)
-#if LRPXH_NT_STORE & 2
+#if LRPX_EPI_EXP & 2
+            if (rel == 1.2345e-30f) ob[dq * ostr] = rel;
+#elif LRPXH_NT_STORE & 2
             __builtin_nontemporal_store(rel, &ob[dq * ostr]);
 #else
             ob[dq * ostr] = rel;
