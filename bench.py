@@ -22,7 +22,7 @@ Rank 0 prints ONE JSON line.  At N=1 it also carries
   roofline     : MFMA roofline of the dominant kernel (the relevance conv kernel with the largest total time of the
                  12 conv launches per step = 30.69 GFLOP per map), timed live with HIP events on the launch stream;
                  `traffic` is read from the PMC summary named in `traffic_source` (profiles/, separate --pmc passes);
-                 `modes`: the same step and chain in every matrix-core mode (0 fp32 MFMA ... 3 fp16+fp8), same process
+                 `modes`: the same step and chain in every matrix-core mode (0 fp32 MFMA ... 3 fp16+fp6), same process
   sustained    : the same step repeated for >= --sustain seconds (power-limited clocks show here, not in 20 steps)
   median_ms    : median interval between step completions (HIP events) inside the timed region
   cpu_baseline : the reference-equivalent CPU mode (oracle/ref_equiv.py, kind "port") on a bounded sample.
@@ -58,15 +58,17 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E
 DOM_FLOP_PER_MAP = 2.0 * 9 * 256 * 256 * 56 * 56
 MODE_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "bf16x6: exact 3-way bf16 split, 6 products, fp32 accumulate",
              2: "f16x3: per-map power-of-two scaling, 2-way fp16 split, 3 products, fp32 accumulate",
-             3: "f16+f8x2: as f16x3, the two cross products (2^-11 of the result) as fp8 e4m3 MFMAs (v_mfma_f32_32x32x64_f8f6f4)"}
+             3: "f16+f6x2: as f16x3, the two cross products (2^-11 of the result) as block-scaled fp6 e2m3 MFMAs "
+                "(v_mfma_scale_f32_32x32x64_f8f6f4, one E8M0 exponent per 16-channel slice; rounds 1-2: fp8 e4m3)"}
 MODE_KERNEL = {0: "conv_mfma_kernel<56,16,1,4,9,REL>", 1: "conv_bf16x6_kernel<56,1,4,true,REL>",
                2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>", 3: "conv_f16x3_kernel<28,1,8,true,REL_MUL,false,true>"}
-# mode 3: one fp16 product + two fp8 products; the fp8 dense peak is twice the fp16 one, so an fp8 flop counts half:
-# `achieved` / `peak` is then (time the matrix cores need at their peaks) / (measured time), as in the other modes
-PRODUCTS = {0: 1, 1: 6, 2: 3, 3: 2}
+# mode 3: one fp16 product + two fp6 products; the fp6 dense peak is four times the fp16 one (MI355X_MICROARCH.md: 32 cycles per
+# 32x32x64 MFMA, measured tools/micro/mfma_f6.hip), so an fp6 flop counts a quarter: `achieved` / `peak` is then (time the matrix
+# cores need at their peaks) / (measured time), as in the other modes.  (Rounds 1-2 ran the cross products in fp8: 2.0.)
+PRODUCTS = {0: 1, 1: 6, 2: 3, 3: 1.5}
 # arithmetic the contractions run in (tensors in HBM are fp32 in every mode; everything outside the convolutions is fp32 VALU)
 MODE_DTYPE = {0: "f32", 1: "bf16x6 split products, f32 accumulate", 2: "f16x3 split products, f32 accumulate",
-              3: "f16 + 2 x f8(e4m3) split products, f32 accumulate"}
+              3: "f16 + 2 x f6(e2m3, block-scaled) split products, f32 accumulate"}
 # HBM traffic of the dominant kernel per launch: tools/prof_summary.py traffic --json writes this file from the two --pmc
 # passes (FETCH_SIZE / WRITE_SIZE, separate from any tracing); bytes = 2 x FETCH_SIZE raw [gfx950 reports half of wide
 # streaming reads, MI355X_MICROARCH.md §HBM] + WRITE_SIZE, divided by the launches and scaled to the maps of this run
@@ -166,7 +168,7 @@ def parse(argv=None):
     ap.add_argument("--chain-streams", type=int, default=1, help="HIP streams the maps of one VGG16 relevance pass are split over (maps are independent)")
     ap.add_argument("--fp32-mfma", action="store_true", help="same as --conv-mode 0")
     ap.add_argument("--conv-mode", type=int, default=3, choices=[0, 1, 2, 3],
-                    help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp8 cross products (default)")
+                    help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp6 cross products (default)")
     a = ap.parse_args(argv)
     if a.explainer is None:
         a.explainer = "lrp+guided" if a.config == 4 else "lrp"
@@ -564,8 +566,9 @@ def roofline(a, lib, eng, state, maps, B, T, mode):
         "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
         "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,
         "traffic": traffic, "traffic_source": src,
-        "accounting": ("executed matrix flop = algorithmic x products; mode 3 executes 1 fp16 + 2 fp8 products per fp32 "
-                       "product and an fp8 flop counts 1/2 (fp8 dense peak = 2 x fp16 peak), so achieved/peak = matrix "
+        "accounting": ("executed matrix flop = algorithmic x products; mode 3 executes 1 fp16 + 2 fp6 products per fp32 "
+                       "product and an fp6 flop counts 1/4 (fp6 dense peak = 4 x fp16 peak; the path's roof is 2500 / 1.5 = 1667 "
+                       "algorithmic TFLOP/s, 1250 with the fp8 cross products of rounds 1-2), so achieved/peak = matrix "
                        "time at peak / measured time; frac_algorithmic = fp32-equivalent flop against the same peak") if mode == 3 else
                       "executed matrix flop = algorithmic x products; frac_algorithmic = fp32-equivalent flop against the same peak",
         "chain": {"ms_per_step": round(c_ms, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * B * T,

@@ -847,15 +847,20 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 // there are zeroed on the fp32 values (bit masks replicated from the SWAR compare of the 16 winner bytes), then hi = cvt_pk of the
 // masked values and one fp6 conversion with the slice's common block scale (the maximum over all 16 channels: a position that
 // keeps only small entries is rounded against the pooled pixel's largest one - the same absolute error as in a layer without pool)
+#ifndef LRPXH_LO_SKIP
+#define LRPXH_LO_SKIP 1       // wave-uniform skips in the pooled commit: a wave none of whose lanes has the window row does not compute it
+#endif
 #define LRPXH_COMMIT_LO1_X6(u, BUFIDX)                                                                       \
-    {                                                                                                        \
+    if (!LRPXH_LO_SKIP || __builtin_amdgcn_ballot_w64(rm_ != 0) != 0) {                                      \
         unsigned hwu_[8], rwu_[8], sb_;                                                                      \
         float bs_;                                                                                           \
         x6_split(sv[u], sc_, hwu_, rwu_, bs_, sb_);                                                          \
         const int o0_ = (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                               \
         const int rb0_ = ((rm_ & 1) && !(LRPXH_EXP & 4)) ? o0_ : POOL_SCRATCH;   /* window row dy = 0 */    \
         const int rb1_ = ((rm_ & 2) && !(LRPXH_EXP & 4)) ? o0_ + ((rm_ & 1) ? PITCH : 0) : POOL_SCRATCH;     \
-        _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                                \
+        const bool need0_ = !LRPXH_LO_SKIP || __builtin_amdgcn_ballot_w64((rm_ & 1) != 0) != 0;              \
+        const bool need1_ = !LRPXH_LO_SKIP || __builtin_amdgcn_ballot_w64((rm_ & 2) != 0) != 0;              \
+        _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) if ((pos >> 1) ? need1_ : need0_) {              \
             unsigned hm_[8], rm2_[8];                                                                        \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                               \
                 const unsigned x_ = amv4[u][q_] ^ (0x01010101u * (unsigned)pos);  /* zero byte <=> winner == pos */ \
@@ -901,6 +906,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         /* (an item with nothing to write converts whatever its registers hold into the scratch bytes) */    \
         char* d_ = ldsb + ((dst_ >= 0 && !(LRPXH_EXP & 4)) ? (BUFIDX) * BUFB + (dst_ & 0x03ffffff) : STAGE_SCRATCH); \
         if constexpr (X6) {                                                                                  \
+            if (!LRPXH_LO_SKIP || __builtin_amdgcn_ballot_w64(dst_ >= 0) != 0) {                             \
             unsigned hwu_[8], rwu_[8], sb_;                                                                  \
             float bs_;                                                                                       \
             x6_split(sv[u], ssc[AL ? 0 : u], hwu_, rwu_, bs_, sb_);                                          \
@@ -909,6 +915,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             *reinterpret_cast<u32x4_*>(d_ + 16) = u32x4_{hwu_[4], hwu_[5], hwu_[6], hwu_[7]};                \
             *reinterpret_cast<u32x4_*>(d_ + 32) = u32x4_{q6_[0], q6_[1], q6_[2], q6_[3]};                    \
             *reinterpret_cast<u32x4_*>(d_ + 48) = u32x4_{q6_[4], q6_[5], 0u, sb_};                           \
+            }                                                                                                \
         } else {                                                                                             \
         const f32x2_ sc2_ = {ssc[AL ? 0 : u], ssc[AL ? 0 : u]};                                              \
         const f32x2_ xa_ = f32x2_{sv[u][0][0], sv[u][0][1]} * sc2_, xb_ = f32x2_{sv[u][0][2], sv[u][0][3]} * sc2_; \
