@@ -61,8 +61,9 @@ int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mo
  * 64-byte header carries 2^-kW for the consumer's epilogue.  Same modes as lrpx_pack_weights_bf16x3. */
 size_t lrpx_packed_f16x2_bytes(int n_oc, int k, int taps);
 int lrpx_pack_weights_f16x2(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream);
-/* weights for lrpx_conv_desc.f16x3 = 2 (fp16 hi.hi product + the two cross products on the fp8 matrix cores): scaled
- * into [2^11, 2^12), stored per tap row as fp16 hi planes + fp8 e4m3 planes of w*2^-4 and (w - hi)*2^4 in the operand
+/* weights for lrpx_conv_desc.f16x3 = 2 (fp16 hi.hi product + the two cross products on the narrow-format matrix cores;
+ * the symbol keeps its round-1 name): scaled into [2^14, 2^15), stored per tap row as fp16 hi planes + block-scaled fp6
+ * e2m3 fields of (w - hi)*2^11 and w with one E8M0 exponent per (output channel, tap, 16 channels) in the operand
  * layout of v_mfma_f32_32x32x64_f8f6f4 (K = 3 taps + a zero slot, x 16 channels).  3x3 kernels, modes BWD_POS / BWD_PLAIN */
 size_t lrpx_packed_f16f8_bytes(int n_oc, int k);
 int lrpx_pack_weights_f16f8(const float* w, int cout, int cin, int mode, void* packed, void* stream);
@@ -96,9 +97,10 @@ typedef struct lrpx_conv_desc {
                              (22-bit operands: below the rounding of the fp32 accumulation itself; half the matrix
                              time of bf16x6).  wpacked from lrpx_pack_weights_f16x2; needs in_amax; REL_MUL or FWD_DUAL epilogue,
                              3x3 convs, cin %% 16 == 0.
-                             2: as 1, but the two cross products hi*lo + lo*hi (2^-11 of the result) run on the fp8 matrix
-                             cores with both factors rounded to e4m3 (error 2^-15 of a product, random sign: the maps
-                             move by < 1e-5 of their maximum); wpacked from lrpx_pack_weights_f16f8; REL_MUL, GUIDED or PLAIN epilogue */
+                             2: as 1, but the two cross products hi*lo + lo*hi (2^-11 of the result) run on the fp6 matrix
+                             cores (e2m3, one block exponent per 16-channel slice; rounds 1-2: fp8 e4m3) - error 2^-15 of a
+                             product, random sign: the maps move by < 1e-5 of their maximum; wpacked from
+                             lrpx_pack_weights_f16f8; REL_MUL, GUIDED or PLAIN epilogue */
     int out_chunk;        /* REL_MUL: > 0 writes the output channel-chunked [C/out_chunk][n_maps*pixels][out_chunk] (16 / 32) */
     const uint32_t* in_amax;  /* f16x3: [n_maps] float bits of max|in| per map (lrpx_amax_maps, or a producer's out1_amax) */
     uint32_t* out1_amax;      /* f16x3 + out1: max|out1| per map is atomicMax-ed into it (zero it first); may be null */
@@ -168,7 +170,7 @@ int lrpx_check(const float* buf, long n, int flags, void* stream);
  * A caller that wants a mode of its own - or that runs while another thread changes the defaults - passes it per call in
  * an lrpx_vgg16_opts to the *_ex entry points; such a call never reads the defaults. */
 typedef struct lrpx_vgg16_opts {
-    int conv_mode;     /* 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp8 cross products; < 0: the process default */
+    int conv_mode;     /* 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp6 cross products; < 0: the process default */
     int forward_f16;   /* forward trace on the fp16 split-product kernels: 0 / 1; < 0: the process default */
     float* layer_ms;   /* lrpx_vgg16_relevance_ex only, may be NULL.  HOST array of 17 floats: the call records HIP events of
                           its own around every conv launch, WAITS for them and stores the milliseconds per VGG16 layer index
@@ -182,7 +184,7 @@ int lrpx_vgg16_resolve_opts(const lrpx_vgg16_opts* opts, int* conv_mode, int* fo
  * everywhere; a negative value only queries.  Returns the previous setting. */
 int lrpx_set_bf16x6(int enable);
 /* Matrix-core mode of the fused VGG16 chains: 0 fp32 MFMA, 1 bf16x6 (exact splits), 2 f16x3 (fp16 split products),
- * 3 = 2 with the cross products of the relevance pass on the fp8 matrix cores (lrpx_conv_desc.f16x3 = 2).
+ * 3 = 2 with the cross products of the relevance pass on the fp6 matrix cores (lrpx_conv_desc.f16x3 = 2).
  * Negative: query only.  Returns the previous mode. */
 int lrpx_set_conv_mode(int mode);
 /* 1: the forward trace of conv1_2..conv5_3 also runs on the fp16 split-product kernels (operand scale = per-image maximum of

@@ -61,7 +61,7 @@ def pack_weights_f16x2(w, cout, cin, mode, taps=9):
 
 
 def pack_weights_f16f8(w, cout, cin, mode):
-    """3x3 conv weights for conv_mfma(..., f16x3=2): fp16 hi planes + fp8 planes of the cross-product operands."""
+    """3x3 conv weights for conv_mfma(..., f16x3=2): fp16 hi planes + block-scaled fp6 fields of the cross-product operands."""
     lib = _lib.load()
     n_oc, k = (cin, cout)
     out = torch.empty(lib.lrpx_packed_f16f8_bytes(n_oc, k) // 4, dtype=torch.float32, device=w.device)

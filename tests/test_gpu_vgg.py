@@ -763,3 +763,63 @@ def test_forward_discrete_decisions_vs_oracle(ops):
     print(f"forward vs the oracle's oneDNN forward, 2 images: {relu} ReLU sign flips of {n_act} activations, "
           f"{pool} pool-winner flips of {n_win} live windows")
     assert relu <= 60 and pool <= 40
+
+
+def _fp6_e2m3(code):
+    """value of a 6-bit e2m3 code (sign, 2 exponent bits with bias 1, 3 mantissa bits; no inf / nan)"""
+    s, e, m = (code >> 5) & 1, (code >> 3) & 3, code & 7
+    v = m * 0.125 if e == 0 else (1.0 + m * 0.125) * (1 << (e - 1))
+    return -v if s else v
+
+
+def test_packed_f16f6_weight_layout(ops):
+    """The blob of lrpx_pack_weights_f16f8 (cross products on the block-scaled fp6 matrix cores, csrc/lrpx_core.hip) decoded on the
+    host: header 2^-kW; per (channel block, 16-channel chunk, tap row) seven planes of 64 lanes x 16 bytes - the fp16 hi halves of the
+    three taps of the row, then per fp6 MFMA 24 bytes of e2m3 fields + the E8M0 block exponent of the lane.  Every lane's block must
+    hold ITS tap (2m for lanes 0-31, 2m + 1 for lanes 32-63) in the field order of the staging code (field c: (W_c - hi) * 2^11,
+    field 16 + c: W_c), scaled so that the block maximum lies in (3.75, 7.5], each field within half an e2m3 step of the value."""
+    from lrp_amd import _lib
+    cout, cin = 32, 64                                  # K = cout = 2 chunks, output channels = cin = 2 blocks of 32
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * torch.exp(2 * torch.randn(cout, cin, 3, 3, generator=g))
+    blob = ops.pack_weights_f16f8(w.cuda(), cout, cin, _lib.PACK_BWD_PLAIN).cpu().numpy()
+    inv_kw = float(blob[0])
+    kw = 1.0 / inv_kw
+    assert 2.0 ** 14 <= np.abs(w.numpy()).max() * kw < 2.0 ** 15
+    raw = blob[16:].view(np.uint8).reshape(cin // 32, cout // 16, 3, 7, 64, 16)
+    worst = 0.0
+    for ocb in range(cin // 32):
+        for chunk in range(cout // 16):
+            for grow in range(3):
+                planes = raw[ocb, chunk, grow]
+                for dx in range(3):                     # hi planes: lane (li, lh) holds channels 8 lh .. 8 lh + 7 of tap (grow, dx)
+                    hi = planes[dx].view(np.float16).reshape(64, 8).astype(np.float64)
+                    for lane in (0, 17, 40, 63):
+                        li, lh = lane & 31, lane >> 5
+                        want = w[chunk * 16 + 8 * lh:chunk * 16 + 8 * lh + 8, ocb * 32 + li, 2 - grow, 2 - dx].numpy().astype(np.float64) * kw
+                        assert np.all(np.abs(hi[lane] - want) <= np.abs(want) * 2.0 ** -11 + 1e-30)
+                for mm in range(2):
+                    m = 2 * grow + mm
+                    if m > 4:
+                        continue
+                    for lane in (0, 9, 31, 32, 50, 63):
+                        li, lh = lane & 31, lane >> 5
+                        tap = 2 * m + lh
+                        words = np.concatenate([planes[3 + 2 * mm, lane], planes[4 + 2 * mm, lane]]).view(np.uint32)
+                        if tap > 8:
+                            assert not words[:7].any()   # the slot of the tap that does not exist: zero fields, zero exponent
+                            continue
+                        bits = int.from_bytes(words[:6].tobytes(), "little")
+                        fields = np.array([_fp6_e2m3((bits >> (6 * i)) & 63) for i in range(32)])
+                        e = int(words[6])
+                        ws = w[chunk * 16:chunk * 16 + 16, ocb * 32 + li, 2 - tap // 3, 2 - tap % 3].numpy().astype(np.float64) * kw
+                        wr = (ws - ws.astype(np.float32).astype(np.float16).astype(np.float64)) * 2048.0
+                        scale = 2.0 ** (e - 127)
+                        top = max(np.abs(ws).max(), np.abs(wr).max()) / scale
+                        assert 3.75 <= top <= 7.5 + 1e-9, (top, e)
+                        step = np.where(np.abs(fields) < 2, 0.125, np.where(np.abs(fields) < 4, 0.25, 0.5))
+                        err_r = np.abs(fields[:16] - wr / scale)
+                        err_w = np.abs(fields[16:] - ws / scale)
+                        assert np.all(err_r <= step[:16] / 2 + 1e-9) and np.all(err_w <= step[16:] / 2 + 1e-9), (ocb, chunk, grow, mm, lane)
+                        worst = max(worst, (err_w * scale / np.abs(ws).max()).max())
+    print("packed fp6 weights: worst field error %.3f of its block's maximum" % worst)

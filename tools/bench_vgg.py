@@ -17,7 +17,7 @@ ap.add_argument("--maps", type=int, default=80)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--fp32", action="store_true", help="same as --mode 0")
-ap.add_argument("--mode", type=int, default=3, help="0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 f16x3 with fp8 cross products in the relevance pass (default)")
+ap.add_argument("--mode", type=int, default=3, help="0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 f16x3 with fp6 cross products in the relevance pass (default)")
 a = ap.parse_args()
 
 from lrp_amd import _lib
