@@ -1135,6 +1135,19 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                             // re-used by the allocator while the read is in flight, and the wait for that write-after-write
                             // hazard is a full drain of the counter)
                             const u32x4_ x0 = *reinterpret_cast<const u32x4_*>(a6);
+#ifndef LRPXH_X6_READ
+#define LRPXH_X6_READ 0
+#endif
+                            if constexpr (LRPXH_X6_READ != 0) {
+                                // (variant, off) two 16-byte reads, conflict-free over consecutive pixels 80 bytes apart; the clear dword
+                                // behind the fields is kept alive past the MFMA by an empty asm (see the MFMA below).  The 8- and 4-byte
+                                // reads of the default hit their banks 2 and 4 times over pixels 80 bytes apart (SQ_LDS_BANK_CONFLICT
+                                // 0.33 of the LDS cycles against 0.03 with fp8) - but the kernels are not bound by the LDS: same-box A/B
+                                // chain 17.33 / 17.27 ms with the conflicts, 17.46 / 17.38 without (the extra live register costs conv2_1
+                                // 12 spilled VGPRs: 1.10 -> 1.26 ms; every other layer +-0.01)
+                                const u32x4_ x1 = *reinterpret_cast<const u32x4_*>(a6 + 16);
+                                return i32x8_{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[3], (int)x1[2]};
+                            }
                             const u32x2_ x1 = *reinterpret_cast<const u32x2_*>(a6 + 16);
                             const unsigned xs = *reinterpret_cast<const unsigned*>(a6 + 28);
                             return i32x8_{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)xs, 0};
@@ -1187,6 +1200,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                             } else {
                                 acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cur, m == 0 ? bm0 : bm1, acc[j], 0, 0, 0, 0, 0, 0);
                             }
+                            if constexpr (X6 && (LRPXH_X6_READ != 0)) {      // (the unused 4th dword of the second read stays allocated until here)
+                                const int keep = cur[7];
+                                asm volatile("" : : "v"(keep));
+                            }
                         } else {
                             const u32x4_ c4 = {(unsigned)cur[0], (unsigned)cur[1], (unsigned)cur[2], (unsigned)cur[3]};
                             if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[m - 2], __builtin_bit_cast(f16x8, c4), acc[j], 0, 0, 0);
@@ -1228,8 +1245,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                         if constexpr (X6) {
                             const char* a6 = abuf + abase[j] + (g == 2 ? e6c : e6a) + LRPXH_TOFF(4 * g);
                             p0 = *reinterpret_cast<const u32x4_*>(a6);
-                            const u32x2_ y_ = *reinterpret_cast<const u32x2_*>(a6 + 16);
-                            p1 = u32x4_{y_[0], y_[1], *reinterpret_cast<const unsigned*>(a6 + 28), 0u};
+                            const u32x4_ y_ = *reinterpret_cast<const u32x4_*>(a6 + 16);
+                            p1 = u32x4_{y_[0], y_[1], y_[3], y_[2]};
                         } else {
                             p0 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(4 * g));
                             p1 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(4 * g + 1));
@@ -1247,8 +1264,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                             if constexpr (X6) {       // taps 4g + 2 / 4g + 3: g = 0: a row less two pixels apart, g = 1: one pixel
                                 const char* a6 = abuf + abase[j] + (g == 0 ? e6b : e6a) + LRPXH_TOFF(g < 2 ? 4 * g + 2 : 0);
                                 q0 = *reinterpret_cast<const u32x4_*>(a6);
-                                const u32x2_ y_ = *reinterpret_cast<const u32x2_*>(a6 + 16);
-                                q1 = u32x4_{y_[0], y_[1], *reinterpret_cast<const unsigned*>(a6 + 28), 0u};
+                                const u32x4_ y_ = *reinterpret_cast<const u32x4_*>(a6 + 16);
+                                q1 = u32x4_{y_[0], y_[1], y_[3], y_[2]};
                             } else {
                                 q0 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(g < 2 ? 4 * g + 2 : 0));
                                 q1 = *reinterpret_cast<const u32x4_*>(a8 + LRPXH_TOFF(g < 2 ? 4 * g + 3 : 0));
