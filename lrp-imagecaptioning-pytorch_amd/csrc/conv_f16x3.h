@@ -1003,7 +1003,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #define LRPXH_NQ_112P 3
 #endif
     // X6 (a staging item holds 16 floats): a third entry spills everywhere
-    constexpr int NQ = F8 ? ((!X6 && POOL && AL && HW <= 112) ? ((HW == 112 && MT * NWN == 4) ? LRPXH_NQ_112P : 3) : 2) : NBQ;
+    #ifndef LRPXH_X6_NQ3
+#define LRPXH_X6_NQ3 0
+#endif
+    constexpr int NQ = F8 ? (((!X6 || (LRPXH_X6_NQ3 && HW == 112 && MT * NWN == 4)) && POOL && AL && HW <= 112) ? ((HW == 112 && MT * NWN == 4) ? LRPXH_NQ_112P : 3) : 2) : NBQ;
 #endif
     // (a wave without a channel block of its own - n_oc not a multiple of the workgroup's channels - multiplies the last
     // valid block again and drops the result: one code path, see PRECISE below)
