@@ -823,3 +823,51 @@ def test_packed_f16f6_weight_layout(ops):
                         assert np.all(err_r <= step[:16] / 2 + 1e-9) and np.all(err_w <= step[16:] / 2 + 1e-9), (ocb, chunk, grow, mm, lane)
                         worst = max(worst, (err_w * scale / np.abs(ws).max()).max())
     print("packed fp6 weights: worst field error %.3f of its block's maximum" % worst)
+
+
+@pytest.mark.parametrize("hw,cin,cout", [(224, 64, 64), (14, 256, 32), (56, 256, 32), (112, 64, 128)])
+def test_conv_rule_f16f6_single_tap_weights(ops, hw, cin, cout):
+    """Weights with ONE non-zero tap: every cross-product MFMA of a K-chunk is exercised on its own (tap pairs share an MFMA, the lane
+    halves hold different taps), and at the image border Z+ is exactly 0 for an off-centre tap, so S = R / safe(Z+) carries outliers
+    of 1e7 times the typical entry - the case the block exponents exist for.  This is the test that exposed the overlapping result
+    registers of the fp6 conversion builtin (wrong cross products in single unrolled copies of the staging code, errors 1e-4 .. 1e-3
+    with exactly this pattern); bound: 5e-5 of the map's maximum against the fp32-MFMA kernel for every tap."""
+    g = torch.Generator().manual_seed(hw * 91 + cin)
+    x = torch.relu(torch.randn(1, cin, hw, hw, generator=g)) + 0.1
+    w_all = torch.rand(cout, cin, 3, 3, generator=g) * 0.03
+    r = torch.randn(2, cout, hw, hw, generator=g)
+    worst = []
+    for tap in range(9):
+        w = torch.zeros_like(w_all)
+        w[:, :, tap // 3, tap % 3] = w_all[:, :, tap // 3, tap % 3]
+        got, _, _ = gpu_conv_rule(ops, x, w, r, [0, 0], f16x3=2)
+        got32, _, _ = gpu_conv_rule(ops, x, w, r, [0, 0])
+        worst.append(max(rel_err(got[i], got32[i]) for i in range(2)))
+    print("single-tap weights, hw %d: error per tap %s" % (hw, " ".join("%.0e" % e for e in worst)))
+    assert max(worst) < 5e-5, worst
+
+
+@pytest.mark.parametrize("f8", [False, True])
+@pytest.mark.parametrize("hw,c", [(56, 32), (28, 32), (112, 128), (224, 64)])
+def test_pooled_input_identity_weights_unpool_exactly(ops, hw, c, f8):
+    """Pooled-input kernels with identity centre-tap weights and x = 1: the output must be the unpooled input EXACTLY (small integers:
+    every split and every fp6 field is exact) - the value at its winner position, zeros at the other three.  Pins the per-position
+    channel masks of the staging code (a vector-element bit_cast once made every channel of a slice carry channel 0's value)."""
+    from lrp_amd import _lib
+    dev = "cuda"
+    ho = hw // 2
+    g = torch.Generator().manual_seed(hw)
+    s_lo = torch.randint(1, 9, (2, ho * ho, c), generator=g).float().to(dev)
+    am = torch.randint(0, 4, (1, ho * ho, c), generator=g, dtype=torch.uint8).to(dev)
+    w = torch.zeros(c, c, 3, 3)
+    w[torch.arange(c), torch.arange(c), 1, 1] = 1.0
+    wb = (ops.pack_weights_f16f8 if f8 else ops.pack_weights_f16x2)(w.to(dev), c, c, _lib.PACK_BWD_POS)
+    out = torch.empty(2, hw * hw, c, device=dev)
+    ops.conv_mfma(s_lo, wb, 2, hw, c, c, 9, _lib.EPI_REL_MUL, oc_split=c, x=torch.ones(1, hw * hw, c, device=dev),
+                  map2img=torch.zeros(2, dtype=torch.int32, device=dev), out0=out, f16x3=2 if f8 else 1,
+                  in_amax=ops.amax_maps(s_lo, 2), pool_am=am)
+    torch.cuda.synchronize()
+    want = torch.zeros(2, hw, hw, c, device=dev)
+    for pos in range(4):
+        want[:, pos // 2::2, pos % 2::2, :] = s_lo.view(2, ho, ho, c) * (am.view(1, ho, ho, c) == pos)
+    assert torch.equal(out.view(2, hw, hw, c), want)
