@@ -204,12 +204,15 @@ __global__ __launch_bounds__(256, 2) void first_layer_mfma_kernel(const float* _
 #pragma unroll
         for (int k = 0; k < FM_NIT; ++k) {
             const bool ok = in_image(k, tx0);
-            _Float16 h[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split2(ok ? stage[k][e] * sc : 0.f, h[e], l[e]);
+            // (packed conversions: v_cvt_pk_f16_f32, bit-identical to four scalar splits)
+            unsigned h01, h23, l01, l23;
+            f32x2_ hf;
+            const f32x2_ z2 = {0.f, 0.f};
+            split2_pk(ok ? f32x2_{stage[k][0], stage[k][1]} * f32x2_{sc, sc} : z2, h01, l01, hf);
+            split2_pk(ok ? f32x2_{stage[k][2], stage[k][3]} * f32x2_{sc, sc} : z2, h23, l23, hf);
             char* d = lds + (l_off[k] >= 0 ? l_off[k] : 128);       // no item: the pad bytes of pixel 0
-            *reinterpret_cast<fm_u32x2*>(d) = fm_u32x2{pack_f16(h[0], h[1]), pack_f16(h[2], h[3])};
-            *reinterpret_cast<fm_u32x2*>(d + (l_off[k] >= 0 ? 64 : 8)) = fm_u32x2{pack_f16(l[0], l[1]), pack_f16(l[2], l[3])};
+            *reinterpret_cast<fm_u32x2*>(d) = fm_u32x2{h01, h23};
+            *reinterpret_cast<fm_u32x2*>(d + (l_off[k] >= 0 ? 64 : 8)) = fm_u32x2{l01, l23};
         }
     };
     // wave w owns image rows 2w, 2w+1 of the band, two 16-pixel tiles each
