@@ -301,6 +301,65 @@ __host__ __device__ __forceinline__ unsigned fp6_e2m3_encode(float v) {
     return sgn | (unsigned)c;
 }
 
+// REL_MUL / GUIDED epilogue of the MAP-ALIGNED kernels (56 / 112 / 224: the workgroup tile lies inside one map) with scalar-base
+// addressing: element (tile j, register e) of a lane sits at  X[(img P + p0 + wm 224 + 32 j + dq(e)) ncol + ocb 32] + (4 lh ncol + li) -
+// ONE wave-uniform 64-bit base per tensor plus a 32-bit byte offset (uniform element part + the lane's part: one v_add_u32) - so every
+// access is `global_load / global_store_dword v, v_off, s[base]`: no 64-bit vector add per access (the generic dword epilogue: 224
+// v_lshl_add_u64 per wave) and half the address bytes on the way to the texture unit.  Same arithmetic, same order: bit-identical.
+template <int HW, int EPI, bool F8>
+__device__ __forceinline__ void epi_rel_mul_al(const ConvArgs& a, f32x16 (&acc)[7], const int wm, const int ocb, const int lane,
+                                               const long g0, const long total_pix, unsigned* __restrict__ oamax, const float inv_w,
+                                               const unsigned* __restrict__ in_amax) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int ncol = a.oc_split;
+    const int oc = ocb * 32 + li;
+    if (oc >= ncol) return;                                     // (padding columns of the last channel block)
+    const unsigned P = (unsigned)a.pix_per_map;
+    const int nmax = a.n_maps - 1;
+    const unsigned n = (unsigned)g0 / (unsigned)HW;             // the tile's map
+    const unsigned p0 = ((unsigned)g0 - n * HW) * HW;           // pixel-in-map of the tile's first pixel
+    const long img = a.map2img ? a.map2img[min((int)n, nmax)] : (long)n;
+    const float f = exp2i(-split_scale_exp<F8>(in_amax[min((int)n, nmax)])) * inv_w;
+    const int ch = a.out_chunk;
+    const int ostr = ch > 0 ? ch : ncol;
+    // uniform bases (bytes) and the lane's offsets (bytes, 32-bit)
+    const char* __restrict__ Xu = reinterpret_cast<const char*>(a.X) + ((img * P + p0 + wm * 224) * (long)ncol + ocb * 32) * 4;
+    char* __restrict__ Ou = reinterpret_cast<char*>(a.out1 ? a.out1 : a.out0) +
+                            ((g0 * HW + wm * 224) * (long)ostr + (ch > 0 ? (long)((ocb * 32) / ch) * total_pix * ch + (ocb * 32) % ch : (long)ocb * 32)) * 4;
+    const unsigned xoff = (unsigned)((4 * lh * ncol + li) * 4);
+    const unsigned ooff = (unsigned)(((long)(4 * lh) * ostr + (ch > 0 ? (long)(li / ch) * total_pix * ch + li % ch : (long)li)) * 4);
+    float xv[7][16];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const unsigned ub = (unsigned)((32 * j + (e & 3) + 8 * (e >> 2)) * ncol * 4);         // uniform, < 2^20
+            xv[j][e] = (LRPX_EPI_EXP & 1) ? 1.f : *reinterpret_cast<const float*>(Xu + (ub + xoff));
+        }
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = acc[j][e] * f;
+            const float r = EPI == EPI_GUIDED ? ((xv[j][e] > 0.f && (a.relu == 2 || v > 0.f)) ? v : 0.f) : xv[j][e] * v;
+            const unsigned ub = (unsigned)((32 * j + (e & 3) + 8 * (e >> 2)) * ostr * 4);         // uniform
+            float* op = reinterpret_cast<float*>(Ou + (ub + ooff));
+#if LRPX_EPI_EXP & 2
+            if (r == 1.2345e-30f) *op = r;
+#elif LRPXH_NT_STORE & 2
+            __builtin_nontemporal_store(r, op);
+#else
+            *op = r;
+#endif
+            m = fmaxf(m, fabsf(r));
+        }
+    if (oamax) {
+        m = wave_max(m);
+        if (lane == 0 && (int)n <= nmax) amax_update(&oamax[n], m);
+    }
+}
+
 // REL_MUL / GUIDED epilogue for TRANSPOSED accumulators (LRPXH_TR): the MFMAs were issued with the weights as the A operand and the
 // pixels as the B operand - the same fragments, the arguments swapped - so the result tile is channels x pixels: a lane owns ONE
 // pixel (tile pixel lane % 32) and 16 channels, 4 lh + 8 k + (0..3), k = 0..3: four float4 per tile straight from the accumulator
@@ -1433,6 +1492,16 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         return;
     }
 
+#ifndef LRPXH_AL_EPI
+#define LRPXH_AL_EPI 1
+#endif
+    // (measured, same box: conv1_2 2.77 -> 2.60 ms, conv2_2 2.07 -> 2.00, conv3_1 0.96 -> 0.93, the 8-wave 56x56 layers +-0; the
+    // 4-row 112x112 kernel of conv2_1 spills 9 registers with it, 1.09 -> 1.14: it keeps the generic epilogue)
+    if constexpr (X6 && AL && (LRPXH_AL_EPI != 0) && !(HW == 112 && MT == 2) && (EPI == EPI_REL_MUL || EPI == EPI_GUIDED)) {
+        unsigned* __restrict__ oamax_a = (EPI == EPI_GUIDED) ? a.out0_amax : (a.out1 ? a.out1_amax : nullptr);
+        epi_rel_mul_al<HW, EPI, F8>(a, acc, wm, ocb, lane, g0, total_pix, oamax_a, inv_w, in_amax);
+        return;
+    }
     EpiCtx cx;
     cx.oc = ocb * 32 + li;
     cx.lane = lane;
