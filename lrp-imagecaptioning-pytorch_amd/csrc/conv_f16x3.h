@@ -197,6 +197,11 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
     for (int j = 0; j < (AL ? 7 : 2); ++j) load_x(j);
     const unsigned n_first = (unsigned)g0 / (unsigned)HW;    // map of the workgroup tile's first pixel
     float m_al = 0.f;
+    // map-straddling tiles: the 224 pixels of the workgroup touch at most the maps n_first, + 1, + 2 (a map has >= 196 pixels).  Their
+    // maxima are kept per lane and reduced ONCE behind the last tile: amax_update reads the word first, and a wait for that read is a
+    // wait for every store issued before it (one in-order counter) - two such waits per tile made the wave sit out the write latency
+    // of each of its 7 tiles
+    float mm0 = 0.f, mm1 = 0.f, mm2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         if constexpr (!AL) { if (j + 2 < 7) load_x(j + 2); }
@@ -239,9 +244,10 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
             if constexpr (AL) {
                 m_al = fmaxf(m_al, m0);
             } else {
-                m0 = wave_max(m0); m1 = wave_max(m1);
-                if (lane == 0 && (int)nt0 <= nmax) amax_update(&oamax[nt0], m0);
-                if (lane == 0 && (int)nt0 + 1 <= nmax) amax_update(&oamax[nt0 + 1], m1);
+                const int k0 = (int)(nt0 - n_first);               // 0 .. 2, wave-uniform
+                mm0 = fmaxf(mm0, k0 == 0 ? m0 : 0.f);
+                mm1 = fmaxf(mm1, k0 == 0 ? m1 : (k0 == 1 ? m0 : 0.f));
+                mm2 = fmaxf(mm2, k0 == 1 ? m1 : (k0 == 2 ? m0 : 0.f));
             }
         }
     }
@@ -249,6 +255,13 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
         if (oamax) {
             m_al = wave_max(m_al);
             if (lane == 0 && (int)n_first <= nmax) amax_update(&oamax[n_first], m_al);
+        }
+    } else {
+        if (oamax) {
+            mm0 = wave_max(mm0); mm1 = wave_max(mm1); mm2 = wave_max(mm2);
+            if (lane == 0 && (int)n_first <= nmax) amax_update(&oamax[n_first], mm0);
+            if (lane == 0 && (int)n_first + 1 <= nmax) amax_update(&oamax[n_first + 1], mm1);
+            if (lane == 0 && (int)n_first + 2 <= nmax) amax_update(&oamax[n_first + 2], mm2);
         }
     }
 }
