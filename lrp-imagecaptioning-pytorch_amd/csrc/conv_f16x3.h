@@ -373,6 +373,39 @@ __device__ __forceinline__ void epi_rel_mul_al(const ConvArgs& a, f32x16 (&acc)[
     }
 }
 
+// FWD_DUAL epilogue of the map-aligned forward kernels, addressed like epi_rel_mul_al (one scalar base, 32-bit offsets): channel blocks
+// below oc_split are activations - out0 = ReLU(acc + bias), per-image maximum to out0_amax -, the blocks above it are Z+ - out1 = acc.
+// A channel block is one or the other as a whole (oc_split is a multiple of 32 for every VGG16 layer; the launcher checks).
+template <int HW, bool F8>
+__device__ __forceinline__ void epi_fwd_dual_al(const ConvArgs& a, f32x16 (&acc)[7], const int wm, const int ocb, const int lane,
+                                                const long g0, const float inv_w, const unsigned* __restrict__ in_amax) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int ncol = a.oc_split;
+    const int nmax = a.n_maps - 1;
+    const unsigned n = (unsigned)g0 / (unsigned)HW;             // the tile's image
+    const float f = exp2i(-split_scale_exp<F8>(in_amax[min((int)n, nmax)])) * inv_w;
+    const bool is_act = ocb * 32 < ncol;                        // wave-uniform
+    const int ocl = (is_act ? ocb * 32 : ocb * 32 - ncol);      // first channel of the block inside its tensor
+    if (ocl + li >= ncol) return;
+    const float bias = (is_act && a.bias) ? a.bias[ocl + li] : 0.f;
+    char* __restrict__ Ou = reinterpret_cast<char*>(is_act ? a.out0 : a.out1) + ((g0 * HW + wm * 224) * (long)ncol + ocl) * 4;
+    const unsigned ooff = (unsigned)((4 * lh * ncol + li) * 4);
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float v = acc[j][e] * f;
+            if (is_act) { v += bias; v = v > 0.f ? v : 0.f; m = fmaxf(m, v); }
+            const unsigned ub = (unsigned)((32 * j + (e & 3) + 8 * (e >> 2)) * ncol * 4);         // uniform
+            *reinterpret_cast<float*>(Ou + (ub + ooff)) = v;
+        }
+    if (is_act && a.out0_amax) {
+        m = wave_max(m);
+        if (lane == 0 && (int)n <= nmax) amax_update(&a.out0_amax[n], m);
+    }
+}
+
 // REL_MUL / GUIDED epilogue for TRANSPOSED accumulators (LRPXH_TR): the MFMAs were issued with the weights as the A operand and the
 // pixels as the B operand - the same fragments, the arguments swapped - so the result tile is channels x pixels: a lane owns ONE
 // pixel (tile pixel lane % 32) and 16 channels, 4 lh + 8 k + (0..3), k = 0..3: four float4 per tile straight from the accumulator
@@ -1514,6 +1547,15 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         unsigned* __restrict__ oamax_a = (EPI == EPI_GUIDED) ? a.out0_amax : (a.out1 ? a.out1_amax : nullptr);
         epi_rel_mul_al<HW, EPI, F8>(a, acc, wm, ocb, lane, g0, total_pix, oamax_a, inv_w, in_amax);
         return;
+    }
+#ifndef LRPXH_AL_FWD
+#define LRPXH_AL_FWD 1
+#endif
+    if constexpr (AL && (LRPXH_AL_FWD != 0) && EPI == EPI_FWD_DUAL) {
+        if ((a.oc_split & 31) == 0) {                      // (uniform; every VGG16 layer)
+            epi_fwd_dual_al<HW, F8>(a, acc, wm, ocb, lane, g0, inv_w, in_amax);
+            return;
+        }
     }
     EpiCtx cx;
     cx.oc = ocb * 32 + li;
