@@ -150,10 +150,13 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
     const int oc4 = ocb * 32 + 4 * qd;
     const bool col_ok = oc4 < ncol;
     const float* __restrict__ X = a.X;
-    float* __restrict__ O = a.out1 ? a.out1 : a.out0;
     const int ch = a.out_chunk;
     const int ostr = ch > 0 ? ch : ncol;
-    const long obase = ch > 0 ? (long)(oc4 / ch) * total_pix * ch + (oc4 % ch) : (long)oc4;
+    // stores: one wave-uniform base + (uniform element offset + the lane's offset), 32 bits (cf. epi_rel_mul_al)
+    const int ocu = ocb * 32, ocl4 = 4 * (lane & 7);
+    char* __restrict__ Ou = reinterpret_cast<char*>(a.out1 ? a.out1 : a.out0) +
+                            ((g0 * HW + wm * 224) * (long)ostr + (ch > 0 ? (long)(ocu / ch) * total_pix * ch + ocu % ch : (long)ocu)) * 4;
+    const unsigned ooff = (unsigned)(((long)(lane >> 3) * ostr + (ch > 0 ? (long)(ocl4 / ch) * total_pix * ch + ocl4 % ch : (long)ocl4)) * 4);
     const unsigned P = (unsigned)a.pix_per_map;
     const int nmax = a.n_maps - 1;
     const long pix0 = g0 * HW;
@@ -228,7 +231,7 @@ __device__ __forceinline__ void epi_rel_mul_wide(const ConvArgs& a, f32x16 (&acc
             const int dq = r0 + 8 * k;
             const long gp = pix0 + wm * 224 + 32 * j + dq;
             if (col_ok && (AL || gp < total_pix)) {
-                float* op = O + gp * (long)ostr + obase;
+                float* op = reinterpret_cast<float*>(Ou + ((unsigned)((32 * j + 8 * k) * ostr * 4) + ooff));     // scalar base + 32-bit offset
 #if LRPX_EPI_EXP & 2
                 if (r[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(op) = r;
 #elif LRPXH_NT_STORE & 1
