@@ -204,6 +204,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void dense_f16x3_kernel(
     unsigned* __restrict__ oamax = o1 ? a.out1_amax : nullptr;
     const int ncol = a.oc_split;
     const int nmax = a.n_maps - 1;
+    // (the per-map maxima of both row tiles are published behind the last store: amax_update reads the word first, and the wait for
+    // that read is a wait for every store issued before it - cf. epi_rel_mul_wide of conv_f16x3.h)
+    float mres[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    unsigned nres[2] = {0u, 0u};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         // max|out1| per map: a 32-row accumulator tile holds at most ONE map boundary (P >= 32, host-checked): m0 for the
@@ -269,11 +273,16 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void dense_f16x3_kernel(
                 }
             }
         }
-        if (oamax) {
-            m0 = wave_max(m0); m1 = wave_max(m1);
+        mres[i][0] = m0; mres[i][1] = m1; nres[i] = nt0;
+    }
+    if (oamax) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long rt = row0 + wm * 64 + 32 * i;
+            const float m0 = wave_max(mres[i][0]), m1 = wave_max(mres[i][1]);
             if (lane == 0 && rt < M) {
-                amax_update(&oamax[nt0], m0);
-                if ((int)nt0 + 1 <= nmax) amax_update(&oamax[nt0 + 1], m1);
+                amax_update(&oamax[nres[i]], m0);
+                if ((int)nres[i] + 1 <= nmax) amax_update(&oamax[nres[i] + 1], m1);
             }
         }
     }
