@@ -34,6 +34,10 @@ enum {
 
 int lrpx_version(void);
 const char* lrpx_last_error_string(void);
+/* "" for a release build.  Otherwise the list of timing-experiment / profiling switches the library was compiled with
+ * (-DLRPX_EXPERIMENTS with -DLRPXH_EXP=.. / -DLRPX_EPI_EXP=.. / ..., make STAMP=1): such a build computes WRONG results by
+ * design (or carries profiling atomics) and must never serve a caller - tests/test_abi.py and smoke() assert "". */
+const char* lrpx_build_flags(void);
 
 /* ---- weight packing ------------------------------------------------------------------------- */
 enum {
@@ -467,6 +471,13 @@ int lrpx_batchnorm_rule(const float* x, const float* r_out, const float* gamma, 
  * plus r_out / 2 each where x1 + x2 == 0.  Non-finite results (x1 == -x2 != 0) are left for lrpx_check, as the reference's
  * asserts (:276-279) catch them. */
 int lrpx_add_rule(const float* x1, const float* x2, const float* r_out, float* r1, float* r2, long n, void* stream);
+/* Pool2d.propagate_relevance for nn.AvgPool2d (LRPtools/lrp_modules.py:176-177,182-195; table entry :327): Z = avgpool(x),
+ * S = r_out / (Z + 1e-7 [Z == 0]) (utils.py:16-18), r_in = x * avgpool^T(S).  x / r_in: (planes, h, w), r_out: (planes, oh, ow) with
+ * planes = N * C of the module's NCHW tensors; s_ws: planes * oh * ow floats of scratch.  Window bounds, divisor
+ * (count_include_pad, divisor_override > 0, ceil_mode through oh / ow) and summation orders follow ATen's CPU kernels:
+ * bit-exact against the reference. */
+int lrpx_avgpool_rule(const float* x, const float* r_out, float* s_ws, float* r_in, long planes, int h, int w, int oh, int ow,
+                      int kh, int kw, int sh, int sw, int ph, int pw, int count_include_pad, int divisor_override, void* stream);
 /* max |a - b| into one device float (Dropout.propagate_relevance's check, LRPtools/lrp_modules.py:251; NaN counts as inf) */
 int lrpx_max_abs_diff(const float* a, const float* b, long n, float* out_dev, void* stream);
 

@@ -7,7 +7,7 @@ layer input, as the reference's `save_input_hook` leaves it (lrp_wrapper.py:24-2
 device, as in the reference; layouts are converted at this boundary.
 
 Conv2d 3x3/pad 1, MaxPool2d(2,2) and ReLU are the layers VGG16 exercises (kernels for square maps of 224/112/56/28/14
-pixels; any other H x W <= 224 runs zero-embedded in the next larger of those; other kernel sizes / strides raise ValueError).  Linear / BatchNorm2d / BatchNorm1d / Dropout / Add / Flatten (only
+pixels; any other H x W <= 224 runs zero-embedded in the next larger of those; other kernel sizes / strides raise ValueError).  Linear / BatchNorm2d / BatchNorm1d / Dropout / Add / Flatten / AvgPool2d (SURVEY.md §8(a) M4 and W3's table, only
 reached with the reference's ResNet encoders) are HBM-bound streaming kernels (csrc/lrpx_rules.hip), any shape."""
 import torch
 import torch.nn as nn
@@ -114,11 +114,36 @@ class Conv2d:
         return (R,)
 
 
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
 class Pool2d:
-    """MaxPool2d(2,2) rule (lrp_modules.py:182-195): winner-take-all routing, first maximum wins."""
+    """Pool2d rule (lrp_modules.py:172-195).  MaxPool2d(2,2): winner-take-all routing, first maximum wins.
+    AvgPool2d (any kernel / stride / padding / count_include_pad / ceil_mode - the attributes the reference clones at :176-177):
+    Z = avgpool(X), R = X * avgpool^T(R_out / safe(Z)).  Quirk reproduced: the reference's clone does NOT carry
+    `divisor_override`, so its rule divides by the default window size whatever the module says (fixture `k23_div5`)."""
+
+    def _avgpool(self, module, relevance_output):
+        x = _f32c(module.input[0])
+        r_out = _f32c(relevance_output[0])
+        _require(x.dim() == 4 and r_out.dim() == 4, "lrpx Pool2d rule: AvgPool2d on (N, C, H, W) tensors")
+        n, c, h, w = x.shape
+        (kh, kw), (ph, pw) = _pair(module.kernel_size), _pair(module.padding)
+        sh, sw = _pair(module.stride if module.stride is not None else module.kernel_size)
+        oh, ow = r_out.shape[2], r_out.shape[3]
+        _require(r_out.shape[:2] == (n, c), "relevance_output shape mismatch")
+        R = torch.empty_like(x)
+        s_ws = torch.empty_like(r_out)
+        check(_lib.load().lrpx_avgpool_rule(ptr(x), ptr(r_out), ptr(s_ws), ptr(R), n * c, h, w, oh, ow, kh, kw, sh, sw, ph, pw,
+                                            1 if module.count_include_pad else 0, 0, stream_ptr()))   # (divisor_override: dropped by the reference's clone)
+        ops.check_relevance(R)                                      # lrp_modules.py:192-193
+        return (R,)
 
     def propagate_relevance(self, module, relevance_input, relevance_output, lrp_method, lrp_params=None):
-        _require(isinstance(module, nn.MaxPool2d), "lrpx Pool2d rule: MaxPool2d only (AvgPool2d is not on the VGG16 path)")
+        if isinstance(module, nn.AvgPool2d):
+            return self._avgpool(module, relevance_output)
+        _require(isinstance(module, nn.MaxPool2d), "lrpx Pool2d rule: MaxPool2d / AvgPool2d only")    # lrp_modules.py:179
         ks = module.kernel_size if isinstance(module.kernel_size, tuple) else (module.kernel_size,) * 2
         stq = module.stride if isinstance(module.stride, tuple) else (module.stride,) * 2
         _require(ks == (2, 2) and stq == (2, 2) and module.padding in (0, (0, 0)), "lrpx Pool2d rule: 2x2 / stride 2 only")
@@ -266,15 +291,14 @@ class Flatten:
         return (R,)
 
 
-_RULES = {nn.ReLU: ReLU, nn.Conv2d: Conv2d, nn.MaxPool2d: Pool2d, nn.Linear: Linear, nn.BatchNorm2d: BatchNorm2d,
+_RULES = {nn.ReLU: ReLU, nn.Conv2d: Conv2d, nn.MaxPool2d: Pool2d, nn.AvgPool2d: Pool2d, nn.Linear: Linear, nn.BatchNorm2d: BatchNorm2d,
           nn.BatchNorm1d: BatchNorm1d, nn.Dropout: Dropout, nn.Dropout2d: Dropout, resAdd: Add, resFlatten: Flatten}
 # the reference's own `models.resnet.Add` / `Flatten` classes (a user's ResNet is built from those) dispatch by name
 _RULES_BY_NAME = {"Add": Add, "Flatten": Flatten}
 
 
 def get_lrp_module(module):
-    """type(module) -> rule object; ValueError for leaves the path does not know (lrp_modules.py:321-341).
-    (`nn.AvgPool2d` is in the reference's table but no encoder of the reference contains one: not built -> ValueError.)"""
+    """type(module) -> rule object; ValueError for leaves the path does not know (lrp_modules.py:321-341)."""
     cls = _RULES.get(type(module))
     if cls is None and type(module).__module__.endswith("resnet"):
         cls = _RULES_BY_NAME.get(type(module).__name__)

@@ -75,6 +75,7 @@ class VggOpts(C.Structure):
 SIGNATURES = {
     "lrpx_version": (_i, []),
     "lrpx_last_error_string": (C.c_char_p, []),
+    "lrpx_build_flags": (C.c_char_p, []),
     "lrpx_packed_floats": (_sz, [_i, _i, _i, _i]),
     "lrpx_pack_weights": (_i, [_f, _i, _i, _i, _i, _i, _f, _f]),
     "lrpx_packed_bf16x3_bytes": (_sz, [_i, _i, _i]),
@@ -169,6 +170,7 @@ SIGNATURES = {
     "lrpx_linear_eps_rule": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
     "lrpx_batchnorm_rule": (_i, [_f, _f, _f, _f, _f, _f, C.c_float, _f, _l, _i, _l, _i, _f]),
     "lrpx_add_rule": (_i, [_f, _f, _f, _f, _f, _l, _f]),
+    "lrpx_avgpool_rule": (_i, [_f, _f, _f, _f, _l] + [_i] * 12 + [_f]),
     "lrpx_max_abs_diff": (_i, [_f, _f, _l, _f, _f]),
 }
 

@@ -8,6 +8,8 @@
 
 #include "../../include/lrpx.h"
 
+#include "build_guard.h"
+
 namespace lrpx {
 
 void set_error(const char* fmt, ...);

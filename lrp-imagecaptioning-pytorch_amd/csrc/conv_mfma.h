@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "build_guard.h"
+
 #ifndef LRPXH_NT_STORE
 #define LRPXH_NT_STORE 3      // bit 0: float4 (wide) REL_MUL epilogue, bit 1: dword epilogue: streaming stores
 #endif

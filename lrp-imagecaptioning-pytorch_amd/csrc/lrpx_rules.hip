@@ -3,6 +3,7 @@
 //   BatchNorm2d / BatchNorm1d   |xw| / (|xw| + |b|) split      LRPtools/lrp_modules.py:197-246
 //   Add          proportional split, 0.5 / 0.5 on zero sums     LRPtools/lrp_modules.py:256-280
 //   Dropout      |R_out - R_in| < 1e-7 check                    LRPtools/lrp_modules.py:248-254
+//   AvgPool2d    Z = avgpool(X), R = X * avgpool^T(R_out / Z)    LRPtools/lrp_modules.py:172-195 (Pool2d, the nn.AvgPool2d branch)
 // (Flatten, :282-291, is a copy: lrpx_scale with factor 1.)
 // All of them are HBM-bound: one streaming pass each, the Linear rule streams W twice (Z = x W^T, then (R/Z) W) with the
 // handful of batch rows held in registers.  Arithmetic follows the reference expression by expression (IEEE division and
@@ -153,6 +154,63 @@ __global__ void max_abs_diff_kernel(const float* __restrict__ a, const float* __
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
 }
 
+
+// ---- Pool2d rule for nn.AvgPool2d (lrp_modules.py:176-177 clone, :182-195 rule; dispatch entry :327) -----------------------
+// Z = avgpool(X), S = safe_divide(R_out, Z) (utils.py:16-18), Z.backward(S), R = X * X.grad.  NCHW fp32 as the module sees it,
+// any kernel / stride / padding / count_include_pad / ceil_mode / divisor_override.  Window bounds and divisor follow ATen's
+// CPU kernels statement by statement (the padded window end is clipped at H + pad BEFORE the divisor is taken, then the window
+// is clipped to the image), the window sum runs row-major and the input gradient adds its windows in ascending (oh, ow) order
+// - what the reference's autograd executes - so the result is bit-exact against it.
+struct AvgPoolGeom { int H, W, OH, OW, kh, kw, sh, sw, ph, pw, count_include_pad, divisor_override; };
+
+__device__ __forceinline__ void avg_window(const AvgPoolGeom& g, int oh, int ow, int& h0, int& h1, int& w0, int& w1, int& div) {
+    h0 = oh * g.sh - g.ph; w0 = ow * g.sw - g.pw;
+    h1 = min(h0 + g.kh, g.H + g.ph); w1 = min(w0 + g.kw, g.W + g.pw);
+    const int pool_size = (h1 - h0) * (w1 - w0);
+    h0 = max(h0, 0); w0 = max(w0, 0); h1 = min(h1, g.H); w1 = min(w1, g.W);
+    div = g.divisor_override ? g.divisor_override : (g.count_include_pad ? pool_size : (h1 - h0) * (w1 - w0));
+}
+
+// one thread per output element: sd = (R_out / (Z + 1e-7 [Z == 0])) / divisor  (what every input of the window receives)
+__global__ void avgpool_rule_s_kernel(const float* __restrict__ x, const float* __restrict__ r_out, float* __restrict__ sd,
+                                      long planes, AvgPoolGeom g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)g.OH * g.OW;
+    if (i >= planes * per) return;
+    const long pl = i / per;
+    const int o = (int)(i - pl * per), oh = o / g.OW, ow = o - oh * g.OW;
+    int h0, h1, w0, w1, div;
+    avg_window(g, oh, ow, h0, h1, w0, w1, div);
+    float z = 0.f;
+    if (h0 < h1 && w0 < w1) {
+        const float* xp = x + pl * g.H * g.W;
+        float sum = 0.f;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) sum += xp[h * g.W + w];
+        z = sum / (float)div;
+    }
+    const float s = r_out[i] / (z + kZEps * (z == 0.f ? 1.f : 0.f));
+    sd[i] = (h0 < h1 && w0 < w1) ? s / (float)div : 0.f;
+}
+
+// one thread per input element: X.grad = sum of sd over the windows that contain it (ascending), R = X * X.grad
+__global__ void avgpool_rule_back_kernel(const float* __restrict__ x, const float* __restrict__ sd, float* __restrict__ r_in,
+                                         long planes, AvgPoolGeom g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)g.H * g.W;
+    if (i >= planes * per) return;
+    const long pl = i / per;
+    const int p = (int)(i - pl * per), h = p / g.W, w = p - h * g.W;
+    // windows with h0 <= h < h0 + kh (h < H: the clips at H + pad and at H never cut an image row out of a window)
+    const int oh_lo = max(0, (h + g.ph - g.kh + g.sh) / g.sh), oh_hi = min(g.OH - 1, (h + g.ph) / g.sh);
+    const int ow_lo = max(0, (w + g.pw - g.kw + g.sw) / g.sw), ow_hi = min(g.OW - 1, (w + g.pw) / g.sw);
+    const float* sp = sd + pl * g.OH * g.OW;
+    float grad = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) grad += sp[oh * g.OW + ow];
+    r_in[i] = x[i] * grad;
+}
+
 }  // namespace lrpx
 
 using namespace lrpx;
@@ -189,6 +247,21 @@ int lrpx_add_rule(const float* x1, const float* x2, const float* r_out, float* r
     hipLaunchKernelGGL(add_rule_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x1, x2, r_out,
                        r1, r2, n);
     return check_launch("add_rule");
+}
+
+int lrpx_avgpool_rule(const float* x, const float* r_out, float* s_ws, float* r_in, long planes, int h, int w, int oh, int ow,
+                      int kh, int kw, int sh, int sw, int ph, int pw, int count_include_pad, int divisor_override, void* stream) {
+    LRPX_REQUIRE(x && r_out && s_ws && r_in && planes > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "avgpool_rule: bad arguments");
+    LRPX_REQUIRE(kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && 2 * ph <= kh && 2 * pw <= kw && divisor_override >= 0,
+                 "avgpool_rule: bad window (kernel %dx%d stride %dx%d padding %dx%d)", kh, kw, sh, sw, ph, pw);
+    // every window must start inside the image or its left padding (what ATen's output-size rule guarantees)
+    LRPX_REQUIRE((long)(oh - 1) * sh < h + ph && (long)(ow - 1) * sw < w + pw, "avgpool_rule: output %dx%d does not fit input %dx%d", oh, ow, h, w);
+    LRPX_REQUIRE(planes * (long)h * w < (1L << 40), "avgpool_rule: tensor too large");
+    const AvgPoolGeom g = {h, w, oh, ow, kh, kw, sh, sw, ph, pw, count_include_pad ? 1 : 0, divisor_override};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(avgpool_rule_s_kernel, dim3((unsigned)ceil_div(planes * oh * ow, 256)), dim3(256), 0, st, x, r_out, s_ws, planes, g);
+    hipLaunchKernelGGL(avgpool_rule_back_kernel, dim3((unsigned)ceil_div(planes * h * w, 256)), dim3(256), 0, st, x, s_ws, r_in, planes, g);
+    return check_launch("avgpool_rule");
 }
 
 int lrpx_max_abs_diff(const float* a, const float* b, long n, float* out_dev, void* stream) {

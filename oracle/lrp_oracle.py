@@ -86,6 +86,41 @@ def maxpool_rule(x, r_out):
     return x * g
 
 
+def avgpool_rule(x, r_out, kernel_size, stride=None, padding=0, ceil_mode=False, count_include_pad=True,
+                 divisor_override=None):
+    """LRPtools/lrp_modules.py:172-195 `Pool2d` on an `nn.AvgPool2d` (clone at :176-177, table entry :327):
+    Z = avgpool(x); S = safe_divide(R, Z); R_in = x * dZ/dx(S).  Written out as explicit window loops (no autograd): every
+    output distributes S / divisor to the inputs of its (clipped) window; divisor = padded window size clipped at H + pad
+    (count_include_pad), the clipped window size, or divisor_override - ATen's avg_pool2d definition.  (The reference's clone
+    copies stride / padding / count_include_pad / ceil_mode only: a module's divisor_override never reaches its rule.)"""
+    kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else kernel_size
+    stride = kernel_size if stride is None else stride
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    n, c, h, w = x.shape
+    oh, ow = r_out.shape[2], r_out.shape[3]
+    z = torch.zeros_like(r_out)
+    wins = []
+    for i in range(oh):
+        for j in range(ow):
+            h0, w0 = i * sh - ph, j * sw - pw
+            h1, w1 = min(h0 + kh, h + ph), min(w0 + kw, w + pw)
+            pool = (h1 - h0) * (w1 - w0)
+            h0, w0, h1, w1 = max(h0, 0), max(w0, 0), min(h1, h), min(w1, w)
+            div = divisor_override or (pool if count_include_pad else (h1 - h0) * (w1 - w0))
+            wins.append((i, j, h0, h1, w0, w1, float(div)))
+            acc = torch.zeros_like(z[:, :, i, j])
+            for hh in range(h0, h1):              # row-major, one addend at a time: the order of ATen's window loop
+                for ww in range(w0, w1):
+                    acc = acc + x[:, :, hh, ww]
+            z[:, :, i, j] = acc / div
+    s = safe_divide(r_out, z)
+    g = torch.zeros_like(x)
+    for i, j, h0, h1, w0, w1, div in wins:
+        g[:, :, h0:h1, w0:w1] += (s[:, :, i, j] / div)[:, :, None, None]
+    return x * g
+
+
 # ----------------------------------------------------------------------------------------------
 # rules of the layers VGG16 never reaches (SURVEY §8(a) row M4; ResNet encoders)
 # ----------------------------------------------------------------------------------------------

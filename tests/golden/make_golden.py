@@ -826,6 +826,61 @@ def gen_toy(out):
     print("toy_resnet.npz: r1 absmax %.4f sum %.4f; r2 - r1 absmax %.4f" % (r1.abs().max(), r1.sum(), (r2 - r1).abs().max()))
 
 
+AVGPOOL_CASES = [   # (name, input shape, AvgPool2d kwargs)
+    ("k2", (2, 5, 8, 6), dict(kernel_size=2, stride=2)),
+    ("k3s2p1", (1, 3, 7, 9), dict(kernel_size=3, stride=2, padding=1)),
+    ("k3s2p1_nopad", (1, 3, 7, 9), dict(kernel_size=3, stride=2, padding=1, count_include_pad=False)),
+    ("k3s2_ceil", (1, 2, 8, 8), dict(kernel_size=3, stride=2, ceil_mode=True)),
+    ("k23_div5", (2, 2, 6, 7), dict(kernel_size=(2, 3), stride=(1, 2), padding=(1, 0), divisor_override=5)),   # (dropped by the reference's clone)
+    ("global7", (2, 4, 7, 7), dict(kernel_size=7)),
+]
+
+
+def avgpool_net(rs, Flatten):
+    """Conv - ReLU - AvgPool2d(2,2) - Conv - ReLU - AvgPool2d(7) - Flatten - Linear: the ResNet-style head the reference's table
+    entry exists for (lrp_modules.py:327), small enough for a fixture"""
+    import collections
+    f32 = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    net = nn.Sequential(collections.OrderedDict([
+        ("conv1", nn.Conv2d(3, 8, 3, padding=1)), ("relu1", nn.ReLU()), ("pool1", nn.AvgPool2d(2, 2)),
+        ("conv2", nn.Conv2d(8, 16, 3, padding=1)), ("relu2", nn.ReLU()), ("pool2", nn.AvgPool2d(7)),
+        ("flat", Flatten()), ("fc", nn.Linear(16, 5))]))
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            m.weight.data = f32(rs.standard_normal(tuple(m.weight.shape)) * 0.2)
+            m.bias.data = f32(rs.standard_normal(tuple(m.bias.shape)) * 0.05)
+    return net.eval()
+
+
+def gen_avgpool(out):
+    """Pool2d.propagate_relevance on nn.AvgPool2d modules (LRPtools/lrp_modules.py:172-195; the table entry :327): rule-level
+    cases (non-overlapping 2x2 incl. an all-zero window, overlapping windows with padding counted or not, ceil_mode,
+    divisor_override, a global pool) and a small Conv / AvgPool / Linear net through the reference's own add_lrp."""
+    from LRPtools import lrp_wrapper, lrp_modules
+    params = lrp_wrapper.SequentialPresetA().lrp_params
+    rs = np.random.RandomState(77)
+    g = {}
+    for name, shape, kw in AVGPOOL_CASES:
+        m = nn.AvgPool2d(**kw)
+        x = torch.from_numpy(rs.standard_normal(shape).astype(np.float32))
+        if name == "k2":
+            x[0, 1, 2:4, 2:4] = 0.0          # an all-zero window: Z == 0 -> safe_divide's 1e-7
+            x[1, 0, 0, 0] = 0.0
+        m.input = (x,)
+        r = torch.from_numpy(rs.standard_normal(tuple(m(x).shape)).astype(np.float32))
+        res = lrp_modules.Pool2d().propagate_relevance(m, None, (r,), 'alpha_beta', params)
+        g[name + "_x"], g[name + "_rout"], g[name + "_rin"] = x.numpy(), r.numpy(), res[0].detach().numpy()
+    import models.resnet as rn
+    net = avgpool_net(np.random.RandomState(78), rn.Flatten)
+    lrp_wrapper.add_lrp(net)
+    x = torch.from_numpy(rs.standard_normal((2, 3, 14, 14)).astype(np.float32))
+    target = torch.from_numpy(rs.standard_normal((2, 5)).astype(np.float32))
+    rn, logits = net.compute_lrp(x.clone(), target=target.clone(), return_output=True)
+    g["net_x"], g["net_target"], g["net_r"], g["net_logits"] = x.numpy(), target.numpy(), rn.numpy(), logits.detach().numpy()
+    np.savez(os.path.join(out, "avgpool.npz"), **g)
+    print("avgpool.npz:", {k: float(np.abs(v).max()) for k, v in g.items() if k.endswith("_rin") or k == "net_r"})
+
+
 def gen_m4(out):
     """The rule classes the VGG16 path never reaches (ResNet encoders): Linear epsilon rule with the
     in-place zero nudge (LRPtools/lrp_modules.py:9-37), BatchNorm2d / BatchNorm1d (:197-246), Dropout (:248-254),
@@ -1058,7 +1113,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,t20_f64,t20_guided,toy,m4,forwardlrp,guided_gradcam,beam")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,t20_f64,t20_guided,toy,m4,avgpool,forwardlrp,guided_gradcam,beam")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -1086,6 +1141,8 @@ def main():
         gen_toy(HERE)
     if "m4" in todo:
         gen_m4(HERE)
+    if "avgpool" in todo:
+        gen_avgpool(HERE)
     if "forwardlrp" in todo:
         gen_forwardlrp(HERE, weights)
     if "guided_gradcam" in todo:

@@ -51,6 +51,40 @@ def test_version_and_pure_host_entry_points():
         _lib.check(_lib.EZERO)
 
 
+def test_release_library_carries_no_experiment_switches():
+    """wrong-result timing experiments must not be able to pose as the product."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("liblrpx.so not built")
+    assert _lib.load().lrpx_build_flags() == b"", "this liblrpx.so is a timing-experiment / profiling build"
+
+
+def _compile_flags_unit(tmp_path, name, flags):
+    import subprocess
+    src = os.path.join(ROOT, "lrp-imagecaptioning-pytorch_amd", "csrc", "lrpx_build_flags.hip")
+    out = str(tmp_path / name)
+    r = subprocess.run(["g++", "-x", "c++", "-shared", "-fPIC", "-o", out, src] + flags, capture_output=True, text=True)
+    return r, out
+
+
+def test_experiment_switches_need_the_experiments_flag_and_show_up(tmp_path):
+    """build_guard.h: -DLRPXH_EXP=.. (and the other wrong-result / profiling switches) alone does not compile; together with
+    -DLRPX_EXPERIMENTS the library names them in lrpx_build_flags(), which the test above (and smoke()) refuse."""
+    for sw in ("-DLRPXH_EXP=1", "-DLRPX_EPI_EXP=2", "-DLRPXB_EXP=1", "-DLRPXD_EXP=8", "-DLRPXH_END_SLEEP=4",
+               "-DLRPXH_START_SKEW=2", "-DLRPX_STAMP"):
+        r, _ = _compile_flags_unit(tmp_path, "refused.so", [sw])
+        assert r.returncode != 0 and "LRPX_EXPERIMENTS" in r.stderr, sw
+    r, so = _compile_flags_unit(tmp_path, "exp.so", ["-DLRPX_EXPERIMENTS", "-DLRPXH_EXP=33", "-DLRPX_EPI_EXP=2"])
+    assert r.returncode == 0, r.stderr
+    f = ctypes.CDLL(so).lrpx_build_flags
+    f.restype = ctypes.c_char_p
+    assert f() == b"LRPX_EXPERIMENTS LRPXH_EXP=33 LRPX_EPI_EXP=2"
+    r, so = _compile_flags_unit(tmp_path, "rel.so", [])
+    assert r.returncode == 0, r.stderr
+    f = ctypes.CDLL(so).lrpx_build_flags
+    f.restype = ctypes.c_char_p
+    assert f() == b""
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liblrpx.so")

@@ -156,3 +156,33 @@ def test_flatten_and_dropout_rules(M):
     bad[1, 3] += 1e-3
     with pytest.raises(AssertionError):                                       # :251
         R.Dropout().propagate_relevance(dr, (bad,), (M("drop_r"),), "alpha_beta", PARAMS)
+
+
+def test_avgpool2d_rule_bit_exact_vs_reference_and_through_add_lrp():
+    """`nn.AvgPool2d` of the reference's dispatch table (LRPtools/lrp_modules.py:327 -> Pool2d :172-195), VERDICT r3 item 9:
+    the rule-level cases of avgpool.npz (the reference's own Pool2d on AvgPool2d modules: 2x2 with an all-zero window, overlapping
+    windows, padding counted or not, ceil_mode, divisor_override, a global pool) bit for bit, and a Conv / AvgPool / Linear net
+    through the generic add_lrp against the reference's add_lrp on the same net."""
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    R = _rules()
+    sys.path.insert(0, GOLDEN)
+    from make_golden import AVGPOOL_CASES, avgpool_net
+    A = np.load(os.path.join(GOLDEN, "avgpool.npz"))
+    for name, shape, kw in AVGPOOL_CASES:
+        m = nn.AvgPool2d(**kw)
+        m.input = (torch.from_numpy(A[name + "_x"]).cuda(),)
+        rule = R.get_lrp_module(m)
+        assert type(rule).__name__ == "Pool2d"
+        out = rule.propagate_relevance(m, None, (torch.from_numpy(A[name + "_rout"]).cuda(),), "alpha_beta", PARAMS)
+        assert len(out) == 1 and tuple(out[0].shape) == shape
+        assert torch.equal(out[0].cpu(), torch.from_numpy(A[name + "_rin"])), (name, rel_err(out[0].cpu(), A[name + "_rin"]))
+    from lrp_amd.LRPtools import lrp_wrapper
+    net = avgpool_net(np.random.RandomState(78), R.resFlatten).cuda()
+    lrp_wrapper.add_lrp(net)
+    r, logits = net.compute_lrp(torch.from_numpy(A["net_x"]).cuda(), target=torch.from_numpy(A["net_target"]).cuda(),
+                                return_output=True)
+    e = rel_err(r.cpu(), A["net_r"])
+    print(f"generic add_lrp, Conv / AvgPool2d / Linear net: {e:.2e}")
+    assert rel_err(logits.cpu(), A["net_logits"]) < 1e-5 and e < 1e-4

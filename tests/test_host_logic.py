@@ -37,9 +37,10 @@ def test_unknown_leaf_raises_value_error_like_reference():
 
 
 def test_dispatch_table_matches_reference():
-    # LRPtools/lrp_modules.py:321-341: every leaf type of the reference's table except AvgPool2d (in no encoder of the
-    # reference), incl. the reference's own resnet.Add / resnet.Flatten classes by name
+    # LRPtools/lrp_modules.py:321-341: every leaf type of the reference's table, incl. the reference's own resnet.Add /
+    # resnet.Flatten classes by name
     table = {nn.Linear(4, 4): "Linear", nn.ReLU(): "ReLU", nn.Conv2d(3, 8, 3): "Conv2d", nn.MaxPool2d(2): "Pool2d",
+             nn.AvgPool2d(2): "Pool2d",
              nn.BatchNorm2d(4): "BatchNorm2d", nn.BatchNorm1d(4): "BatchNorm1d", nn.Dropout(): "Dropout",
              nn.Dropout2d(): "Dropout", lrp_modules.resFlatten(): "Flatten", lrp_modules.resAdd(): "Add"}
     for mod, name in table.items():
@@ -50,7 +51,7 @@ def test_dispatch_table_matches_reference():
     Add.__module__ = "models.resnet"
     assert type(lrp_modules.get_lrp_module(Add())).__name__ == "Add"
     with pytest.raises(ValueError, match="not known"):
-        lrp_modules.get_lrp_module(nn.AvgPool2d(2))
+        lrp_modules.get_lrp_module(nn.AdaptiveAvgPool2d(1))
 
 
 def test_vgg16_structure_matching():

@@ -94,6 +94,23 @@ def test_m4_add_flatten_dropout_rules():
     assert torch.equal(M("drop_rin"), M("drop_r"))                           # Dropout: passes relevance_input (:248-254)
 
 
+def test_avgpool_rule_vs_reference_pool2d():
+    # LRPtools/lrp_modules.py:172-195 on nn.AvgPool2d modules (tests/golden/avgpool.npz, make_golden.py:gen_avgpool): 2x2 with an
+    # all-zero window, overlapping windows with and without counted padding, ceil_mode, divisor_override, a global pool
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden import AVGPOOL_CASES
+    A = np.load(os.path.join(GOLDEN, "avgpool.npz"))
+    for name, shape, kw in AVGPOOL_CASES:
+        x, r_out, want = (torch.from_numpy(A[f"{name}_{k}"]) for k in ("x", "rout", "rin"))
+        assert tuple(x.shape) == shape
+        kw = {k: v for k, v in kw.items() if k != "divisor_override"}      # the reference's clone drops it (lrp_modules.py:176-177)
+        got = O.avgpool_rule(x, r_out, **kw)
+        assert torch.equal(got, want), (name, rel_err(got, want))       # same summation orders as ATen's loops: bit-exact
+    x = torch.from_numpy(A["k2_x"])
+    assert (x[0, 1, 2:4, 2:4] == 0).all() and (torch.from_numpy(A["k2_rin"])[0, 1, 2:4, 2:4] == 0).all()   # Z == 0: 0 * (R / 1e-7)
+
+
 def test_toy_residual_net_through_the_rules():
     # tests/golden/toy_resnet.npz: the reference's add_lrp / compute_lrp on Conv-BN-ReLU, a skip through the explicit Add
     # module, MaxPool, Flatten, Linear (make_golden.py:gen_toy).  The oracle's rule restatements walked by hand in the order
