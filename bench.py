@@ -19,8 +19,9 @@ Other BASELINE configs as optional lines (the headline stays config 2):
     --config 5                 AoA bottom-up, 36x2048 region features, B=32 per GPU, relevance back to the features
 
 Rank 0 prints ONE JSON line.  At N=1 it also carries
-  roofline     : MFMA roofline of the dominant kernel (the relevance conv kernel with the largest total time of the
-                 12 conv launches per step = 30.69 GFLOP per map), timed live with HIP events on the launch stream;
+  roofline     : MFMA roofline of the dominant kernel = the relevance conv kernel NAME with the largest total time over the
+                 12 conv launches of one pass (30.69 GFLOP per map), picked from this run's own per-launch HIP-event times
+                 (on the launch stream); `chain_frac`: the same fraction over all 13 layers; `per_layer`: every layer's;
                  `traffic` is read from the PMC summary named in `traffic_source` (profiles/, separate --pmc passes);
                  `modes`: the same step and chain in every matrix-core mode (0 fp32 MFMA ... 3 fp16+fp6), same process
   sustained    : the same step repeated for >= --sustain seconds (power-limited clocks show here, not in 20 steps)
@@ -49,19 +50,71 @@ GFLOP_PER_MAP = 30.69          # one transposed conv per VGG16 la
 PEAK_FP32_MFMA_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_16BIT_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E
-# The dominant kernel: the relevance step of a 256->256 conv on 56x56 maps (conv3_x) or of a 512->512 conv on 28x28 maps
-# (conv4_x) - the same work; the three conv3 and three conv4 launches are 55 % of the chain, and in the default mode the
-# 28x28 kernel has the largest total time (conv4_1 / conv4_2; conv4_3 is its pooled-input instantiation).  Algorithmic work per launch and map: one transposed 3x3 conv =
-# 2*9*256*256*56*56 = 2*9*512*512*28*28 flop.  The matrix cores execute PRODUCTS[mode] 16-bit MFMA products per fp32 product (operand
-# splits, csrc/conv_f16x3.h / conv_bf16x6.h), so `achieved` counts executed MFMA flop against the 16-bit dense peak;
-# `algorithmic_tflops` is the fp32-equivalent rate.
-DOM_FLOP_PER_MAP = 2.0 * 9 * 256 * 256 * 56 * 56
+# VGG16 cfg 'D' without the last pool: conv layer index of the fused chain -> (name, map size, cin, cout).  The relevance step of
+# layer l is one transposed 3x3 conv: 2*9*cin*cout*hw*hw algorithmic flop per map (the 13 layers sum to 30.69 GFLOP).
+# The matrix cores execute PRODUCTS[mode] 16-bit MFMA products per fp32 product (operand splits, csrc/conv_f16x3.h /
+# conv_bf16x6.h), so `achieved` counts executed MFMA flop against the 16-bit dense peak; `algorithmic_tflops` is the
+# fp32-equivalent rate.
+VGG_CONV = {0: ("conv1_1", 224, 3, 64), 1: ("conv1_2", 224, 64, 64), 3: ("conv2_1", 112, 64, 128), 4: ("conv2_2", 112, 128, 128),
+            6: ("conv3_1", 56, 128, 256), 7: ("conv3_2", 56, 256, 256), 8: ("conv3_3", 56, 256, 256),
+            10: ("conv4_1", 28, 256, 512), 11: ("conv4_2", 28, 512, 512), 12: ("conv4_3", 28, 512, 512),
+            14: ("conv5_1", 14, 512, 512), 15: ("conv5_2", 14, 512, 512), 16: ("conv5_3", 14, 512, 512)}
+POOL_ABOVE = {1, 4, 8, 12}        # the relevance of these layers arrives at the resolution of the pool above them
+EPI_ID = {"EPI_FWD_DUAL": 0, "EPI_REL": 1, "EPI_FIRST": 2, "EPI_PLAIN": 3, "EPI_GUIDED": 4, "EPI_REL_MUL": 5}
+
+
+def layer_flop_per_map(l):
+    _, hw, cin, cout = VGG_CONV[l]
+    return 2.0 * 9 * cin * cout * hw * hw
+
+
+def rel_launcher(l, mode):
+    """the launch function csrc/lrpx_vgg.hip:conv_dispatch picks for the relevance step of conv layer l (default switches)"""
+    _, hw, cin, _ = VGG_CONV[l]
+    n_oc, pooled = cin, l in POOL_ABOVE
+    if l == 0:
+        return "first_layer_mfma_kernel" if mode >= 2 else "first_layer_kernel"
+    if mode == 3:
+        if pooled:
+            return {224: "launch_h8_224_pool", 112: "launch_h8_112_pool", 56: "launch_h8_56w_pool", 28: "launch_h8_28w_pool"}[hw]
+        if n_oc >= 256 and hw in (56, 28, 14):
+            return f"launch_h8_{hw}w_rel"
+        return "launch_h8_112n_rel" if (hw == 112 and n_oc <= 64) else f"launch_h8_{hw}_rel"
+    if mode == 2:
+        if pooled:
+            return f"launch_h3_{hw}_pool"
+        return "launch_h3_112n_rel" if (hw == 112 and n_oc <= 64) else f"launch_h3_{hw}_rel"
+    if mode == 1:
+        return "launch_x6_112n_rel" if (hw == 112 and n_oc <= 64) else f"launch_x6_{hw}_rel"
+    return {224: "launch_conv_224_8_2_2_9_rel", 112: "launch_conv_112_8_2_2_9_rel" if n_oc <= 64 else "launch_conv_112_8_1_4_9_rel",
+            56: "launch_conv_56_16_1_4_9_rel", 28: "launch_conv_28_16_1_4_9_rel", 14: "launch_conv_14_16_1_4_9_rel"}[hw]
+
+
+_INST = {}
+
+
+def kernel_name(launcher):
+    """kernel name as rocprofv3 prints it, read from the explicit instantiations in csrc/conv_inst_*.hip (so that the name in
+    the bench line follows the source, whatever tile shape a layer is built with)"""
+    import glob
+    import re
+    if not launcher.startswith("launch_"):
+        return launcher
+    if not _INST:
+        for f in glob.glob(os.path.join(ROOT, "lrp-imagecaptioning-pytorch_amd", "csrc", "conv_inst_*.hip")):
+            for m in re.finditer(r"int (launch_\w+)\([^)]*\)\s*\{\s*return (launch_conv_cfg|launch_conv_f16x3|launch_conv_bf16x6)<([^>]*)>", open(f).read()):
+                args = [EPI_ID.get(x.strip(), x.strip()) for x in m.group(3).split(",")]
+                kern = {"launch_conv_cfg": "conv_mfma_kernel", "launch_conv_f16x3": "conv_f16x3_kernel", "launch_conv_bf16x6": "conv_bf16x6_kernel"}[m.group(2)]
+                if kern == "conv_f16x3_kernel":
+                    args += ["false"] * (7 - len(args))           # POOL, F8 default to false
+                _INST[m.group(1)] = f"{kern}<{', '.join(str(x) for x in args)}>"
+    return _INST.get(launcher, launcher)
+
+
 MODE_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "bf16x6: exact 3-way bf16 split, 6 products, fp32 accumulate",
              2: "f16x3: per-map power-of-two scaling, 2-way fp16 split, 3 products, fp32 accumulate",
              3: "f16+f6x2: as f16x3, the two cross products (2^-11 of the result) as block-scaled fp6 e2m3 MFMAs "
                 "(v_mfma_scale_f32_32x32x64_f8f6f4, one E8M0 exponent per 16-channel slice; rounds 1-2: fp8 e4m3)"}
-MODE_KERNEL = {0: "conv_mfma_kernel<56,16,1,4,9,REL>", 1: "conv_bf16x6_kernel<56,1,4,true,REL>",
-               2: "conv_f16x3_kernel<56,1,4,true,REL_MUL,false>", 3: "conv_f16x3_kernel<28,1,8,true,REL_MUL,false,true>"}
 # mode 3: one fp16 product + two fp6 products; the fp6 dense peak is four times the fp16 one (MI355X_MICROARCH.md: 32 cycles per
 # 32x32x64 MFMA, measured tools/micro/mfma_f6.hip), so an fp6 flop counts a quarter: `achieved` / `peak` is then (time the matrix
 # cores need at their peaks) / (measured time), as in the other modes.  (Rounds 1-2 ran the cross products in fp8: 2.0.)
@@ -69,12 +122,10 @@ PRODUCTS = {0: 1, 1: 6, 2: 3, 3: 1.5}
 # arithmetic the contractions run in (tensors in HBM are fp32 in every mode; everything outside the convolutions is fp32 VALU)
 MODE_DTYPE = {0: "f32", 1: "bf16x6 split products, f32 accumulate", 2: "f16x3 split products, f32 accumulate",
               3: "f16 + 2 x f6(e2m3, block-scaled) split products, f32 accumulate"}
-# HBM traffic of the dominant kernel per launch: tools/prof_summary.py traffic --json writes this file from the two --pmc
-# passes (FETCH_SIZE / WRITE_SIZE, separate from any tracing); bytes = 2 x FETCH_SIZE raw [gfx950 reports half of wide
-# streaming reads, MI355X_MICROARCH.md §HBM] + WRITE_SIZE, divided by the launches and scaled to the maps of this run
-TRAFFIC_FILES = ["profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
-TRAFFIC_KERNEL = {0: "conv_mfma_kernel<56, 16, 1, 4, 9, 1>", 1: "conv_bf16x6_kernel<56, 1, 4, true, 1>",
-                  2: "conv_f16x3_kernel<56, 1, 4, true, 5, false, false>", 3: "conv_f16x3_kernel<28, 1, 8, true, 5, false, true>"}
+# HBM traffic per launch: tools/prof_summary.py traffic-json writes this file from the two --pmc passes (FETCH_SIZE /
+# WRITE_SIZE, separate from any tracing); bytes = 2 x FETCH_SIZE raw [gfx950 reports half of wide streaming reads,
+# MI355X_MICROARCH.md §HBM; re-calibrated by tools/pmc_calibrate.py] + WRITE_SIZE, divided by the launches and scaled to the maps of this run
+TRAFFIC_FILES = ["profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
 
 
 def host_cores():
@@ -105,10 +156,11 @@ def cpu_baseline(V, T, words):
     img = torch.from_numpy(weights.make_images(0, 1))
     cap = weights.make_captions(1, 1, T, V)[0]
     _, _, t_trace, t_words = RE.explain_words(sd, img, cap, words)
-    per_image = t_trace + t_words * T / len(words)       # trace once per image, word cost pro-rated
+    per_image = t_trace + t_words * T / len(words)       # trace once per image (word cost pro-rated if a subset was asked for)
+    note = "all of them, nothing extrapolated" if len(words) == T else f"scaled to {T} words"
     return {"value": round(T / per_image, 4), "unit": "maps/s", "cores": cores, "kind": "port",
-            "sample": f"1 image, T={T}, V={V}, words {words} explained by oracle/ref_equiv.py "
-                      f"({t_words:.1f} s) + trace {t_trace:.1f} s, scaled to {T} words"}
+            "sample": f"1 image, T={T}, V={V}: trace {t_trace:.1f} s + {len(words)} words explained by oracle/ref_equiv.py in {t_words:.1f} s ({note}); "
+                      "ref_equiv.py against the imported reference on the same image in the build container: profiles/r04_ref_equiv_vs_reference.json"}
 
 
 def launch_ranks(a):
@@ -125,15 +177,15 @@ def launch_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
-def read_traffic(mode, n_maps):
-    """(bytes per launch of the dominant kernel for `n_maps` maps, source file) from the PMC summary under profiles/."""
+def read_traffic(kernel, n_maps):
+    """(bytes per launch of `kernel` for `n_maps` maps, source file) from the PMC summary under profiles/."""
     for rel in TRAFFIC_FILES:
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
         try:
             doc = json.load(open(path))
-            k = doc["kernels"][TRAFFIC_KERNEL[mode]]
+            k = doc["kernels"][kernel]
             per_map = (2.0 * k["fetch_bytes"] + k["write_bytes"]) / k["launches"] / doc["maps_per_launch"]
             return round(per_map * n_maps), rel
         except (KeyError, ValueError, ZeroDivisionError):
@@ -234,7 +286,7 @@ def other_configs(a):
         r = o.get("roofline") or {}
         line = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": n, "maps_per_step": o["config"]["maps_per_step"],
                 "batches_in_flight": o["config"]["batches_in_flight"], "workload": o["config"]["workload"],
-                "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "ms_per_launch") if k in r}}
+                "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "ms_per_launch", "chain_frac") if k in r}}
         if "chain" in r:
             line["roofline"]["chain_ms"] = r["chain"]["ms_per_step"]
         log(f"configs[{key}]: {o['value']:.0f} maps/s, {o['ms_per_step']:.2f} ms/step")
@@ -491,6 +543,11 @@ def run_config(a, dist, rank, world):
             out["roofline"] = roofline(a, lib, eng, state, maps, B, T, mode)
             if a.config == 2 and not guided and not a.no_modes and not a.graph:      # (the sweep switches modes between eager steps)
                 out["roofline"]["modes"] = mode_sweep(lib, engines, streams, one_step, state, B, T, mode)
+                # the same step with three fp16 products per fp32 product (mode 2: <= 1e-6 of max|R| from the exact-split chain):
+                # the figure to quote where the reference's own arithmetic grade is wanted
+                out["value_fp32_grade"] = out["roofline"]["modes"]["2"]["maps_per_s"]
+                out["value_fp32_grade_note"] = ("conv mode 2 (f16x3: every product to 2^-21, fp32 accumulate), same process, 6 timed steps; "
+                                                "`value` runs mode %d: %s" % (mode, MODE_DTYPE[mode]))
         elif world == 1:
             # config 5: no CNN stage; HBM-bound projector / v_proj rules.  Algorithmic bytes per map: read F,
             # write R_feat, read the projected features: 3 x 36 x 2048 x 4 B = 0.9 MB (weights amortised over the batch)
@@ -500,7 +557,7 @@ def run_config(a, dist, rank, world):
                                "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                "traffic": None}
         if world == 1 and a.config == 2 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(V, T, sorted({round(i * (T - 1) / 9) for i in range(10)}))   # 10 words, mean index (T-1)/2
+            out["cpu_baseline"] = cpu_baseline(V, T, list(range(T)))       # every word of one image: nothing extrapolated
         return out
     return None
 
@@ -534,9 +591,8 @@ def roofline(a, lib, eng, state, maps, B, T, mode):
     reps = max(3, min(a.steps, 10))
     # (1) the whole VGG16 relevance chain (12 conv launches + first-layer kernel), HIP events
     c_ms = chain_ms(eng, r_feat, row2img, out, reps)
-    # (2) roofline of the dominant kernel (default mode: the 28x28 relevance conv kernel, 2 launches per pass: conv4_2
-    # with 512 and conv4_1 with 256 output channels), HIP events recorded by the library on the launch
-    # stream around every conv launch of the same chain on the same inputs
+    # (2) per-launch times: HIP events recorded by the library on the launch stream around every conv launch of the same
+    # chain on the same inputs
     per_layer = [0.0] * 17
     lib.lrpx_vgg16_layer_timing(1, None)
     buf = (C.c_float * 17)()
@@ -546,33 +602,54 @@ def roofline(a, lib, eng, state, maps, B, T, mode):
         per_layer = [p + float(v) for p, v in zip(per_layer, buf)]
     lib.lrpx_vgg16_layer_timing(0, None)
     per_layer = [p / reps for p in per_layer]
-    # launches of that kernel NAME per pass: mode 3: the kernel with the largest total time in the serial rocprof summary
-    # is the 28x28 one (conv4_1 with 256 output channels and conv4_2; conv4_3 runs the pooled-input instantiation of the
-    # same template, own name in rocprof): same flop per full launch as the 56x56 layers (2*9*512*512*28*28); mode 2:
-    # conv3_1 / conv3_2 (conv3_3 is the pooled-input variant)
-    dom_layers, dom_w = ([10, 11], [0.5, 1.0]) if mode == 3 else (([6, 7], [0.5, 1.0]) if mode == 2 else ([6, 7, 8], [0.5, 1.0, 1.0]))
-    dom_desc = ("conv4_1/conv4_2 on 28x28 maps" if mode == 3 else
-                ("conv3_1/conv3_2 on 56x56 maps" if mode == 2 else "conv3_1/conv3_2/conv3_3 on 56x56 maps"))
-    dom_ms = sum(per_layer[l] for l in dom_layers) / len(dom_layers)          # average launch of that kernel
-    flop = DOM_FLOP_PER_MAP * B * T * sum(dom_w) / len(dom_w)                 # average algorithmic flop / launch
+    # The dominant kernel = the kernel NAME with the largest total time over the launches of one pass (what a rocprofv3 --stats
+    # summary of the serial step ranks first among the chain's kernels), chosen from THIS run's per-layer times, not hard-coded.
+    peak = PEAK_FP32_MFMA_TF if mode == 0 else PEAK_16BIT_MFMA_TF
+    n = B * T
+    groups, table = {}, []
+    for l in sorted(VGG_CONV):
+        if per_layer[l] <= 0:
+            continue
+        name = kernel_name(rel_launcher(l, mode))
+        fl = layer_flop_per_map(l) * n
+        alg_l = fl / per_layer[l] / 1e9
+        g = groups.setdefault(name, {"ms": 0.0, "flop": 0.0, "layers": []})
+        g["ms"] += per_layer[l]; g["flop"] += fl; g["layers"].append(VGG_CONV[l][0])
+        row = {"layer": VGG_CONV[l][0], "kernel": name, "ms": round(per_layer[l], 4), "algorithmic_tflops": round(alg_l, 1),
+               "frac": round(PRODUCTS[mode] * alg_l / peak, 4)}
+        if l == 0:          # the 3-channel first layer: 0.3 % of the flop, bound by reading S (64 channels x 224 x 224 fp32 per map)
+            gbs = 224 * 224 * 64 * 4.0 * n / per_layer[l] / 1e6
+            row.update({"bound": "hbm", "algorithmic_gbs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        table.append(row)
+    conv_groups = {k: v for k, v in groups.items() if not k.startswith("first_layer")}
+    dom_name = max(conv_groups, key=lambda k: conv_groups[k]["ms"])
+    dom = conv_groups[dom_name]
+    dom_ms = dom["ms"] / len(dom["layers"])                                   # average launch of that kernel
+    flop = dom["flop"] / len(dom["layers"])                                   # average algorithmic flop / launch
     alg = flop / dom_ms / 1e9                                                 # TFLOP/s, fp32-equivalent
     exe = PRODUCTS[mode] * alg
-    peak = PEAK_FP32_MFMA_TF if mode == 0 else PEAK_16BIT_MFMA_TF
-    traffic, src = read_traffic(mode, B * T)
+    traffic, src = read_traffic(dom_name, n)
+    sum_ms = sum(per_layer)
+    chain_alg = GFLOP_PER_MAP * n / sum_ms                                    # all 13 layers' flop over all 13 launches' time
     return {
-        "bound": "mfma", "kernel": MODE_KERNEL[mode] + f" (relevance step of {dom_desc}, {B * T} maps per launch, {len(dom_layers)} launches per step)",
+        "bound": "mfma", "kernel": dom_name,
+        "kernel_note": f"relevance step of {' / '.join(dom['layers'])}: {n} maps per launch, {len(dom['layers'])} launch(es) per step; the "
+                       f"kernel name with the largest total time in this run's chain ({dom['ms']:.3f} of {sum_ms:.3f} ms)",
         "achieved": round(exe, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(exe / peak, 4),
         "frac_algorithmic": round(alg / peak, 4), "mfma_dtype": MODE_NAME[mode],
         "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
         "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,
         "traffic": traffic, "traffic_source": src,
+        "chain_frac": round(PRODUCTS[mode] * chain_alg / peak, 4),
+        "chain_frac_note": "sum of the 13 layers' algorithmic flop / sum of their launch times (HIP events per launch), same accounting as frac",
+        "per_layer": table,
         "accounting": ("executed matrix flop = algorithmic x products; mode 3 executes 1 fp16 + 2 fp6 products per fp32 "
                        "product and an fp6 flop counts 1/4 (fp6 dense peak = 4 x fp16 peak; the path's roof is 2500 / 1.5 = 1667 "
                        "algorithmic TFLOP/s, 1250 with the fp8 cross products of rounds 1-2), so achieved/peak = matrix "
                        "time at peak / measured time; frac_algorithmic = fp32-equivalent flop against the same peak") if mode == 3 else
                       "executed matrix flop = algorithmic x products; frac_algorithmic = fp32-equivalent flop against the same peak",
-        "chain": {"ms_per_step": round(c_ms, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * B * T,
-                  "algorithmic_tflops": round(GFLOP_PER_MAP * B * T / c_ms, 1),
+        "chain": {"ms_per_step": round(c_ms, 3), "sum_of_launches_ms": round(sum_ms, 3), "flop_per_step": GFLOP_PER_MAP * 1e9 * n,
+                  "algorithmic_tflops": round(GFLOP_PER_MAP * n / c_ms, 1),
                   "conv_ms_by_layer": {str(l): round(v, 3) for l, v in enumerate(per_layer) if v > 0}}}
 
 

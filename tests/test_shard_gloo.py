@@ -44,13 +44,26 @@ def _fake_explain_lens(images, captions, lens):
     return maps.expand(-1, -1, 4, 4).contiguous(), rw
 
 
-def _worker(rank, world, port, n_img, out, lens=None):
+def _worker(rank, world, port, n_img, out, lens=None, loader=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.Generator().manual_seed(0)
     images = torch.randn(n_img, 3, 8, 8, generator=g)
     caps = torch.randint(1, 50, (n_img, 5 if lens is None else max(lens) + 1), generator=g)
-    if lens is None:
+    if loader:
+        # per-rank loader: the rank asks for its block only, once, and never sees the global batch
+        asked = []
+
+        def load(lo, hi):
+            asked.append((lo, hi))
+            return images[lo:hi].clone(), caps[lo:hi].clone()
+        if lens is None:
+            maps, rw = shard.explain_sharded(_fake_explain, load, gather=True, n_items=n_img)
+            assert asked == [shard.shard_bounds(n_img, world, rank)]
+        else:
+            maps, rw = shard.explain_sharded(_fake_explain_lens, load, gather=True, lens=lens)
+            assert asked == [shard.balanced_bounds(lens, world)[rank]]
+    elif lens is None:
         maps, rw = shard.explain_sharded(_fake_explain, images, caps, gather=True)
     else:
         seen = []
@@ -107,3 +120,23 @@ def test_two_ranks_gloo_unequal_caption_lengths():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok_m and ok_w and shape[0] == len(lens)
+
+
+@pytest.mark.parametrize("lens", [None, [20, 20, 20, 3, 2, 4, 3, 2]])
+def test_two_ranks_gloo_per_rank_loader(lens):
+    """`explain_sharded(fn, loader, n_items=...)` - every rank asks its loader for its own block [lo, hi)
+    only (by count, or by cost when caption lengths are given) and rank 0 still gets the whole batch in input order"""
+    n_img = 5 if lens is None else len(lens)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_img, q, lens, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok_m, ok_w, shape = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok_m and ok_w and shape[0] == n_img
