@@ -495,7 +495,8 @@ def run_config(a, dist, rank, world):
     events = [ev0]
     dt, outs = timed(a.steps, events)
     maps = outs[0]
-    ops.check_relevance(maps, finite=True, nonzero=True)      # the reference's asserts, outside the timed region
+    if not lib.lrpx_build_flags():                            # (a timing-experiment build computes garbage on purpose: tools/ab_chain.sh)
+        ops.check_relevance(maps, finite=True, nonzero=True)  # the reference's asserts, outside the timed region
     # step completions by HIP events; with n_pipe batches in flight completions come in bursts, so the per-step time is
     # taken over windows of n_pipe consecutive completions: (end[i] - end[i - n_pipe]) / n_pipe, median over the region
     ends = [0.0] + [ev0.elapsed_time(e) for e in events[1:]]

@@ -117,6 +117,10 @@ typedef struct lrpx_conv_desc {
                                  image (the g words of a caption): their tiles of the same image rows are scheduled next to
                                  each other on one XCD, so the per-image multiplicand `x` is fetched from HBM once, not g
                                  times.  0 / 1: plain order.  Needs n_maps %% g == 0 and map-aligned tiles (hw >= 56) */
+    int blocked;              /* bit 0 (1): `in`, bit 1 (2): `x`, bit 2 (4): the output are in the BLOCKED layout (lrpx_nhwc_to_blocked
+                                 below): [16-channel chunk][32-pixel block][4-channel part][pixel][4] - `in` / out: ONE block set over
+                                 all n_maps * pixels, `x`: one block set per image.  f16x3 = 2 with REL_MUL (the relevance chain of conv
+                                 mode 3) REQUIRES 7; its 224 x 224 kernel 1 (x and the output stay NHWC); every other kernel 0 */
 } lrpx_conv_desc;
 /* 3x3/pad-1 convolution (taps=9, square hw x hw maps) or dense GEMM (taps=1) on the fp32 MFMA with
  * the fused epilogues of the relevance rules.  Replaces F.conv2d / conv backward inside
@@ -124,6 +128,13 @@ typedef struct lrpx_conv_desc {
 int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream);
 
 /* ---- elementwise / layout kernels -------------------------------------------------------------- */
+/* NHWC <-> BLOCKED (csrc/blocked.h): n_groups tensors of pix_per_group pixels x c channels (c %% 16 == 0), each its own block set
+ * of lrpx_blocked_floats(pix_per_group, c) floats: element (pixel p, channel ch) at (ch / 16) * CS + (p / 32) * 512 + ((ch % 16) / 4)
+ * * 128 + (p % 32) * 4 + ch % 4, CS = ceil(pix / 32) * 512.  An S tensor of the mode-3 chain is ONE group of n_maps * pixels; the
+ * per-image multiplicands are n_img groups. */
+size_t lrpx_blocked_floats(long n_pix, int c);
+int lrpx_nhwc_to_blocked(const float* src, float* dst, long n_groups, int pix_per_group, int c, void* stream);
+int lrpx_blocked_to_nhwc(const float* src, float* dst, long n_groups, int pix_per_group, int c, void* stream);
 /* (n,c,h,w) -> [n*h*w][c_pad] with zero padding channels; and back (first c of c_src channels) */
 int lrpx_nchw_to_nhwc(const float* src, float* dst, int n, int c, int hw_pix, int c_pad, void* stream);
 int lrpx_nhwc_to_nchw(const float* src, float* dst, int n, int c, int hw_pix, int c_src, void* stream);

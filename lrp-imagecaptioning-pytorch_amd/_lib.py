@@ -63,7 +63,7 @@ class ConvDesc(C.Structure):
                 ("bias", _f), ("x", _f), ("u", _f), ("zdiv", _f), ("map2img", _f),
                 ("out0", _f), ("out1", _f),
                 ("f16x3", _i), ("out_chunk", _i), ("in_amax", _f), ("out1_amax", _f), ("out0_amax", _f), ("pool_am", _f),
-                ("tile_group", _i)]
+                ("tile_group", _i), ("blocked", _i)]
 
 
 class VggOpts(C.Structure):
@@ -76,6 +76,9 @@ SIGNATURES = {
     "lrpx_version": (_i, []),
     "lrpx_last_error_string": (C.c_char_p, []),
     "lrpx_build_flags": (C.c_char_p, []),
+    "lrpx_blocked_floats": (_sz, [_l, _i]),
+    "lrpx_nhwc_to_blocked": (_i, [_f, _f, _l, _i, _i, _f]),
+    "lrpx_blocked_to_nhwc": (_i, [_f, _f, _l, _i, _i, _f]),
     "lrpx_packed_floats": (_sz, [_i, _i, _i, _i]),
     "lrpx_pack_weights": (_i, [_f, _i, _i, _i, _i, _i, _f, _f]),
     "lrpx_packed_bf16x3_bytes": (_sz, [_i, _i, _i]),
@@ -194,6 +197,8 @@ def load():
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if not hasattr(lib, name) and os.environ.get("LRPX_LIB_PATH"):
+            continue          # (A/B against an OLDER build of the ABI through LRPX_LIB_PATH: entry points it predates stay unbound)
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     _lib = lib

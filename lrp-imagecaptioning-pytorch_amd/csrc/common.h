@@ -43,6 +43,8 @@ int maxpool_relevance_amax(const float* x, const float* r_out, const float* zdiv
                            hipStream_t stream);
 int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c, int stab,
                      unsigned* amax, hipStream_t stream);
+int divide_stab_blocked(const float* r, const float* z, const int32_t* map2img, float* s_blk, int n_maps, int pix, int c,
+                        unsigned* amax, hipStream_t stream);
 
 // max|x| over a flat tensor, atomically max-ed into *out as float bits (lrpx_core.hip)
 int amax_flat(const float* x, long n, unsigned* out, hipStream_t stream);
@@ -84,7 +86,6 @@ struct Switches {
     int fwd_wide;        // LRPX_FWD_WIDE (bit mask, default 0): 8-wave forward kernels for 112 (1), 56 (2), 28 (4), K-split 14 (8)
     int conv11_f16;      // LRPX_CONV11_F16 (default 1): conv1_1 of the forward trace on the f16x3 kernel; 0 = fp32 MFMA kernel
     int first_valu;      // LRPX_FIRST_VALU: first-layer rule on the VALU kernel (and S from conv1_2 in 16-channel chunks)
-    int pool28;          // LRPX_POOL28 (default 1): conv4_3 unpools while staging; 0 = scatter kernel + plain 28x28 kernel
     int s21_nhwc;        // LRPX_S21_NHWC: S between conv2_2 and conv2_1 as NHWC instead of 16-channel chunks
     int guided_poolbwd;  // LRPX_GUIDED_POOLBWD: image-gradient chain with pool-backward kernels
     int dense_wide;      // LRPX_DENSE_WIDE (default 0): 256-row 8-wave tiles for the many-row dense f16x3 GEMM (1), 128-row tiles (0)

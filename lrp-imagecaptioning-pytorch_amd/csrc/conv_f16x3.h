@@ -19,6 +19,7 @@
 // image-row wraps (conflict-free ds_read_b128).
 #pragma once
 #include "conv_mfma.h"
+#include "blocked.h"
 
 namespace lrpx {
 
@@ -317,16 +318,22 @@ __host__ __device__ __forceinline__ unsigned fp6_e2m3_encode(float v) {
     return sgn | (unsigned)c;
 }
 
+// lane's channel within its 32-channel block for the ROW-PERMUTED weight pack of the mode-3 relevance kernels (pack_weights_f16f8_kernel,
+// BWD_POS): fragment row / column rho carries channel 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3)
+__device__ __forceinline__ int perm_row_channel(const int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); }
+
 // REL_MUL / GUIDED epilogue of the MAP-ALIGNED kernels (56 / 112 / 224: the workgroup tile lies inside one map) with scalar-base
 // addressing: element (tile j, register e) of a lane sits at  X[(img P + p0 + wm 224 + 32 j + dq(e)) ncol + ocb 32] + (4 lh ncol + li) -
 // ONE wave-uniform 64-bit base per tensor plus a 32-bit byte offset (uniform element part + the lane's part: one v_add_u32) - so every
 // access is `global_load / global_store_dword v, v_off, s[base]`: no 64-bit vector add per access (the generic dword epilogue: 224
 // v_lshl_add_u64 per wave) and half the address bytes on the way to the texture unit.  Same arithmetic, same order: bit-identical.
-template <int HW, int EPI, bool F8>
+template <int HW, int EPI, bool F8, bool PERM = false>
 __device__ __forceinline__ void epi_rel_mul_al(const ConvArgs& a, f32x16 (&acc)[7], const int wm, const int ocb, const int lane,
                                                const long g0, const long total_pix, unsigned* __restrict__ oamax, const float inv_w,
                                                const unsigned* __restrict__ in_amax) {
-    const int li = lane & 31, lh = lane >> 5;
+    // PERM: the weights come from the row-permuted pack (the B-fragment column of lane l holds channel perm_row_channel(l % 32) of the
+    // block): the lane's channel, nothing else, changes - the same 128-byte lines per instruction
+    const int li = PERM ? perm_row_channel(lane & 31) : (lane & 31), lh = lane >> 5;
     const int ncol = a.oc_split;
     const int oc = ocb * 32 + li;
     if (oc >= ncol) return;                                     // (padding columns of the last channel block)
@@ -409,107 +416,143 @@ __device__ __forceinline__ void epi_fwd_dual_al(const ConvArgs& a, f32x16 (&acc)
     }
 }
 
-// REL_MUL / GUIDED epilogue for TRANSPOSED accumulators (LRPXH_TR): the MFMAs were issued with the weights as the A operand and the
-// pixels as the B operand - the same fragments, the arguments swapped - so the result tile is channels x pixels: a lane owns ONE
-// pixel (tile pixel lane % 32) and 16 channels, 4 lh + 8 k + (0..3), k = 0..3: four float4 per tile straight from the accumulator
-// registers - no LDS transposition, 4 loads + 4 stores of 16 bytes per lane and tile (the dword epilogue: 16 + 16 of 4 bytes), and
-// everything per pixel (map, image, operand scale, the pixel's address) is per LANE: one value, no per-element selects.
-template <int HW, bool AL, int EPI, bool F8>
-__device__ __forceinline__ void epi_rel_mul_t(const ConvArgs& a, f32x16 (&acc)[7], const int wm, const int ocb, const int lane,
-                                              const long g0, const long total_pix, unsigned* __restrict__ oamax,
-                                              const int* __restrict__ tab, const float inv_w, const unsigned* __restrict__ in_amax) {
+// REL_MUL epilogue of the mode-3 relevance kernels (BLK): TRANSPOSED accumulators and the BLOCKED layout (blocked.h).  The MFMAs were
+// issued with the weights as the A operand and the pixels as the B operand - the same fragments, the arguments swapped - so the
+// result tile is channels x pixels: a lane owns ONE pixel (tile pixel lane % 32) and, with the weight rows permuted at pack time
+// (pack_weights_f16f8_kernel), the 16 CONTIGUOUS channels 32 ocb + 16 lh + e, e = 0..15: one 16-channel slice.  Multiplicand and
+// output are blocked, so part k (4 channels) of the 32 pixels of a tile is one 512-byte run per lane half: 4 float4 loads + 4 float4
+// stores per lane and tile, each wave instruction 8 whole 128-byte lines, nothing through LDS (the dword epilogue: 16 + 16 accesses
+// of 4 bytes; the LDS-transposed float4 epilogue: the same 4 + 4 plus 16 ds_write + 4 ds_read per tile; the transposed result in
+// NHWC - round 3's LRPXH_TR experiment - touched 32 lines per instruction and lost 12 % of the chain).  Arithmetic and its order are
+// those of epi_rel_mul_al / epi_rel_mul_wide: out = x * (acc * 2^-kA 2^-kW), per-map maxima from the stored values.
+template <int HW, bool AL, bool F8>
+__device__ __forceinline__ void epi_rel_mul_blk(const ConvArgs& a, f32x16 (&acc)[7], const int wm, const int ocb, const int lane,
+                                                const long g0, const long total_pix, unsigned* __restrict__ oamax,
+                                                const int* __restrict__ tab, const float inv_w, const unsigned* __restrict__ in_amax) {
     const int li = lane & 31, lh = lane >> 5;
     const int ncol = a.oc_split;
-    const int oc0 = ocb * 32 + 4 * lh;                  // the lane's channels: oc0 + 8 k + (0..3)
-    const float* __restrict__ X = a.X;
-    float* __restrict__ O = a.out1 ? a.out1 : a.out0;
-    const int ch = a.out_chunk;
-    const int ostr = ch > 0 ? ch : ncol;
+    const int chunk = 2 * ocb + lh;                     // the lane's 16-channel slice
+    const bool col_ok = chunk * 16 < ncol;
     const unsigned P = (unsigned)a.pix_per_map;
     const int nmax = a.n_maps - 1;
-    const long pix0 = g0 * HW;
-    // per tile j: the lane's pixel - global index gp, X row xrow (elements), factor f = 2^-kA(map) * 2^-kW, second-map flag
-    auto pixel = [&](const int j, long& gp, long& xrow, float& f, bool& second, unsigned& n0) {
-        const unsigned q0t = (unsigned)(wm * 224 + 32 * j);
-        const unsigned rr = q0t / (unsigned)HW, c0 = q0t - rr * HW;
-        const unsigned g = (unsigned)g0 + rr;
-        n0 = g / (unsigned)HW;
-        const int p = (int)((g - n0 * HW) * HW + c0) + li;
-        gp = pix0 + q0t + li;
-        if constexpr (AL) {
-            const long img = a.map2img ? a.map2img[min((int)n0, nmax)] : (long)n0;
-            second = false;
-            xrow = (img * P + p) * (long)ncol;
-            f = exp2i(-split_scale_exp<F8>(in_amax[min((int)n0, nmax)])) * inv_w;
-        } else {
-            second = p >= (int)P;
-            const long img = tab[(wm * 7 + j) * 4 + (second ? 3 : 2)];
-            xrow = (img * P + (second ? p - (int)P : p)) * (long)ncol;
-            f = __builtin_bit_cast(float, tab[(wm * 7 + j) * 4 + (second ? 1 : 0)]) * inv_w;
-        }
+    const long cs_o = blk_chunk_stride(total_pix), cs_x = blk_chunk_stride(P);
+    const long gq0 = g0 * HW + wm * 224;                // global pixel of the wave's first tile pixel: a multiple of 32
+    // tile j, part k of the lane: Op + j * 512 + k * 128 floats (compile-time offsets from one pointer)
+    float* __restrict__ Op = (a.out1 ? a.out1 : a.out0) + (long)chunk * cs_o + ((gq0 >> 5) << 9) + li * 4;
+    const float* __restrict__ X = a.X;
+    const long ximg = (long)(ncol >> 4) * cs_x;         // floats of one image's multiplicand
+    auto store4 = [&](float* op, const f32x4 r) {
+#if LRPX_EPI_EXP & 2
+        if (r[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(op) = r;
+#elif LRPXH_NT_STORE & 1
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(op));
+#else
+        *reinterpret_cast<f32x4*>(op) = r;
+#endif
     };
-    constexpr int RING = AL ? 7 : 4;
-    f32x4 xv[RING][4];
-    auto load_x = [&](const int j) {
-        long gp, xrow; float f; bool second; unsigned n0;
-        pixel(j, gp, xrow, f, second, n0);
+    if constexpr (AL) {
+        // the workgroup tile lies inside one map: one image, one operand scale, and the tile's first pixel-in-map is a multiple of 32
+        const unsigned n = (unsigned)g0 / (unsigned)HW;
+        const unsigned p0 = ((unsigned)g0 - n * HW) * HW + wm * 224;
+        const long img = a.map2img ? a.map2img[min((int)n, nmax)] : (long)n;
+        const float f = exp2i(-split_scale_exp<F8>(in_amax[min((int)n, nmax)])) * inv_w;
+        const float* __restrict__ Xp = X + img * ximg + (long)chunk * cs_x + ((long)(p0 >> 5) << 9) + li * 4;
+        f32x4 xv[7][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int oc = oc0 + 8 * k;
-            const bool ok = oc < ncol && (AL || gp < total_pix);
-            xv[j % RING][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok && !(LRPX_EPI_EXP & 1)) xv[j % RING][k] = *reinterpret_cast<const f32x4*>(X + xrow + oc);
-        }
-    };
+        for (int j = 0; j < 7; ++j)
 #pragma unroll
-    for (int j = 0; j < (AL ? 7 : RING - 1); ++j) load_x(j);
-    float m_al = 0.f;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        if constexpr (!AL) { if (j + RING - 1 < 7) load_x(j + RING - 1); }
-        long gp, xrow; float f; bool second; unsigned n0;
-        pixel(j, gp, xrow, f, second, n0);
+            for (int k = 0; k < 4; ++k) {
+                xv[j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (col_ok && !(LRPX_EPI_EXP & 1)) xv[j][k] = *reinterpret_cast<const f32x4*>(Xp + j * 512 + k * 128);
+            }
         float m = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int oc = oc0 + 8 * k;
-            const f32x4 xk = xv[j % RING][k];
-            const f32x4 v = f32x4{acc[j][4 * k] * f, acc[j][4 * k + 1] * f, acc[j][4 * k + 2] * f, acc[j][4 * k + 3] * f};
-            f32x4 r;
-            if constexpr (EPI == EPI_GUIDED) {     // ReLU hook of the layer below (a.relu == 2: the plain autograd mask)
+        for (int j = 0; j < 7; ++j) {
+            f32x4 r[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) r[c] = (xk[c] > 0.f && (a.relu == 2 || v[c] > 0.f)) ? v[c] : 0.f;
-            } else {
-                r = v * xk;
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float v = acc[j][4 * k + c] * f; r[k][c] = xv[j][k][c] * v; }
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(r[k][0]), fabsf(r[k][1])), fmaxf(fabsf(r[k][2]), fabsf(r[k][3]))));
             }
-            if (oc < ncol && (AL || gp < total_pix)) {
-                const long obase = ch > 0 ? (long)(oc / ch) * total_pix * ch + (oc % ch) : (long)oc;
-                float* op = O + gp * (long)ostr + obase;
-#if LRPX_EPI_EXP & 2
-                if (r[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(op) = r;
-#elif LRPXH_NT_STORE & 1
-                __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(op));
-#else
-                *reinterpret_cast<f32x4*>(op) = r;
+            if (col_ok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store4(Op + j * 512 + k * 128, r[k]);
+            }
+        }
+        if (!col_ok) m = 0.f;
+        if (oamax) {
+            m = wave_max(m);
+            if (lane == 0 && (int)n <= nmax) amax_update(&oamax[n], m);
+        }
+    } else {
+        // map-straddling tiles (28 x 28 / 14 x 14): a 32-pixel accumulator tile is shorter than a map - at most ONE map boundary inside
+        // it, so a lane's pixel belongs to the map of the tile's first pixel or to the next one (scales and images of both from the
+        // workgroup's table); its pixel-in-map is per lane, the multiplicand address with it (blocks of 32 pixels per image)
+        const unsigned n_first = (unsigned)g0 / (unsigned)HW;
+        auto pixel = [&](const int j, long& gp, long& xoff, float& f, int& kmap) {
+            const unsigned q0t = (unsigned)(wm * 224 + 32 * j);
+            const unsigned rr = q0t / (unsigned)HW, c0 = q0t - rr * HW;
+            const unsigned g = (unsigned)g0 + rr;
+            const unsigned n0 = g / (unsigned)HW;
+            const int p = (int)((g - n0 * HW) * HW + c0) + li;
+            const bool second = p >= (int)P;
+            const int pp = second ? p - (int)P : p;
+            const long img = tab[(wm * 7 + j) * 4 + (second ? 3 : 2)];
+            gp = gq0 + 32 * j + li;
+            xoff = img * ximg + (long)chunk * cs_x + blk_pix_off(pp);
+            f = __builtin_bit_cast(float, tab[(wm * 7 + j) * 4 + (second ? 1 : 0)]) * inv_w;
+            kmap = (int)(n0 - n_first) + (second ? 1 : 0);         // 0 .. 2: the 224 pixels of a wave touch at most three maps
+        };
+#ifndef LRPXH_BLK_RING
+#define LRPXH_BLK_RING 3          // multiplicand tiles in flight in the map-straddling epilogue (7: all loads before the first store)
 #endif
-                m = fmaxf(m, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
+        constexpr int RING = LRPXH_BLK_RING;
+        f32x4 xv[RING][4];
+        auto load_x = [&](const int j) {
+            long gp, xoff; float f; int kmap;
+            pixel(j, gp, xoff, f, kmap);
+            const bool ok = col_ok && gp < total_pix;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                xv[j % RING][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok && !(LRPX_EPI_EXP & 1)) xv[j % RING][k] = *reinterpret_cast<const f32x4*>(X + xoff + k * 128);
             }
-        }
-        if (oamax) {
-            if constexpr (AL) {
-                m_al = fmaxf(m_al, m);
+        };
+#pragma unroll
+        for (int j = 0; j < RING - 1; ++j) load_x(j);
+        // per-map maxima in registers until the last tile (amax_update reads the word first, and a wait for that read is a wait for
+        // every store issued before it)
+        float mm0 = 0.f, mm1 = 0.f, mm2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            if (j + RING - 1 < 7) load_x(j + RING - 1);
+            long gp, xoff; float f; int kmap;
+            pixel(j, gp, xoff, f, kmap);
+            const bool ok = col_ok && gp < total_pix;
+            float m = 0.f;
+            f32x4 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float v = acc[j][4 * k + c] * f; r[k][c] = xv[j % RING][k][c] * v; }
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(r[k][0]), fabsf(r[k][1])), fmaxf(fabsf(r[k][2]), fabsf(r[k][3]))));
+            }
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store4(Op + j * 512 + k * 128, r[k]);
             } else {
-                const float m0 = wave_max(second ? 0.f : m), m1 = wave_max(second ? m : 0.f);
-                if (lane == 0 && (int)n0 <= nmax) amax_update(&oamax[n0], m0);
-                if (lane == 0 && (int)n0 + 1 <= nmax) amax_update(&oamax[n0 + 1], m1);
+                m = 0.f;
             }
+            mm0 = fmaxf(mm0, kmap == 0 ? m : 0.f);
+            mm1 = fmaxf(mm1, kmap == 1 ? m : 0.f);
+            mm2 = fmaxf(mm2, kmap == 2 ? m : 0.f);
         }
-    }
-    if constexpr (AL) {
         if (oamax) {
-            m_al = wave_max(m_al);
-            const unsigned n_first = (unsigned)g0 / (unsigned)HW;
-            if (lane == 0 && (int)n_first <= nmax) amax_update(&oamax[n_first], m_al);
+            mm0 = wave_max(mm0); mm1 = wave_max(mm1); mm2 = wave_max(mm2);
+            if (lane == 0 && (int)n_first <= nmax) amax_update(&oamax[n_first], mm0);
+            if (lane == 0 && (int)n_first + 1 <= nmax) amax_update(&oamax[n_first + 1], mm1);
+            if (lane == 0 && (int)n_first + 2 <= nmax) amax_update(&oamax[n_first + 2], mm2);
         }
     }
 }
@@ -552,14 +595,13 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // c = 0..15, all divided by the slice's block scale 2^s (24 B) | E8M0 byte s - 11 + 127 (dword at byte 60; byte 56 stays clear so that the 8 + 4 byte reads do not fuse into a slower ds_read_b96) | pad.  A staging item is one
     // pixel's whole 16-channel slice (4 float4): the block maximum and v_cvt_scalef32_pk32_fp6_f16 need the 16 values in one lane.
     constexpr bool X6 = F8 && (LRPXH_XP6 != 0);
-#ifndef LRPXH_TR
-#define LRPXH_TR 0
-#endif
-    // TR (experiment, off): the relevance kernels accumulate channels x pixels (the arguments of every MFMA swapped): see epi_rel_mul_t.
-    // Measured (same box, chain of 320 maps): 17.7 -> 19.9 ms (conv1_2 +35 %, the 56x56 layers +15 %, 28x28 / 14x14 +3 %): a float4
-    // instruction of the transposed layout touches 32 cache lines (32-byte pieces of 32 pixels) where the dword and the LDS-transposed
-    // float4 epilogues touch 2 and 8 WHOLE lines - the epilogue costs by lines touched per instruction, not by instructions.
-    constexpr bool TR = X6 && (LRPXH_TR != 0) && (EPI == EPI_REL_MUL || EPI == EPI_GUIDED);
+    // BLK: the mode-3 relevance kernels (REL_MUL) read S and the multiplicand and write S in the BLOCKED layout (blocked.h) and
+    // accumulate channels x pixels (TR: the arguments of every MFMA swapped, weight rows permuted at pack time): see epi_rel_mul_blk.
+    // conv1_2 (HW == 224, pooled fp32 input, BLOCKED) keeps the plain accumulators and its NHWC multiplicand / 32-channel-chunk output:
+    // its consumer, the first-layer kernel, walks 34-pixel halo rows, and 32-pixel blocks cost it 1.4x the lines (0.98 -> 1.42 ms)
+    // for the 3 % the transposed epilogue gave conv1_2.
+    constexpr bool BLK = X6 && (EPI == EPI_REL_MUL);
+    constexpr bool TR = BLK && (HW != 224);
     constexpr int NV = X6 ? 4 : 1;                     // float4 loads per staging item
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
@@ -794,6 +836,17 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         const bool ok = (tr < RI - rem_c) && (s_c + th < C::NSLOT) && (y >= 0) && (y < H);
         return ok ? et + (unsigned)(s_c * W + rem_c / SEG) * in_pix_stride_ : (unsigned)W * in_pix_stride_;
     };
+    // BLK: the same item as a pixel index relative to the row above the tile's first (LDS row 0); nothing to load: the tile's first pixel
+    auto item_p = [&](const int u) -> int {
+        constexpr int RPSv = RPS, SPRv = SPR;
+        const int s_c = RPSv == 2 ? 2 * u : u / SPRv;
+        const int rem_c = RPSv == 2 ? 0 : (u % SPRv) * NT;
+        const int tr = trem_c, th = RPSv == 2 ? thalf_c : 0;
+        const int gt = gthr_c;
+        const int y = y_al - 1 + s_c + th;
+        const bool ok = (tr < RI - rem_c) && (s_c + th < C::NSLOT) && (y >= 0) && (y < H);
+        return ok ? gt + (s_c * W + rem_c / SEG) : W;
+    };
     // POOL: stage at LOW resolution - one item = 4 channels of one pooled pixel, loaded and split once, then written
     // (or zero) to the 4 pixels of its window: 4x fewer loads and splits than per-pixel staging.
     //   map-aligned tiles: pooled rows y_al/2 - 1 .. y_al/2 + R/2 (the first / last only reach the tile's halo row);
@@ -873,14 +926,21 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // a wave's time on address arithmetic (s_memtime stamps).  The base is the row ABOVE the tile's first row (LDS row 0),
     // so offsets are never negative; an item with nothing to load reads the tile's first pixel (always inside the tensor).
     const unsigned in_pix_stride = a.in_chunk_stride ? KC : a.cin;
-    const long in_chunk_step = a.in_chunk_stride ? a.in_chunk_stride : KC;
+    const long in_chunk_step = BLK ? blk_chunk_stride(POOL ? (long)a.n_maps * (HO * WO) : total_pix)
+                                   : (a.in_chunk_stride ? a.in_chunk_stride : KC);
     const float* __restrict__ in_tile = a.in + (g0 - 1) * W * (long)in_pix_stride + c_begin * in_chunk_step;
     const unsigned char* __restrict__ am_tile = a.pool_am;
+    // BLK (blocked.h): chunk c of pixel gp at a.in + c * in_chunk_step + blk_pix_off(gp); gp = blk_pix0 + (the item's pixel relative
+    // to the row above the tile's first / to the pooled row above it); parts 1..3 of the slice 128 floats apart
+    int blk_pix0 = (int)((g0 - 1) * W);
+    if constexpr (BLK) in_tile = a.in;
     if constexpr (LOSTAGE && AL) {
         const long lo_row = (long)(y_al >> 1) - 1;
-        in_tile = a.in + ((long)n_al * (HO * WO) + lo_row * WO) * a.cin;
+        if constexpr (!BLK) in_tile = a.in + ((long)n_al * (HO * WO) + lo_row * WO) * a.cin;
+        blk_pix0 = (int)((long)n_al * (HO * WO) + lo_row * WO);
         am_tile = a.pool_am + (img_al * (HO * WO) + lo_row * WO) * a.cin;
     }
+    constexpr int VSTEP = BLK ? 32 : 1;       // float4 units between the four parts of a staging item's slice
     f32x4 sv[LOSTAGE ? UL : U][NV];
     unsigned amv[(POOL && !X6) ? (LOSTAGE ? UL : U) : 1];
     u32x4_ amv4[(POOL && X6) ? (LOSTAGE ? UL : U) : 1];      // X6: the 16 winner bytes of the item's slice
@@ -898,13 +958,15 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             const unsigned e_ = __umul24((unsigned)(gp_ >= 0 ? gp_ : WO), (unsigned)a.cin) + (unsigned)sg_;  \
             sp_ = in_tile + (CHUNK) * KC + e_;                                                               \
             ap_ = am_tile + (CHUNK) * KC + e_;                                                               \
+            if constexpr (BLK) sp_ = in_tile + (CHUNK) * in_chunk_step + blk_pix_off32(blk_pix0 + (gp_ >= 0 ? gp_ : WO)); \
         } else {                                                                                             \
             const long g_ = gp_ >= 0 ? gp_ : 0;                                                              \
             const int am_ = gp_ >= 0 ? amo_ : 0;                                                             \
             sp_ = a.in + g_ * a.cin + (CHUNK) * KC + sg_;                                                    \
             ap_ = a.pool_am + am_ + (CHUNK) * KC + sg_;                                                      \
+            if constexpr (BLK) sp_ = in_tile + (CHUNK) * in_chunk_step + blk_pix_off32((int)g_);    \
         }                                                                                                    \
-        _Pragma("unroll") for (int v_ = 0; v_ < NV; ++v_) sv[u][v_] = reinterpret_cast<const f32x4*>(sp_)[v_]; \
+        _Pragma("unroll") for (int v_ = 0; v_ < NV; ++v_) sv[u][v_] = reinterpret_cast<const f32x4*>(sp_)[v_ * VSTEP]; \
         if constexpr (X6) amv4[u] = *reinterpret_cast<const u32x4_*>(ap_);                                   \
         else amv[u] = *reinterpret_cast<const unsigned*>(ap_);                                               \
     }
@@ -997,7 +1059,12 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     {                                                                                                        \
         int dst_, gp_, amo_;                                                                                 \
         unsigned e_;                                                                                         \
-        if constexpr (AL && ROWMAP && !POOL) {                                                               \
+        if constexpr (BLK) {                                                                                 \
+            int rel_;                                                                                        \
+            if constexpr (AL && ROWMAP && !POOL) rel_ = item_p(u);                                           \
+            else { item(u, dst_, gp_, amo_); rel_ = gp_ >= 0 ? gp_ : W; }                                    \
+            e_ = blk_pix_off32(blk_pix0 + rel_);                                                             \
+        } else if constexpr (AL && ROWMAP && !POOL) {                                                        \
             e_ = item_e(u);                                                                                  \
         } else {                                                                                             \
             item(u, dst_, gp_, amo_);                                                                        \
@@ -1005,7 +1072,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             e_ = __umul24((unsigned)(gp_ >= 0 ? gp_ : W), in_pix_stride) + (unsigned)sg_;                    \
         }                                                                                                    \
         _Pragma("unroll") for (int v_ = 0; v_ < NV; ++v_)                                                    \
-            sv[u][v_] = reinterpret_cast<const f32x4*>(in_tile + (CHUNK) * in_chunk_step + e_)[v_];          \
+            sv[u][v_] = reinterpret_cast<const f32x4*>(in_tile + (CHUNK) * in_chunk_step + e_)[v_ * VSTEP];  \
     }
 #define LRPXH_COMMIT1(u, BUFIDX)                                                                             \
     {                                                                                                        \
@@ -1516,9 +1583,12 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         return;
     }
     LRPXH_T(t_epi);
+    if constexpr (BLK && !TR) {
+        epi_rel_mul_al<HW, EPI, F8, true>(a, acc, wm, ocb, lane, g0, total_pix, a.out1 ? a.out1_amax : nullptr, inv_w, in_amax);
+        return;
+    }
     if constexpr (TR) {
-        unsigned* __restrict__ oamax_t = (EPI == EPI_GUIDED) ? a.out0_amax : (a.out1 ? a.out1_amax : nullptr);
-        epi_rel_mul_t<HW, AL, EPI, F8>(a, acc, wm, ocb, lane, g0, total_pix, oamax_t, tile_tab, inv_w, in_amax);
+        epi_rel_mul_blk<HW, AL, F8>(a, acc, wm, ocb, lane, g0, total_pix, a.out1 ? a.out1_amax : nullptr, tile_tab, inv_w, in_amax);
 #ifdef LRPXH_END_SLEEP
         for (int i = 0; i < LRPXH_END_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
 #endif

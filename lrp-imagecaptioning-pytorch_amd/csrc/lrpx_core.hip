@@ -8,6 +8,7 @@
 #include "common.h"
 #include "conv_mfma.h"
 #include "conv_bf16x6.h"
+#include "blocked.h"
 #include "conv_f16x3.h"
 
 namespace lrpx {
@@ -32,7 +33,6 @@ const Switches& switches() {
         w.fwd_wide = num("LRPX_FWD_WIDE", 0);
         w.conv11_f16 = num("LRPX_CONV11_F16", 1);
         w.first_valu = set("LRPX_FIRST_VALU");
-        w.pool28 = num("LRPX_POOL28", 1);
         w.s21_nhwc = set("LRPX_S21_NHWC");
         w.guided_poolbwd = set("LRPX_GUIDED_POOLBWD");
         w.dense_wide = num("LRPX_DENSE_WIDE", 0);
@@ -309,7 +309,13 @@ __global__ void pack_weights_f16f8_kernel(const float* __restrict__ w, float* __
     const int nchunk = k_pad / 16;
     const int chunk = rest % nchunk; rest /= nchunk;
     const int ocb = (int)rest;
-    const int oc = ocb * 32 + (lane & 31), lh = lane >> 5;
+    // BWD_POS (the relevance pass, REL_MUL epilogue): the kernel multiplies with the weights as the A operand (transposed result:
+    // a lane owns one pixel and the 16 channels of rows (e & 3) + 8 (e >> 2) + 4 lh, e = 0..15), so fragment row rho carries
+    // output channel 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3) of the block: a lane's 16 results are then the CONTIGUOUS
+    // channels 16 lh .. 16 lh + 15 - one slice of the blocked layout (blocked.h)
+    const int rho = lane & 31;
+    const int row_ch = mode == LRPX_PACK_BWD_POS ? 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3) : rho;
+    const int oc = ocb * 32 + row_ch, lh = lane >> 5;
     auto wv = [&](int k, int dx) -> float {      // scaled weight of (input channel k of this pass, tap (g, dx))
         const int tap = g * 3 + dx;
         float v = 0.f;
@@ -492,6 +498,28 @@ __global__ void unpool_winner_kernel(const float* __restrict__ s_lo, const unsig
     }
 }
 
+// NHWC <-> BLOCKED (blocked.h): a wave moves 16 pixels x 16 channels - 64-byte pieces on the NHWC side, 256-byte runs on the
+// blocked side.  `n_groups` tensors of P pixels each (per-image multiplicands: one block set per image; an S tensor: ONE group of
+// n_maps * P pixels); to_blocked = 0: the way back.
+__global__ void blocked_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int P, int C, long total,
+                                       int to_blocked) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int l = (int)(t & 63);
+    long r = t >> 6;
+    const int npg = (P + 15) >> 4, nch = C >> 4;
+    const int pg = (int)(r % npg); r /= npg;
+    const int chunk = (int)(r % nch);
+    const long grp = r / nch;
+    const int pix = pg * 16 + (l >> 2), k = l & 3;
+    if (pix >= P) return;
+    const long cs = blk_chunk_stride(P);
+    const long nh = (grp * P + pix) * C + chunk * 16 + k * 4;
+    const long bl = grp * (long)nch * cs + (long)chunk * cs + blk_pix_off(pix) + k * 128;
+    if (to_blocked) *reinterpret_cast<f32x4*>(dst + bl) = *reinterpret_cast<const f32x4*>(src + nh);
+    else *reinterpret_cast<f32x4*>(dst + nh) = *reinterpret_cast<const f32x4*>(src + bl);
+}
+
 // winners of a 2x2 max-pool + the fused multiplicand max / safe(Z+ at the winner); one thread = one pooled pixel x 4 ch
 __global__ void pool_winner_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ xzw,
                                    unsigned char* __restrict__ am, int ho, int wo, int c4, long total) {
@@ -613,6 +641,55 @@ __global__ void divide_stab_kernel(const float* __restrict__ r, const float* __r
         mabs = fmaxf(mabs, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
     if (amax) amax_commit(amax, n, mabs);
+}
+
+// S = R / safe(Z+) at the top of the mode-3 chain, written BLOCKED (blocked.h) with the per-map maxima.
+// r: [n_maps][P][C] NHWC, z: [n_img][P][C].  A lane
+// owns one (pixel, 16-channel slice): 64 contiguous bytes in, four 16-byte parts out (32 consecutive pixels of a chunk = one
+// 512-byte run per part); a wave walks ITER groups of 64 pixels of one chunk - not more pixels than a map has (the launcher checks),
+// so they belong to the map of the wave's first pixel or to the next one: two maxima per wave.
+template <int ITER>
+__global__ void divide_stab_blocked_kernel(const float* __restrict__ r, const float* __restrict__ z,
+                                           const int* __restrict__ map2img, float* __restrict__ s, int P, int C, long n_pix,
+                                           unsigned* __restrict__ amax, int n_maps) {
+    const long gw = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int l = threadIdx.x & 63;
+    const int nch = C >> 4;
+    const int chunk = (int)(gw % nch);
+    const long pix0 = (gw / nch) * (64 * ITER);
+    if (pix0 >= n_pix) return;
+    const long cs = blk_chunk_stride(n_pix);
+    const long n_w0 = pix0 / P;
+    float m_lo = 0.f, m_hi = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const long pix = pix0 + it * 64 + l;
+        if (pix >= n_pix) break;
+        const long n = pix / P, p = pix - n * P;
+        const long img = map2img ? map2img[n] : n;
+        const float* rp = r + pix * C + chunk * 16;
+        const float* zp = z + (img * P + p) * C + chunk * 16;
+        f32x4 o[4];
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(rp + 4 * k), zv = *reinterpret_cast<const f32x4*>(zp + 4 * k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[k][e] = rv[e] / stab_safe(zv[e]);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(o[k][0]), fabsf(o[k][1])), fmaxf(fabsf(o[k][2]), fabsf(o[k][3]))));
+        }
+        float* sp = s + (long)chunk * cs + blk_pix_off(pix);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(sp + k * 128) = o[k];
+        if (n == n_w0) m_lo = fmaxf(m_lo, m); else m_hi = fmaxf(m_hi, m);
+    }
+    if (amax) {
+        m_lo = wave_max(m_lo); m_hi = wave_max(m_hi);
+        if (l == 0) {
+            amax_update(&amax[n_w0], m_lo);
+            if (n_w0 + 1 < n_maps) amax_update(&amax[n_w0 + 1], m_hi);
+        }
+    }
 }
 
 __global__ void cumsum_maps_kernel(const float* __restrict__ in, float* __restrict__ out, int t_per_img, long per4,
@@ -858,6 +935,17 @@ int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, flo
     }
     return check_launch("divide_stab");
 }
+int divide_stab_blocked(const float* r, const float* z, const int32_t* map2img, float* s_blk, int n_maps, int pix, int c,
+                        unsigned* amax, hipStream_t stream) {
+    constexpr int ITER = 2;
+    LRPX_REQUIRE(r && z && s_blk && n_maps > 0 && pix >= 64 * ITER && c > 0 && c % 16 == 0,
+                 "divide_stab_blocked: bad arguments (c %% 16, >= %d pixels per map)", 64 * ITER);
+    const long n_pix = (long)n_maps * pix;
+    const long waves = (long)(c / 16) * ceil_div(n_pix, 64 * ITER);
+    hipLaunchKernelGGL(divide_stab_blocked_kernel<ITER>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, r, z, map2img, s_blk, pix, c,
+                       n_pix, amax, n_maps);
+    return check_launch("divide_stab_blocked");
+}
 }  // namespace lrpx
 extern "C" {
 
@@ -866,6 +954,22 @@ int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* z
                               void* stream) {
     return maxpool_relevance_amax(x, r_out, zdiv, map2img, r_in, s_out, n_maps, h_out, w_out, c, s_chunk, nullptr,
                                   (hipStream_t)stream);
+}
+
+size_t lrpx_blocked_floats(long n_pix, int c) { return (size_t)blk_floats(n_pix, c); }
+
+static int blocked_convert(const float* src, float* dst, long n_groups, int pix_per_group, int c, int to_blocked, void* stream) {
+    LRPX_REQUIRE(src && dst && n_groups > 0 && pix_per_group > 0 && c > 0 && c % 16 == 0, "blocked layout: bad arguments (c %% 16)");
+    const long total = n_groups * (c / 16) * ((pix_per_group + 15) / 16) * 64;
+    hipLaunchKernelGGL(blocked_convert_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, pix_per_group, c,
+                       total, to_blocked);
+    return check_launch("blocked_convert");
+}
+int lrpx_nhwc_to_blocked(const float* src, float* dst, long n_groups, int pix_per_group, int c, void* stream) {
+    return blocked_convert(src, dst, n_groups, pix_per_group, c, 1, stream);
+}
+int lrpx_blocked_to_nhwc(const float* src, float* dst, long n_groups, int pix_per_group, int c, void* stream) {
+    return blocked_convert(src, dst, n_groups, pix_per_group, c, 0, stream);
 }
 
 int lrpx_pool_winner(const float* x, const float* z, float* xzw, uint8_t* am, int n, int h_out, int w_out, int c,

@@ -10,6 +10,7 @@
 
 #include "conv_launch.h"
 #include "conv_f16x3.h"
+#include "blocked.h"
 
 namespace lrpx {
 
@@ -87,6 +88,19 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
                      "or bias-free PLAIN epilogue");
         LRPX_REQUIRE(d->f16x3 != 2 || d->epi == EPI_REL_MUL || d->epi == EPI_GUIDED || d->epi == EPI_PLAIN,
                      "conv_mfma: the f16+f8 kernels (f16x3 = 2) are built for the REL_MUL, GUIDED and PLAIN epilogues");
+        // the mode-3 relevance kernels (f16x3 = 2, REL_MUL) are built for the BLOCKED layout of in / x / out only (blocked.h,
+        // lrpx_nhwc_to_blocked); everything else takes NHWC
+        // the mode-3 relevance kernels (f16x3 = 2, REL_MUL) take `in` in the BLOCKED layout (blocked.h, lrpx_nhwc_to_blocked) and, except the
+        // 224 x 224 one (conv1_2: NHWC multiplicand, NHWC / channel-chunked output for the first-layer kernel), x and the output too
+        if (d->f16x3 == 2 && d->epi == EPI_REL_MUL) {
+            if (d->hw == 224)
+                LRPX_REQUIRE(d->blocked == 1 && !d->in_chunked, "conv_mfma: the 224x224 f16x3 = 2 REL_MUL kernel takes `in` blocked (blocked = 1), x / out NHWC");
+            else
+                LRPX_REQUIRE(d->blocked == 7 && d->oc_split % 16 == 0 && !d->in_chunked && !d->out_chunk,
+                             "conv_mfma: f16x3 = 2 with REL_MUL takes in / x / out in the blocked layout (blocked = 7, oc_split %% 16 == 0, no chunk options)");
+        } else {
+            LRPX_REQUIRE(d->blocked == 0, "conv_mfma: only the f16x3 = 2 REL_MUL kernels take the blocked layout");
+        }
         const int wide_g = switches().wide;
         if (d->f16x3 == 2 && d->epi == EPI_GUIDED && d->pool_am) {
             LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
@@ -268,7 +282,8 @@ int fwd_dual_finish(const float* part, int nsplit, const float* bias, float* act
                     int cout, unsigned* amax, hipStream_t s);
 int first_layer_pack_mfma(const float* w, float* packed, int plain, hipStream_t s);
 int first_layer_relevance_mfma(const float* S, const float* packed, const float* X8, const int* map2img,
-                               const unsigned* s_amax, float* out, int n_maps, int plain, int chunked32, hipStream_t s);
+                               const unsigned* s_amax, float* out, int n_maps, int plain, int s_layout, hipStream_t s);
+
 int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, int plain,
                 hipStream_t s);
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
@@ -335,11 +350,12 @@ static VggPacked vgg_packed_layout() {
 }
 
 struct VggTrace {   // offsets in floats; act[l] = input of layer l, act[17] = encoder output
-    size_t act[18], zpos[17], xz[17], am[17], famax, total;   // famax: [18][n_img] max of act[l] per image (f16x3 forward)
+    size_t act[18], zpos[17], xz[17], xzp[17], am[17], famax, total;   // famax: [18][n_img] max of act[l] per image (f16x3 forward)
     // xz[l]: multiplicand of conv l's fused relevance step = act[l] / safe(Z+ of the conv below): directly below
     //        (zpos[l-1]) or under a pool (zpos[l-2] at the window's winner, lrpx_pool_winner);
     //        xz[1] (n_img x 224*224*64 floats, the largest) doubles as the SCRATCH of the K-split forward layers while
     //        lrpx_vgg16_forward runs: the xz tensors are only valid after lrpx_vgg16_trace_derive, its last step;
+    // xzp[l]: the same multiplicand in the BLOCKED layout (blocked.h; one block set per image) for the mode-3 kernels;
     // am[lp]: winner positions of pool lp (bytes, stored in a float-aligned region)
 };
 static VggTrace vgg_trace_layout(int n_img) {
@@ -357,10 +373,12 @@ static VggTrace vgg_trace_layout(int n_img) {
         if (kVgg[l].conv) off += (size_t)n_img * kVgg[l].hw * kVgg[l].hw * kVgg[l].cout;
     }
     for (int l = 0; l < kNL; ++l) {
-        t.xz[l] = t.am[l] = 0;
+        t.xz[l] = t.xzp[l] = t.am[l] = 0;
         if (l >= 1 && kVgg[l].conv) {
             t.xz[l] = off;
             off += (size_t)n_img * kVgg[l].hw * kVgg[l].hw * kVgg[l].cin;
+            t.xzp[l] = off;
+            if (l >= 3) off += (size_t)n_img * (size_t)blk_floats((long)kVgg[l].hw * kVgg[l].hw, kVgg[l].cin);
         }
         if (!kVgg[l].conv) {
             t.am[l] = off;
@@ -477,6 +495,8 @@ int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream) {
             LRPX_TRY(lrpx_pool_winner(tr + t.act[l - 1], tr + t.zpos[l - 2], tr + t.xz[l], (uint8_t*)(tr + t.am[l - 1]),
                                       n_img, kVgg[l].hw, kVgg[l].hw, kVgg[l].cin, stream));
         }
+        // the blocked copy the mode-3 relevance kernels multiply with (one block set per image; conv1_2's kernel takes NHWC)
+        if (l >= 3) LRPX_TRY(lrpx_nhwc_to_blocked(tr + t.xz[l], tr + t.xzp[l], n_img, kVgg[l].hw * kVgg[l].hw, kVgg[l].cin, stream));
     }
     return LRPX_OK;
 }
@@ -649,9 +669,15 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
         set_error("vgg16_relevance: cannot zero the amax words");
         return LRPX_ELAUNCH;
     }
+    // mode 3: every S tensor of the chain and the multiplicands are BLOCKED (blocked.h), the kernels accumulate channels x pixels
+    const bool blk = mode == 3;
     // S_16 = R_feat / safe(Z+_16)
-    LRPX_TRY(divide_stab_amax(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, STAB_SAFE,
-                              h3 ? amax + (size_t)16 * n_maps : nullptr, (hipStream_t)stream));
+    if (blk)
+        LRPX_TRY(divide_stab_blocked(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, 196, 512, amax + (size_t)16 * n_maps,
+                                     (hipStream_t)stream));
+    else
+        LRPX_TRY(divide_stab_amax(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, STAB_SAFE,
+                                  h3 ? amax + (size_t)16 * n_maps : nullptr, (hipStream_t)stream));
     const bool timing = cx.layer_ms != nullptr;
     if (timing) LRPX_TRY(timer.begin());
 #define LRPX_TIMED_DISPATCH(L_, DESC)                                                   \
@@ -672,13 +698,15 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
         if (l == 0) {
             // 3 output channels (first_layer.hip): 16x16x32 MFMAs on the split halves of S in the split-product modes (S
             // comes with its per-map maximum, in 32-channel chunks), the direct fp32 VALU conv otherwise
-            const int fl_mfma = switches().first_valu ? 0 : 1;
+            const int fl_mfma = (blk || !switches().first_valu) ? 1 : 0;
+            if (timing) (void)hipEventRecord(timer.ev[0][0], (hipStream_t)stream);
             if (h3 && fl_mfma)
                 LRPX_TRY(first_layer_relevance_mfma(S[cur], pk + p.first16, tr + t.act[0], map2img, amax, out_nchw, n_maps,
                                                     0, 1, (hipStream_t)stream));
             else
                 LRPX_TRY(first_layer_relevance(S[cur], pk + p.first6, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 0,
                                                h3 ? 1 : 0, (hipStream_t)stream));
+            if (timing) { (void)hipEventRecord(timer.ev[0][1], (hipStream_t)stream); timer.valid[0] = true; }
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
@@ -692,34 +720,28 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
             if (mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwd8[l]; }
             // under a pool: S[cur] is the low-resolution tensor the conv above the pool wrote, unpooled while staged
             if (pooled_in) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
-            // conv4_3 in mode 3 used to unpool S with a scatter kernel (0.5 GB written) and run the plain 28x28 kernel: the
-            // map-straddling pooled-input kernel spilled 40 VGPRs with the fp8 operands.  With the SWAR commit it fits (8-wave
-            // version: 3 spills, as fast as the plain kernel), so the scatter is gone; LRPX_POOL28=0 brings it back (A/B)
-            if (!switches().pool28 && mode == 3 && pooled_in && L.hw == 28) {
-                LRPX_TRY(lrpx_unpool_winner(S[cur], d.pool_am, map2img, S[cur ^ 1], n_maps, L.hw / 2, L.hw / 2, L.cout, stream));
-                cur ^= 1;
-                d.in = S[cur]; d.pool_am = nullptr;
-            }
+            // blocked: in (1), x (2), out (4); conv1_2 (l == 1): blocked input only (see conv_f16x3.h, TR)
+            if (blk) d.blocked = l == 1 ? 1 : 7;
         }
         else if (use_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
         if (kVgg[l - 1].conv) {
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
             d.out1 = S[cur ^ 1];
-            if (h3) { d.x = tr + t.xz[l]; d.out1_amax = amax + (size_t)(l - 1) * n_maps; }   // x / safe(Z+) precomputed
+            if (h3) { d.x = tr + ((blk && l != 1) ? t.xzp[l] : t.xz[l]); d.out1_amax = amax + (size_t)(l - 1) * n_maps; }   // x / safe(Z+) precomputed
             // the first-layer kernel walks S in channel chunks (MFMA version: 32 = whole 128-byte lines per pixel; VALU: 16)
-            const int fl_chunk = switches().first_valu ? 16 : 32;
+            const int fl_chunk = (!blk && switches().first_valu) ? 16 : 32;
             if (h3 && l == 1) d.out_chunk = fl_chunk;
-            else { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
-            // conv2_2 -> conv2_1: S in 16-channel chunks, the K-chunk of the consumer (64-byte slices of 512-byte NHWC pixels
+            else if (!blk) { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
+            // mode 2, conv2_2 -> conv2_1: S in 16-channel chunks, the K-chunk of the consumer (64-byte slices of 512-byte NHWC pixels
             // drag every 128-byte line through the fabric twice: FETCH 3.1x the tensor; chunked: conv2_1 1.44 -> 1.37 ms)
             const int s21_chunk = switches().s21_nhwc ? 0 : 16;
-            if (h3 && l == 4 && s21_chunk) { d.out_chunk = s21_chunk; cur_chunked = 1; }
+            if (h3 && !blk && l == 4 && s21_chunk) { d.out_chunk = s21_chunk; cur_chunked = 1; }
             LRPX_TIMED_DISPATCH(l, &d);
         } else {
             if (h3) {
                 // a pool lies below: x = max / safe(Z+ at the winner) turns the accumulator straight into S of the conv
                 // under the pool (at the winners); that conv unpools it while staging - no pool kernel, no 4x tensor
-                d.x = tr + t.xz[l]; d.out1 = S[cur ^ 1]; d.out1_amax = amax + (size_t)(l - 2) * n_maps;
+                d.x = tr + (blk ? t.xzp[l] : t.xz[l]); d.out1 = S[cur ^ 1]; d.out1_amax = amax + (size_t)(l - 2) * n_maps;
                 LRPX_TIMED_DISPATCH(l, &d);
                 cur ^= 1;
                 continue;

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ConvDesc, EPI_FIRST, EPI_FWD_DUAL, EPI_PLAIN, EPI_REL, PACK_BWD_FIRST, PACK_BWD_POS,
+from ._lib import (ConvDesc, EPI_FIRST, EPI_FWD_DUAL, EPI_PLAIN, EPI_REL, EPI_REL_MUL, PACK_BWD_FIRST, PACK_BWD_POS,
                    PACK_DENSE, PACK_DENSE_T, PACK_FWD_DUAL, STAB_EPS, STAB_NONE, STAB_SAFE, check, ptr, stream_ptr)
 
 
@@ -79,7 +79,7 @@ def amax_maps(s, n_maps):
 
 def conv_desc(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, *, pix_per_map=0, stab=STAB_NONE, oc_split=0,
               relu=0, bias=None, x=None, u=None, zdiv=None, map2img=None, out0=None, out1=None, bf16x6=0,
-              f16x3=0, in_amax=None, out1_amax=None, pool_am=None, out0_amax=None):
+              f16x3=0, in_amax=None, out1_amax=None, pool_am=None, out0_amax=None, blocked=0):
     """the lrpx_conv_desc of one contraction (the tensors must outlive its use: the descriptor holds raw pointers)"""
     d = ConvDesc()
     d.in_, d.wpacked = ptr(_dev(inp)), ptr(_dev(wpacked))
@@ -89,10 +89,56 @@ def conv_desc(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, *, pix_per_map=0, 
     d.in_amax, d.out1_amax, d.pool_am, d.out0_amax = ptr(in_amax), ptr(out1_amax), ptr(pool_am), ptr(out0_amax)
     d.bias, d.x, d.u, d.zdiv, d.map2img = ptr(bias), ptr(x), ptr(u), ptr(zdiv), ptr(map2img)
     d.out0, d.out1 = ptr(out0), ptr(out1)
+    d.blocked = blocked
     return d
 
 
+def nhwc_to_blocked(src, n_groups, pix_per_group, c):
+    """NHWC [n_groups][pix][c] -> the BLOCKED layout of the mode-3 relevance kernels (csrc/blocked.h), one block set per group"""
+    lib = _lib.load()
+    dst = torch.zeros(n_groups * lib.lrpx_blocked_floats(pix_per_group, c), dtype=torch.float32, device=src.device)
+    check(lib.lrpx_nhwc_to_blocked(ptr(_dev(src)), ptr(dst), n_groups, pix_per_group, c, stream_ptr()))
+    return dst
+
+
+def blocked_to_nhwc(src, n_groups, pix_per_group, c, out=None):
+    if out is None:
+        out = torch.empty(n_groups, pix_per_group, c, dtype=torch.float32, device=src.device)
+    check(_lib.load().lrpx_blocked_to_nhwc(ptr(src), ptr(out), n_groups, pix_per_group, c, stream_ptr()))
+    return out
+
+
+def _conv_rel_mul_blocked(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, **kw):
+    """The f16x3 = 2 REL_MUL kernels take `in` BLOCKED and, except the 224 x 224 one, x and the output too (the fused VGG16 chain
+    keeps them so end to end).  For callers with NHWC tensors - the single-layer parity tests - convert at this boundary: in as one
+    block set over all maps, x as one block set per image, the output back into the caller's tensor."""
+    lib = _lib.load()
+    ncol = kw.get("oc_split") or n_oc
+    pin = (hw // 2) ** 2 if kw.get("pool_am") is not None else hw * hw
+    x, out0, out1 = kw.get("x"), kw.get("out0"), kw.get("out1")
+    kw = dict(kw)
+    inb = nhwc_to_blocked(inp, 1, n_maps * pin, cin)
+    if hw == 224:                      # conv1_2's kernel: NHWC multiplicand and output
+        kw["blocked"] = 1
+        d = conv_desc(inb, wpacked, n_maps, hw, cin, n_oc, taps, epi, **kw)
+        check(lib.lrpx_conv_mfma(C.byref(d), stream_ptr()))
+        return
+    kw["blocked"] = 7
+    if x is not None:
+        kw["x"] = nhwc_to_blocked(x, x.shape[0], hw * hw, ncol)
+    ob = None
+    if out0 is not None or out1 is not None:
+        ob = torch.zeros(lib.lrpx_blocked_floats(n_maps * hw * hw, ncol), dtype=torch.float32, device=inp.device)
+        kw["out0"] = ob if out0 is not None else None
+        kw["out1"] = ob if out1 is not None else None
+    d = conv_desc(inb, wpacked, n_maps, hw, cin, n_oc, taps, epi, **kw)
+    check(lib.lrpx_conv_mfma(C.byref(d), stream_ptr()))
+    blocked_to_nhwc(ob, 1, n_maps * hw * hw, ncol, out=out0 if out0 is not None else out1)
+
+
 def conv_mfma(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, **kw):
+    if kw.get("f16x3") == 2 and epi == EPI_REL_MUL and not kw.get("blocked"):
+        return _conv_rel_mul_blocked(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, **kw)
     d = conv_desc(inp, wpacked, n_maps, hw, cin, n_oc, taps, epi, **kw)
     check(_lib.load().lrpx_conv_mfma(C.byref(d), stream_ptr()))
 

@@ -20,6 +20,10 @@ sys.path.insert(0, %r)
 import lrp_amd
 from lrp_amd import weights
 from lrp_amd.explainers.gridtd import GridTDEngine
+import os
+from lrp_amd import _lib
+if os.environ.get("LRPX_CHILD_MODE"):
+    _lib.load().lrpx_set_conv_mode(int(os.environ["LRPX_CHILD_MODE"]))
 V = 307
 eng = GridTDEngine(weights.make_gridtd_state(seed=3, vocab_size=V))
 img = torch.from_numpy(weights.make_images(4, 2))
@@ -41,22 +45,34 @@ def _run(tmp_path, name, env):
     return torch.load(out)
 
 
+_DEFAULTS = {}
+
+
 @pytest.fixture(scope="module")
 def default_run(tmp_path_factory):
+    """the same explanation with every switch at its default, per conv mode (one child process each, on first use)"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    return _run(tmp_path_factory.mktemp("sw"), "default", {})
+
+    def get(mode):
+        if mode not in _DEFAULTS:
+            _DEFAULTS[mode] = _run(tmp_path_factory.mktemp("sw"), f"default{mode}", {"LRPX_CHILD_MODE": mode} if mode else {})
+        return _DEFAULTS[mode]
+    return get
 
 
-SWITCHES = [("LRPX_FWD_WIDE", "15"), ("LRPX_CONV11_F16", "0"), ("LRPX_WIDE", "0"), ("LRPX_FWD_KSPLIT", "1"), ("LRPX_FWD_KSPLIT28", "4"), ("LRPX_FIRST_VALU", "1"), ("LRPX_POOL28", "0"),
-            ("LRPX_S21_NHWC", "1"), ("LRPX_GUIDED_POOLBWD", "1"), ("LRPX_DENSE_1WAVE", "1"), ("LRPX_LINEAR_VALU", "1")]
+# (switch, value, conv mode of the child: "" = the default mode 3; LRPX_FIRST_VALU / LRPX_S21_NHWC choose kernels of the NHWC
+# chain of mode 2 - the mode-3 chain keeps its tensors in the blocked layout and has no such alternatives)
+SWITCHES = [("LRPX_FWD_WIDE", "15", ""), ("LRPX_CONV11_F16", "0", ""), ("LRPX_WIDE", "0", ""), ("LRPX_FWD_KSPLIT", "1", ""),
+            ("LRPX_FWD_KSPLIT28", "4", ""), ("LRPX_FIRST_VALU", "1", "2"), ("LRPX_S21_NHWC", "1", "2"), ("LRPX_GUIDED_POOLBWD", "1", ""),
+            ("LRPX_DENSE_1WAVE", "1", ""), ("LRPX_LINEAR_VALU", "1", "")]
 
 
-@pytest.mark.parametrize("name,value", SWITCHES)
-def test_non_default_switch_gives_the_same_results(default_run, tmp_path, name, value):
+@pytest.mark.parametrize("name,value,mode", SWITCHES)
+def test_non_default_switch_gives_the_same_results(default_run, tmp_path, name, value, mode):
     from conftest import rel_err
-    got = _run(tmp_path, name, {name: value})
-    ref = default_run
+    got = _run(tmp_path, name, {name: value, **({"LRPX_CHILD_MODE": mode} if mode else {})})
+    ref = default_run(mode)
     fwd = name.startswith("LRPX_FWD") or name == "LRPX_CONV11_F16"
     # forward switches change the summation order of the trace (features move at the 1e-6 level, a pool winner may flip);
     # everything else runs the same trace through another kernel of the same arithmetic

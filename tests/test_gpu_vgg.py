@@ -675,8 +675,22 @@ def test_rel_mul_rejects_two_outputs_and_never_writes_past_the_last_map(ops):
                           f16x3=f16x3, in_amax=amax)
         with pytest.raises(ValueError):
             ops.conv_mfma(s, wb, n_maps, hw, cout, cin, 9, _lib.EPI_REL_MUL, oc_split=cin, x=x, f16x3=f16x3, in_amax=amax)
-        ops.conv_mfma(s, wb, n_maps, hw, cout, cin, 9, _lib.EPI_REL_MUL, oc_split=cin, x=x, out1=out, f16x3=f16x3,
-                      in_amax=amax, out1_amax=oamax)
+        if f16x3 == 2:
+            # the mode-3 kernels write the BLOCKED layout (csrc/blocked.h): the guard band sits behind the blocked tensor, and the
+            # padding pixels of its last 32-pixel block (980 = 30 * 32 + 20; 2352 = 73 * 32 + 16) must stay untouched too
+            n_pix = n_maps * hw * hw
+            nf = _lib.load().lrpx_blocked_floats(n_pix, cin)
+            bufb = torch.full((nf + guard,), 12345.0, device="cuda")
+            ops.conv_mfma(ops.nhwc_to_blocked(s, 1, n_pix, cout), wb, n_maps, hw, cout, cin, 9, _lib.EPI_REL_MUL, oc_split=cin,
+                          x=ops.nhwc_to_blocked(x, n_maps, hw * hw, cin), out1=bufb[:nf], f16x3=2, in_amax=amax, out1_amax=oamax,
+                          blocked=7)
+            torch.cuda.synchronize()
+            assert (bufb[nf:] == 12345.0).all(), (hw, f16x3)
+            assert int((bufb[:nf] != 12345.0).sum()) == n_pix * cin, (hw, "padding pixels of the last block were written")
+            ops.blocked_to_nhwc(bufb[:nf], 1, n_pix, cin, out=out)
+        else:
+            ops.conv_mfma(s, wb, n_maps, hw, cout, cin, 9, _lib.EPI_REL_MUL, oc_split=cin, x=x, out1=out, f16x3=f16x3,
+                          in_amax=amax, out1_amax=oamax)
         torch.cuda.synchronize()
         assert (buf[n_out:] == 12345.0).all(), (hw, f16x3)
         assert torch.isfinite(out).all() and (out != 12345.0).all()
@@ -722,7 +736,7 @@ def test_per_context_conv_mode_in_flight_on_two_streams(ops, gridtd_case):
         ms = (C.c_float * 17)()
         a.relevance(r_feat, m2i, layer_ms=ms)
         convs = [l for l in range(1, 17) if ops.Vgg16.IS_CONV[l]]
-        assert all(ms[l] > 0 for l in convs) and ms[0] == 0 and all(ms[l] == 0 for l in (2, 5, 9, 13))
+        assert all(ms[l] > 0 for l in convs) and ms[0] > 0 and all(ms[l] == 0 for l in (2, 5, 9, 13))    # (layer 0: the first-layer kernel)
     finally:
         lib.lrpx_set_conv_mode(prev)
 
@@ -871,3 +885,38 @@ def test_pooled_input_identity_weights_unpool_exactly(ops, hw, c, f8):
     for pos in range(4):
         want[:, pos // 2::2, pos % 2::2, :] = s_lo.view(2, ho, ho, c) * (am.view(1, ho, ho, c) == pos)
     assert torch.equal(out.view(2, hw, hw, c), want)
+
+
+def test_blocked_layout_converters_and_weight_row_order(ops):
+    """csrc/blocked.h: element (pixel p, channel c) of a blocked tensor sits at (c / 16) * CS + (p / 32) * 512 + ((c % 16) / 4) * 128 +
+    (p % 32) * 4 + c % 4 with CS = ceil(pixels / 32) * 512; one block set per group.  Round trip and the closed form on ragged sizes
+    (196 pixels per group: the last block is partial), and the row order of the BWD_POS fp16+fp6 weight pack that goes with it:
+    fragment row rho carries output channel 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3), so that a lane of the transposed result
+    owns 16 contiguous channels."""
+    from lrp_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    for groups, pix, c in ((1, 980, 64), (3, 196, 32), (2, 3136, 16), (1, 33, 48)):
+        src = torch.randn(groups, pix, c, generator=g).cuda()
+        nf = lib.lrpx_blocked_floats(pix, c)
+        cs = -(-pix // 32) * 512
+        assert nf == (c // 16) * cs
+        blk = ops.nhwc_to_blocked(src, groups, pix, c)
+        assert blk.numel() == groups * nf
+        pp, cc = torch.meshgrid(torch.arange(pix), torch.arange(c), indexing="ij")
+        off = (cc // 16) * cs + (pp // 32) * 512 + ((cc % 16) // 4) * 128 + (pp % 32) * 4 + cc % 4
+        for gidx in range(groups):
+            assert torch.equal(blk[gidx * nf:(gidx + 1) * nf].cpu()[off], src[gidx].cpu()), (groups, pix, c)
+        assert torch.equal(ops.blocked_to_nhwc(blk, groups, pix, c), src)
+    # weight rows: hi plane of tap row 0, dx 0 of the first K chunk - lane l holds the 8 input channels 8 (l >> 5) .. of its output channel
+    cout = cin = 32
+    w = torch.zeros(cout, cin, 3, 3)
+    w[:, :, 2, 2] = (torch.arange(cin).view(1, cin) + 1.0).expand(cout, cin)        # flipped tap (0, 0); value = transposed-conv output channel + 1
+    for mode, perm in ((_lib.PACK_BWD_POS, True), (_lib.PACK_BWD_PLAIN, False)):
+        blob = ops.pack_weights_f16f8(w.cuda(), cout, cin, mode).cpu()
+        inv_scale = blob[0].item()
+        hi = blob[16:16 + 256].view(torch.float16).view(64, 8).float() * inv_scale         # plane 0: 64 lanes x 8 fp16
+        for lane in range(32):
+            rho = lane
+            ch = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3) if perm else rho
+            assert hi[lane, 0].item() == ch + 1.0, (mode, lane, hi[lane, 0].item())
