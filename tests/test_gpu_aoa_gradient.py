@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import lrp_amd  # noqa: F401
-from conftest import GOLDEN, rel_err, assert_close_modulo_pool_ties
+from conftest import GOLDEN, rel_err, assert_close_modulo_pool_ties, forward_flips, gradient_e2e_bounds
 
 pytestmark = pytest.mark.gpu
 # End to end the ReLU masks come from the GPU forward (see tests/test_gpu_gradient.py).  The AoA decoder gradient is dense
@@ -16,7 +16,18 @@ pytestmark = pytest.mark.gpu
 # ... 0.99989 / relative L2 up to 1.5e-2 on the golden image.  The decoder itself is held to 1e-4 (d_feat below, and per row against the
 # oracle on identical features); the CNN backward kernels are held to 1e-4 on identical activations in
 # tests/test_gpu_gradient.py / test_gpu_guided.py.
-E2E = dict(frac=0.3, l2=3e-2, cos=0.9995, hard=0.15)
+# the plain-gradient bound is chosen from the flips of the golden image IN THIS RUN (conftest.forward_flips /
+# gradient_e2e_bounds).  Guided backprop clamps every gradient at every ReLU, which confines a flipped path: its maps hold the
+# bounds of tests/test_gpu_guided.py (observed over the suite: 0.33 % of the pixels, max 4.7e-3, relative L2 5.7e-4).
+GUIDED = dict(frac=0.07, hard=0.01, l2=2e-3, cos=0.99999)
+_E2E = {}
+
+
+def _e2e(sd, eng, img):
+    if "b" not in _E2E:
+        eng.vgg.forward(img.cuda())
+        _E2E["b"] = gradient_e2e_bounds(forward_flips(eng.vgg, sd, img), "AoA plain gradient, golden image")
+    return _E2E["b"]
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +52,7 @@ def test_aoa_gradient_decoder_and_maps_vs_reference(case):
         want = torch.from_numpy(g[f"d_feat_{t}"])[0].reshape(512, 196).t()
         assert rel_err(d_feat[0, t].cpu(), want) < 1e-4, t
         assert np.abs(r_words[0, t, :t + 1].cpu().numpy() - g[f"r_words_{t}"]).max() < 5e-5
-        assert_close_modulo_pool_ties(maps[0, t][None, :, ::4, ::4].cpu(), g[f"grad_map_sub4_{t}"], what=t, **E2E)
+        assert_close_modulo_pool_ties(maps[0, t][None, :, ::4, ::4].cpu(), g[f"grad_map_sub4_{t}"], what=t, **_e2e(sd, eng, img))
 
 
 def test_aoa_guided_and_gradcam_vs_reference(case):
@@ -50,7 +61,7 @@ def test_aoa_guided_and_gradcam_vs_reference(case):
     cams, _ = eng.explain_batch_gradient(cap, head, img, kind="gradcam")
     assert tuple(cams.shape) == (1, 3, 196)
     for t in range(3):
-        assert_close_modulo_pool_ties(gmaps[0, t][None, :, ::4, ::4].cpu(), g[f"guided_map_sub4_{t}"], what=t, **E2E)
+        assert_close_modulo_pool_ties(gmaps[0, t][None, :, ::4, ::4].cpu(), g[f"guided_map_sub4_{t}"], what=t, **GUIDED)
         assert np.abs(cams[0, t].cpu().numpy() - g[f"cam_{t}"][0]).max() < 1e-3, t
 
 
@@ -116,7 +127,7 @@ def test_aoa_drop_in_classes(case):
     assert len(maps) == 3 and tuple(maps[0].shape) == (1, 3, 224, 224) and tuple(rws[2].shape) == (3,)
     assert np.abs(rws[2].cpu().numpy() - g["r_words_2"]).max() < 5e-5
     gm, _ = ExplainAOAGuidedGradient(args, wm, model=sd).explain_caption(img, head, caption_encode=ce)
-    assert_close_modulo_pool_ties(gm[1][:, :, ::4, ::4].cpu(), g["guided_map_sub4_1"], what="guided drop-in", **E2E)
+    assert_close_modulo_pool_ties(gm[1][:, :, ::4, ::4].cpu(), g["guided_map_sub4_1"], what="guided drop-in", **GUIDED)
     cams, _ = ExplainAOAGradCam(args, wm, model=sd).explain_caption(img, head, caption_encode=ce)
     assert tuple(cams[0].shape) == (1, 196) and np.abs(cams[0].cpu().numpy() - g["cam_0"]).max() < 1e-3
 
@@ -140,6 +151,6 @@ def test_aoa_guided_gradcam_vs_reference_fixture():
     dmaps, _ = ex.explain_caption(img, head, caption_encode=g["aoa_caption"].tolist())
     for t in range(3):
         assert torch.equal(dmaps[t][0], maps[0, t])
-        assert_close_modulo_pool_ties(maps[0, t][None, :, ::4, ::4].cpu(), g[f"aoa_map_sub4_{t}"], what=("aoa ggc", t), **E2E)
+        assert_close_modulo_pool_ties(maps[0, t][None, :, ::4, ::4].cpu(), g[f"aoa_map_sub4_{t}"], what=("aoa ggc", t), **GUIDED)
         assert np.abs(r_words[0, t, :t + 1].cpu().numpy() - g[f"aoa_r_words_{t}"]).max() < 5e-5
-    assert_close_modulo_pool_ties(maps[0, 2].cpu(), g["aoa_map_full_2"][0], what="aoa ggc full", **E2E)
+    assert_close_modulo_pool_ties(maps[0, 2].cpu(), g["aoa_map_full_2"][0], what="aoa ggc full", **GUIDED)
