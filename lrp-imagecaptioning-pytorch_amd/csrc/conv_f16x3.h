@@ -563,7 +563,7 @@ __device__ __forceinline__ void epi_rel_mul_blk(const ConvArgs& a, f32x16 (&acc)
 // v_mfma_f32_32x32x64_f8f6f4, K = 64 = 4 (tap, 16-channel) slices: 5 fp8 MFMAs per K-chunk (f8_slot_*) instead of 18
 // fp16 ones.  LDS pixel (80 B as before): 16 fp16 hi | 16 fp8 of x*2^-4 | 16 fp8 of (x-hi)*2^4 | pad.
 template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
-__device__ __forceinline__ void conv_f16x3_body(ConvArgs a, const int m_tiles, const int n_blocks, const int bid) {
+__global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     LRPXH_T(t_start);
 #ifdef LRPX_STAMP
     unsigned long long s_issue = 0, s_mfma = 0, s_commit = 0, s_barrier = 0, s_tap0 = 0, s_tap1 = 0, s_tap2 = 0;
@@ -609,6 +609,9 @@ __device__ __forceinline__ void conv_f16x3_body(ConvArgs a, const int m_tiles, c
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
+    // (the body stays in the __global__ function: as an inlined device function taking the argument struct by value it spilled 12 - 25
+    // registers in every instantiation - the struct no longer lived in the kernel-argument segment - and ran 6 - 8 % slower)
+    const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
     // Workgroup ids go round-robin over the 8 XCDs (each with its own L2): XCD x walks a CONTIGUOUS range of tiles, so the
     // halo rows that neighbouring tiles share and the multiplicand tiles of an image's words are re-read from one L2
@@ -1784,11 +1787,6 @@ __device__ __forceinline__ void conv_f16x3_body(ConvArgs a, const int m_tiles, c
         atomicAdd(&g_stamp_h3[8], s_tap0); atomicAdd(&g_stamp_h3[9], s_tap1); atomicAdd(&g_stamp_h3[10], s_tap2);
     }
 #endif
-}
-
-template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
-__global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
-    conv_f16x3_body<HW, MT, NWN, DB, EPI, POOL, F8>(a, m_tiles, n_blocks, (int)blockIdx.x);
 }
 
 template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
