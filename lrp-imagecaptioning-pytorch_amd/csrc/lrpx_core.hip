@@ -522,7 +522,7 @@ __global__ void blocked_convert_kernel(const float* __restrict__ src, float* __r
 
 // winners of a 2x2 max-pool + the fused multiplicand max / safe(Z+ at the winner); one thread = one pooled pixel x 4 ch
 __global__ void pool_winner_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ xzw,
-                                   unsigned char* __restrict__ am, int ho, int wo, int c4, long total) {
+                                   unsigned char* __restrict__ am, int ho, int wo, int c4, long total, float* __restrict__ xzw_blk) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*ho*wo*c4
     if (idx >= total) return;
     const int cc = idx % c4;
@@ -553,6 +553,10 @@ __global__ void pool_winner_kernel(const float* __restrict__ x, const float* __r
     }
     reinterpret_cast<f32x4*>(xzw)[idx] = o;
     reinterpret_cast<unsigned*>(am)[idx] = pk;
+    if (xzw_blk) {          // the same multiplicand in the BLOCKED layout (blocked.h), one block set per image
+        const int P = ho * wo;
+        *reinterpret_cast<f32x4*>(xzw_blk + n * (long)(c4 >> 2) * blk_chunk_stride(P) + blk_off((long)yo * wo + xo, 4 * cc, blk_chunk_stride(P))) = o;
+    }
 }
 
 // Pool2d rule + division by the Z+ of the conv below.  One thread = ITER x (one hi-res pixel x 4 channels); a block
@@ -690,6 +694,24 @@ __global__ void divide_stab_blocked_kernel(const float* __restrict__ r, const fl
             if (n_w0 + 1 < n_maps) amax_update(&amax[n_w0 + 1], m_hi);
         }
     }
+}
+
+// x / safe(z) per image (the multiplicand of a conv directly above another conv), NHWC and BLOCKED in one pass
+__global__ void divide_safe_blk_kernel(const float* __restrict__ r, const float* __restrict__ z, float* __restrict__ s,
+                                       float* __restrict__ s_blk, int P, int c4, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 units over n_img * P * c4
+    if (idx >= total) return;
+    const int cq = (int)(idx % c4);
+    const long rp = idx / c4;
+    const long n = rp / P;
+    const int pix = (int)(rp - n * P);
+    const f32x4 rv = reinterpret_cast<const f32x4*>(r)[idx], zv = reinterpret_cast<const f32x4*>(z)[idx];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = rv[e] / stab_safe(zv[e]);
+    reinterpret_cast<f32x4*>(s)[idx] = o;
+    const long cs = blk_chunk_stride(P);
+    *reinterpret_cast<f32x4*>(s_blk + n * (long)(c4 >> 2) * cs + blk_off(pix, 4 * cq, cs)) = o;
 }
 
 __global__ void cumsum_maps_kernel(const float* __restrict__ in, float* __restrict__ out, int t_per_img, long per4,
@@ -946,6 +968,19 @@ int divide_stab_blocked(const float* r, const float* z, const int32_t* map2img, 
                        n_pix, amax, n_maps);
     return check_launch("divide_stab_blocked");
 }
+// the two producers of the per-image multiplicands (lrpx_vgg16_trace_derive) with the BLOCKED copy written in the same pass
+int pool_winner_blk(const float* x, const float* z, float* xzw, uint8_t* am, float* xzw_blk, int n, int h_out, int w_out, int c, hipStream_t stream) {
+    LRPX_REQUIRE(x && z && xzw && am && n > 0 && h_out > 0 && w_out > 0 && c % 16 == 0, "pool_winner: bad arguments");
+    const long total = (long)n * h_out * w_out * (c / 4);
+    hipLaunchKernelGGL(pool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, z, xzw, am, h_out, w_out, c / 4, total, xzw_blk);
+    return check_launch("pool_winner");
+}
+int divide_safe_blk(const float* r, const float* z, float* s, float* s_blk, int n_img, int pix, int c, hipStream_t stream) {
+    LRPX_REQUIRE(r && z && s && s_blk && n_img > 0 && pix > 0 && c % 16 == 0, "divide_safe_blk: bad arguments");
+    const long total = (long)n_img * pix * (c / 4);
+    hipLaunchKernelGGL(divide_safe_blk_kernel, dim3(grid_for(total)), dim3(256), 0, stream, r, z, s, s_blk, pix, c / 4, total);
+    return check_launch("divide_safe_blk");
+}
 }  // namespace lrpx
 extern "C" {
 
@@ -977,7 +1012,7 @@ int lrpx_pool_winner(const float* x, const float* z, float* xzw, uint8_t* am, in
     LRPX_REQUIRE(x && z && xzw && am && n > 0 && h_out > 0 && w_out > 0 && c % 4 == 0, "pool_winner: bad arguments");
     const long total = (long)n * h_out * w_out * (c / 4);
     hipLaunchKernelGGL(pool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, z, xzw, am,
-                       h_out, w_out, c / 4, total);
+                       h_out, w_out, c / 4, total, (float*)nullptr);
     return check_launch("pool_winner");
 }
 

@@ -485,18 +485,21 @@ int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream) {
     float* tr = (float*)trace;
     for (int l = 1; l < kNL; ++l) {
         if (!t.xz[l]) continue;
+        // l >= 3: the blocked copy the mode-3 relevance kernels multiply with (one block set per image) is written in the same pass
+        // (conv1_2's kernel takes NHWC)
+        const int pix = kVgg[l].hw * kVgg[l].hw;
         if (kVgg[l - 1].conv) {
             // multiplicand of the fused step  S_{l-1} = x_l * convT(S_l, W+) / safe(Z+_{l-1})   (lrp_modules.py:124-150
             // for conv l, then utils.py:16-18 safe_divide of the conv below)
-            LRPX_TRY(lrpx_divide_stab(tr + t.act[l], tr + t.zpos[l - 1], nullptr, tr + t.xz[l], n_img,
-                                      (long)kVgg[l].hw * kVgg[l].hw * kVgg[l].cin, STAB_SAFE, stream));
+            if (l >= 3)
+                LRPX_TRY(divide_safe_blk(tr + t.act[l], tr + t.zpos[l - 1], tr + t.xz[l], tr + t.xzp[l], n_img, pix, kVgg[l].cin, (hipStream_t)stream));
+            else
+                LRPX_TRY(lrpx_divide_stab(tr + t.act[l], tr + t.zpos[l - 1], nullptr, tr + t.xz[l], n_img, (long)pix * kVgg[l].cin, STAB_SAFE, stream));
         } else {
             // a pool lies below: max / safe(Z+_{l-2} at the winner) + the winner positions (lrp_modules.py:182-195)
-            LRPX_TRY(lrpx_pool_winner(tr + t.act[l - 1], tr + t.zpos[l - 2], tr + t.xz[l], (uint8_t*)(tr + t.am[l - 1]),
-                                      n_img, kVgg[l].hw, kVgg[l].hw, kVgg[l].cin, stream));
+            LRPX_TRY(pool_winner_blk(tr + t.act[l - 1], tr + t.zpos[l - 2], tr + t.xz[l], (uint8_t*)(tr + t.am[l - 1]), tr + t.xzp[l],
+                                     n_img, kVgg[l].hw, kVgg[l].hw, kVgg[l].cin, (hipStream_t)stream));
         }
-        // the blocked copy the mode-3 relevance kernels multiply with (one block set per image; conv1_2's kernel takes NHWC)
-        if (l >= 3) LRPX_TRY(lrpx_nhwc_to_blocked(tr + t.xz[l], tr + t.xzp[l], n_img, kVgg[l].hw * kVgg[l].hw, kVgg[l].cin, stream));
     }
     return LRPX_OK;
 }
