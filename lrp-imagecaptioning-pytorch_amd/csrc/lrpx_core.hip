@@ -648,43 +648,37 @@ __global__ void divide_stab_kernel(const float* __restrict__ r, const float* __r
 }
 
 // S = R / safe(Z+) at the top of the mode-3 chain, written BLOCKED (blocked.h) with the per-map maxima.
-// r: [n_maps][P][C] NHWC, z: [n_img][P][C].  A lane
-// owns one (pixel, 16-channel slice): 64 contiguous bytes in, four 16-byte parts out (32 consecutive pixels of a chunk = one
-// 512-byte run per part); a wave walks ITER groups of 64 pixels of one chunk - not more pixels than a map has (the launcher checks),
-// so they belong to the map of the wave's first pixel or to the next one: two maxima per wave.
+// r: [n_maps][P][C] NHWC, z: [n_img][P][C].  A wave moves 8 pixels x 32 channels per step: 8 lanes read one pixel's 128 contiguous
+// bytes (whole lines in), and write per (16-channel chunk, 4-channel part) 8 pixels x 16 bytes = one 128-byte run (whole lines out).
+// It walks ITER such steps - fewer pixels than a map has, so they belong to the map of its first pixel or to the next one: two maxima.
 template <int ITER>
 __global__ void divide_stab_blocked_kernel(const float* __restrict__ r, const float* __restrict__ z,
                                            const int* __restrict__ map2img, float* __restrict__ s, int P, int C, long n_pix,
                                            unsigned* __restrict__ amax, int n_maps) {
     const long gw = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int l = threadIdx.x & 63;
-    const int nch = C >> 4;
-    const int chunk = (int)(gw % nch);
-    const long pix0 = (gw / nch) * (64 * ITER);
+    const int ncp = C >> 5;                                  // pairs of 16-channel chunks
+    const int cp = (int)(gw % ncp);
+    const long pix0 = (gw / ncp) * (8 * ITER);
     if (pix0 >= n_pix) return;
     const long cs = blk_chunk_stride(n_pix);
     const long n_w0 = pix0 / P;
+    const int q = l & 7;                                     // 4-channel quad of the 32 channels: chunk 2 cp + (q >> 2), part q & 3
+    const int c = cp * 32 + q * 4;
     float m_lo = 0.f, m_hi = 0.f;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const long pix = pix0 + it * 64 + l;
+        const long pix = pix0 + it * 8 + (l >> 3);
         if (pix >= n_pix) break;
         const long n = pix / P, p = pix - n * P;
         const long img = map2img ? map2img[n] : n;
-        const float* rp = r + pix * C + chunk * 16;
-        const float* zp = z + (img * P + p) * C + chunk * 16;
-        f32x4 o[4];
-        float m = 0.f;
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(r + pix * C + c);
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (img * P + p) * C + c);
+        f32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(rp + 4 * k), zv = *reinterpret_cast<const f32x4*>(zp + 4 * k);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[k][e] = rv[e] / stab_safe(zv[e]);
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(o[k][0]), fabsf(o[k][1])), fmaxf(fabsf(o[k][2]), fabsf(o[k][3]))));
-        }
-        float* sp = s + (long)chunk * cs + blk_pix_off(pix);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(sp + k * 128) = o[k];
+        for (int e = 0; e < 4; ++e) o[e] = rv[e] / stab_safe(zv[e]);
+        *reinterpret_cast<f32x4*>(s + (long)(2 * cp + (q >> 2)) * cs + blk_pix_off(pix) + (q & 3) * 128) = o;
+        const float m = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
         if (n == n_w0) m_lo = fmaxf(m_lo, m); else m_hi = fmaxf(m_hi, m);
     }
     if (amax) {
@@ -959,11 +953,11 @@ int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, flo
 }
 int divide_stab_blocked(const float* r, const float* z, const int32_t* map2img, float* s_blk, int n_maps, int pix, int c,
                         unsigned* amax, hipStream_t stream) {
-    constexpr int ITER = 2;
-    LRPX_REQUIRE(r && z && s_blk && n_maps > 0 && pix >= 64 * ITER && c > 0 && c % 16 == 0,
-                 "divide_stab_blocked: bad arguments (c %% 16, >= %d pixels per map)", 64 * ITER);
+    constexpr int ITER = 16;           // 128 pixels per wave
+    LRPX_REQUIRE(r && z && s_blk && n_maps > 0 && pix >= 8 * ITER && c > 0 && c % 32 == 0,
+                 "divide_stab_blocked: bad arguments (c %% 32, >= %d pixels per map)", 8 * ITER);
     const long n_pix = (long)n_maps * pix;
-    const long waves = (long)(c / 16) * ceil_div(n_pix, 64 * ITER);
+    const long waves = (long)(c / 32) * ceil_div(n_pix, 8 * ITER);
     hipLaunchKernelGGL(divide_stab_blocked_kernel<ITER>, dim3(grid_for(waves * 64)), dim3(256), 0, stream, r, z, map2img, s_blk, pix, c,
                        n_pix, amax, n_maps);
     return check_launch("divide_stab_blocked");
