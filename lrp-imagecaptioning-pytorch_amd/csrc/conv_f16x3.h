@@ -603,6 +603,11 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     constexpr bool BLK = X6 && (EPI == EPI_REL_MUL);
     constexpr bool TR = BLK && (HW != 224);
     constexpr int NV = X6 ? 4 : 1;                     // float4 loads per staging item
+#ifndef LRPXH_X6_READ
+#define LRPXH_X6_READ 1
+#endif
+    // fp6 operands from LDS as two conflict-free 16-byte reads (else 16 + 8 + 4 bytes: 2- and 4-way bank conflicts over pixels 80 bytes apart)
+    constexpr bool X6RD = X6 && (EPI == EPI_REL_MUL) && (LRPXH_X6_READ != 0) && !(HW == 112 && MT == 2);      // (measured on the relevance chain only)
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
     const int tid = threadIdx.x;
@@ -1316,10 +1321,13 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                             // hazard is a full drain of the counter)
                             const u32x4_ x0 = *reinterpret_cast<const u32x4_*>(a6);
 #ifndef LRPXH_X6_READ
-#define LRPXH_X6_READ 0
+#define LRPXH_X6_READ 1
 #endif
-                            if constexpr (LRPXH_X6_READ != 0) {
-                                // (variant, off) two 16-byte reads, conflict-free over consecutive pixels 80 bytes apart; the clear dword
+                            if constexpr (X6RD) {
+                                // (round 4: the default except for conv2_1's 4-row 112 x 112 kernel, which spills with the extra live register:
+                                // 1.05 -> 1.19 ms; same-box A/B of the rest: conv4_3 1.68 -> 1.60, conv1_2 2.50 -> 2.44, conv5_x 0.51 -> 0.50, conv2_2
+                                // 1.89 -> 1.87, the others +-0.01: profiles/r04_ab_x6_read.txt)
+                                // two 16-byte reads, conflict-free over consecutive pixels 80 bytes apart; the clear dword
                                 // behind the fields is kept alive past the MFMA by an empty asm (see the MFMA below).  The 8- and 4-byte
                                 // reads of the default hit their banks 2 and 4 times over pixels 80 bytes apart (SQ_LDS_BANK_CONFLICT
                                 // 0.33 of the LDS cycles against 0.03 with fp8) - but the kernels are not bound by the LDS: same-box A/B
@@ -1380,7 +1388,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                             } else {
                                 acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cur, m == 0 ? bm0 : bm1, acc[j], 0, 0, 0, 0, 0, 0);
                             }
-                            if constexpr (X6 && (LRPXH_X6_READ != 0)) {      // (the unused 4th dword of the second read stays allocated until here)
+                            if constexpr (X6RD) {      // (the unused 4th dword of the second read stays allocated until here)
                                 const int keep = cur[7];
                                 asm volatile("" : : "v"(keep));
                             }
