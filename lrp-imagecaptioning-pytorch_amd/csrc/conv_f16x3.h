@@ -1230,6 +1230,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     }
 
     LRPXH_T(t_loop);
+#ifndef LRPXH_CHUNK_UNROLL
+#define LRPXH_CHUNK_UNROLL 1
+#endif
+#pragma unroll LRPXH_CHUNK_UNROLL
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = chunk + 1 < nchunk;
         LRPXH_REFRESH

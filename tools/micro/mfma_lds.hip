@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -19,8 +20,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int W = 56, PSTRIDE = 80, PITCH = W * PSTRIDE + 256, NSLOT = 6, BUFB = NSLOT * PITCH;
 
-template <int NB, int WAVES, bool RD>
-__global__ __launch_bounds__(64 * WAVES, 1) void k(const unsigned* __restrict__ src, float* __restrict__ dst, int iters) {
+template <int NB, int WAVES, bool RD, int BQ = 0>
+__global__ __launch_bounds__(64 * WAVES, 1) void k(const unsigned* __restrict__ src, float* __restrict__ dst, int iters, const u32x4* __restrict__ wsrc = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     for (int i = tid; i < 2 * BUFB / 4; i += 64 * WAVES) reinterpret_cast<unsigned*>(lds)[i] = src[i & 4095] & 0x3b3b3b3bu;   // finite fp16 / fp6
@@ -39,7 +40,17 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(const unsigned* __restrict__ 
     for (int d = 0; d < 3; ++d) for (int j = 0; j < 8; ++j) nord[d][j] = (int)(src[lane * 8 + j + 29 * d] & 0x3b3b3b3bu);
     for (int d = 0; d < 3; ++d) nord[d][6] = 127;
     const int e6a = 32 - 16 * lh + lh * PSTRIDE, e6b = 32 - 16 * lh + lh * (PITCH - 2 * PSTRIDE), e6c = 32 - 16 * lh;
+    // BQ: the weight stream of the kernel: per tap row 7 planes of 64 lanes x 16 bytes from global memory (L2-resident here), entry
+    // g + 1 loaded while entry g is multiplied
+    u32x4 bq[2][7];
+    const u32x4* wp = wsrc + lane;
+    if constexpr (BQ != 0) {
+#pragma unroll
+        for (int p = 0; p < 7; ++p) { bq[0][p] = wp[p * 64]; bq[1][p] = bq[0][p]; }
+    }
     for (int it = 0; it < iters; ++it) {
+        auto chunk_body = [&](auto par_c, const int it) {
+        constexpr int PAR0 = decltype(par_c)::value;
         const char* abuf = lds + (it & 1) * BUFB;
         constexpr int D = 3;
         auto og = [](const int k) constexpr { return k < 35 ? 0 : (k < 70 ? 1 : 2); };
@@ -66,6 +77,22 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(const unsigned* __restrict__ 
         constexpr int K0[3] = {0, 35, 70}, KN[3] = {35, 35, 28};
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
+            // which queue entry is current: BQ 1 rotates (entry 0 always current, moves behind the row); BQ 2 alternates with static
+            // indices (the step parity: `it` advances by 2 per loop trip in that variant, see the loop increment)
+            constexpr int dummy = 0; (void)dummy;
+            const int s_par = (BQ == 2) ? ((PAR0 * 3 + g) & 1) : 0;
+            if constexpr (BQ != 0) {
+                const long e = ((long)(it * 3 + g + 1) % 96) * 7;
+#pragma unroll
+                for (int p = 0; p < 7; ++p) bq[BQ == 2 ? (s_par ^ 1) : 1][p] = wp[(e + p) * 64];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const u32x4* c = bq[s_par];
+                    bh[n][0] = __builtin_bit_cast(f16x8, c[0]); bh[n][1] = __builtin_bit_cast(f16x8, c[1]); bh[n][2] = __builtin_bit_cast(f16x8, c[2]);
+                    bm[n][0] = i32x8{(int)c[3][0], (int)c[3][1], (int)c[3][2], (int)c[3][3], (int)c[4][0], (int)c[4][1], 127, 0};
+                    bm[n][1] = i32x8{(int)c[5][0], (int)c[5][1], (int)c[5][2], (int)c[5][3], (int)c[6][0], (int)c[6][1], 127, 0};
+                }
+            }
 #pragma unroll
             for (int k2 = 0; k2 < KN[g]; ++k2) {
                 const int kk = K0[g] + k2;
@@ -82,25 +109,32 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(const unsigned* __restrict__ 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (BQ == 1) {
+#pragma unroll
+                for (int p = 0; p < 7; ++p) bq[0][p] = bq[1][p];
+            }
         }
+        };      // chunk_body
+        if constexpr (BQ == 2) { chunk_body(std::integral_constant<int, 0>{}, it); chunk_body(std::integral_constant<int, 1>{}, it + 1); ++it; }
+        else chunk_body(std::integral_constant<int, 0>{}, it);
     }
     float s = 0.f;
     for (int n = 0; n < NB; ++n) for (int i = 0; i < 7; ++i) for (int j = 0; j < 16; ++j) s += acc[n][i][j];
     dst[blockIdx.x * 64 * WAVES + threadIdx.x] = s;
 }
 
-template <int NB, int WAVES, bool RD> double run(const unsigned* src, float* dst, int iters, const char* name) {
-    auto kern = k<NB, WAVES, RD>;
+template <int NB, int WAVES, bool RD, int BQ = 0> double run(const unsigned* src, float* dst, int iters, const char* name, const u32x4* w = nullptr) {
+    auto kern = k<NB, WAVES, RD, BQ>;
     const int ldsb = 2 * BUFB;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int grid = 256 * 4;          // 4 rounds of one workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), ldsb, 0, src, dst, 10);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), ldsb, 0, src, dst, 10, w);
     hipDeviceSynchronize();
     double best = 1e30, tot = 0;
     for (int rep = 0; rep < 8; ++rep) {            // ~ sustained: 8 launches back to back
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), ldsb, 0, src, dst, iters);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), ldsb, 0, src, dst, iters, w);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep >= 2) { tot += ms; if (ms < best) best = ms; }
@@ -120,6 +154,8 @@ int main() {
     srand(1);
     for (int i = 0; i < 4096 + 1024; ++i) h[i] = (unsigned)rand() * 2654435761u;
     hipMemcpy(src, h, sizeof(h), hipMemcpyHostToDevice);
+    u32x4* w; hipMalloc(&w, 96 * 7 * 64 * 16 + 4096);
+    { unsigned* hw = (unsigned*)malloc(96 * 7 * 64 * 16); for (int i = 0; i < 96 * 7 * 64 * 4; ++i) hw[i] = ((unsigned)rand() * 2654435761u) & 0x3b3b3b3bu; hipMemcpy(w, hw, 96 * 7 * 64 * 16, hipMemcpyHostToDevice); free(hw); }
     const int iters = 600;
     for (int rep = 0; rep < 2; ++rep) {
         run<1, 8, false>(src, dst, iters, "A: 1 block / wave, 8 waves / CU, operands in registers");
@@ -127,6 +163,8 @@ int main() {
         run<2, 4, true>(src, dst, iters, "C: 2 blocks / wave, 4 waves / CU, LDS read per 2 MFMAs");
         run<2, 4, false>(src, dst, iters, "D: 2 blocks / wave, 4 waves / CU, operands in registers");
         run<1, 4, true>(src, dst, 2 * iters, "E: 1 block / wave, 4 waves / CU (1 per SIMD), LDS read per MFMA");
+        run<1, 8, true, 1>(src, dst, iters, "F: as B + the weight stream from L2, queue ROTATED by moves (shipped)", w);
+        run<1, 8, true, 2>(src, dst, iters, "G: as B + the weight stream from L2, queue double-buffered (no moves)", w);
     }
     return 0;
 }
