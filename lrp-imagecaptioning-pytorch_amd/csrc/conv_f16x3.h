@@ -1599,6 +1599,22 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     LRPXH_T(t_epi);
     if constexpr (BLK && !TR) {
         epi_rel_mul_al<HW, EPI, F8, true>(a, acc, wm, ocb, lane, g0, total_pix, a.out1 ? a.out1_amax : nullptr, inv_w, in_amax);
+#ifdef LRPX_STAMP
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LRPXH_T(t_endp);
+            if (lane == 0 && HW == LRPX_STAMP_HW) {
+                atomicAdd(&g_stamp_h3[0], t_loop - t_start);
+                atomicAdd(&g_stamp_h3[1], s_issue);
+                atomicAdd(&g_stamp_h3[2], s_mfma);
+                atomicAdd(&g_stamp_h3[3], s_commit);
+                atomicAdd(&g_stamp_h3[4], s_barrier);
+                atomicAdd(&g_stamp_h3[5], t_endp - t_epi);
+                atomicAdd(&g_stamp_h3[6], t_endp - t_start);
+                atomicAdd(&g_stamp_h3[7], 1ull);
+            }
+        }
+#endif
         return;
     }
     if constexpr (TR) {
