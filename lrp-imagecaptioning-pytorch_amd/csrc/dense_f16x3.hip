@@ -288,6 +288,249 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void dense_f16x3_kernel(
     }
 }
 
+// ---- many rows, wide column blocks --------------------------------------------------------------------------------------
+// 128 rows x 256 columns per workgroup, the four waves SIDE BY SIDE: a wave owns all 128 rows x 64 columns (4 x 2 accumulator
+// tiles, 24 MFMAs per k-step).  Against the 2 x 2 arrangement above: a B fragment streamed from L2 is fetched by ONE wave of the
+// workgroup and feeds 4 row tiles (2 x 2: fetched by two waves, 2 row tiles each), and the A rows are fetched, converted and
+// written to LDS once per 256 columns instead of once per 128 - 24 KB from L2 per 768 matrix cycles of a SIMD instead of per 384
+// (which is the 64 bytes per clock a CU can take in: the 2 x 2 kernel's K loop ran at the speed of its loads, not of its MFMAs).
+// Same products in the same order per accumulator as dense_f16x3_kernel: bit-identical results.
+// The per-row constants of the epilogue (map, multiplicand row, result scale) are computed ONCE by the first 128 threads at the
+// start and parked in LDS: the epilogue's loads no longer hang on a chain row -> map -> image -> operand maximum.
+constexpr int DN_BM = 128, DN_BN = 256, DN_KC = 32, DN_KS = DN_KC / 16, DN_ROWB = DN_KS * 64 + 16, DN_BUF = DN_BM * DN_ROWB;
+constexpr int DN_LDS = 2 * DN_BUF + DN_BM * 16;
+template <int EPI, bool HAS_U, bool HAS_O1>      // REL: with the addend U; writing out1 = r / stab(Zdiv) (+ its per-map maxima) instead of out0 = r
+__global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    u32x4_* rowinfo = reinterpret_cast<u32x4_*>(ldsb + 2 * DN_BUF);       // [128] {map, multiplicand row offset, result scale, -}
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long total = (long)m_tiles * n_blocks;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const long t0 = (xcd * total) >> 3, t1 = ((xcd + 1) * total) >> 3;
+    const long lin = t0 + idx;
+    if (lin >= t1) return;
+    const int mtile = (int)(lin / n_blocks), nblk = (int)(lin - (long)mtile * n_blocks);
+    const long M = (long)a.n_maps * a.pix_per_map;
+    const long row0 = (long)mtile * DN_BM;
+    const int K = a.cin, nchunk = K / DN_KC;
+    const unsigned P = (unsigned)a.pix_per_map;
+    const unsigned* __restrict__ in_amax = a.in_amax;
+    const int ncol = a.oc_split;
+    const float inv_w = a.wp[0];
+
+    if (tid < DN_BM) {
+        const long r = row0 + tid;
+        const unsigned rc = (unsigned)(r < M ? r : M - 1);
+        const unsigned n = rc / P, p = rc - n * P;
+        const unsigned img = EPI == EPI_PLAIN ? n : (unsigned)a.map2img[n];          // (REL: map2img is required)
+        const float sc = exp2i(-f16_scale_exp(in_amax[n])) * inv_w;
+        rowinfo[tid] = u32x4_{n, (img * P + p) * (unsigned)ncol, __builtin_bit_cast(unsigned, sc), 0u};     // (< 2^31: host-checked)
+    }
+
+    // ---- staging: thread -> 4 items (row = tid / 8 + 32 u, 16-byte segment tid % 8 of the 128-byte chunk row)
+    constexpr int NU = 4;
+    const int s_row = tid >> 3, s_seg = tid & 7;
+    float ssc[NU];
+    unsigned soff[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const long r = row0 + s_row + 32 * u;
+        const unsigned rc = (unsigned)(r < M ? r : M - 1);        // rows past the end re-read the last row (results dropped)
+        soff[u] = rc * (unsigned)K + s_seg * 4;                    // (M * K < 2^31: host-checked)
+        ssc[u] = exp2i(f16_scale_exp(in_amax[rc / P]));
+    }
+    const int s_off = (s_seg >> 2) * 64 + ((s_seg >> 1) & 1) * 16 + (s_seg & 1) * 8;
+    f32x4 sv[NU];
+    const float* __restrict__ A = a.in;
+    auto issue = [&](const int chunk) {
+        const float* __restrict__ Ac = A + chunk * DN_KC;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) sv[u] = *reinterpret_cast<const f32x4*>(Ac + soff[u]);
+    };
+    auto commit = [&](const int bufi) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            unsigned h0_, h1_, l0_, l1_;
+            f32x2_ f0_, f1_;
+            split2_pk(f32x2_{sv[u][0], sv[u][1]} * f32x2_{ssc[u], ssc[u]}, h0_, l0_, f0_);
+            split2_pk(f32x2_{sv[u][2], sv[u][3]} * f32x2_{ssc[u], ssc[u]}, h1_, l1_, f1_);
+            char* d_ = ldsb + bufi * DN_BUF + (s_row + 32 * u) * DN_ROWB + s_off;
+            *reinterpret_cast<u32x2_*>(d_) = u32x2_{h0_, h1_};
+            *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{l0_, l1_};
+        }
+    };
+    issue(0);
+
+    // ---- B fragments of the wave's two column tiles: [ocb][k-step][plane 2][lane 64][16 B], one k-step ahead in registers
+    const int ocb0 = nblk * 8 + wave * 2;
+    const int ocb_last = (a.n_oc - 1) / 32;
+    const int nks = K / 16;
+    const u32x4_* wp0 = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) + (long)min(ocb0, ocb_last) * nks * 128 + lane;
+    const u32x4_* wp1 = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) + (long)min(ocb0 + 1, ocb_last) * nks * 128 + lane;
+    u32x4_ bq[2][4];                 // [tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo] of k-steps s, s + 1
+    auto load_b = [&](const int ks, u32x4_ (&b)[4]) {
+        const int k = min(ks, nks - 1);
+        b[0] = wp0[(long)k * 128]; b[1] = wp0[(long)k * 128 + 64];
+        b[2] = wp1[(long)k * 128]; b[3] = wp1[(long)k * 128 + 64];
+    };
+    load_b(0, bq[0]);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    commit(0);
+    __syncthreads();
+    const int a_off = li * DN_ROWB + lh * 16;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        issue(min(chunk + 1, nchunk - 1));               // (past the last chunk: re-read it, nobody commits it)
+        __builtin_amdgcn_sched_barrier(0);               // keep the loads here (cf. dense_f16x3_kernel)
+        const char* abuf = ldsb + (chunk & 1) * DN_BUF + a_off;
+        // A fragments of a PAIR of row tiles one step ahead of their 12 MFMAs: [tile 2p hi, lo, tile 2p + 1 hi, lo]
+        f16x8 af[2][4];
+        auto read_pair = [&](const int t, f16x8 (&f)[4]) {
+            const char* q = abuf + (64 * (t & 1)) * DN_ROWB + (t >> 1) * 64;
+            f[0] = *reinterpret_cast<const f16x8*>(q);
+            f[1] = *reinterpret_cast<const f16x8*>(q + 32);
+            f[2] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB);
+            f[3] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB + 32);
+        };
+        read_pair(0, af[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2 * DN_KS; ++t) {           // t = 2 * k-step + pair
+            const int s = t >> 1, pr = t & 1;
+            if (pr == 0) load_b(chunk * DN_KS + s + 1, bq[(s + 1) & 1]);
+            if (t + 1 < 2 * DN_KS) read_pair(t + 1, af[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 a0h = af[t & 1][0], a0l = af[t & 1][1], a1h = af[t & 1][2], a1l = af[t & 1][3];
+            const u32x4_(&b)[4] = bq[s & 1];
+            const f16x8 b0h = __builtin_bit_cast(f16x8, b[0]), b0l = __builtin_bit_cast(f16x8, b[1]);
+            const f16x8 b1h = __builtin_bit_cast(f16x8, b[2]), b1l = __builtin_bit_cast(f16x8, b[3]);
+            f32x16 &c00 = acc[2 * pr][0], &c01 = acc[2 * pr][1], &c10 = acc[2 * pr + 1][0], &c11 = acc[2 * pr + 1][1];
+            // small terms first
+            c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, c11, 0, 0, 0);
+            c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0l, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1l, c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0l, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1l, c11, 0, 0, 0);
+            c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, c11, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (chunk + 1 < nchunk) commit((chunk + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (EPI_REL of conv_mfma.h / EPI_PLAIN): element e of tile (i, j): row = row0 + 32 i + (e&3) + 8 (e>>2) + 4 lh,
+    // column = 32 (ocb0 + j) + li.  STRAIGHT-LINE code: which operands exist is a template parameter (a branch on `U != null`
+    // around a load makes the compiler wait for every load in flight at the merge), columns past the end load the last column,
+    // rows past the end the last row; only the stores are predicated.
+    const float* __restrict__ X = a.X;
+    const float* __restrict__ Uu = a.U;
+    const float* __restrict__ Zd = a.Zdiv;
+    float* __restrict__ out = HAS_O1 ? a.out1 : a.out0;
+    unsigned* __restrict__ oamax = HAS_O1 ? a.out1_amax : nullptr;
+    const int nmax = a.n_maps - 1;
+    float mres[4][2];
+    unsigned nres[4];
+    const int oc0 = ocb0 * 32 + li;
+    const float bv0 = (EPI == EPI_PLAIN && a.bias) ? a.bias[min(oc0, ncol - 1)] : 0.f;
+    const float bv1 = (EPI == EPI_PLAIN && a.bias) ? a.bias[min(oc0 + 32, ncol - 1)] : 0.f;
+    const int stab = a.stab;
+    constexpr int JB = (HAS_U || HAS_O1) ? 1 : 2;        // column tiles whose loads are in flight together (registers)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long rt = row0 + 32 * i;
+        unsigned nn[16], xb[16];
+        float sc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const u32x4_ ri = rowinfo[32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh];
+            const unsigned scb = ri[2];          // (a scalar copy first: __builtin_bit_cast of a vector ELEMENT reads element 0, clang)
+            nn[e] = ri[0]; xb[e] = ri[1]; sc[e] = __builtin_bit_cast(float, scb);
+        }
+        const unsigned nt0 = rowinfo[32 * i][0];
+        float m0 = 0.f, m1 = 0.f;
+        // stores: one scalar base per row tile + a 32-bit offset (rows of the tile x ncol < 2^31), rows / columns past the end masked
+        float* __restrict__ orow = out + rt * ncol;
+        const int mrem = (int)(M - rt < 32 ? M - rt : 32);
+        if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oc = oc0 + 32 * j;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    float v = acc[i][j][e] * sc[e] + (j ? bv1 : bv0);
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    if (rl < mrem && oc < ncol) orow[(unsigned)(rl * ncol + oc)] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j0 = 0; j0 < 2; j0 += JB) {
+                float xv[JB][16], uv[JB][16], zv[JB][16];
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) {
+                    const unsigned oc = (unsigned)min(oc0 + 32 * (j0 + jj), ncol - 1);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        xv[jj][e] = X[xb[e] + oc];
+                        uv[jj][e] = HAS_U ? Uu[nn[e] * (unsigned)ncol + oc] : 0.f;          // (n_maps * ncol < 2^31: host-checked)
+                        zv[jj][e] = HAS_O1 ? Zd[xb[e] + oc] : 1.f;
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) {
+                    const int oc = oc0 + 32 * (j0 + jj);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rl = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        const bool ok = rl < mrem && oc < ncol;
+                        const float rel = xv[jj][e] * (acc[i][j0 + jj][e] * sc[e] + uv[jj][e]);
+                        if constexpr (!HAS_O1) {
+                            if (ok) orow[(unsigned)(rl * ncol + oc)] = rel;
+                        } else {
+                            float z = zv[jj][e];
+                            z = (stab == STAB_SAFE) ? stab_safe(z) : ((stab == STAB_EPS) ? stab_eps(z) : z);
+                            const float sv_ = fast_div(rel, z);
+                            if (ok) {
+                                orow[(unsigned)(rl * ncol + oc)] = sv_;
+                                if (nn[e] == nt0) m0 = fmaxf(m0, fabsf(sv_)); else m1 = fmaxf(m1, fabsf(sv_));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        mres[i][0] = m0; mres[i][1] = m1; nres[i] = nt0;
+    }
+    if constexpr (HAS_O1) {
+        if (oamax) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long rt = row0 + 32 * i;
+                const float m0 = wave_max(mres[i][0]), m1 = wave_max(mres[i][1]);
+                if (lane == 0 && rt < M) {
+                    amax_update(&oamax[nres[i]], m0);
+                    if ((int)nres[i] + 1 <= nmax) amax_update(&oamax[nres[i] + 1], m1);
+                }
+            }
+        }
+    }
+}
+
 // ---- few rows (the lock-step gate rules of the decoders: rows = images x words, 320 .. 1280; K = 512) -------------------
 // dense_small.hip on the fp16 matrix cores: one workgroup = 32 rows x 128 columns, the whole 32 x K slab of A staged ONCE
 // into LDS - scaled per ROW by 2^kA from the row's own maximum (found while staging: the slab passes through registers) and
@@ -456,6 +699,24 @@ int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
     LRPX_REQUIRE(M > 0 && M < 0x7fffffffL, "dense_f16x3: %ld rows out of range", M);
     LRPX_REQUIRE(plain || (long)a.n_maps * a.pix_per_map * a.oc_split < 0x7fffffffL, "dense_f16x3: too many multiplicand elements for 32-bit offsets");
     LRPX_REQUIRE(!(a.out1 && a.out1_amax) || a.pix_per_map >= 32, "dense_f16x3: out1_amax needs at least 32 rows per map");
+    // 128 x 256 tiles, waves side by side: the default for many rows and at least 256 columns with ONE output (REL: out0, or out1
+    // with its denominator); LRPX_DENSE_N256=0 or anything else: the 128 x 128 kernel
+    const bool one_out = plain || (a.out1 ? (!a.out0 && a.Zdiv) : true);
+    if (switches().dense_n256 && one_out && M >= 4096 && a.n_oc >= 256 && a.cin % DN_KC == 0 && M * a.cin < 0x7fffffffL
+        && (long)a.n_maps * a.oc_split < 0x7fffffffL && (!a.out1 || a.pix_per_map >= 32)) {
+        const long m_tiles = ceil_div(M, DN_BM);
+        const int n_blocks = (int)ceil_div(a.n_oc, DN_BN);
+        const long grid = ceil_div(m_tiles * n_blocks, 8) * 8;
+        LRPX_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "dense_f16x3: grid %ld out of range", grid);
+        static LdsOnce once_n[5];
+        const int v = plain ? 4 : (a.U ? 1 : 0) + (a.out1 ? 2 : 0);
+        auto kern = v == 4 ? dense_f16x3_n256_kernel<EPI_PLAIN, false, false>
+                    : (v == 0 ? dense_f16x3_n256_kernel<EPI_REL, false, false> : (v == 1 ? dense_f16x3_n256_kernel<EPI_REL, true, false>
+                    : (v == 2 ? dense_f16x3_n256_kernel<EPI_REL, false, true> : dense_f16x3_n256_kernel<EPI_REL, true, true>)));
+        LRPX_TRY(reserve_lds_once(once_n[v], kern, DN_LDS, "dense_f16x3_n256"));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), DN_LDS, stream, a, (int)m_tiles, n_blocks);
+        return check_launch("dense_f16x3_n256");
+    }
     const bool wide = switches().dense_wide && M >= 8192;      // 256-row tiles (8 waves) for many rows: measured slower, off (A/B)
     const long m_tiles = ceil_div(M, wide ? 256 : 128);
     const int n_blocks = (int)ceil_div(a.n_oc, DH_BN);

@@ -36,6 +36,7 @@ const Switches& switches() {
         w.s21_nhwc = set("LRPX_S21_NHWC");
         w.guided_poolbwd = set("LRPX_GUIDED_POOLBWD");
         w.dense_wide = num("LRPX_DENSE_WIDE", 0);
+        w.dense_n256 = num("LRPX_DENSE_N256", 1);
         w.dense_1wave = set("LRPX_DENSE_1WAVE");
         w.linear_valu = set("LRPX_LINEAR_VALU");
         return w;

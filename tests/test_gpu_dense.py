@@ -109,6 +109,63 @@ def test_dense_f16x3_rel_many_rows(ops, n_maps, P, k, n, n_img):
     print(f"dense f16x3 ({n_maps} maps x {P} rows, {k} -> {n}): worst map {worst:.2e} of its maximum")
 
 
+@pytest.mark.parametrize("n_maps,P,k,n,n_img", [(120, 36, 512, 2048, 7), (41, 196, 512, 512, 4), (131, 33, 64, 288, 3), (47, 100, 128, 1000, 5)])
+def test_dense_f16x3_n256_tiles_match_the_128_tiles_bitwise(ops, n_maps, P, k, n, n_img):
+    """dense_f16x3_n256_kernel (128 x 256 tiles, waves side by side: taken for >= 4096 rows, >= 256 columns and ONE output) against
+    dense_f16x3_kernel (taken when both outputs are asked for): the same products in the same order per accumulator, so out0,
+    out1 and out1_amax are BIT-identical, with and without the addend U; row counts off the 128-row tile, 288 / 1000 columns (a
+    partial column block: waves without a column tile of their own), an all-zero map; nothing written behind the outputs.
+    And EPI_PLAIN (scores with bias) through the same tiles against fp64."""
+    from lrp_amd import _lib
+    g = torch.Generator().manual_seed(n_maps * 11 + P)
+    a = torch.randn(n_maps, P, k, generator=g) * torch.exp(1.5 * torch.randn(n_maps, P, k, generator=g))
+    a = (a * torch.logspace(-10, 10, n_maps).view(-1, 1, 1)).cuda()
+    a[n_maps // 3] = 0.0
+    w = torch.randn(k, n, generator=g) * 0.05
+    x = torch.randn(n_img, P, n, generator=g).cuda()
+    u = (torch.randn(n_maps, n, generator=g) * 0.3).cuda() * a.abs().amax(dim=(1, 2)).view(-1, 1)
+    z = torch.randn(n_img, P, n, generator=g)
+    z[0, 0, :5] = 0.0
+    z = z.cuda()
+    m2i = torch.randint(0, n_img, (n_maps,), generator=g).to(torch.int32).cuda()
+    n_pad = -(-n // 32) * 32
+    rows = n_maps * P
+    assert rows >= 4096 and n_pad >= 256
+    wp = ops.pack_weights_f16x2(w.cuda(), k, n, _lib.PACK_BWD_PLAIN, taps=1)
+    amax_in = ops.amax_maps(a, n_maps)
+
+    def run(uu, want0, want1):
+        b0 = torch.full((rows * n + 4096,), 777.0, device="cuda") if want0 else None
+        b1 = torch.full((rows * n + 4096,), 777.0, device="cuda") if want1 else None
+        am = torch.zeros(n_maps, dtype=torch.int32, device="cuda")
+        ops.conv_mfma(a, wp, n_maps, 0, k, n_pad, 1, _lib.EPI_REL, pix_per_map=P, oc_split=n, x=x, u=uu, zdiv=z if want1 else None,
+                      stab=_lib.STAB_EPS, map2img=m2i, out0=b0[:rows * n] if want0 else None, out1=b1[:rows * n] if want1 else None,
+                      f16x3=1, in_amax=amax_in, out1_amax=am if want1 else None)
+        torch.cuda.synchronize()
+        for b in (b0, b1):
+            assert b is None or (b[rows * n:] == 777.0).all()
+        return (b0[:rows * n] if want0 else None), (b1[:rows * n] if want1 else None), am
+
+    for uu in (u, None):
+        ref0, ref1, ref_am = run(uu, True, True)            # both outputs: the 128 x 128 kernel
+        got0, _, _ = run(uu, True, False)                   # one output: the 128 x 256 kernel
+        _, got1, got_am = run(uu, False, True)
+        assert torch.equal(got0, ref0) and torch.equal(got1, ref1) and torch.equal(got_am, ref_am), ("addend" if uu is not None else "no addend")
+        assert ref0.abs().max().item() > 0
+    # PLAIN: out = A W + b, per-map operand scale
+    b = (torch.randn(n, generator=g) * 0.1).cuda()
+    buf = torch.full((rows * n + 4096,), 333.0, device="cuda")
+    a1 = a * torch.logspace(10, -10, n_maps, device="cuda").view(-1, 1, 1)       # maps back to O(1): the bias matters
+    ops.conv_mfma(a1, wp, n_maps, 0, k, n_pad, 1, _lib.EPI_PLAIN, pix_per_map=P, oc_split=n, bias=b, out0=buf[:rows * n], f16x3=1,
+                  in_amax=ops.amax_maps(a1, n_maps))
+    torch.cuda.synchronize()
+    assert (buf[rows * n:] == 333.0).all()
+    want = a1.double().view(rows, k) @ w.double().cuda() + b.double()
+    err = ((buf[:rows * n].view(rows, n).double() - want).abs().amax(dim=1) / want.abs().amax(dim=1)).max().item()
+    print(f"dense f16x3 n256 PLAIN ({rows} x {k} -> {n}): worst row {err:.2e} of its maximum")
+    assert err < 2e-6
+
+
 @pytest.mark.parametrize("rows,k,n,n_src", [(320, 512, 1536, 16), (1280, 512, 2048, 64), (37, 96, 64, 5), (640, 1024, 160, 640)])
 def test_dense_f16x3_rel_few_rows(ops, rows, k, n, n_src):
     """the lock-step gate rules on the fp16 matrix cores (dense_small_f16x3_kernel): out[row] = X[src(row)] * (A[row] W + U[row]),
