@@ -297,14 +297,29 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void dense_f16x3_kernel(
 // Same products in the same order per accumulator as dense_f16x3_kernel: bit-identical results.
 // The per-row constants of the epilogue (map, multiplicand row, result scale) are computed ONCE by the first 128 threads at the
 // start and parked in LDS: the epilogue's loads no longer hang on a chain row -> map -> image -> operand maximum.
-constexpr int DN_BM = 128, DN_BN = 256, DN_KC = 32, DN_KS = DN_KC / 16, DN_ROWB = DN_KS * 64 + 16, DN_BUF = DN_BM * DN_ROWB;
+#ifndef LRPXB_KC
+#define LRPXB_KC 32        // K chunk of the 128 x 256 kernel (one barrier and one commit per chunk)
+#endif
+constexpr int DN_BM = 128, DN_BN = 256, DN_KC = LRPXB_KC, DN_KS = DN_KC / 16, DN_ROWB = DN_KS * 64 + 16, DN_BUF = DN_BM * DN_ROWB;
 constexpr int DN_LDS = 2 * DN_BUF + DN_BM * 16;
+#ifdef LRPX_STAMP
+static __device__ unsigned long long g_stamp_dn[16384 * 10];      // per wave: start, loop start, loop end, stores issued, stores drained, sum issue..MFMAs, sum commit, sum barrier, HW_ID, XCC_ID
+#endif
+#ifndef LRPXB_NBQ
+#define LRPXB_NBQ 2        // B ring of the 128 x 256 kernel: k-steps in registers (2: one ahead; 3: two ahead - measured +-0, 16 registers more)
+#endif
 template <int EPI, bool HAS_U, bool HAS_O1>      // REL: with the addend U; writing out1 = r / stab(Zdiv) (+ its per-map maxima) instead of out0 = r
 __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
-    u32x4_* rowinfo = reinterpret_cast<u32x4_*>(ldsb + 2 * DN_BUF);       // [128] {map, multiplicand row offset, result scale, -}
+    unsigned* ri_n = reinterpret_cast<unsigned*>(ldsb + 2 * DN_BUF);        // [128] map of the row
+    unsigned* ri_xb = ri_n + DN_BM;                                         // [128] offset of its multiplicand row
+    float* ri_sc = reinterpret_cast<float*>(ri_n + 2 * DN_BM);              // [128] result scale 2^-kA 2^-kW
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LRPXH_T(ts0);
+#ifdef LRPX_STAMP
+    unsigned long long s_mfma = 0, s_commit = 0, s_barrier = 0;
+#endif
     const long total = (long)m_tiles * n_blocks;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const long t0 = (xcd * total) >> 3, t1 = ((xcd + 1) * total) >> 3;
@@ -325,17 +340,17 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
         const unsigned n = rc / P, p = rc - n * P;
         const unsigned img = EPI == EPI_PLAIN ? n : (unsigned)a.map2img[n];          // (REL: map2img is required)
         const float sc = exp2i(-f16_scale_exp(in_amax[n])) * inv_w;
-        rowinfo[tid] = u32x4_{n, (img * P + p) * (unsigned)ncol, __builtin_bit_cast(unsigned, sc), 0u};     // (< 2^31: host-checked)
+        ri_n[tid] = n; ri_xb[tid] = (img * P + p) * (unsigned)ncol; ri_sc[tid] = sc;     // (< 2^31: host-checked)
     }
 
-    // ---- staging: thread -> 4 items (row = tid / 8 + 32 u, 16-byte segment tid % 8 of the 128-byte chunk row)
-    constexpr int NU = 4;
-    const int s_row = tid >> 3, s_seg = tid & 7;
+    // ---- staging: thread -> NU items (row = tid / SEGS + RP u, 16-byte segment tid % SEGS of the chunk row)
+    constexpr int SEGS = DN_KC / 4, RP = 256 / SEGS, NU = DN_BM / RP;
+    const int s_row = tid / SEGS, s_seg = tid % SEGS;
     float ssc[NU];
     unsigned soff[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const long r = row0 + s_row + 32 * u;
+        const long r = row0 + s_row + RP * u;
         const unsigned rc = (unsigned)(r < M ? r : M - 1);        // rows past the end re-read the last row (results dropped)
         soff[u] = rc * (unsigned)K + s_seg * 4;                    // (M * K < 2^31: host-checked)
         ssc[u] = exp2i(f16_scale_exp(in_amax[rc / P]));
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
             f32x2_ f0_, f1_;
             split2_pk(f32x2_{sv[u][0], sv[u][1]} * f32x2_{ssc[u], ssc[u]}, h0_, l0_, f0_);
             split2_pk(f32x2_{sv[u][2], sv[u][3]} * f32x2_{ssc[u], ssc[u]}, h1_, l1_, f1_);
-            char* d_ = ldsb + bufi * DN_BUF + (s_row + 32 * u) * DN_ROWB + s_off;
+            char* d_ = ldsb + bufi * DN_BUF + (s_row + RP * u) * DN_ROWB + s_off;
             *reinterpret_cast<u32x2_*>(d_) = u32x2_{h0_, h1_};
             *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{l0_, l1_};
         }
@@ -368,13 +383,16 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     const int nks = K / 16;
     const u32x4_* wp0 = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) + (long)min(ocb0, ocb_last) * nks * 128 + lane;
     const u32x4_* wp1 = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) + (long)min(ocb0 + 1, ocb_last) * nks * 128 + lane;
-    u32x4_ bq[2][4];                 // [tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo] of k-steps s, s + 1
+    // B ring: k-step s + NBQ - 1 is loaded while k-step s multiplies (24 MFMAs = 768 matrix cycles per k-step)
+    constexpr int NBQ = LRPXB_NBQ;
+    u32x4_ bq[NBQ][4];               // [tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo]
     auto load_b = [&](const int ks, u32x4_ (&b)[4]) {
         const int k = min(ks, nks - 1);
         b[0] = wp0[(long)k * 128]; b[1] = wp0[(long)k * 128 + 64];
         b[2] = wp1[(long)k * 128]; b[3] = wp1[(long)k * 128 + 64];
     };
-    load_b(0, bq[0]);
+#pragma unroll
+    for (int i = 0; i < NBQ - 1; ++i) load_b(i, bq[i]);
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -386,51 +404,66 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
 
     commit(0);
     __syncthreads();
+    LRPXH_T(ts1);
     const int a_off = li * DN_ROWB + lh * 16;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        issue(min(chunk + 1, nchunk - 1));               // (past the last chunk: re-read it, nobody commits it)
-        __builtin_amdgcn_sched_barrier(0);               // keep the loads here (cf. dense_f16x3_kernel)
-        const char* abuf = ldsb + (chunk & 1) * DN_BUF + a_off;
-        // A fragments of a PAIR of row tiles one step ahead of their 12 MFMAs: [tile 2p hi, lo, tile 2p + 1 hi, lo]
-        f16x8 af[2][4];
-        auto read_pair = [&](const int t, f16x8 (&f)[4]) {
-            const char* q = abuf + (64 * (t & 1)) * DN_ROWB + (t >> 1) * 64;
-            f[0] = *reinterpret_cast<const f16x8*>(q);
-            f[1] = *reinterpret_cast<const f16x8*>(q + 32);
-            f[2] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB);
-            f[3] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB + 32);
-        };
-        read_pair(0, af[0]);
-        __builtin_amdgcn_sched_barrier(0);
+    // (NBQ chunks per loop iteration: the ring positions are compile-time constants - 2 NBQ k-steps, a multiple of the ring)
+    for (int c0 = 0; c0 < nchunk; c0 += NBQ) {
 #pragma unroll
-        for (int t = 0; t < 2 * DN_KS; ++t) {           // t = 2 * k-step + pair
-            const int s = t >> 1, pr = t & 1;
-            if (pr == 0) load_b(chunk * DN_KS + s + 1, bq[(s + 1) & 1]);
-            if (t + 1 < 2 * DN_KS) read_pair(t + 1, af[(t + 1) & 1]);
+        for (int cc = 0; cc < NBQ; ++cc) {
+            const int chunk = c0 + cc;
+            if (chunk >= nchunk) break;                      // (uniform)
+            LRPXH_T(ta);
+            issue(min(chunk + 1, nchunk - 1));               // (past the last chunk: re-read it, nobody commits it)
+            __builtin_amdgcn_sched_barrier(0);               // keep the loads here (cf. dense_f16x3_kernel)
+            const char* abuf = ldsb + (chunk & 1) * DN_BUF + a_off;
+            // A fragments of a PAIR of row tiles one step ahead of their 12 MFMAs: [tile 2p hi, lo, tile 2p + 1 hi, lo]
+            f16x8 af[2][4];
+            auto read_pair = [&](const int t, f16x8 (&f)[4]) {
+                const char* q = abuf + (64 * (t & 1)) * DN_ROWB + (t >> 1) * 64;
+                f[0] = *reinterpret_cast<const f16x8*>(q);
+                f[1] = *reinterpret_cast<const f16x8*>(q + 32);
+                f[2] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB);
+                f[3] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB + 32);
+            };
+            read_pair(0, af[0]);
             __builtin_amdgcn_sched_barrier(0);
-            const f16x8 a0h = af[t & 1][0], a0l = af[t & 1][1], a1h = af[t & 1][2], a1l = af[t & 1][3];
-            const u32x4_(&b)[4] = bq[s & 1];
-            const f16x8 b0h = __builtin_bit_cast(f16x8, b[0]), b0l = __builtin_bit_cast(f16x8, b[1]);
-            const f16x8 b1h = __builtin_bit_cast(f16x8, b[2]), b1l = __builtin_bit_cast(f16x8, b[3]);
-            f32x16 &c00 = acc[2 * pr][0], &c01 = acc[2 * pr][1], &c10 = acc[2 * pr + 1][0], &c11 = acc[2 * pr + 1][1];
-            // small terms first
-            c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, c11, 0, 0, 0);
-            c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0l, c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1l, c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0l, c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1l, c11, 0, 0, 0);
-            c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, c11, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2 * DN_KS; ++t) {           // t = 2 * k-step + pair
+                const int s = t >> 1, pr = t & 1;
+                const int q = cc * DN_KS + s;                // position of the k-step in the iteration: static ring indices
+                if (pr == 0) load_b(chunk * DN_KS + s + NBQ - 1, bq[(q + NBQ - 1) % NBQ]);
+                if (t + 1 < 2 * DN_KS) read_pair(t + 1, af[(t + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 a0h = af[t & 1][0], a0l = af[t & 1][1], a1h = af[t & 1][2], a1l = af[t & 1][3];
+                const u32x4_(&b)[4] = bq[q % NBQ];
+                const f16x8 b0h = __builtin_bit_cast(f16x8, b[0]), b0l = __builtin_bit_cast(f16x8, b[1]);
+                const f16x8 b1h = __builtin_bit_cast(f16x8, b[2]), b1l = __builtin_bit_cast(f16x8, b[3]);
+                f32x16 &c00 = acc[2 * pr][0], &c01 = acc[2 * pr][1], &c10 = acc[2 * pr + 1][0], &c11 = acc[2 * pr + 1][1];
+                // small terms first
+                c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, c11, 0, 0, 0);
+                c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0l, c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1l, c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0l, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1l, c11, 0, 0, 0);
+                c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, c11, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            LRPXH_T(tb);
+            if (chunk + 1 < nchunk) commit((chunk + 1) & 1);
+            LRPXH_T(tc);
+            __syncthreads();
+#ifdef LRPX_STAMP
+            { LRPXH_T(td); s_mfma += tb - ta; s_commit += tc - tb; s_barrier += td - tc; }
+#endif
         }
-        if (chunk + 1 < nchunk) commit((chunk + 1) & 1);
-        __syncthreads();
     }
+    LRPXH_T(ts2);
 
     // ---- epilogue (EPI_REL of conv_mfma.h / EPI_PLAIN): element e of tile (i, j): row = row0 + 32 i + (e&3) + 8 (e>>2) + 4 lh,
     // column = 32 (ocb0 + j) + li.  STRAIGHT-LINE code: which operands exist is a template parameter (a branch on `U != null`
@@ -444,78 +477,99 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     const int nmax = a.n_maps - 1;
     float mres[4][2];
     unsigned nres[4];
-    const int oc0 = ocb0 * 32 + li;
-    const float bv0 = (EPI == EPI_PLAIN && a.bias) ? a.bias[min(oc0, ncol - 1)] : 0.f;
-    const float bv1 = (EPI == EPI_PLAIN && a.bias) ? a.bias[min(oc0 + 32, ncol - 1)] : 0.f;
     const int stab = a.stab;
-    constexpr int JB = (HAS_U || HAS_O1) ? 1 : 2;        // column tiles whose loads are in flight together (registers)
+    // Units of one accumulator tile (i = u / 2, j = u % 2).  The tile goes through a per-wave LDS scratch (the A buffers are free after
+    // the last barrier) into ROW-MAJOR lanes - lane l holds rows l / 8 + 8 q, columns 4 (l % 8) .. + 3 - so that the multiplicand, the
+    // addend, the denominator and the result move as 16 bytes per lane: 4 + 4 memory instructions per tile instead of 16 + 16, every
+    // wave instruction 8 rows x 128 bytes.  (With dword accesses the epilogue ran at 3.8 TB/s of stores when it was all the kernel
+    // did - K = 64 - against 6.9 for a fill of the same bytes.)  The loads of unit u + 1 are in flight while unit u is finished.
+    float* scr = reinterpret_cast<float*>(ldsb) + wave * (32 * 36);            // [32 rows][36]: 16-byte aligned rows, conflict-free both ways
+    const int tr = lane >> 3, tc = (lane & 7) * 4;
+    constexpr int DEPTH = 2;
+    f32x4 xr[DEPTH][4], ur[HAS_U ? DEPTH : 1][4], zr[HAS_O1 ? DEPTH : 1][4];
+    auto issue_u = [&](const int u) {
+        if constexpr (EPI != EPI_PLAIN) {
+            const int i = u >> 1, j = u & 1;
+            const unsigned oc = (unsigned)min((ocb0 + j) * 32 + tc, ncol - 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+            for (int q = 0; q < 4; ++q) {
+                const int row = 32 * i + tr + 8 * q;
+                const unsigned xb = ri_xb[row];
+                xr[u % DEPTH][q] = *reinterpret_cast<const f32x4*>(X + xb + oc);
+                if constexpr (HAS_U) ur[u % DEPTH][q] = *reinterpret_cast<const f32x4*>(Uu + ri_n[row] * (unsigned)ncol + oc);   // (n_maps * ncol < 2^31: host-checked)
+                if constexpr (HAS_O1) zr[u % DEPTH][q] = *reinterpret_cast<const f32x4*>(Zd + xb + oc);
+            }
+        }
+    };
+    auto finish_u = [&](const int u) {
+        const int i = u >> 1, j = u & 1;
         const long rt = row0 + 32 * i;
-        unsigned nn[16], xb[16];
-        float sc[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const u32x4_ ri = rowinfo[32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh];
-            const unsigned scb = ri[2];          // (a scalar copy first: __builtin_bit_cast of a vector ELEMENT reads element 0, clang)
-            nn[e] = ri[0]; xb[e] = ri[1]; sc[e] = __builtin_bit_cast(float, scb);
-        }
-        const unsigned nt0 = rowinfo[32 * i][0];
-        float m0 = 0.f, m1 = 0.f;
-        // stores: one scalar base per row tile + a 32-bit offset (rows of the tile x ncol < 2^31), rows / columns past the end masked
-        float* __restrict__ orow = out + rt * ncol;
+        float* __restrict__ orow = out + rt * ncol;           // one scalar base per row tile + a 32-bit offset (32 rows x ncol < 2^31)
         const int mrem = (int)(M - rt < 32 ? M - rt : 32);
-        if constexpr (EPI == EPI_PLAIN) {
+        const int oc = (ocb0 + j) * 32 + tc;
+        const unsigned nt0 = ri_n[32 * i];
+        if (j == 0) { mres[i][0] = 0.f; mres[i][1] = 0.f; nres[i] = nt0; }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int oc = oc0 + 32 * j;
+        for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + li] = acc[i][j][e];
+        // (same wave, LDS instructions execute in order: the reads below see the writes above)
+        f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_PLAIN) { if (a.bias) bv4 = *reinterpret_cast<const f32x4*>(a.bias + min(oc, ncol - 4)); }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rl = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    float v = acc[i][j][e] * sc[e] + (j ? bv1 : bv0);
-                    if (a.relu) v = v > 0.f ? v : 0.f;
-                    if (rl < mrem && oc < ncol) orow[(unsigned)(rl * ncol + oc)] = v;
+        for (int q = 0; q < 4; ++q) {
+            const int rl = tr + 8 * q;
+            const bool ok = rl < mrem && oc < ncol;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(scr + rl * 36 + tc);
+            const float sc = ri_sc[32 * i + rl];
+            f32x4 res;
+            if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    res[c] = __builtin_fmaf(av[c], sc, bv4[c]);
+                    if (a.relu) res[c] = res[c] > 0.f ? res[c] : 0.f;
+                }
+            } else {
+                f32x4 rel;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)          // (the same two roundings as the dword epilogue: fma, then the product)
+                    rel[c] = xr[u % DEPTH][q][c] * __builtin_fmaf(av[c], sc, HAS_U ? ur[u % DEPTH][q][c] : 0.f);
+                if constexpr (!HAS_O1) {
+                    res = rel;
+                } else {
+                    float mx = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float z = zr[u % DEPTH][q][c];
+                        z = (stab == STAB_SAFE) ? stab_safe(z) : ((stab == STAB_EPS) ? stab_eps(z) : z);
+                        res[c] = fast_div(rel[c], z);
+                        mx = fmaxf(mx, fabsf(res[c]));
+                    }
+                    if (ok) { if (ri_n[32 * i + rl] == nt0) mres[i][0] = fmaxf(mres[i][0], mx); else mres[i][1] = fmaxf(mres[i][1], mx); }
                 }
             }
-        } else {
-#pragma unroll
-            for (int j0 = 0; j0 < 2; j0 += JB) {
-                float xv[JB][16], uv[JB][16], zv[JB][16];
-#pragma unroll
-                for (int jj = 0; jj < JB; ++jj) {
-                    const unsigned oc = (unsigned)min(oc0 + 32 * (j0 + jj), ncol - 1);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        xv[jj][e] = X[xb[e] + oc];
-                        uv[jj][e] = HAS_U ? Uu[nn[e] * (unsigned)ncol + oc] : 0.f;          // (n_maps * ncol < 2^31: host-checked)
-                        zv[jj][e] = HAS_O1 ? Zd[xb[e] + oc] : 1.f;
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < JB; ++jj) {
-                    const int oc = oc0 + 32 * (j0 + jj);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int rl = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        const bool ok = rl < mrem && oc < ncol;
-                        const float rel = xv[jj][e] * (acc[i][j0 + jj][e] * sc[e] + uv[jj][e]);
-                        if constexpr (!HAS_O1) {
-                            if (ok) orow[(unsigned)(rl * ncol + oc)] = rel;
-                        } else {
-                            float z = zv[jj][e];
-                            z = (stab == STAB_SAFE) ? stab_safe(z) : ((stab == STAB_EPS) ? stab_eps(z) : z);
-                            const float sv_ = fast_div(rel, z);
-                            if (ok) {
-                                orow[(unsigned)(rl * ncol + oc)] = sv_;
-                                if (nn[e] == nt0) m0 = fmaxf(m0, fabsf(sv_)); else m1 = fmaxf(m1, fabsf(sv_));
-                            }
-                        }
-                    }
-                }
-            }
+            if (ok) *reinterpret_cast<f32x4*>(orow + (unsigned)(rl * ncol + oc)) = res;
         }
-        mres[i][0] = m0; mres[i][1] = m1; nres[i] = nt0;
+    };
+    issue_u(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u + 1 < 8) issue_u(u + 1);
+        finish_u(u);
     }
+#ifdef LRPX_STAMP
+    {
+        LRPXH_T(ts3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the stores acknowledged)
+        LRPXH_T(ts4);
+        unsigned hwid, xccid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xccid));
+        const unsigned w = blockIdx.x * 4 + wave;
+        if (lane == 0 && w < 16384) {
+            unsigned long long* r = g_stamp_dn + (unsigned long)w * 10;
+            r[0] = ts0; r[1] = ts1; r[2] = ts2; r[3] = ts3; r[4] = ts4; r[5] = s_mfma; r[6] = s_commit; r[7] = s_barrier; r[8] = hwid; r[9] = (xccid & 15) | ((unsigned long long)blockIdx.x << 8);
+        }
+    }
+#endif
     if constexpr (HAS_O1) {
         if (oamax) {
 #pragma unroll
@@ -702,7 +756,9 @@ int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
     // 128 x 256 tiles, waves side by side: the default for many rows and at least 256 columns with ONE output (REL: out0, or out1
     // with its denominator); LRPX_DENSE_N256=0 or anything else: the 128 x 128 kernel
     const bool one_out = plain || (a.out1 ? (!a.out0 && a.Zdiv) : true);
-    if (switches().dense_n256 && one_out && M >= 4096 && a.n_oc >= 256 && a.cin % DN_KC == 0 && M * a.cin < 0x7fffffffL
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };      // (its epilogue moves 16 bytes per lane)
+    const bool aligned = al16(a.X) && al16(a.U) && al16(a.Zdiv) && al16(a.out0) && al16(a.out1) && al16(a.bias);
+    if (switches().dense_n256 && one_out && aligned && M >= 4096 && a.n_oc >= 256 && a.oc_split % 4 == 0 && a.cin % DN_KC == 0 && M * a.cin < 0x7fffffffL
         && (long)a.n_maps * a.oc_split < 0x7fffffffL && (!a.out1 || a.pix_per_map >= 32)) {
         const long m_tiles = ceil_div(M, DN_BM);
         const int n_blocks = (int)ceil_div(a.n_oc, DN_BN);
@@ -738,3 +794,11 @@ int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
 }
 
 }  // namespace lrpx
+#ifdef LRPX_STAMP
+extern "C" int lrpx_debug_stamps_dn(unsigned long long* out, int n_waves, int reset) {
+    if (n_waves > 16384) return 2;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lrpx::g_stamp_dn), (size_t)n_waves * 80) != hipSuccess) return 1;
+    if (reset) { if (hipMemset(nullptr, 0, 0) != hipSuccess) {} }
+    return 0;
+}
+#endif
