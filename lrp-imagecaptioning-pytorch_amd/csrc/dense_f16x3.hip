@@ -305,6 +305,9 @@ constexpr int DN_LDS = 2 * DN_BUF + DN_BM * 16;
 #ifdef LRPX_STAMP
 static __device__ unsigned long long g_stamp_dn[16384 * 10];      // per wave: start, loop start, loop end, stores issued, stores drained, sum issue..MFMAs, sum commit, sum barrier, HW_ID, XCC_ID
 #endif
+#ifndef LRPXB_SHADOW
+#define LRPXB_SHADOW 1     // the 128 x 256 kernel converts / commits the next chunk between the MFMAs of the current one (0: a commit phase per chunk)
+#endif
 #ifndef LRPXB_NBQ
 #define LRPXB_NBQ 2        // B ring of the 128 x 256 kernel: k-steps in registers (2: one ahead; 3: two ahead - measured +-0, 16 registers more)
 #endif
@@ -356,26 +359,28 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
         ssc[u] = exp2i(f16_scale_exp(in_amax[rc / P]));
     }
     const int s_off = (s_seg >> 2) * 64 + ((s_seg >> 1) & 1) * 16 + (s_seg & 1) * 8;
-    f32x4 sv[NU];
+    constexpr bool SHADOW = LRPXB_SHADOW != 0;      // the next chunk's conversion + LDS writes between the MFMAs of this one (loads two chunks ahead)
+    f32x4 sv[SHADOW ? 2 : 1][NU];
     const float* __restrict__ A = a.in;
-    auto issue = [&](const int chunk) {
+    auto issue = [&](const int chunk, const int set) {
         const float* __restrict__ Ac = A + chunk * DN_KC;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) sv[u] = *reinterpret_cast<const f32x4*>(Ac + soff[u]);
+        for (int u = 0; u < NU; ++u) sv[set][u] = *reinterpret_cast<const f32x4*>(Ac + soff[u]);
     };
-    auto commit = [&](const int bufi) {
+    auto commit_item = [&](const int bufi, const int set, const int u) {
+        unsigned h0_, h1_, l0_, l1_;
+        f32x2_ f0_, f1_;
+        split2_pk(f32x2_{sv[set][u][0], sv[set][u][1]} * f32x2_{ssc[u], ssc[u]}, h0_, l0_, f0_);
+        split2_pk(f32x2_{sv[set][u][2], sv[set][u][3]} * f32x2_{ssc[u], ssc[u]}, h1_, l1_, f1_);
+        char* d_ = ldsb + bufi * DN_BUF + (s_row + RP * u) * DN_ROWB + s_off;
+        *reinterpret_cast<u32x2_*>(d_) = u32x2_{h0_, h1_};
+        *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{l0_, l1_};
+    };
+    auto commit = [&](const int bufi, const int set) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            unsigned h0_, h1_, l0_, l1_;
-            f32x2_ f0_, f1_;
-            split2_pk(f32x2_{sv[u][0], sv[u][1]} * f32x2_{ssc[u], ssc[u]}, h0_, l0_, f0_);
-            split2_pk(f32x2_{sv[u][2], sv[u][3]} * f32x2_{ssc[u], ssc[u]}, h1_, l1_, f1_);
-            char* d_ = ldsb + bufi * DN_BUF + (s_row + RP * u) * DN_ROWB + s_off;
-            *reinterpret_cast<u32x2_*>(d_) = u32x2_{h0_, h1_};
-            *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{l0_, l1_};
-        }
+        for (int u = 0; u < NU; ++u) commit_item(bufi, set, u);
     };
-    issue(0);
+    issue(0, 0);
 
     // ---- B fragments of the wave's two column tiles: [ocb][k-step][plane 2][lane 64][16 B], one k-step ahead in registers
     const int ocb0 = nblk * 8 + wave * 2;
@@ -402,10 +407,12 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    commit(0);
+    commit(0, 0);
+    if constexpr (SHADOW) issue(min(1, nchunk - 1), 1);
     __syncthreads();
     LRPXH_T(ts1);
     const int a_off = li * DN_ROWB + lh * 16;
+    static_assert(!SHADOW || (NU == 2 * DN_KS && NBQ == 2), "one staging item per (k-step, pair) step; two chunks per loop trip");
     // (NBQ chunks per loop iteration: the ring positions are compile-time constants - 2 NBQ k-steps, a multiple of the ring)
     for (int c0 = 0; c0 < nchunk; c0 += NBQ) {
 #pragma unroll
@@ -413,7 +420,9 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
             const int chunk = c0 + cc;
             if (chunk >= nchunk) break;                      // (uniform)
             LRPXH_T(ta);
-            issue(min(chunk + 1, nchunk - 1));               // (past the last chunk: re-read it, nobody commits it)
+            // SHADOW: chunk + 2 into the register set chunk's data left at the end of the previous trip (set index = cc: c0 is even)
+            if constexpr (SHADOW) issue(min(chunk + 2, nchunk - 1), cc & 1);
+            else issue(min(chunk + 1, nchunk - 1), 0);       // (past the last chunk: re-read it, nobody commits it)
             __builtin_amdgcn_sched_barrier(0);               // keep the loads here (cf. dense_f16x3_kernel)
             const char* abuf = ldsb + (chunk & 1) * DN_BUF + a_off;
             // A fragments of a PAIR of row tiles one step ahead of their 12 MFMAs: [tile 2p hi, lo, tile 2p + 1 hi, lo]
@@ -434,6 +443,10 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
                 if (pr == 0) load_b(chunk * DN_KS + s + NBQ - 1, bq[(q + NBQ - 1) % NBQ]);
                 if (t + 1 < 2 * DN_KS) read_pair(t + 1, af[(t + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
+                // SHADOW: item t of the NEXT chunk (loaded a chunk ago) is scaled, split and written to the other buffer under these
+                // 12 MFMAs - two vector instructions behind each (the vector issue is free for most of an MFMA's 32 cycles)
+                // (no branch around it - the scheduler mixes within a basic block only: the last chunk writes a copy of itself into the idle buffer)
+                if constexpr (SHADOW) commit_item((chunk + 1) & 1, (cc + 1) & 1, t);
                 const f16x8 a0h = af[t & 1][0], a0l = af[t & 1][1], a1h = af[t & 1][2], a1l = af[t & 1][3];
                 const u32x4_(&b)[4] = bq[q % NBQ];
                 const f16x8 b0h = __builtin_bit_cast(f16x8, b[0]), b0l = __builtin_bit_cast(f16x8, b[1]);
@@ -452,10 +465,20 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
                 c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, c01, 0, 0, 0);
                 c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, c10, 0, 0, 0);
                 c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, c11, 0, 0, 0);
+                if constexpr (SHADOW) {
+#pragma unroll
+                    for (int g = 0; g < 10; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two vector instructions
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);          // the LDS writes
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             LRPXH_T(tb);
-            if (chunk + 1 < nchunk) commit((chunk + 1) & 1);
+            if constexpr (!SHADOW) { if (chunk + 1 < nchunk) commit((chunk + 1) & 1, 0); }
             LRPXH_T(tc);
             __syncthreads();
 #ifdef LRPX_STAMP
