@@ -1027,12 +1027,19 @@ int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* s
         return LRPX_ELAUNCH;
     }
     const long per4 = per / 4, total = (long)n_maps * per4;
-    if (per4 % 2048 == 0)
-        hipLaunchKernelGGL(amax_maps_kernel<8>, dim3(grid_for(total, 2048)), dim3(256), 0, (hipStream_t)stream, s, per4, total, amax);
-    else if (per4 % 1792 == 0)
-        hipLaunchKernelGGL(amax_maps_kernel<7>, dim3(grid_for(total, 1792)), dim3(256), 0, (hipStream_t)stream, s, per4, total, amax);
-    else
-        hipLaunchKernelGGL(amax_maps_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, per4, total, amax);
+    // ITER float4 per thread where 256 * ITER divides a map (one atomic per block of 256 * ITER float4, ITER loads in flight per thread)
+    const long q = per4 % 256 == 0 ? per4 / 256 : 0;
+    auto go = [&](auto kern, int iter) {
+        hipLaunchKernelGGL(kern, dim3(grid_for(total, 256 * iter)), dim3(256), 0, (hipStream_t)stream, s, per4, total, amax);
+    };
+    if (q && q % 8 == 0) go(amax_maps_kernel<8>, 8);
+    else if (q && q % 7 == 0) go(amax_maps_kernel<7>, 7);
+    else if (q && q % 9 == 0) go(amax_maps_kernel<9>, 9);          // (36 rows x 512: the bottom-up projector rules)
+    else if (q && q % 6 == 0) go(amax_maps_kernel<6>, 6);
+    else if (q && q % 4 == 0) go(amax_maps_kernel<4>, 4);
+    else if (q && q % 3 == 0) go(amax_maps_kernel<3>, 3);
+    else if (q && q % 2 == 0) go(amax_maps_kernel<2>, 2);
+    else go(amax_maps_kernel<1>, 1);
     return check_launch("amax_maps");
 }
 

@@ -109,6 +109,19 @@ def test_dense_f16x3_rel_many_rows(ops, n_maps, P, k, n, n_img):
     print(f"dense f16x3 ({n_maps} maps x {P} rows, {k} -> {n}): worst map {worst:.2e} of its maximum")
 
 
+@pytest.mark.parametrize("per", [36 * 512, 196 * 512, 1024, 2048, 3072, 4096, 6144, 8192, 100, 4 * 1037])
+def test_amax_maps_exact_for_every_block_shape(ops, per):
+    """lrpx_amax_maps: float bits of max|.| per map, exact, for every float4-per-thread instantiation (256 * ITER float4 dividing
+    a map, ITER = 9 / 7 / 1 / 2 / 3 / 4 / 6 / 8) and for map sizes no block divides; a map of zeros gives 0; negative maxima count"""
+    n_maps = 37
+    g = torch.Generator().manual_seed(per)
+    a = torch.randn(n_maps, per, generator=g) * torch.logspace(-20, 20, n_maps).view(-1, 1)
+    a[5] = 0.0
+    a[7, per // 2] = -3e30
+    got = ops.amax_maps(a.cuda(), n_maps).view(torch.float32).cpu()
+    assert torch.equal(got, a.abs().amax(dim=1))
+
+
 @pytest.mark.parametrize("n_maps,P,k,n,n_img", [(120, 36, 512, 2048, 7), (41, 196, 512, 512, 4), (131, 33, 64, 288, 3), (47, 100, 128, 1000, 5)])
 def test_dense_f16x3_n256_tiles_match_the_128_tiles_bitwise(ops, n_maps, P, k, n, n_img):
     """dense_f16x3_n256_kernel (128 x 256 tiles, waves side by side: taken for >= 4096 rows, >= 256 columns and ONE output) against
