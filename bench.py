@@ -644,6 +644,11 @@ def roofline(a, lib, eng, state, maps, B, T, mode):
         "chain_frac": round(PRODUCTS[mode] * chain_alg / peak, 4),
         "chain_frac_note": "sum of the 13 layers' algorithmic flop / sum of their launch times (HIP events per launch), same accounting as frac",
         "per_layer": table,
+        "peak_note": ("`peak` is the guide's nominal dense fp16 rate.  Measured on this part the matrix cores' rate depends on the operands "
+                      "(power-limited clock): v_mfma_f32_32x32x16_f16 from registers runs at 2484 TFLOP/s on zeros and at 1656 on random "
+                      "fp16 operands (tools/micro/mfma_f16_peak.hip, profiles/r04_mfma_f16_peak.txt); this path's instruction mix from "
+                      "registers reaches 1050 algorithmic TFLOP/s (tools/micro/mfma_lds.hip, profiles/r04_mfma_lds.txt) against the "
+                      "nominal 1667"),
         "accounting": ("executed matrix flop = algorithmic x products; mode 3 executes 1 fp16 + 2 fp6 products per fp32 "
                        "product and an fp6 flop counts 1/4 (fp6 dense peak = 4 x fp16 peak; the path's roof is 2500 / 1.5 = 1667 "
                        "algorithmic TFLOP/s, 1250 with the fp8 cross products of rounds 1-2), so achieved/peak = matrix "
