@@ -109,18 +109,17 @@ class AOAEngine:
 
     def _alloc_trace(self, B, T, P, grad=False):
         dev, H, E, NH = self.device, self.H, self.E, self.NH
-        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
-        tr = dict(B=B, T=T, P=P)
-        tr["xh"] = z(B, T, E + 2 * H)
-        tr["h"], tr["c"] = z(B, T + 1, H), z(B, T + 1, H)
+        shapes = {"xh": (B, T, E + 2 * H), "h": (B, T + 1, H), "c": (B, T + 1, H), "alpha": (B, T, NH, P)}
         for k in ("g", "i", "f", "ctx", "lin", "c_aoa", "hc"):
-            tr[k] = z(B, T, H)
-        tr["alpha"] = z(B, T, NH, P)
+            shapes[k] = (B, T, H)
+        if grad:      # the gradient explainers also keep the output gate and sigmoid(aoa gate)  (:1309-1376)
+            shapes["o"], shapes["sg"] = (B, T, H), (B, T, H)
+        tr = dict(B=B, T=T, P=P)
+        tr.update(ops.zeros_arena(dev, shapes))            # one allocation, one fill
         c = AoaTrace()
         c.B, c.T, c.H, c.E, c.P, c.NH = B, T, H, E, P, NH
         names = ["xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha"]
-        if grad:      # the gradient explainers also keep the output gate and sigmoid(aoa gate)  (:1309-1376)
-            tr["o"], tr["sg"] = z(B, T, H), z(B, T, H)
+        if grad:
             names += ["o", "sg"]
         for k in names:
             setattr(c, k, ptr(tr[k]))

@@ -83,20 +83,19 @@ class GridTDEngine:
     # ------------------------------------------------------------------------------------------
     def _alloc_trace(self, B, T, grad=False):
         dev, H, E, P = self.device, self.H, self.E, self.P
-        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
-        tr = dict(B=B, T=T)
-        tr["xh1"], tr["xh2"] = z(B, T, 2 * E + 2 * H), z(B, T, 3 * H)
+        shapes = {"xh1": (B, T, 2 * E + 2 * H), "xh2": (B, T, 3 * H), "alpha": (B, T, P), "beta": (B, T)}
         for k in ("h1", "c1", "h2", "c2"):
-            tr[k] = z(B, T + 1, H)
+            shapes[k] = (B, T + 1, H)
         for k in ("g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat", "hc"):
-            tr[k] = z(B, T, H)
-        tr["alpha"], tr["beta"] = z(B, T, P), z(B, T)
+            shapes[k] = (B, T, H)
         names = ["xh1", "xh2", "h1", "c1", "h2", "c2", "g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat", "hc",
                  "alpha", "beta"]
         if grad:     # the gradient explainers also keep the output gates and the sentinel gate (:1323-1422)
             for k in ("o1", "o2", "sgate"):
-                tr[k] = z(B, T, H)
+                shapes[k] = (B, T, H)
             names += ["o1", "o2", "sgate"]
+        tr = dict(B=B, T=T)
+        tr.update(ops.zeros_arena(dev, shapes))            # one allocation, one fill
         c = GridTrace()
         c.B, c.T, c.H, c.E, c.P = B, T, H, E, P
         for k in names:
