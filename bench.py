@@ -271,16 +271,17 @@ def main():
 
 
 def other_configs(a):
-    """BASELINE configs 3 / 4 / 5 and the 64-image gridTD batch, measured in this process after the headline: 2 warm-up +
+    """BASELINE configs 3 / 4 / 5 and the 64-image gridTD batch, measured in this process after the headline: 4 warm-up (one
+    more than the batches in flight: every replica - its buffers come from an allocator emptied just before - has run once) +
     `n` timed steps each with that config's own batches in flight, no sustained leg, no mode sweep, no CPU baseline."""
     import gc
     res = {}
     todo = [("3", ["--config", "3"], 6), ("3_all_heads", ["--config", "3", "--all-heads"], 2),
-            ("4", ["--config", "4"], 6), ("5", ["--config", "5"], 40), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 6)]
+            ("4", ["--config", "4"], 6), ("5", ["--config", "5"], 80), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 6)]
     for key, argv, n in todo:
         gc.collect()
         torch.cuda.empty_cache()
-        b = parse(argv + ["--steps", str(n), "--warmup", "2", "--sustain", "0", "--no-modes", "--no-cpu-baseline", "--no-configs",
+        b = parse(argv + ["--steps", str(n), "--warmup", "4", "--sustain", "0", "--no-modes", "--no-cpu-baseline", "--no-configs",
                           "--conv-mode", str(a.conv_mode)])
         o = run_config(b, None, 0, 1)
         r = o.get("roofline") or {}
