@@ -617,6 +617,9 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
 // B queue: 11 k-steps ahead (a k-step is 3 MFMAs = 96 matrix cycles, an L2 round trip ~1000: 5 ahead left the K loop bound by
 // the load latency - 28 us per GEMM against 25 for the fp32 kernel it replaces)
 constexpr int DS_NB = 12;
+#ifndef LRPXD_EARLY
+#define LRPXD_EARLY 1     // few-row kernel, K = 512: the epilogue's multiplicand / addend loads issued before the K loop (0: in the epilogue)
+#endif
 #ifndef LRPXD_EXP
 #define LRPXD_EXP 0       // timing experiments (wrong results): 1 no multiplicand / addend loads in the epilogue, 2 no K loop, 4 no A staging, 8 no stores
 #endif
@@ -639,6 +642,22 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
     u32x4_ bq[DS_NB][2];
 #pragma unroll
     for (int i = 0; i < DS_NB - 1; ++i) { bq[i][0] = wp[(long)min(i, nks - 1) * 128]; bq[i][1] = wp[(long)min(i, nks - 1) * 128 + 64]; }
+    // EARLY (K = 512, where the registers allow it): the epilogue's operands do not depend on the product - the row -> source-row
+    // lookups are issued HERE, the multiplicands and addends right after the slab has gone to LDS, and both arrive under the K loop:
+    // three dependent round trips (~3.5 of the kernel's 17 us) leave the epilogue.  Same arithmetic, bit-identical.
+    constexpr bool EARLY = (LRPXD_EARLY != 0) && MAXU == 16;
+    const int* __restrict__ m2i = a.map2img;
+    const unsigned P = (unsigned)a.pix_per_map;
+    const unsigned last = (unsigned)(rows - 1);
+    int img_e[16];
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const unsigned row = min((unsigned)row0 + (unsigned)((e & 3) + 8 * (e >> 2) + 4 * lh), last);
+            const unsigned n = P == 1u ? row : row / P;
+            img_e[e] = (m2i && !(LRPXD_EXP & 1)) ? m2i[n] : (int)n;
+        }
+    }
     if (tid < 32) rowmax[tid] = 0u;
     __syncthreads();
     // pass 1: the slab through registers, row maxima into LDS.  BRANCH-FREE: every load is issued unconditionally (rows past the
@@ -687,6 +706,20 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
             }
         }
     }
+    const int ncol = a.oc_split;
+    const float* __restrict__ X = a.X;
+    const float* __restrict__ Uu = a.U;
+    float xv[16], uv[16];
+    if constexpr (EARLY) {
+        const int occ = min(ocb * 32 + li, ncol - 1);          // (a lane past the last column loads the last one and stores nothing)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const unsigned row = min((unsigned)row0 + (unsigned)((e & 3) + 8 * (e >> 2) + 4 * lh), last);
+            const unsigned n = P == 1u ? row : row / P, p = P == 1u ? 0u : row - n * P;
+            xv[e] = (LRPXD_EXP & 1) ? 1.f : X[((long)img_e[e] * P + p) * ncol + occ];
+            uv[e] = (Uu && !(LRPXD_EXP & 1)) ? Uu[(long)n * ncol + occ] : 0.f;
+        }
+    }
     __syncthreads();
     if (!wave_active) return;
     f32x16 acc;
@@ -712,31 +745,26 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
         }
     }
     const int oc = ocb * 32 + li;
-    const int ncol = a.oc_split;
     if (oc >= ncol) return;
-    const unsigned P = (unsigned)a.pix_per_map;
     const float inv_w = a.wp[0];
-    // (branch-free as the staging: all 16 row -> source-row lookups, then all 16 multiplicands / addends, then the stores;
-    // 32-bit index arithmetic - rows < 2^31 host-checked - and no division at all for the lock-step rules' pix_per_map = 1)
-    float xv[16], uv[16];
-    long src[16];
-    unsigned nn[16];
-    const int* __restrict__ m2i = a.map2img;
-    const float* __restrict__ X = a.X;
-    const float* __restrict__ Uu = a.U;
-    const unsigned last = (unsigned)(rows - 1);
+    if constexpr (!EARLY) {
+        // (branch-free as the staging: all 16 row -> source-row lookups, then all 16 multiplicands / addends, then the stores;
+        // 32-bit index arithmetic - rows < 2^31 host-checked - and no division at all for the lock-step rules' pix_per_map = 1)
+        long src[16];
+        unsigned nn[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const unsigned row = min((unsigned)row0 + (unsigned)((e & 3) + 8 * (e >> 2) + 4 * lh), last);
-        const unsigned n = P == 1u ? row : row / P, p = P == 1u ? 0u : row - n * P;
-        nn[e] = n;
-        const long img = (m2i && !(LRPXD_EXP & 1)) ? (long)m2i[n] : (long)n;
-        src[e] = (img * P + p) * ncol + oc;
-    }
+        for (int e = 0; e < 16; ++e) {
+            const unsigned row = min((unsigned)row0 + (unsigned)((e & 3) + 8 * (e >> 2) + 4 * lh), last);
+            const unsigned n = P == 1u ? row : row / P, p = P == 1u ? 0u : row - n * P;
+            nn[e] = n;
+            const long img = (m2i && !(LRPXD_EXP & 1)) ? (long)m2i[n] : (long)n;
+            src[e] = (img * P + p) * ncol + oc;
+        }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        xv[e] = (LRPXD_EXP & 1) ? 1.f : X[src[e]];
-        uv[e] = (Uu && !(LRPXD_EXP & 1)) ? Uu[(long)nn[e] * ncol + oc] : 0.f;
+        for (int e = 0; e < 16; ++e) {
+            xv[e] = (LRPXD_EXP & 1) ? 1.f : X[src[e]];
+            uv[e] = (Uu && !(LRPXD_EXP & 1)) ? Uu[(long)nn[e] * ncol + oc] : 0.f;
+        }
     }
     float* __restrict__ O0 = a.out0;
 #pragma unroll

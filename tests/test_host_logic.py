@@ -119,3 +119,22 @@ def test_bench_arguments_of_every_baseline_config():
     b64 = bench.parse(["--config", "2", "--batch", "64", "--pipeline", "2"])
     assert (b64.batch, b64.pipeline, b64.vocab) == (64, 2, 9586)
     assert bench.parse(["--config", "3", "--all-heads"]).all_heads
+
+
+def test_zeros_arena_views_are_zero_disjoint_and_aligned():
+    """ops.zeros_arena (the decoder traces: one allocation, one fill): every view has its shape, is contiguous, zero, starts on a
+    256-byte boundary and shares no element with another view"""
+    from lrp_amd import ops
+    shapes = {"a": (3, 5, 7), "b": (2, 64), "c": (1,), "d": (4, 3, 2, 5)}
+    v = ops.zeros_arena("cpu", shapes)
+    base = min(t.data_ptr() for t in v.values())
+    spans = []
+    for k, shp in shapes.items():
+        t = v[k]
+        assert tuple(t.shape) == shp and t.is_contiguous() and t.dtype == torch.float32 and not t.any()
+        assert (t.data_ptr() - base) % 256 == 0
+        spans.append((t.data_ptr(), t.data_ptr() + 4 * t.numel()))
+    spans.sort()
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+    v["a"].fill_(1.0)
+    assert not v["b"].any() and not v["c"].any() and not v["d"].any()
