@@ -179,6 +179,45 @@ def test_dense_f16x3_n256_tiles_match_the_128_tiles_bitwise(ops, n_maps, P, k, n
     assert err < 2e-6
 
 
+_N256_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import lrp_amd
+from lrp_amd import ops, _lib
+g = torch.Generator().manual_seed(77)
+n_maps, P, k, n, n_img = 130, 36, 256, 512, 6
+a = (torch.randn(n_maps, P, k, generator=g) * torch.logspace(-6, 6, n_maps).view(-1, 1, 1)).cuda()
+w = (torch.randn(k, n, generator=g) * 0.05).cuda()
+x = torch.randn(n_img, P, n, generator=g).cuda()
+u = torch.randn(n_maps, n, generator=g).cuda() * a.abs().amax(dim=(1, 2)).view(-1, 1) * 0.3
+m2i = torch.randint(0, n_img, (n_maps,), generator=g).to(torch.int32).cuda()
+wp = ops.pack_weights_f16x2(w, k, n, _lib.PACK_BWD_PLAIN, taps=1)
+out = torch.empty(n_maps, P, n, device="cuda")
+ops.conv_mfma(a, wp, n_maps, 0, k, n, 1, _lib.EPI_REL, pix_per_map=P, oc_split=n, x=x, u=u, map2img=m2i, out0=out, f16x3=1,
+              in_amax=ops.amax_maps(a, n_maps))
+torch.cuda.synchronize()
+torch.save(out.cpu(), sys.argv[1])
+"""
+
+
+def test_dense_n256_switch_off_gives_the_same_bits(tmp_path):
+    """LRPX_DENSE_N256=0 (the switch is read once per process: a child each) sends the many-row rule with one output to the 128 x 128
+    kernel, the default to the 128 x 256 one: bit-identical results"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, env in (("default", {}), ("off", {"LRPX_DENSE_N256": "0"})):
+        f = tmp_path / f"{name}.pt"
+        e = dict(os.environ)
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", _N256_CHILD % root, str(f)], env=e, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(torch.load(f))
+    assert outs[0].abs().max().item() > 0 and torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("rows,k,n,n_src", [(320, 512, 1536, 16), (1280, 512, 2048, 64), (37, 96, 64, 5), (640, 1024, 160, 640)])
 def test_dense_f16x3_rel_few_rows(ops, rows, k, n, n_src):
     """the lock-step gate rules on the fp16 matrix cores (dense_small_f16x3_kernel): out[row] = X[src(row)] * (A[row] W + U[row]),
