@@ -43,7 +43,8 @@ int maxpool_relevance_amax(const float* x, const float* r_out, const float* zdiv
                            hipStream_t stream);
 int divide_stab_amax(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c, int stab,
                      unsigned* amax, hipStream_t stream);
-int pool_winner_blk(const float* x, const float* z, float* xzw, uint8_t* am, float* xzw_blk, int n, int h_out, int w_out, int c, hipStream_t stream);
+int pool_winner_blk(const float* x, const float* z, float* xzw, uint8_t* am, float* xzw_blk, int n, int h_out, int w_out, int c, hipStream_t stream,
+                    float* y_pool = nullptr);     // y_pool: also the pooled activations (the forward pass)
 int divide_safe_blk(const float* r, const float* z, float* s, float* s_blk, int n_img, int pix, int c, hipStream_t stream);
 int divide_stab_blocked(const float* r, const float* z, const int32_t* map2img, float* s_blk, int n_maps, int pix, int c,
                         unsigned* amax, hipStream_t stream);

@@ -523,7 +523,8 @@ __global__ void blocked_convert_kernel(const float* __restrict__ src, float* __r
 
 // winners of a 2x2 max-pool + the fused multiplicand max / safe(Z+ at the winner); one thread = one pooled pixel x 4 ch
 __global__ void pool_winner_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ xzw,
-                                   unsigned char* __restrict__ am, int ho, int wo, int c4, long total, float* __restrict__ xzw_blk) {
+                                   unsigned char* __restrict__ am, int ho, int wo, int c4, long total, float* __restrict__ xzw_blk,
+                                   float* __restrict__ y_pool) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*ho*wo*c4
     if (idx >= total) return;
     const int cc = idx % c4;
@@ -554,6 +555,12 @@ __global__ void pool_winner_kernel(const float* __restrict__ x, const float* __r
     }
     reinterpret_cast<f32x4*>(xzw)[idx] = o;
     reinterpret_cast<unsigned*>(am)[idx] = pk;
+    if (y_pool) {           // the pooled activations themselves (the forward pass: this kernel then replaces maxpool_fwd_kernel - same expression)
+        f32x4 m4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m4[e] = fmaxf(fmaxf(w4[0][e], w4[1][e]), fmaxf(w4[2][e], w4[3][e]));
+        reinterpret_cast<f32x4*>(y_pool)[idx] = m4;
+    }
     if (xzw_blk) {          // the same multiplicand in the BLOCKED layout (blocked.h), one block set per image
         const int P = ho * wo;
         *reinterpret_cast<f32x4*>(xzw_blk + n * (long)(c4 >> 2) * blk_chunk_stride(P) + blk_off((long)yo * wo + xo, 4 * cc, blk_chunk_stride(P))) = o;
@@ -964,10 +971,11 @@ int divide_stab_blocked(const float* r, const float* z, const int32_t* map2img, 
     return check_launch("divide_stab_blocked");
 }
 // the two producers of the per-image multiplicands (lrpx_vgg16_trace_derive) with the BLOCKED copy written in the same pass
-int pool_winner_blk(const float* x, const float* z, float* xzw, uint8_t* am, float* xzw_blk, int n, int h_out, int w_out, int c, hipStream_t stream) {
+int pool_winner_blk(const float* x, const float* z, float* xzw, uint8_t* am, float* xzw_blk, int n, int h_out, int w_out, int c, hipStream_t stream,
+                    float* y_pool) {
     LRPX_REQUIRE(x && z && xzw && am && n > 0 && h_out > 0 && w_out > 0 && c % 16 == 0, "pool_winner: bad arguments");
     const long total = (long)n * h_out * w_out * (c / 4);
-    hipLaunchKernelGGL(pool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, z, xzw, am, h_out, w_out, c / 4, total, xzw_blk);
+    hipLaunchKernelGGL(pool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, z, xzw, am, h_out, w_out, c / 4, total, xzw_blk, y_pool);
     return check_launch("pool_winner");
 }
 int divide_safe_blk(const float* r, const float* z, float* s, float* s_blk, int n_img, int pix, int c, hipStream_t stream) {
@@ -1007,7 +1015,7 @@ int lrpx_pool_winner(const float* x, const float* z, float* xzw, uint8_t* am, in
     LRPX_REQUIRE(x && z && xzw && am && n > 0 && h_out > 0 && w_out > 0 && c % 4 == 0, "pool_winner: bad arguments");
     const long total = (long)n * h_out * w_out * (c / 4);
     hipLaunchKernelGGL(pool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, z, xzw, am,
-                       h_out, w_out, c / 4, total, (float*)nullptr);
+                       h_out, w_out, c / 4, total, (float*)nullptr, (float*)nullptr);
     return check_launch("pool_winner");
 }
 

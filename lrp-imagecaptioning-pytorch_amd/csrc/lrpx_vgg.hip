@@ -479,12 +479,15 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
     return LRPX_OK;
 }
 
-int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream) {
+// pools_done: the forward pass already wrote the pooled multiplicands (its pools run pool_winner_blk, which reads the activations once
+// for the pooled activations, the winners and the multiplicand - see lrpx_vgg16_forward_ex)
+static int trace_derive_impl(void* trace, int n_img, void* stream, bool pools_done) {
     LRPX_REQUIRE(trace && n_img > 0, "vgg16_trace_derive: bad arguments");
     const VggTrace t = vgg_trace_layout(n_img);
     float* tr = (float*)trace;
     for (int l = 1; l < kNL; ++l) {
         if (!t.xz[l]) continue;
+        if (pools_done && !kVgg[l - 1].conv) continue;
         // l >= 3: the blocked copy the mode-3 relevance kernels multiply with (one block set per image) is written in the same pass
         // (conv1_2's kernel takes NHWC)
         const int pix = kVgg[l].hw * kVgg[l].hw;
@@ -503,6 +506,8 @@ int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream) {
     }
     return LRPX_OK;
 }
+
+int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream) { return trace_derive_impl(trace, n_img, stream, false); }
 
 int lrpx_vgg16_trace_layout(int n_img, size_t* act_off, size_t* zpos_off) {
     LRPX_REQUIRE(n_img > 0 && act_off && zpos_off, "vgg16_trace_layout: bad arguments");
@@ -537,6 +542,7 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
     }
     // the signed image is kept split into x+ / x- (channels 0-2 / 3-5 of 8): Z of the first conv needs both
     LRPX_TRY(lrpx_nchw_to_nhwc_posneg(img_nchw, tr + t.act[0], n_img, 3, 224 * 224, 8, stream));
+    bool pools_fused = false, pools_plain = false;
     for (int l = 0; l < kNL; ++l) {
         const VggLayer& L = kVgg[l];
         if (L.conv) {
@@ -591,11 +597,19 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
                 }
             }
             LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream));
+        } else if (l >= 2 && l + 1 < kNL && t.xz[l + 1] && kVgg[l - 1].conv && L.cin % 16 == 0) {
+            // a pool whose output a relevance layer multiplies with: ONE pass over the activations writes the pooled activations,
+            // the winner positions and the multiplicand max / safe(Z+ at the winner) (NHWC + blocked) - what maxpool_fwd here and
+            // pool_winner in lrpx_vgg16_trace_derive did in two (the larger tensor read twice: 4 x ~20 us per 16 images)
+            LRPX_TRY(pool_winner_blk(tr + t.act[l], tr + t.zpos[l - 1], tr + t.xz[l + 1], (uint8_t*)(tr + t.am[l]), tr + t.xzp[l + 1],
+                                     n_img, L.hw / 2, L.hw / 2, L.cin, (hipStream_t)stream, tr + t.act[l + 1]));
+            pools_fused = true;
         } else {
             LRPX_TRY(lrpx_maxpool2x2_fwd(tr + t.act[l], tr + t.act[l + 1], n_img, L.hw, L.hw, L.cin, stream));
+            pools_plain = true;
         }
     }
-    LRPX_TRY(lrpx_vgg16_trace_derive(trace, n_img, stream));
+    LRPX_TRY(trace_derive_impl(trace, n_img, stream, pools_fused && !pools_plain));
     if (feat_nhwc) {
         if (hipMemcpyAsync(feat_nhwc, tr + t.act[kNL], (size_t)n_img * 196 * 512 * sizeof(float),
                            hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
