@@ -311,7 +311,9 @@ static __device__ unsigned long long g_stamp_dn[16384 * 10];      // per wave: s
 #ifndef LRPXB_NBQ
 #define LRPXB_NBQ 2        // B ring of the 128 x 256 kernel: k-steps in registers (2: one ahead; 3: two ahead - measured +-0, 16 registers more)
 #endif
-template <int EPI, bool HAS_U, bool HAS_O1>      // REL: with the addend U; writing out1 = r / stab(Zdiv) (+ its per-map maxima) instead of out0 = r
+template <int EPI, bool HAS_U, bool HAS_O1, int RT>      // REL: with the addend U; writing out1 = r / stab(Zdiv) (+ its per-map maxima) instead of
+                                                         // out0 = r; RT row tiles per wave: 4 (128-row tiles) or 3 (96 rows: the launcher picks the
+                                                         // tile height that fills the 512 resident slots in fewer (rounds x rows))
 __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     unsigned* ri_n = reinterpret_cast<unsigned*>(ldsb + 2 * DN_BUF);        // [128] map of the row
@@ -330,14 +332,15 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     if (lin >= t1) return;
     const int mtile = (int)(lin / n_blocks), nblk = (int)(lin - (long)mtile * n_blocks);
     const long M = (long)a.n_maps * a.pix_per_map;
-    const long row0 = (long)mtile * DN_BM;
+    constexpr int BM = 32 * RT;                          // rows of the workgroup tile
+    const long row0 = (long)mtile * BM;
     const int K = a.cin, nchunk = K / DN_KC;
     const unsigned P = (unsigned)a.pix_per_map;
     const unsigned* __restrict__ in_amax = a.in_amax;
     const int ncol = a.oc_split;
     const float inv_w = a.wp[0];
 
-    if (tid < DN_BM) {
+    if (tid < BM) {
         const long r = row0 + tid;
         const unsigned rc = (unsigned)(r < M ? r : M - 1);
         const unsigned n = rc / P, p = rc - n * P;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     }
 
     // ---- staging: thread -> NU items (row = tid / SEGS + RP u, 16-byte segment tid % SEGS of the chunk row)
-    constexpr int SEGS = DN_KC / 4, RP = 256 / SEGS, NU = DN_BM / RP;
+    constexpr int SEGS = DN_KC / 4, RP = 256 / SEGS, NU = BM / RP;
     const int s_row = tid / SEGS, s_seg = tid % SEGS;
     float ssc[NU];
     unsigned soff[NU];
@@ -399,9 +402,9 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
 #pragma unroll
     for (int i = 0; i < NBQ - 1; ++i) load_b(i, bq[i]);
 
-    f32x16 acc[4][2];
+    f32x16 acc[RT][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -412,7 +415,8 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     __syncthreads();
     LRPXH_T(ts1);
     const int a_off = li * DN_ROWB + lh * 16;
-    static_assert(!SHADOW || (NU == 2 * DN_KS && NBQ == 2), "one staging item per (k-step, pair) step; two chunks per loop trip");
+    static_assert(!SHADOW || (NU <= 2 * DN_KS && NBQ == 2), "at most one staging item per (k-step, pair) step; two chunks per loop trip");
+    static_assert(RT == 4 || RT == 3, "two pairs of row tiles, or a pair and a single one");
     // (NBQ chunks per loop iteration: the ring positions are compile-time constants - 2 NBQ k-steps, a multiple of the ring)
     for (int c0 = 0; c0 < nchunk; c0 += NBQ) {
 #pragma unroll
@@ -431,8 +435,10 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
                 const char* q = abuf + (64 * (t & 1)) * DN_ROWB + (t >> 1) * 64;
                 f[0] = *reinterpret_cast<const f16x8*>(q);
                 f[1] = *reinterpret_cast<const f16x8*>(q + 32);
-                f[2] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB);
-                f[3] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB + 32);
+                if (RT == 4 || (t & 1) == 0) {               // (RT = 3: the second step of a k-step holds row tile 2 alone)
+                    f[2] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB);
+                    f[3] = *reinterpret_cast<const f16x8*>(q + 32 * DN_ROWB + 32);
+                }
             };
             read_pair(0, af[0]);
             __builtin_amdgcn_sched_barrier(0);
@@ -446,30 +452,45 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
                 // SHADOW: item t of the NEXT chunk (loaded a chunk ago) is scaled, split and written to the other buffer under these
                 // 12 MFMAs - two vector instructions behind each (the vector issue is free for most of an MFMA's 32 cycles)
                 // (no branch around it - the scheduler mixes within a basic block only: the last chunk writes a copy of itself into the idle buffer)
-                if constexpr (SHADOW) commit_item((chunk + 1) & 1, (cc + 1) & 1, t);
+                if constexpr (SHADOW) { if (t < NU) commit_item((chunk + 1) & 1, (cc + 1) & 1, t); }
                 const f16x8 a0h = af[t & 1][0], a0l = af[t & 1][1], a1h = af[t & 1][2], a1l = af[t & 1][3];
                 const u32x4_(&b)[4] = bq[q % NBQ];
                 const f16x8 b0h = __builtin_bit_cast(f16x8, b[0]), b0l = __builtin_bit_cast(f16x8, b[1]);
                 const f16x8 b1h = __builtin_bit_cast(f16x8, b[2]), b1l = __builtin_bit_cast(f16x8, b[3]);
-                f32x16 &c00 = acc[2 * pr][0], &c01 = acc[2 * pr][1], &c10 = acc[2 * pr + 1][0], &c11 = acc[2 * pr + 1][1];
+                const bool two = RT == 4 || pr == 0;           // (compile-time per unrolled step)
+                f32x16 &c00 = acc[2 * pr][0], &c01 = acc[2 * pr][1], &c10 = acc[two ? 2 * pr + 1 : 0][0], &c11 = acc[two ? 2 * pr + 1 : 0][1];
                 // small terms first
                 c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, c00, 0, 0, 0);
                 c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, c01, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, c11, 0, 0, 0);
+                if (two) {
+                    c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, c11, 0, 0, 0);
+                }
                 c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0l, c00, 0, 0, 0);
                 c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1l, c01, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0l, c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1l, c11, 0, 0, 0);
+                if (two) {
+                    c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0l, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1l, c11, 0, 0, 0);
+                }
                 c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, c00, 0, 0, 0);
                 c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, c01, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, c11, 0, 0, 0);
+                if (two) {
+                    c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, c11, 0, 0, 0);
+                }
                 if constexpr (SHADOW) {
+                    if (two) {
 #pragma unroll
-                    for (int g = 0; g < 10; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two vector instructions
+                        for (int g = 0; g < 10; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two vector instructions
+                        }
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);          // the LDS writes
@@ -498,8 +519,8 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     float* __restrict__ out = HAS_O1 ? a.out1 : a.out0;
     unsigned* __restrict__ oamax = HAS_O1 ? a.out1_amax : nullptr;
     const int nmax = a.n_maps - 1;
-    float mres[4][2];
-    unsigned nres[4];
+    float mres[RT][2];
+    unsigned nres[RT];
     const int stab = a.stab;
     // Units of one accumulator tile (i = u / 2, j = u % 2).  The tile goes through a per-wave LDS scratch (the A buffers are free after
     // the last barrier) into ROW-MAJOR lanes - lane l holds rows l / 8 + 8 q, columns 4 (l % 8) .. + 3 - so that the multiplicand, the
@@ -574,8 +595,8 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     };
     issue_u(0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        if (u + 1 < 8) issue_u(u + 1);
+    for (int u = 0; u < 2 * RT; ++u) {
+        if (u + 1 < 2 * RT) issue_u(u + 1);
         finish_u(u);
     }
 #ifdef LRPX_STAMP
@@ -596,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     if constexpr (HAS_O1) {
         if (oamax) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RT; ++i) {
                 const long rt = row0 + 32 * i;
                 const float m0 = wave_max(mres[i][0]), m1 = wave_max(mres[i][1]);
                 if (lane == 0 && rt < M) {
@@ -811,16 +832,26 @@ int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
     const bool aligned = al16(a.X) && al16(a.U) && al16(a.Zdiv) && al16(a.out0) && al16(a.out1) && al16(a.bias);
     if (switches().dense_n256 && one_out && aligned && M >= 4096 && a.n_oc >= 256 && a.oc_split % 4 == 0 && a.cin % DN_KC == 0 && M * a.cin < 0x7fffffffL
         && (long)a.n_maps * a.oc_split < 0x7fffffffL && (!a.out1 || a.pix_per_map >= 32)) {
-        const long m_tiles = ceil_div(M, DN_BM);
         const int n_blocks = (int)ceil_div(a.n_oc, DN_BN);
+        // tile height: 128 rows, or 96 where that fills the 512 resident workgroup slots in fewer (rounds x rows) - e.g. 23 040 x 512
+        // columns: 360 tiles of 128 rows leave 152 slots empty while the CUs that hold two run at half speed; 480 tiles of 96 rows do not
+        auto cost = [&](int rows) { return ceil_div(ceil_div(M, rows) * n_blocks, 512) * rows; };
+        const int rt = switches().dense_rt == 3 || switches().dense_rt == 4 ? switches().dense_rt : (cost(96) < cost(128) ? 3 : 4);
+        const long m_tiles = ceil_div(M, 32 * rt);
         const long grid = ceil_div(m_tiles * n_blocks, 8) * 8;
         LRPX_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "dense_f16x3: grid %ld out of range", grid);
-        static LdsOnce once_n[5];
+        static LdsOnce once_n[10];
         const int v = plain ? 4 : (a.U ? 1 : 0) + (a.out1 ? 2 : 0);
-        auto kern = v == 4 ? dense_f16x3_n256_kernel<EPI_PLAIN, false, false>
-                    : (v == 0 ? dense_f16x3_n256_kernel<EPI_REL, false, false> : (v == 1 ? dense_f16x3_n256_kernel<EPI_REL, true, false>
-                    : (v == 2 ? dense_f16x3_n256_kernel<EPI_REL, false, true> : dense_f16x3_n256_kernel<EPI_REL, true, true>)));
-        LRPX_TRY(reserve_lds_once(once_n[v], kern, DN_LDS, "dense_f16x3_n256"));
+        using Kern = void (*)(ConvArgs, int, int);
+        static const Kern kerns[2][5] = {
+            {dense_f16x3_n256_kernel<EPI_REL, false, false, 4>, dense_f16x3_n256_kernel<EPI_REL, true, false, 4>,
+             dense_f16x3_n256_kernel<EPI_REL, false, true, 4>, dense_f16x3_n256_kernel<EPI_REL, true, true, 4>,
+             dense_f16x3_n256_kernel<EPI_PLAIN, false, false, 4>},
+            {dense_f16x3_n256_kernel<EPI_REL, false, false, 3>, dense_f16x3_n256_kernel<EPI_REL, true, false, 3>,
+             dense_f16x3_n256_kernel<EPI_REL, false, true, 3>, dense_f16x3_n256_kernel<EPI_REL, true, true, 3>,
+             dense_f16x3_n256_kernel<EPI_PLAIN, false, false, 3>}};
+        Kern kern = kerns[rt == 3][v];
+        LRPX_TRY(reserve_lds_once(once_n[(rt == 3 ? 5 : 0) + v], kern, DN_LDS, "dense_f16x3_n256"));
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), DN_LDS, stream, a, (int)m_tiles, n_blocks);
         return check_launch("dense_f16x3_n256");
     }

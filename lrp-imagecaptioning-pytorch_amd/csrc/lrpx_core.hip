@@ -37,6 +37,7 @@ const Switches& switches() {
         w.guided_poolbwd = set("LRPX_GUIDED_POOLBWD");
         w.dense_wide = num("LRPX_DENSE_WIDE", 0);
         w.dense_n256 = num("LRPX_DENSE_N256", 1);
+        w.dense_rt = num("LRPX_DENSE_RT", 0);
         w.dense_1wave = set("LRPX_DENSE_1WAVE");
         w.linear_valu = set("LRPX_LINEAR_VALU");
         return w;

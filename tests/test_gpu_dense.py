@@ -122,12 +122,14 @@ def test_amax_maps_exact_for_every_block_shape(ops, per):
     assert torch.equal(got, a.abs().amax(dim=1))
 
 
-@pytest.mark.parametrize("n_maps,P,k,n,n_img", [(120, 36, 512, 2048, 7), (41, 196, 512, 512, 4), (131, 33, 64, 288, 3), (47, 100, 128, 1000, 5)])
+@pytest.mark.parametrize("n_maps,P,k,n,n_img", [(120, 36, 512, 2048, 7), (41, 196, 512, 512, 4), (131, 33, 64, 288, 3), (47, 100, 128, 1000, 5),
+                                                 (401, 36, 128, 2048, 9)])
 def test_dense_f16x3_n256_tiles_match_the_128_tiles_bitwise(ops, n_maps, P, k, n, n_img):
     """dense_f16x3_n256_kernel (128 x 256 tiles, waves side by side: taken for >= 4096 rows, >= 256 columns and ONE output) against
     dense_f16x3_kernel (taken when both outputs are asked for): the same products in the same order per accumulator, so out0,
     out1 and out1_amax are BIT-identical, with and without the addend U; row counts off the 128-row tile, 288 / 1000 columns (a
-    partial column block: waves without a column tile of their own), an all-zero map; nothing written behind the outputs.
+    partial column block: waves without a column tile of their own), an all-zero map; nothing written behind the outputs.  The
+    launcher picks 96-row tiles for the first four shapes (one round of workgroups either way) and 128-row tiles for the last one.
     And EPI_PLAIN (scores with bias) through the same tiles against fp64."""
     from lrp_amd import _lib
     g = torch.Generator().manual_seed(n_maps * 11 + P)
