@@ -305,6 +305,10 @@ constexpr int DN_LDS = 2 * DN_BUF + DN_BM * 16;
 #ifdef LRPX_STAMP
 static __device__ unsigned long long g_stamp_dn[16384 * 10];      // per wave: start, loop start, loop end, stores issued, stores drained, sum issue..MFMAs, sum commit, sum barrier, HW_ID, XCC_ID
 #endif
+#ifndef LRPXB_SCR_PITCH
+#define LRPXB_SCR_PITCH 32   // epilogue scratch of the 128 x 256 kernel, floats per row: 32 = no padding - the dword writes of a half wave and the
+                            // 16-byte reads of two rows each cover 32 / 64 distinct banks (36: the reads of rows r, r + 1 overlap in 4 banks)
+#endif
 #ifndef LRPXB_SHADOW
 #define LRPXB_SHADOW 1     // the 128 x 256 kernel converts / commits the next chunk between the MFMAs of the current one (0: a commit phase per chunk)
 #endif
@@ -527,7 +531,8 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     // addend, the denominator and the result move as 16 bytes per lane: 4 + 4 memory instructions per tile instead of 16 + 16, every
     // wave instruction 8 rows x 128 bytes.  (With dword accesses the epilogue ran at 3.8 TB/s of stores when it was all the kernel
     // did - K = 64 - against 6.9 for a fill of the same bytes.)  The loads of unit u + 1 are in flight while unit u is finished.
-    float* scr = reinterpret_cast<float*>(ldsb) + wave * (32 * 36);            // [32 rows][36]: 16-byte aligned rows, conflict-free both ways
+    constexpr int SP = LRPXB_SCR_PITCH;                                        // floats per scratch row
+    float* scr = reinterpret_cast<float*>(ldsb) + wave * (32 * SP);            // [32 rows][SP]
     const int tr = lane >> 3, tc = (lane & 7) * 4;
     constexpr int DEPTH = 2;
     f32x4 xr[DEPTH][4], ur[HAS_U ? DEPTH : 1][4], zr[HAS_O1 ? DEPTH : 1][4];
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
         const unsigned nt0 = ri_n[32 * i];
         if (j == 0) { mres[i][0] = 0.f; mres[i][1] = 0.f; nres[i] = nt0; }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + li] = acc[i][j][e];
+        for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * lh) * SP + li] = acc[i][j][e];
         // (same wave, LDS instructions execute in order: the reads below see the writes above)
         f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (EPI == EPI_PLAIN) { if (a.bias) bv4 = *reinterpret_cast<const f32x4*>(a.bias + min(oc, ncol - 4)); }
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
         for (int q = 0; q < 4; ++q) {
             const int rl = tr + 8 * q;
             const bool ok = rl < mrem && oc < ncol;
-            const f32x4 av = *reinterpret_cast<const f32x4*>(scr + rl * 36 + tc);
+            const f32x4 av = *reinterpret_cast<const f32x4*>(scr + rl * SP + tc);
             const float sc = ri_sc[32 * i + rl];
             f32x4 res;
             if constexpr (EPI == EPI_PLAIN) {
