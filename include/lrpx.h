@@ -169,6 +169,14 @@ int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* s
 /* running sum over the maps of one image: out[b,t] = sum_{t'<=t} in[b,t']  (the reference's
  * `sample.grad` accumulation, LRPtools/lrp_wrapper.py:64-82); per = floats per map */
 int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long per, void* stream);
+/* Captions of unequal length (the reference explains whatever length its beam search returns, models/gridTDmodel.py:935-937,
+ * 1147-1153): `in` holds only the VALID (image, word) maps, image b's lens[b] maps starting at map offs[b]; `out` is the padded
+ * [n_img][t_per_img] layout - the valid maps (accumulate = 1: their running sums, as lrpx_cumsum_maps) and exact zeros behind
+ * an image's last word. */
+int lrpx_scatter_maps(const float* in, float* out, int n_img, int t_per_img, const int32_t* lens, const int32_t* offs,
+                      long per, int accumulate, void* stream);
+/* dst[r][0..width) = src[rows[r]][0..width) for 4-byte items (per-row operands of the compacted (word, pixel) rules) */
+int lrpx_gather_rows(const void* src, const int32_t* rows, void* dst, int n_rows, int width, void* stream);
 /* dst += src  (the `.grad` accumulation of autograd that compute_lrp relies on, lrp_wrapper.py:80-82) */
 int lrpx_accumulate(float* dst, const float* src, long n, void* stream);
 /* out[row][c] = in[row][c] + in[row][half + c]: joins the x+ / x- halves of a split relevance tensor
@@ -349,6 +357,11 @@ int lrpx_gridtd_rel_glob(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate
 int lrpx_rel_avg_u(const float* r_avg, const float* avg, float* u, int rows, int T, int C, int P, void* stream);
 int lrpx_gridtd_rel_pix(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* Vp,
                         const float* proj_pre, float* a_proj, void* stream);
+/* the same for the n_rows (image, word) rows listed in `rows` (row = image * T + word) only, written COMPACTLY: a_proj
+ * [n_rows][P][H] - padded words of captions shorter than T then cost nothing in the (word, pixel) rules and in the VGG16
+ * chain.  rows = null: all B*T rows (n_rows must be B*T). */
+int lrpx_gridtd_rel_pix_rows(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* Vp,
+                             const float* proj_pre, float* a_proj, const int32_t* rows, int n_rows, void* stream);
 int lrpx_rel_words_norm(float* r_words, int rows, int T, void* stream);
 
 /* ---- AoA decoder: trace (get_hidden_parameters, models/aoamodel.py:990-1062) -------------------------- */
@@ -404,6 +417,8 @@ int lrpx_aoa_grad_step(const lrpx_aoa_trace* tr, const lrpx_aoa_gradstate* gs, i
  * the projector: both are rank-1 in the pixel index) */
 int lrpx_aoa_grad_pix(const lrpx_aoa_trace* tr, int head, const float* v1, const float* v2, float* d_feat, int C,
                       void* stream);
+int lrpx_aoa_grad_pix_rows(const lrpx_aoa_trace* tr, int head, const float* v1, const float* v2, float* d_feat, int C,
+                           const int32_t* rows, int n_rows, void* stream);   /* compact output for the listed rows */
 /* x[row][c] = 0 for c outside [lo, hi)  (only one head passes gradient, :1428) */
 int lrpx_keep_cols(float* x, long rows, int ncol, int lo, int hi, void* stream);
 
@@ -418,6 +433,8 @@ int lrpx_aoa_rel_init(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, con
                       const long long* tok, int tok_ld, void* stream);
 int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
                        int head, float* a_val, void* stream);
+int lrpx_aoa_rel_value_rows(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
+                            int head, float* a_val, const int32_t* rows, int n_rows, void* stream);   /* compact a_val */
 /* lock-step s: phase 0 g-gate split (:1116-1120) -> A ; phase 1 after the LSTM dense rule (:1129-1133) */
 int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int s, int phase, void* stream);
 /* lock-steps 0 <= s < n_steps of explain_caption_wordt's `for i in range(t+1)[::-1]` (models/aoamodel.py:1114-1134) in ONE
@@ -444,6 +461,8 @@ int lrpx_gridtd_grad_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_gradsta
 /* a_proj[row][k][:] = sum_{i<=t} alpha[b][i][k] * wacc[row][i][:]   (:1642-1643) */
 int lrpx_spread_pixels(const float* wacc, const float* alpha, const int32_t* lens, float* a_proj, int B, int T, int H,
                        int P, void* stream);
+int lrpx_spread_pixels_rows(const float* wacc, const float* alpha, const int32_t* lens, float* a_proj, int B, int T, int H,
+                            int P, const int32_t* rows, int n_rows, void* stream);   /* compact a_proj for the listed rows */
 int lrpx_scale(const float* x, float* y, long n, float alpha, void* stream);
 int lrpx_positive_mask(const float* x, float* y, long n, void* stream);   /* y = [x > 0]  (:1674) */
 

@@ -111,6 +111,12 @@ SIGNATURES = {
     "lrpx_heatmap": (_i, [_f, _i, _i, _l, C.c_float, _f, _i, _f, _f, _f]),
     "lrpx_amax_maps": (_i, [_f, _i, _l, _f, _f]),
     "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),
+    "lrpx_scatter_maps": (_i, [_f, _f, _i, _i, _f, _f, _l, _i, _f]),
+    "lrpx_gather_rows": (_i, [_f, _f, _f, _i, _i, _f]),
+    "lrpx_gridtd_rel_pix_rows": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f, _f, _i, _f]),
+    "lrpx_aoa_rel_value_rows": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _i, _f, _f, _i, _f]),
+    "lrpx_aoa_grad_pix_rows": (_i, [C.POINTER(AoaTrace), _i, _f, _f, _f, _i, _f, _i, _f]),
+    "lrpx_spread_pixels_rows": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f, _i, _f]),
     "lrpx_accumulate": (_i, [_f, _f, _l, _f]),
     "lrpx_fold_halves": (_i, [_f, _f, _l, _i, _f]),
     "lrpx_check": (_i, [_f, _l, _i, _f]),

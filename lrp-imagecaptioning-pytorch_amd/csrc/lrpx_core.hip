@@ -731,6 +731,38 @@ __global__ void cumsum_maps_kernel(const float* __restrict__ in, float* __restri
     }
 }
 
+// Variable caption lengths: `in` holds only the valid (image, word) rows, image b's len[b] rows starting at row off[b]; `out` is the
+// padded [n_img][t_per_img] layout: running sums (accumulate, lrp_wrapper.py:64-82 quirk) or copies of the valid rows, exact zeros
+// behind an image's last word.
+__global__ void scatter_maps_kernel(const float* __restrict__ in, float* __restrict__ out, int t_per_img,
+                                    const int* __restrict__ lens, const int* __restrict__ offs, long per4, long total,
+                                    int accumulate) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 units over n_img*per4
+    if (idx >= total) return;
+    long b = idx / per4, i = idx - b * per4;
+    const int len = min(lens[b], t_per_img);
+    const long src0 = offs[b];
+    f32x4 run = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < t_per_img; ++t) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (t < len) {
+            f32x4 v = reinterpret_cast<const f32x4*>(in)[(src0 + t) * per4 + i];
+            run = (t == 0 || !accumulate) ? v : run + v;
+            o = run;
+        }
+        reinterpret_cast<f32x4*>(out)[(b * t_per_img + t) * per4 + i] = o;
+    }
+}
+
+// dst[r][:] = src[rows[r]][:]  (per-row operands of the compacted (word, pixel) rules; 4-byte items of any type)
+__global__ void gather_rows_kernel(const uint32_t* __restrict__ src, const int* __restrict__ rows, uint32_t* __restrict__ dst,
+                                   int width, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long r = idx / width;
+    dst[idx] = src[(long)rows[r] * width + (idx - r * width)];
+}
+
 // Grad-CAM (models/gridTDmodel.py:1760-1771): cam[p] = relu(sum_c F[img][p][c] * mean_p'(G[row][p'][c])) / (max + 1e-6).
 // One workgroup per (image, word) row; P <= 256 pixels, any C (multiple of 4).
 __global__ __launch_bounds__(256) void gradcam_kernel(const float* __restrict__ feats, const float* __restrict__ grads,
@@ -1109,6 +1141,23 @@ int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long
     hipLaunchKernelGGL(cumsum_maps_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out,
                        t_per_img, per / 4, total);
     return check_launch("cumsum_maps");
+}
+
+int lrpx_scatter_maps(const float* in, float* out, int n_img, int t_per_img, const int32_t* lens, const int32_t* offs,
+                      long per, int accumulate, void* stream) {
+    LRPX_REQUIRE(in && out && lens && offs && (per % 4 == 0) && t_per_img > 0 && n_img > 0, "scatter_maps: bad arguments");
+    long total = (long)n_img * (per / 4);
+    hipLaunchKernelGGL(scatter_maps_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, t_per_img,
+                       lens, offs, per / 4, total, accumulate);
+    return check_launch("scatter_maps");
+}
+
+int lrpx_gather_rows(const void* src, const int32_t* rows, void* dst, int n_rows, int width, void* stream) {
+    LRPX_REQUIRE(src && rows && dst && n_rows > 0 && width > 0, "gather_rows: bad arguments");
+    long total = (long)n_rows * width;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src,
+                       rows, (uint32_t*)dst, width, total);
+    return check_launch("gather_rows");
 }
 
 extern "C++" {

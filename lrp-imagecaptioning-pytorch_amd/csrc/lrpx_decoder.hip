@@ -664,8 +664,11 @@ __global__ void gridtd_rel_u_kernel(const float* __restrict__ r_avg, const float
 __global__ __launch_bounds__(256) void gridtd_rel_pix_kernel(GridRel g, const float* __restrict__ Vp,
                                                              const float* __restrict__ proj_pre,
                                                              const float* __restrict__ alpha,
-                                                             float* __restrict__ Aproj, int kchunk) {
-    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, P = g.P;
+                                                             float* __restrict__ Aproj, int kchunk,
+                                                             const int* __restrict__ rowlist) {
+    // rowlist (variable caption lengths): workgroup x computes row rowlist[x] and writes it as row x of a COMPACT Aproj
+    const int row = rowlist ? rowlist[blockIdx.x] : blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, P = g.P;
+    const long orow = blockIdx.x;
     const int len = g.lens ? g.lens[b] : g.T;
     const int k0 = blockIdx.y * kchunk, k1 = min(k0 + kchunk, P);
     extern __shared__ float al[];    // [t+1][kchunk]
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(256) void gridtd_rel_pix_kernel(GridRel g, const fl
                 for (int i = n - 1; i >= 0; --i) a += al[i * kchunk + (k - k0)] * g.wacc[((long)row * g.T + i) * H + c];
             }
             const long pi = ((long)b * P + k) * H + c;
-            Aproj[((long)row * P + k) * H + c] = act ? Vp[pi] * a / stab_eps(proj_pre[pi]) : 0.f;
+            Aproj[(orow * P + k) * H + c] = act ? Vp[pi] * a / stab_eps(proj_pre[pi]) : 0.f;
         }
     }
 }
@@ -817,8 +820,10 @@ __global__ __launch_bounds__(256) void gridtd_grad_c_kernel(GridGrad g, int s) {
 // Aproj[row][k][c] = sum_{i<=t} alpha[b][i][k] * wacc[row][i][c]   (:1642-1643 summed over i)
 __global__ __launch_bounds__(256) void spread_pixels_kernel(const float* __restrict__ wacc, const float* __restrict__ alpha,
                                                             const int* __restrict__ lens, float* __restrict__ Aproj,
-                                                            int T, int H, int P, int kchunk) {
-    const int row = blockIdx.x, b = row / T, t = row - b * T;
+                                                            int T, int H, int P, int kchunk,
+                                                            const int* __restrict__ rowlist) {
+    const int row = rowlist ? rowlist[blockIdx.x] : blockIdx.x, b = row / T, t = row - b * T;
+    const long orow = blockIdx.x;
     const int len = lens ? lens[b] : T;
     const int k0 = blockIdx.y * kchunk, k1 = min(k0 + kchunk, P);
     extern __shared__ float al[];
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(256) void spread_pixels_kernel(const float* __restr
         for (int k = k0; k < k1; ++k) {
             float a = 0.f;
             for (int i = n - 1; i >= 0; --i) a += al[i * kchunk + (k - k0)] * wacc[((long)row * T + i) * H + c];
-            Aproj[((long)row * P + k) * H + c] = a;
+            Aproj[(orow * P + k) * H + c] = a;
         }
 }
 
@@ -1112,13 +1117,14 @@ __global__ void aoa_grad_step1_kernel(AoaGrad g, int s) {
 
 __global__ void aoa_grad_pix_kernel(const float* __restrict__ alpha, int T, int NH, int P, int head,
                                     const float* __restrict__ v1, const float* __restrict__ v2,
-                                    float* __restrict__ d_feat, int C4, long total) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over rows*P*C4
+                                    float* __restrict__ d_feat, int C4, long total,
+                                    const int* __restrict__ rowlist) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over (output rows)*P*C4
     if (idx >= total) return;
     const int c4 = idx % C4;
     const long rp = idx / C4;
     const int p = rp % P;
-    const long row = rp / P;
+    const long row = rowlist ? rowlist[rp / P] : rp / P;
     const float a = alpha[(row * NH + head) * P + p];
     const f32x4 x1 = reinterpret_cast<const f32x4*>(v1)[row * C4 + c4], x2 = reinterpret_cast<const f32x4*>(v2)[row * C4 + c4];
     f32x4 o;
@@ -1168,8 +1174,9 @@ __global__ void aoa_rel_init_kernel(AoaRel g, const float* __restrict__ fcw, con
 // `head`, 0 elsewhere — the prologue of the v_proj dense rule (:1141-1144).  r_ctx: [rows][H]
 __global__ __launch_bounds__(256) void aoa_rel_value_kernel(AoaRel g, const float* __restrict__ r_ctx,
                                                             const float* __restrict__ value, int head,
-                                                            float* __restrict__ Aval) {
-    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, P = g.P, dk = H / g.NH;
+                                                            float* __restrict__ Aval, const int* __restrict__ rowlist) {
+    const int row = rowlist ? rowlist[blockIdx.x] : blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, P = g.P, dk = H / g.NH;
+    const long orow = blockIdx.x;
     const int len = g.lens ? g.lens[b] : g.T;
     const bool act = t < len;
     const float* al = g.alpha + (((long)b * g.T + t) * g.NH + head) * P;
@@ -1181,7 +1188,7 @@ __global__ __launch_bounds__(256) void aoa_rel_value_kernel(AoaRel g, const floa
             const float rv = eps_id(r_ctx[(long)row * H + c], val * al[k], g.ctx[(long)row * H + c]);
             v = rv / stab_eps(val);
         }
-        Aval[((long)row * P + k) * H + c] = v;
+        Aval[(orow * P + k) * H + c] = v;
     }
 }
 
@@ -1456,15 +1463,22 @@ int lrpx_rel_avg_u(const float* r_avg, const float* avg, float* u, int rows, int
     return check_launch("rel_avg_u");
 }
 
-int lrpx_gridtd_rel_pix(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* Vp,
-                        const float* proj_pre, float* a_proj, void* stream) {
+int lrpx_gridtd_rel_pix_rows(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* Vp,
+                             const float* proj_pre, float* a_proj, const int32_t* rows, int n_rows, void* stream) {
     LRPX_TRY(check_rel(tr, rs));
     LRPX_REQUIRE(Vp && proj_pre && a_proj, "gridtd_rel_pix: null pointer");
+    LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= tr->B * tr->T) : n_rows == tr->B * tr->T, "gridtd_rel_pix: bad row list");
     const int kchunk = 28;
     const size_t lds = (size_t)tr->T * kchunk * sizeof(float);
-    hipLaunchKernelGGL(gridtd_rel_pix_kernel, dim3(tr->B * tr->T, (tr->P + kchunk - 1) / kchunk), dim3(256), lds,
-                       (hipStream_t)stream, to_rel(tr, rs), Vp, proj_pre, tr->alpha, a_proj, kchunk);
+    hipLaunchKernelGGL(gridtd_rel_pix_kernel, dim3(n_rows, (tr->P + kchunk - 1) / kchunk), dim3(256), lds,
+                       (hipStream_t)stream, to_rel(tr, rs), Vp, proj_pre, tr->alpha, a_proj, kchunk, rows);
     return check_launch("gridtd_rel_pix");
+}
+
+int lrpx_gridtd_rel_pix(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* Vp,
+                        const float* proj_pre, float* a_proj, void* stream) {
+    LRPX_REQUIRE(tr, "gridtd_rel_pix: null trace");
+    return lrpx_gridtd_rel_pix_rows(tr, rs, Vp, proj_pre, a_proj, nullptr, tr->B * tr->T, stream);
 }
 
 int lrpx_rel_words_norm(float* r_words, int rows, int T, void* stream) {
@@ -1513,13 +1527,19 @@ int lrpx_gridtd_grad_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_gradsta
     return check_launch("gridtd_grad_step");
 }
 
+int lrpx_spread_pixels_rows(const float* wacc, const float* alpha, const int32_t* lens, float* a_proj, int B, int T, int H,
+                            int P, const int32_t* rows, int n_rows, void* stream) {
+    LRPX_REQUIRE(wacc && alpha && a_proj && B > 0 && T > 0, "spread_pixels: bad arguments");
+    LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= B * T) : n_rows == B * T, "spread_pixels: bad row list");
+    const int kchunk = 28;
+    hipLaunchKernelGGL(spread_pixels_kernel, dim3(n_rows, (P + kchunk - 1) / kchunk), dim3(256),
+                       (size_t)T * kchunk * sizeof(float), (hipStream_t)stream, wacc, alpha, lens, a_proj, T, H, P, kchunk, rows);
+    return check_launch("spread_pixels");
+}
+
 int lrpx_spread_pixels(const float* wacc, const float* alpha, const int32_t* lens, float* a_proj, int B, int T, int H,
                        int P, void* stream) {
-    LRPX_REQUIRE(wacc && alpha && a_proj && B > 0 && T > 0, "spread_pixels: bad arguments");
-    const int kchunk = 28;
-    hipLaunchKernelGGL(spread_pixels_kernel, dim3(B * T, (P + kchunk - 1) / kchunk), dim3(256),
-                       (size_t)T * kchunk * sizeof(float), (hipStream_t)stream, wacc, alpha, lens, a_proj, T, H, P, kchunk);
-    return check_launch("spread_pixels");
+    return lrpx_spread_pixels_rows(wacc, alpha, lens, a_proj, B, T, H, P, nullptr, B * T, stream);
 }
 
 int lrpx_scale(const float* x, float* y, long n, float alpha, void* stream) {
@@ -1616,14 +1636,21 @@ int lrpx_aoa_grad_step(const lrpx_aoa_trace* tr, const lrpx_aoa_gradstate* gs, i
     return check_launch("aoa_grad_step");
 }
 
-int lrpx_aoa_grad_pix(const lrpx_aoa_trace* tr, int head, const float* v1, const float* v2, float* d_feat, int C,
-                      void* stream) {
+int lrpx_aoa_grad_pix_rows(const lrpx_aoa_trace* tr, int head, const float* v1, const float* v2, float* d_feat, int C,
+                           const int32_t* rows, int n_rows, void* stream) {
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(v1 && v2 && d_feat && head >= 0 && head < tr->NH && C > 0 && C % 4 == 0, "aoa_grad_pix: bad arguments");
-    const long total = (long)tr->B * tr->T * tr->P * (C / 4);
+    LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= tr->B * tr->T) : n_rows == tr->B * tr->T, "aoa_grad_pix: bad row list");
+    const long total = (long)n_rows * tr->P * (C / 4);
     hipLaunchKernelGGL(aoa_grad_pix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       tr->alpha, tr->T, tr->NH, tr->P, head, v1, v2, d_feat, C / 4, total);
+                       tr->alpha, tr->T, tr->NH, tr->P, head, v1, v2, d_feat, C / 4, total, rows);
     return check_launch("aoa_grad_pix");
+}
+
+int lrpx_aoa_grad_pix(const lrpx_aoa_trace* tr, int head, const float* v1, const float* v2, float* d_feat, int C,
+                      void* stream) {
+    LRPX_REQUIRE(tr, "aoa_grad_pix: null trace");
+    return lrpx_aoa_grad_pix_rows(tr, head, v1, v2, d_feat, C, nullptr, tr->B * tr->T, stream);
 }
 
 int lrpx_keep_cols(float* x, long rows, int ncol, int lo, int hi, void* stream) {
@@ -1658,13 +1685,20 @@ int lrpx_aoa_rel_init(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, con
     return check_launch("aoa_rel_init");
 }
 
-int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
-                       int head, float* a_val, void* stream) {
+int lrpx_aoa_rel_value_rows(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
+                            int head, float* a_val, const int32_t* rows, int n_rows, void* stream) {
     LRPX_TRY(check_arel(tr, rs));
     LRPX_REQUIRE(r_ctx && value && a_val && head >= 0 && head < tr->NH, "aoa_rel_value: bad arguments");
-    hipLaunchKernelGGL(aoa_rel_value_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_arel(tr, rs),
-                       r_ctx, value, head, a_val);
+    LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= tr->B * tr->T) : n_rows == tr->B * tr->T, "aoa_rel_value: bad row list");
+    hipLaunchKernelGGL(aoa_rel_value_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, to_arel(tr, rs),
+                       r_ctx, value, head, a_val, rows);
     return check_launch("aoa_rel_value");
+}
+
+int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
+                       int head, float* a_val, void* stream) {
+    LRPX_REQUIRE(tr, "aoa_rel_value: null trace");
+    return lrpx_aoa_rel_value_rows(tr, rs, r_ctx, value, head, a_val, nullptr, tr->B * tr->T, stream);
 }
 
 int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int s, int phase, void* stream) {

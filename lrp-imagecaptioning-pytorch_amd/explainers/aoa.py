@@ -11,6 +11,7 @@ from .. import _lib, ops
 from .._lib import (AoaGradState, AoaRelState, AoaStepArgs, AoaTrace, EPI_PLAIN, EPI_REL, PACK_DENSE, PACK_DENSE_T, STAB_EPS, check, ptr, ptr_at,
                     stream_ptr)
 from .gridtd import VGG_PREFIX, _t
+from .ragged import ragged
 
 
 class AOAEngine:
@@ -271,11 +272,14 @@ class AOAEngine:
     def gradient(self, enc, tr, head_idx, lens=None):
         """`ExplainAOAGradient.explain_caption_wordt` (models/aoamodel.py:1435-1499; the guided and Grad-CAM classes
         inherit it unchanged) for every (image, word) row in lock-step.  `tr` must be a grad=True trace.
-        Returns d_feat (B*T, P, C), r_words (B*T, T), row2img."""
+        Returns d_feat (B*T, P, C), r_words (B*T, T), row2img.  With `lens` (explainers/ragged.py) d_feat holds the valid
+        (image, word) rows only, compact, with the matching row -> image table."""
         lib = _lib.load()
         st = stream_ptr()
         B, T, H, E, P, Cc = tr["B"], tr["T"], self.H, self.E, tr["P"], self.C
         rows = B * T
+        rg = ragged(lens, B, T, self.device)
+        lens = rg.lens if rg is not None else None
         e = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
         gs = dict(d_h=e(rows, H), d_c=e(rows, H), dA=e(rows, H), dB=e(rows, H), gates=e(rows, 4 * H),
                   dx=e(rows, E + 2 * H), d_glob=e(rows, H), r_words=e(rows, T))
@@ -306,9 +310,13 @@ class AOAEngine:
         v1 = dense(u, self.p_proj_rel, Cc)                                           # :1492
         v2 = dense(gs["d_glob"], self.p_proj_rel, Cc)
         check(lib.lrpx_scale(ptr(v2), ptr(v2), v2.numel(), 1.0 / P, st))             # :1491  d_glob / P
-        d_feat = e(rows, P, Cc)
-        check(lib.lrpx_aoa_grad_pix(ctr, head_idx, ptr(v1), ptr(v2), ptr(d_feat), Cc, st))
         check(lib.lrpx_rel_words_norm(ptr(gs["r_words"]), rows, T, st))
+        n, rowlist = rows, None
+        if rg is not None and not rg.full:
+            n, rowlist, row2img = rg.n, rg.rows, rg.row2img
+        d_feat = e(n, P, Cc)
+        if n:
+            check(lib.lrpx_aoa_grad_pix_rows(ctr, head_idx, ptr(v1), ptr(v2), ptr(d_feat), Cc, ptr(rowlist), n, st))
         return d_feat, gs["r_words"], row2img
 
     def explain_batch_gradient(self, captions, head_idx, images, kind="gradient", lens=None, return_features=False):
@@ -319,22 +327,29 @@ class AOAEngine:
         captions = captions.to(self.device, torch.int64).contiguous()
         B, T = captions.shape[0], captions.shape[1] - 1
         tr = self.trace(enc, captions, predictions=False, grad=True)
-        d_feat, r_words, row2img = self.gradient(enc, tr, head_idx, lens)
-        if kind == "gradcam":
-            maps = torch.empty(B * T, enc["P"], device=self.device, dtype=torch.float32)
-            check(_lib.load().lrpx_gradcam(ptr(enc["feats"]), ptr(d_feat), ptr(row2img), ptr(maps), B * T, enc["P"], self.C,
+        rg = ragged(lens, B, T, self.device)
+        d_feat, r_words, row2img = self.gradient(enc, tr, head_idx, rg)
+        n = d_feat.shape[0]                      # B*T, or the valid rows of captions of unequal length
+        if n == 0:
+            maps = d_feat.new_zeros((0, enc["P"]) if kind == "gradcam" else (0, 3, 224, 224))
+        elif kind == "gradcam":
+            maps = torch.empty(n, enc["P"], device=self.device, dtype=torch.float32)
+            check(_lib.load().lrpx_gradcam(ptr(enc["feats"]), ptr(d_feat), ptr(row2img), ptr(maps), n, enc["P"], self.C,
                                            stream_ptr()))
-            maps = maps.view(B, T, enc["P"])
         elif kind in ("guided", "guided_gradcam"):
             maps = self.vgg.guided_backprop(d_feat, row2img)
             if kind == "guided_gradcam":         # ExplainAOAGuidedGradCam (:1714-1751): x the expanded Grad-CAM map
-                cam = torch.empty(B * T, enc["P"], device=self.device, dtype=torch.float32)
-                check(_lib.load().lrpx_gradcam(ptr(enc["feats"]), ptr(d_feat), ptr(row2img), ptr(cam), B * T, enc["P"],
+                cam = torch.empty(n, enc["P"], device=self.device, dtype=torch.float32)
+                check(_lib.load().lrpx_gradcam(ptr(enc["feats"]), ptr(d_feat), ptr(row2img), ptr(cam), n, enc["P"],
                                                self.C, stream_ptr()))
                 maps = ops.guided_gradcam(maps, cam, int(round(enc["P"] ** 0.5)))
-            maps = maps.view(B, T, 3, 224, 224)
         else:
-            maps = self.vgg.gradient(d_feat, row2img).view(B, T, 3, 224, 224)
+            maps = self.vgg.gradient(d_feat, row2img)
+        if rg is not None and not rg.full:       # back to the padded layout, zeros behind an image's last word
+            maps = ops.scatter_maps(maps, rg)
+            if return_features:
+                d_feat = ops.scatter_maps(d_feat, rg)
+        maps = maps.view(B, T, enc["P"]) if kind == "gradcam" else maps.view(B, T, 3, 224, 224)
         out = (maps, r_words.view(B, T, T))
         if return_features:
             out = out + (d_feat.view(B, T, enc["P"], self.C), tr, enc)
@@ -366,12 +381,17 @@ class AOAEngine:
             self._idx_cache[key] = (idx, row2img, rowid)
         return self._idx_cache[key]
 
-    def relevance(self, enc, tr, head_idx, lens=None):
-        """explain_caption_wordt (:1064-1156) for every (image, word) row -> r_feat (B*T,P,C), r_words (B*T,T)."""
+    def relevance(self, enc, tr, head_idx, lens=None, compact=True):
+        """explain_caption_wordt (:1064-1156) for every (image, word) row -> r_feat (B*T,P,C), r_words (B*T,T), row -> image.
+        lens (one caption length per image; explainers/ragged.py): padded words are skipped by the lock-step kernels and, with
+        compact=True (the image path: the rows feed the VGG16 chain), the (word, pixel) rules run on the valid rows only:
+        r_feat is then (sum(lens), P, C) with the matching row -> image table."""
         lib = _lib.load()
         st = stream_ptr()
         B, T, P, H, E, Cc = tr["B"], tr["T"], tr["P"], self.H, self.E, self.C
         rows = B * T
+        rg = ragged(lens, B, T, self.device)
+        lens = rg.lens if rg is not None else None
         e = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
         rs = dict(r_hn=e(rows, H), r_glob=e(rows, H), A=e(rows, H), rx=e(rows, E + 2 * H), r_words=e(rows, T))
         c = AoaRelState()
@@ -386,8 +406,6 @@ class AOAEngine:
         f16 = 1 if self.lockstep_f16 else 0
         ops.conv_mfma(rs["A"], self.p_lin_rel_h if f16 else self.p_lin_rel, rows, 0, H, H, 1, EPI_REL, pix_per_map=1, oc_split=H,
                       x=tr["ctx"], map2img=rowid, out0=r_ctx, f16x3=f16)
-        a_val = e(rows, P, H)
-        check(lib.lrpx_aoa_rel_value(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), st))
         W = E + 2 * H
         # the lock-steps s = 0..T-1 (:1114-1134) in one native call: phase 0, the LSTM dense rule with map2img = idx[s], phase 1
         dense = ops.conv_desc(rs["A"], self.p_wg_h if f16 else self.p_wg, rows, 0, H, W, 1, EPI_REL, pix_per_map=1, oc_split=W,
@@ -396,21 +414,29 @@ class AOAEngine:
         # :1136-1144  r_proj = eye rule on the mean (U) + v_proj dense rule; fused division for the projector rule
         U = e(rows, H)
         check(lib.lrpx_rel_avg_u(ptr(rs["r_glob"]), ptr(enc["glob"]), ptr(U), rows, T, H, P, st))
-        a_proj = e(rows, P, H)
-        r_feat = e(rows, P, Cc)
+        check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
+        n, rowlist = rows, None
+        if rg is not None and not rg.full and compact:     # unequal lengths: the (word, pixel) rules on the valid rows only
+            n, rowlist, row2img = rg.n, rg.rows, rg.row2img
+            if n == 0:
+                return e(0, P, Cc), rs["r_words"], row2img
+            U = ops.gather_rows(U, rowlist)
+        a_val = e(n, P, H)
+        check(lib.lrpx_aoa_rel_value_rows(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), ptr(rowlist), n, st))
+        a_proj = e(n, P, H)
+        r_feat = e(n, P, Cc)
         if self.p_v_rel_h is not None and P >= 32:
-            amax2 = torch.zeros(rows, dtype=torch.int32, device=self.device)         # max|a_proj| per row: recorded by the first GEMM
-            ops.conv_mfma(a_val, self.p_v_rel_h, rows, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
+            amax2 = torch.zeros(n, dtype=torch.int32, device=self.device)         # max|a_proj| per row: recorded by the first GEMM
+            ops.conv_mfma(a_val, self.p_v_rel_h, n, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
                           zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img, out1=a_proj, f16x3=1,
-                          in_amax=ops.amax_maps(a_val, rows), out1_amax=amax2)
-            ops.conv_mfma(a_proj, self.p_proj_rel_h, rows, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
+                          in_amax=ops.amax_maps(a_val, n), out1_amax=amax2)
+            ops.conv_mfma(a_proj, self.p_proj_rel_h, n, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
                           x=enc["feats"], map2img=row2img, out0=r_feat, f16x3=1, in_amax=amax2)       # :1145-1148
         else:
-            ops.conv_mfma(a_val, self.p_v_rel, rows, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
+            ops.conv_mfma(a_val, self.p_v_rel, n, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
                           zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img, out1=a_proj)
-            ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=enc["feats"],
+            ops.conv_mfma(a_proj, self.p_proj_rel, n, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=enc["feats"],
                           map2img=row2img, out0=r_feat)                                   # :1145-1148
-        check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
         return r_feat, rs["r_words"], row2img
 
     def explain_batch(self, captions, head_idx, images=None, features=None, lens=None, accumulate=False,
@@ -422,12 +448,22 @@ class AOAEngine:
         captions = captions.to(self.device, torch.int64).contiguous()
         B, T = captions.shape[0], captions.shape[1] - 1
         tr = self.trace(enc, captions, predictions=predictions)
-        r_feat, r_words, row2img = self.relevance(enc, tr, head_idx, lens)
-        if features is not None:
+        rg = ragged(lens, B, T, self.device)
+        if features is not None:         # bottom-up: the region relevance IS the result; rows behind an image's last word are zero
+            r_feat, r_words, _ = self.relevance(enc, tr, head_idx, rg, compact=False)
             return r_feat.view(B, T, enc["P"], self.C), r_words.view(B, T, T)
-        maps = self.vgg.relevance(r_feat, row2img)
-        if accumulate:
-            maps = ops.cumsum_maps(maps, B, T)
+        r_feat, r_words, row2img = self.relevance(enc, tr, head_idx, rg)
+        if rg is not None and not rg.full:
+            # unequal caption lengths (models/aoamodel.py:1171-1176 explains `caption_length` words): the VGG16 chain runs on the
+            # sum(lens) valid maps; back to the padded layout afterwards (running sums per image over ITS words)
+            maps = self.vgg.relevance(r_feat, row2img) if rg.n else r_feat.new_zeros(0, 3, 224, 224)
+            maps = ops.scatter_maps(maps, rg, accumulate=accumulate)
+            if return_features:
+                r_feat = ops.scatter_maps(r_feat, rg)
+        else:
+            maps = self.vgg.relevance(r_feat, row2img)
+            if accumulate:
+                maps = ops.cumsum_maps(maps, B, T)
         out = (maps.view(B, T, 3, 224, 224), r_words.view(B, T, T))
         if return_features:
             out = out + (r_feat.view(B, T, enc["P"], self.C), tr, enc)
@@ -491,12 +527,14 @@ class AOAEngine:
             self._replicas.append(self.replica())
             self._streams.append(torch.cuda.Stream(device=self.device))
         pending = []
-        for i, (images, captions) in enumerate(batches):
+        for i, batch in enumerate(batches):
+            images, captions = batch[0], batch[1]
+            lens = batch[2] if len(batch) > 2 else None                 # (images, captions[, lens])
             k = i % depth
             st = self._streams[k]
             st.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(st):
-                out = self._replicas[k].explain_batch(captions, head_idx, images=images, accumulate=accumulate)
+                out = self._replicas[k].explain_batch(captions, head_idx, images=images, lens=lens, accumulate=accumulate)
                 ev = torch.cuda.Event()
                 ev.record(st)
             for t in out:

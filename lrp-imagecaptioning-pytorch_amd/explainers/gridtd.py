@@ -12,6 +12,7 @@ import torch
 from .. import _lib, ops
 from .._lib import (EPI_PLAIN, EPI_REL, GridGradState, GridRelState, GridTrace, PACK_DENSE, PACK_DENSE_T, check, ptr,
                     ptr_at, stream_ptr)
+from .ragged import ragged
 
 VGG_PREFIX = "img_encoder.encoder."
 
@@ -334,18 +335,22 @@ class GridTDEngine:
 
     def relevance(self, enc, tr, lens=None, want_r_feat=True):
         """explain_caption_wordt (gridTDmodel.py:1014-1135) for every (image, word) row at once.
-        Returns r_feat (B*T, P, C) relevance of the encoder output (NHWC) and r_words (B*T, T)."""
+        Returns r_feat (B*T, P, C) relevance of the encoder output (NHWC), r_words (B*T, T) and the row -> image table.
+        lens (one caption length per image, list / array / tensor; explainers/ragged.py): words past an image's length are
+        skipped by the lock-step kernels (their r_words rows stay zero), and the (word, pixel) rules run on the VALID rows only -
+        r_feat is then COMPACT, (sum(lens), P, C) in image-major order, with the matching row -> image table."""
         lib = _lib.load()
         st = stream_ptr()
         B, T, H, E, P, Cc = tr["B"], tr["T"], self.H, self.E, self.P, self.C
         rows = B * T
         dev = self.device
+        rg = ragged(lens, B, T, dev)
         e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         rs = dict(r_h2n=e(rows, H), r_c2=e(rows, H), r_c1=e(rows, H), r_ch0=e(rows, H), r_h2p=e(rows, H),
                   r_glob=e(rows, E), A=e(rows, H), rx=e(rows, 2 * E + 2 * H), wacc=torch.zeros(rows, T, H, device=dev),
                   r_words=e(rows, T))
         c = GridRelState()
-        c.lens = ptr(lens)
+        c.lens = ptr(rg.lens) if rg is not None else None
         for k, v in rs.items():
             setattr(c, k, ptr(v))
         ctr, crs = C.byref(tr["_c"]), C.byref(c)
@@ -370,16 +375,22 @@ class GridTDEngine:
                       pix_per_map=1, oc_split=Cc, x=enc["avg"], map2img=row2img, out0=r_avg, f16x3=f16)
         U = e(rows, Cc)
         check(lib.lrpx_rel_avg_u(ptr(r_avg), ptr(enc["avg"]), ptr(U), rows, T, Cc, P, st))
-        a_proj = e(rows, P, H)
-        check(lib.lrpx_gridtd_rel_pix(ctr, crs, ptr(enc["Vp"]), ptr(enc["proj_pre"]), ptr(a_proj), st))
-        r_feat = e(rows, P, Cc)
-        if self.p_proj_rel_h is not None:
-            ops.conv_mfma(a_proj, self.p_proj_rel_h, rows, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
-                          x=enc["feats"], u=U, map2img=row2img, out0=r_feat, f16x3=1, in_amax=ops.amax_maps(a_proj, rows))
-        else:
-            ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
-                          x=enc["feats"], u=U, map2img=row2img, out0=r_feat)
         check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
+        n, rowlist = rows, None
+        if rg is not None and not rg.full:       # unequal lengths: the (word, pixel) rule on the valid rows only, compact
+            n, rowlist, row2img = rg.n, rg.rows, rg.row2img
+            if n == 0:
+                return e(0, P, Cc), rs["r_words"], row2img
+            U = ops.gather_rows(U, rowlist)
+        a_proj = e(n, P, H)
+        check(lib.lrpx_gridtd_rel_pix_rows(ctr, crs, ptr(enc["Vp"]), ptr(enc["proj_pre"]), ptr(a_proj), ptr(rowlist), n, st))
+        r_feat = e(n, P, Cc)
+        if self.p_proj_rel_h is not None:
+            ops.conv_mfma(a_proj, self.p_proj_rel_h, n, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
+                          x=enc["feats"], u=U, map2img=row2img, out0=r_feat, f16x3=1, in_amax=ops.amax_maps(a_proj, n))
+        else:
+            ops.conv_mfma(a_proj, self.p_proj_rel, n, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
+                          x=enc["feats"], u=U, map2img=row2img, out0=r_feat)
         return r_feat, rs["r_words"], row2img
 
     def explain_batch_graph(self, images, captions, accumulate=False, predictions=False):
@@ -414,11 +425,13 @@ class GridTDEngine:
     def guided_gradient(self, enc, tr, lens=None, mask_features=True):
         """ExplainiGridTDGuidedGradient.explain_caption_wordt (gridTDmodel.py:1588-1675) for every (image, word)
         row: decoder BPTT with alpha/beta constant.  `tr` must be a grad=True trace.
-        Returns d_feat (B*T, P, C), r_words (B*T, T), row2img."""
+        Returns d_feat (B*T, P, C), r_words (B*T, T), row2img.  With `lens` d_feat holds the valid rows only (as `relevance`)."""
         lib = _lib.load()
         st = stream_ptr()
         B, T, H, E, P, Cc = tr["B"], tr["T"], self.H, self.E, self.P, self.C
         rows = B * T
+        rg = ragged(lens, B, T, self.device)
+        lens = rg.lens if rg is not None else None
         e = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
         gs = dict(d_h2n=e(rows, H), d_c2=e(rows, H), d_c1=e(rows, H), d_ch0=e(rows, H), d_h2p=e(rows, H),
                   d_glob=e(rows, E), gates=e(rows, 4 * H), dx=e(rows, 3 * H), wacc=torch.zeros(rows, T, H, device=self.device),
@@ -442,8 +455,16 @@ class GridTDEngine:
         ops.conv_mfma(gs["d_glob"], self.p_gp_grad, rows, 0, E, Cc, 1, EPI_PLAIN, pix_per_map=1, oc_split=Cc, out0=d_avg)
         U = e(rows, Cc)
         check(lib.lrpx_scale(ptr(d_avg), ptr(U), d_avg.numel(), 1.0 / P, st))                    # :1667
+        check(lib.lrpx_rel_words_norm(ptr(gs["r_words"]), rows, T, st))
+        rowlist = None
+        if rg is not None and not rg.full:
+            rows, rowlist, row2img = rg.n, rg.rows, rg.row2img
+            if rows == 0:
+                return e(0, P, Cc), gs["r_words"], row2img
+            U = ops.gather_rows(U, rowlist)
         a_proj = e(rows, P, H)
-        check(lib.lrpx_spread_pixels(ptr(gs["wacc"]), ptr(tr["alpha"]), ptr(lens), ptr(a_proj), B, T, H, P, st))
+        check(lib.lrpx_spread_pixels_rows(ptr(gs["wacc"]), ptr(tr["alpha"]), ptr(lens), ptr(a_proj), B, T, H, P, ptr(rowlist),
+                                          rows, st))
         if mask_features:
             mask = e(B, P, Cc)
             check(lib.lrpx_positive_mask(ptr(enc["feats"]), ptr(mask), mask.numel(), st))         # :1674
@@ -452,7 +473,6 @@ class GridTDEngine:
         d_feat = e(rows, P, Cc)
         ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=mask, u=U,
                       map2img=row2img, out0=d_feat)                                              # :1668, :1674
-        check(lib.lrpx_rel_words_norm(ptr(gs["r_words"]), rows, T, st))
         return d_feat, gs["r_words"], row2img
 
     def explain_batch_guided(self, images, captions, lens=None, return_features=False, gradcam=False):
@@ -465,10 +485,18 @@ class GridTDEngine:
         B, T = captions.shape[0], captions.shape[1] - 1
         enc = self.encode(images)
         tr = self.trace(enc, captions, predictions=False, grad=True)
-        d_feat, r_words, row2img = self.guided_gradient(enc, tr, lens)
-        maps = self.vgg.guided_backprop(d_feat, row2img)
-        if gradcam:
-            maps = ops.guided_gradcam(maps, self.grad_cam(enc, d_feat, row2img), int(round(self.P ** 0.5)))
+        rg = ragged(lens, B, T, self.device)
+        d_feat, r_words, row2img = self.guided_gradient(enc, tr, rg)
+        if d_feat.shape[0] == 0:                  # every caption empty
+            maps = d_feat.new_zeros(0, 3, 224, 224)
+        else:
+            maps = self.vgg.guided_backprop(d_feat, row2img)
+            if gradcam:
+                maps = ops.guided_gradcam(maps, self.grad_cam(enc, d_feat, row2img), int(round(self.P ** 0.5)))
+        if rg is not None and not rg.full:        # back to the padded (image, word) layout, zeros behind the last word
+            maps = ops.scatter_maps(maps, rg)
+            if return_features:
+                d_feat = ops.scatter_maps(d_feat, rg)
         out = (maps.view(B, T, 3, 224, 224), r_words.view(B, T, T))
         if return_features:
             out = out + (d_feat.view(B, T, self.P, self.C), tr, enc)
@@ -483,11 +511,19 @@ class GridTDEngine:
         B, T = captions.shape[0], captions.shape[1] - 1
         enc = self.encode(images)
         tr = self.trace(enc, captions, predictions=False, grad=True)
-        d_feat, r_words, row2img = self.guided_gradient(enc, tr, lens, mask_features=False)
-        if cam:
-            maps = self.grad_cam(enc, d_feat, row2img).view(B, T, self.P)
+        rg = ragged(lens, B, T, self.device)
+        d_feat, r_words, row2img = self.guided_gradient(enc, tr, rg, mask_features=False)
+        if d_feat.shape[0] == 0:
+            maps = d_feat.new_zeros((0, self.P) if cam else (0, 3, 224, 224))
+        elif cam:
+            maps = self.grad_cam(enc, d_feat, row2img)
         else:
-            maps = self.vgg.gradient(d_feat, row2img).view(B, T, 3, 224, 224)
+            maps = self.vgg.gradient(d_feat, row2img)
+        if rg is not None and not rg.full:
+            maps = ops.scatter_maps(maps, rg)
+            if return_features:
+                d_feat = ops.scatter_maps(d_feat, rg)
+        maps = maps.view(B, T, self.P) if cam else maps.view(B, T, 3, 224, 224)
         out = (maps, r_words.view(B, T, T))
         if return_features:
             out = out + (d_feat.view(B, T, self.P, self.C), tr, enc)
@@ -512,10 +548,19 @@ class GridTDEngine:
         B, T = captions.shape[0], captions.shape[1] - 1
         enc = self.encode(images)
         tr = self.trace(enc, captions, predictions=predictions)
-        r_feat, r_words, row2img = self.relevance(enc, tr, lens)
-        maps = self.vgg.relevance(r_feat, row2img)
-        if accumulate:
-            maps = ops.cumsum_maps(maps, B, T)
+        rg = ragged(lens, B, T, self.device)
+        r_feat, r_words, row2img = self.relevance(enc, tr, rg)
+        if rg is not None and not rg.full:
+            # unequal caption lengths (models/gridTDmodel.py:1147-1153 explains `caption_length` words): the chain runs on
+            # the sum(lens) valid maps; the result goes back to the padded layout (running sums per image over ITS words)
+            maps = self.vgg.relevance(r_feat, row2img) if rg.n else r_feat.new_zeros(0, 3, 224, 224)
+            maps = ops.scatter_maps(maps, rg, accumulate=accumulate)
+            if return_features:
+                r_feat = ops.scatter_maps(r_feat, rg)
+        else:
+            maps = self.vgg.relevance(r_feat, row2img)
+            if accumulate:
+                maps = ops.cumsum_maps(maps, B, T)
         out = (maps.view(B, T, 3, 224, 224), r_words.view(B, T, T))
         if predictions:
             out = out + (tr["pred"],)
@@ -547,12 +592,14 @@ class GridTDEngine:
             self._replicas.append(self.replica())
             self._streams.append(torch.cuda.Stream(device=self.device))
         pending = []
-        for i, (images, captions) in enumerate(batches):
+        for i, batch in enumerate(batches):
+            images, captions = batch[0], batch[1]
+            lens = batch[2] if len(batch) > 2 else None                 # (images, captions[, lens])
             k = i % depth
             st = self._streams[k]
             st.wait_stream(torch.cuda.current_stream(self.device))     # inputs produced on the caller's stream
             with torch.cuda.stream(st):
-                out = self._replicas[k].explain_batch(images, captions, accumulate=accumulate)
+                out = self._replicas[k].explain_batch(images, captions, lens=lens, accumulate=accumulate)
                 ev = torch.cuda.Event()
                 ev.record(st)
             for t in out:

@@ -201,6 +201,29 @@ def cumsum_maps(maps, n_img, t_per_img, out=None):
     return out
 
 
+def gather_rows(src, rows):
+    """src (R, ...) 4-byte items, rows int32 (n,) on device -> (n, ...) = src[rows] (lrpx_gather_rows)"""
+    src = _dev(src).contiguous()
+    n = rows.shape[0]
+    out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if n:
+        check(_lib.load().lrpx_gather_rows(ptr(src), ptr(rows), ptr(out), n, src[0].numel(), stream_ptr()))
+    return out
+
+
+def scatter_maps(compact, rg, accumulate=False):
+    """compact (n_valid, ...) results of the valid (image, word) rows of `rg` (explainers.ragged.RaggedRows) -> the padded
+    (B*T, ...) layout: the rows themselves (accumulate: per-image running sums, the `explain_caption` quirk) and exact zeros
+    behind every image's last word."""
+    out = torch.empty((rg.B * rg.T,) + tuple(compact.shape[1:]), dtype=torch.float32, device=rg.rows.device)
+    per = out[0].numel()
+    if rg.n == 0:
+        return out.zero_()
+    check(_lib.load().lrpx_scatter_maps(ptr(_dev(compact).contiguous()), ptr(out), rg.B, rg.T, ptr(rg.lens), ptr(rg.offs), per,
+                                        1 if accumulate else 0, stream_ptr()))
+    return out
+
+
 def check_relevance(buf, finite=True, nonzero=False):
     """The reference's inline asserts (lrp_modules.py:154-155, lrp_wrapper.py:81); syncs the stream."""
     check(_lib.load().lrpx_check(ptr(buf), buf.numel(), (1 if finite else 0) | (2 if nonzero else 0), stream_ptr()))

@@ -70,12 +70,16 @@ def words_bound(got, ref32, ref64, what):
     return e64, noise
 
 
-def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout, g64=None):
+def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout, g64=None, pos=POS, lens=None):
     """r_feat (B,T,P,C) / r_words (B,T,T) of the engine vs the golden rows `prefix{k}_*`.
     layout 'chw': golden sub = (C/stride, 14, 14); 'pc': golden sub = (P, C/stride).
-    tol_words: flat bound against the reference's fp32 rows, or None = the fp64-anchored bound (g64 = t20_f64.npz view)."""
+    tol_words: flat bound against the reference's fp32 rows, or None = the fp64-anchored bound (g64 = t20_f64.npz view).
+    pos: batch positions of the golden images; lens: words of golden image k that the batch explains (a caption cut after
+    lens[k] words: word t depends on the steps 0..t only, so the fixture's first lens[k] rows are the reference's result)."""
     worst_f, worst_w, worst_ratio, worst_well, n_well = 0.0, 0.0, 0.0, 0.0, 0
-    for k, p in enumerate(POS):
+    T_pad = T
+    for k, p in enumerate(pos):
+        T = T_pad if lens is None else int(lens[k])
         for t in range(T):
             st = g[f"{prefix}{k}_r_feat_stats_{t}"]                       # sum, absmax, L2, L1 over ALL channels
             got = r_feat[p, t].double()                                   # (P,C)
@@ -105,9 +109,11 @@ def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout, g64
                     assert w <= 1e-5, (prefix, k, t, "vs the reference's fp32 row", float(w), "its own distance from fp64", noise)
                 st64 = g64[f"{prefix}{k}_r_feat_stats64_{t}"]           # r_feat of the fp64 evaluation: L2 and max agree
                 assert abs(got.norm().item() - st64[2]) <= 1e-4 * st64[2] and abs(got.abs().max().item() - st64[1]) <= 1e-4 * st64[1]
-            if t + 1 < T:
+            if t + 1 < T_pad:
                 assert r_words[p, t, t + 1:].abs().max().item() == 0      # nothing beyond the word's own prefix
-        tf = T - 1 - 9 * k
+        tf = T_pad - 1 - 9 * k
+        if tf >= T:
+            continue
         full = torch.from_numpy(g[f"{prefix}{k}_r_feat_full_{tf}"])
         want = full.reshape(full.shape[0], -1).t() if layout == "chw" else full
         assert rel_err(r_feat[p, tf], want) < TOL, (prefix, k, "full")

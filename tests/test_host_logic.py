@@ -138,3 +138,25 @@ def test_zeros_arena_views_are_zero_disjoint_and_aligned():
     assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
     v["a"].fill_(1.0)
     assert not v["b"].any() and not v["c"].any() and not v["d"].any()
+
+
+def test_ragged_rows_of_unequal_caption_lengths():
+    """explainers/ragged.py: the row tables of a batch whose captions differ in length (models/gridTDmodel.py:1147-1153 explains
+    `caption_length` words per image): valid rows image-major, their images, the first compact row of every image; cached per
+    pattern; bad patterns refused"""
+    from lrp_amd.explainers.ragged import RaggedRows, ragged
+    r = RaggedRows([3, 0, 1, 4], 4, 4, "cpu")
+    assert r.n == 8 and not r.full
+    assert r.rows.tolist() == [0, 1, 2, 8, 12, 13, 14, 15] and r.row2img.tolist() == [0, 0, 0, 2, 3, 3, 3, 3]
+    assert r.offs.tolist() == [0, 3, 3, 4] and r.lens.tolist() == [3, 0, 1, 4]
+    assert r.rows.dtype == torch.int32 and r.offs.dtype == torch.int32
+    assert RaggedRows([2, 2], 2, 2, "cpu").full and RaggedRows([0, 0], 2, 5, "cpu").n == 0
+    assert ragged(None, 2, 2, "cpu") is None
+    a = ragged([1, 2], 2, 2, "cpu")
+    assert ragged(torch.tensor([1, 2]), 2, 2, "cpu") is a and ragged(a, 2, 2, "cpu") is a
+    with pytest.raises(ValueError):
+        RaggedRows([1, 2, 3], 2, 4, "cpu")
+    with pytest.raises(ValueError):
+        RaggedRows([1, 5], 2, 4, "cpu")
+    with pytest.raises(ValueError):
+        RaggedRows([-1, 2], 2, 4, "cpu")
