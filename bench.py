@@ -205,6 +205,12 @@ def parse(argv=None):
     ap.add_argument("--vocab", type=int, default=None)
     ap.add_argument("--head", type=int, default=0, help="AoA head explained (configs 3 / 5)")
     ap.add_argument("--gather", action="store_true", help="gather the maps to rank 0 over RCCL inside the step")
+    ap.add_argument("--lens", default=None, choices=[None, "uniform"],
+                    help="config 2: captions of unequal length, words per image ~U[8, --words] (seeded); the step is "
+                         "explain_batch(lens=...) and maps/s counts the VALID (image, word) maps only")
+    ap.add_argument("--allow-experiment", action="store_true",
+                    help="print a line even when liblrpx.so is a timing-experiment / profiling build (lrpx_build_flags() non-empty); "
+                         "the line is marked value_valid=false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the roofline.modes sweep (every conv mode, same process)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 3 / 4 / 5 and the B=64 line, same process)")
@@ -277,13 +283,24 @@ def other_configs(a):
     import gc
     res = {}
     todo = [("3", ["--config", "3"], 6), ("3_all_heads", ["--config", "3", "--all-heads"], 2),
-            ("4", ["--config", "4"], 6), ("5", ["--config", "5"], 80), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 6)]
+            ("4", ["--config", "4"], 6), ("5", ["--config", "5"], 80), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 6),
+            ("varlen", ["--config", "2", "--lens", "uniform"], 12)]
+    # the same lines with three fp16 products per fp32 product (conv mode 2, <= 1e-6 of max|R|): for a reader who rejects the fp6 cross terms
+    grade = [("3", ["--config", "3"], 4), ("4", ["--config", "4"], 4), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 4)]
+    todo += [(k + "#fp32_grade", argv, n) for k, argv, n in grade] if a.conv_mode == 3 else []
     for key, argv, n in todo:
         gc.collect()
         torch.cuda.empty_cache()
+        fp32_grade = key.endswith("#fp32_grade")
         b = parse(argv + ["--steps", str(n), "--warmup", "4", "--sustain", "0", "--no-modes", "--no-cpu-baseline", "--no-configs",
-                          "--conv-mode", str(a.conv_mode)])
+                          "--conv-mode", "2" if fp32_grade else str(a.conv_mode)])
         o = run_config(b, None, 0, 1)
+        if fp32_grade:
+            k0 = key.split("#")[0]
+            res[k0]["value_fp32_grade"] = o["value"]
+            res[k0]["value_fp32_grade_note"] = f"conv mode 2 (f16x3: every product to 2^-21, fp32 accumulate), {n} timed steps, same process"
+            log(f"configs[{k0}] fp32-grade (mode 2): {o['value']:.0f} maps/s")
+            continue
         r = o.get("roofline") or {}
         line = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": n, "maps_per_step": o["config"]["maps_per_step"],
                 "batches_in_flight": o["config"]["batches_in_flight"], "workload": o["config"]["workload"],
@@ -321,6 +338,19 @@ def run_config(a, dist, rank, world):
     heads = list(range(8)) if (a.all_heads and a.config == 3) else [a.head]
     maps_per_gpu = B * T * (2 if guided else 1) * len(heads)
     has_vgg = a.config != 5
+    build_flags = lib.lrpx_build_flags().decode()
+    if build_flags and not a.allow_experiment:
+        # a timing-experiment / STAMP library (loaded through LRPX_LIB_PATH) computes wrong results on purpose; its maps/s
+        # must never be recorded as a product number
+        print(f"bench.py: liblrpx.so is an experiment build ({build_flags!r}); pass --allow-experiment for a line marked invalid",
+              file=sys.stderr)
+        sys.exit(3)
+    lens = None
+    if a.lens == "uniform":
+        assert a.config == 2 and not guided, "--lens applies to config 2 (LRP)"
+        import numpy as np
+        lens = np.random.RandomState(300 + rank).randint(8, T + 1, size=B).tolist()
+        maps_per_gpu = int(sum(lens))
 
     def buf(name, k, *shape):
         key = f"{name}{k}"
@@ -335,6 +365,9 @@ def run_config(a, dist, rank, world):
         state["images"] = images
 
         def one_step(e, k):
+            if lens is not None:          # captions of unequal length: the public entry, padded (B,T,...) results with running sums
+                maps, r_words, _ = e.explain_batch(images, caps, lens=lens, accumulate=True, predictions=True)
+                return maps, r_words
             enc = e.encode(images)
             tr = e.trace(enc, caps, predictions=True)
             r_feat, r_words, row2img = e.relevance(enc, tr)
@@ -349,6 +382,9 @@ def run_config(a, dist, rank, world):
             return cum, r_words
         workload = (f"BASELINE configs[{a.config - 1}]: batch-{B} 224x224 images x {T}-word captions per GPU, VGG16+gridTD, "
                     f"LRP alpha1beta0 (conv) + epsilon (decoder){' + Guided-Backprop side by side' if guided else ''}, V={V}, random-init")
+        if lens is not None:
+            workload += (f"; captions of UNEQUAL length, words per image ~U[8, {T}] = {lens} ({sum(lens)} valid maps per step, "
+                         "padded words cost no (word, pixel) rule and no VGG16 chain time; maps/s counts valid maps only)")
     elif a.config == 3:
         from lrp_amd.explainers.aoa import AOAEngine
         eng = AOAEngine(weights.make_aoa_state(seed=0, vocab_size=V))
@@ -496,7 +532,7 @@ def run_config(a, dist, rank, world):
     events = [ev0]
     dt, outs = timed(a.steps, events)
     maps = outs[0]
-    if not lib.lrpx_build_flags():                            # (a timing-experiment build computes garbage on purpose: tools/ab_chain.sh)
+    if not build_flags:                                       # (a timing-experiment build computes garbage on purpose: tools/ab_chain.sh)
         ops.check_relevance(maps, finite=True, nonzero=True)  # the reference's asserts, outside the timed region
     # step completions by HIP events; with n_pipe batches in flight completions come in bursts, so the per-step time is
     # taken over windows of n_pipe consecutive completions: (end[i] - end[i - n_pipe]) / n_pipe, median over the region
@@ -538,10 +574,13 @@ def run_config(a, dist, rank, world):
                                           "running sums of the maps" if has_vgg else "decoder trace (predictions kept) + decoder relevance",
                           "sharding": f"images x{world}, no data-path collective" + (" + gather" if a.gather else ""),
                           "batches_in_flight": n_pipe, "launch": ("HIP graph replay per batch in flight" if a.graph else "eager") + (", one host thread per batch in flight" if host_threads else "")},
-               "median_ms": round(median_ms, 3), "hip_event_ms_per_step": round(ends[-1] / a.steps, 3), "sustained": sustained}
+               "median_ms": round(median_ms, 3), "hip_event_ms_per_step": round(ends[-1] / a.steps, 3), "sustained": sustained,
+               "build_flags": build_flags, "value_valid": not build_flags}
+        if build_flags:
+            out["metric"] = "INVALID (experiment build of liblrpx.so: " + build_flags + ") " + out["metric"]
         out["median_ms_note"] = (f"median over the timed region of (completion[i] - completion[i-{w}]) / {w} by HIP events "
                                  f"({w} batches in flight complete in bursts); hip_event_ms_per_step = last completion / steps")
-        if world == 1 and has_vgg:
+        if world == 1 and has_vgg and lens is None:
             out["roofline"] = roofline(a, lib, eng, state, maps, B, T, mode)
             if a.config == 2 and not guided and not a.no_modes and not a.graph:      # (the sweep switches modes between eager steps)
                 out["roofline"]["modes"] = mode_sweep(lib, engines, streams, one_step, state, B, T, mode)

@@ -10,7 +10,7 @@ import torch
 from .. import _lib, ops
 from .._lib import (AoaGradState, AoaRelState, AoaStepArgs, AoaTrace, EPI_PLAIN, EPI_REL, PACK_DENSE, PACK_DENSE_T, STAB_EPS, check, ptr, ptr_at,
                     stream_ptr)
-from .gridtd import VGG_PREFIX, _t
+from .gridtd import IMAGENET_MEAN, IMAGENET_STD, VGG_PREFIX, _t, load_image
 from .ragged import ragged
 
 
@@ -550,12 +550,16 @@ class AOAEngine:
 
 
 class ExplainAOAAttention(object):
-    """Drop-in for the reference's `ExplainAOAAttention` (models/aoamodel.py:748-1194): `explain_caption(img, head_idx)`,
-    `explain_caption_wordt(t, head_idx)`, `explain_cnn(R)`, `explain_caption_words(img)`; see
-    explainers/gridtd.py:ExplainGridTDAttention for the conventions (without `caption_encode=` the image is captioned
-    by the reference's own procedure, beam search with beam 3 over 20 steps, :992; nothing written to disk)."""
+    """Drop-in for the reference's `ExplainAOAAttention` (models/aoamodel.py:748-1194), called as evaluation.py:637,702,767 call
+    it: `explain_caption(img_filepath, head_idx)`, `explain_caption_wordt(t, head_idx)`, `explain_cnn(R)`,
+    `explain_caption_words(img_filepath)`, `teacherforce_forward(img, beam_caption_encode)`, `get_hidden_parameters(img_filepath)`,
+    `preprocess_img(img_filepath)`; attributes `.model .word_map .img .img_filepath .beam_caption .beam_caption_encode .predictions
+    .alphas .args`.  Wherever the reference takes a file path a (1,3,H,W) tensor is accepted too.  See
+    explainers/gridtd.py:ExplainGridTDAttention for the conventions (without `caption_encode=` the image is captioned by the
+    reference's own procedure, beam search with beam 3 over 20 steps, :992; nothing written to disk)."""
     EPS = 0.01
     EX_TYPE = 'lrp'
+    TF_MODEL_BIAS = False      # the LRP explainer's LanguageLSTM forward adds bias_ih twice (:873); the gradient family's is correct (:1298)
 
     def __init__(self, args, word_map, model=None):
         self.args = args
@@ -571,10 +575,22 @@ class ExplainAOAAttention(object):
         self.model = model
         self.engine = AOAEngine(state, self.num_head)
         self.rev_word_map = {v: k for k, v in word_map.items()}
+        self.mean = list(IMAGENET_MEAN)
+        self.std = list(IMAGENET_STD)
+
+    def preprocess_img(self, img_filepath):
+        """Resize -> ToTensor -> Normalize (models/aoamodel.py:864-868), host side."""
+        return load_image(img_filepath, getattr(self.args, "height", 224), getattr(self.args, "width", 224), self.mean, self.std,
+                          self.engine.device)
 
     def get_hidden_parameters(self, img, caption_encode=None):
+        """Forward trace (:990-1062).  `img`: file path (the reference's argument) or a (1,3,224,224) tensor."""
         eng = self.engine
-        self.img = img.to(eng.device, torch.float32)
+        if isinstance(img, str):
+            self.img_filepath = img
+            self.img = self.preprocess_img(img)
+        else:
+            self.img = img.to(eng.device, torch.float32)
         self._enc = eng.encode(self.img)
         if caption_encode is None:       # the reference captions the image itself: beam 3, 20 steps (:992-995)
             from .beam import caption_from_sequence
@@ -617,8 +633,22 @@ class ExplainAOAAttention(object):
         ops.check_relevance(self._img_grad, finite=True, nonzero=True)
         return self._img_grad.clone()
 
-    def explain_caption(self, img, head_idx, t_list=None, caption_encode=None):
+    def teacherforce_forward(self, img, beam_caption_encode):
+        """(:952-988; gradient family :1377-1413) -> predictions (len(beam_caption_encode), V) under teacher forcing: step t reads
+        token t (evaluation.py:702,767 hand the caption WITH <start>), with this explainer's own LanguageLSTM forward."""
+        eng = self.engine
+        if isinstance(img, str):
+            img = self.preprocess_img(img)
+        enc = eng.encode(img.to(eng.device, torch.float32))
+        cap = torch.tensor([[int(c) for c in beam_caption_encode] + [0]], dtype=torch.int64, device=eng.device)
+        n = cap.shape[1] - 1
+        tr = eng.trace(enc, cap, model_bias=self.TF_MODEL_BIAS, predictions=False)
+        return eng.logits(tr["hc"].view(n, eng.H))       # the fp32 kernel of the decoding loops, at any caption length
+
+    def explain_caption(self, img_filepath, head_idx, t_list=None, caption_encode=None):
         """(:1165-1181); the returned maps are the reference's running sums (lrp_wrapper.py:64-82)."""
+        img = img_filepath
+        self.img_filepath = img_filepath
         self.get_hidden_parameters(img, caption_encode)
         if self.caption_length == 0:
             return [], []
@@ -629,9 +659,12 @@ class ExplainAOAAttention(object):
         return ([maps[t:t + 1] for t in range(self.caption_length)],
                 [r_words[t, :t + 1] for t in range(self.caption_length)])
 
-    def explain_caption_words(self, img, caption_encode):
+    def explain_caption_words(self, img_filepath, caption_encode=None):
         """(:1183-1194) linguistic relevance only, head 0."""
-        self.get_hidden_parameters(img, caption_encode)
+        self.img_filepath = img_filepath
+        self.get_hidden_parameters(img_filepath, caption_encode)
+        if self.caption_length == 0:
+            return []
         _, r_words, _ = self._relevance(0)
         return [r_words[t, :t + 1] for t in range(self.caption_length)]
 
@@ -641,6 +674,7 @@ class ExplainAOAGradient(ExplainAOAAttention):
     language LSTM for one attention head (`explain_caption_wordt`, :1435-1499) and the autograd gradient through the
     encoder (`explain_cnn`, :1501-1515).  Same surface: `explain_caption(img, head_idx) -> (maps, word scores)`."""
     EX_TYPE = 'gradient'
+    TF_MODEL_BIAS = True
 
     def get_hidden_parameters(self, img, caption_encode=None):
         super().get_hidden_parameters(img, caption_encode)
@@ -663,9 +697,10 @@ class ExplainAOAGradient(ExplainAOAAttention):
         t_nhwc = ops.nchw_to_nhwc(d_img_feature.to(torch.float32))
         return self._cnn(t_nhwc, torch.zeros(d_img_feature.shape[0], dtype=torch.int32, device=self.engine.device))
 
-    def explain_caption(self, img, head_idx, t_list=None, caption_encode=None):
+    def explain_caption(self, img_filepath, head_idx, t_list=None, caption_encode=None):
         """(:1517-1534) no running sums here: the image gradient is a fresh tensor per word."""
-        self.get_hidden_parameters(img, caption_encode)
+        self.img_filepath = img_filepath
+        self.get_hidden_parameters(img_filepath, caption_encode)
         if self.caption_length == 0:
             return [], []
         d_feat, r_words, row2img = self._relevance(head_idx)

@@ -23,6 +23,20 @@ def _t(v, dev):
     return v.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
+IMAGENET_MEAN, IMAGENET_STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def load_image(img_filepath, height, width, mean, std, device):
+    """`preprocess_img` of every reference explainer (models/gridTDmodel.py:767-771, models/aoamodel.py:864-868): PIL open ->
+    RGB -> `transforms.Resize((height, width))` (PIL bilinear) -> `ToTensor` (/255, CHW) -> `Normalize(mean, std)` -> (1,3,H,W)
+    on the device.  Host side, as in the reference (image decoding is outside the path)."""
+    from PIL import Image
+    im = Image.open(img_filepath).convert('RGB').resize((width, height), Image.BILINEAR)
+    x = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1)
+    x = (x - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+    return x.unsqueeze(0).contiguous().to(device)
+
+
 class GridTDEngine:
     """Device-resident gridTD model + trace/relevance pipelines.  `state` is the reference model's
     `state_dict` (torch tensors or numpy arrays, names of models/gridTDmodel.py:111-130)."""
@@ -645,18 +659,14 @@ class ExplainGridTDAttention(object):
             state = model
         self.model = model
         self.engine = GridTDEngine(state)
-        self.mean = [0.485, 0.456, 0.406]
-        self.std = [0.229, 0.224, 0.225]
+        self.mean = list(IMAGENET_MEAN)
+        self.std = list(IMAGENET_STD)
         self.rev_word_map = {v: k for k, v in word_map.items()}
 
     def preprocess_img(self, img_filepath):
         """Resize -> ToTensor -> Normalize (models/gridTDmodel.py:767-771), host side."""
-        from PIL import Image
-        h, w = getattr(self.args, "height", 224), getattr(self.args, "width", 224)
-        im = Image.open(img_filepath).convert('RGB').resize((w, h), Image.BILINEAR)
-        x = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1)
-        x = (x - torch.tensor(self.mean).view(3, 1, 1)) / torch.tensor(self.std).view(3, 1, 1)
-        return x.unsqueeze(0).to(self.engine.device)
+        return load_image(img_filepath, getattr(self.args, "height", 224), getattr(self.args, "width", 224), self.mean, self.std,
+                          self.engine.device)
 
     def get_hidden_parameters(self, img, caption_encode=None, max_cap_length=50):
         """Forward trace (:933-1012).  `img`: file path or a (1,3,224,224) tensor."""
@@ -726,18 +736,26 @@ class ExplainGridTDAttention(object):
         assert len(relevance_imgs) == self.caption_length
         return relevance_imgs, relevance_preceeding_words
 
+    TF_MODEL_BIAS = False      # the LRP explainer's LanguageLSTM forward adds bias_ih twice (:789); the gradient family's is correct (:1265)
+
     def teacherforce_forward(self, img, beam_caption_encode):
-        """(:892-931) -> predictions (len, V) under teacher forcing (explainer forward incl. the bias quirk)."""
+        """(:892-931; gradient family :1282-1321) -> predictions (len(beam_caption_encode), V) under teacher forcing: step t reads
+        token t - evaluation.py:266,437 hands the caption WITH <start> - with this explainer's own forward."""
         eng = self.engine
+        if isinstance(img, str):
+            img = self.preprocess_img(img)
         enc = eng.encode(img.to(eng.device, torch.float32))
-        cap = torch.tensor([list(beam_caption_encode) + [0]], dtype=torch.int64, device=eng.device)
-        return eng.trace(enc, cap, predictions=True)["pred"][0]
+        cap = torch.tensor([[int(c) for c in beam_caption_encode] + [0]], dtype=torch.int64, device=eng.device)
+        n = cap.shape[1] - 1
+        tr = eng.trace(enc, cap, model_bias=self.TF_MODEL_BIAS, predictions=False)
+        return eng.logits(tr["hc"].view(n, eng.H))       # the fp32 kernel of the decoding loops, at any caption length
 
 
 class ExplainiGridTDGuidedGradient(ExplainGridTDAttention):
     """Drop-in for the reference's `ExplainiGridTDGuidedGradient` (models/gridTDmodel.py:1585-1723; the spelling is
     the reference's): guided backprop instead of LRP, same `explain_caption` surface."""
     EX_TYPE = 'GuidedBackpropagate'
+    TF_MODEL_BIAS = True
 
     def get_hidden_parameters(self, img, caption_encode=None, max_cap_length=50):
         super().get_hidden_parameters(img, caption_encode, max_cap_length)

@@ -1021,3 +1021,22 @@ def aoa_gradient_explain_caption(sd, img, caption, head_idx, kind="gradient", nu
     if return_feat:
         return maps, rws, dfs, tr
     return maps, rws
+
+
+# ----------------------------------------------------------------------------------------------
+# teacherforce_forward of the explainers (the evaluation experiments call it after every explanation: evaluation.py:266,437,702,767)
+# ----------------------------------------------------------------------------------------------
+def gridtd_teacherforce(sd, img, caption_with_start, gradient_family=False):
+    """models/gridTDmodel.py:892-931 (LRP explainer; LanguageLSTM adds bias_ih twice, :789) / :1282-1321 (gradient family: correct
+    bias, :1265): scores (len(caption_with_start), V) - step t reads token t, the last word included."""
+    feats, avg, _ = vgg_forward(sd, img)
+    cap = [int(c) for c in caption_with_start] + [0]          # one more step than words: the step that reads the last word
+    return gridtd_trace(sd, feats[0], avg[0], cap, model_bias=gradient_family)["pred"]
+
+
+def aoa_teacherforce(sd, img, caption_with_start, gradient_family=False, num_head=8):
+    """models/aoamodel.py:952-988 (LRP explainer, bias quirk :873) / :1377-1413 (gradient family, :1298)"""
+    feats, _, _ = vgg_forward(sd, img)
+    F_pix = feats[0].reshape(feats.shape[1], -1).t().contiguous()
+    cap = [int(c) for c in caption_with_start] + [0]
+    return aoa_trace(sd, F_pix, cap, num_head, grad=gradient_family)["pred"]

@@ -1095,6 +1095,45 @@ def gen_beam(out, weights, seed=0):
 
 
 
+def gen_teacherforce(out, weights, T=3, seed=0):
+    """`teacherforce_forward(img, beam_caption_encode)` of the four explainer families, called as evaluation.py:266,437,702,767 call
+    it (after `get_hidden_parameters`, with the explainer's own image and the caption INCLUDING <start>): models/gridTDmodel.py
+    :892-931 (LRP explainer: LanguageLSTM adds bias_ih twice) and :1282-1321 (gradient family: correct bias), models/aoamodel.py
+    :952-988 and :1377-1413.  Stored: every 97th score of every step, the arg-max ids, the full last row."""
+    import models.aoamodel as aoa
+    import models.gridTDmodel as gtd
+    g = dict(seed=np.int64(seed), T=np.int64(T))
+    for tag, mod, cls_name, V, make_state in (("grid_lrp", gtd, "ExplainGridTDAttention", 9586, weights.make_gridtd_state),
+                                              ("grid_grad", gtd, "ExplainGridTDGradient", 9586, weights.make_gridtd_state),
+                                              ("aoa_lrp", aoa, "ExplainAOAAttention", 11027, weights.make_aoa_state),
+                                              ("aoa_grad", aoa, "ExplainAOAGradient", 11027, weights.make_aoa_state)):
+        sd = make_state(seed=seed, vocab_size=V)
+        wm = weights.make_word_map(V)
+        img = weights.make_images(seed, 1)
+        cap = weights.make_captions(seed + 1, 1, T, V)[0]
+        with tempfile.TemporaryDirectory() as tmp:
+            real_load = torch.load
+            torch.load = lambda *a, **k: {"state_dict": to_torch_sd(sd)}
+            try:
+                ex = getattr(mod, cls_name)(make_args(tmp, weight="synthetic.pth"), wm)
+            finally:
+                torch.load = real_load
+            _patch_explainer(ex, img, cap)
+            with torch.no_grad():
+                ex.get_hidden_parameters("synthetic.jpg")
+                assert list(ex.beam_caption_encode) == [int(c) for c in cap]
+                pred = ex.teacherforce_forward(ex.img.detach().clone(), ex.beam_caption_encode)
+        assert tuple(pred.shape) == (T + 1, V)
+        g[f"{tag}_V"] = np.int64(V)
+        g[f"{tag}_caption"] = cap
+        g[f"{tag}_pred_sub"] = pred[:, ::97].detach().numpy()
+        g[f"{tag}_argmax"] = pred.argmax(-1).numpy().astype(np.int64)
+        g[f"{tag}_pred_last"] = pred[-1].detach().numpy()
+        g[f"{tag}_absmax"] = np.float64(pred.abs().max().item())
+    np.savez(os.path.join(out, "teacherforce.npz"), **g)
+    print("teacherforce.npz written:", {k: getattr(v, "shape", v) for k, v in g.items() if k.endswith("argmax")})
+
+
 def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
     """Config 1: greedy token ids from the reference model's own `greedy_search`
     (models/gridTDmodel.py:480-520), int64, bit-exact target."""
@@ -1113,7 +1152,7 @@ def gen_greedy(out, weights, V=9586, seed=0, max_len=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,t20_f64,t20_guided,toy,m4,avgpool,forwardlrp,guided_gradcam,beam")
+    ap.add_argument("--only", default="layers,gridtd,aoa,aoa_bu,greedy,guided,gradient,gradcam,aoa_gradient,eval,sample_lrp,aoa_sample_lrp,t20,t20_f64,t20_guided,toy,m4,avgpool,forwardlrp,guided_gradcam,beam,teacherforce")
     ap.add_argument("--threads", type=int, default=1)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -1149,6 +1188,8 @@ def main():
         gen_guided_gradcam(HERE, weights)
     if "beam" in todo:
         gen_beam(HERE, weights)
+    if "teacherforce" in todo:
+        gen_teacherforce(HERE, weights)
     if "guided" in todo:
         gen_guided(HERE, weights)
     if "gradient" in todo:

@@ -920,3 +920,95 @@ def test_blocked_layout_converters_and_weight_row_order(ops):
             rho = lane
             ch = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3) if perm else rho
             assert hi[lane, 0].item() == ch + 1.0, (mode, lane, hi[lane, 0].item())
+
+
+def _trained_like_vgg_state(seed, sigma, dead_frac, heavy, bias_std):
+    """A VGG16 state with the statistics of TRAINED weights instead of kaiming-normal ones (`models/vgg.py:86-94`
+    loads pretrained weights, that is what users run): per-output-channel log-normal scales (spread ~ exp(+-3 sigma)), a fraction of
+    DEAD output channels (all-negative weights + negative bias: exact zeros through the ReLU and exact Z+ = 0 planes for every
+    non-negative input), heavy-tailed entries randn * exp(randn), non-zero biases.  Every layer is renormalised to the kaiming
+    second moment so that 13 layers neither explode nor vanish."""
+    from lrp_amd import weights
+    sd = weights.make_gridtd_state(seed=seed, vocab_size=32)
+    rs = np.random.RandomState(seed + 1000)
+    names = [k for k in sd if k.startswith("img_encoder.encoder.") and k.endswith(".weight")]
+    for li, k in enumerate(names):
+        w = sd[k]
+        cout, cin = w.shape[0], w.shape[1]
+        base = rs.randn(*w.shape)
+        if heavy:
+            base = base * np.exp(rs.randn(*w.shape))
+        scale = np.exp(sigma * rs.randn(cout, 1, 1, 1))
+        wn = base * scale
+        wn *= np.sqrt(2.0 / (cout * 9)) / np.sqrt((wn ** 2).mean())        # kaiming fan_out second moment (models/vgg.py:48-59)
+        b = bias_std * rs.randn(cout) * np.sqrt((wn ** 2).mean()) * np.sqrt(cin * 9)
+        if li > 0 and dead_frac > 0:
+            dead = rs.rand(cout) < dead_frac
+            wn[dead] = -np.abs(wn[dead])
+            b[dead] = -np.abs(b[dead]) - 1e-3
+        sd[k] = wn.astype(np.float32)
+        sd[k.replace(".weight", ".bias")] = b.astype(np.float32)
+    return sd
+
+
+@pytest.mark.parametrize("family,sigma,dead_frac,heavy,bias_std", [
+    ("trained-like", 1.5, 0.10, True, 0.05),          # VERDICT r4 item 3's recipe
+    ("wide channel scales", 2.5, 0.0, False, 0.02),   # per-channel spread ~ 1e6 inside a layer
+    ("dead third + heavy tails", 0.5, 0.33, True, 0.1)])
+def test_chain_hostile_weights_all_modes(ops, gridtd_case, family, sigma, dead_frac, heavy, bias_std):
+    """Chain-level accuracy of the reduced-precision matrix-core modes on hostile WEIGHTS: mode 3's fp6 cross
+    terms are block-scaled per 16-channel slice of BOTH operands, so its error scales with the spread inside a weight slice and with
+    activation outliers; kaiming-normal weights exercise neither.  2 images x 20 maps (signed heavy-tailed relevance, per-map
+    scales 1e-6 .. 1e6, sparse maps, the reference's own decoder relevance) on the oracle's injected trace, conv modes 3 / 2 / 0
+    against `O.vgg_lrp` (LRPtools/lrp_modules.py:56-84,124-195 restated) on EVERY map and against the exact-split bf16x6 chain:
+    < 1e-4 of max|R| per map (BASELINE north_star).  Prints the worst map per relevance family and mode."""
+    from lrp_amd import _lib, weights
+    from oracle import lrp_oracle as O
+    lib = _lib.load()
+    g, _, _ = gridtd_case
+    sd = _trained_like_vgg_state(41, sigma, dead_frac, heavy, bias_std)
+    vgg = _vgg(ops, sd)
+    n_img, n_maps = 2, 40
+    img_cpu = torch.from_numpy(weights.make_images(43, n_img))
+    feats = vgg.forward(img_cpu.cuda())
+    _inject_oracle_trace(vgg, sd, img_cpu)
+    sdt = O.state_to_torch(sd)
+    f_cpu, _, saved = O.vgg_forward(sdt, img_cpu)
+    if dead_frac > 0:          # the dead channels really are dead: exact zero planes in the trace the kernels read
+        frac0 = [float((x == 0).all(dim=(0, 2, 3)).float().mean()) for x in saved[2:] + [f_cpu]]
+        print(f"[{family}] fraction of all-zero channel planes per layer input: " + " ".join(f"{v:.2f}" for v in frac0))
+        assert max(frac0) >= 0.5 * dead_frac
+    assert torch.isfinite(f_cpu).all() and f_cpu.abs().max() > 0
+    m2i = (torch.arange(n_maps, device="cuda") * n_img // n_maps).to(torch.int32)
+    r_feat, names = _hostile_targets(feats, m2i, n_maps, g)
+    out = {}
+    prev = lib.lrpx_set_conv_mode(1)
+    try:
+        for mode in (1, 0, 2, 3):
+            lib.lrpx_set_conv_mode(mode)
+            out[mode] = vgg.relevance(r_feat, m2i).clone().cpu().double()
+            assert torch.isfinite(out[mode]).all(), mode
+    finally:
+        lib.lrpx_set_conv_mode(prev)
+    worst = {}
+    for k in range(n_maps):
+        b = int(m2i[k])
+        want = O.vgg_lrp(sdt, [x[b:b + 1] for x in saved], from_nhwc(r_feat[k:k + 1].cpu(), 512, 14, 14)).double()
+        sc = want.abs().max()
+        assert sc > 0
+        for mode in (3, 2, 1, 0):
+            e = ((out[mode][k:k + 1] - want).abs().max() / sc).item()
+            key = (mode, names[k])
+            if e > worst.get(key, (0.0, -1))[0]:
+                worst[key] = (e, k)
+    for fam in ("heavy", "scaled", "sparse", "reference"):
+        print(f"[{family}] hostile weights, relevance %-9s vs the CPU oracle | " % fam + " | ".join(
+            "mode %d: %.2e (map %d)" % ((m,) + worst[(m, fam)]) for m in (3, 2, 1, 0)))
+    base = out[1]
+    scale = base.abs().amax(dim=(1, 2, 3))
+    for mode in (3, 2, 0):
+        err = ((out[mode] - base).abs().amax(dim=(1, 2, 3)) / scale)
+        print(f"[{family}] mode {mode} vs the bf16x6 chain: worst map {err.max().item():.2e}, mean {err.mean().item():.2e}")
+        assert err.max().item() < TOL, (family, mode, err.max().item())
+    for (mode, fam), (e, k) in worst.items():
+        assert e < TOL, (family, "oracle", mode, fam, e, k)

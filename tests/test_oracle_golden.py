@@ -377,3 +377,24 @@ def test_t20_fp64_fixture_is_the_reference_in_double():
     ill = {("aoa0_h0", 17), ("aoa0_h0", 19)}
     assert all(v <= (7e-5 if k in ill else 1e-5) for k, v in worst.items()), max(worst.items(), key=lambda kv: kv[1])
     assert worst[("aoa0_h0", 17)] > 3e-5 and worst[("aoa0_h0", 19)] > 3e-5       # (the rows the anchoring exists for)
+
+
+def test_teacherforce_forward_vs_reference():
+    """`teacherforce_forward` of the LRP and the gradient explainers of both models (tests/golden/teacherforce.npz: the reference's
+    own methods called as evaluation.py:702 calls them): scores to 2e-5 of their maximum, arg-max ids bit-exact; the two
+    families differ (the LRP explainers add bias_ih twice), so a wrong bias shows"""
+    g = np.load(os.path.join(GOLDEN, "teacherforce.npz"))
+    seed = int(g["seed"])
+    img = torch.from_numpy(weights.make_images(seed, 1))
+    for tag, make_state, fn in (("grid", weights.make_gridtd_state, O.gridtd_teacherforce), ("aoa", weights.make_aoa_state, O.aoa_teacherforce)):
+        sd = O.state_to_torch(make_state(seed=seed, vocab_size=int(g[f"{tag}_lrp_V"])))
+        preds = {}
+        for fam, grad in (("lrp", False), ("grad", True)):
+            k = f"{tag}_{fam}"
+            pred = fn(sd, img, g[f"{k}_caption"], gradient_family=grad)
+            preds[fam] = pred
+            assert tuple(pred.shape) == (int(g["T"]) + 1, int(g[f"{k}_V"]))
+            assert (pred[:, ::97] - torch.from_numpy(g[f"{k}_pred_sub"])).abs().max().item() < 2e-5 * float(g[f"{k}_absmax"]), k
+            assert (pred[-1] - torch.from_numpy(g[f"{k}_pred_last"])).abs().max().item() < 2e-5 * float(g[f"{k}_absmax"]), k
+            assert np.array_equal(pred.argmax(-1).numpy(), g[f"{k}_argmax"]), k
+        assert (preds["lrp"] - preds["grad"]).abs().max().item() > 1e-3     # the bias quirk is visible in the scores
