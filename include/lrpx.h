@@ -275,6 +275,12 @@ int lrpx_vgg16_relevance(const void* packed, const void* trace, int n_img, const
 int lrpx_vgg16_trace_layout(int n_img, size_t* act_off, size_t* zpos_off);
 /* pointer to the encoder output features (n_img,196,512) inside a trace */
 const float* lrpx_vgg16_trace_features(const void* trace, int n_img);
+/* Channel balance of the Z+ / relevance side: conv layer `layer` (0..16, a conv of cfg 'D') keeps its Z+ in the trace as
+ * Z'_c = rs[c] * conv(X, W+)_c and every alpha1beta0 relevance pack carries rs[c] * W+[c,:], rs[c] = 2^(e_max - e_c), e_c = floor(log2
+ * max W+[c,:]) (exact powers of two: S'_c (rs_c W+[c,i]) is the reference's product S_c W+[c,i] of LRPtools/lrp_modules.py:124-150 bit
+ * for bit).  It keeps the operands of the split-product modes inside fp16's range when a channel's weights are small against its bias
+ * (trained weights, models/vgg.py:86-94).  Returns the DEVICE pointer of rs inside `packed` (n_channels floats), null for a pool. */
+const float* lrpx_vgg16_channel_scales(const void* packed, int layer, int* n_channels);
 
 
 /* ---- small dense / utility kernels of the decoders ----------------------------------------------- */

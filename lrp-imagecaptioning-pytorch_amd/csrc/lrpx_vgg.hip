@@ -318,6 +318,8 @@ static thread_local float tl_ms[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
     size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], fwdh0, first6, first6p, first16, first16p, total;
+    size_t chs[17];      // per-output-channel balance factors rs_l[c] of conv l (powers of two, see lrpx_vgg16_pack)
+    size_t scratch;      // scaled weight copies while packing: cout*cin*9 + 2*cout*2*cin*9 floats of the largest layer
 };
 static VggPacked vgg_packed_layout() {
     VggPacked p;
@@ -345,8 +347,74 @@ static VggPacked vgg_packed_layout() {
     p.first6p = off; off += (size_t)64 * 9 * 6;  // ... and of its plain transposed conv (guided backprop)
     p.first16 = off; off += (size_t)16 + 2 * 9 * 64 * 4;   // first layer's rule on the matrix cores (header + A fragments)
     p.first16p = off; off += (size_t)16 + 2 * 9 * 64 * 4;  // ... and its plain transposed conv
+    for (int l = 0; l < kNL; ++l) {
+        p.chs[l] = off;
+        if (kVgg[l].conv) off += (size_t)kVgg[l].cout;
+    }
+    p.scratch = off; off += (size_t)512 * 512 * 9 * 3;
     p.total = off;
     return p;
+}
+
+// ---- channel balance of the Z+ / relevance side (round 5) ----------------------------------------------------------------------
+// The relevance step of conv l contracts over ITS output channels c:  R_in[i] = x_i * sum_{c,taps} S_c W+[c,i],  S_c = R_c / Z+_c
+// (LRPtools/lrp_modules.py:124-150, utils.py:16-31).  A channel whose weights are small against its bias - common in trained
+// networks: models/vgg.py:86-94 loads pretrained weights - has activations ~ b_c but Z+_c ~ |W_c|: S_c ~ 1/|W_c| is huge exactly
+// where W+[c,:] is tiny.  In fp32 (the reference) the product is harmless; operands split into fp16 halves behind ONE scale per map
+// / per layer hold ~2^17 of range at full precision, and the huge S planes push every ordinary entry out of it (measured: 7e-2 of
+// max|R| on a chain with log-normal channel scales, tests/test_gpu_vgg.py::test_chain_hostile_weights_all_modes).
+// Cure, exact in every mode: the Z+ half of the forward weights and every alpha1beta0 relevance pack carry row c multiplied by
+//     rs_l[c] = 2^(e_max - e_c),   e_c = floor(log2 max_{i,taps} W+[c,i])   (first layer: max |W|; a row without positive
+// weights: 1).  The trace then holds Z'_c = rs_c Z+_c, every S the chain forms is S'_c = S_c / rs_c, and S'_c (rs_c W+[c,i]) is
+// the reference's product bit for bit (powers of two).  Where Z+ == 0 the reference divides by 1e-7 (utils.py:16-18); there every
+// product x_i W+[c,i] of the window is zero, so the value of S at such a pixel never reaches R_in, scaled or not.
+__global__ __launch_bounds__(512) void row_scale_kernel(const float* __restrict__ w, int cout, int per_row, int use_abs,
+                                                        float* __restrict__ rs) {
+    __shared__ float sh[512];
+    const int c = threadIdx.x;
+    float m = 0.f;
+    if (c < cout)
+        for (int j = 0; j < per_row; ++j) {
+            const float x = w[(long)c * per_row + j];
+            m = fmaxf(m, use_abs ? fabsf(x) : fmaxf(x, 0.f));
+        }
+    // d = 2^floor(log2 m) for a normal m (the exponent field alone); 0 for rows without a usable weight
+    const unsigned eb = __float_as_uint(m) & 0x7f800000u;
+    const float d = (eb != 0u && eb != 0x7f800000u) ? __uint_as_float(eb) : 0.f;
+    sh[c] = c < cout ? d : 0.f;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) {
+        if (c < o) sh[c] = fmaxf(sh[c], sh[c + o]);
+        __syncthreads();
+    }
+    const float dmax = sh[0];
+    if (c < cout) rs[c] = (d > 0.f && dmax > 0.f) ? dmax / d : 1.f;
+}
+
+__global__ void scale_rows_kernel(const float* __restrict__ w, const float* __restrict__ rs, float* __restrict__ wr,
+                                  int per_row, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) wr[idx] = w[idx] * rs[idx / per_row];
+}
+
+// wd (2 cout, cin2, 9): rows [0, cout) = W (the activation half), rows [cout, 2 cout) = the Z half, rs_c W+ (first layer, cin2 =
+// 2 cin, input channels [x+ | x-]: [W | W] above, [rs W+ | rs W-] below) - packed with LRPX_PACK_FWD this is the LRPX_PACK_FWD_DUAL
+// (_FIRST) layout with the balanced Z half
+__global__ void dual_rows_kernel(const float* __restrict__ w, const float* __restrict__ rs, float* __restrict__ wd, int cout,
+                                 int cin, int first, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cin2 = first ? 2 * cin : cin;
+    const int t = idx % 9;
+    const int ci2 = (idx / 9) % cin2;
+    const int oc = idx / (9L * cin2);
+    const int co = oc < cout ? oc : oc - cout, ci = ci2 < cin ? ci2 : ci2 - cin;
+    float x = w[((long)co * cin + ci) * 9 + t];
+    if (oc >= cout) {
+        x *= rs[co];
+        x = (!first || ci2 < cin) ? fmaxf(x, 0.f) : fminf(x, 0.f);
+    }
+    wd[idx] = x;
 }
 
 struct VggTrace {   // offsets in floats; act[l] = input of layer l, act[17] = encoder output
@@ -441,14 +509,26 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
     VggPacked p = vgg_packed_layout();
     float* base = (float*)packed;
     int ci = 0;
+    hipStream_t st = (hipStream_t)stream;
     for (int l = 0; l < kNL; ++l) {
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         LRPX_REQUIRE(w[ci] && b[ci], "vgg16_pack: null weight %d", ci);
-        LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, l == 0 ? LRPX_PACK_FWD_DUAL_FIRST : LRPX_PACK_FWD_DUAL,
-                                   lrpx_conv_kc(L.hw, 9, cin_pad(l)),
-                                   base + p.fwd[l], stream));
-        LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, l == 0 ? LRPX_PACK_BWD_FIRST : LRPX_PACK_BWD_POS,
+        // channel balance (see row_scale_kernel): rs, wr = rs W (every row), wd = [W ; rs W+] for the forward packs
+        float* rs = base + p.chs[l];
+        float* wr = base + p.scratch;
+        float* wd = wr + (size_t)L.cout * L.cin * 9;
+        const int first = l == 0, cin2 = first ? 2 * L.cin : L.cin;
+        hipLaunchKernelGGL(row_scale_kernel, dim3(1), dim3(512), 0, st, w[ci], L.cout, L.cin * 9, first, rs);
+        LRPX_TRY(check_launch("vgg16_pack: row scales"));
+        const long n_w = (long)L.cout * L.cin * 9, n_d = (long)2 * L.cout * cin2 * 9;
+        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, w[ci], rs, wr, L.cin * 9, n_w);
+        LRPX_TRY(check_launch("vgg16_pack: scaled rows"));
+        hipLaunchKernelGGL(dual_rows_kernel, dim3((unsigned)((n_d + 255) / 256)), dim3(256), 0, st, w[ci], rs, wd, L.cout, L.cin, first, n_d);
+        LRPX_TRY(check_launch("vgg16_pack: dual rows"));
+        const float* w_plain = w[ci];      // the image-gradient chains (guided backprop, plain gradient) take W itself
+        LRPX_TRY(lrpx_pack_weights(wd, 2 * L.cout, cin2, 9, LRPX_PACK_FWD, lrpx_conv_kc(L.hw, 9, cin_pad(l)), base + p.fwd[l], stream));
+        LRPX_TRY(lrpx_pack_weights(wr, L.cout, L.cin, 9, l == 0 ? LRPX_PACK_BWD_FIRST : LRPX_PACK_BWD_POS,
                                    lrpx_conv_kc(L.hw, 9, L.cout), base + p.bwd[l], stream));
         if (hipMemcpyAsync(base + p.bias[l], b[ci], L.cout * sizeof(float), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream) != hipSuccess) {
@@ -456,23 +536,23 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
             return LRPX_ELAUNCH;
         }
         if (l == 0) {
-            LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL_FIRST, base + p.fwdh0, stream));
-            LRPX_TRY(first_layer_pack(w[ci], base + p.first6, L.cout, 0, (hipStream_t)stream));
-            LRPX_TRY(first_layer_pack(w[ci], base + p.first6p, L.cout, 1, (hipStream_t)stream));
-            LRPX_TRY(first_layer_pack_mfma(w[ci], base + p.first16, 0, (hipStream_t)stream));
-            LRPX_TRY(first_layer_pack_mfma(w[ci], base + p.first16p, 1, (hipStream_t)stream));
+            LRPX_TRY(lrpx_pack_weights_f16x2(wd, 2 * L.cout, cin2, 9, LRPX_PACK_FWD, base + p.fwdh0, stream));
+            LRPX_TRY(first_layer_pack(wr, base + p.first6, L.cout, 0, (hipStream_t)stream));
+            LRPX_TRY(first_layer_pack(w_plain, base + p.first6p, L.cout, 1, (hipStream_t)stream));
+            LRPX_TRY(first_layer_pack_mfma(wr, base + p.first16, 0, (hipStream_t)stream));
+            LRPX_TRY(first_layer_pack_mfma(w_plain, base + p.first16p, 1, (hipStream_t)stream));
         } else {
-            LRPX_TRY(lrpx_pack_weights(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, lrpx_conv_kc(L.hw, 9, L.cout),
+            LRPX_TRY(lrpx_pack_weights(w_plain, L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, lrpx_conv_kc(L.hw, 9, L.cout),
                                        base + p.bwdp[l], stream));
         }
-        if (l > 0) LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwd6[l], stream));
-        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwdh[l], stream));
-        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwdh[l], stream));
-        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w[ci], L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, base + p.bwdph[l], stream));
-        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16f8(w[ci], L.cout, L.cin, LRPX_PACK_BWD_POS, base + p.bwd8[l], stream));
-        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16f8(w[ci], L.cout, L.cin, LRPX_PACK_BWD_PLAIN, base + p.bwdp8[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_bf16x3(wr, L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwd6[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(wr, L.cout, L.cin, 9, LRPX_PACK_BWD_POS, base + p.bwdh[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(wd, 2 * L.cout, L.cin, 9, LRPX_PACK_FWD, base + p.fwdh[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w_plain, L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, base + p.bwdph[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16f8(wr, L.cout, L.cin, LRPX_PACK_BWD_POS, base + p.bwd8[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_f16f8(w_plain, L.cout, L.cin, LRPX_PACK_BWD_PLAIN, base + p.bwdp8[l], stream));
         if (L.hw <= 112) {
-            LRPX_TRY(lrpx_pack_weights_bf16x3(w[ci], L.cout, L.cin, 9, LRPX_PACK_FWD_DUAL, base + p.fwd6[l], stream));
+            LRPX_TRY(lrpx_pack_weights_bf16x3(wd, 2 * L.cout, L.cin, 9, LRPX_PACK_FWD, base + p.fwd6[l], stream));
         }
         ++ci;
     }
@@ -519,6 +599,12 @@ int lrpx_vgg16_trace_layout(int n_img, size_t* act_off, size_t* zpos_off) {
 
 const float* lrpx_vgg16_trace_features(const void* trace, int n_img) {
     return (const float*)trace + vgg_trace_layout(n_img).act[kNL];
+}
+
+const float* lrpx_vgg16_channel_scales(const void* packed, int layer, int* n_channels) {
+    if (!packed || layer < 0 || layer >= kNL || !kVgg[layer].conv) return nullptr;
+    if (n_channels) *n_channels = kVgg[layer].cout;
+    return (const float*)packed + vgg_packed_layout().chs[layer];
 }
 
 int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, void* trace, float* feat_nhwc,

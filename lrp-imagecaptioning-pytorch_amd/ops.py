@@ -335,9 +335,19 @@ class Vgg16:
                 (56, 256), (28, 256), (28, 512), (28, 512), (28, 512), (14, 512), (14, 512), (14, 512), (14, 512)]
     IS_CONV = [1, 1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1]
 
+    def channel_scales(self, layer):
+        """rs (cout,) of conv layer `layer` (0..16): the trace keeps Z+ of that layer as rs[c] * conv(X, W+)[c] and the relevance
+        packs carry rs[c] * W+[c, :] (exact powers of two; lrpx_vgg16_channel_scales, include/lrpx.h)."""
+        n = C.c_int(0)
+        p = _lib.load().lrpx_vgg16_channel_scales(ptr(self.packed), int(layer), C.byref(n))
+        if not p:
+            raise ValueError(f"layer {layer} is not a conv layer of VGG16 cfg 'D'")
+        off = (p - self.packed.data_ptr()) // 4
+        return self.packed[off: off + n.value]
+
     def trace_views(self):
         """Views of the saved per-layer tensors (what `module.input` is to the reference's hooks):
-        ([act[0..17]] as (n_img, hw*hw, C), [zpos[l] or None])."""
+        ([act[0..17]] as (n_img, hw*hw, C), [zpos[l] or None]); zpos[l] is Z+ of conv l TIMES `channel_scales(l)` per channel."""
         lib = _lib.load()
         n = self.n_img
         a_off = (C.c_size_t * 18)()

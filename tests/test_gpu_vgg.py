@@ -360,7 +360,8 @@ def _inject_oracle_trace(vgg, sd, img):
             w = sdt[f"img_encoder.encoder.{idx}.weight"]
             x = saved[l]
             z = F.conv2d(x.clamp(min=0), w.clamp(min=0), padding=1) + F.conv2d(x.clamp(max=0), w.clamp(max=0), padding=1)
-            zs[l].copy_(to_nhwc(z))
+            # the trace keeps Z+ times the layer's channel-balance factors (powers of two: include/lrpx.h, lrpx_vgg16_channel_scales)
+            zs[l].copy_(to_nhwc(z * vgg.channel_scales(l).cpu().view(1, -1, 1, 1)))
     vgg.derive()      # the fused conv->conv multiplicand x / safe(Z+) follows the injected activations
 
 
@@ -971,9 +972,16 @@ def test_chain_hostile_weights_all_modes(ops, gridtd_case, family, sigma, dead_f
     n_img, n_maps = 2, 40
     img_cpu = torch.from_numpy(weights.make_images(43, n_img))
     feats = vgg.forward(img_cpu.cuda())
+    feats_gpu = from_nhwc(feats.cpu(), 512, 14, 14)
+    rs = [vgg.channel_scales(l).cpu() for l in range(17) if vgg.IS_CONV[l]]
+    assert all(((r >= 1) & (torch.frexp(r).mantissa == 0.5)).all() for r in rs), "channel-balance factors are powers of two >= 1"
+    print(f"[{family}] channel-balance factors: largest per layer " + " ".join(f"2^{int(torch.log2(r.max()))}" for r in rs))
     _inject_oracle_trace(vgg, sd, img_cpu)
     sdt = O.state_to_torch(sd)
     f_cpu, _, saved = O.vgg_forward(sdt, img_cpu)
+    fe = rel_err(feats_gpu, f_cpu)
+    print(f"[{family}] GPU forward features vs the oracle's oneDNN forward: {fe:.2e} of the maximum")
+    assert fe < TOL
     if dead_frac > 0:          # the dead channels really are dead: exact zero planes in the trace the kernels read
         frac0 = [float((x == 0).all(dim=(0, 2, 3)).float().mean()) for x in saved[2:] + [f_cpu]]
         print(f"[{family}] fraction of all-zero channel planes per layer input: " + " ".join(f"{v:.2f}" for v in frac0))
