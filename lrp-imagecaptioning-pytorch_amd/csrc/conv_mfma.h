@@ -43,7 +43,7 @@ enum Epilogue : int {
                         // following division folded into the multiplicand: X = x for R, X = x / safe(Z_below) for S_next
 };
 
-enum Stab : int { STAB_NONE = 0, STAB_SAFE = 1, STAB_EPS = 2 };
+enum Stab : int { STAB_NONE = 0, STAB_SAFE = 1, STAB_EPS = 2, STAB_SAFE0 = 3 /* internal: r / z, 0 where z == 0 (lrpx_core.hip, div_safe0) */ };
 
 struct ConvArgs {
     const float* in;        // [n_maps*P][cin]  A operand (already S = R/Z for relevance passes)

@@ -522,6 +522,13 @@ __global__ void blocked_convert_kernel(const float* __restrict__ src, float* __r
     else *reinterpret_cast<f32x4*>(dst + nh) = *reinterpret_cast<const f32x4*>(src + bl);
 }
 
+// r / z of the split-product chains, with 0 where z == 0.  The reference divides by z + 1e-7 [z == 0] (LRPtools/utils.py:16-18), which
+// makes S = R / 1e-7 at such a pixel - and multiplies it with zeros only: Z+_c(p) = sum_{i,taps} x_i W+[c,i] = 0 with every term >= 0 means
+// every product that S_c(p) meets in R_in = x * convT(S, W+) is zero (the first layer's x+ W+ + x- W- likewise).  The VALUE there never
+// reaches a result, but in the fp16 split-product kernels it would set the map's operand scale 1e7 above everything that matters
+// (relevance on a dead feature channel: tests/test_gpu_vgg.py::test_chain_hostile_weights_all_modes).  So those kernels' S is 0 there.
+__device__ __forceinline__ float div_safe0(float r, float z) { return z == 0.f ? 0.f : r / z; }
+
 // winners of a 2x2 max-pool + the fused multiplicand max / safe(Z+ at the winner); one thread = one pooled pixel x 4 ch
 __global__ void pool_winner_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ xzw,
                                    unsigned char* __restrict__ am, int ho, int wo, int c4, long total, float* __restrict__ xzw_blk,
@@ -551,7 +558,7 @@ __global__ void pool_winner_kernel(const float* __restrict__ x, const float* __r
         if (w4[1][e] > m) { m = w4[1][e]; zz = z4[1][e]; a_ = 1; }
         if (w4[2][e] > m) { m = w4[2][e]; zz = z4[2][e]; a_ = 2; }
         if (w4[3][e] > m) { m = w4[3][e]; zz = z4[3][e]; a_ = 3; }
-        o[e] = m / stab_safe(zz);
+        o[e] = div_safe0(m, zz);
         pk |= a_ << (8 * e);
     }
     reinterpret_cast<f32x4*>(xzw)[idx] = o;
@@ -648,7 +655,7 @@ __global__ void divide_stab_kernel(const float* __restrict__ r, const float* __r
         for (int e = 0; e < 4; ++e) {
             float zz = zv[e];
             zz = stab == STAB_SAFE ? stab_safe(zz) : (stab == STAB_EPS ? stab_eps(zz) : zz);
-            o[e] = rv[e] / zz;
+            o[e] = stab == STAB_SAFE0 ? div_safe0(rv[e], zv[e]) : rv[e] / zz;
         }
         reinterpret_cast<f32x4*>(s)[idx] = o;
         mabs = fmaxf(mabs, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
@@ -685,7 +692,7 @@ __global__ void divide_stab_blocked_kernel(const float* __restrict__ r, const fl
         const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (img * P + p) * C + c);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rv[e] / stab_safe(zv[e]);
+        for (int e = 0; e < 4; ++e) o[e] = div_safe0(rv[e], zv[e]);
         *reinterpret_cast<f32x4*>(s + (long)(2 * cp + (q >> 2)) * cs + blk_pix_off(pix) + (q & 3) * 128) = o;
         const float m = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
         if (n == n_w0) m_lo = fmaxf(m_lo, m); else m_hi = fmaxf(m_hi, m);
@@ -711,7 +718,7 @@ __global__ void divide_safe_blk_kernel(const float* __restrict__ r, const float*
     const f32x4 rv = reinterpret_cast<const f32x4*>(r)[idx], zv = reinterpret_cast<const f32x4*>(z)[idx];
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = rv[e] / stab_safe(zv[e]);
+    for (int e = 0; e < 4; ++e) o[e] = div_safe0(rv[e], zv[e]);
     reinterpret_cast<f32x4*>(s)[idx] = o;
     const long cs = blk_chunk_stride(P);
     *reinterpret_cast<f32x4*>(s_blk + n * (long)(c4 >> 2) * cs + blk_off(pix, 4 * cq, cs)) = o;
@@ -1132,6 +1139,7 @@ int lrpx_pack_weights_f16x2(const float* w, int cout, int cin, int taps, int mod
 
 int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c,
                      int stab, void* stream) {
+    LRPX_REQUIRE(stab >= LRPX_STAB_NONE && stab <= LRPX_STAB_EPS, "divide_stab: unknown stabiliser %d", stab);
     return divide_stab_amax(r, z, map2img, s, n_maps, pix_c, stab, nullptr, (hipStream_t)stream);
 }
 

@@ -577,7 +577,7 @@ static int trace_derive_impl(void* trace, int n_img, void* stream, bool pools_do
             if (l >= 3)
                 LRPX_TRY(divide_safe_blk(tr + t.act[l], tr + t.zpos[l - 1], tr + t.xz[l], tr + t.xzp[l], n_img, pix, kVgg[l].cin, (hipStream_t)stream));
             else
-                LRPX_TRY(lrpx_divide_stab(tr + t.act[l], tr + t.zpos[l - 1], nullptr, tr + t.xz[l], n_img, (long)pix * kVgg[l].cin, STAB_SAFE, stream));
+                LRPX_TRY(divide_stab_amax(tr + t.act[l], tr + t.zpos[l - 1], nullptr, tr + t.xz[l], n_img, (long)pix * kVgg[l].cin, STAB_SAFE0, nullptr, (hipStream_t)stream));
         } else {
             // a pool lies below: max / safe(Z+_{l-2} at the winner) + the winner positions (lrp_modules.py:182-195)
             LRPX_TRY(pool_winner_blk(tr + t.act[l - 1], tr + t.zpos[l - 2], tr + t.xz[l], (uint8_t*)(tr + t.am[l - 1]), tr + t.xzp[l],
@@ -779,7 +779,7 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
         LRPX_TRY(divide_stab_blocked(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, 196, 512, amax + (size_t)16 * n_maps,
                                      (hipStream_t)stream));
     else
-        LRPX_TRY(divide_stab_amax(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, STAB_SAFE,
+        LRPX_TRY(divide_stab_amax(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, h3 ? STAB_SAFE0 : STAB_SAFE,
                                   h3 ? amax + (size_t)16 * n_maps : nullptr, (hipStream_t)stream));
     const bool timing = cx.layer_ms != nullptr;
     if (timing) LRPX_TRY(timer.begin());
