@@ -220,10 +220,16 @@ def test_pooled_input_conv_rule(ops, hw, cpool, cin, n_img, n_maps, f8):
     ho = hw // 2
     xin = torch.relu(torch.randn(n_img, cin, hw, hw, generator=g))                  # input of the conv under the pool
     w = torch.randn(cpool, cin, 3, 3, generator=g) * 0.05
-    y = torch.relu(F.conv2d(xin, w, padding=1))                                      # pool input
+    # exact zeros of Z+ (the safe_divide guard, LRPtools/utils.py:16-18) the way they occur: channels without a positive weight
+    # that a positive bias keeps alive - activations > 0, Z+ == 0.  The reference forms S = R / 1e-7 there and multiplies it with
+    # W+ = 0; the split-product kernels' multiplicand is 0 there (csrc/lrpx_core.hip, div_safe0): the same R_in.
+    bias = torch.zeros(cpool)
+    w[1], w[5] = -w[1].abs(), -w[5].abs()
+    bias[1], bias[5] = 40.0, 25.0
+    y = torch.relu(F.conv2d(xin, w, bias, padding=1))                                # pool input
     y[:, :, ::4, ::4] = y[:, :, ::4, 1::4]                                           # exact ties inside windows
     z = F.conv2d(xin, w.clamp(min=0), padding=1)                                     # Z+ of the conv under the pool
-    z[:, :, 1::6, ::5] = 0.0                                                         # exact zeros (safe_divide guard)
+    assert (z[:, 1] == 0).all() and (y[:, 1] > 0).any()
     m2i = [i % n_img for i in range(n_maps)]
     r_pool_out = torch.randn(n_maps, cpool, ho, ho, generator=g)                     # relevance at the pool output
     # oracle: pool rule, then S = R / safe(Z), then the conv rule's transposed conv and input multiplication
