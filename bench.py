@@ -208,6 +208,7 @@ def parse(argv=None):
     ap.add_argument("--lens", default=None, choices=[None, "uniform"],
                     help="config 2: captions of unequal length, words per image ~U[8, --words] (seeded); the step is "
                          "explain_batch(lens=...) and maps/s counts the VALID (image, word) maps only")
+    ap.add_argument("--only-dropin", action="store_true", help="print only the configs.dropin_b1 block (the drop-in's one-image calling pattern)")
     ap.add_argument("--allow-experiment", action="store_true",
                     help="print a line even when liblrpx.so is a timing-experiment / profiling build (lrpx_build_flags() non-empty); "
                          "the line is marked value_valid=false")
@@ -267,6 +268,9 @@ def main():
         dist = None
         torch.cuda.set_device(0)
 
+    if a.only_dropin:
+        print(json.dumps({"dropin_b1": dropin_b1(a.conv_mode)}), flush=True)
+        return
     out = run_config(a, dist, rank, world)
     if rank == 0:
         if world == 1 and a.config == 2 and a.explainer == "lrp" and not a.no_configs and not a.graph and a.batch == 16:
@@ -284,7 +288,7 @@ def other_configs(a):
     res = {}
     todo = [("3", ["--config", "3"], 6), ("3_all_heads", ["--config", "3", "--all-heads"], 2),
             ("4", ["--config", "4"], 6), ("5", ["--config", "5"], 80), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 6),
-            ("varlen", ["--config", "2", "--lens", "uniform"], 12)]
+            ("varlen", ["--config", "2", "--lens", "uniform", "--batch", "23"], 12)]
     # the same lines with three fp16 products per fp32 product (conv mode 2, <= 1e-6 of max|R|): for a reader who rejects the fp6 cross terms
     grade = [("3", ["--config", "3"], 4), ("4", ["--config", "4"], 4), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 4)]
     todo += [(k + "#fp32_grade", argv, n) for k, argv, n in grade] if a.conv_mode == 3 else []
@@ -315,6 +319,63 @@ def other_configs(a):
             res[key] = line
     gc.collect()
     torch.cuda.empty_cache()
+    res["dropin_b1"] = dropin_b1(a.conv_mode)
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def dropin_b1(conv_mode):
+    """The drop-in's OWN calling pattern: one image per `explain_caption` call, as evaluation.py:806-838 and
+    models/gridTDmodel.py:1141-1156 run it - a 20-word caption handed over (`caption_encode=`) and the explainer's own beam search
+    (beam 2, up to 50 words, :935); the explainer constructed once, and constructed anew for every image as the reference's
+    evaluation loop does (the device engine is then shared per weight set: explainers/engine_cache.py)."""
+    import types
+    import lrp_amd  # noqa: F401
+    from lrp_amd import _lib, weights
+    from lrp_amd.explainers import engine_cache
+    from lrp_amd.explainers.gridtd import ExplainGridTDAttention
+    _lib.load().lrpx_set_conv_mode(conv_mode)
+    V, T = 9586, 20
+    sd = {k: torch.from_numpy(v) for k, v in weights.make_gridtd_state(seed=0, vocab_size=V).items()}
+    wm = weights.make_word_map(V)
+    args = types.SimpleNamespace(embed_dim=512, hidden_dim=512, encoder="vgg16", weight="", save_path="/tmp", dataset="synthetic",
+                                 height=224, width=224)
+    img = torch.from_numpy(weights.make_images(100, 1)).cuda()
+    cap = [int(c) for c in weights.make_captions(200, 1, T, V)[0]]
+
+    def timed(fn, n):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+    engine_cache.clear()
+    t_cold = timed(lambda: ExplainGridTDAttention(args, wm, model=sd), 1)          # weight upload + every weight pack
+    ex = ExplainGridTDAttention(args, wm, model=sd)
+    for _ in range(3):
+        ex.explain_caption(img, caption_encode=cap)
+    ms_warm = timed(lambda: ex.explain_caption(img, caption_encode=cap), 10)
+    ms_new = timed(lambda: ExplainGridTDAttention(args, wm, model=sd).explain_caption(img, caption_encode=cap), 5)
+    ex.explain_caption(img)
+    n_beam = ex.caption_length
+    ms_beam = timed(lambda: ex.explain_caption(img), 5)
+    res = {"workload": "ExplainGridTDAttention.explain_caption on ONE resident 224x224 image (B = 1), V=9586, conv mode %d" % conv_mode,
+           "given_caption": {"words": T, "ms_per_call": round(ms_warm, 3), "maps_per_s": round(T / ms_warm * 1e3, 1),
+                             "note": "explainer constructed once; median of 10 calls, each synchronised (the caller reads the maps)"},
+           "new_explainer_per_image": {"words": T, "ms_per_call": round(ms_new, 3), "maps_per_s": round(T / ms_new * 1e3, 1),
+                                       "note": "ExplainGridTDAttention(args, word_map, model) + explain_caption per image (evaluation.py:811-838); "
+                                               "the device engine of the weight set is reused (explainers/engine_cache.py)"},
+           "first_construction_ms": round(t_cold, 1),
+           "beam_search_caption": {"words": n_beam, "ms_per_call": round(ms_beam, 3), "maps_per_s": round(n_beam / ms_beam * 1e3, 1) if n_beam else 0.0,
+                                   "note": "the explainer captions the image itself: beam 2, up to 50 steps (models/gridTDmodel.py:935), host "
+                                           "bookkeeping with one small device->host read per step as the reference's"}}
+    log(f"configs[dropin_b1]: {ms_warm:.2f} ms per 20-word image warm, {ms_new:.2f} ms with a new explainer per image, first construction "
+        f"{t_cold:.0f} ms, beam-search caption of {n_beam} words {ms_beam:.2f} ms")
+    engine_cache.clear()
     return res
 
 

@@ -566,14 +566,20 @@ class ExplainAOAAttention(object):
         self.word_map = word_map
         self.vocab_size = len(word_map)
         self.num_head = getattr(args, "num_head", 8)
-        if model is None:
-            state = torch.load(args.weight, map_location="cpu")['state_dict']
-        elif hasattr(model, "state_dict"):
-            state = model.state_dict()
-        else:
-            state = model
+        from . import engine_cache
+        key = engine_cache.fingerprint("aoa", args.weight if model is None else model, (self.num_head,))
+
+        def build():
+            if model is None:
+                state = torch.load(args.weight, map_location="cpu")['state_dict']
+            elif hasattr(model, "state_dict"):
+                state = model.state_dict()
+            else:
+                state = model
+            return AOAEngine(state, self.num_head)
         self.model = model
-        self.engine = AOAEngine(state, self.num_head)
+        # one device engine per weight set (explainers/engine_cache.py); weights shared, trace / workspace buffers this explainer's own
+        self.engine = engine_cache.get(key, build).replica()
         self.rev_word_map = {v: k for k, v in word_map.items()}
         self.mean = list(IMAGENET_MEAN)
         self.std = list(IMAGENET_STD)

@@ -651,14 +651,21 @@ class ExplainGridTDAttention(object):
         self.args = args
         self.word_map = word_map
         self.vocab_size = len(word_map)
-        if model is None:
-            state = torch.load(args.weight, map_location="cpu")['state_dict']
-        elif hasattr(model, "state_dict"):
-            state = model.state_dict()
-        else:
-            state = model
+        # one device engine per weight set (explainers/engine_cache.py): evaluation.py:806-838 builds an explainer per image
+        from . import engine_cache
+        key = engine_cache.fingerprint("gridtd", args.weight if model is None else model)
+
+        def build():
+            if model is None:
+                state = torch.load(args.weight, map_location="cpu")['state_dict']
+            elif hasattr(model, "state_dict"):
+                state = model.state_dict()
+            else:
+                state = model
+            return GridTDEngine(state)
         self.model = model
-        self.engine = GridTDEngine(state)
+        # the weights are shared, the trace / workspace buffers are this explainer's own: two live explainers never see each other's image
+        self.engine = engine_cache.get(key, build).replica()
         self.mean = list(IMAGENET_MEAN)
         self.std = list(IMAGENET_STD)
         self.rev_word_map = {v: k for k, v in word_map.items()}

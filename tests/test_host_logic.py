@@ -160,3 +160,32 @@ def test_ragged_rows_of_unequal_caption_lengths():
         RaggedRows([1, 5], 2, 4, "cpu")
     with pytest.raises(ValueError):
         RaggedRows([-1, 2], 2, 4, "cpu")
+
+
+def test_engine_cache_keys(tmp_path):
+    """explainers/engine_cache.py: one engine per weight set - a checkpoint path keys by file identity, torch tensors by (pointer,
+    version): an in-place update or a rewritten file gives a new key; numpy arrays are never cached"""
+    from lrp_amd.explainers import engine_cache as ec
+    ec.clear()
+    sd = {"a": torch.zeros(3), "b": torch.ones(2, 2)}
+    k1 = ec.fingerprint("gridtd", sd)
+    assert k1 is not None and k1 == ec.fingerprint("gridtd", sd) and k1 != ec.fingerprint("aoa", sd, (8,))
+    sd["a"].add_(1.0)
+    assert ec.fingerprint("gridtd", sd) != k1
+    lin = torch.nn.Linear(2, 2)
+    assert ec.fingerprint("gridtd", lin) == ec.fingerprint("gridtd", lin)
+    assert ec.fingerprint("gridtd", {"a": np.zeros(3)}) is None and ec.fingerprint("gridtd", {}) is None
+    f = tmp_path / "ckpt.pth"
+    f.write_bytes(b"x" * 10)
+    kp = ec.fingerprint("gridtd", str(f))
+    assert kp is not None and ec.fingerprint("gridtd", str(f)) == kp
+    f.write_bytes(b"y" * 11)
+    assert ec.fingerprint("gridtd", str(f)) != kp and ec.fingerprint("gridtd", str(tmp_path / "missing.pth")) is None
+    built = []
+    mk = lambda: built.append(1) or object()
+    a = ec.get(k1, mk)
+    assert ec.get(k1, mk) is a and len(built) == 1 and ec.get(None, mk) is not a and len(built) == 2
+    for i in range(ec.MAX_ENGINES + 1):
+        ec.get(("k", i), mk)
+    assert ec.get(k1, mk) is not a          # evicted: the cache holds MAX_ENGINES engines
+    ec.clear()
