@@ -204,7 +204,11 @@ def parse(argv=None):
     ap.add_argument("--words", type=int, default=20)
     ap.add_argument("--vocab", type=int, default=None)
     ap.add_argument("--head", type=int, default=0, help="AoA head explained (configs 3 / 5)")
-    ap.add_argument("--gather", action="store_true", help="gather the maps to rank 0 over RCCL inside the step")
+    ap.add_argument("--gather", nargs="?", const="maps", default=None, choices=["maps", "heatmap", "stats", "none"],
+                    help="terminal collective of a step (north_star's 'trivial gather', RCCL over xGMI): maps = the fp32 maps to rank 0 from a "
+                         "double-buffered copy on a side stream (overlaps the next step); heatmap = the channel mean, reduced on the device "
+                         "first (a third of the bytes), all_gather_into_tensor on preallocated buffers; stats = the tpfp statistics of that "
+                         "heat map (4 floats per map); none / absent = no collective")
     ap.add_argument("--lens", default=None, choices=[None, "uniform"],
                     help="config 2: captions of unequal length, words per image ~U[8, --words] (seeded); the step is "
                          "explain_batch(lens=...) and maps/s counts the VALID (image, word) maps only")
@@ -229,6 +233,8 @@ def parse(argv=None):
     ap.add_argument("--conv-mode", type=int, default=3, choices=[0, 1, 2, 3],
                     help="matrix-core mode of the VGG16 chains: 0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 fp16 + fp6 cross products (default)")
     a = ap.parse_args(argv)
+    if a.gather == "none":
+        a.gather = None
     if a.explainer is None:
         a.explainer = "lrp+guided" if a.config == 4 else "lrp"
     if a.batch is None:
@@ -478,24 +484,26 @@ def run_config(a, dist, rank, world):
         workload = (f"BASELINE configs[4]: batch-{B} x 36x2048 bottom-up region features x {T}-word captions per GPU, AoA-BU "
                     f"decoder, LRP relevance back to the region features (head {a.head}), V={V}, random-init")
     engines = [eng] + [eng.replica() for _ in range(n_pipe - 1)]     # shared weights, own trace / workspace buffers
-    gathered = None
-    if a.gather and world > 1 and rank == 0:
-        gathered = [torch.empty(B * T, 3, 224, 224, device="cuda") for _ in range(world)]
-
     gloo = dist is not None and dist.get_backend() == "gloo"
-    if a.gather and gloo:          # rehearsal backend: gloo gathers host tensors only, so the maps are staged through pinned memory
-        state["host_maps"] = torch.empty(B * T, 3, 224, 224).pin_memory()
-        if rank == 0:
-            gathered = [torch.empty(B * T, 3, 224, 224) for _ in range(world)]
+    og = None
+    if a.gather and world > 1 and has_vgg:
+        # lrp_amd.shard.OverlappedGather: copy + collective on a side stream, one slot more than batches in flight.  The rehearsal
+        # backend (gloo) moves host tensors only: its slots are pinned host memory and the copy is waited for before the collective.
+        from lrp_amd import shard
+        shape = {"maps": (B * T, 3, 224, 224), "heatmap": (B * T, 224, 224), "stats": (B * T, 4)}[a.gather]
+        og = shard.OverlappedGather(shape, device="cpu" if gloo else "cuda", depth=n_pipe + 1,
+                                    mode="gather" if a.gather == "maps" else "all_gather")
+        if gloo:
+            og.stage = [t_.pin_memory() for t_ in og.stage]
 
     def gather_maps(m):
-        """the terminal collective of north_star: every rank's maps to rank 0 (RCCL over xGMI; device tensors end to end)"""
+        """the terminal collective of north_star: every rank's (reduced) maps travel from a side stream (RCCL over xGMI; device tensors
+        end to end) while the next step computes"""
+        from lrp_amd import shard
+        red = shard.reduce_for_gather(m.view(B * T, 3, 224, 224), a.gather)
         if gloo:
-            state["host_maps"].copy_(m.view(B * T, 3, 224, 224), non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            dist.gather(state["host_maps"], gathered, dst=0)
-        else:
-            dist.gather(m.view(B * T, 3, 224, 224), gathered, dst=0)
+        og.submit(red)
 
     step_no = [0]
 
@@ -508,7 +516,7 @@ def run_config(a, dist, rank, world):
                 # --graph: the step replayed from a HIP graph captured per replica (same kernels, same buffers every step)
                 out = engines[k].explain_batch_graph(images, caps, accumulate=True, predictions=True) if use_graph \
                     else one_step(engines[k], k)
-                if a.gather and world > 1 and has_vgg:
+                if og is not None:
                     gather_maps(out[0])
                 if end_events is not None:
                     ev = torch.cuda.Event(enable_timing=True)
@@ -519,8 +527,8 @@ def run_config(a, dist, rank, world):
             out = eng.explain_batch_graph(images, caps, accumulate=True, predictions=True)
         else:
             out = one_step(eng, 0)
-        if a.gather and world > 1 and has_vgg:
-            gather_maps(out[0].view(B * T, 3, 224, 224))
+        if og is not None:
+            gather_maps(out[0])
         if end_events is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -528,6 +536,8 @@ def run_config(a, dist, rank, world):
         return out
 
     def barrier():
+        if og is not None:
+            og.finish()                 # every collective of the region has delivered before the clock stops
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -633,7 +643,7 @@ def run_config(a, dist, rank, world):
                           "maps_per_step": world * maps_per_gpu,
                           "unit_of_work": "trace (VGG16 forward + decoder, predictions kept) + decoder relevance + CNN relevance + "
                                           "running sums of the maps" if has_vgg else "decoder trace (predictions kept) + decoder relevance",
-                          "sharding": f"images x{world}, no data-path collective" + (" + gather" if a.gather else ""),
+                          "sharding": f"images x{world}, no data-path collective" + (f" + terminal gather of the {a.gather} (side stream, double-buffered)" if a.gather else ""),
                           "batches_in_flight": n_pipe, "launch": ("HIP graph replay per batch in flight" if a.graph else "eager") + (", one host thread per batch in flight" if host_threads else "")},
                "median_ms": round(median_ms, 3), "hip_event_ms_per_step": round(ends[-1] / a.steps, 3), "sustained": sustained,
                "build_flags": build_flags, "value_valid": not build_flags}

@@ -140,3 +140,77 @@ def test_two_ranks_gloo_per_rank_loader(lens):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok_m and ok_w and shape[0] == n_img
+
+
+def _gather_worker(rank, world, port, out):
+    """gather_to_rank0 with known / unknown sizes, equal / unequal shards, a preallocated result; the reduced gather of
+    explain_sharded; OverlappedGather in both modes (depth 2, five steps: every slot reused)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    # equal shards, sizes known: the result tensor is written in place (no padding, no concatenation)
+    local = torch.arange(3 * 4, dtype=torch.float32).view(3, 4) + 100 * rank
+    pre = torch.full((world * 3, 4), -1.0) if rank == 0 else None
+    got = shard.gather_to_rank0(local, sizes=[3] * world, out=pre)
+    want = torch.cat([torch.arange(12, dtype=torch.float32).view(3, 4) + 100 * r for r in range(world)])
+    if rank == 0:
+        ok &= got is pre and torch.equal(got, want)
+    else:
+        ok &= got is None
+    # sizes unknown: one exchange; unequal shards keep the rank order
+    loc2 = torch.full((2 + rank, 5), float(rank))
+    got2 = shard.gather_to_rank0(loc2)
+    if rank == 0:
+        ok &= tuple(got2.shape) == (sum(2 + r for r in range(world)), 5)
+        ok &= torch.equal(got2, torch.cat([torch.full((2 + r, 5), float(r)) for r in range(world)]))
+    got3 = shard.gather_to_rank0(loc2, sizes=[2 + r for r in range(world)])
+    if rank == 0:
+        ok &= torch.equal(got3, got2)
+    # explain_sharded with a reducer: the channel mean is what travels (a third of the bytes), in input order
+    g = torch.Generator().manual_seed(0)
+    images = torch.randn(5, 3, 8, 8, generator=g)
+    caps = torch.randint(1, 50, (5, 5), generator=g)
+    heat = lambda m: m.mean(dim=1)
+    hm, rw = shard.explain_sharded(_fake_explain, images, caps, gather=True, reduce=heat)
+    if rank == 0:
+        ok &= torch.equal(hm, heat(_fake_explain(images, caps)[0])) and tuple(hm.shape) == (5, 4, 4)
+    try:
+        shard.reduce_for_gather(images, "nonsense")
+        ok = False
+    except ValueError:
+        pass
+    # the overlapped gather: results of step i are complete when asked for, slots are reused safely
+    for mode in ("gather", "all_gather"):
+        og = shard.OverlappedGather((2, 3), device="cpu", depth=2, mode=mode)
+        slots = []
+        for step in range(5):
+            k = og.submit(torch.full((2, 3), float(10 * step + rank)))
+            slots.append(k)
+            res = og.result(k)
+            if mode == "all_gather" or rank == 0:
+                ok &= torch.equal(res, torch.stack([torch.full((2, 3), float(10 * step + r)) for r in range(world)]))
+            else:
+                ok &= res is None
+        og.finish()
+        ok &= slots == [0, 1, 0, 1, 0]
+    out.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_gather_paths():
+    """the terminal gather without size exchange / padding / concatenation when the blocks are known, the
+    reduced gather (channel mean) of `explain_sharded`, and `OverlappedGather` (double-buffered, gather and all_gather_into_tensor)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
