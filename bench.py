@@ -501,8 +501,6 @@ def run_config(a, dist, rank, world):
         end to end) while the next step computes"""
         from lrp_amd import shard
         red = shard.reduce_for_gather(m.view(B * T, 3, 224, 224), a.gather)
-        if gloo:
-            torch.cuda.current_stream().synchronize()
         og.submit(red)
 
     step_no = [0]

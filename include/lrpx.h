@@ -403,6 +403,22 @@ typedef struct lrpx_aoa_step_args {
     float *zz, *qg, *lin;               /* scratch [B][4H], [B][2H], [B][H] */
 } lrpx_aoa_step_args;
 int lrpx_aoa_fwd_steps(const lrpx_aoa_trace* tr, int t0, int t1, const lrpx_aoa_step_args* a, void* stream);
+/* The teacher-forced trace with the recurrence decoupled from what hangs off it: in this model the LSTM reads x_t = [emb(word_t) |
+ * global feature] and its own h_{t-1} only (models/aoamodel.py:1030-1033); attention, AoA gate and scores read h_t and feed nothing
+ * back.  So: (1) lrpx_aoa_fwd_inputs gathers x_t of every (image, word) row (into xh and, contiguous, into xin [B*T][E+H]); the caller
+ * forms zin = xin W_ih^T + b for all rows in one GEMM (columns in the interleaved gate order of w_cat_il above); (2)
+ * lrpx_aoa_fwd_recurrence runs the T dependent steps  z = zin[t] + W_hh h_{t-1} -> LSTM cell, ONE launch of K = H each (w_hh_il:
+ * (4H, H), rows interleaved); (3) lrpx_aoa_fwd_gather_h writes hn [B*T][H] = h_t rows and the h part of xh; the q / gate linear,
+ * lrpx_aoa_fwd_attention_all, decoder_aoa_linear and lrpx_aoa_fwd_post_all then run ONCE over all B*T rows (qg [B*T][ldq] =
+ * [q_proj(h_t) | aoa_linear_gate(h_t)], lin [B*T][H]).  Same trace tensors as the stepwise entry points (values equal to rounding:
+ * z is (x W_ih^T + b) + W_hh h instead of one dot product over [x | h]). */
+int lrpx_aoa_fwd_inputs(const lrpx_aoa_trace* tr, const float* glob, const float* emb, const long long* tok, int tok_ld,
+                        float* xin, void* stream);
+int lrpx_aoa_fwd_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* zin, void* stream);
+int lrpx_aoa_fwd_gather_h(const lrpx_aoa_trace* tr, float* hn, void* stream);
+int lrpx_aoa_fwd_attention_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* key, const float* value,
+                               void* stream);
+int lrpx_aoa_fwd_post_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* lin, void* stream);
 
 /* ---- AoA decoder: gradient explainers (ExplainAOAGradient.explain_caption_wordt, models/aoamodel.py:1435-1499;
  *      inherited unchanged by the guided / Grad-CAM variants) --------------------------------------------------- */

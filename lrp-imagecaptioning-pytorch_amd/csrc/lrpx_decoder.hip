@@ -1046,6 +1046,108 @@ __global__ __launch_bounds__(256) void aoa_linear_post_kernel(AoaFwd g, int t, c
     }
 }
 
+// ---- the teacher-forced trace with the recurrence DECOUPLED from what hangs off it (round 5) ------------------------------------
+// In this model the LSTM input is x_t = [emb(word_t) | global feature] and its own h_{t-1} (models/aoamodel.py:1030-1033): the
+// attention, the AoA gate and the scores READ h_t but never feed the recurrence.  Under teacher forcing every x_t is known up front,
+// so the only sequential work is  z_t = Zin[t] + W_hh h_{t-1}  with  Zin = [emb | glob] W_ih^T + b  computed for all (image, word)
+// rows in ONE GEMM, and q / gate linear, attention, decoder_aoa_linear, gated sum run once over all B*T rows afterwards: a step of
+// the reference's loop (:1019-1052) costs one launch of K = 512 instead of four launches with K = 1536 in the first.
+__global__ void aoa_fwd_inputs_kernel(AoaFwd g, const float* __restrict__ glob, const float* __restrict__ emb,
+                                      const long long* __restrict__ tok, int tok_ld, float* __restrict__ xin) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, W = g.E + 2 * g.H, EH = g.E + g.H;
+    float* dst = g.xh + (long)row * W;
+    const long long k = tok[(long)b * tok_ld + t];
+    for (int c = threadIdx.x; c < EH; c += blockDim.x) {
+        const float v = c < g.E ? emb[k * g.E + c] : glob[(long)b * g.H + (c - g.E)];
+        dst[c] = v;
+        xin[(long)row * EH + c] = v;
+    }
+}
+
+// z = zin[b, t] + W_hh h[b, t]  ->  LSTM cell (the point-wise code of aoa_fwd_lstm_kernel).  w: (4H, H), rows interleaved as in
+// aoa_linear_lstm_kernel; zin: [B*T][4H] in the same interleaved column order (bias included)
+template <int RT>
+__global__ __launch_bounds__(256) void aoa_rec_lstm_kernel(AoaFwd g, int t, const float* __restrict__ w,
+                                                           const float* __restrict__ zin) {
+    __shared__ float red[4][RT][16][17];
+    const int H = g.H;
+    linear_mfma_core<RT>(g.h + (long)t * H, (long)(g.T + 1) * H, w, g.B, H, 4 * H, red);
+    for (int e = threadIdx.x; e < RT * 64; e += 256) {
+        const int r = e >> 6, row = (e >> 2) & 15, u = e & 3;
+        const int b = r * 16 + row, c = blockIdx.x * 4 + u;
+        if (b >= g.B || c >= H) continue;
+        const float* zi = zin + ((long)b * g.T + t) * 4 * H + blockIdx.x * 16;
+        float z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 4 * q + u;
+            z[q] = ((red[0][r][row][col] + red[1][r][row][col]) + (red[2][r][row][col] + red[3][r][row][col])) + zi[col];
+        }
+        const long st0 = ((long)b * (g.T + 1) + t) * H, st1 = st0 + H, tr = ((long)b * g.T + t) * H;
+        const float i = sigmoidf_(z[0]), f = sigmoidf_(z[1]), zg = z[2], o = sigmoidf_(z[3]);
+        const float cn = f * g.c[st0 + c] + i * tanhf(zg);
+        g.c[st1 + c] = cn; g.h[st1 + c] = o * tanhf(cn);
+        g.g[tr + c] = zg; g.i[tr + c] = i; g.f[tr + c] = f;
+        if (g.o) g.o[tr + c] = o;
+    }
+}
+
+// after the recurrence: hn[b, t] = h[b, t + 1] (contiguous rows for the q / gate GEMM), xh[b, t][E + H :] = h[b, t] (:1075)
+__global__ void aoa_fwd_gather_h_kernel(AoaFwd g, float* __restrict__ hn) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, W = g.E + 2 * H;
+    const long st0 = ((long)b * (g.T + 1) + t) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        g.xh[(long)row * W + g.E + H + c] = g.h[st0 + c];
+        hn[(long)row * H + c] = g.h[st0 + H + c];
+    }
+}
+
+// aoa_fwd_attention_kernel for every (image, word) row at once: block (row, head); qg: [B*T][ldq]
+__global__ __launch_bounds__(64) void aoa_fwd_attention_all_kernel(AoaFwd g, const float* __restrict__ qg, int ldq,
+                                                                   const float* __restrict__ key, const float* __restrict__ value) {
+    extern __shared__ float sm[];
+    const int row = blockIdx.x, b = row / g.T, hd = blockIdx.y, H = g.H, P = g.P, dk = H / g.NH, tid = threadIdx.x;
+    float* q = sm;          // dk
+    float* sc = q + dk;     // P
+    for (int c = tid; c < dk; c += 64) q[c] = qg[(long)row * ldq + hd * dk + c];
+    __syncthreads();
+    const float inv = 1.f / sqrtf((float)dk);
+    for (int k = tid; k < P; k += 64) {
+        const float* kp = key + ((long)b * P + k) * H + hd * dk;
+        float a = 0.f;
+        for (int c = 0; c < dk; ++c) a += q[c] * kp[c];
+        sc[k] = a * inv;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int k = tid; k < P; k += 64) m = fmaxf(m, sc[k]);
+    m = wave_max(m);
+    float e = 0.f;
+    for (int k = tid; k < P; k += 64) e += expf(sc[k] - m);
+    const float denom = wave_sum(e);
+    float* al = g.alpha + ((long)row * g.NH + hd) * P;
+    for (int k = tid; k < P; k += 64) { const float a = expf(sc[k] - m) / denom; sc[k] = a; al[k] = a; }
+    __syncthreads();
+    for (int c = tid; c < dk; c += 64) {
+        float a = 0.f;
+        for (int k = 0; k < P; ++k) a += sc[k] * value[((long)b * P + k) * H + hd * dk + c];
+        g.ctx[(long)row * H + hd * dk + c] = a;
+    }
+}
+
+// aoa_fwd_post_kernel for every row: lin [B*T][H] = decoder_aoa_linear(ctx), qg [B*T][ldq] (gate in the second half)
+__global__ void aoa_fwd_post_all_kernel(AoaFwd g, const float* __restrict__ qg, int ldq, const float* __restrict__ lin) {
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
+    const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = (long)row * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float l = lin[tr + c];
+        const float sgv = sigmoidf_(qg[(long)row * ldq + H + c]);
+        const float ca = sgv * l;
+        g.lin[tr + c] = l; g.c_aoa[tr + c] = ca; g.hc[tr + c] = ca + g.h[st1 + c];
+        if (g.sg) g.sg[tr + c] = sgv;
+    }
+}
+
 // ---- AoA gradient explainers (models/aoamodel.py:1435-1499), all (image, word) rows in lock-step -------------------
 struct AoaGrad {
     int B, T, H, E, P, NH;
@@ -1755,6 +1857,55 @@ int lrpx_aoa_fwd_steps(const lrpx_aoa_trace* tr, int t0, int t1, const lrpx_aoa_
         LRPX_TRY(lrpx_aoa_fwd_post(tr, t, a->qg, 2 * H, a->lin, stream));
     }
     return LRPX_OK;
+}
+
+int lrpx_aoa_fwd_inputs(const lrpx_aoa_trace* tr, const float* glob, const float* emb, const long long* tok, int tok_ld,
+                        float* xin, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(glob && emb && tok && xin, "aoa_fwd_inputs: null pointer");
+    hipLaunchKernelGGL(aoa_fwd_inputs_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), glob, emb, tok,
+                       tok_ld, xin);
+    return check_launch("aoa_fwd_inputs");
+}
+
+int lrpx_aoa_fwd_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* zin, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(w_hh_il && zin && tr->B <= 64 && tr->H % 16 == 0, "aoa_fwd_recurrence: bad arguments (<= 64 images, H %% 16)");
+    const AoaFwd g = to_afwd(tr);
+    const int H = tr->H, B = tr->B;
+    hipStream_t st = (hipStream_t)stream;
+    for (int t = 0; t < tr->T; ++t) {
+        if (B <= 16) hipLaunchKernelGGL((aoa_rec_lstm_kernel<1>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin);
+        else if (B <= 32) hipLaunchKernelGGL((aoa_rec_lstm_kernel<2>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin);
+        else if (B <= 48) hipLaunchKernelGGL((aoa_rec_lstm_kernel<3>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin);
+        else hipLaunchKernelGGL((aoa_rec_lstm_kernel<4>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin);
+        LRPX_TRY(check_launch("aoa_rec_lstm"));
+    }
+    return LRPX_OK;
+}
+
+int lrpx_aoa_fwd_gather_h(const lrpx_aoa_trace* tr, float* hn, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(hn, "aoa_fwd_gather_h: null pointer");
+    hipLaunchKernelGGL(aoa_fwd_gather_h_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), hn);
+    return check_launch("aoa_fwd_gather_h");
+}
+
+int lrpx_aoa_fwd_attention_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* key, const float* value,
+                               void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(qg && key && value && tr->H % tr->NH == 0, "aoa_fwd_attention_all: bad arguments");
+    const size_t lds = (size_t)(tr->H / tr->NH + tr->P) * sizeof(float);
+    hipLaunchKernelGGL(aoa_fwd_attention_all_kernel, dim3(tr->B * tr->T, tr->NH), dim3(64), lds, (hipStream_t)stream, to_afwd(tr), qg,
+                       ldq, key, value);
+    return check_launch("aoa_fwd_attention_all");
+}
+
+int lrpx_aoa_fwd_post_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* lin, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(qg && lin, "aoa_fwd_post_all: null pointer");
+    hipLaunchKernelGGL(aoa_fwd_post_all_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), qg, ldq, lin);
+    return check_launch("aoa_fwd_post_all");
 }
 
 int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int n_steps, const lrpx_conv_desc* dense,

@@ -48,6 +48,10 @@ class AOAEngine:
         il = (qq * H + 4 * jj + uu).reshape(-1).to(self.device)
         self.Wcat_il = self.Wcat[il].contiguous()
         self.bcat_model_il, self.bcat_explainer_il = self.bcat_model[il].contiguous(), self.bcat_explainer[il].contiguous()
+        # the decoupled teacher-forced trace (lrpx_aoa_fwd_recurrence, include/lrpx.h): input part and recurrent part of the gate rows
+        self.decoupled = H % 16 == 0 and E % 16 == 0          # False: the stepwise kernels (A/B; the decoding loops always use them)
+        self.W_ih_il = self.Wcat_il[:, :E + H].contiguous()
+        self.W_hh_il = self.Wcat_il[:, E + H:].contiguous()
         self.Wqg = torch.cat([sd["decoder_multihead_attention.q_proj.weight"], sd["decoder_aoa_linear_gate.weight"]], 0).contiguous()
         self.bqg = torch.cat([sd["decoder_multihead_attention.q_proj.bias"], sd["decoder_aoa_linear_gate.bias"]]).contiguous()
         self.w_proj2d = w_proj.reshape(H, Cc).contiguous()
@@ -57,6 +61,13 @@ class AOAEngine:
         self.p_v_fwd = ops.pack_weights(sd["decoder_v_proj.weight"], H, H, 1, PACK_DENSE, kc)
         self.p_fc_fwd = ops.pack_weights(sd["fc.weight"], self.V, H, 1, PACK_DENSE, kc)
         self.p_fc_fwd_h = ops.pack_weights_f16x2(sd["fc.weight"], self.V, H, _lib.PACK_FWD, taps=1) if H % 64 == 0 else None
+        # plain GEMMs over all (image, word) rows of the decoupled trace: (pack for the fp16 split-product kernel, fp32 pack)
+        self._plain = {}
+        if self.decoupled:
+            for name, w in (("ih", self.W_ih_il), ("qg", self.Wqg), ("lin", sd["decoder_aoa_linear.weight"])):
+                n, k = w.shape
+                self._plain[name] = (ops.pack_weights_f16x2(w, n, k, _lib.PACK_FWD, taps=1) if k % 64 == 0 else None,
+                                     ops.pack_weights(w, n, k, 1, PACK_DENSE, kc), n, k)
         wg = torch.cat([sd[l + "weight_ih"][2 * H:3 * H], sd[l + "weight_hh"][2 * H:3 * H]], 1).contiguous()
         self.p_wg = ops.pack_weights(wg, H, E + 2 * H, 1, PACK_DENSE_T, kc)
         self.p_lin_rel = ops.pack_weights(sd["decoder_aoa_linear.weight"], H, H, 1, PACK_DENSE_T, kc)
@@ -237,6 +248,40 @@ class AOAEngine:
             wpreds[:, t] = self.logits(hcw)
         return preds, wpreds, L
 
+    def _plain_rows(self, x, name, bias):
+        """x (R, K) @ W^T + bias -> (R, N) for one of the trace's plain linears over all (image, word) rows: split products on the
+        fp16 matrix cores for many rows (as `logits(fast=True)`: <= 2e-7 of a row's maximum), the fp32 MFMA kernel otherwise"""
+        p_h, p_f, n, k = self._plain[name]
+        R = x.shape[0]
+        out = torch.empty(R, n, device=self.device)
+        if R >= 128 and p_h is not None:
+            ops.conv_mfma(x, p_h, R, 0, k, -(-n // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=n, bias=bias, out0=out, f16x3=1,
+                          in_amax=ops.amax_maps(x, R))
+        else:
+            ops.conv_mfma(x, p_f, R, 0, k, -(-n // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=n, bias=bias, out0=out)
+        return out
+
+    def _trace_decoupled(self, tr, enc, captions, model_bias):
+        """get_hidden_parameters' loop (models/aoamodel.py:1019-1052) with the recurrence decoupled (include/lrpx.h,
+        lrpx_aoa_fwd_recurrence): one GEMM for the input part of all gate pre-activations, T launches of K = H for the recurrence,
+        then q / gate linear, attention, decoder_aoa_linear and the gated sum once over all B*T rows."""
+        lib = _lib.load()
+        st = stream_ptr()
+        B, T, H, E = tr["B"], tr["T"], self.H, self.E
+        R = B * T
+        c = C.byref(tr["_c"])
+        sd = self.sd
+        xin = torch.empty(R, E + H, device=self.device)
+        check(lib.lrpx_aoa_fwd_inputs(c, ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), captions.shape[1], ptr(xin), st))
+        zin = self._plain_rows(xin, "ih", self.bcat_model_il if model_bias else self.bcat_explainer_il)
+        check(lib.lrpx_aoa_fwd_recurrence(c, ptr(self.W_hh_il), ptr(zin), st))
+        hn = torch.empty(R, H, device=self.device)
+        check(lib.lrpx_aoa_fwd_gather_h(c, ptr(hn), st))
+        qg = self._plain_rows(hn, "qg", self.bqg)
+        check(lib.lrpx_aoa_fwd_attention_all(c, ptr(qg), 2 * H, ptr(enc["key"]), ptr(enc["value"]), st))
+        lin = self._plain_rows(tr["ctx"].view(R, H), "lin", sd["decoder_aoa_linear.bias"])
+        check(lib.lrpx_aoa_fwd_post_all(c, ptr(qg), 2 * H, ptr(lin), st))
+
     def trace(self, enc, captions, model_bias=False, predictions=True, grad=False):
         """grad=True: the trace of the gradient explainers (:1309-1376): correct LSTM bias, output gate and aoa gate kept."""
         model_bias = model_bias or grad
@@ -250,6 +295,15 @@ class AOAEngine:
         W = E + 2 * H
         bias = self.bcat_model if model_bias else self.bcat_explainer
         sd = self.sd
+        if self.decoupled and B <= 64 and T > 0:
+            self._trace_decoupled(tr, enc, captions, model_bias)
+            tr["captions"] = captions
+            tr["logit"] = torch.empty(B * T, device=self.device)
+            check(lib.lrpx_target_logit(ptr(tr["hc"]), ptr(sd["fc.weight"]), ptr(sd["fc.bias"]), ptr(captions), T + 1,
+                                        ptr(tr["logit"]), B, T, H, st))
+            if predictions:
+                tr["pred"] = self.logits(tr["hc"].view(B * T, H), fast=True).view(B, T, self.V)
+            return tr
         # the T decoder steps (:1019-1052) in one native call (the host loop of `_step` in C: the bottom-up path is bound by the
         # launch rate of the interpreter otherwise)
         tr["_zz"], tr["_qg"], tr["_lin"] = (torch.empty(B, n * H, device=self.device) for n in (4, 2, 1))

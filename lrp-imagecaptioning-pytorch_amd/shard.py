@@ -134,11 +134,43 @@ class OverlappedGather:
         bufs = list(self.out[k].unbind(0)) if self.rank == 0 else None
         return self.dist.gather(self.stage[k], bufs, dst=0, group=self.group, async_op=True)
 
+    class _HostStaged:
+        """handle of a collective whose device -> pinned-host copy is still in flight: a helper thread waits for the copy and
+        starts the collective (the rehearsal backend, gloo, moves host tensors only); wait() joins both"""
+
+        def __init__(self, og, k, ev):
+            import threading
+            self.work = None
+
+            def run():
+                ev.synchronize()
+                self.work = og._collective(k)
+            self.th = threading.Thread(target=run)
+            self.th.start()
+
+        def wait(self):
+            self.th.join()
+            if self.work is not None:
+                self.work.wait()
+
     def submit(self, local):
         k = self.k
         self.k = (k + 1) % self.depth
         if self.work[k] is not None:
             self.work[k].wait()                 # the slot's previous collective (two steps ago) has its data out
+        if not self.cuda and local.is_cuda:     # host-staged (gloo rehearsal on a GPU box): async copy into the pinned slot
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=local.device)
+            ev0 = torch.cuda.Event()
+            ev0.record()
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev0)
+                self.stage[k].copy_(local, non_blocking=True)
+                local.record_stream(self.stream)
+                ev = torch.cuda.Event()
+                ev.record()
+            self.work[k] = OverlappedGather._HostStaged(self, k, ev)
+            return k
         if not self.cuda:
             self.stage[k].copy_(local)
             self.work[k] = self._collective(k)
@@ -163,6 +195,8 @@ class OverlappedGather:
                 w.wait()
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
+        elif self.stream is not None:
+            self.stream.synchronize()
 
 
 def explain_sharded(explain_fn, images, captions=None, gather=True, group=None, lens=None, n_items=None, reduce="maps"):

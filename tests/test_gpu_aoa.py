@@ -164,3 +164,34 @@ def test_aoa_beam_search_caption_bit_exact():
     ex = ExplainAOAAttention(types.SimpleNamespace(num_head=8), cases[1][1], model=sd)
     maps, rw = ex.explain_caption(img, 0)
     assert ex.beam_caption_encode[1:] == g["aoa_sen_end"].tolist() and len(maps) == len(g["aoa_sen_end"])
+
+
+@pytest.mark.parametrize("bu", [False, True])
+def test_aoa_decoupled_trace_matches_the_stepwise_trace(bu):
+    """The teacher-forced trace with the recurrence decoupled (lrpx_aoa_fwd_recurrence: one GEMM for the input part of all gate
+    pre-activations, T launches of K = H, the attention / AoA half once over all rows) against the stepwise kernels that follow the
+    reference's loop statement by statement (models/aoamodel.py:1019-1052): every trace tensor to 1e-5 of its maximum (z is formed
+    as (x W_ih^T + b) + W_hh h instead of one dot product), both LSTM biases, with and without the gradient explainers' extras."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    V, B, T = 523, 20, 7
+    if bu:
+        eng = AOAEngine(weights.make_aoa_state(seed=31, vocab_size=V, feat_dim=2048, with_encoder=False))
+        enc = eng.encode(features=torch.from_numpy(weights.make_bu_features(32, B)))
+    else:
+        eng = AOAEngine(weights.make_aoa_state(seed=31, vocab_size=V))
+        enc = eng.encode(torch.from_numpy(weights.make_images(32, B)))
+    cap = torch.from_numpy(weights.make_captions(33, B, T, V)).cuda()
+    assert eng.decoupled
+    for grad in (False, True):
+        a = eng.trace(enc, cap, predictions=True, grad=grad)
+        eng.decoupled = False
+        try:
+            b = eng.trace(enc, cap, predictions=True, grad=grad)
+        finally:
+            eng.decoupled = True
+        for k in ["xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha", "logit", "pred"] + (["o", "sg"] if grad else []):
+            e = rel_err(a[k].cpu(), b[k].cpu())
+            assert e < 1e-5, (k, grad, e)
