@@ -250,11 +250,12 @@ class AOAEngine:
 
     def _plain_rows(self, x, name, bias):
         """x (R, K) @ W^T + bias -> (R, N) for one of the trace's plain linears over all (image, word) rows: split products on the
-        fp16 matrix cores for many rows (as `logits(fast=True)`: <= 2e-7 of a row's maximum), the fp32 MFMA kernel otherwise"""
+        fp16 matrix cores (as `logits(fast=True)`: <= 2e-7 of a row's maximum; operand scale per ROW), the fp32 MFMA kernel where K is
+        no multiple of 64.  The kernel never depends on the number of rows: an image's trace is the same in every batch."""
         p_h, p_f, n, k = self._plain[name]
         R = x.shape[0]
         out = torch.empty(R, n, device=self.device)
-        if R >= 128 and p_h is not None:
+        if p_h is not None:
             ops.conv_mfma(x, p_h, R, 0, k, -(-n // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=n, bias=bias, out0=out, f16x3=1,
                           in_amax=ops.amax_maps(x, R))
         else:
