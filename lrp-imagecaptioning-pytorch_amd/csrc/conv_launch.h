@@ -127,6 +127,16 @@ int launch_h3_28_pool(const ConvArgs& a, hipStream_t s);
 // dense relevance GEMMs with many rows on the fp16 matrix cores (dense_f16x3.hip)
 int launch_dense_f16x3(const ConvArgs& a, hipStream_t s);
 int launch_dense_small_f16x3(const ConvArgs& a, hipStream_t s);     // few rows: whole K per workgroup, row scales found in-kernel
+// lock-step s of the AoA decoder relevance fused into that GEMM (dense_f16x3.hip, FUSE): rows are (image, word) pairs, row = image * T + word
+struct AoaStepFuse {
+    int T = 0, s = 0;
+    const int* lens = nullptr;                                   // [B] words per image (null: T)
+    const float *g = nullptr, *i = nullptr, *c = nullptr;       // trace: g pre-activation / i gate [B][T][H], cell state [B][T+1][H]
+    float* A_next = nullptr;                                     // [rows][H] GEMM input of lock-step s + 1 (the OTHER buffer than `in`)
+    float* r_glob = nullptr;                                     // [rows][H], accumulated
+    float* wpart = nullptr;                                      // [rows][T][4] partial sums of r_words
+};
+int launch_dense_small_f16x3_aoa_step(const ConvArgs& a, const AoaStepFuse& fz, hipStream_t s);
 
 // few-row dense GEMMs (dense_small.hip)
 bool dense_small_fits(const ConvArgs& a);

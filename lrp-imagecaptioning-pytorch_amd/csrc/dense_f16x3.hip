@@ -649,9 +649,19 @@ constexpr int DS_NB = 12;
 #ifndef LRPXD_EXP
 #define LRPXD_EXP 0       // timing experiments (wrong results): 1 no multiplicand / addend loads in the epilogue, 2 no K loop, 4 no A staging, 8 no stores
 #endif
-template <int MAXU, bool EXACT>   // float4 items of the A slab per thread: 16 for K = 512, 32 for K = 1024 (EXACT: no tail); else guarded
-__global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+// FUSE (round 5): lock-step s of the AoA decoder relevance (models/aoamodel.py:1114-1134) inside the gate rule's GEMM.  The product
+// r_xh = xh * (W_g^T A) (:1125-1128) is consumed right where it is formed - the three column ranges of r_xh = [emb | glob | h] (:1129-1133):
+//   emb  -> r_words[row][i] = sum over the E embedding columns: per 128-column workgroup one partial sum (wpart), added up in a fixed order
+//           by rel_words_norm_parts_kernel (deterministic);
+//   glob -> r_glob += r_xh[E : E + H];
+//   h    -> r_h, and from it the NEXT lock-step's GEMM input A = (r_h * i tanh(g) / z~(c)) / z~(g) (:1116-1120, aoa_rel_a_kernel's
+//           expression and operation order) into the other A buffer.
+// r_xh itself is never stored and the separate point-wise launch between two GEMMs (aoa_rel_ca_kernel) is gone: 2 launches per
+// lock-step -> 1.  E = H, both multiples of 128 (host-checked).
+template <int MAXU, bool EXACT, bool FUSE = false>   // float4 items of the A slab per thread: 16 for K = 512, 32 for K = 1024 (EXACT: no tail); else guarded
+__global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks, AoaStepFuse fz) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    __shared__ float wsum[4][32];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mtile = blockIdx.x / n_blocks, nblk = blockIdx.x % n_blocks;
@@ -746,6 +756,26 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
             uv[e] = (Uu && !(LRPXD_EXP & 1)) ? Uu[(long)n * ncol + occ] : 0.f;
         }
     }
+    // FUSE, h columns: the coefficients of the next lock-step's A (they do not depend on the product: issued here, they arrive under the K loop)
+    float q1[16], dg[16];
+    if constexpr (FUSE) {
+        const int Hh = a.cin;                              // E = H = K
+        if (nblk * 128 >= 2 * Hh && fz.s + 1 < fz.T) {
+            const int ch = min(ocb * 32 + li, a.oc_split - 1) - 2 * Hh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned row = min((unsigned)row0 + (unsigned)((e & 3) + 8 * (e >> 2) + 4 * lh), last);
+                const int b = (int)(row / (unsigned)fz.T), t = (int)row - b * fz.T;
+                const int len = fz.lens ? fz.lens[b] : fz.T;
+                const bool act = t < len && t >= fz.s + 1;
+                const int i = act ? t - fz.s - 1 : 0;
+                const long ti = ((long)b * fz.T + i) * Hh + ch, sc1 = ((long)b * (fz.T + 1) + i + 1) * Hh + ch;
+                const float gg = fz.g[ti];
+                q1[e] = act ? (fz.i[ti] * tanhf(gg)) / stab_eps(fz.c[sc1]) : 0.f;
+                dg[e] = act ? stab_eps(gg) : 1.f;
+            }
+        }
+    }
     __syncthreads();
     if (!wave_active) return;
     f32x16 acc;
@@ -792,6 +822,55 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
             uv[e] = (Uu && !(LRPXD_EXP & 1)) ? Uu[(long)nn[e] * ncol + oc] : 0.f;
         }
     }
+    if constexpr (FUSE) {
+        const int Hh = a.cin, T = fz.T, sNow = fz.s;
+        const int part = (nblk * 128) / Hh;              // 0 emb, 1 glob, 2 h (workgroup-uniform)
+        float rx[16];
+        bool act[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rl = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const long row = row0 + rl;
+            const unsigned rr = (unsigned)min(row, rows - 1);
+            const int b = (int)(rr / (unsigned)T), t = (int)rr - b * T;
+            const int len = fz.lens ? fz.lens[b] : T;
+            act[e] = row < rows && t < len && t >= sNow;
+            rx[e] = xv[e] * (acc[e] * (exp2i(-f16_scale_exp(rowmax[rl])) * inv_w) + uv[e]);
+        }
+        if (part == 0) {
+            // per row the sum over this wave's 32 columns (the 32 lanes of a half-wave), then over the 4 waves in wave order
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = rx[e];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (li == 0) wsum[wave][(e & 3) + 8 * (e >> 2) + 4 * lh] = v;
+            }
+            __syncthreads();
+            if (tid < 32) {
+                const long row = row0 + tid;
+                if (row < rows) {
+                    const int b = (int)(row / T), t = (int)(row - (long)b * T);
+                    const int len = fz.lens ? fz.lens[b] : T;
+                    if (t < len && t >= sNow)
+                        fz.wpart[(row * T + (t - sNow)) * 4 + (nblk & 3)] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
+                }
+            }
+        } else if (part == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (act[e]) fz.r_glob[row * Hh + (oc - Hh)] += rx[e];
+            }
+        } else if (sNow + 1 < T) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row < rows) fz.A_next[row * Hh + (oc - 2 * Hh)] = (q1[e] * rx[e]) / dg[e];      // q1 = 0 for a row that is not active at s + 1
+            }
+        }
+        return;
+    }
     float* __restrict__ O0 = a.out0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -817,8 +896,25 @@ int launch_dense_small_f16x3(const ConvArgs& a, hipStream_t stream) {
                 : (which == 2 ? dense_small_f16x3_kernel<16, false> : dense_small_f16x3_kernel<32, false>));
     static LdsOnce once[4];
     LRPX_TRY(reserve_lds_once(once[which], kern, LDS_MAX, "dense_small_f16x3"));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks, AoaStepFuse{});
     return check_launch("dense_small_f16x3");
+}
+
+// lock-step fz.s of the AoA relevance: the gate rule's GEMM with the step's point-wise code in its epilogue (FUSE above)
+int launch_dense_small_f16x3_aoa_step(const ConvArgs& a, const AoaStepFuse& fz, hipStream_t stream) {
+    const long rows = (long)a.n_maps * a.pix_per_map;
+    LRPX_REQUIRE(a.cin == 512 && a.n_oc == 3 * a.cin && a.oc_split == a.n_oc && a.pix_per_map == 1 && !a.U && a.X && a.map2img,
+                 "dense_small_f16x3 (AoA lock-step): built for E = H = K = 512, N = 1536, one row per map, x and map2img given");
+    LRPX_REQUIRE(rows > 0 && rows < 0x7fffffffL && fz.T > 0 && rows % fz.T == 0 && fz.s >= 0 && fz.s < fz.T && fz.g && fz.i && fz.c &&
+                     fz.r_glob && fz.wpart && (fz.A_next || fz.s + 1 >= fz.T), "dense_small_f16x3 (AoA lock-step): bad step arguments");
+    const int m_tiles = (int)ceil_div(rows, 32), n_blocks = a.n_oc / 128;
+    const int lds = 32 * ((a.cin / 16) * 64 + 16) + 128;
+    constexpr int LDS_MAX = 32 * (64 * 64 + 16) + 128;
+    auto kern = dense_small_f16x3_kernel<16, true, true>;
+    static LdsOnce once;
+    LRPX_TRY(reserve_lds_once(once, kern, LDS_MAX, "dense_small_f16x3 (AoA lock-step)"));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_blocks)), dim3(256), lds, stream, a, m_tiles, n_blocks, fz);
+    return check_launch("dense_small_f16x3 (AoA lock-step)");
 }
 
 int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {

@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "conv_mfma.h"
+#include "conv_launch.h"
 
 namespace lrpx {
 
@@ -709,6 +710,31 @@ __global__ void rel_words_norm_kernel(float* __restrict__ r_words, int rows, int
     for (int i = 0; i <= t; ++i) m = fmaxf(m, fabsf(r_words[(long)row * T + i]));
     if (m > 0.f)
         for (int i = 0; i <= t; ++i) r_words[(long)row * T + i] /= m;
+}
+
+// the same after the fused AoA lock-steps (dense_f16x3.hip, FUSE): r_words[row][i] = the four 128-column partial sums of the
+// embedding part in a fixed order, then :1129-1132; rows behind an image's last word stay zero
+__global__ void rel_words_norm_parts_kernel(float* __restrict__ r_words, const float* __restrict__ wpart, const int* __restrict__ lens,
+                                            int rows, int T) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int b = row / T, t = row - b * T;
+    const int len = lens ? lens[b] : T;
+    float* rw = r_words + (long)row * T;
+    if (t >= len) {
+        for (int i = 0; i < T; ++i) rw[i] = 0.f;
+        return;
+    }
+    float m = 0.f;
+    for (int i = 0; i <= t; ++i) {
+        const float* p = wpart + ((long)row * T + i) * 4;
+        const float v = (p[0] + p[1]) + (p[2] + p[3]);
+        rw[i] = v;
+        m = fmaxf(m, fabsf(v));
+    }
+    for (int i = t + 1; i < T; ++i) rw[i] = 0.f;
+    if (m > 0.f)
+        for (int i = 0; i <= t; ++i) rw[i] /= m;
 }
 
 
@@ -1926,6 +1952,32 @@ int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, in
         }
     }
     return LRPX_OK;
+}
+
+int lrpx_aoa_rel_steps_fused(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const lrpx_conv_desc* dense, const int32_t* idx,
+                             int idx_ld, float* a_alt, float* wpart, void* stream) {
+    LRPX_TRY(check_arel(tr, rs));
+    const int T = tr->T, rows = tr->B * tr->T, H = tr->H;
+    LRPX_REQUIRE(dense && idx && a_alt && wpart && idx_ld >= rows, "aoa_rel_steps_fused: bad arguments");
+    LRPX_REQUIRE(dense->f16x3 == 1 && dense->taps == 1 && dense->epi == EPI_REL && dense->in == rs->A && dense->x && !dense->u &&
+                     dense->cin == H && tr->E == H && H == 512 && dense->n_oc == 3 * H && dense->oc_split == 3 * H && dense->n_maps == rows &&
+                     dense->pix_per_map == 1, "aoa_rel_steps_fused: the fused lock-step is built for E = H = 512 on the f16x3 gate rule");
+    hipStream_t st = (hipStream_t)stream;
+    LRPX_TRY(lrpx_aoa_rel_step(tr, rs, 0, 0, stream));                 // A of lock-step 0 (:1116-1120)
+    ConvArgs a = {};
+    a.wp = dense->wpacked; a.n_maps = rows; a.cin = H; a.n_oc = 3 * H; a.pix_per_map = 1; a.epi = EPI_REL; a.oc_split = 3 * H;
+    a.X = dense->x; a.ksplit = 1;
+    AoaStepFuse fz;
+    fz.T = T; fz.lens = rs->lens; fz.g = tr->g; fz.i = tr->i; fz.c = tr->c; fz.r_glob = rs->r_glob; fz.wpart = wpart;
+    float* buf[2] = {rs->A, a_alt};
+    for (int s = 0; s < T; ++s) {
+        a.in = buf[s & 1];
+        a.map2img = idx + (long)s * idx_ld;        // row -> source row of the multiplicand at lock-step s
+        fz.s = s; fz.A_next = buf[(s + 1) & 1];
+        LRPX_TRY(launch_dense_small_f16x3_aoa_step(a, fz, st));
+    }
+    hipLaunchKernelGGL(rel_words_norm_parts_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, rs->r_words, wpart, rs->lens, rows, T);
+    return check_launch("rel_words_norm_parts");
 }
 
 }  // extern "C"

@@ -81,6 +81,7 @@ class AOAEngine:
             self.p_proj_rel_h = ops.pack_weights_f16x2(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1)
         # ... and the lock-step gate rule / the aoa_linear rule (rows = images x words): the few-row kernel of the same file
         self.fused_steps = True          # decoder steps as 4 launches instead of 7 (False: the unfused kernels; A/B and tests)
+        self.fused_rel = True            # relevance lock-steps as ONE launch each (False: GEMM + point-wise kernel; A/B and tests)
         self.lockstep_f16 = H % 16 == 0 and E % 16 == 0
         self.p_wg_h = ops.pack_weights_f16x2(wg, H, E + 2 * H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
         self.p_lin_rel_h = ops.pack_weights_f16x2(sd["decoder_aoa_linear.weight"], H, H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
@@ -465,11 +466,17 @@ class AOAEngine:
         # the lock-steps s = 0..T-1 (:1114-1134) in one native call: phase 0, the LSTM dense rule with map2img = idx[s], phase 1
         dense = ops.conv_desc(rs["A"], self.p_wg_h if f16 else self.p_wg, rows, 0, H, W, 1, EPI_REL, pix_per_map=1, oc_split=W,
                               x=tr["xh"], map2img=idx[0], out0=rs["rx"], f16x3=f16)
-        check(lib.lrpx_aoa_rel_steps(ctr, crs, T, C.byref(dense), ptr(idx), idx.shape[1], st))
+        fused = self.fused_rel and f16 and E == H == 512
+        if fused:      # one launch per lock-step: the step's point-wise code in the GEMM's epilogue (lrpx_aoa_rel_steps_fused)
+            a_alt, wpart = e(rows, H), e(rows, T, 4)
+            check(lib.lrpx_aoa_rel_steps_fused(ctr, crs, C.byref(dense), ptr(idx), idx.shape[1], ptr(a_alt), ptr(wpart), st))
+        else:
+            check(lib.lrpx_aoa_rel_steps(ctr, crs, T, C.byref(dense), ptr(idx), idx.shape[1], st))
         # :1136-1144  r_proj = eye rule on the mean (U) + v_proj dense rule; fused division for the projector rule
         U = e(rows, H)
         check(lib.lrpx_rel_avg_u(ptr(rs["r_glob"]), ptr(enc["glob"]), ptr(U), rows, T, H, P, st))
-        check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
+        if not fused:
+            check(lib.lrpx_rel_words_norm(ptr(rs["r_words"]), rows, T, st))
         n, rowlist = rows, None
         if rg is not None and not rg.full and compact:     # unequal lengths: the (word, pixel) rules on the valid rows only
             n, rowlist, row2img = rg.n, rg.rows, rg.row2img

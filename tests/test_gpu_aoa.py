@@ -195,3 +195,35 @@ def test_aoa_decoupled_trace_matches_the_stepwise_trace(bu):
         for k in ["xh", "h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha", "logit", "pred"] + (["o", "sg"] if grad else []):
             e = rel_err(a[k].cpu(), b[k].cpu())
             assert e < 1e-5, (k, grad, e)
+
+
+@pytest.mark.parametrize("bu", [False, True])
+def test_aoa_fused_lock_steps_match_the_two_launch_steps(bu):
+    """The relevance lock-steps with the step's point-wise code inside the gate rule's GEMM (lrpx_aoa_rel_steps_fused: one launch per
+    step, r_xh never stored) against GEMM + point-wise kernel: the same expressions in the same order, so r_feat - everything behind
+    r_h and r_glob - is bit-identical; r_words sums its 512 embedding columns in another order (four 128-column partial sums): equal
+    to 2e-6 of the row's largest entry.  Rows that do not fill a 32-row tile, captions of unequal length, two heads."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    V, B, T = 523, 5, 9
+    if bu:
+        eng = AOAEngine(weights.make_aoa_state(seed=35, vocab_size=V, feat_dim=2048, with_encoder=False))
+        enc = eng.encode(features=torch.from_numpy(weights.make_bu_features(36, B)))
+    else:
+        eng = AOAEngine(weights.make_aoa_state(seed=35, vocab_size=V))
+        enc = eng.encode(torch.from_numpy(weights.make_images(36, B)))
+    cap = torch.from_numpy(weights.make_captions(37, B, T, V)).cuda()
+    tr = eng.trace(enc, cap, predictions=False)
+    assert eng.fused_rel
+    for head, lens in ((0, None), (6, [9, 2, 5, 0, 9])):
+        a_feat, a_words, _ = eng.relevance(enc, tr, head, lens, compact=False)
+        eng.fused_rel = False
+        try:
+            b_feat, b_words, _ = eng.relevance(enc, tr, head, lens, compact=False)
+        finally:
+            eng.fused_rel = True
+        assert torch.equal(a_feat, b_feat), (head, (a_feat - b_feat).abs().max().item())
+        assert (a_words - b_words).abs().max().item() < 2e-6, (head, (a_words - b_words).abs().max().item())
+        assert a_words.abs().max().item() == 1.0
