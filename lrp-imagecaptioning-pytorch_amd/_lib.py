@@ -153,7 +153,7 @@ SIGNATURES = {
     "lrpx_aoa_rel_value": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _i, _f, _f]),
     "lrpx_aoa_rel_step": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _i, _i, _f]),
     "lrpx_aoa_rel_steps": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _i, C.POINTER(ConvDesc), _f, _i, _f]),
-    "lrpx_aoa_rel_steps_fused": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), C.POINTER(ConvDesc), _f, _i, _f, _f, _f]),
+    "lrpx_aoa_rel_steps_fused": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), C.POINTER(ConvDesc), _f, _i, _f, _f, _f, _f]),
     "lrpx_gridtd_grad_init": (_i, [C.POINTER(GridTrace), C.POINTER(GridGradState), _f, _f, _i, _f]),
     "lrpx_gridtd_grad_step": (_i, [C.POINTER(GridTrace), C.POINTER(GridGradState), _i, _i, _f]),
     "lrpx_spread_pixels": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),

@@ -130,8 +130,8 @@ int launch_dense_small_f16x3(const ConvArgs& a, hipStream_t s);     // few rows:
 // lock-step s of the AoA decoder relevance fused into that GEMM (dense_f16x3.hip, FUSE): rows are (image, word) pairs, row = image * T + word
 struct AoaStepFuse {
     int T = 0, s = 0;
-    const int* lens = nullptr;                                   // [B] words per image (null: T)
-    const float *g = nullptr, *i = nullptr, *c = nullptr;       // trace: g pre-activation / i gate [B][T][H], cell state [B][T+1][H]
+    const int* tmax = nullptr;                                   // [rows] word index t of the row if its caption has that word, else -1
+    const float *q1 = nullptr, *dg = nullptr;                    // [B][T][H]: i tanh(g) / z~(c next), z~(g)  (lrpx_decoder.hip, aoa_rel_coef_kernel)
     float* A_next = nullptr;                                     // [rows][H] GEMM input of lock-step s + 1 (the OTHER buffer than `in`)
     float* r_glob = nullptr;                                     // [rows][H], accumulated
     float* wpart = nullptr;                                      // [rows][T][4] partial sums of r_words

@@ -756,23 +756,30 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
             uv[e] = (Uu && !(LRPXD_EXP & 1)) ? Uu[(long)n * ncol + occ] : 0.f;
         }
     }
-    // FUSE, h columns: the coefficients of the next lock-step's A (they do not depend on the product: issued here, they arrive under the K loop)
+    // FUSE: per row tmax = its word index t if the caption has that word, else -1 (row = image * T + t is active at lock-step s iff
+    // s <= tmax); h columns: the coefficients of the next lock-step's A - Q1 = i tanh(g) / z~(c), DG = z~(g) at time index t - s - 1,
+    // i.e. at flat index row - s - 1 of the [B][T][H] tables (lrpx_aoa_rel_coef) - issued here, they arrive under the K loop
     float q1[16], dg[16];
+    unsigned m_now = 0u, m_next = 0u;                      // bit e: the lane's e-th row is active at lock-step s / s + 1
     if constexpr (FUSE) {
         const int Hh = a.cin;                              // E = H = K
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rl = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int tm = row0 + rl < rows ? fz.tmax[row0 + rl] : -1;
+            m_now |= (fz.s <= tm ? 1u : 0u) << e;
+            m_next |= (fz.s + 1 <= tm ? 1u : 0u) << e;
+        }
         if (nblk * 128 >= 2 * Hh && fz.s + 1 < fz.T) {
             const int ch = min(ocb * 32 + li, a.oc_split - 1) - 2 * Hh;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const unsigned row = min((unsigned)row0 + (unsigned)((e & 3) + 8 * (e >> 2) + 4 * lh), last);
-                const int b = (int)(row / (unsigned)fz.T), t = (int)row - b * fz.T;
-                const int len = fz.lens ? fz.lens[b] : fz.T;
-                const bool act = t < len && t >= fz.s + 1;
-                const int i = act ? t - fz.s - 1 : 0;
-                const long ti = ((long)b * fz.T + i) * Hh + ch, sc1 = ((long)b * (fz.T + 1) + i + 1) * Hh + ch;
-                const float gg = fz.g[ti];
-                q1[e] = act ? (fz.i[ti] * tanhf(gg)) / stab_eps(fz.c[sc1]) : 0.f;
-                dg[e] = act ? stab_eps(gg) : 1.f;
+                const bool act = (m_next >> e) & 1u;
+                const long ti = (long)(act ? (int)row - fz.s - 1 : 0) * Hh + ch;
+                q1[e] = fz.q1[ti];
+                dg[e] = fz.dg[ti];
+                if (!act) { q1[e] = 0.f; dg[e] = 1.f; }
             }
         }
     }
@@ -826,15 +833,9 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
         const int Hh = a.cin, T = fz.T, sNow = fz.s;
         const int part = (nblk * 128) / Hh;              // 0 emb, 1 glob, 2 h (workgroup-uniform)
         float rx[16];
-        bool act[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int rl = (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const long row = row0 + rl;
-            const unsigned rr = (unsigned)min(row, rows - 1);
-            const int b = (int)(rr / (unsigned)T), t = (int)rr - b * T;
-            const int len = fz.lens ? fz.lens[b] : T;
-            act[e] = row < rows && t < len && t >= sNow;
             rx[e] = xv[e] * (acc[e] * (exp2i(-f16_scale_exp(rowmax[rl])) * inv_w) + uv[e]);
         }
         if (part == 0) {
@@ -850,9 +851,8 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
             if (tid < 32) {
                 const long row = row0 + tid;
                 if (row < rows) {
-                    const int b = (int)(row / T), t = (int)(row - (long)b * T);
-                    const int len = fz.lens ? fz.lens[b] : T;
-                    if (t < len && t >= sNow)
+                    const int t = fz.tmax[row];
+                    if (sNow <= t)
                         fz.wpart[(row * T + (t - sNow)) * 4 + (nblk & 3)] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
                 }
             }
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void dense_small_f16x3_kernel(ConvArgs a, i
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const long row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (act[e]) fz.r_glob[row * Hh + (oc - Hh)] += rx[e];
+                if ((m_now >> e) & 1u) fz.r_glob[row * Hh + (oc - Hh)] += rx[e];
             }
         } else if (sNow + 1 < T) {
 #pragma unroll
@@ -905,7 +905,7 @@ int launch_dense_small_f16x3_aoa_step(const ConvArgs& a, const AoaStepFuse& fz, 
     const long rows = (long)a.n_maps * a.pix_per_map;
     LRPX_REQUIRE(a.cin == 512 && a.n_oc == 3 * a.cin && a.oc_split == a.n_oc && a.pix_per_map == 1 && !a.U && a.X && a.map2img,
                  "dense_small_f16x3 (AoA lock-step): built for E = H = K = 512, N = 1536, one row per map, x and map2img given");
-    LRPX_REQUIRE(rows > 0 && rows < 0x7fffffffL && fz.T > 0 && rows % fz.T == 0 && fz.s >= 0 && fz.s < fz.T && fz.g && fz.i && fz.c &&
+    LRPX_REQUIRE(rows > 0 && rows < 0x7fffffffL && fz.T > 0 && rows % fz.T == 0 && fz.s >= 0 && fz.s < fz.T && fz.q1 && fz.dg && fz.tmax &&
                      fz.r_glob && fz.wpart && (fz.A_next || fz.s + 1 >= fz.T), "dense_small_f16x3 (AoA lock-step): bad step arguments");
     const int m_tiles = (int)ceil_div(rows, 32), n_blocks = a.n_oc / 128;
     const int lds = 32 * ((a.cin / 16) * 64 + 16) + 128;

@@ -712,32 +712,6 @@ __global__ void rel_words_norm_kernel(float* __restrict__ r_words, int rows, int
         for (int i = 0; i <= t; ++i) r_words[(long)row * T + i] /= m;
 }
 
-// the same after the fused AoA lock-steps (dense_f16x3.hip, FUSE): r_words[row][i] = the four 128-column partial sums of the
-// embedding part in a fixed order, then :1129-1132; rows behind an image's last word stay zero
-__global__ void rel_words_norm_parts_kernel(float* __restrict__ r_words, const float* __restrict__ wpart, const int* __restrict__ lens,
-                                            int rows, int T) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    const int b = row / T, t = row - b * T;
-    const int len = lens ? lens[b] : T;
-    float* rw = r_words + (long)row * T;
-    if (t >= len) {
-        for (int i = 0; i < T; ++i) rw[i] = 0.f;
-        return;
-    }
-    float m = 0.f;
-    for (int i = 0; i <= t; ++i) {
-        const float* p = wpart + ((long)row * T + i) * 4;
-        const float v = (p[0] + p[1]) + (p[2] + p[3]);
-        rw[i] = v;
-        m = fmaxf(m, fabsf(v));
-    }
-    for (int i = t + 1; i < T; ++i) rw[i] = 0.f;
-    if (m > 0.f)
-        for (int i = 0; i <= t; ++i) rw[i] /= m;
-}
-
-
 // ================================================================================================
 // gridTD guided-backprop decoder: hand-written BPTT with alpha/beta constant (models/gridTDmodel.py:1588-1675)
 // ================================================================================================
@@ -1385,6 +1359,45 @@ __global__ __launch_bounds__(256) void aoa_rel_ca_kernel(AoaRel g, int s) {
     }
 }
 
+// per-trace tables of the fused AoA lock-steps: what aoa_rel_a_kernel evaluates per (row, step) depends on (image, time index) only -
+// q1 = i tanh(g) / z~(c[i + 1]) (eps_id's factor) and dg = z~(g) (:1116-1120) - and tmax[row] = t for a word the caption has, else -1
+__global__ void aoa_rel_coef_kernel(AoaRel g, float* __restrict__ q1, float* __restrict__ dg, int* __restrict__ tmax) {
+    const int row = blockIdx.x, b = row / g.T, i = row - b * g.T, H = g.H;
+    const long ti = (long)row * H, sc1 = ((long)b * (g.T + 1) + i + 1) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float gg = g.g[ti + c];
+        q1[ti + c] = (g.i[ti + c] * tanhf(gg)) / stab_eps(g.c[sc1 + c]);
+        dg[ti + c] = stab_eps(gg);
+    }
+    if (threadIdx.x == 0) tmax[row] = i < (g.lens ? g.lens[b] : g.T) ? i : -1;
+}
+
+// the same after the fused AoA lock-steps (dense_f16x3.hip, FUSE): r_words[row][i] = the four 128-column partial sums of the
+// embedding part in a fixed order, then :1129-1132; rows behind an image's last word stay zero
+__global__ void rel_words_norm_parts_kernel(float* __restrict__ r_words, const float* __restrict__ wpart, const int* __restrict__ lens,
+                                            int rows, int T) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int b = row / T, t = row - b * T;
+    const int len = lens ? lens[b] : T;
+    float* rw = r_words + (long)row * T;
+    if (t >= len) {
+        for (int i = 0; i < T; ++i) rw[i] = 0.f;
+        return;
+    }
+    float m = 0.f;
+    for (int i = 0; i <= t; ++i) {
+        const float* p = wpart + ((long)row * T + i) * 4;
+        const float v = (p[0] + p[1]) + (p[2] + p[3]);
+        rw[i] = v;
+        m = fmaxf(m, fabsf(v));
+    }
+    for (int i = t + 1; i < T; ++i) rw[i] = 0.f;
+    if (m > 0.f)
+        for (int i = 0; i <= t; ++i) rw[i] /= m;
+}
+
+
 }  // namespace lrpx
 
 using namespace lrpx;
@@ -1955,10 +1968,10 @@ int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, in
 }
 
 int lrpx_aoa_rel_steps_fused(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const lrpx_conv_desc* dense, const int32_t* idx,
-                             int idx_ld, float* a_alt, float* wpart, void* stream) {
+                             int idx_ld, float* a_alt, float* wpart, float* coef, void* stream) {
     LRPX_TRY(check_arel(tr, rs));
     const int T = tr->T, rows = tr->B * tr->T, H = tr->H;
-    LRPX_REQUIRE(dense && idx && a_alt && wpart && idx_ld >= rows, "aoa_rel_steps_fused: bad arguments");
+    LRPX_REQUIRE(dense && idx && a_alt && wpart && coef && idx_ld >= rows, "aoa_rel_steps_fused: bad arguments");
     LRPX_REQUIRE(dense->f16x3 == 1 && dense->taps == 1 && dense->epi == EPI_REL && dense->in == rs->A && dense->x && !dense->u &&
                      dense->cin == H && tr->E == H && H == 512 && dense->n_oc == 3 * H && dense->oc_split == 3 * H && dense->n_maps == rows &&
                      dense->pix_per_map == 1, "aoa_rel_steps_fused: the fused lock-step is built for E = H = 512 on the f16x3 gate rule");
@@ -1967,8 +1980,12 @@ int lrpx_aoa_rel_steps_fused(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* 
     ConvArgs a = {};
     a.wp = dense->wpacked; a.n_maps = rows; a.cin = H; a.n_oc = 3 * H; a.pix_per_map = 1; a.epi = EPI_REL; a.oc_split = 3 * H;
     a.X = dense->x; a.ksplit = 1;
+    float *q1 = coef, *dg = coef + (size_t)rows * H;
+    int* tmax = reinterpret_cast<int*>(coef + (size_t)2 * rows * H);
+    hipLaunchKernelGGL(aoa_rel_coef_kernel, dim3(rows), dim3(256), 0, st, to_arel(tr, rs), q1, dg, tmax);
+    LRPX_TRY(check_launch("aoa_rel_coef"));
     AoaStepFuse fz;
-    fz.T = T; fz.lens = rs->lens; fz.g = tr->g; fz.i = tr->i; fz.c = tr->c; fz.r_glob = rs->r_glob; fz.wpart = wpart;
+    fz.T = T; fz.tmax = tmax; fz.q1 = q1; fz.dg = dg; fz.r_glob = rs->r_glob; fz.wpart = wpart;
     float* buf[2] = {rs->A, a_alt};
     for (int s = 0; s < T; ++s) {
         a.in = buf[s & 1];

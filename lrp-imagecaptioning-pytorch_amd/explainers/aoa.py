@@ -468,8 +468,8 @@ class AOAEngine:
                               x=tr["xh"], map2img=idx[0], out0=rs["rx"], f16x3=f16)
         fused = self.fused_rel and f16 and E == H == 512
         if fused:      # one launch per lock-step: the step's point-wise code in the GEMM's epilogue (lrpx_aoa_rel_steps_fused)
-            a_alt, wpart = e(rows, H), e(rows, T, 4)
-            check(lib.lrpx_aoa_rel_steps_fused(ctr, crs, C.byref(dense), ptr(idx), idx.shape[1], ptr(a_alt), ptr(wpart), st))
+            a_alt, wpart, coef = e(rows, H), e(rows, T, 4), e(2 * rows * H + rows)
+            check(lib.lrpx_aoa_rel_steps_fused(ctr, crs, C.byref(dense), ptr(idx), idx.shape[1], ptr(a_alt), ptr(wpart), ptr(coef), st))
         else:
             check(lib.lrpx_aoa_rel_steps(ctr, crs, T, C.byref(dense), ptr(idx), idx.shape[1], st))
         # :1136-1144  r_proj = eye rule on the mean (U) + v_proj dense rule; fused division for the projector rule

@@ -202,7 +202,7 @@ def test_aoa_fused_lock_steps_match_the_two_launch_steps(bu):
     """The relevance lock-steps with the step's point-wise code inside the gate rule's GEMM (lrpx_aoa_rel_steps_fused: one launch per
     step, r_xh never stored) against GEMM + point-wise kernel: the same expressions in the same order, so r_feat - everything behind
     r_h and r_glob - is bit-identical; r_words sums its 512 embedding columns in another order (four 128-column partial sums): equal
-    to 2e-6 of the row's largest entry.  Rows that do not fill a 32-row tile, captions of unequal length, two heads."""
+    to 1e-5 (the rows are normalised to a largest entry of 1; ~100x cancellation).  Rows that do not fill a 32-row tile, captions of unequal length, two heads."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from lrp_amd import weights
@@ -225,5 +225,5 @@ def test_aoa_fused_lock_steps_match_the_two_launch_steps(bu):
         finally:
             eng.fused_rel = True
         assert torch.equal(a_feat, b_feat), (head, (a_feat - b_feat).abs().max().item())
-        assert (a_words - b_words).abs().max().item() < 2e-6, (head, (a_words - b_words).abs().max().item())
+        assert (a_words - b_words).abs().max().item() < 1e-5, (head, (a_words - b_words).abs().max().item())
         assert a_words.abs().max().item() == 1.0
