@@ -125,7 +125,7 @@ MODE_DTYPE = {0: "f32", 1: "bf16x6 split products, f32 accumulate", 2: "f16x3 sp
 # HBM traffic per launch: tools/prof_summary.py traffic-json writes this file from the two --pmc passes (FETCH_SIZE /
 # WRITE_SIZE, separate from any tracing); bytes = 2 x FETCH_SIZE raw [gfx950 reports half of wide streaming reads,
 # MI355X_MICROARCH.md §HBM; re-calibrated by tools/pmc_calibrate.py] + WRITE_SIZE, divided by the launches and scaled to the maps of this run
-TRAFFIC_FILES = ["profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
+TRAFFIC_FILES = ["profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
 
 
 def host_cores():
@@ -750,6 +750,9 @@ def roofline(a, lib, eng, state, maps, B, T, mode):
         "mfma_products_per_fp32_product": PRODUCTS[mode], "algorithmic_tflops": round(alg, 1),
         "ms_per_launch": round(dom_ms, 4), "flop_per_launch": flop,
         "traffic": traffic, "traffic_source": src,
+        #  `kernel` is named by bench.rel_launcher, a restatement of csrc/lrpx_vgg.hip:conv_dispatch for the default switches:
+        # true when a kernel of exactly that name was profiled in the PMC passes of `traffic_source` (same library, same dispatch)
+        "kernel_name_verified": traffic is not None,
         "chain_frac": round(PRODUCTS[mode] * chain_alg / peak, 4),
         "chain_frac_note": "sum of the 13 layers' algorithmic flop / sum of their launch times (HIP events per launch), same accounting as frac",
         "per_layer": table,

@@ -1618,6 +1618,9 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         return;
     }
     if constexpr (TR) {
+        // the map-straddling branch of epi_rel_mul_blk numbers a wave's maps from the WORKGROUP's first row and keeps three maxima: with
+        // more than one pixel sub-tile per workgroup (MT > 1) the later waves would drop theirs; every such instantiation is AL
+        static_assert(AL || MT == 1, "epi_rel_mul_blk: non-aligned (map-straddling) tiles need MT == 1");
         epi_rel_mul_blk<HW, AL, F8>(a, acc, wm, ocb, lane, g0, total_pix, a.out1 ? a.out1_amax : nullptr, tile_tab, inv_w, in_amax);
 #ifdef LRPXH_END_SLEEP
         for (int i = 0; i < LRPXH_END_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);

@@ -558,9 +558,14 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
         const int oc = (ocb0 + j) * 32 + tc;
         const unsigned nt0 = ri_n[32 * i];
         if (j == 0) { mres[i][0] = 0.f; mres[i][1] = 0.f; nres[i] = nt0; }
+        // (the previous unit's reads of this wave's scratch are complete before it is overwritten, and the reads below see the writes
+        // above: LDS instructions of one wave execute in order; the fences pin that order for the COMPILER too - ADVICE r4 - and cost nothing)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * lh) * SP + li] = acc[i][j][e];
-        // (same wave, LDS instructions execute in order: the reads below see the writes above)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (EPI == EPI_PLAIN) { if (a.bias) bv4 = *reinterpret_cast<const f32x4*>(a.bias + min(oc, ncol - 4)); }
 #pragma unroll
@@ -981,7 +986,10 @@ int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
 extern "C" int lrpx_debug_stamps_dn(unsigned long long* out, int n_waves, int reset) {
     if (n_waves > 16384) return 2;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lrpx::g_stamp_dn), (size_t)n_waves * 80) != hipSuccess) return 1;
-    if (reset) { if (hipMemset(nullptr, 0, 0) != hipSuccess) {} }
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(lrpx::g_stamp_dn)) != hipSuccess || hipMemset(p, 0, (size_t)16384 * 80) != hipSuccess) return 1;
+    }
     return 0;
 }
 #endif

@@ -59,7 +59,10 @@ def test_release_library_carries_no_experiment_switches():
 
 
 def _compile_flags_unit(tmp_path, name, flags):
+    import shutil
     import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler on this machine")
     src = os.path.join(ROOT, "lrp-imagecaptioning-pytorch_amd", "csrc", "lrpx_build_flags.hip")
     out = str(tmp_path / name)
     r = subprocess.run(["g++", "-x", "c++", "-shared", "-fPIC", "-o", out, src] + flags, capture_output=True, text=True)
