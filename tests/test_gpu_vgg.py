@@ -1026,3 +1026,27 @@ def test_chain_hostile_weights_all_modes(ops, gridtd_case, family, sigma, dead_f
         assert err.max().item() < TOL, (family, mode, err.max().item())
     for (mode, fam), (e, k) in worst.items():
         assert e < TOL, (family, "oracle", mode, fam, e, k)
+    # ---- the image-gradient chains (guided backprop / plain gradient: models/gridTDmodel.py:1677-1723, :1507-1521) on the same weights
+    # and trace: their split-product kernels take W itself (no Z+ side), scaled per layer; first map of every relevance family
+    picks = [names.index(f) for f in ("heavy", "scaled", "sparse", "reference")]
+    d_feat = r_feat[picks].contiguous()
+    m2p = m2i[picks].contiguous()
+    for kind, fn, ofn in (("guided", vgg.guided_backprop, O.vgg_guided_backprop), ("gradient", vgg.gradient, O.vgg_gradient)):
+        got = {}
+        prev = lib.lrpx_set_conv_mode(3)
+        try:
+            for mode in (3, 2, 0):
+                lib.lrpx_set_conv_mode(mode)
+                got[mode] = fn(d_feat, m2p).clone().cpu().double()
+        finally:
+            lib.lrpx_set_conv_mode(prev)
+        line = []
+        for j, k in enumerate(picks):
+            b = int(m2i[k])
+            want = ofn(sdt, [x[b:b + 1] for x in saved], from_nhwc(r_feat[k:k + 1].cpu(), 512, 14, 14)).double()
+            sc = want.abs().max()
+            for mode in (3, 2, 0):
+                e = ((got[mode][j:j + 1] - want).abs().max() / sc).item() if sc > 0 else 0.0
+                line.append(f"{names[k]} mode {mode}: {e:.1e}")
+                assert e < TOL, (family, kind, names[k], mode, e)
+        print(f"[{family}] {kind} chain vs the CPU oracle | " + " | ".join(line))
