@@ -281,6 +281,13 @@ const float* lrpx_vgg16_trace_features(const void* trace, int n_img);
  * for bit).  It keeps the operands of the split-product modes inside fp16's range when a channel's weights are small against its bias
  * (trained weights, models/vgg.py:86-94).  Returns the DEVICE pointer of rs inside `packed` (n_channels floats), null for a pool. */
 const float* lrpx_vgg16_channel_scales(const void* packed, int layer, int* n_channels);
+/* DEVICE pointer of 17 floats inside `packed` (index = layer; pools: unset): the largest ratio of row maxima max|W[c,:,:,:]| inside one
+ * 16-row slice of a conv layer's weights.  The image-gradient chains (guided backprop / plain gradient) multiply with W itself; in conv
+ * mode 3 the cross terms of their operands are fp6 fields that share ONE scale per 16-channel slice, so a slice whose rows differ by
+ * 2^6 and more loses the cross terms of its small rows (measured on log-normal channel scales: 1.1e-4 of max|gradient|, fp16 split
+ * products 4e-6).  A caller that wants the 1e-4 grade on any weights runs those chains in conv mode 2 when a layer exceeds ~64
+ * (lrp_amd.ops.Vgg16 does).  The relevance chain is not affected: its rows are balanced (lrpx_vgg16_channel_scales). */
+const float* lrpx_vgg16_row_spread(const void* packed);
 
 
 /* ---- small dense / utility kernels of the decoders ----------------------------------------------- */

@@ -176,6 +176,7 @@ SIGNATURES = {
     "lrpx_vgg16_trace_layout": (_i, [_i, C.POINTER(_sz), C.POINTER(_sz)]),
     "lrpx_vgg16_trace_features": (_f, [_f, _i]),
     "lrpx_vgg16_channel_scales": (_f, [_f, _i, C.POINTER(_i)]),
+    "lrpx_vgg16_row_spread": (_f, [_f]),
     "lrpx_vgg16_resolve_opts": (_i, [C.POINTER(VggOpts), C.POINTER(_i), C.POINTER(_i)]),
     "lrpx_vgg16_forward_ex": (_i, [_f, _f, _i, _f, _f, C.POINTER(VggOpts), _f]),
     "lrpx_vgg16_relevance_ex": (_i, [_f, _f, _i, _f, _f, _i, _f, _f, C.POINTER(VggOpts), _f]),

@@ -319,6 +319,7 @@ static thread_local float tl_ms[17];
 struct VggPacked {   // offsets in floats into the packed blob
     size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], fwdh0, first6, first6p, first16, first16p, total;
     size_t chs[17];      // per-output-channel balance factors rs_l[c] of conv l (powers of two, see lrpx_vgg16_pack)
+    size_t spread;       // [17] per conv layer: largest ratio of row maxima max|W[c,:]| inside one 16-row K slice (lrpx_vgg16_row_spread)
     size_t scratch;      // scaled weight copies while packing: cout*cin*9 + 2*cout*2*cin*9 floats of the largest layer
 };
 static VggPacked vgg_packed_layout() {
@@ -351,6 +352,7 @@ static VggPacked vgg_packed_layout() {
         p.chs[l] = off;
         if (kVgg[l].conv) off += (size_t)kVgg[l].cout;
     }
+    p.spread = off; off += 32;
     p.scratch = off; off += (size_t)512 * 512 * 9 * 3;
     p.total = off;
     return p;
@@ -369,15 +371,31 @@ static VggPacked vgg_packed_layout() {
 // the reference's product bit for bit (powers of two).  Where Z+ == 0 the reference divides by 1e-7 (utils.py:16-18); there every
 // product x_i W+[c,i] of the window is zero, so the value of S at such a pixel never reaches R_in, scaled or not.
 __global__ __launch_bounds__(512) void row_scale_kernel(const float* __restrict__ w, int cout, int per_row, int use_abs,
-                                                        float* __restrict__ rs) {
+                                                        float* __restrict__ rs, float* __restrict__ spread) {
     __shared__ float sh[512];
+    __shared__ float sa[512];
     const int c = threadIdx.x;
-    float m = 0.f;
+    float m = 0.f, ma = 0.f;
     if (c < cout)
         for (int j = 0; j < per_row; ++j) {
             const float x = w[(long)c * per_row + j];
             m = fmaxf(m, use_abs ? fabsf(x) : fmaxf(x, 0.f));
+            ma = fmaxf(ma, fabsf(x));
         }
+    // spread of the PLAIN weights' row maxima inside a 16-row K slice (the block the fp6 cross-term operands share one scale over):
+    // what the image-gradient chains' mode-3 kernels are sensitive to (they multiply with W itself, rows unbalanced)
+    sa[c] = c < cout ? ma : 0.f;
+    __syncthreads();
+    if (c == 0) {
+        float worst = 1.f;
+        for (int g0 = 0; g0 < cout; g0 += 16) {
+            float hi = 0.f, lo = 3.0e38f;
+            for (int k = g0; k < min(g0 + 16, cout); ++k) { hi = fmaxf(hi, sa[k]); if (sa[k] > 0.f) lo = fminf(lo, sa[k]); }
+            if (hi > 0.f && lo < 3.0e38f) worst = fmaxf(worst, hi / lo);
+        }
+        *spread = worst;
+    }
+    __syncthreads();
     // d = 2^floor(log2 m) for a normal m (the exponent field alone); 0 for rows without a usable weight
     const unsigned eb = __float_as_uint(m) & 0x7f800000u;
     const float d = (eb != 0u && eb != 0x7f800000u) ? __uint_as_float(eb) : 0.f;
@@ -519,7 +537,7 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
         float* wr = base + p.scratch;
         float* wd = wr + (size_t)L.cout * L.cin * 9;
         const int first = l == 0, cin2 = first ? 2 * L.cin : L.cin;
-        hipLaunchKernelGGL(row_scale_kernel, dim3(1), dim3(512), 0, st, w[ci], L.cout, L.cin * 9, first, rs);
+        hipLaunchKernelGGL(row_scale_kernel, dim3(1), dim3(512), 0, st, w[ci], L.cout, L.cin * 9, first, rs, base + p.spread + l);
         LRPX_TRY(check_launch("vgg16_pack: row scales"));
         const long n_w = (long)L.cout * L.cin * 9, n_d = (long)2 * L.cout * cin2 * 9;
         hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, w[ci], rs, wr, L.cin * 9, n_w);
@@ -599,6 +617,10 @@ int lrpx_vgg16_trace_layout(int n_img, size_t* act_off, size_t* zpos_off) {
 
 const float* lrpx_vgg16_trace_features(const void* trace, int n_img) {
     return (const float*)trace + vgg_trace_layout(n_img).act[kNL];
+}
+
+const float* lrpx_vgg16_row_spread(const void* packed) {
+    return packed ? (const float*)packed + vgg_packed_layout().spread : nullptr;
 }
 
 const float* lrpx_vgg16_channel_scales(const void* packed, int layer, int* n_channels) {

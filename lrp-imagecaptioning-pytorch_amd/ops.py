@@ -291,6 +291,12 @@ class Vgg16:
         bp = (C.c_void_p * 13)(*[b.data_ptr() for b in bs])
         check(lib.lrpx_vgg16_pack(wp, bp, ptr(self.packed), stream_ptr()))
         torch.cuda.current_stream().synchronize()   # ws/bs may be temporaries
+        # the image-gradient chains in conv mode 3 keep the 1e-4 grade only while the rows of a 16-row weight slice stay within ~2^6 of
+        # each other (lrpx_vgg16_row_spread, include/lrpx.h): beyond that this context runs them on the fp16 split products (mode 2)
+        off = (lib.lrpx_vgg16_row_spread(ptr(self.packed)) - self.packed.data_ptr()) // 4
+        spread = self.packed[off: off + 17].cpu()
+        self.row_spread = float(max(spread[l] for l in range(17) if self.IS_CONV[l] and l > 0))
+        self.grad_mode2 = self.row_spread > self.GRAD_SPREAD_MAX
         self.trace = None
         self.n_img = 0
         self._ws = None
@@ -299,9 +305,16 @@ class Vgg16:
         self.conv_mode = None
         self.forward_f16 = None
 
-    def _opts(self, layer_ms=None):
+    GRAD_SPREAD_MAX = 64.0
+
+    def _opts(self, layer_ms=None, grad=False):
         o = _lib.VggOpts()
         o.conv_mode = -1 if self.conv_mode is None else int(self.conv_mode)
+        if grad and self.grad_mode2:
+            cm, ff = C.c_int(0), C.c_int(0)
+            check(_lib.load().lrpx_vgg16_resolve_opts(C.byref(o), C.byref(cm), C.byref(ff)))
+            if cm.value == 3:
+                o.conv_mode = 2
         o.forward_f16 = -1 if self.forward_f16 is None else int(self.forward_f16)
         o.layer_ms = layer_ms
         return C.byref(o)
@@ -387,7 +400,7 @@ class Vgg16:
         if out is None:
             out = torch.empty(n_maps, 3, 224, 224, dtype=torch.float32, device=self.device)
         check(getattr(lib, _fn)(ptr(self.packed), ptr(self.trace), self.n_img, ptr(d_feat_nhwc.contiguous()),
-                                ptr(map2img), n_maps, ptr(self._ws), ptr(out), self._opts(), stream_ptr()))
+                                ptr(map2img), n_maps, ptr(self._ws), ptr(out), self._opts(grad=True), stream_ptr()))
         return out
 
     def relevance(self, r_feat_nhwc, map2img=None, out=None, streams=1, layer_ms=None):

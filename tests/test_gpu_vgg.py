@@ -340,6 +340,7 @@ def gridtd_case(ops):
 def test_vgg_forward_vs_reference_features(ops, gridtd_case):
     g, sd, img = gridtd_case
     vgg = _vgg(ops, sd)
+    assert not vgg.grad_mode2 and 1.0 <= vgg.row_spread < 8.0      # kaiming-normal rows: the gradient chains keep conv mode 3
     feats = vgg.forward(img.cuda())
     torch.cuda.synchronize()
     got = from_nhwc(feats.cpu(), 512, 14, 14)
@@ -1027,7 +1028,13 @@ def test_chain_hostile_weights_all_modes(ops, gridtd_case, family, sigma, dead_f
     for (mode, fam), (e, k) in worst.items():
         assert e < TOL, (family, "oracle", mode, fam, e, k)
     # ---- the image-gradient chains (guided backprop / plain gradient: models/gridTDmodel.py:1677-1723, :1507-1521) on the same weights
-    # and trace: their split-product kernels take W itself (no Z+ side), scaled per layer; first map of every relevance family
+    # and trace: their split-product kernels take W itself (no Z+ side), scaled per layer; first map of every relevance family.
+    # In conv mode 3 their fp6 cross-term fields share one scale per 16-row weight slice: rows 2^25 apart (sigma = 2.5) lose the cross
+    # terms of the small rows - 1.1e-4 measured.  ops.Vgg16 reads the slices' spread from the pack (lrpx_vgg16_row_spread) and runs
+    # these chains on the fp16 split products (mode 2) beyond a ratio of 64: "mode 3" below is what a caller in the default mode gets
+    print(f"[{family}] largest row-maximum ratio inside a 16-row weight slice: {vgg.row_spread:.3g} -> gradient chains "
+          f"{'fall back to conv mode 2' if vgg.grad_mode2 else 'run in the requested mode'}")
+    assert vgg.grad_mode2 == (vgg.row_spread > vgg.GRAD_SPREAD_MAX) and (family != "wide channel scales" or vgg.grad_mode2)
     picks = [names.index(f) for f in ("heavy", "scaled", "sparse", "reference")]
     d_feat = r_feat[picks].contiguous()
     m2p = m2i[picks].contiguous()
