@@ -244,6 +244,18 @@ def ptr_at(t, offset_elems=0):
     return C.c_void_p(t.data_ptr() + 4 * offset_elems)
 
 
+_raw_stream = None
+
+
 def stream_ptr():
+    """the current HIP stream of the current device as a void* (torch owns the streams).  `torch.cuda.current_stream()` builds a
+    Stream object through three Python layers (~3 us, ~20 times per decoder step); the raw getter of the same value is ~0.3 us."""
+    global _raw_stream
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is None:
+        get_raw, get_dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if get_raw is not None and get_dev is not None:
+            _raw_stream = lambda: get_raw(get_dev())
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return C.c_void_p(_raw_stream())
