@@ -360,11 +360,30 @@ typedef struct lrpx_gridtd_relstate {
     float* wacc;                        /* [B*T][T][H] */
     float* r_words;                     /* [B*T][T] */
 } lrpx_gridtd_relstate;
+/* decoder steps t0 <= t < t1 of get_hidden_parameters (models/gridTDmodel.py:952-1012) in ONE call - fwd_pre, the AdaLSTM gate linear,
+ * its cell + sentinel, the adaptive attention, the LanguageLSTM linear, its cell - the `for t in range(...)` loop with its host side in
+ * native code (the same launches as the per-step entry points: bit-identical) */
+typedef struct lrpx_gridtd_step_args {
+    const float *glob, *emb;            /* relu(global_img_feature_proj(avg)) [B][E], embedding table */
+    const long long* tok; int tok_ld;   /* token ids [B][tok_ld] */
+    const float *w_cat1, *b_cat1;       /* [AdaLSTM W_ih | W_hh ; x_gate | h_gate] (5H x (2E+2H)) and bias */
+    const float *w_cat2, *b_cat2;       /* LanguageLSTM [W_ih | W_hh] (4H x 3H) and its bias (the explainers' quirk or the model's) */
+    const float *Vp, *att_img;          /* relu(img_projector(features)) [B][P][H]; W_v_proj(Vp) + b [B][P][P] */
+    const float *Wg, *Ws, *bs, *wh;     /* AdaAttention W_g_proj, W_s_proj (+ bias), w_h */
+    float *zz1, *zz2, *att_scratch;     /* scratch [B][5H], [B][4H], [B][3P] */
+} lrpx_gridtd_step_args;
+int lrpx_gridtd_fwd_steps(const lrpx_gridtd_trace* tr, int t0, int t1, const lrpx_gridtd_step_args* a, void* stream);
+
 int lrpx_gridtd_rel_init(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* fcw,
                          const float* logit, const long long* tok, int tok_ld, void* stream);
 /* lock-step s, phase 0: LanguageLSTM cell split (:1061-1069) -> A ; 1: after its dense rule (:1074-1105) -> A ;
  * 2: after the AdaLSTM dense rule (:1110-1115) */
 int lrpx_gridtd_rel_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, int s, int phase, void* stream);
+/* lock-steps 0 <= s < n_steps of explain_caption_wordt's `for i in range(t+1)[::-1]` (models/gridTDmodel.py:1060-1113) in ONE call: phase 0,
+ * the LanguageLSTM dense rule `dense2`, phase 1, the AdaLSTM dense rule `dense1`, phase 2 (lrpx_conv_mfma descriptors whose map2img is
+ * replaced by idx + s * idx_ld: row -> source row of the multiplicand at lock-step s) */
+int lrpx_gridtd_rel_steps(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, int n_steps, const lrpx_conv_desc* dense2,
+                          const lrpx_conv_desc* dense1, const int32_t* idx, int idx_ld, void* stream);
 int lrpx_gridtd_rel_glob(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* glob_pre,
                          float* a_glob, void* stream);
 int lrpx_rel_avg_u(const float* r_avg, const float* avg, float* u, int rows, int T, int C, int P, void* stream);

@@ -48,6 +48,12 @@ class AoaStepArgs(C.Structure):
         "w_cat", "b_cat", "w_cat_il", "b_cat_il", "w_qg", "b_qg", "w_lin", "b_lin", "key", "value", "zz", "qg", "lin")]
 
 
+class GridStepArgs(C.Structure):
+    """lrpx_gridtd_step_args"""
+    _fields_ = [("glob", _f), ("emb", _f), ("tok", _f), ("tok_ld", _i)] + [(k, _f) for k in (
+        "w_cat1", "b_cat1", "w_cat2", "b_cat2", "Vp", "att_img", "Wg", "Ws", "bs", "wh", "zz1", "zz2", "att_scratch")]
+
+
 class AoaGradState(C.Structure):
     _fields_ = [(k, _f) for k in ("lens", "d_h", "d_c", "dA", "dB", "gates", "dx", "d_glob", "r_words")]
 
@@ -133,6 +139,8 @@ SIGNATURES = {
     "lrpx_lrp_reweight_rows": (_i, [_f, _l, _i, _f, _l, _f, _l, _f, _f, _f, _i, _i, _i, _f]),
     "lrpx_argmax_logprob_rows": (_i, [_f, _l, _i, _i, _f, _f, _f]),
     "lrpx_gridtd_fwd_attention": (_i, [C.POINTER(GridTrace), _i, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "lrpx_gridtd_fwd_steps": (_i, [C.POINTER(GridTrace), _i, _i, C.POINTER(GridStepArgs), _f]),
+    "lrpx_gridtd_rel_steps": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _i, C.POINTER(ConvDesc), C.POINTER(ConvDesc), _f, _i, _f]),
     "lrpx_gridtd_rel_init": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f, _i, _f]),
     "lrpx_gridtd_rel_step": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _i, _i, _f]),
     "lrpx_gridtd_rel_glob": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f]),

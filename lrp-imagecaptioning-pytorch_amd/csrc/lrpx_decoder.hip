@@ -1967,6 +1967,42 @@ int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, in
     return LRPX_OK;
 }
 
+// ---- the host loops of the gridTD decoder in native code (round 5; as lrpx_aoa_fwd_steps / lrpx_aoa_rel_steps for the AoA decoder): every
+// launch is one of the entry points above, what goes away is the interpreter between them (~4 us per call through ctypes against ~1.5 us
+// from here): 7 x T + 5 x T calls per explanation - a third of the 5 ms one image costs through the drop-in class
+int lrpx_gridtd_fwd_steps(const lrpx_gridtd_trace* tr, int t0, int t1, const lrpx_gridtd_step_args* a, void* stream) {
+    LRPX_TRY(check_trace(tr));
+    LRPX_REQUIRE(a && a->glob && a->emb && a->tok && a->w_cat1 && a->b_cat1 && a->w_cat2 && a->b_cat2 && a->Vp && a->att_img && a->Wg &&
+                     a->Ws && a->bs && a->wh && a->zz1 && a->zz2 && a->att_scratch && t0 >= 0 && t0 <= t1 && t1 <= tr->T,
+                 "gridtd_fwd_steps: bad arguments");
+    const int B = tr->B, T = tr->T, H = tr->H, E = tr->E, W1 = 2 * E + 2 * H;
+    for (int t = t0; t < t1; ++t) {
+        LRPX_TRY(lrpx_gridtd_fwd_pre(tr, t, a->glob, a->emb, a->tok, a->tok_ld, stream));
+        LRPX_TRY(lrpx_linear_small(tr->xh1 + (long)t * W1, (long)T * W1, a->w_cat1, a->b_cat1, a->zz1, 5 * H, B, W1, 5 * H, 0, stream));
+        LRPX_TRY(lrpx_gridtd_fwd_lstm(tr, t, a->zz1, 5 * H, 1, stream));
+        LRPX_TRY(lrpx_gridtd_fwd_attention(tr, t, a->Vp, a->att_img, a->Wg, a->Ws, a->bs, a->wh, a->att_scratch, stream));
+        LRPX_TRY(lrpx_linear_small(tr->xh2 + (long)t * 3 * H, (long)T * 3 * H, a->w_cat2, a->b_cat2, a->zz2, 4 * H, B, 3 * H, 4 * H, 0, stream));
+        LRPX_TRY(lrpx_gridtd_fwd_lstm(tr, t, a->zz2, 4 * H, 2, stream));
+    }
+    return LRPX_OK;
+}
+
+int lrpx_gridtd_rel_steps(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, int n_steps, const lrpx_conv_desc* dense2,
+                          const lrpx_conv_desc* dense1, const int32_t* idx, int idx_ld, void* stream) {
+    LRPX_TRY(check_rel(tr, rs));
+    LRPX_REQUIRE(dense1 && dense2 && idx && n_steps >= 0 && n_steps <= tr->T && idx_ld >= tr->B * tr->T, "gridtd_rel_steps: bad arguments");
+    lrpx_conv_desc d2 = *dense2, d1 = *dense1;
+    for (int s = 0; s < n_steps; ++s) {
+        d2.map2img = d1.map2img = idx + (long)s * idx_ld;      // row -> source row of the multiplicands at lock-step s
+        LRPX_TRY(lrpx_gridtd_rel_step(tr, rs, s, 0, stream));
+        LRPX_TRY(lrpx_conv_mfma(&d2, stream));
+        LRPX_TRY(lrpx_gridtd_rel_step(tr, rs, s, 1, stream));
+        LRPX_TRY(lrpx_conv_mfma(&d1, stream));
+        LRPX_TRY(lrpx_gridtd_rel_step(tr, rs, s, 2, stream));
+    }
+    return LRPX_OK;
+}
+
 int lrpx_aoa_rel_steps_fused(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const lrpx_conv_desc* dense, const int32_t* idx,
                              int idx_ld, float* a_alt, float* wpart, float* coef, void* stream) {
     LRPX_TRY(check_arel(tr, rs));

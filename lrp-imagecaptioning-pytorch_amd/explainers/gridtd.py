@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
-from .._lib import (EPI_PLAIN, EPI_REL, GridGradState, GridRelState, GridTrace, PACK_DENSE, PACK_DENSE_T, check, ptr,
+from .._lib import (EPI_PLAIN, EPI_REL, GridGradState, GridRelState, GridStepArgs, GridTrace, PACK_DENSE, PACK_DENSE_T, check, ptr,
                     ptr_at, stream_ptr)
 from .ragged import ragged
 
@@ -183,8 +183,17 @@ class GridTDEngine:
         captions = captions.contiguous()
         tr = self._alloc_trace(B, T, grad)
         model_bias = model_bias or grad
-        for t in range(T):
-            self._step(tr, enc, t, captions, model_bias)
+        # the T steps in one native call (lrpx_gridtd_fwd_steps: the launches of `_step`, its host loop in C)
+        H, P, dev = self.H, self.P, self.device
+        tr["_zz1"], tr["_zz2"], tr["_att_scr"] = torch.empty(B, 5 * H, device=dev), torch.empty(B, 4 * H, device=dev), torch.empty(B, 3 * P, device=dev)
+        sa, sd, aa = GridStepArgs(), self.sd, "AdaAttention."
+        sa.glob, sa.emb, sa.tok, sa.tok_ld = ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), captions.shape[1]
+        sa.w_cat1, sa.b_cat1, sa.w_cat2 = ptr(self.Wcat1), ptr(self.bcat1), ptr(self.Wcat2)
+        sa.b_cat2 = ptr(self.bcat2_model if model_bias else self.bcat2_explainer)
+        sa.Vp, sa.att_img = ptr(enc["Vp"]), ptr(enc["att_img"])
+        sa.Wg, sa.Ws, sa.bs, sa.wh = ptr(sd[aa + "W_g_proj.weight"]), ptr(sd[aa + "W_s_proj.weight"]), ptr(sd[aa + "W_s_proj.bias"]), ptr(sd[aa + "w_h.weight"])
+        sa.zz1, sa.zz2, sa.att_scratch = ptr(tr["_zz1"]), ptr(tr["_zz2"]), ptr(tr["_att_scr"])
+        check(lib.lrpx_gridtd_fwd_steps(C.byref(tr["_c"]), 0, T, C.byref(sa), stream_ptr()))
         tr["captions"] = captions
         tr["logit"] = torch.empty(B * T, device=self.device)
         check(lib.lrpx_target_logit(ptr(tr["hc"]), ptr(self.sd["fc.weight"]), ptr(self.sd["fc.bias"]), ptr(captions),
@@ -373,14 +382,12 @@ class GridTDEngine:
                                        T + 1, st))
         W1 = 2 * E + 2 * H
         f16 = 1 if self.lockstep_f16 else 0
-        for s in range(T):
-            check(lib.lrpx_gridtd_rel_step(ctr, crs, s, 0, st))
-            ops.conv_mfma(rs["A"], self.p_wg2_h if f16 else self.p_wg2, rows, 0, H, 3 * H, 1, EPI_REL, pix_per_map=1, oc_split=3 * H,
-                          x=tr["xh2"], map2img=idx[s], out0=rs["rx"], f16x3=f16)
-            check(lib.lrpx_gridtd_rel_step(ctr, crs, s, 1, st))
-            ops.conv_mfma(rs["A"], self.p_wg1_h if f16 else self.p_wg1, rows, 0, H, W1, 1, EPI_REL, pix_per_map=1, oc_split=W1,
-                          x=tr["xh1"], map2img=idx[s], out0=rs["rx"], f16x3=f16)
-            check(lib.lrpx_gridtd_rel_step(ctr, crs, s, 2, st))
+        # the T lock-steps in one native call (lrpx_gridtd_rel_steps): phase 0, LanguageLSTM dense rule, phase 1, AdaLSTM dense rule, phase 2
+        d2 = ops.conv_desc(rs["A"], self.p_wg2_h if f16 else self.p_wg2, rows, 0, H, 3 * H, 1, EPI_REL, pix_per_map=1, oc_split=3 * H,
+                           x=tr["xh2"], map2img=idx[0], out0=rs["rx"], f16x3=f16)
+        d1 = ops.conv_desc(rs["A"], self.p_wg1_h if f16 else self.p_wg1, rows, 0, H, W1, 1, EPI_REL, pix_per_map=1, oc_split=W1,
+                           x=tr["xh1"], map2img=idx[0], out0=rs["rx"], f16x3=f16)
+        check(lib.lrpx_gridtd_rel_steps(ctr, crs, T, C.byref(d2), C.byref(d1), ptr(idx), idx.shape[1], st))
         # global feature path (:1116-1124) and projector (:1125-1128)
         a_glob = e(rows, E)
         check(lib.lrpx_gridtd_rel_glob(ctr, crs, ptr(enc["glob_pre"]), ptr(a_glob), st))
