@@ -1027,7 +1027,20 @@ def test_chain_hostile_weights_all_modes(ops, gridtd_case, family, sigma, dead_f
         assert err.max().item() < TOL, (family, mode, err.max().item())
     for (mode, fam), (e, k) in worst.items():
         assert e < TOL, (family, "oracle", mode, fam, e, k)
-    # ---- the image-gradient chains (guided backprop / plain gradient: models/gridTDmodel.py:1677-1723, :1507-1521) on the same weights
+    # ---- end to end on these weights: the GPU's OWN forward trace (nothing injected) and the default chain against the oracle, modulo
+    # pool-winner flips between the two forwards (conftest.assert_close_modulo_pool_ties); the reference's decoder relevance as target
+    vgg2 = _vgg(ops, sd)
+    vgg2.forward(img_cpu.cuda())
+    ks = [names.index("reference"), names.index("reference") + 1]
+    e2e = vgg2.relevance(r_feat[ks].contiguous(), m2i[ks].contiguous()).cpu()
+    for j, k in enumerate(ks):
+        b = int(m2i[k])
+        want = O.vgg_lrp(sdt, [x[b:b + 1] for x in saved], from_nhwc(r_feat[k:k + 1].cpu(), 512, 14, 14))
+        # (sigma = 2.5, rows 2^25 apart: a flipped pool winner there moves more pixels above 1e-4 of the maximum - observed 1.1 % / 9.7e-4 /
+        # relative L2 4.7e-4 / cosine 0.9999999; the suite's default bounds for the other two families)
+        kw = dict(frac=3e-2) if family == "wide channel scales" else {}
+        assert_close_modulo_pool_ties(e2e[j:j + 1], want, what=(family, "end to end", k), **kw)
+
     # and trace: their split-product kernels take W itself (no Z+ side), scaled per layer; first map of every relevance family.
     # In conv mode 3 their fp6 cross-term fields share one scale per 16-row weight slice: rows 2^25 apart (sigma = 2.5) lose the cross
     # terms of the small rows - 1.1e-4 measured.  ops.Vgg16 reads the slices' spread from the pack (lrpx_vgg16_row_spread) and runs
