@@ -665,7 +665,7 @@ def run_config(a, dist, rank, world):
                 out["value_fp32_grade"] = out["roofline"]["modes"]["2"]["maps_per_s"]
                 out["value_fp32_grade_note"] = ("conv mode 2 (f16x3: every product to 2^-21, fp32 accumulate), same process, 6 timed steps; "
                                                 "`value` runs mode %d: %s" % (mode, MODE_DTYPE[mode]))
-        elif world == 1:
+        elif world == 1 and not has_vgg:
             # config 5: no CNN stage; HBM-bound projector / v_proj rules.  Algorithmic bytes per map: read F,
             # write R_feat, read the projected features: 3 x 36 x 2048 x 4 B = 0.9 MB (weights amortised over the batch)
             byts = 3.0 * 36 * 2048 * 4 * B * T
