@@ -441,10 +441,17 @@ int lrpx_aoa_fwd_steps(const lrpx_aoa_trace* tr, int t0, int t1, const lrpx_aoa_
 int lrpx_aoa_fwd_inputs(const lrpx_aoa_trace* tr, const float* glob, const float* emb, const long long* tok, int tok_ld,
                         float* xin, void* stream);
 int lrpx_aoa_fwd_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* zin, void* stream);
-int lrpx_aoa_fwd_gather_h(const lrpx_aoa_trace* tr, float* hn, void* stream);
+/* the same with the input part from tables instead of a GEMM per trace: the embedding part of x_t W_ih^T depends on the token alone -
+ * tab [V][4H] = embedding W_ie^T (interleaved gate order; once per MODEL), gimg [B][4H] = glob W_ig^T + bias (one small linear per
+ * trace): z = (W_hh h + tab[tok[b, t]]) + gimg[b].  xin of lrpx_aoa_fwd_inputs may then be null. */
+int lrpx_aoa_fwd_recurrence_tab(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* tab, const float* gimg,
+                                const long long* tok, int tok_ld, void* stream);
+/* hn_amax / ctx_amax / hc_amax (optional, [B*T] words): float bits of max|row| of hn / ctx / hc, recorded by the kernel that writes
+ * the row - the operand scales of the GEMMs that read it (ctx_amax must come zeroed: its 8 heads meet in an atomic maximum) */
+int lrpx_aoa_fwd_gather_h(const lrpx_aoa_trace* tr, float* hn, uint32_t* hn_amax, void* stream);
 int lrpx_aoa_fwd_attention_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* key, const float* value,
-                               void* stream);
-int lrpx_aoa_fwd_post_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* lin, void* stream);
+                               uint32_t* ctx_amax, void* stream);
+int lrpx_aoa_fwd_post_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* lin, uint32_t* hc_amax, void* stream);
 
 /* ---- AoA decoder: gradient explainers (ExplainAOAGradient.explain_caption_wordt, models/aoamodel.py:1435-1499;
  *      inherited unchanged by the guided / Grad-CAM variants) --------------------------------------------------- */

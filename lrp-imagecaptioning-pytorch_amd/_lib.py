@@ -154,9 +154,10 @@ SIGNATURES = {
     "lrpx_aoa_fwd_steps": (_i, [C.POINTER(AoaTrace), _i, _i, C.POINTER(AoaStepArgs), _f]),
     "lrpx_aoa_fwd_inputs": (_i, [C.POINTER(AoaTrace), _f, _f, _f, _i, _f, _f]),
     "lrpx_aoa_fwd_recurrence": (_i, [C.POINTER(AoaTrace), _f, _f, _f]),
-    "lrpx_aoa_fwd_gather_h": (_i, [C.POINTER(AoaTrace), _f, _f]),
-    "lrpx_aoa_fwd_attention_all": (_i, [C.POINTER(AoaTrace), _f, _i, _f, _f, _f]),
-    "lrpx_aoa_fwd_post_all": (_i, [C.POINTER(AoaTrace), _f, _i, _f, _f]),
+    "lrpx_aoa_fwd_recurrence_tab": (_i, [C.POINTER(AoaTrace), _f, _f, _f, _f, _i, _f]),
+    "lrpx_aoa_fwd_gather_h": (_i, [C.POINTER(AoaTrace), _f, _f, _f]),
+    "lrpx_aoa_fwd_attention_all": (_i, [C.POINTER(AoaTrace), _f, _i, _f, _f, _f, _f]),
+    "lrpx_aoa_fwd_post_all": (_i, [C.POINTER(AoaTrace), _f, _i, _f, _f, _f]),
     "lrpx_aoa_rel_init": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _f, _i, _f]),
     "lrpx_aoa_rel_value": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _i, _f, _f]),
     "lrpx_aoa_rel_step": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _i, _i, _f]),

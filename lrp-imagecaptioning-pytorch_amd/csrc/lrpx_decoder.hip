@@ -1060,15 +1060,19 @@ __global__ void aoa_fwd_inputs_kernel(AoaFwd g, const float* __restrict__ glob, 
     for (int c = threadIdx.x; c < EH; c += blockDim.x) {
         const float v = c < g.E ? emb[k * g.E + c] : glob[(long)b * g.H + (c - g.E)];
         dst[c] = v;
-        xin[(long)row * EH + c] = v;
+        if (xin) xin[(long)row * EH + c] = v;
     }
 }
 
 // z = zin[b, t] + W_hh h[b, t]  ->  LSTM cell (the point-wise code of aoa_fwd_lstm_kernel).  w: (4H, H), rows interleaved as in
 // aoa_linear_lstm_kernel; zin: [B*T][4H] in the same interleaved column order (bias included)
+// zin == null: the input part comes from a per-MODEL table instead of a per-step GEMM - the embedding part of x_t W_ih^T depends on the
+// token alone: tab[token] = emb[token] W_ie^T (V x 4H, computed once per engine), gimg[b] = glob[b] W_ig^T + bias (one small linear
+// per trace): z = (W_hh h + tab[tok[b, t]]) + gimg[b]
 template <int RT>
 __global__ __launch_bounds__(256) void aoa_rec_lstm_kernel(AoaFwd g, int t, const float* __restrict__ w,
-                                                           const float* __restrict__ zin) {
+                                                           const float* __restrict__ zin, const float* __restrict__ tab,
+                                                           const float* __restrict__ gimg, const long long* __restrict__ tok, int tok_ld) {
     __shared__ float red[4][RT][16][17];
     const int H = g.H;
     linear_mfma_core<RT>(g.h + (long)t * H, (long)(g.T + 1) * H, w, g.B, H, 4 * H, red);
@@ -1076,12 +1080,15 @@ __global__ __launch_bounds__(256) void aoa_rec_lstm_kernel(AoaFwd g, int t, cons
         const int r = e >> 6, row = (e >> 2) & 15, u = e & 3;
         const int b = r * 16 + row, c = blockIdx.x * 4 + u;
         if (b >= g.B || c >= H) continue;
-        const float* zi = zin + ((long)b * g.T + t) * 4 * H + blockIdx.x * 16;
+        const float* zi = zin ? zin + ((long)b * g.T + t) * 4 * H + blockIdx.x * 16
+                              : tab + (long)tok[(long)b * tok_ld + t] * 4 * H + blockIdx.x * 16;
+        const float* gi = zin ? nullptr : gimg + (long)b * 4 * H + blockIdx.x * 16;
         float z[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = 4 * q + u;
             z[q] = ((red[0][r][row][col] + red[1][r][row][col]) + (red[2][r][row][col] + red[3][r][row][col])) + zi[col];
+            if (gi) z[q] += gi[col];
         }
         const long st0 = ((long)b * (g.T + 1) + t) * H, st1 = st0 + H, tr = ((long)b * g.T + t) * H;
         const float i = sigmoidf_(z[0]), f = sigmoidf_(z[1]), zg = z[2], o = sigmoidf_(z[3]);
@@ -1093,18 +1100,27 @@ __global__ __launch_bounds__(256) void aoa_rec_lstm_kernel(AoaFwd g, int t, cons
 }
 
 // after the recurrence: hn[b, t] = h[b, t + 1] (contiguous rows for the q / gate GEMM), xh[b, t][E + H :] = h[b, t] (:1075)
-__global__ void aoa_fwd_gather_h_kernel(AoaFwd g, float* __restrict__ hn) {
+__global__ __launch_bounds__(256) void aoa_fwd_gather_h_kernel(AoaFwd g, float* __restrict__ hn, unsigned* __restrict__ hn_amax) {
+    __shared__ float red[8];
     const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, W = g.E + 2 * H;
     const long st0 = ((long)b * (g.T + 1) + t) * H;
-    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float m = 0.f;
+    for (int c = threadIdx.x; c < H; c += 256) {
         g.xh[(long)row * W + g.E + H + c] = g.h[st0 + c];
-        hn[(long)row * H + c] = g.h[st0 + H + c];
+        const float v = g.h[st0 + H + c];
+        hn[(long)row * H + c] = v;
+        m = fmaxf(m, fabsf(v));
+    }
+    if (hn_amax) {          // max|hn[row]|: the operand scale of the q / gate GEMM (what lrpx_amax_maps would read the row again for)
+        m = block_max(m, red);
+        if (threadIdx.x == 0) hn_amax[row] = __float_as_uint(m);
     }
 }
 
 // aoa_fwd_attention_kernel for every (image, word) row at once: block (row, head); qg: [B*T][ldq]
 __global__ __launch_bounds__(64) void aoa_fwd_attention_all_kernel(AoaFwd g, const float* __restrict__ qg, int ldq,
-                                                                   const float* __restrict__ key, const float* __restrict__ value) {
+                                                                   const float* __restrict__ key, const float* __restrict__ value,
+                                                                   unsigned* __restrict__ ctx_amax) {
     extern __shared__ float sm[];
     const int row = blockIdx.x, b = row / g.T, hd = blockIdx.y, H = g.H, P = g.P, dk = H / g.NH, tid = threadIdx.x;
     float* q = sm;          // dk
@@ -1128,23 +1144,38 @@ __global__ __launch_bounds__(64) void aoa_fwd_attention_all_kernel(AoaFwd g, con
     float* al = g.alpha + ((long)row * g.NH + hd) * P;
     for (int k = tid; k < P; k += 64) { const float a = expf(sc[k] - m) / denom; sc[k] = a; al[k] = a; }
     __syncthreads();
+    float mx = 0.f;
     for (int c = tid; c < dk; c += 64) {
         float a = 0.f;
         for (int k = 0; k < P; ++k) a += sc[k] * value[((long)b * P + k) * H + hd * dk + c];
         g.ctx[(long)row * H + hd * dk + c] = a;
+        mx = fmaxf(mx, fabsf(a));
+    }
+    if (ctx_amax) {         // max|ctx[row]| over the heads (zero-initialised by the caller; non-negative floats order like unsigned integers)
+        mx = wave_max(mx);
+        if (tid == 0) atomicMax(&ctx_amax[row], __float_as_uint(mx));
     }
 }
 
 // aoa_fwd_post_kernel for every row: lin [B*T][H] = decoder_aoa_linear(ctx), qg [B*T][ldq] (gate in the second half)
-__global__ void aoa_fwd_post_all_kernel(AoaFwd g, const float* __restrict__ qg, int ldq, const float* __restrict__ lin) {
+__global__ __launch_bounds__(256) void aoa_fwd_post_all_kernel(AoaFwd g, const float* __restrict__ qg, int ldq, const float* __restrict__ lin,
+                                                               unsigned* __restrict__ hc_amax) {
+    __shared__ float red[8];
     const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H;
     const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = (long)row * H;
-    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float m = 0.f;
+    for (int c = threadIdx.x; c < H; c += 256) {
         const float l = lin[tr + c];
         const float sgv = sigmoidf_(qg[(long)row * ldq + H + c]);
         const float ca = sgv * l;
-        g.lin[tr + c] = l; g.c_aoa[tr + c] = ca; g.hc[tr + c] = ca + g.h[st1 + c];
+        const float hcv = ca + g.h[st1 + c];
+        g.lin[tr + c] = l; g.c_aoa[tr + c] = ca; g.hc[tr + c] = hcv;
         if (g.sg) g.sg[tr + c] = sgv;
+        m = fmaxf(m, fabsf(hcv));
+    }
+    if (hc_amax) {          // max|hc[row]|: the operand scale of the (T, V) score GEMM
+        m = block_max(m, red);
+        if (threadIdx.x == 0) hc_amax[row] = __float_as_uint(m);
     }
 }
 
@@ -1901,49 +1932,61 @@ int lrpx_aoa_fwd_steps(const lrpx_aoa_trace* tr, int t0, int t1, const lrpx_aoa_
 int lrpx_aoa_fwd_inputs(const lrpx_aoa_trace* tr, const float* glob, const float* emb, const long long* tok, int tok_ld,
                         float* xin, void* stream) {
     LRPX_TRY(check_atrace(tr));
-    LRPX_REQUIRE(glob && emb && tok && xin, "aoa_fwd_inputs: null pointer");
+    LRPX_REQUIRE(glob && emb && tok, "aoa_fwd_inputs: null pointer");
     hipLaunchKernelGGL(aoa_fwd_inputs_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), glob, emb, tok,
                        tok_ld, xin);
     return check_launch("aoa_fwd_inputs");
 }
 
-int lrpx_aoa_fwd_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* zin, void* stream) {
-    LRPX_TRY(check_atrace(tr));
-    LRPX_REQUIRE(w_hh_il && zin && tr->B <= 64 && tr->H % 16 == 0, "aoa_fwd_recurrence: bad arguments (<= 64 images, H %% 16)");
+static int aoa_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* zin, const float* tab, const float* gimg,
+                          const long long* tok, int tok_ld, hipStream_t st) {
     const AoaFwd g = to_afwd(tr);
     const int H = tr->H, B = tr->B;
-    hipStream_t st = (hipStream_t)stream;
     for (int t = 0; t < tr->T; ++t) {
-        if (B <= 16) hipLaunchKernelGGL((aoa_rec_lstm_kernel<1>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin);
-        else if (B <= 32) hipLaunchKernelGGL((aoa_rec_lstm_kernel<2>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin);
-        else if (B <= 48) hipLaunchKernelGGL((aoa_rec_lstm_kernel<3>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin);
-        else hipLaunchKernelGGL((aoa_rec_lstm_kernel<4>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin);
+        if (B <= 16) hipLaunchKernelGGL((aoa_rec_lstm_kernel<1>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin, tab, gimg, tok, tok_ld);
+        else if (B <= 32) hipLaunchKernelGGL((aoa_rec_lstm_kernel<2>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin, tab, gimg, tok, tok_ld);
+        else if (B <= 48) hipLaunchKernelGGL((aoa_rec_lstm_kernel<3>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin, tab, gimg, tok, tok_ld);
+        else hipLaunchKernelGGL((aoa_rec_lstm_kernel<4>), dim3(4 * H / 16), dim3(256), 0, st, g, t, w_hh_il, zin, tab, gimg, tok, tok_ld);
         LRPX_TRY(check_launch("aoa_rec_lstm"));
     }
     return LRPX_OK;
 }
 
-int lrpx_aoa_fwd_gather_h(const lrpx_aoa_trace* tr, float* hn, void* stream) {
+int lrpx_aoa_fwd_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* zin, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(w_hh_il && zin && tr->B <= 64 && tr->H % 16 == 0, "aoa_fwd_recurrence: bad arguments (<= 64 images, H %% 16)");
+    return aoa_recurrence(tr, w_hh_il, zin, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+int lrpx_aoa_fwd_recurrence_tab(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* tab, const float* gimg,
+                                const long long* tok, int tok_ld, void* stream) {
+    LRPX_TRY(check_atrace(tr));
+    LRPX_REQUIRE(w_hh_il && tab && gimg && tok && tok_ld >= tr->T && tr->B <= 64 && tr->H % 16 == 0,
+                 "aoa_fwd_recurrence_tab: bad arguments (<= 64 images, H %% 16)");
+    return aoa_recurrence(tr, w_hh_il, nullptr, tab, gimg, tok, tok_ld, (hipStream_t)stream);
+}
+
+int lrpx_aoa_fwd_gather_h(const lrpx_aoa_trace* tr, float* hn, uint32_t* hn_amax, void* stream) {
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(hn, "aoa_fwd_gather_h: null pointer");
-    hipLaunchKernelGGL(aoa_fwd_gather_h_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), hn);
+    hipLaunchKernelGGL(aoa_fwd_gather_h_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), hn, hn_amax);
     return check_launch("aoa_fwd_gather_h");
 }
 
 int lrpx_aoa_fwd_attention_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* key, const float* value,
-                               void* stream) {
+                               uint32_t* ctx_amax, void* stream) {
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(qg && key && value && tr->H % tr->NH == 0, "aoa_fwd_attention_all: bad arguments");
     const size_t lds = (size_t)(tr->H / tr->NH + tr->P) * sizeof(float);
     hipLaunchKernelGGL(aoa_fwd_attention_all_kernel, dim3(tr->B * tr->T, tr->NH), dim3(64), lds, (hipStream_t)stream, to_afwd(tr), qg,
-                       ldq, key, value);
+                       ldq, key, value, ctx_amax);
     return check_launch("aoa_fwd_attention_all");
 }
 
-int lrpx_aoa_fwd_post_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* lin, void* stream) {
+int lrpx_aoa_fwd_post_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* lin, uint32_t* hc_amax, void* stream) {
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(qg && lin, "aoa_fwd_post_all: null pointer");
-    hipLaunchKernelGGL(aoa_fwd_post_all_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), qg, ldq, lin);
+    hipLaunchKernelGGL(aoa_fwd_post_all_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), qg, ldq, lin, hc_amax);
     return check_launch("aoa_fwd_post_all");
 }
 

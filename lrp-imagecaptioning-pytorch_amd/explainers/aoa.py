@@ -63,11 +63,20 @@ class AOAEngine:
         self.p_fc_fwd_h = ops.pack_weights_f16x2(sd["fc.weight"], self.V, H, _lib.PACK_FWD, taps=1) if H % 64 == 0 else None
         # plain GEMMs over all (image, word) rows of the decoupled trace: (pack for the fp16 split-product kernel, fp32 pack)
         self._plain = {}
+        self.tok_table = None
         if self.decoupled:
             for name, w in (("ih", self.W_ih_il), ("qg", self.Wqg), ("lin", sd["decoder_aoa_linear.weight"])):
                 n, k = w.shape
                 self._plain[name] = (ops.pack_weights_f16x2(w, n, k, _lib.PACK_FWD, taps=1) if k % 64 == 0 else None,
                                      ops.pack_weights(w, n, k, 1, PACK_DENSE, kc), n, k)
+            # The embedding part of the gate pre-activations depends on the TOKEN alone: tok_table[v] = embedding[v] W_ie^T (V x 4H, once per
+            # model, exact fp32 products on the fp32 matrix cores); the image part is one small linear per trace (W_ig, bias).  The trace then
+            # needs no GEMM over its B*T rows for the LSTM input at all (lrpx_aoa_fwd_recurrence_tab).
+            w_ie = self.W_ih_il[:, :E].contiguous()
+            self.W_ig_il = self.W_ih_il[:, E:].contiguous()
+            self.tok_table = torch.empty(self.V, 4 * H, device=self.device)
+            ops.conv_mfma(sd["embedding.weight"], ops.pack_weights(w_ie, 4 * H, E, 1, PACK_DENSE, kc), self.V, 0, E, 4 * H, 1, EPI_PLAIN,
+                          pix_per_map=1, oc_split=4 * H, out0=self.tok_table)
         wg = torch.cat([sd[l + "weight_ih"][2 * H:3 * H], sd[l + "weight_hh"][2 * H:3 * H]], 1).contiguous()
         self.p_wg = ops.pack_weights(wg, H, E + 2 * H, 1, PACK_DENSE_T, kc)
         self.p_lin_rel = ops.pack_weights(sd["decoder_aoa_linear.weight"], H, H, 1, PACK_DENSE_T, kc)
@@ -127,6 +136,7 @@ class AOAEngine:
             shapes[k] = (B, T, H)
         if grad:      # the gradient explainers also keep the output gate and sigmoid(aoa gate)  (:1309-1376)
             shapes["o"], shapes["sg"] = (B, T, H), (B, T, H)
+        shapes["_amax"] = (3, B * T)      # row maxima (float bits) the decoupled trace records for its GEMMs' operand scales
         tr = dict(B=B, T=T, P=P)
         tr.update(ops.zeros_arena(dev, shapes))            # one allocation, one fill
         c = AoaTrace()
@@ -249,7 +259,7 @@ class AOAEngine:
             wpreds[:, t] = self.logits(hcw)
         return preds, wpreds, L
 
-    def _plain_rows(self, x, name, bias):
+    def _plain_rows(self, x, name, bias, amax=None):
         """x (R, K) @ W^T + bias -> (R, N) for one of the trace's plain linears over all (image, word) rows: split products on the
         fp16 matrix cores (as `logits(fast=True)`: <= 2e-7 of a row's maximum; operand scale per ROW), the fp32 MFMA kernel where K is
         no multiple of 64.  The kernel never depends on the number of rows: an image's trace is the same in every batch."""
@@ -258,7 +268,7 @@ class AOAEngine:
         out = torch.empty(R, n, device=self.device)
         if p_h is not None:
             ops.conv_mfma(x, p_h, R, 0, k, -(-n // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=n, bias=bias, out0=out, f16x3=1,
-                          in_amax=ops.amax_maps(x, R))
+                          in_amax=amax if amax is not None else ops.amax_maps(x, R))      # (amax: recorded by the kernel that wrote x)
         else:
             ops.conv_mfma(x, p_f, R, 0, k, -(-n // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=n, bias=bias, out0=out)
         return out
@@ -273,16 +283,18 @@ class AOAEngine:
         R = B * T
         c = C.byref(tr["_c"])
         sd = self.sd
-        xin = torch.empty(R, E + H, device=self.device)
-        check(lib.lrpx_aoa_fwd_inputs(c, ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), captions.shape[1], ptr(xin), st))
-        zin = self._plain_rows(xin, "ih", self.bcat_model_il if model_bias else self.bcat_explainer_il)
-        check(lib.lrpx_aoa_fwd_recurrence(c, ptr(self.W_hh_il), ptr(zin), st))
+        check(lib.lrpx_aoa_fwd_inputs(c, ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), captions.shape[1], None, st))
+        bias_il = self.bcat_model_il if model_bias else self.bcat_explainer_il
+        gimg = torch.empty(B, 4 * H, device=self.device)                     # glob W_ig^T + bias: the image part of every step's z
+        check(lib.lrpx_linear_small(ptr(enc["glob"]), H, ptr(self.W_ig_il), ptr(bias_il), ptr(gimg), 4 * H, B, H, 4 * H, 0, st))
+        check(lib.lrpx_aoa_fwd_recurrence_tab(c, ptr(self.W_hh_il), ptr(self.tok_table), ptr(gimg), ptr(captions), captions.shape[1], st))
         hn = torch.empty(R, H, device=self.device)
-        check(lib.lrpx_aoa_fwd_gather_h(c, ptr(hn), st))
-        qg = self._plain_rows(hn, "qg", self.bqg)
-        check(lib.lrpx_aoa_fwd_attention_all(c, ptr(qg), 2 * H, ptr(enc["key"]), ptr(enc["value"]), st))
-        lin = self._plain_rows(tr["ctx"].view(R, H), "lin", sd["decoder_aoa_linear.bias"])
-        check(lib.lrpx_aoa_fwd_post_all(c, ptr(qg), 2 * H, ptr(lin), st))
+        am = tr["_amax"].view(torch.int32)                                    # [3][R] row maxima of hn / ctx / hc (ctx: zeroed with the trace)
+        check(lib.lrpx_aoa_fwd_gather_h(c, ptr(hn), ptr(am[0]), st))
+        qg = self._plain_rows(hn, "qg", self.bqg, amax=am[0])
+        check(lib.lrpx_aoa_fwd_attention_all(c, ptr(qg), 2 * H, ptr(enc["key"]), ptr(enc["value"]), ptr(am[1]), st))
+        lin = self._plain_rows(tr["ctx"].view(R, H), "lin", sd["decoder_aoa_linear.bias"], amax=am[1])
+        check(lib.lrpx_aoa_fwd_post_all(c, ptr(qg), 2 * H, ptr(lin), ptr(am[2]), st))
 
     def trace(self, enc, captions, model_bias=False, predictions=True, grad=False):
         """grad=True: the trace of the gradient explainers (:1309-1376): correct LSTM bias, output gate and aoa gate kept."""
@@ -304,7 +316,7 @@ class AOAEngine:
             check(lib.lrpx_target_logit(ptr(tr["hc"]), ptr(sd["fc.weight"]), ptr(sd["fc.bias"]), ptr(captions), T + 1,
                                         ptr(tr["logit"]), B, T, H, st))
             if predictions:
-                tr["pred"] = self.logits(tr["hc"].view(B * T, H), fast=True).view(B, T, self.V)
+                tr["pred"] = self.logits(tr["hc"].view(B * T, H), fast=True, amax=tr["_amax"].view(torch.int32)[2]).view(B, T, self.V)
             return tr
         # the T decoder steps (:1019-1052) in one native call (the host loop of `_step` in C: the bottom-up path is bound by the
         # launch rate of the interpreter otherwise)
@@ -411,7 +423,7 @@ class AOAEngine:
             out = out + (d_feat.view(B, T, enc["P"], self.C), tr, enc)
         return out
 
-    def logits(self, hc_rows, fast=False):
+    def logits(self, hc_rows, fast=False, amax=None):
         """fc scores for R rows -> (R,V).  fast=True (the (T,V) block a trace keeps, not the decisions of a decoding loop): split
         products on the fp16 matrix cores (csrc/dense_f16x3.hip, fp32-grade: <= 2e-7 of a row's maximum)"""
         R = hc_rows.shape[0]
@@ -419,7 +431,7 @@ class AOAEngine:
         if fast and R >= 128 and self.p_fc_fwd_h is not None:
             hc_rows = hc_rows.contiguous()
             ops.conv_mfma(hc_rows, self.p_fc_fwd_h, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=self.V,
-                          bias=self.sd["fc.bias"], out0=out, f16x3=1, in_amax=ops.amax_maps(hc_rows, R))
+                          bias=self.sd["fc.bias"], out0=out, f16x3=1, in_amax=amax if amax is not None else ops.amax_maps(hc_rows, R))
             return out
         ops.conv_mfma(hc_rows, self.p_fc_fwd, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1,
                       oc_split=self.V, bias=self.sd["fc.bias"], out0=out)
