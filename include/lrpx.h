@@ -490,6 +490,12 @@ int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, co
                        int head, float* a_val, void* stream);
 int lrpx_aoa_rel_value_rows(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
                             int head, float* a_val, const int32_t* rows, int n_rows, void* stream);   /* compact a_val */
+/* the same, only the head's H / NH non-zero columns: a_val_head [n_rows][P][H/NH] (rows = null: all B*T rows).  `lrp_mha` passes
+ * relevance through ONE head (models/aoamodel.py:848-860), so the v_proj rule behind it contracts over that head's H/NH rows of W_v
+ * (lrpx_pack_weights_f16x2 of the row slice) instead of over H with zeros in 7/8 of the operand: an eighth of the matrix work and of
+ * the operand traffic, the same products in the same order (bit-identical). */
+int lrpx_aoa_rel_value_head(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
+                            int head, float* a_val_head, const int32_t* rows, int n_rows, void* stream);
 /* lock-step s: phase 0 g-gate split (:1116-1120) -> A ; phase 1 after the LSTM dense rule (:1129-1133) */
 int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int s, int phase, void* stream);
 /* lock-steps 0 <= s < n_steps of explain_caption_wordt's `for i in range(t+1)[::-1]` (models/aoamodel.py:1114-1134) in ONE

@@ -121,6 +121,7 @@ SIGNATURES = {
     "lrpx_gather_rows": (_i, [_f, _f, _f, _i, _i, _f]),
     "lrpx_gridtd_rel_pix_rows": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f, _f, _i, _f]),
     "lrpx_aoa_rel_value_rows": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _i, _f, _f, _i, _f]),
+    "lrpx_aoa_rel_value_head": (_i, [C.POINTER(AoaTrace), C.POINTER(AoaRelState), _f, _f, _i, _f, _f, _i, _f]),
     "lrpx_aoa_grad_pix_rows": (_i, [C.POINTER(AoaTrace), _i, _f, _f, _f, _i, _f, _i, _f]),
     "lrpx_spread_pixels_rows": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f, _i, _f]),
     "lrpx_accumulate": (_i, [_f, _f, _l, _f]),

@@ -1307,12 +1307,27 @@ __global__ void aoa_rel_init_kernel(AoaRel g, const float* __restrict__ fcw, con
 // `head`, 0 elsewhere — the prologue of the v_proj dense rule (:1141-1144).  r_ctx: [rows][H]
 __global__ __launch_bounds__(256) void aoa_rel_value_kernel(AoaRel g, const float* __restrict__ r_ctx,
                                                             const float* __restrict__ value, int head,
-                                                            float* __restrict__ Aval, const int* __restrict__ rowlist) {
+                                                            float* __restrict__ Aval, const int* __restrict__ rowlist, int head_only) {
     const int row = rowlist ? rowlist[blockIdx.x] : blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, P = g.P, dk = H / g.NH;
     const long orow = blockIdx.x;
     const int len = g.lens ? g.lens[b] : g.T;
     const bool act = t < len;
     const float* al = g.alpha + (((long)b * g.T + t) * g.NH + head) * P;
+    if (head_only) {
+        // only the head's dk columns are non-zero: Aval [rows][P][dk] - the v_proj rule then contracts over K = dk with the head's
+        // dk rows of W_v instead of K = H with zeros in 7/8 of the operand (the same products in the same order: bit-identical)
+        for (int j = threadIdx.x; j < P * dk; j += 256) {
+            const int k = j / dk, c = head * dk + (j - k * dk);
+            float v = 0.f;
+            if (act) {
+                const float val = value[((long)b * P + k) * H + c];
+                const float rv = eps_id(r_ctx[(long)row * H + c], val * al[k], g.ctx[(long)row * H + c]);
+                v = rv / stab_eps(val);
+            }
+            Aval[(orow * P + k) * dk + (c - head * dk)] = v;
+        }
+        return;
+    }
     for (int j = threadIdx.x; j < P * H; j += 256) {
         const int k = j / H, c = j - k * H;
         float v = 0.f;
@@ -1863,8 +1878,18 @@ int lrpx_aoa_rel_value_rows(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* r
     LRPX_REQUIRE(r_ctx && value && a_val && head >= 0 && head < tr->NH, "aoa_rel_value: bad arguments");
     LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= tr->B * tr->T) : n_rows == tr->B * tr->T, "aoa_rel_value: bad row list");
     hipLaunchKernelGGL(aoa_rel_value_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, to_arel(tr, rs),
-                       r_ctx, value, head, a_val, rows);
+                       r_ctx, value, head, a_val, rows, 0);
     return check_launch("aoa_rel_value");
+}
+
+int lrpx_aoa_rel_value_head(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
+                            int head, float* a_val_head, const int32_t* rows, int n_rows, void* stream) {
+    LRPX_TRY(check_arel(tr, rs));
+    LRPX_REQUIRE(r_ctx && value && a_val_head && head >= 0 && head < tr->NH && tr->H % tr->NH == 0, "aoa_rel_value_head: bad arguments");
+    LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= tr->B * tr->T) : n_rows == tr->B * tr->T, "aoa_rel_value_head: bad row list");
+    hipLaunchKernelGGL(aoa_rel_value_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, to_arel(tr, rs),
+                       r_ctx, value, head, a_val_head, rows, 1);
+    return check_launch("aoa_rel_value_head");
 }
 
 int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,

@@ -85,9 +85,15 @@ class AOAEngine:
         # the v_proj / projector rules run over every (word, pixel) row: split products on the fp16 matrix cores
         # (csrc/dense_f16x3.hip)
         self.p_v_rel_h = self.p_proj_rel_h = None
+        self.p_v_rel_head = None
         if H % 64 == 0:
             self.p_v_rel_h = ops.pack_weights_f16x2(sd["decoder_v_proj.weight"], H, H, _lib.PACK_BWD_PLAIN, taps=1)
             self.p_proj_rel_h = ops.pack_weights_f16x2(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1)
+            dk = H // self.NH
+            if dk % 64 == 0:      # `lrp_mha` passes one head: the v_proj rule contracts over that head's dk rows of W_v only
+                self.p_v_rel_head = [ops.pack_weights_f16x2(sd["decoder_v_proj.weight"][h * dk:(h + 1) * dk].contiguous(), dk, H,
+                                                            _lib.PACK_BWD_PLAIN, taps=1) for h in range(self.NH)]
+        self.head_only = True            # (False: the v_proj rule over all H columns, 7/8 of them zero; A/B and tests)
         # ... and the lock-step gate rule / the aoa_linear rule (rows = images x words): the few-row kernel of the same file
         self.fused_steps = True          # decoder steps as 4 launches instead of 7 (False: the unfused kernels; A/B and tests)
         self.fused_rel = True            # relevance lock-steps as ONE launch each (False: GEMM + point-wise kernel; A/B and tests)
@@ -495,13 +501,20 @@ class AOAEngine:
             if n == 0:
                 return e(0, P, Cc), rs["r_words"], row2img
             U = ops.gather_rows(U, rowlist)
-        a_val = e(n, P, H)
-        check(lib.lrpx_aoa_rel_value_rows(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), ptr(rowlist), n, st))
         a_proj = e(n, P, H)
         r_feat = e(n, P, Cc)
+        head_only = self.head_only and self.p_v_rel_head is not None and P >= 32
+        if head_only:
+            dk = H // self.NH
+            a_val = e(n, P, dk)
+            check(lib.lrpx_aoa_rel_value_head(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), ptr(rowlist), n, st))
+        else:
+            a_val = e(n, P, H)
+            check(lib.lrpx_aoa_rel_value_rows(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), ptr(rowlist), n, st))
         if self.p_v_rel_h is not None and P >= 32:
             amax2 = torch.zeros(n, dtype=torch.int32, device=self.device)         # max|a_proj| per row: recorded by the first GEMM
-            ops.conv_mfma(a_val, self.p_v_rel_h, n, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
+            ops.conv_mfma(a_val, self.p_v_rel_head[int(head_idx)] if head_only else self.p_v_rel_h, n, 0, dk if head_only else H, H, 1,
+                          EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
                           zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img, out1=a_proj, f16x3=1,
                           in_amax=ops.amax_maps(a_val, n), out1_amax=amax2)
             ops.conv_mfma(a_proj, self.p_proj_rel_h, n, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,

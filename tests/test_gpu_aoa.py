@@ -227,3 +227,33 @@ def test_aoa_fused_lock_steps_match_the_two_launch_steps(bu):
         assert torch.equal(a_feat, b_feat), (head, (a_feat - b_feat).abs().max().item())
         assert (a_words - b_words).abs().max().item() < 1e-5, (head, (a_words - b_words).abs().max().item())
         assert a_words.abs().max().item() == 1.0
+
+
+@pytest.mark.parametrize("bu", [False, True])
+def test_aoa_head_slice_of_the_v_proj_rule_is_bit_identical(bu):
+    """`lrp_mha` passes relevance through one head (models/aoamodel.py:848-860): the v_proj dense rule behind it (:1141-1144) contracts over
+    that head's 64 rows of W_v (lrpx_aoa_rel_value_head + a pack of the row slice) instead of over all 512 with 448 zero columns in the
+    operand - the same products in the same order: r_feat bit for bit, with captions of unequal length and every head position (first /
+    middle / last)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    V, B, T = 523, 6, 5
+    if bu:
+        eng = AOAEngine(weights.make_aoa_state(seed=38, vocab_size=V, feat_dim=2048, with_encoder=False))
+        enc = eng.encode(features=torch.from_numpy(weights.make_bu_features(39, B)))
+    else:
+        eng = AOAEngine(weights.make_aoa_state(seed=38, vocab_size=V))
+        enc = eng.encode(torch.from_numpy(weights.make_images(39, B)))
+    cap = torch.from_numpy(weights.make_captions(40, B, T, V)).cuda()
+    tr = eng.trace(enc, cap, predictions=False)
+    assert eng.head_only and eng.p_v_rel_head is not None
+    for head, lens in ((0, None), (4, [5, 1, 0, 3, 5, 2]), (7, None)):
+        a_feat, a_words, _ = eng.relevance(enc, tr, head, lens)
+        eng.head_only = False
+        try:
+            b_feat, b_words, _ = eng.relevance(enc, tr, head, lens)
+        finally:
+            eng.head_only = True
+        assert torch.equal(a_feat, b_feat) and torch.equal(a_words, b_words), (head, (a_feat - b_feat).abs().max().item())
