@@ -494,8 +494,8 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
                                                         long long* __restrict__ out_idx, float* __restrict__ out_val) {
     __shared__ float red[8];
     __shared__ float lse[8];
-    __shared__ float cv[256 * KMAX];
-    __shared__ int ci[256 * KMAX];
+    __shared__ float cv[4];
+    __shared__ int ci[4];
     const int tid = threadIdx.x;
     for (int r = 0; r < n_rows; ++r) {
         const float* xr = x + (long)r * ld;
@@ -525,18 +525,31 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
             v = tv; vi = ti;
         }
     }
+    // merge: k rounds of a block-wide arg-max over the heads of the 256 sorted lists (value descending, flat index ascending on ties -
+    // the order of the serial scan this replaces: one thread walking 1024 LDS candidates per output was 100 us of the kernel's 270)
+    int head = 0;
+    for (int o = 0; o < k; ++o) {
+        float v = -INFINITY; int vi = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) { cv[tid * KMAX + j] = bv[j]; ci[tid * KMAX + j] = bi[j]; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int o = 0; o < k; ++o) {
-            float best = -INFINITY; int bidx = 0x7fffffff, at = -1;
-            for (int c = 0; c < 256 * KMAX; ++c)
-                if (ci[c] != 0x7fffffff && (cv[c] > best || (cv[c] == best && ci[c] < bidx))) { best = cv[c]; bidx = ci[c]; at = c; }
-            if (at >= 0) ci[at] = 0x7fffffff;
-            out_idx[o] = at >= 0 ? bidx : 0;
-            out_val[o] = best;
+        for (int j = 0; j < KMAX; ++j) if (j == head) { v = bv[j]; vi = bi[j]; }
+        float wv = v; int wi = vi;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(wv, off, 64); const int oi = __shfl_xor(wi, off, 64);
+            const bool take = ov > wv || (ov == wv && oi < wi);
+            wv = take ? ov : wv; wi = take ? oi : wi;
         }
+        __syncthreads();                               // (cv / ci of the previous round have been read)
+        if ((tid & 63) == 0) { cv[tid >> 6] = wv; ci[tid >> 6] = wi; }
+        __syncthreads();
+        float best = cv[0]; int bidx = ci[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const bool take = cv[w] > best || (cv[w] == best && ci[w] < bidx);
+            best = take ? cv[w] : best; bidx = take ? ci[w] : bidx;
+        }
+        if (bidx != 0x7fffffff && vi == bidx) ++head;                       // the owner of the winner moves on to its next candidate
+        if (tid == 0) { out_idx[o] = bidx != 0x7fffffff ? bidx : 0; out_val[o] = best; }
     }
 }
 

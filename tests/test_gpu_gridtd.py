@@ -211,3 +211,36 @@ def test_beam_search_caption_bit_exact_and_drop_in_explains_it():
     assert torch.equal(torch.cat(maps), want[0])
     ex0 = ExplainGridTDAttention(types.SimpleNamespace(height=224, width=224), cases[2][1], model=sd)  # empty caption
     assert ex0.explain_caption(img) == ([], [])
+
+
+def test_beam_topk_kernel_vs_host_reference():
+    """`lrpx_beam_topk` (one step of the reference's beam search, models/gridTDmodel.py:437-444: the k best of cum[r] + log_softmax(x[r])
+    over the live beams, flat index r * V + w) against the same selection on the host in float64: indices bit-exact incl. exact ties
+    (lower flat index first), values to 1e-5; 1 - 4 live rows, k = 1 - 4, a vocabulary that is no multiple of the block."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ctypes as C
+    from lrp_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for n_rows, k, V in ((1, 2, 9586), (2, 2, 9586), (3, 3, 11027), (4, 4, 1001), (2, 1, 257)):
+        x = torch.randn(n_rows, V, generator=g) * 3
+        x[:, 7] = x[:, 11]                                   # exact ties inside a row ...
+        if n_rows > 1:
+            x[1] = x[0]                                      # ... and across rows (equal cumulative scores below)
+        cum = torch.zeros(n_rows) if n_rows > 1 else None
+        xd = x.cuda()
+        idx = torch.zeros(4, dtype=torch.int64, device="cuda")
+        val = torch.zeros(4, device="cuda")
+        _lib.check(lib.lrpx_beam_topk(_lib.ptr(xd), V, n_rows, V, _lib.ptr(cum.cuda()) if cum is not None else None, k, _lib.ptr(idx),
+                                      _lib.ptr(val), _lib.stream_ptr()))
+        lp = torch.log_softmax(xd.cpu().double(), dim=1).flatten()
+        order = sorted(range(n_rows * V), key=lambda f: (-lp[f].item(), f))[:k]
+        # float32 scores may order two float64-distinct candidates differently only when they are equal in float32: compare values, and
+        # indices where the float64 gap to the next candidate is resolvable
+        got_i, got_v = idx[:k].cpu().tolist(), val[:k].cpu()
+        for o in range(k):
+            assert abs(got_v[o].item() - lp[order[o]].item()) < 1e-5, (n_rows, k, V, o)
+        lp32 = (xd - torch.logsumexp(xd, dim=1, keepdim=True)).cpu().flatten()
+        want32 = sorted(range(n_rows * V), key=lambda f: (-lp32[f].item(), f))[:k]
+        assert got_i == want32 or got_i == order, (n_rows, k, V, got_i, want32, order)
