@@ -21,8 +21,9 @@ def run_beam_search(step, logits, reorder, vocab, beam_size, max_cap_length, sta
     seqs = [[start_id] for _ in range(beam_size)]
     cum = torch.zeros(beam_size, dtype=torch.float32, device=device)
     prev = torch.full((beam_size,), start_id, dtype=torch.int64, device=device)
-    idx = torch.zeros(4, dtype=torch.int64, device=device)
-    val = torch.zeros(4, dtype=torch.float32, device=device)
+    # indices (4 x int64) and scores (4 x float32) of a step in ONE 48-byte buffer: one device -> host read per step instead of two
+    buf = torch.zeros(6, dtype=torch.int64, device=device)
+    idx, val = buf[:4], buf[4:].view(torch.float32)
     complete, complete_scores = [], []
     n_live = beam_size
     for t in range(max_cap_length):
@@ -30,7 +31,8 @@ def run_beam_search(step, logits, reorder, vocab, beam_size, max_cap_length, sta
         lg = logits(t)
         rows, k = (1, beam_size) if t == 0 else (n_live, n_live)          # :440-443
         check(lib.lrpx_beam_topk(ptr(lg), lg.shape[1], rows, vocab, ptr(cum), k, ptr(idx), ptr(val), stream_ptr()))
-        top, sc = idx[:k].tolist(), val[:k].tolist()
+        host = buf.cpu()
+        top, sc = host[:k].tolist(), host[4:].view(torch.float32)[:k].tolist()
         beam_idx = [w // vocab for w in top]                               # :444 (floor division: PyTorch 1.4 `/` on int64)
         nxt = [w % vocab for w in top]
         seqs = [seqs[b] + [w] for b, w in zip(beam_idx, nxt)]              # :447
