@@ -486,47 +486,64 @@ __global__ __launch_bounds__(256) void argmax_logprob_rows_kernel(const float* _
 
 // Beam-search step (GridTDModel.beam_search, models/gridTDmodel.py:437-444; AOAModel.beam_search): the k best of
 // cum[r] + log_softmax(x[r])[w] over the n_rows live beams (flat index r * n + w, value).  One workgroup: row maxima and
-// log-sum-exps, a per-thread top-k (k <= 4) over the flat range, then a serial merge of the 256 x k candidates.
+// log-sum-exps, a per-thread top-k (k <= 4) over the flat range, then k rounds of a block-wide arg-max over the list heads
+// (1024 threads: one workgroup has to walk n_rows x vocab scores three times, so the width of the group is the speed).
 // Ties: lower flat index first.
 template <int KMAX>
-__global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ x, long ld, int n_rows, int n,
-                                                        const float* __restrict__ cum, int k,
-                                                        long long* __restrict__ out_idx, float* __restrict__ out_val) {
-    __shared__ float red[8];
+__global__ __launch_bounds__(1024) void beam_topk_kernel(const float* __restrict__ x, long ld, int n_rows, int n,
+                                                         const float* __restrict__ cum, int k,
+                                                         long long* __restrict__ out_idx, float* __restrict__ out_val) {
+    constexpr int NT = 1024, NW = NT / 64;
+    __shared__ float red[NW];
     __shared__ float lse[8];
-    __shared__ float cv[4];
-    __shared__ int ci[4];
+    __shared__ float cv[NW];
+    __shared__ int ci[NW];
     const int tid = threadIdx.x;
     for (int r = 0; r < n_rows; ++r) {
         const float* xr = x + (long)r * ld;
         float m = -INFINITY;
-        for (int i = tid; i < n; i += 256) m = fmaxf(m, xr[i]);
-        m = block_max(m, red);
-        float se = 0.f;
-        for (int i = tid; i < n; i += 256) se += expf(xr[i] - m);
-        se = block_sum(se, red);
-        if (tid == 0) lse[r] = m + logf(se);
+        for (int i = tid; i < n; i += NT) m = fmaxf(m, xr[i]);
+        m = wave_max(m);
         __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+        float se = 0.f;
+        for (int i = tid; i < n; i += NT) se += expf(xr[i] - m);
+        se = wave_sum(se);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = se;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[w];
+            lse[r] = m + logf(t);
+        }
     }
+    __syncthreads();
     float bv[KMAX];
     int bi[KMAX];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) { bv[j] = -INFINITY; bi[j] = 0x7fffffff; }
-    const int total = n_rows * n;
-    for (int f = tid; f < total; f += 256) {
-        const int r = f / n, w = f - r * n;
-        float v = (cum ? cum[r] : 0.f) + (x[(long)r * ld + w] - lse[r]);
-        int vi = f;
+    for (int r = 0; r < n_rows; ++r) {
+        const float off = (cum ? cum[r] : 0.f), l = lse[r];
+        const float* xr = x + (long)r * ld;
+        for (int w = tid; w < n; w += NT) {
+            float v = off + (xr[w] - l);
+            int vi = r * n + w;
 #pragma unroll
-        for (int j = 0; j < KMAX; ++j) {          // insertion into the sorted list (descending value, ascending index)
-            const bool better = v > bv[j] || (v == bv[j] && vi < bi[j]);
-            const float tv = better ? bv[j] : v; const int ti = better ? bi[j] : vi;
-            bv[j] = better ? v : bv[j]; bi[j] = better ? vi : bi[j];
-            v = tv; vi = ti;
+            for (int j = 0; j < KMAX; ++j) {          // insertion into the sorted list (descending value, ascending index)
+                const bool better = v > bv[j] || (v == bv[j] && vi < bi[j]);
+                const float tv = better ? bv[j] : v; const int ti = better ? bi[j] : vi;
+                bv[j] = better ? v : bv[j]; bi[j] = better ? vi : bi[j];
+                v = tv; vi = ti;
+            }
         }
     }
-    // merge: k rounds of a block-wide arg-max over the heads of the 256 sorted lists (value descending, flat index ascending on ties -
-    // the order of the serial scan this replaces: one thread walking 1024 LDS candidates per output was 100 us of the kernel's 270)
+    // merge: k rounds of a block-wide arg-max over the heads of the 1024 sorted lists (value descending, flat index ascending on ties)
     int head = 0;
     for (int o = 0; o < k; ++o) {
         float v = -INFINITY; int vi = 0x7fffffff;
@@ -544,7 +561,7 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
         __syncthreads();
         float best = cv[0]; int bidx = ci[0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NW; ++w) {
             const bool take = cv[w] > best || (cv[w] == best && ci[w] < bidx);
             best = take ? cv[w] : best; bidx = take ? ci[w] : bidx;
         }
@@ -1574,7 +1591,7 @@ int lrpx_beam_topk(const float* x, long ld, int n_rows, int n, const float* cum,
                    void* stream) {
     LRPX_REQUIRE(x && out_idx && out_val && n_rows > 0 && n_rows <= 8 && n > 0 && k > 0 && k <= 4 && (long)n_rows * n < 0x7fffffffL,
                  "beam_topk: bad arguments (at most 8 live beams, k <= 4)");
-    hipLaunchKernelGGL((beam_topk_kernel<4>), dim3(1), dim3(256), 0, (hipStream_t)stream, x, ld, n_rows, n, cum, k, out_idx,
+    hipLaunchKernelGGL((beam_topk_kernel<4>), dim3(1), dim3(1024), 0, (hipStream_t)stream, x, ld, n_rows, n, cum, k, out_idx,
                        out_val);
     return check_launch("beam_topk");
 }

@@ -370,21 +370,38 @@ static VggPacked vgg_packed_layout() {
 // weights: 1).  The trace then holds Z'_c = rs_c Z+_c, every S the chain forms is S'_c = S_c / rs_c, and S'_c (rs_c W+[c,i]) is
 // the reference's product bit for bit (powers of two).  Where Z+ == 0 the reference divides by 1e-7 (utils.py:16-18); there every
 // product x_i W+[c,i] of the window is zero, so the value of S at such a pixel never reaches R_in, scaled or not.
-__global__ __launch_bounds__(512) void row_scale_kernel(const float* __restrict__ w, int cout, int per_row, int use_abs,
+// one workgroup per weight row: m[c] = max over the row of w+ (first layer: |w|), ma[c] = max |w|   (coalesced; a lone thread per row
+// walking 4 608 strided floats took 0.6 ms per layer)
+__global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ w, int per_row, int use_abs, float* __restrict__ m_out,
+                                                      float* __restrict__ ma_out) {
+    __shared__ float r1[4], r2[4];
+    const int c = blockIdx.x;
+    float m = 0.f, ma = 0.f;
+    for (int j = threadIdx.x; j < per_row; j += 256) {
+        const float x = w[(long)c * per_row + j];
+        m = fmaxf(m, use_abs ? fabsf(x) : fmaxf(x, 0.f));
+        ma = fmaxf(ma, fabsf(x));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); ma = fmaxf(ma, __shfl_xor(ma, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = m; r2[threadIdx.x >> 6] = ma; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m_out[c] = fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3]));
+        ma_out[c] = fmaxf(fmaxf(r2[0], r2[1]), fmaxf(r2[2], r2[3]));
+    }
+}
+
+// rs[c] = 2^(e_max - e_c) from the row maxima; spread = the largest ratio of |w| row maxima inside one 16-row K slice
+__global__ __launch_bounds__(512) void row_scale_kernel(const float* __restrict__ m_in, const float* __restrict__ ma_in, int cout,
                                                         float* __restrict__ rs, float* __restrict__ spread) {
     __shared__ float sh[512];
     __shared__ float sa[512];
     const int c = threadIdx.x;
-    float m = 0.f, ma = 0.f;
-    if (c < cout)
-        for (int j = 0; j < per_row; ++j) {
-            const float x = w[(long)c * per_row + j];
-            m = fmaxf(m, use_abs ? fabsf(x) : fmaxf(x, 0.f));
-            ma = fmaxf(ma, fabsf(x));
-        }
+    const float m = c < cout ? m_in[c] : 0.f;
     // spread of the PLAIN weights' row maxima inside a 16-row K slice (the block the fp6 cross-term operands share one scale over):
     // what the image-gradient chains' mode-3 kernels are sensitive to (they multiply with W itself, rows unbalanced)
-    sa[c] = c < cout ? ma : 0.f;
+    sa[c] = c < cout ? ma_in[c] : 0.f;
     __syncthreads();
     if (c == 0) {
         float worst = 1.f;
@@ -537,7 +554,10 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
         float* wr = base + p.scratch;
         float* wd = wr + (size_t)L.cout * L.cin * 9;
         const int first = l == 0, cin2 = first ? 2 * L.cin : L.cin;
-        hipLaunchKernelGGL(row_scale_kernel, dim3(1), dim3(512), 0, st, w[ci], L.cout, L.cin * 9, first, rs, base + p.spread + l);
+        float* rmax = wr;                                    // (row maxima: 2 x cout floats at the head of the scratch, consumed before wr is written)
+        hipLaunchKernelGGL(row_max_kernel, dim3(L.cout), dim3(256), 0, st, w[ci], L.cin * 9, first, rmax, rmax + L.cout);
+        LRPX_TRY(check_launch("vgg16_pack: row maxima"));
+        hipLaunchKernelGGL(row_scale_kernel, dim3(1), dim3(512), 0, st, rmax, rmax + L.cout, L.cout, rs, base + p.spread + l);
         LRPX_TRY(check_launch("vgg16_pack: row scales"));
         const long n_w = (long)L.cout * L.cin * 9, n_d = (long)2 * L.cout * cin2 * 9;
         hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, w[ci], rs, wr, L.cin * 9, n_w);

@@ -492,8 +492,12 @@ class GridTDEngine:
         else:   # ExplainGridTDGradient.explain_caption_wordt (:1424-1505): same BPTT, no `features <= 0` gate
             mask = torch.ones(B, P, Cc, device=self.device, dtype=torch.float32)
         d_feat = e(rows, P, Cc)
-        ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=mask, u=U,
-                      map2img=row2img, out0=d_feat)                                              # :1668, :1674
+        if self.p_proj_rel_h is not None:      # the split-fp16 GEMM of the relevance path (fp32-grade, 4x the fp32 MFMA's rate)
+            ops.conv_mfma(a_proj, self.p_proj_rel_h, rows, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=mask,
+                          u=U, map2img=row2img, out0=d_feat, f16x3=1, in_amax=ops.amax_maps(a_proj, rows))
+        else:
+            ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=mask, u=U,
+                          map2img=row2img, out0=d_feat)                                          # :1668, :1674
         return d_feat, gs["r_words"], row2img
 
     def explain_batch_guided(self, images, captions, lens=None, return_features=False, gradcam=False):
