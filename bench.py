@@ -22,7 +22,9 @@ Rank 0 prints ONE JSON line.  At N=1 it also carries
   roofline     : MFMA roofline of the dominant kernel = the relevance conv kernel NAME with the largest total time over the
                  12 conv launches of one pass (30.69 GFLOP per map), picked from this run's own per-launch HIP-event times
                  (on the launch stream); `chain_frac`: the same fraction over all 13 layers; `per_layer`: every layer's;
-                 `traffic` is read from the PMC summary named in `traffic_source` (profiles/, separate --pmc passes);
+                 `traffic` = HBM bytes per launch from the PMC counters: measured in this run by two `rocprofv3 --pmc` child passes
+                 over the chain alone before the timed region (`traffic_source` says so; --no-live-traffic or any failure: the PMC
+                 summary committed under profiles/, separate --pmc passes of tools/pmc_passes.sh);
                  `modes`: the same step and chain in every matrix-core mode (0 fp32 MFMA ... 3 fp16+fp6), same process
   sustained    : the same step repeated for >= --sustain seconds (power-limited clocks show here, not in 20 steps)
   median_ms    : median interval between step completions (HIP events) inside the timed region
@@ -177,8 +179,72 @@ def launch_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
+LIVE_TRAFFIC = {"doc": None, "note": None}
+
+
+def live_traffic(n_img, n_maps, mode):
+    """HBM traffic of the chain's kernels measured IN THIS RUN (the committed summary is not driver-witnessed):
+    two `rocprofv3 --pmc` child passes over tools/bench_vgg.py (the relevance chain on the same library: 2 forward + 2 relevance passes of
+    `n_maps` maps over `n_img` images) - counters only, one pass per counter group as MI355X_MICROARCH.md's HBM section prescribes, the
+    program itself after `--`, cwd and TMPDIR in /tmp.  Runs BEFORE this process touches the GPU (the children need the card to
+    themselves, and nothing is exec'd from a process that holds a HIP context).  Any failure leaves the committed summary in charge."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        LIVE_TRAFFIC["note"] = "rocprofv3 not on PATH"
+        return
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        LIVE_TRAFFIC["note"] = "this process runs under a profiler itself"
+        return
+    out = tempfile.mkdtemp(prefix="lrpx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    passes = (("fetch", ["FETCH_SIZE", "GRBM_GUI_ACTIVE"]), ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]))
+    t0 = time.time()
+    try:
+        for name, ctr in passes:
+            cmd = [exe, "--pmc", *ctr, "--output-format", "csv", "-d", os.path.join(out, name), "--", "python3",
+                   os.path.join(ROOT, "tools", "bench_vgg.py"), "--images", str(n_img), "--maps", str(n_maps), "--iters", "1", "--mode", str(mode)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            if r.returncode != 0:
+                LIVE_TRAFFIC["note"] = f"rocprofv3 --pmc pass '{name}' exited {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"
+                return
+        data = {}
+        for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = re.sub(r"\(.*", "", re.sub(r"void lrpx::|lrpx::", "", row["Kernel_Name"]))
+                data.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        doc = {"maps_per_launch": n_maps, "kernels": {}}
+        for k, c in data.items():
+            if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or ("conv_" not in k and "first_layer" not in k):
+                continue
+            hit, miss = sum(c.get("TCC_HIT_sum", [0])), sum(c.get("TCC_MISS_sum", [0]))
+            doc["kernels"][k] = {"launches": len(c["FETCH_SIZE"]), "fetch_bytes": sum(c["FETCH_SIZE"]) * 1024,
+                                 "write_bytes": sum(c["WRITE_SIZE"]) * 1024, "l2_hit": round(hit / max(hit + miss, 1), 4)}
+        if doc["kernels"]:
+            LIVE_TRAFFIC["doc"] = doc
+            LIVE_TRAFFIC["note"] = (f"measured in this run: two rocprofv3 --pmc child passes (FETCH_SIZE GRBM_GUI_ACTIVE / WRITE_SIZE TCC_HIT_sum "
+                                    f"TCC_MISS_sum) over tools/bench_vgg.py --images {n_img} --maps {n_maps} --mode {mode} before the timed region, "
+                                    f"{time.time() - t0:.0f} s; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches "
+                                    "(gfx950 reports half of wide streaming reads: MI355X_MICROARCH.md, HBM section; tools/pmc_calibrate.py)")
+        else:
+            LIVE_TRAFFIC["note"] = "the --pmc passes returned no conv kernels"
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        LIVE_TRAFFIC["note"] = f"live --pmc passes failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def read_traffic(kernel, n_maps):
-    """(bytes per launch of `kernel` for `n_maps` maps, source file) from the PMC summary under profiles/."""
+    """(bytes per launch of `kernel` for `n_maps` maps, source) - from this run's own --pmc passes (live_traffic) when they ran, else
+    from the PMC summary under profiles/."""
+    doc = LIVE_TRAFFIC["doc"]
+    if doc is not None and kernel in doc["kernels"]:
+        k = doc["kernels"][kernel]
+        return round((2.0 * k["fetch_bytes"] + k["write_bytes"]) / k["launches"] / doc["maps_per_launch"] * n_maps), LIVE_TRAFFIC["note"]
     for rel in TRAFFIC_FILES:
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
@@ -218,6 +284,8 @@ def parse(argv=None):
                          "the line is marked value_valid=false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the roofline.modes sweep (every conv mode, same process)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (the committed PMC summary under profiles/ is used)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 3 / 4 / 5 and the B=64 line, same process)")
     ap.add_argument("--all-heads", action="store_true", help="config 3: explain all 8 heads of every word in the step (8 x B x T maps)")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained sub-measurement (0 = off)")
@@ -272,6 +340,11 @@ def main():
             dist.init_process_group(backend)
     else:
         dist = None
+        if (a.config == 2 and a.explainer == "lrp" and not a.no_configs and not a.graph and a.batch == 16 and not a.no_live_traffic
+                and not a.only_dropin and not a.fp32_mfma):
+            log("HBM traffic of the chain's kernels: two rocprofv3 --pmc child passes (before this process touches the GPU) ...")
+            live_traffic(a.batch, a.batch * a.words, a.conv_mode)
+            log(f"  -> {LIVE_TRAFFIC['note']}")
         torch.cuda.set_device(0)
 
     if a.only_dropin:
@@ -381,6 +454,24 @@ def dropin_b1(conv_mode):
                                            "bookkeeping with one small device->host read per step as the reference's"}}
     log(f"configs[dropin_b1]: {ms_warm:.2f} ms per 20-word image warm, {ms_new:.2f} ms with a new explainer per image, first construction "
         f"{t_cold:.0f} ms, beam-search caption of {n_beam} words {ms_beam:.2f} ms")
+    engine_cache.clear()
+    del ex
+    # the AoA explainer the same way: evaluation.py:637 `explain_caption(img_filepath, head_idx)`, models/aoamodel.py:1171-1176
+    from lrp_amd.explainers.aoa import ExplainAOAAttention
+    Va = 11027
+    sda = {k: torch.from_numpy(v) for k, v in weights.make_aoa_state(seed=0, vocab_size=Va).items()}
+    wma = weights.make_word_map(Va)
+    args.num_head = 8
+    capa = [int(c) for c in weights.make_captions(201, 1, T, Va)[0]]
+    exa = ExplainAOAAttention(args, wma, model=sda)
+    for _ in range(3):
+        exa.explain_caption(img, 0, caption_encode=capa)
+    ms_a = timed(lambda: exa.explain_caption(img, 0, caption_encode=capa), 10)
+    ms_a_new = timed(lambda: ExplainAOAAttention(args, wma, model=sda).explain_caption(img, 0, caption_encode=capa), 5)
+    res["aoa_given_caption"] = {"words": T, "head": 0, "vocab": Va, "ms_per_call": round(ms_a, 3), "maps_per_s": round(T / ms_a * 1e3, 1),
+                                "new_explainer_per_image_ms": round(ms_a_new, 3),
+                                "note": "ExplainAOAAttention.explain_caption(img, head_idx, caption_encode=...) on the same image, V=11027"}
+    log(f"configs[dropin_b1]: AoA {ms_a:.2f} ms per 20-word image warm, {ms_a_new:.2f} ms with a new explainer per image")
     engine_cache.clear()
     return res
 
