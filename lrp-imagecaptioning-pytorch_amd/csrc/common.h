@@ -83,7 +83,6 @@ inline int reserve_lds_once(LdsOnce& st, K kern, int bytes, const char* what) {
 // (LRPX_FIRST_VALU picks both the first-layer kernel and the chunk width its producer writes) cannot diverge.  Defaults are
 // what every number in DESIGN.md is measured with; the non-default values are exercised by tests/test_gpu_switches.py.
 struct Switches {
-    int strip12;         // LRPX_STRIP12 (default 1): conv1_2's mode-3 relevance step on the strip-persistent kernel (conv_inst_strip12.hip); 0 = the generic 2-row-tile kernel
     int wide;            // LRPX_WIDE (bit mask, default 7): 8-wave relevance kernels for 56/28 (1), 14 (2), pooled-input 56/28 (4)
     int fwd_ksplit14;    // LRPX_FWD_KSPLIT (default 8): K ranges per tile of the 14x14 forward layers (1 = unsplit)
     int fwd_ksplit28;    // LRPX_FWD_KSPLIT28 (default 1 = unsplit; 2 / 4 built and tested): ... of the 28x28 forward layers

@@ -79,7 +79,6 @@ int launch_h8_112_rel(const ConvArgs& a, hipStream_t s);
 int launch_h8_112n_rel(const ConvArgs& a, hipStream_t s);
 int launch_h8_224_rel(const ConvArgs& a, hipStream_t s);
 int launch_h8_224_pool(const ConvArgs& a, hipStream_t s);
-int launch_strip12_224_pool(const ConvArgs& a, hipStream_t s);   // conv1_2's relevance step, strip-persistent (conv_inst_strip12.hip)
 int launch_h8_112_pool(const ConvArgs& a, hipStream_t s);
 int launch_h8_56_pool(const ConvArgs& a, hipStream_t s);
 int launch_h8_28_pool(const ConvArgs& a, hipStream_t s);

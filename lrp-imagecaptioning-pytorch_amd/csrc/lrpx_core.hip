@@ -28,7 +28,6 @@ const Switches& switches() {
         auto set = [](const char* name) { return getenv(name) ? 1 : 0; };
         Switches w;
         w.wide = num("LRPX_WIDE", 7);
-        w.strip12 = num("LRPX_STRIP12", 0);
         w.fwd_ksplit14 = num("LRPX_FWD_KSPLIT", 8);
         w.fwd_ksplit28 = num("LRPX_FWD_KSPLIT28", 1);
         w.fwd_wide = num("LRPX_FWD_WIDE", 0);

@@ -169,8 +169,6 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
                 const int widep = switches().wide;
                 if ((widep & 4) && d->hw == 56 && d->n_oc >= 256) return launch_h8_56w_pool(a, s);
                 if ((widep & 4) && d->hw == 28 && d->n_oc >= 256) return launch_h8_28w_pool(a, s);
-                if (d->hw == 224 && d->n_oc == 64 && d->cin == 64 && d->epi == EPI_REL_MUL && d->blocked == 1 && a.out_chunk == 32 && switches().strip12)
-                    return launch_strip12_224_pool(a, s);
                 if (d->hw == 224 && d->n_oc <= 64) return launch_h8_224_pool(a, s);
                 if (d->hw == 112 && d->n_oc > 64) return launch_h8_112_pool(a, s);
                 if (d->hw == 56) return launch_h8_56_pool(a, s);
