@@ -1649,7 +1649,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #endif
     // (measured, same box: conv1_2 2.77 -> 2.60 ms, conv2_2 2.07 -> 2.00, conv3_1 0.96 -> 0.93, the 8-wave 56x56 layers +-0; the
     // 4-row 112x112 kernel of conv2_1 spills 9 registers with it, 1.09 -> 1.14: it keeps the generic epilogue)
-    if constexpr (X6 && AL && (LRPXH_AL_EPI != 0) && !(HW == 112 && MT == 2) && (EPI == EPI_REL_MUL || EPI == EPI_GUIDED)) {
+#ifndef LRPXH_AL_EPI_H3
+#define LRPXH_AL_EPI_H3 1      // mode 2 (three fp16 products) too: round 5
+#endif
+    if constexpr ((X6 || (!F8 && (LRPXH_AL_EPI_H3 != 0))) && AL && (LRPXH_AL_EPI != 0) && !(HW == 112 && MT == 2) && (EPI == EPI_REL_MUL || EPI == EPI_GUIDED)) {
         unsigned* __restrict__ oamax_a = (EPI == EPI_GUIDED) ? a.out0_amax : (a.out1 ? a.out1_amax : nullptr);
         epi_rel_mul_al<HW, EPI, F8>(a, acc, wm, ocb, lane, g0, total_pix, oamax_a, inv_w, in_amax);
         return;
