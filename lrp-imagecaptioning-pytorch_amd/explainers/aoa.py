@@ -684,6 +684,8 @@ class ExplainAOAAttention(object):
             self.img = self.preprocess_img(img)
         else:
             self.img = img.to(eng.device, torch.float32)
+        # (a caption that is handed over is uploaded before the encoder is enqueued: the copy of a pageable list waits for the stream)
+        cap_dev = None if caption_encode is None else torch.tensor([[int(c) for c in caption_encode]], dtype=torch.int64, device=eng.device)
         self._enc = eng.encode(self.img)
         if caption_encode is None:       # the reference captions the image itself: beam 3, 20 steps (:992-995)
             from .beam import caption_from_sequence
@@ -697,7 +699,8 @@ class ExplainAOAAttention(object):
         self._rel = {}
         if self.caption_length == 0:
             return
-        cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=eng.device)
+        cap = cap_dev if cap_dev is not None else torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=eng.device)
+        self._cap_dev = cap
         self._tr = eng.trace(self._enc, cap, predictions=True)
         self.image_features = ops.nhwc_to_nchw(self._enc["feats"].contiguous(), eng.C, 14, 14)
         self.num_pixels = self._enc["P"]
@@ -773,8 +776,7 @@ class ExplainAOAGradient(ExplainAOAAttention):
         super().get_hidden_parameters(img, caption_encode)
         if self.caption_length == 0:
             return
-        cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=self.engine.device)
-        self._tr = self.engine.trace(self._enc, cap, predictions=True, grad=True)      # :1309-1376 (correct LSTM bias)
+        self._tr = self.engine.trace(self._enc, self._cap_dev, predictions=True, grad=True)      # :1309-1376 (correct LSTM bias)
         self.predictions = self._tr["pred"][0]
         self.alphas = self._tr["alpha"][0]
 

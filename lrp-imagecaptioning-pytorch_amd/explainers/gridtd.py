@@ -690,6 +690,9 @@ class ExplainGridTDAttention(object):
         """Forward trace (:933-1012).  `img`: file path or a (1,3,224,224) tensor."""
         self.img = self.preprocess_img(img) if isinstance(img, str) else img.to(self.engine.device, torch.float32)
         eng = self.engine
+        # a caption that is handed over goes to the device BEFORE the encoder is enqueued: the copy of a pageable host list waits for the
+        # stream, and behind the VGG16 forward it stalled the host for 1 ms per call (the device then idled until the decoder was issued)
+        cap_dev = None if caption_encode is None else torch.tensor([[int(c) for c in caption_encode]], dtype=torch.int64, device=eng.device)
         self._enc = eng.encode(self.img)
         if caption_encode is None:
             from .beam import caption_from_sequence
@@ -704,7 +707,8 @@ class ExplainGridTDAttention(object):
         self._rel = None
         if self.caption_length == 0:
             return
-        cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=eng.device)
+        cap = cap_dev if cap_dev is not None else torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=eng.device)
+        self._cap_dev = cap
         self._tr = eng.trace(self._enc, cap, predictions=True)
         self.image_features = ops.nhwc_to_nchw(self._enc["feats"].contiguous(), eng.C, 14, 14)
         self.num_pixels = eng.P
@@ -779,8 +783,7 @@ class ExplainiGridTDGuidedGradient(ExplainGridTDAttention):
         super().get_hidden_parameters(img, caption_encode, max_cap_length)
         if self.caption_length == 0:
             return
-        cap = torch.tensor([self.beam_caption_encode], dtype=torch.int64, device=self.engine.device)
-        self._tr = self.engine.trace(self._enc, cap, predictions=True, grad=True)     # :1323-1422 (correct LSTM bias)
+        self._tr = self.engine.trace(self._enc, self._cap_dev, predictions=True, grad=True)     # :1323-1422 (correct LSTM bias)
         self.predictions = self._tr["pred"][0]
         self.alphas, self.betas = self._tr["alpha"][0], self._tr["beta"][0]
 
