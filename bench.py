@@ -182,15 +182,34 @@ def launch_ranks(a):
 LIVE_TRAFFIC = {"doc": None, "note": None}
 
 
+def pmc_traffic_doc(out_dir, n_maps):
+    """rocprofv3 --pmc output directories (any depth below out_dir, one *_counter_collection.csv per pass: columns Kernel_Name, Counter_Name,
+    Counter_Value, one row per dispatch and counter) -> {"maps_per_launch", "kernels": {short name: launches, fetch_bytes, write_bytes, l2_hit}}
+    for the conv / first-layer kernels; FETCH_SIZE / WRITE_SIZE count kilobytes."""
+    import csv
+    import glob
+    import re
+    data = {}
+    for f in glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = re.sub(r"\(.*", "", re.sub(r"void lrpx::|lrpx::", "", row["Kernel_Name"]))
+            data.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    doc = {"maps_per_launch": n_maps, "kernels": {}}
+    for k, c in data.items():
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or ("conv_" not in k and "first_layer" not in k):
+            continue
+        hit, miss = sum(c.get("TCC_HIT_sum", [0])), sum(c.get("TCC_MISS_sum", [0]))
+        doc["kernels"][k] = {"launches": len(c["FETCH_SIZE"]), "fetch_bytes": sum(c["FETCH_SIZE"]) * 1024,
+                             "write_bytes": sum(c["WRITE_SIZE"]) * 1024, "l2_hit": round(hit / max(hit + miss, 1), 4)}
+    return doc
+
+
 def live_traffic(n_img, n_maps, mode):
     """HBM traffic of the chain's kernels measured IN THIS RUN (the committed summary is not driver-witnessed):
     two `rocprofv3 --pmc` child passes over tools/bench_vgg.py (the relevance chain on the same library: 2 forward + 2 relevance passes of
     `n_maps` maps over `n_img` images) - counters only, one pass per counter group as MI355X_MICROARCH.md's HBM section prescribes, the
     program itself after `--`, cwd and TMPDIR in /tmp.  Runs BEFORE this process touches the GPU (the children need the card to
     themselves, and nothing is exec'd from a process that holds a HIP context).  Any failure leaves the committed summary in charge."""
-    import csv
-    import glob
-    import re
     import shutil
     import tempfile
     exe = shutil.which("rocprofv3")
@@ -212,18 +231,7 @@ def live_traffic(n_img, n_maps, mode):
             if r.returncode != 0:
                 LIVE_TRAFFIC["note"] = f"rocprofv3 --pmc pass '{name}' exited {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"
                 return
-        data = {}
-        for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
-            for row in csv.DictReader(open(f)):
-                k = re.sub(r"\(.*", "", re.sub(r"void lrpx::|lrpx::", "", row["Kernel_Name"]))
-                data.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-        doc = {"maps_per_launch": n_maps, "kernels": {}}
-        for k, c in data.items():
-            if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or ("conv_" not in k and "first_layer" not in k):
-                continue
-            hit, miss = sum(c.get("TCC_HIT_sum", [0])), sum(c.get("TCC_MISS_sum", [0]))
-            doc["kernels"][k] = {"launches": len(c["FETCH_SIZE"]), "fetch_bytes": sum(c["FETCH_SIZE"]) * 1024,
-                                 "write_bytes": sum(c["WRITE_SIZE"]) * 1024, "l2_hit": round(hit / max(hit + miss, 1), 4)}
+        doc = pmc_traffic_doc(out, n_maps)
         if doc["kernels"]:
             LIVE_TRAFFIC["doc"] = doc
             LIVE_TRAFFIC["note"] = (f"measured in this run: two rocprofv3 --pmc child passes (FETCH_SIZE GRBM_GUI_ACTIVE / WRITE_SIZE TCC_HIT_sum "

@@ -189,3 +189,38 @@ def test_engine_cache_keys(tmp_path):
         ec.get(("k", i), mk)
     assert ec.get(k1, mk) is not a          # evicted: the cache holds MAX_ENGINES engines
     ec.clear()
+
+
+def test_bench_pmc_traffic_parser_and_precedence(tmp_path):
+    """bench.py's roofline.traffic: the counters of its own `rocprofv3 --pmc` child passes (one *_counter_collection.csv per pass, a row
+    per dispatch and counter, FETCH_SIZE / WRITE_SIZE in kilobytes) -> bytes per launch = (2 x FETCH + WRITE) x 1024 / launches, scaled to
+    the maps of the line; a live measurement takes precedence over the summary committed under profiles/; kernels it did not see fall back."""
+    import bench
+    name = "void lrpx::conv_f16x3_kernel<224, 2, 2, false, 5, true, true>(lrpx::ConvArgs, int, int)"
+    for sub, rows in (("fetch/runA/1", [(name, "FETCH_SIZE", 1000.0), (name, "GRBM_GUI_ACTIVE", 5.0), (name, "FETCH_SIZE", 3000.0),
+                                        ("lrpx::amax_maps_kernel<7>(float const*)", "FETCH_SIZE", 7.0)]),
+                      ("write/runB/2", [(name, "WRITE_SIZE", 4000.0), (name, "TCC_HIT_sum", 30.0), (name, "TCC_MISS_sum", 10.0),
+                                        (name, "WRITE_SIZE", 4000.0)])):
+        d = tmp_path / sub
+        d.mkdir(parents=True)
+        with open(d / "77_counter_collection.csv", "w") as f:
+            f.write("Correlation_Id,Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n")
+            for i, (k, c, v) in enumerate(rows):
+                f.write(f'{i},{i},"{k}",{c},{v}\n')
+    doc = bench.pmc_traffic_doc(str(tmp_path), 320)
+    short = "conv_f16x3_kernel<224, 2, 2, false, 5, true, true>"
+    assert list(doc["kernels"]) == [short]                       # only conv / first-layer kernels with both byte counters
+    k = doc["kernels"][short]
+    assert k == {"launches": 2, "fetch_bytes": 4000.0 * 1024, "write_bytes": 8000.0 * 1024, "l2_hit": 0.75}
+    saved = dict(bench.LIVE_TRAFFIC)
+    try:
+        bench.LIVE_TRAFFIC.update(doc=doc, note="live")
+        t, src = bench.read_traffic(short, 320)
+        assert t == round((2 * 4000.0 + 8000.0) * 1024 / 2) and src == "live"
+        t2, _ = bench.read_traffic(short, 640)                   # per map, scaled to the line's maps
+        assert t2 == 2 * t
+        t3, src3 = bench.read_traffic("conv_f16x3_kernel<14, 1, 8, true, 5, false, true>", 320)
+        assert src3 != "live" and (t3 is None or t3 > 0)         # not measured live: the committed summary (if it holds the kernel)
+    finally:
+        bench.LIVE_TRAFFIC.clear()
+        bench.LIVE_TRAFFIC.update(saved)
