@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""conv1_2's strip-persistent relevance kernel (csrc/conv_inst_strip12.hip, LRPX_STRIP12=1) against the generic 2-row-tile kernel
+"""(needs tools/experiments/r5_conv12_strip_kernel.patch applied and `make`: the strip kernel is not in the shipped library)
+conv1_2's strip-persistent relevance kernel (csrc/conv_inst_strip12.hip, LRPX_STRIP12=1) against the generic 2-row-tile kernel
 (LRPX_STRIP12=0): the switch is read once per process, so this script runs itself twice and compares the maps bit for bit; per-layer
 times by the chain's own HIP events.   python tools/dbg/strip12_check.py [images] [maps]"""
 import ctypes as C

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""per-layer times of the relevance chain with the current LRPX_STRIP12 / LRPX_S12_DBG environment (diagnosis)"""
+"""(needs tools/experiments/r5_conv12_strip_kernel.patch applied and `make`: the strip kernel is not in the shipped library)
+per-layer times of the relevance chain with the current LRPX_STRIP12 / LRPX_S12_DBG environment (diagnosis)"""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
