@@ -377,7 +377,7 @@ int lrpx_gridtd_fwd_steps(const lrpx_gridtd_trace* tr, int t0, int t1, const lrp
 int lrpx_gridtd_rel_init(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* fcw,
                          const float* logit, const long long* tok, int tok_ld, void* stream);
 /* lock-step s, phase 0: LanguageLSTM cell split (:1061-1069) -> A ; 1: after its dense rule (:1074-1105) -> A ;
- * 2: after the AdaLSTM dense rule (:1110-1115) */
+ * 2: after the AdaLSTM dense rule (:1110-1115) ; 3: phase 2 of lock-step s and phase 0 of lock-step s + 1 in one launch */
 int lrpx_gridtd_rel_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, int s, int phase, void* stream);
 /* lock-steps 0 <= s < n_steps of explain_caption_wordt's `for i in range(t+1)[::-1]` (models/gridTDmodel.py:1060-1113) in ONE call: phase 0,
  * the LanguageLSTM dense rule `dense2`, phase 1, the AdaLSTM dense rule `dense1`, phase 2 (lrpx_conv_mfma descriptors whose map2img is

@@ -675,6 +675,43 @@ __global__ __launch_bounds__(256) void gridtd_rel_c_kernel(GridRel g, int s) {
     if (threadIdx.x == 0) g.r_words[(long)row * g.T + i] = acc;
 }
 
+// gridtd_rel_c_kernel of lock-step s and gridtd_rel_a_kernel of lock-step s + 1 in one launch (same expressions, same order: a thread owns
+// the same channels c in both; the r_h2n it writes is the one it reads).  One launch less per lock-step: they are ~5 us dependent launches.
+__global__ __launch_bounds__(256) void gridtd_rel_ca_kernel(GridRel g, int s) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, b = row / g.T, t = row - b * g.T, H = g.H, E = g.E;
+    const long tr = (long)row * H;
+    if (!row_active(g, b, t, s)) {                 // (then not active at s + 1 either)
+        for (int c = threadIdx.x; c < H; c += 256) g.A[tr + c] = 0.f;
+        return;
+    }
+    const int i = t - s;
+    const float* rx = g.rx + (long)row * (2 * E + 2 * H);
+    const bool nxt = row_active(g, b, t, s + 1);
+    const int i1 = i - 1;                          // time step of lock-step s + 1
+    const long ti = ((long)b * g.T + i1) * H, sc1 = ((long)b * (g.T + 1) + i1 + 1) * H, sc0 = sc1 - H;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float r_h2n = g.r_h2p[tr + c] + rx[c];                                                  // :1111
+        g.r_h2n[tr + c] = r_h2n;
+        if (nxt) {                                                                                    // :1061-1069 at s + 1
+            const float rc = g.r_c2[tr + c] + r_h2n;
+            const float cn = g.c2[sc1 + c];
+            const float rg = eps_id(rc, g.i2[ti + c] * tanhf(g.g2[ti + c]), cn);
+            g.r_c2[tr + c] = eps_id(rc, g.f2[ti + c] * g.c2[sc0 + c], cn);
+            g.A[tr + c] = rg / stab_eps(g.g2[ti + c]);
+        } else {
+            g.A[tr + c] = 0.f;
+        }
+    }
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < E; c += 256) {
+        g.r_glob[(long)row * E + c] += rx[H + c];                                                    // :1114
+        acc += rx[H + E + c];                                                                        // :1115, :1129
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) g.r_words[(long)row * g.T + i] = acc;
+}
+
 // :1116-1119 prologue: A = r_glob / z~(glob_pre)
 __global__ void gridtd_rel_glob_kernel(GridRel g, const float* __restrict__ glob_pre, float* __restrict__ Aglob) {
     const int row = blockIdx.x, b = row / g.T;
@@ -1656,12 +1693,13 @@ int lrpx_gridtd_rel_init(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate
 
 int lrpx_gridtd_rel_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, int s, int phase, void* stream) {
     LRPX_TRY(check_rel(tr, rs));
-    LRPX_REQUIRE(s >= 0 && s < tr->T && phase >= 0 && phase <= 2, "gridtd_rel_step: bad step/phase");
+    LRPX_REQUIRE(s >= 0 && s < tr->T && phase >= 0 && phase <= 3, "gridtd_rel_step: bad step/phase");
     const GridRel g = to_rel(tr, rs);
     const dim3 grid(tr->B * tr->T), blk(256);
     if (phase == 0) hipLaunchKernelGGL(gridtd_rel_a_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
     else if (phase == 1) hipLaunchKernelGGL(gridtd_rel_b_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
-    else hipLaunchKernelGGL(gridtd_rel_c_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
+    else if (phase == 2) hipLaunchKernelGGL(gridtd_rel_c_kernel, grid, blk, 0, (hipStream_t)stream, g, s);
+    else hipLaunchKernelGGL(gridtd_rel_ca_kernel, grid, blk, 0, (hipStream_t)stream, g, s);       // 3: phase 2 of s + phase 0 of s + 1
     return check_launch("gridtd_rel_step");
 }
 
@@ -2092,11 +2130,12 @@ int lrpx_gridtd_rel_steps(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstat
     lrpx_conv_desc d2 = *dense2, d1 = *dense1;
     for (int s = 0; s < n_steps; ++s) {
         d2.map2img = d1.map2img = idx + (long)s * idx_ld;      // row -> source row of the multiplicands at lock-step s
-        LRPX_TRY(lrpx_gridtd_rel_step(tr, rs, s, 0, stream));
+        if (s == 0) LRPX_TRY(lrpx_gridtd_rel_step(tr, rs, s, 0, stream));
         LRPX_TRY(lrpx_conv_mfma(&d2, stream));
         LRPX_TRY(lrpx_gridtd_rel_step(tr, rs, s, 1, stream));
         LRPX_TRY(lrpx_conv_mfma(&d1, stream));
-        LRPX_TRY(lrpx_gridtd_rel_step(tr, rs, s, 2, stream));
+        // the tail of lock-step s and the head of s + 1 in one launch
+        LRPX_TRY(lrpx_gridtd_rel_step(tr, rs, s, s + 1 < n_steps ? 3 : 2, stream));
     }
     return LRPX_OK;
 }
