@@ -371,6 +371,10 @@ typedef struct lrpx_gridtd_step_args {
     const float *Vp, *att_img;          /* relu(img_projector(features)) [B][P][H]; W_v_proj(Vp) + b [B][P][P] */
     const float *Wg, *Ws, *bs, *wh;     /* AdaAttention W_g_proj, W_s_proj (+ bias), w_h */
     float *zz1, *zz2, *att_scratch;     /* scratch [B][5H], [B][4H], [B][3P] */
+    /* optional (all four or none): the first 4H rows of w_cat1 / w_cat2 and their biases with the gate rows INTERLEAVED - row 16 j + 4 gate + u =
+     * row gate * H + 4 j + u - for the fused step (gate linear + LSTM cell in one launch, the next input row behind the second: 4 launches per
+     * time step instead of 7, bit-identical traces; <= 64 images) */
+    const float *w_il1, *b_il1, *w_il2, *b_il2;
 } lrpx_gridtd_step_args;
 int lrpx_gridtd_fwd_steps(const lrpx_gridtd_trace* tr, int t0, int t1, const lrpx_gridtd_step_args* a, void* stream);
 

@@ -51,7 +51,8 @@ class AoaStepArgs(C.Structure):
 class GridStepArgs(C.Structure):
     """lrpx_gridtd_step_args"""
     _fields_ = [("glob", _f), ("emb", _f), ("tok", _f), ("tok_ld", _i)] + [(k, _f) for k in (
-        "w_cat1", "b_cat1", "w_cat2", "b_cat2", "Vp", "att_img", "Wg", "Ws", "bs", "wh", "zz1", "zz2", "att_scratch")]
+        "w_cat1", "b_cat1", "w_cat2", "b_cat2", "Vp", "att_img", "Wg", "Ws", "bs", "wh", "zz1", "zz2", "att_scratch",
+        "w_il1", "b_il1", "w_il2", "b_il2")]
 
 
 class AoaGradState(C.Structure):

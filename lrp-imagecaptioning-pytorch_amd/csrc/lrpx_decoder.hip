@@ -250,13 +250,25 @@ constexpr int ATT_CB = 32;    // channels per block in (2): 8 pixel slices x 32 
 
 __global__ __launch_bounds__(256) void gridtd_fwd_att_scores_kernel(
     GridFwd g, int t, const float* __restrict__ att_img, const float* __restrict__ Wg, const float* __restrict__ Ws,
-    const float* __restrict__ bs, const float* __restrict__ wh, float* __restrict__ scr) {
+    const float* __restrict__ bs, const float* __restrict__ wh, float* __restrict__ scr, const float* __restrict__ sg_in) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, H = g.H, P = g.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float* h1n = sm;          // H
     float* sv = h1n + H;      // H
     const long st1 = ((long)b * (g.T + 1) + t + 1) * H, tr = ((long)b * g.T + t) * H;
-    for (int c = tid; c < H; c += 256) { h1n[c] = g.h1[st1 + c]; sv[c] = g.s[tr + c]; }
+    if (sg_in) {
+        // fused step (gridtd_linear_lstm_kernel): the sentinel s = sigmoid(gate) * tanh(c1) (:982-983) is formed here from the gate the
+        // gate linear left in sg_in [B][H] and the cell state it wrote - the expression of gridtd_fwd_lstm_kernel on the same values;
+        // the first pixel block keeps it for the trace
+        for (int c = tid; c < H; c += 256) {
+            const float sgv = sg_in[(long)b * H + c];
+            const float s = sgv * tanhf(g.c1[st1 + c]);
+            h1n[c] = g.h1[st1 + c]; sv[c] = s;
+            if (blockIdx.y == 0) { g.s[tr + c] = s; if (g.sgate) g.sgate[tr + c] = sgv; }
+        }
+    } else {
+        for (int c = tid; c < H; c += 256) { h1n[c] = g.h1[st1 + c]; sv[c] = g.s[tr + c]; }
+    }
     __syncthreads();
     float* zsc = scr + (long)b * 3 * P;       // [z | h_proj | s_proj]
     const int k0 = blockIdx.y * ATT_PB, k1 = min(k0 + ATT_PB, P);
@@ -1020,10 +1032,9 @@ __global__ void aoa_fwd_post_kernel(AoaFwd g, int t, const float* __restrict__ q
 // that of aoa_fwd_lstm / _post / _pre: results are bit-identical to the unfused step (token ids of the sampling goldens, traces).
 template <int RT>
 __device__ __forceinline__ void linear_mfma_core(const float* __restrict__ x, long ldx, const float* __restrict__ w, int B, int K,
-                                                 int N, float (&red)[4][RT][16][17]) {
+                                                 int N, float (&red)[4][RT][16][17], const int n0) {
     const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
     const int nl = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
     const int kslice = ((K / 16 + 3) / 4) * 16;
     const int k_lo = wv_ * kslice, k_hi = min(K, k_lo + kslice);
     const float* __restrict__ wrow = w + (long)min(n0 + nl, N - 1) * K + kq * 4;
@@ -1049,13 +1060,87 @@ __device__ __forceinline__ void linear_mfma_core(const float* __restrict__ x, lo
     __syncthreads();
 }
 
+// ---- gridTD: the two gate linears of a decoder step with their LSTM cells (gridtd_fwd_lstm_kernel) in the epilogue, and the next step's
+// input row (gridtd_fwd_pre_kernel) behind the second: 7 launches per time step -> 4.  Weight rows interleaved as above (w_il / b_il:
+// row 16 j + 4 gate + u = row gate * H + 4 j + u of [W_ih | W_hh]); the same dot products in the same order as linear_mfma_kernel and the
+// point-wise expressions of gridtd_fwd_lstm_kernel: bit-identical traces.
+// WHICH == 1, AdaLSTM (models/gridTDmodel.py:777-784, sentinel gate :982): workgroups 0 .. H/4 - 1 hold the cells of hidden units 4 j .. 4 j + 3;
+// workgroups H/4 .. H/4 + H/16 - 1 the 16 sentinel-gate rows 4 H + 16 (j - H/4) .. of the UN-interleaved [.. ; x_gate | h_gate] - sigmoid(gate) goes
+// to sg [B][H], the sentinel s = sigmoid(gate) tanh(c1) is formed by the attention kernel that reads it (the cell state comes from other workgroups).
+// WHICH == 2, LanguageLSTM: cells + fc input hc = h2 + ctx_hat (:990), then xh1[b, t + 1] = [h2[b, t + 1] | glob[b] | emb[tok[b, t + 1]] | h1[b, t + 1]]:
+// the workgroup's own four h2 columns from its registers, a slice of the other columns copied.
+template <int RT, int WHICH>
+__global__ __launch_bounds__(256) void gridtd_linear_lstm_kernel(GridFwd g, int t, const float* __restrict__ w_il, const float* __restrict__ b_il,
+                                                                 const float* __restrict__ w_cat, const float* __restrict__ b_cat,
+                                                                 float* __restrict__ sg, const float* __restrict__ glob,
+                                                                 const float* __restrict__ emb, const long long* __restrict__ tok, int tok_ld) {
+    __shared__ float red[4][RT][16][17];
+    const int H = g.H, E = g.E;
+    const int K = WHICH == 1 ? 2 * E + 2 * H : 3 * H;
+    const float* x = WHICH == 1 ? g.xh1 + (long)t * K : g.xh2 + (long)t * K;
+    const int n_cell = H / 4;                                   // workgroups that hold cells
+    if (WHICH == 1 && (int)blockIdx.x >= n_cell) {              // sentinel-gate rows (workgroup-uniform branch)
+        const int n0 = 4 * H + ((int)blockIdx.x - n_cell) * 16;
+        linear_mfma_core<RT>(x, (long)g.T * K, w_cat, g.B, K, 5 * H, red, n0);
+        for (int e = threadIdx.x; e < RT * 256; e += 256) {
+            const int r = e >> 8, row = (e >> 4) & 15, col = e & 15;
+            const int b = r * 16 + row, c = n0 - 4 * H + col;
+            if (b >= g.B || c >= H) continue;
+            float z = (red[0][r][row][col] + red[1][r][row][col]) + (red[2][r][row][col] + red[3][r][row][col]);
+            if (b_cat) z += b_cat[n0 + col];
+            sg[(long)b * H + c] = sigmoidf_(z);
+        }
+        return;
+    }
+    linear_mfma_core<RT>(x, (long)g.T * K, w_il, g.B, K, 4 * H, red, blockIdx.x * 16);
+    float *hh = WHICH == 1 ? g.h1 : g.h2, *cc = WHICH == 1 ? g.c1 : g.c2;
+    float *gg = WHICH == 1 ? g.g1 : g.g2, *ii = WHICH == 1 ? g.i1 : g.i2, *ff = WHICH == 1 ? g.f1 : g.f2, *oo = WHICH == 1 ? g.o1 : g.o2;
+    for (int e = threadIdx.x; e < RT * 64; e += 256) {
+        const int r = e >> 6, row = (e >> 2) & 15, u = e & 3;
+        const int b = r * 16 + row, c = blockIdx.x * 4 + u;
+        if (b >= g.B || c >= H) continue;
+        float z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 4 * q + u;
+            z[q] = (red[0][r][row][col] + red[1][r][row][col]) + (red[2][r][row][col] + red[3][r][row][col]);
+            if (b_il) z[q] += b_il[blockIdx.x * 16 + col];
+        }
+        const long st0 = ((long)b * (g.T + 1) + t) * H, st1 = st0 + H, tr = ((long)b * g.T + t) * H;
+        const float i = sigmoidf_(z[0]), f = sigmoidf_(z[1]), zg = z[2], o = sigmoidf_(z[3]);
+        const float cn = f * cc[st0 + c] + i * tanhf(zg);
+        const float hn = o * tanhf(cn);
+        cc[st1 + c] = cn; hh[st1 + c] = hn;
+        gg[tr + c] = zg; ii[tr + c] = i; ff[tr + c] = f;
+        if (oo) oo[tr + c] = o;
+        if (WHICH == 2) {
+            g.hc[tr + c] = hn + g.ctx_hat[tr + c];
+            if (t + 1 < g.T) g.xh1[((long)b * g.T + t + 1) * (2 * E + 2 * H) + c] = hn;
+        }
+    }
+    if (WHICH == 2 && t + 1 < g.T) {        // the other columns H .. 2 E + 2 H of the next input row: this workgroup's slice, every image
+        const int W1 = 2 * E + 2 * H, rest = W1 - H;
+        const int per = (rest + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int c0 = H + blockIdx.x * per, c1 = min(W1, c0 + per);
+        for (int e = threadIdx.x; e < g.B * per; e += 256) {
+            const int b = e / per, c = c0 + e - b * per;
+            if (c >= c1) continue;
+            float v;
+            if (c < H + E) v = glob[(long)b * E + (c - H)];
+            else if (c < H + 2 * E) v = emb[tok[(long)b * tok_ld + t + 1] * E + (c - H - E)];
+            else v = g.h1[((long)b * (g.T + 1) + t + 1) * H + (c - H - 2 * E)];
+            g.xh1[((long)b * g.T + t + 1) * W1 + c] = v;
+        }
+    }
+}
+
 // gate linear + LSTM cell (aoa_fwd_lstm_kernel).  w / bias: rows interleaved, row 16 j + 4 gate + u = original row gate * H + 4 j + u
 template <int RT>
 __global__ __launch_bounds__(256) void aoa_linear_lstm_kernel(AoaFwd g, int t, const float* __restrict__ w,
                                                               const float* __restrict__ bias) {
     __shared__ float red[4][RT][16][17];
     const int H = g.H, W = g.E + 2 * H;
-    linear_mfma_core<RT>(g.xh + (long)t * W, (long)g.T * W, w, g.B, W, 4 * H, red);
+    linear_mfma_core<RT>(g.xh + (long)t * W, (long)g.T * W, w, g.B, W, 4 * H, red, blockIdx.x * 16);
     for (int e = threadIdx.x; e < RT * 64; e += 256) {
         const int r = e >> 6, row = (e >> 2) & 15, u = e & 3;
         const int b = r * 16 + row, c = blockIdx.x * 4 + u;
@@ -1084,7 +1169,7 @@ __global__ __launch_bounds__(256) void aoa_linear_post_kernel(AoaFwd g, int t, c
                                                               const long long* __restrict__ tok, int tok_ld) {
     __shared__ float red[4][RT][16][17];
     const int H = g.H, W = g.E + 2 * H;
-    linear_mfma_core<RT>(g.ctx + (long)t * H, (long)g.T * H, w, g.B, H, H, red);
+    linear_mfma_core<RT>(g.ctx + (long)t * H, (long)g.T * H, w, g.B, H, H, red, blockIdx.x * 16);
     for (int e = threadIdx.x; e < RT * 256; e += 256) {
         const int r = e >> 8, row = (e >> 4) & 15, col = e & 15;
         const int b = r * 16 + row, c = blockIdx.x * 16 + col;
@@ -1142,7 +1227,7 @@ __global__ __launch_bounds__(256) void aoa_rec_lstm_kernel(AoaFwd g, int t, cons
                                                            const float* __restrict__ gimg, const long long* __restrict__ tok, int tok_ld) {
     __shared__ float red[4][RT][16][17];
     const int H = g.H;
-    linear_mfma_core<RT>(g.h + (long)t * H, (long)(g.T + 1) * H, w, g.B, H, 4 * H, red);
+    linear_mfma_core<RT>(g.h + (long)t * H, (long)(g.T + 1) * H, w, g.B, H, 4 * H, red, blockIdx.x * 16);
     for (int e = threadIdx.x; e < RT * 64; e += 256) {
         const int r = e >> 6, row = (e >> 2) & 15, u = e & 3;
         const int b = r * 16 + row, c = blockIdx.x * 4 + u;
@@ -1641,20 +1726,31 @@ int lrpx_gridtd_fwd_lstm(const lrpx_gridtd_trace* tr, int t, const float* zz, in
     return check_launch("gridtd_fwd_lstm");
 }
 
+}  // extern "C"
+// sg: the sentinel gate [B][H] of the fused step (null: the trace's s is already there)
+static int gridtd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img, const float* Wg, const float* Ws,
+                            const float* bs, const float* wh, float* scratch, const float* sg, void* stream);
+extern "C" {
 int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img,
                               const float* Wg, const float* Ws, const float* bs, const float* wh, float* scratch,
                               void* stream) {
+    return gridtd_attention(tr, t, Vp, att_img, Wg, Ws, bs, wh, scratch, nullptr, stream);
+}
+}  // extern "C"
+static int gridtd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img, const float* Wg, const float* Ws,
+                            const float* bs, const float* wh, float* scratch, const float* sg, void* stream) {
     LRPX_TRY(check_trace(tr));
     LRPX_REQUIRE(Vp && att_img && Wg && Ws && bs && wh && scratch && t >= 0 && t < tr->T, "gridtd_fwd_attention: bad arguments");
     const GridFwd g = to_fwd(tr);
     hipLaunchKernelGGL(gridtd_fwd_att_scores_kernel, dim3(tr->B, (tr->P + ATT_PB - 1) / ATT_PB), dim3(256),
-                       (size_t)2 * tr->H * sizeof(float), (hipStream_t)stream, g, t, att_img, Wg, Ws, bs, wh, scratch);
+                       (size_t)2 * tr->H * sizeof(float), (hipStream_t)stream, g, t, att_img, Wg, Ws, bs, wh, scratch, sg);
     LRPX_TRY(check_launch("gridtd_fwd_att_scores"));
     hipLaunchKernelGGL(gridtd_fwd_att_context_kernel, dim3(tr->B, (tr->H + ATT_CB - 1) / ATT_CB), dim3(256),
                        (size_t)((2 * tr->P + 1 > 256 ? 2 * tr->P + 1 : 256) + 8) * sizeof(float), (hipStream_t)stream, g, t, Vp,
                        wh, scratch);
     return check_launch("gridtd_fwd_att_context");
 }
+extern "C" {
 
 int lrpx_target_logit(const float* hc, const float* fcw, const float* fcb, const long long* tok, int tok_ld,
                       float* logit, int B, int T, int H, void* stream) {
@@ -2106,12 +2202,38 @@ int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, in
 // ---- the host loops of the gridTD decoder in native code (round 5; as lrpx_aoa_fwd_steps / lrpx_aoa_rel_steps for the AoA decoder): every
 // launch is one of the entry points above, what goes away is the interpreter between them (~4 us per call through ctypes against ~1.5 us
 // from here): 7 x T + 5 x T calls per explanation - a third of the 5 ms one image costs through the drop-in class
+}  // extern "C"
+template <int RT>
+static int gridtd_fused_steps(const lrpx_gridtd_trace* tr, int t0, int t1, const lrpx_gridtd_step_args* a, hipStream_t st) {
+    const GridFwd g = to_fwd(tr);
+    const int H = tr->H;
+    for (int t = t0; t < t1; ++t) {
+        hipLaunchKernelGGL((gridtd_linear_lstm_kernel<RT, 1>), dim3(H / 4 + H / 16), dim3(256), 0, st, g, t, a->w_il1, a->b_il1, a->w_cat1,
+                           a->b_cat1, a->zz1, a->glob, a->emb, a->tok, a->tok_ld);
+        LRPX_TRY(check_launch("gridtd_linear_lstm1"));
+        LRPX_TRY(gridtd_attention(tr, t, a->Vp, a->att_img, a->Wg, a->Ws, a->bs, a->wh, a->att_scratch, a->zz1, st));
+        hipLaunchKernelGGL((gridtd_linear_lstm_kernel<RT, 2>), dim3(H / 4), dim3(256), 0, st, g, t, a->w_il2, a->b_il2, a->w_cat2, a->b_cat2,
+                           a->zz1, a->glob, a->emb, a->tok, a->tok_ld);
+        LRPX_TRY(check_launch("gridtd_linear_lstm2"));
+    }
+    return LRPX_OK;
+}
+extern "C" {
 int lrpx_gridtd_fwd_steps(const lrpx_gridtd_trace* tr, int t0, int t1, const lrpx_gridtd_step_args* a, void* stream) {
     LRPX_TRY(check_trace(tr));
     LRPX_REQUIRE(a && a->glob && a->emb && a->tok && a->w_cat1 && a->b_cat1 && a->w_cat2 && a->b_cat2 && a->Vp && a->att_img && a->Wg &&
                      a->Ws && a->bs && a->wh && a->zz1 && a->zz2 && a->att_scratch && t0 >= 0 && t0 <= t1 && t1 <= tr->T,
                  "gridtd_fwd_steps: bad arguments");
     const int B = tr->B, T = tr->T, H = tr->H, E = tr->E, W1 = 2 * E + 2 * H;
+    // fused steps (4 launches instead of 7): interleaved gate rows given, <= 64 images, dims the matrix-core linear takes
+    if (a->w_il1 && a->b_il1 && a->w_il2 && a->b_il2 && B <= 64 && W1 % 16 == 0 && H % 16 == 0 && t0 < t1) {
+        LRPX_TRY(lrpx_gridtd_fwd_pre(tr, t0, a->glob, a->emb, a->tok, a->tok_ld, stream));      // (later rows: written by the step before)
+        hipStream_t st = (hipStream_t)stream;
+        if (B <= 16) return gridtd_fused_steps<1>(tr, t0, t1, a, st);
+        if (B <= 32) return gridtd_fused_steps<2>(tr, t0, t1, a, st);
+        if (B <= 48) return gridtd_fused_steps<3>(tr, t0, t1, a, st);
+        return gridtd_fused_steps<4>(tr, t0, t1, a, st);
+    }
     for (int t = t0; t < t1; ++t) {
         LRPX_TRY(lrpx_gridtd_fwd_pre(tr, t, a->glob, a->emb, a->tok, a->tok_ld, stream));
         LRPX_TRY(lrpx_linear_small(tr->xh1 + (long)t * W1, (long)T * W1, a->w_cat1, a->b_cat1, a->zz1, 5 * H, B, W1, 5 * H, 0, stream));

@@ -67,6 +67,15 @@ class GridTDEngine:
         self.Wcat2 = torch.cat([sd[l + "weight_ih"], sd[l + "weight_hh"]], 1).contiguous()
         self.bcat2_explainer = (sd[l + "bias_ih"] + sd[l + "bias_ih"]).contiguous()   # quirk: gridTDmodel.py:789
         self.bcat2_model = (sd[l + "bias_ih"] + sd[l + "bias_hh"]).contiguous()       # nn.LSTMCell
+        # gate rows interleaved for the fused decoder step of the teacher-forced trace (lrpx_gridtd_fwd_steps): row 16 j + 4 gate + u = row
+        # gate * H + 4 j + u, so that one workgroup of a gate linear holds the i, f, g, o pre-activations of the hidden units 4j .. 4j+3
+        self.fused_steps = H % 16 == 0 and E % 16 == 0          # False: the 7-launch step (A/B; the decoding loops always use it)
+        if self.fused_steps:
+            jj, qq, uu = torch.meshgrid(torch.arange(H // 4), torch.arange(4), torch.arange(4), indexing="ij")
+            il = (qq * H + 4 * jj + uu).reshape(-1).to(self.Wcat1.device)
+            self.Wcat1_il, self.bcat1_il = self.Wcat1[:4 * H][il].contiguous(), self.bcat1[:4 * H][il].contiguous()
+            self.Wcat2_il = self.Wcat2[il].contiguous()
+            self.bcat2_explainer_il, self.bcat2_model_il = self.bcat2_explainer[il].contiguous(), self.bcat2_model[il].contiguous()
         self.w_proj2d = sd["img_projector.weight"].reshape(H, Cc).contiguous()
         kc = ops.conv_kc(0, 1, Cc)
         self.p_proj_fwd = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE, kc)
@@ -190,6 +199,9 @@ class GridTDEngine:
         sa.glob, sa.emb, sa.tok, sa.tok_ld = ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), captions.shape[1]
         sa.w_cat1, sa.b_cat1, sa.w_cat2 = ptr(self.Wcat1), ptr(self.bcat1), ptr(self.Wcat2)
         sa.b_cat2 = ptr(self.bcat2_model if model_bias else self.bcat2_explainer)
+        if self.fused_steps:         # gate rows interleaved: gate linear + LSTM cell in one launch (lrpx_gridtd_fwd_steps)
+            sa.w_il1, sa.b_il1, sa.w_il2 = ptr(self.Wcat1_il), ptr(self.bcat1_il), ptr(self.Wcat2_il)
+            sa.b_il2 = ptr(self.bcat2_model_il if model_bias else self.bcat2_explainer_il)
         sa.Vp, sa.att_img = ptr(enc["Vp"]), ptr(enc["att_img"])
         sa.Wg, sa.Ws, sa.bs, sa.wh = ptr(sd[aa + "W_g_proj.weight"]), ptr(sd[aa + "W_s_proj.weight"]), ptr(sd[aa + "W_s_proj.bias"]), ptr(sd[aa + "w_h.weight"])
         sa.zz1, sa.zz2, sa.att_scratch = ptr(tr["_zz1"]), ptr(tr["_zz2"]), ptr(tr["_att_scr"])

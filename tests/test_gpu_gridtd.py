@@ -244,3 +244,35 @@ def test_beam_topk_kernel_vs_host_reference():
         lp32 = (xd - torch.logsumexp(xd, dim=1, keepdim=True)).cpu().flatten()
         want32 = sorted(range(n_rows * V), key=lambda f: (-lp32[f].item(), f))[:k]
         assert got_i == want32 or got_i == order, (n_rows, k, V, got_i, want32, order)
+
+
+@pytest.mark.parametrize("B", [3, 20, 50])
+def test_fused_trace_steps_are_bit_identical_to_the_seven_launch_step(B):
+    """The teacher-forced trace with the gate linears and their LSTM cells in one launch each and the next input row behind the second
+    (lrpx_gridtd_fwd_steps with interleaved gate rows: 4 launches per time step) against the 7-launch step that follows the reference's
+    loop statement by statement (models/gridTDmodel.py:952-1012): the same dot products in the same order and the same point-wise
+    expressions, so EVERY trace tensor is bit-identical - both LSTM biases (the explainers' quirk and the model's), with and without
+    the gradient explainers' extras, 1 .. 4 row tiles of 16 images."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine
+    V, T = 467, 6
+    eng = GridTDEngine(weights.make_gridtd_state(seed=41, vocab_size=V))
+    enc = eng.encode(torch.from_numpy(weights.make_images(42, B)))
+    cap = torch.from_numpy(weights.make_captions(43, B, T, V)).cuda()
+    assert eng.fused_steps
+    for grad in (False, True):
+        a = eng.trace(enc, cap, predictions=True, grad=grad)
+        eng.fused_steps = False
+        try:
+            b = eng.trace(enc, cap, predictions=True, grad=grad)
+        finally:
+            eng.fused_steps = True
+        keys = [k for k, v in a.items() if torch.is_tensor(v) and not k.startswith("_") and k != "captions"]
+        assert {"xh1", "xh2", "h1", "c1", "h2", "c2", "g1", "i1", "f1", "g2", "i2", "f2", "s", "ctx", "ctx_hat", "hc", "alpha", "beta",
+                "logit", "pred"} <= set(keys), keys
+        if grad:
+            assert {"o1", "o2", "sgate"} <= set(keys), keys
+        for k in keys:
+            assert torch.equal(a[k], b[k]), (k, grad, B, (a[k] - b[k]).abs().max().item())
