@@ -246,12 +246,18 @@ def ptr(t):
     """Device pointer of a contiguous torch tensor (or None)."""
     if t is None:
         return None
+    # a host tensor's address handed to a kernel is a GPU page fault that comes and goes with what the runtime happens to have
+    # mapped (round 5: a test that passed CPU images aborted the process in two of three sessions): refuse it here, loudly
+    if not t.is_cuda:
+        raise TypeError("lrpx kernels take CUDA tensors (got a %s tensor): there is no CPU path" % t.device.type)
     assert t.is_contiguous(), "lrpx needs contiguous tensors"
     return C.c_void_p(t.data_ptr())
 
 
 def ptr_at(t, offset_elems=0):
     """Device pointer of t's storage start + offset (for strided row views)."""
+    if not t.is_cuda:
+        raise TypeError("lrpx kernels take CUDA tensors (got a %s tensor): there is no CPU path" % t.device.type)
     return C.c_void_p(t.data_ptr() + 4 * offset_elems)
 
 

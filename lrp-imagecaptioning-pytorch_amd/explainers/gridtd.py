@@ -133,6 +133,7 @@ class GridTDEngine:
         st = stream_ptr()
         B = images.shape[0]
         H, E, Cc, P = self.H, self.E, self.C, self.P
+        images = images.to(self.device, torch.float32).contiguous()
         feats = self.vgg.forward(images)                                   # (B,P,C) NHWC view into the trace
         enc = dict(B=B, feats=feats)
         enc["avg"] = torch.empty(B, Cc, device=self.device)

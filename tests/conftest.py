@@ -140,3 +140,31 @@ def gradient_e2e_bounds(flips, what=""):
     if deep == 0:
         return dict(frac=0.02, l2=6e-3, cos=0.99997, hard=0.1)
     return dict(frac=0.3, l2=3e-2, cos=0.9995, hard=0.15)
+
+
+import pytest as _pytest
+
+
+@_pytest.fixture(autouse=True)
+def _lrpx_test_diag(request):
+    """LRPX_TEST_DIAG=1: one line per test (open file descriptors, threads, reserved / allocated device memory) appended to
+    gpurun_out/test_diag.txt BEFORE the test runs - what a process that dies without a message leaves behind."""
+    if os.environ.get("LRPX_TEST_DIAG") == "1":
+        import resource
+        import threading
+        line = f"{request.node.nodeid} fds={len(os.listdir('/proc/self/fd'))}/{resource.getrlimit(resource.RLIMIT_NOFILE)[0]} threads={threading.active_count()}"
+        try:
+            import torch
+            if torch.cuda.is_available():
+                free, total = torch.cuda.mem_get_info()
+                line += f" reserved={torch.cuda.memory_reserved() >> 20}MiB allocated={torch.cuda.memory_allocated() >> 20}MiB free={free >> 20}MiB of {total >> 20}MiB"
+            with open("/proc/self/status") as f:
+                st = f.read()
+            line += " " + " ".join(l.replace("\t", "") for l in st.splitlines() if l.startswith(("VmRSS", "Threads")))
+        except Exception as e:  # noqa: BLE001
+            line += f" ({e})"
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "test_diag.txt"), "a") as f:
+            f.write(line + "\n")
+    yield

@@ -259,7 +259,10 @@ def test_fused_trace_steps_are_bit_identical_to_the_seven_launch_step(B):
     from lrp_amd.explainers.gridtd import GridTDEngine
     V, T = 467, 6
     eng = GridTDEngine(weights.make_gridtd_state(seed=41, vocab_size=V))
-    enc = eng.encode(torch.from_numpy(weights.make_images(42, B)))
+    imgs = torch.from_numpy(weights.make_images(42, B))
+    with pytest.raises(TypeError, match="no CPU path"):          # a host tensor never reaches a kernel (the engines move their inputs)
+        eng.vgg.forward(imgs)
+    enc = eng.encode(imgs)
     cap = torch.from_numpy(weights.make_captions(43, B, T, V)).cuda()
     assert eng.fused_steps
     for grad in (False, True):

@@ -88,6 +88,16 @@ def test_no_cpu_fallback():
         pools.compute_lrp(torch.zeros(1, 2, 4, 4), target=torch.ones(1, 2, 2, 2))
 
 
+def test_device_pointer_helper_refuses_host_tensors():
+    """`_lib.ptr` / `ptr_at` hand addresses to HIP kernels: a host tensor's address there is a GPU page fault that comes and goes with
+    what the runtime has mapped (round 5).  They refuse it - on any machine, before the library is even loaded."""
+    from lrp_amd import _lib
+    assert _lib.ptr(None) is None
+    for f in (_lib.ptr, _lib.ptr_at):
+        with pytest.raises(TypeError, match="no CPU path"):
+            f(torch.zeros(4))
+
+
 def test_generic_add_lrp_hooks_every_leaf_once():
     """lrp_wrapper.py:37-59 hooks every leaf of ANY model; a second add_lrp must not stack hooks (the reference does)"""
     net = nn.Sequential(nn.MaxPool2d(2, 2), nn.ReLU(), nn.Dropout())
