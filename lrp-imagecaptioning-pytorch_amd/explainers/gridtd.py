@@ -190,7 +190,7 @@ class GridTDEngine:
         (:1323-1422: correct LSTM bias, output + sentinel gates kept)."""
         lib = _lib.load()
         B, T = captions.shape[0], captions.shape[1] - 1
-        captions = captions.contiguous()
+        captions = captions.to(self.device, torch.int64).contiguous()      # (token ids index the embedding table: never another width)
         tr = self._alloc_trace(B, T, grad)
         model_bias = model_bias or grad
         # the T steps in one native call (lrpx_gridtd_fwd_steps: the launches of `_step`, its host loop in C)
