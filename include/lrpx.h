@@ -88,7 +88,9 @@ typedef struct lrpx_conv_desc {
     int in_chunked;       /* input stored in K-chunks of lrpx_conv_kc(hw,taps,cin) channels (see lrpx_maxpool2x2_relevance) */
     int bf16x6;           /* 1: contraction on the bf16 matrix cores with exact 3-way operand splits and the 6 leading
                              partial products (fp32 accuracy, 2.67x less matrix-pipe time); wpacked must come from
-                             lrpx_pack_weights_bf16x3; 3x3 convs on 56/28/14-pixel maps, cin %% 16 == 0 */
+                             lrpx_pack_weights_bf16x3; 3x3 convs, cin %% 16 == 0.  Epilogues: REL, FWD_DUAL (conv_bf16x6.h) and - round 6,
+                             on the conv_f16x3.h tiling - REL_MUL (x = the precomputed multiplicand; with pool_am the input is the
+                             relevance at the pool's output and is unpooled while staged).  No operand scales: in_amax / out1_amax unused */
     const float* bias;
     const float* x;
     const float* u;
@@ -109,11 +111,11 @@ typedef struct lrpx_conv_desc {
     const uint32_t* in_amax;  /* f16x3: [n_maps] float bits of max|in| per map (lrpx_amax_maps, or a producer's out1_amax) */
     uint32_t* out1_amax;      /* f16x3 + out1: max|out1| per map is atomicMax-ed into it (zero it first); may be null */
     uint32_t* out0_amax;      /* f16x3 + FWD_DUAL: max of out0 (the activations) per map is atomicMax-ed into it; may be null */
-    const uint8_t* pool_am;   /* f16x3 only: the conv sits under a 2x2 max-pool and `in` is the relevance at the pool's
+    const uint8_t* pool_am;   /* f16x3, or bf16x6 with REL_MUL: the conv sits under a 2x2 max-pool and `in` is the relevance at the pool's
                                  OUTPUT [n_maps][hw/2*hw/2][cin]; pool_am [n_img][hw/2*hw/2][cin] = window position
                                  (0..3, row-major) of each maximum (lrpx_pool_winner): Pool2d.propagate_relevance
                                  (lrp_modules.py:182-195) is applied while the operand is staged */
-    int tile_group;           /* f16x3, performance hint only (results do not depend on it): maps [k*g, (k+1)*g) share an
+    int tile_group;           /* f16x3 / bf16x6 REL_MUL, performance hint only (results do not depend on it): maps [k*g, (k+1)*g) share an
                                  image (the g words of a caption): their tiles of the same image rows are scheduled next to
                                  each other on one XCD, so the per-image multiplicand `x` is fetched from HBM once, not g
                                  times.  0 / 1: plain order.  Needs n_maps %% g == 0 and map-aligned tiles (hw >= 56) */
@@ -206,8 +208,12 @@ int lrpx_vgg16_resolve_opts(const lrpx_vgg16_opts* opts, int* conv_mode, int* fo
  * the bf16 matrix cores with exact operand splits (fp32 accuracy, see lrpx_conv_desc.bf16x6), 0 keeps the fp32 MFMA
  * everywhere; a negative value only queries.  Returns the previous setting. */
 int lrpx_set_bf16x6(int enable);
-/* Matrix-core mode of the fused VGG16 chains: 0 fp32 MFMA, 1 bf16x6 (exact splits), 2 f16x3 (fp16 split products),
- * 3 = 2 with the cross products of the relevance pass on the fp6 matrix cores (lrpx_conv_desc.f16x3 = 2).
+/* Matrix-core mode of the fused VGG16 chains: 0 fp32 MFMA, 1 bf16x6 (exact 3-way bf16 splits of both operands, six products, fp32
+ * accumulate: 24 significand bits and fp32's exponent range per operand - THE DEFAULT since round 6, arithmetic no narrower than the
+ * reference's fp32 convolutions, LRPtools/lrp_modules.py:124-150), 2 f16x3 (fp16 split products behind per-map power-of-two
+ * scales: 22 operand bits, fp16's exponent range below the map maximum), 3 = 2 with the cross products of the relevance pass on the fp6
+ * matrix cores (lrpx_conv_desc.f16x3 = 2).  Modes 2 / 3 are opt-in speed modes (1.8x / 2.4x the maps/s of mode 1, inside the 1e-4
+ * contract on every tested input).  LRPX_CONV_MODE in the environment sets the initial default (read once at load).
  * Negative: query only.  Returns the previous mode. */
 int lrpx_set_conv_mode(int mode);
 /* 1: the forward trace of conv1_2..conv5_3 also runs on the fp16 split-product kernels (operand scale = per-image maximum of

@@ -96,6 +96,7 @@ struct Switches {
     int dense_rt;        // LRPX_DENSE_RT (default 0 = by the grid): row tiles per wave of that kernel, 4 (128-row tiles) or 3 (96-row tiles)
     int dense_1wave;     // LRPX_DENSE_1WAVE: PLAIN few-row GEMMs without the 4-wave K split
     int linear_valu;     // LRPX_LINEAR_VALU: the VALU skinny linear instead of the fp32-MFMA one
+    int x6_legacy;       // LRPX_X6_LEGACY: conv mode 1 on round 1's flow (conv_bf16x6.h with EPI_REL + pool kernels) instead of the fused B6 kernels
 };
 const Switches& switches();      // (lrpx_core.hip)
 

@@ -19,6 +19,7 @@
 // image-row wraps (conflict-free ds_read_b128).
 #pragma once
 #include "conv_mfma.h"
+#include "conv_bf16x6.h"
 #include "blocked.h"
 
 namespace lrpx {
@@ -90,6 +91,21 @@ __device__ __forceinline__ void split2_pk(const f32x2_ x, unsigned& hi, unsigned
         hi_f = f32x2_{(float)h0, (float)h1};
         hi = pack_f16(h0, h1); lo = pack_f16(l0, l1);
     }
+}
+
+// B6 (conv mode 1, "bf16x6" in this kernel's tiling): EXACT three-way split of two values at once, x == p0 + p1 + p2 with every part a
+// bf16 (8 + 8 + 8 significand bits, fp32's exponent range: no operand scale, no per-map maximum), packed pairs; the same roundings as
+// split3 of conv_bf16x6.h (v_cvt_pk_bf16_f32, round to nearest even), 10 VALU instructions per pair
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_ bf16pair_to_f32(const unsigned p) {
+    return f32x2_{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)};
+}
+__device__ __forceinline__ void split3_pk(const f32x2_ x, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_));
+    const f32x2_ r1 = x - bf16pair_to_f32(p0);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_));
+    const f32x2_ r2 = r1 - bf16pair_to_f32(p1);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_));
 }
 
 // two / four floats -> fp8 e4m3 (OCP, round to nearest even), packed
@@ -327,7 +343,7 @@ __device__ __forceinline__ int perm_row_channel(const int rho) { return 16 * ((r
 // ONE wave-uniform 64-bit base per tensor plus a 32-bit byte offset (uniform element part + the lane's part: one v_add_u32) - so every
 // access is `global_load / global_store_dword v, v_off, s[base]`: no 64-bit vector add per access (the generic dword epilogue: 224
 // v_lshl_add_u64 per wave) and half the address bytes on the way to the texture unit.  Same arithmetic, same order: bit-identical.
-template <int HW, int EPI, bool F8, bool PERM = false>
+template <int HW, int EPI, bool F8, bool PERM = false, bool B6 = false>
 __device__ __forceinline__ void epi_rel_mul_al(const ConvArgs& a, f32x16 (&acc)[7], const int wm, const int ocb, const int lane,
                                                const long g0, const long total_pix, unsigned* __restrict__ oamax, const float inv_w,
                                                const unsigned* __restrict__ in_amax) {
@@ -342,7 +358,8 @@ __device__ __forceinline__ void epi_rel_mul_al(const ConvArgs& a, f32x16 (&acc)[
     const unsigned n = (unsigned)g0 / (unsigned)HW;             // the tile's map
     const unsigned p0 = ((unsigned)g0 - n * HW) * HW;           // pixel-in-map of the tile's first pixel
     const long img = a.map2img ? a.map2img[min((int)n, nmax)] : (long)n;
-    const float f = exp2i(-split_scale_exp<F8>(in_amax[min((int)n, nmax)])) * inv_w;
+    float f = 1.f;                                              // (B6: exact bf16 splits, nothing was scaled)
+    if constexpr (!B6) f = exp2i(-split_scale_exp<F8>(in_amax[min((int)n, nmax)])) * inv_w;
     const int ch = a.out_chunk;
     const int ostr = ch > 0 ? ch : ncol;
     // uniform bases (bytes) and the lane's offsets (bytes, 32-bit)
@@ -364,7 +381,7 @@ __device__ __forceinline__ void epi_rel_mul_al(const ConvArgs& a, f32x16 (&acc)[
     for (int j = 0; j < 7; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float v = acc[j][e] * f;
+            const float v = B6 ? acc[j][e] : acc[j][e] * f;
             const float r = EPI == EPI_GUIDED ? ((xv[j][e] > 0.f && (a.relu == 2 || v > 0.f)) ? v : 0.f) : xv[j][e] * v;
             const unsigned ub = (unsigned)((32 * j + (e & 3) + 8 * (e >> 2)) * ostr * 4);         // uniform
             float* op = reinterpret_cast<float*>(Ou + (ub + ooff));
@@ -386,14 +403,15 @@ __device__ __forceinline__ void epi_rel_mul_al(const ConvArgs& a, f32x16 (&acc)[
 // FWD_DUAL epilogue of the map-aligned forward kernels, addressed like epi_rel_mul_al (one scalar base, 32-bit offsets): channel blocks
 // below oc_split are activations - out0 = ReLU(acc + bias), per-image maximum to out0_amax -, the blocks above it are Z+ - out1 = acc.
 // A channel block is one or the other as a whole (oc_split is a multiple of 32 for every VGG16 layer; the launcher checks).
-template <int HW, bool F8>
+template <int HW, bool F8, bool B6 = false>
 __device__ __forceinline__ void epi_fwd_dual_al(const ConvArgs& a, f32x16 (&acc)[7], const int wm, const int ocb, const int lane,
                                                 const long g0, const float inv_w, const unsigned* __restrict__ in_amax) {
     const int li = lane & 31, lh = lane >> 5;
     const int ncol = a.oc_split;
     const int nmax = a.n_maps - 1;
     const unsigned n = (unsigned)g0 / (unsigned)HW;             // the tile's image
-    const float f = exp2i(-split_scale_exp<F8>(in_amax[min((int)n, nmax)])) * inv_w;
+    float f = 1.f;
+    if constexpr (!B6) f = exp2i(-split_scale_exp<F8>(in_amax[min((int)n, nmax)])) * inv_w;
     const bool is_act = ocb * 32 < ncol;                        // wave-uniform
     const int ocl = (is_act ? ocb * 32 : ocb * 32 - ncol);      // first channel of the block inside its tensor
     if (ocl + li >= ncol) return;
@@ -405,7 +423,7 @@ __device__ __forceinline__ void epi_fwd_dual_al(const ConvArgs& a, f32x16 (&acc)
     for (int j = 0; j < 7; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            float v = acc[j][e] * f;
+            float v = B6 ? acc[j][e] : acc[j][e] * f;
             if (is_act) { v += bias; v = v > 0.f ? v : 0.f; m = fmaxf(m, v); }
             const unsigned ub = (unsigned)((32 * j + (e & 3) + 8 * (e >> 2)) * ncol * 4);         // uniform
             *reinterpret_cast<float*>(Ou + (ub + ooff)) = v;
@@ -562,8 +580,15 @@ __device__ __forceinline__ void epi_rel_mul_blk(const ConvArgs& a, f32x16 (&acc)
 // through all 13 layers the maps move by < 1e-5 of their maximum (tolerance 1e-4; plain f16x3: ~1e-6).  They run on
 // v_mfma_f32_32x32x64_f8f6f4, K = 64 = 4 (tap, 16-channel) slices: 5 fp8 MFMAs per K-chunk (f8_slot_*) instead of 18
 // fp16 ones.  LDS pixel (80 B as before): 16 fp16 hi | 16 fp8 of x*2^-4 | 16 fp8 of (x-hi)*2^4 | pad.
-template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
+//
+// B6 (conv mode 1): the same tiling, staging, B queue and epilogues with EXACT operand splits on the bf16 matrix cores - every fp32
+// operand a = a0 + a1 + a2 (three bf16 parts, 24 significand bits, fp32's exponent range: no operand scales, in_amax unused), the six
+// products with i + j <= 2 accumulated in fp32 smallest first (conv_bf16x6.h:1-6: dropped terms <= 3 * 2^-24 of a product, what the
+// rounding of an fp32 product itself costs).  LDS pixel = 3 planes x 32 B + 16 B pad = 112 B (pitch / 16 == 7 W (mod 16): conflict-free
+// ds_read_b128 as with 80 B); weights from lrpx_pack_weights_bf16x3 (three planes per k-step, no header).
+template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false, bool B6 = false>
 __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f16x3_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+    static_assert(!(F8 && B6), "conv_f16x3_kernel: F8 (fp16 + narrow cross products) and B6 (exact bf16 splits) exclude each other");
     LRPXH_T(t_start);
 #ifdef LRPX_STAMP
     unsigned long long s_issue = 0, s_mfma = 0, s_commit = 0, s_barrier = 0, s_tap0 = 0, s_tap1 = 0, s_tap2 = 0;
@@ -571,8 +596,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     constexpr int KC = 16, TAPS = 9;
     using C = ConvCfg<HW, KC, MT, NWN, TAPS>;
     constexpr int W = C::W, H = C::H, NT = C::NT;
-    constexpr int PSTRIDE = 80;                        // bytes per LDS pixel
-    constexpr int PITCH = W * PSTRIDE + 256;           // pitch/16 == 5*W (mod 16), >= (W+2) pixels
+    constexpr int PSTRIDE = B6 ? 112 : 80;             // bytes per LDS pixel
+    constexpr int PITCH = W * PSTRIDE + 256;           // pitch/16 == 5*W (B6: 7*W) (mod 16), >= (W+2) pixels
     constexpr int BUFB = C::NSLOT * PITCH;
     constexpr int NBUF = DB ? 2 : 1;
     constexpr int STAGE_SCRATCH = NBUF * BUFB + 16;    // 256 bytes behind the buffers take the writes of items with nothing to write
@@ -590,7 +615,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #ifndef LRPXH_APIPE_MIN_HW
 #define LRPXH_APIPE_MIN_HW 14
 #endif
-    constexpr bool APIPE = (HW >= LRPXH_APIPE_MIN_HW) && !F8;
+#ifndef LRPXB6_APIPE
+#define LRPXB6_APIPE 1
+#endif
+    constexpr bool APIPE = B6 ? (LRPXB6_APIPE != 0) : ((HW >= LRPXH_APIPE_MIN_HW) && !F8);
     // X6: the cross products as block-scaled fp6.  LDS pixel: 16 fp16 hi (32 B) | 32 fp6 e2m3 = x_0..x_15, then (x_c - hi_c) * 2^11,
     // c = 0..15, all divided by the slice's block scale 2^s (24 B) | E8M0 byte s - 11 + 127 (dword at byte 60; byte 56 stays clear so that the 8 + 4 byte reads do not fuse into a slower ds_read_b96) | pad.  A staging item is one
     // pixel's whole 16-channel slice (4 float4): the block maximum and v_cvt_scalef32_pk32_fp6_f16 need the 16 values in one lane.
@@ -692,8 +720,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             const unsigned g = (unsigned)((long)mtile * C::R) + q0t / (unsigned)HW;
             const int n0 = (int)(g / (unsigned)HW), nmax_ = a.n_maps - 1;
             const int na = min(n0, nmax_), nb = min(n0 + 1, nmax_);
-            tile_tab[tid * 4 + 0] = __builtin_bit_cast(int, exp2i(-split_scale_exp<F8>(in_amax[na])));
-            tile_tab[tid * 4 + 1] = __builtin_bit_cast(int, exp2i(-split_scale_exp<F8>(in_amax[nb])));
+            if constexpr (!B6) {
+                tile_tab[tid * 4 + 0] = __builtin_bit_cast(int, exp2i(-split_scale_exp<F8>(in_amax[na])));
+                tile_tab[tid * 4 + 1] = __builtin_bit_cast(int, exp2i(-split_scale_exp<F8>(in_amax[nb])));
+            }
             tile_tab[tid * 4 + 2] = a.map2img ? a.map2img[na] : n0;
             tile_tab[tid * 4 + 3] = a.map2img ? a.map2img[nb] : n0 + 1;
         }
@@ -747,7 +777,8 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     const int n_al = (int)((unsigned)g0 / (unsigned)H), y_al = (int)g0 - n_al * H;
     long img_al = 0;
     if constexpr (AL) {
-        ssc[0] = exp2i(split_scale_exp<F8>(in_amax[min(n_al, a.n_maps - 1)]));
+        ssc[0] = 1.f;
+        if constexpr (!B6) ssc[0] = exp2i(split_scale_exp<F8>(in_amax[min(n_al, a.n_maps - 1)]));
         if constexpr (POOL) img_al = a.map2img ? a.map2img[min(n_al, a.n_maps - 1)] : n_al;
     } else {
 #pragma unroll
@@ -765,7 +796,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 if ((v_ >= 0) && (y < H) && (n < a.n_maps)) {
                     sdst[u] = (s * PITCH + (px + 1) * PSTRIDE + seg * 8) | (seg << 28);
                     sgp[u] = (int)((n * H + y - (g0 - 1)) * W + px);     // relative to the row above the tile's first
-                    ssc[u] = exp2i(split_scale_exp<F8>(in_amax[n]));
+                    if constexpr (!B6) ssc[u] = exp2i(split_scale_exp<F8>(in_amax[n]));
                     if constexpr (POOL) {
                         const int lo = (y >> 1) * WO + (px >> 1);
                         const long img = a.map2img ? a.map2img[n] : n;
@@ -892,7 +923,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                     ldst[u] = ((s0 < 0 ? 0 : s0) * PITCH + (2 * pxl + 1) * PSTRIDE + seg * 8) | (seg << 28) | (rowmask << 26);
                     lgp[u] = (int)(n * (HO * WO) + lo);
                     lam[u] = (int)((img * (HO * WO) + lo) * a.cin);
-                    lsc[u] = exp2i(split_scale_exp<F8>(in_amax[n]));
+                    if constexpr (!B6) lsc[u] = exp2i(split_scale_exp<F8>(in_amax[n]));
                 }
             }
         }
@@ -987,7 +1018,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
         int dst_, gp_, amo_, rm_;                                                                            \
         float sc_;                                                                                           \
         item_lo(u, dst_, gp_, amo_, rm_, sc_);                                                               \
-        if constexpr (X6) { LRPXH_COMMIT_LO1_X6(u, BUFIDX) } else {                                          \
+        if constexpr (X6) { LRPXH_COMMIT_LO1_X6(u, BUFIDX) } else if constexpr (B6) { LRPXH_COMMIT_LO1_B6(u, BUFIDX) } else { \
         const f32x2_ xa_ = f32x2_{sv[u][0][0], sv[u][0][1]} * f32x2_{sc_, sc_}, xb_ = f32x2_{sv[u][0][2], sv[u][0][3]} * f32x2_{sc_, sc_}; \
         unsigned hw0_, hw1_, lw0_, lw1_;                                                                     \
         f32x2_ ha_, hb_;                                                                                     \
@@ -1018,6 +1049,26 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                 *reinterpret_cast<u32x2_*>(d_ + 32) = u32x2_{lw0_ & m01_, lw1_ & m23_};                      \
             }                                                                                                \
         }                                                                                                    \
+        }                                                                                                    \
+    }
+// B6: the three bf16 planes of the item's 4 channels, split once, then masked per window position (the masks of the fp16 path)
+#define LRPXH_COMMIT_LO1_B6(u, BUFIDX)                                                                       \
+    {                                                                                                        \
+        unsigned pa_[3], pb_[3];                                                                             \
+        split3_pk(f32x2_{sv[u][0][0], sv[u][0][1]}, pa_[0], pa_[1], pa_[2]);                                 \
+        split3_pk(f32x2_{sv[u][0][2], sv[u][0][3]}, pb_[0], pb_[1], pb_[2]);                                 \
+        const int o0_ = (BUFIDX) * BUFB + (dst_ & 0x03ffffff);                                               \
+        const int rb0_ = (rm_ & 1) ? o0_ : POOL_SCRATCH;                         /* window row dy = 0 */    \
+        const int rb1_ = (rm_ & 2) ? o0_ + ((rm_ & 1) ? PITCH : 0) : POOL_SCRATCH;                           \
+        _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {                                                \
+            const unsigned x_ = amv[u] ^ (0x01010101u * (unsigned)pos);       /* zero byte <=> winner == pos */ \
+            const unsigned eq_ = ((x_ | (x_ >> 1)) & 0x01010101u) ^ 0x01010101u;                             \
+            const unsigned bm_ = (eq_ << 8) - eq_;                            /* 0xff per winner byte */     \
+            const unsigned m01_ = __builtin_amdgcn_perm(bm_, bm_, 0x01010000u);                              \
+            const unsigned m23_ = __builtin_amdgcn_perm(bm_, bm_, 0x03030202u);                              \
+            char* d_ = ldsb + ((pos >> 1) ? rb1_ : rb0_) + (pos & 1) * PSTRIDE;                              \
+            _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_)                                              \
+                *reinterpret_cast<u32x2_*>(d_ + 32 * pl_) = u32x2_{pa_[pl_] & m01_, pb_[pl_] & m23_};        \
         }                                                                                                    \
     }
 // X6: the item is the whole 16-channel slice of a pooled pixel.  Split once; per window position the channels that did not win
@@ -1098,6 +1149,12 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
             *reinterpret_cast<u32x4_*>(d_ + 32) = u32x4_{q6_[0], q6_[1], q6_[2], q6_[3]};                    \
             *reinterpret_cast<u32x4_*>(d_ + 48) = u32x4_{q6_[4], q6_[5], 0u, sb_};                           \
             }                                                                                                \
+        } else if constexpr (B6) {                                                                           \
+            unsigned pa_[3], pb_[3];                                                                         \
+            split3_pk(f32x2_{sv[u][0][0], sv[u][0][1]}, pa_[0], pa_[1], pa_[2]);                             \
+            split3_pk(f32x2_{sv[u][0][2], sv[u][0][3]}, pb_[0], pb_[1], pb_[2]);                             \
+            _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_)                                              \
+                *reinterpret_cast<u32x2_*>(d_ + 32 * pl_) = u32x2_{pa_[pl_], pb_[pl_]};                      \
         } else {                                                                                             \
         const f32x2_ sc2_ = {ssc[AL ? 0 : u], ssc[AL ? 0 : u]};                                              \
         const f32x2_ xa_ = f32x2_{sv[u][0][0], sv[u][0][1]} * sc2_, xb_ = f32x2_{sv[u][0][2], sv[u][0][3]} * sc2_; \
@@ -1169,12 +1226,18 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #else
     // measured (tools/variant_sweep2.sh, chain of 320 maps): depth 2 -> 28.9 ms, 4 -> 26.9, 6 -> 25.9, 8 -> 25.0; the
     // map-straddling tiles (28/14) spill beyond 7
-    constexpr int NBQ = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : (((HW == 112 && NWN == 2) || (HOIST && !POOL)) ? 8 : 9));
+    constexpr int NBQ_H3 = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : (((HW == 112 && NWN == 2) || (HOIST && !POOL)) ? 8 : 9));
+    // B6: three planes per entry (12 registers)
+#ifndef LRPXB6_NBQ
+#define LRPXB6_NBQ ((HW <= 56) ? 5 : 4)
 #endif
-    const float inv_w = a.wp[0];
+    constexpr int NBQ = B6 ? LRPXB6_NBQ : NBQ_H3;
+#endif
+    float inv_w = 1.f;
+    if constexpr (!B6) inv_w = a.wp[0];
     // F8: one queue entry per tap ROW g = 7 planes of 64 lanes x 16 B: fp16 hi of dx = 0,1,2 | the B operands of fp8
     // MFMAs 2g and 2g+1 (2 planes each = the lane's two slots x 16 channels; row 2 has MFMA 4 only)
-    constexpr int BP = F8 ? 7 : 2;                  // planes per queue entry
+    constexpr int BP = F8 ? 7 : (B6 ? 3 : 2);       // planes per queue entry
     constexpr int BSTEPS = F8 ? 3 : TAPS;           // queue entries per K-chunk
     // measured (tools/variant_sweep3.sh, chain of 320 maps): 2 entries 24.1 ms, 3 entries 25.1 (spills), 4: 30.1; the
     // pooled-input 112 / 56 kernels have the registers for a third entry (2.39 -> 2.27 ms, 1.96 -> 1.89 ms)
@@ -1193,7 +1256,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // (a wave without a channel block of its own - n_oc not a multiple of the workgroup's channels - multiplies the last
     // valid block again and drops the result: one code path, see PRECISE below)
     const int ocb_w = wave_active ? ocb : (a.n_oc - 1) / 32;
-    const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) +
+    const u32x4_* wp = reinterpret_cast<const u32x4_*>(a.wp + (B6 ? 0 : F16X3_HEADER_FLOATS)) +
                        ((long)ocb_w * nchunk_all + c_begin) * (BSTEPS * BP * 64) + lane;
     const int last_step = nchunk * BSTEPS - 1;
     // plane p of queue entry `e`; X6: planes 4 and 6 hold 8 bytes of fp6 + the block-scale dword - 12 bytes, loaded as such
@@ -1491,6 +1554,58 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
                         for (int p = 0; p < BP; ++p) bq[i][p] = bq[i + 1][p];
                 }
                 }
+            } else if constexpr (B6) {
+            // six bf16 products per (tap, accumulator tile), smallest first; A fragments (three planes) one tile ahead of their MFMAs
+            bf16x8 n0, n1, n2;
+            if constexpr (APIPE) {
+                n0 = *reinterpret_cast<const bf16x8*>(abuf + abase[0]);
+                n1 = *reinterpret_cast<const bf16x8*>(abuf + abase[0] + 32);
+                n2 = *reinterpret_cast<const bf16x8*>(abuf + abase[0] + 64);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            }
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const long nxt = (long)min(chunk * TAPS + tap + NBQ - 1, last_step) * 3;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bq[NBQ - 1][p] = wp[(nxt + p) * 64];
+                if (tap == 0 && ISSUE_LATE) { __builtin_amdgcn_sched_barrier(0); LRPXH_ISSUE_NEXT }
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, bq[0][0]);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, bq[0][1]);
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, bq[0][2]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    bf16x8 a0, a1, a2;
+                    if constexpr (APIPE) {
+                        a0 = n0; a1 = n1; a2 = n2;
+                        if (!(tap == TAPS - 1 && j == 6)) {
+                            const int jn = (j + 1) % 7, tn = tap + (j == 6 ? 1 : 0);
+                            const char* apn = abuf + abase[jn] + (tn / 3) * PITCH + (tn % 3) * PSTRIDE;
+                            n2 = *reinterpret_cast<const bf16x8*>(apn + 64);
+                            n1 = *reinterpret_cast<const bf16x8*>(apn + 32);
+                            n0 = *reinterpret_cast<const bf16x8*>(apn);
+                        }
+                    } else {
+                        const char* ap = abuf + abase[j] + (tap / 3) * PITCH + (tap % 3) * PSTRIDE;
+                        a0 = *reinterpret_cast<const bf16x8*>(ap);
+                        a1 = *reinterpret_cast<const bf16x8*>(ap + 32);
+                        a2 = *reinterpret_cast<const bf16x8*>(ap + 64);
+                    }
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+                    if constexpr (APIPE) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the 3 reads of the NEXT tile ...
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... then the 6 MFMAs of this one
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NBQ - 1; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bq[i][p] = bq[i + 1][p];
+            }
             } else {
 #ifndef LRPXH_APIPE_D
 #define LRPXH_APIPE_D 1       // A fragments read this many accumulator tiles ahead of their MFMAs (non-F8 path: forward trace, mode 2)
@@ -1652,9 +1767,25 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #ifndef LRPXH_AL_EPI_H3
 #define LRPXH_AL_EPI_H3 1      // mode 2 (three fp16 products) too: round 5
 #endif
-    if constexpr ((X6 || (!F8 && (LRPXH_AL_EPI_H3 != 0))) && AL && (LRPXH_AL_EPI != 0) && !(HW == 112 && MT == 2) && (EPI == EPI_REL_MUL || EPI == EPI_GUIDED)) {
+    if constexpr ((X6 || (!F8 && (LRPXH_AL_EPI_H3 != 0))) && AL && (LRPXH_AL_EPI != 0) && !(HW == 112 && MT == 2 && !B6) && (EPI == EPI_REL_MUL || EPI == EPI_GUIDED)) {
         unsigned* __restrict__ oamax_a = (EPI == EPI_GUIDED) ? a.out0_amax : (a.out1 ? a.out1_amax : nullptr);
-        epi_rel_mul_al<HW, EPI, F8>(a, acc, wm, ocb, lane, g0, total_pix, oamax_a, inv_w, in_amax);
+        epi_rel_mul_al<HW, EPI, F8, false, B6>(a, acc, wm, ocb, lane, g0, total_pix, oamax_a, inv_w, in_amax);
+#ifdef LRPX_STAMP
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LRPXH_T(t_enda);
+            if (lane == 0 && HW == LRPX_STAMP_HW) {
+                atomicAdd(&g_stamp_h3[0], t_loop - t_start);
+                atomicAdd(&g_stamp_h3[1], s_issue);
+                atomicAdd(&g_stamp_h3[2], s_mfma);
+                atomicAdd(&g_stamp_h3[3], s_commit);
+                atomicAdd(&g_stamp_h3[4], s_barrier);
+                atomicAdd(&g_stamp_h3[5], t_enda - t_epi);
+                atomicAdd(&g_stamp_h3[6], t_enda - t_start);
+                atomicAdd(&g_stamp_h3[7], 1ull);
+            }
+        }
+#endif
         return;
     }
 #ifndef LRPXH_AL_FWD
@@ -1662,7 +1793,7 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #endif
     if constexpr (AL && (LRPXH_AL_FWD != 0) && EPI == EPI_FWD_DUAL) {
         if ((a.oc_split & 31) == 0) {                      // (uniform; every VGG16 layer)
-            epi_fwd_dual_al<HW, F8>(a, acc, wm, ocb, lane, g0, inv_w, in_amax);
+            epi_fwd_dual_al<HW, F8, B6>(a, acc, wm, ocb, lane, g0, inv_w, in_amax);
             return;
         }
     }
@@ -1684,7 +1815,9 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 
     // ---- undo the operand scales: acc * 2^-kA(map of the pixel) * 2^-kW ----
     const int nmax = a.n_maps - 1;
-    if constexpr (AL) {
+    if constexpr (B6) {
+        // exact splits: nothing to undo
+    } else if constexpr (AL) {
         const unsigned n = (unsigned)g0 / (unsigned)H;
         const float inv_a = exp2i(-split_scale_exp<F8>(in_amax[min((int)n, nmax)]));
 #pragma unroll
@@ -1823,10 +1956,11 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
 #endif
 }
 
-template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false>
+template <int HW, int MT, int NWN, bool DB, int EPI, bool POOL = false, bool F8 = false, bool B6 = false>
 int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
     using C = ConvCfg<HW, 16, MT, NWN, 9>;
-    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * 80 + 256) + 256 + 16 + 7 * MT * 16;     // buffers + scratch + tile table
+    constexpr int LDS = (DB ? 2 : 1) * C::NSLOT * (HW * (B6 ? 112 : 80) + 256) + 256 + 16 + 7 * MT * 16;     // buffers + scratch + tile table
+    static_assert(LDS <= 160 * 1024, "conv_f16x3: the tile does not fit the CU's LDS");
     const long m_tiles = ceil_div((long)a.n_maps * HW, C::R);
     const int n_blocks = (int)ceil_div(a.n_oc, 32 * NWN);
     long grid = ceil_div(m_tiles, 8) * 8 * n_blocks;
@@ -1835,7 +1969,7 @@ int launch_conv_f16x3(const ConvArgs& a, hipStream_t stream) {
         const long n_groups = (long)(a.n_maps / a.tile_group) * (HW / CC::R);
         grid = ceil_div(n_groups, 8) * 8 * a.tile_group * n_blocks;
     }
-    auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI, POOL, F8>;
+    auto kern = conv_f16x3_kernel<HW, MT, NWN, DB, EPI, POOL, F8, B6>;
     static LdsOnce attr_once;
     LRPX_TRY(reserve_lds_once(attr_once, kern, LDS, "conv_f16x3"));
     const unsigned ks = (EPI == EPI_PLAIN && a.ksplit > 1) ? (unsigned)a.ksplit : 1u;

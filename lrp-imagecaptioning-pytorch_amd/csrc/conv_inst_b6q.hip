@@ -1,0 +1,14 @@
+// conv mode 1 (B6) relevance kernels whose operand is unpooled while it is staged (conv_f16x3.h, POOL): conv3_3, conv4_3
+#include "conv_launch.h"
+#include "conv_f16x3.h"
+namespace lrpx {
+int launch_b6_56_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<56, 1, 4, true, EPI_REL_MUL, true, false, true>(a, s); }
+int launch_b6_28_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<28, 1, 4, true, EPI_REL_MUL, true, false, true>(a, s); }
+}
+#ifdef LRPX_STAMP
+extern "C" int lrpx_debug_stamps_b6q(unsigned long long* out12, int reset) {
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(lrpx::g_stamp_h3), 96) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lrpx::g_stamp_h3), z, 96) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

@@ -60,6 +60,18 @@ int launch_x6_56_fwd(const ConvArgs& a, hipStream_t s);
 int launch_x6_28_fwd(const ConvArgs& a, hipStream_t s);
 int launch_x6_14_fwd(const ConvArgs& a, hipStream_t s);
 
+// conv mode 1 on the conv_f16x3.h tiling (B6: exact bf16 splits, six products) with the fused multiplicand (REL_MUL) and pooled-input staging
+int launch_b6_224_rel(const ConvArgs& a, hipStream_t s);
+int launch_b6_112_rel(const ConvArgs& a, hipStream_t s);
+int launch_b6_112n_rel(const ConvArgs& a, hipStream_t s);
+int launch_b6_56_rel(const ConvArgs& a, hipStream_t s);
+int launch_b6_28_rel(const ConvArgs& a, hipStream_t s);
+int launch_b6_14_rel(const ConvArgs& a, hipStream_t s);
+int launch_b6_224_pool(const ConvArgs& a, hipStream_t s);
+int launch_b6_112_pool(const ConvArgs& a, hipStream_t s);
+int launch_b6_56_pool(const ConvArgs& a, hipStream_t s);
+int launch_b6_28_pool(const ConvArgs& a, hipStream_t s);
+
 int launch_h3_224_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_112_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_112n_rel(const ConvArgs& a, hipStream_t s);

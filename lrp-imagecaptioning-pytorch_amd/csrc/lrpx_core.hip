@@ -40,6 +40,7 @@ const Switches& switches() {
         w.dense_rt = num("LRPX_DENSE_RT", 0);
         w.dense_1wave = set("LRPX_DENSE_1WAVE");
         w.linear_valu = set("LRPX_LINEAR_VALU");
+        w.x6_legacy = set("LRPX_X6_LEGACY");
         return w;
     }();
     return sw;

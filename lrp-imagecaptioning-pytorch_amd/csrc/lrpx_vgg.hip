@@ -29,7 +29,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
     a.out0 = d->out0; a.out1 = d->out1;
     a.in_amax = d->in_amax; a.out1_amax = d->out1_amax; a.pool_am = d->pool_am; a.out0_amax = d->out0_amax;
     a.out_chunk = d->epi == EPI_REL_MUL ? d->out_chunk : 0;
-    a.tile_group = (d->f16x3 && d->tile_group > 1 && d->n_maps % d->tile_group == 0) ? d->tile_group : 0;
+    a.tile_group = ((d->f16x3 || (d->bf16x6 && d->epi == EPI_REL_MUL)) && d->tile_group > 1 && d->n_maps % d->tile_group == 0) ? d->tile_group : 0;
     a.ksplit = 1;
     // many rows (the (word, pixel) rules of the decoders): split products on the fp16 matrix cores (dense_f16x3.hip);
     // `wpacked` is then an lrpx_pack_weights_f16x2 blob (taps = 1) and `in_amax` holds max|in| per map
@@ -74,7 +74,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
         case EPI_FIRST: LRPX_REQUIRE(d->x && d->out0, "conv_mfma: FIRST needs x,out0"); break;
         case EPI_PLAIN: LRPX_REQUIRE(d->out0, "conv_mfma: PLAIN needs out0"); break;
         case EPI_GUIDED: LRPX_REQUIRE(d->out0 && d->x, "conv_mfma: GUIDED needs x,out0"); break;
-        case EPI_REL_MUL: LRPX_REQUIRE(d->x && d->f16x3 && (!d->out0 != !d->out1), "conv_mfma: REL_MUL is the f16x3 epilogue (needs x and exactly one of out0 / out1)"); break;
+        case EPI_REL_MUL: LRPX_REQUIRE(d->x && (d->f16x3 || d->bf16x6) && (!d->out0 != !d->out1), "conv_mfma: REL_MUL is the epilogue of the split-product kernels (f16x3 / bf16x6; needs x and exactly one of out0 / out1)"); break;
         default: LRPX_REQUIRE(false, "conv_mfma: epilogue %d not built", d->epi);
     }
     if (d->f16x3) {
@@ -206,6 +206,25 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
     }
     if (d->bf16x6) {
         LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0, "conv_mfma: bf16x6 needs a 3x3 conv, cin %% 16 == 0");
+        LRPX_REQUIRE(d->blocked == 0 && (!d->pool_am || d->epi == EPI_REL_MUL), "conv_mfma: bf16x6 takes NHWC tensors; pool_am needs the REL_MUL epilogue");
+        if (d->epi == EPI_REL_MUL && d->pool_am) {
+            // the conv sits under a 2x2 max-pool: `in` at the pool's output resolution, unpooled while staged (conv_f16x3.h, POOL + B6)
+            LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
+                         "conv_mfma: too many (image, pooled pixel, channel) elements for the pooled-input kernel");
+            if (d->hw == 224 && d->n_oc <= 64) return launch_b6_224_pool(a, s);
+            if (d->hw == 112 && d->n_oc > 64) return launch_b6_112_pool(a, s);
+            if (d->hw == 56) return launch_b6_56_pool(a, s);
+            if (d->hw == 28) return launch_b6_28_pool(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no pooled-input bf16x6 kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
+        if (d->epi == EPI_REL_MUL) {
+            if (d->hw == 224 && d->n_oc <= 64) return launch_b6_224_rel(a, s);
+            if (d->hw == 112) return d->n_oc <= 64 ? launch_b6_112n_rel(a, s) : launch_b6_112_rel(a, s);
+            if (d->hw == 56) return launch_b6_56_rel(a, s);
+            if (d->hw == 28) return launch_b6_28_rel(a, s);
+            if (d->hw == 14) return launch_b6_14_rel(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no bf16x6 REL_MUL kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
         if (d->epi == EPI_REL) {
             if (d->hw == 224) return launch_x6_224_rel(a, s);
             if (d->hw == 112) return d->n_oc <= 64 ? launch_x6_112n_rel(a, s) : launch_x6_112_rel(a, s);
@@ -294,7 +313,18 @@ int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, f
 // (lrpx_set_forward_f16).  Atomics: a setter racing with a call on another thread yields one of the two values, never a
 // torn one; callers that need a mode of their own pass it per call (lrpx_vgg16_opts, the *_ex entry points) and are not
 // affected by the setters at all.
-static std::atomic<int> g_default_mode{3};
+// Round 6: the process default is mode 1 - operands split EXACTLY into three bf16 parts (24 significand bits, fp32's exponent range),
+// six products, fp32 accumulate: arithmetic no narrower than the reference's fp32 convolutions (LRPtools/lrp_modules.py:124-150,
+// utils.py:21-31).  The faster modes 2 / 3 (fp16 split products behind per-map power-of-two scales; 22 / ~15 effective operand bits)
+// meet the 1e-4 contract on every tested input but are OPT-IN: lrpx_set_conv_mode, lrpx_vgg16_opts.conv_mode, or LRPX_CONV_MODE in the
+// environment (read once, at load).
+static int initial_mode() {
+    const char* v = getenv("LRPX_CONV_MODE");
+    if (!v || !*v) return 1;
+    const int m = atoi(v);
+    return m < 0 ? 0 : (m > 3 ? 3 : m);
+}
+static std::atomic<int> g_default_mode{initial_mode()};
 static std::atomic<int> g_default_fwd_f16{1};
 
 // what one call runs with: resolved once at entry from its opts (or the process defaults)
@@ -809,6 +839,11 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
     int cur_chunked = 0;   // S[cur] is stored in K-chunks (written so by the pool kernel for the 224^2 / 112^2 layers)
     // f16x3 mode: amax[l*n_maps + n] = bits of max|S| of map n in the S tensor that conv layer l consumes
     const bool h3 = mode >= 2;
+    // mode 1 (round 6): the same FUSED flow - REL_MUL epilogues on the precomputed multiplicands, convs under a pool unpool while they stage,
+    // no pool kernels, no unpooled tensors - on the exact bf16 splits (conv_f16x3.h, B6): no operand scales, hence no amax words.
+    // LRPX_X6_LEGACY=1 keeps round 1's flow (EPI_REL with the division in the epilogue + maxpool_relevance kernels) for A/B.
+    const bool b6 = mode == 1 && !switches().x6_legacy;
+    const bool fused = h3 || b6;
     unsigned* amax = h3 ? reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps) : nullptr;
     if (h3 && hipMemsetAsync(amax, 0, (size_t)kNL * n_maps * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
         set_error("vgg16_relevance: cannot zero the amax words");
@@ -821,7 +856,7 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
         LRPX_TRY(divide_stab_blocked(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, 196, 512, amax + (size_t)16 * n_maps,
                                      (hipStream_t)stream));
     else
-        LRPX_TRY(divide_stab_amax(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, h3 ? STAB_SAFE0 : STAB_SAFE,
+        LRPX_TRY(divide_stab_amax(r_feat_nhwc, tr + t.zpos[16], map2img, S[cur], n_maps, (long)196 * 512, fused ? STAB_SAFE0 : STAB_SAFE,
                                   h3 ? amax + (size_t)16 * n_maps : nullptr, (hipStream_t)stream));
     const bool timing = cx.layer_ms != nullptr;
     if (timing) LRPX_TRY(timer.begin());
@@ -850,12 +885,16 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
                                                     0, 1, (hipStream_t)stream));
             else
                 LRPX_TRY(first_layer_relevance(S[cur], pk + p.first6, tr + t.act[0], map2img, out_nchw, n_maps, L.cout, 0,
-                                               h3 ? 1 : 0, (hipStream_t)stream));
+                                               fused ? 1 : 0, (hipStream_t)stream));
             if (timing) { (void)hipEventRecord(timer.ev[0][1], (hipStream_t)stream); timer.valid[0] = true; }
             break;
         }
         d.n_oc = L.cin; d.epi = EPI_REL; d.oc_split = L.cin;
-        if (h3) {
+        if (b6) {
+            d.bf16x6 = 1; d.epi = EPI_REL_MUL; d.wpacked = pk + p.bwd6[l];
+            d.tile_group = (n_maps % n_img == 0) ? n_maps / n_img : 0;
+            if (l + 1 < kNL && !kVgg[l + 1].conv) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
+        } else if (h3) {
             d.f16x3 = 1; d.epi = EPI_REL_MUL; d.wpacked = pk + p.bwdh[l]; d.in_amax = amax + (size_t)l * n_maps;
             // the maps of one image (the words of its caption) usually follow each other: tile-order hint for the
             // multiplicand reuse in L2 (a wrong guess only costs the reuse)
@@ -868,25 +907,25 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
             // blocked: in (1), x (2), out (4); conv1_2 (l == 1): blocked input only (see conv_f16x3.h, TR)
             if (blk) d.blocked = l == 1 ? 1 : 7;
         }
-        else if (use_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // fp32-accurate bf16 matrix-core path
+        else if (use_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // round 1's flow (LRPX_X6_LEGACY): EPI_REL, pool kernels
         if (kVgg[l - 1].conv) {
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
             d.out1 = S[cur ^ 1];
-            if (h3) { d.x = tr + ((blk && l != 1) ? t.xzp[l] : t.xz[l]); d.out1_amax = amax + (size_t)(l - 1) * n_maps; }   // x / safe(Z+) precomputed
+            if (fused) { d.x = tr + ((blk && l != 1) ? t.xzp[l] : t.xz[l]); if (h3) d.out1_amax = amax + (size_t)(l - 1) * n_maps; }   // x / safe(Z+) precomputed
             // the first-layer kernel walks S in channel chunks (MFMA version: 32 = whole 128-byte lines per pixel; VALU: 16)
-            const int fl_chunk = (!blk && switches().first_valu) ? 16 : 32;
-            if (h3 && l == 1) d.out_chunk = fl_chunk;
-            else if (!blk) { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
+            const int fl_chunk = (b6 || (!blk && switches().first_valu)) ? 16 : 32;
+            if (fused && l == 1) d.out_chunk = fl_chunk;
+            else if (!blk && !b6) { d.zdiv = tr + t.zpos[l - 1]; d.stab = STAB_SAFE; }
             // mode 2, conv2_2 -> conv2_1: S in 16-channel chunks, the K-chunk of the consumer (64-byte slices of 512-byte NHWC pixels
             // drag every 128-byte line through the fabric twice: FETCH 3.1x the tensor; chunked: conv2_1 1.44 -> 1.37 ms)
             const int s21_chunk = switches().s21_nhwc ? 0 : 16;
-            if (h3 && !blk && l == 4 && s21_chunk) { d.out_chunk = s21_chunk; cur_chunked = 1; }
+            if (fused && !blk && l == 4 && s21_chunk) { d.out_chunk = s21_chunk; cur_chunked = 1; }
             LRPX_TIMED_DISPATCH(l, &d);
         } else {
-            if (h3) {
+            if (fused) {
                 // a pool lies below: x = max / safe(Z+ at the winner) turns the accumulator straight into S of the conv
                 // under the pool (at the winners); that conv unpools it while staging - no pool kernel, no 4x tensor
-                d.x = tr + (blk ? t.xzp[l] : t.xz[l]); d.out1 = S[cur ^ 1]; d.out1_amax = amax + (size_t)(l - 2) * n_maps;
+                d.x = tr + (blk ? t.xzp[l] : t.xz[l]); d.out1 = S[cur ^ 1]; if (h3) d.out1_amax = amax + (size_t)(l - 2) * n_maps;
                 LRPX_TIMED_DISPATCH(l, &d);
                 cur ^= 1;
                 continue;
