@@ -71,6 +71,20 @@ int launch_b6_224_pool(const ConvArgs& a, hipStream_t s);
 int launch_b6_112_pool(const ConvArgs& a, hipStream_t s);
 int launch_b6_56_pool(const ConvArgs& a, hipStream_t s);
 int launch_b6_28_pool(const ConvArgs& a, hipStream_t s);
+int launch_b6_112n_guided(const ConvArgs& a, hipStream_t s);   // ... image-gradient chains (GUIDED: guided backprop / plain gradient)
+int launch_b6_56_guided(const ConvArgs& a, hipStream_t s);
+int launch_b6_28_guided(const ConvArgs& a, hipStream_t s);
+int launch_b6_14_guided(const ConvArgs& a, hipStream_t s);
+int launch_b6_224_pool_guided(const ConvArgs& a, hipStream_t s);
+int launch_b6_112_pool_guided(const ConvArgs& a, hipStream_t s);
+int launch_b6_56_pool_guided(const ConvArgs& a, hipStream_t s);
+int launch_b6_28_pool_guided(const ConvArgs& a, hipStream_t s);
+int launch_b6_224_fwd(const ConvArgs& a, hipStream_t s);       // ... forward trace (FWD_DUAL; 14 x 14: K-split PLAIN)
+int launch_b6_112_fwd(const ConvArgs& a, hipStream_t s);
+int launch_b6_56_fwd(const ConvArgs& a, hipStream_t s);
+int launch_b6_28_fwd(const ConvArgs& a, hipStream_t s);
+int launch_b6_14_fwd(const ConvArgs& a, hipStream_t s);
+int launch_b6_14_plain(const ConvArgs& a, hipStream_t s);
 
 int launch_h3_224_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_112_rel(const ConvArgs& a, hipStream_t s);

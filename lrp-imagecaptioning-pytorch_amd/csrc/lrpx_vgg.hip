@@ -29,7 +29,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
     a.out0 = d->out0; a.out1 = d->out1;
     a.in_amax = d->in_amax; a.out1_amax = d->out1_amax; a.pool_am = d->pool_am; a.out0_amax = d->out0_amax;
     a.out_chunk = d->epi == EPI_REL_MUL ? d->out_chunk : 0;
-    a.tile_group = ((d->f16x3 || (d->bf16x6 && d->epi == EPI_REL_MUL)) && d->tile_group > 1 && d->n_maps % d->tile_group == 0) ? d->tile_group : 0;
+    a.tile_group = ((d->f16x3 || (d->bf16x6 && (d->epi == EPI_REL_MUL || d->epi == EPI_GUIDED))) && d->tile_group > 1 && d->n_maps % d->tile_group == 0) ? d->tile_group : 0;
     a.ksplit = 1;
     // many rows (the (word, pixel) rules of the decoders): split products on the fp16 matrix cores (dense_f16x3.hip);
     // `wpacked` is then an lrpx_pack_weights_f16x2 blob (taps = 1) and `in_amax` holds max|in| per map
@@ -206,7 +206,29 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
     }
     if (d->bf16x6) {
         LRPX_REQUIRE(d->taps == 9 && d->cin % 16 == 0, "conv_mfma: bf16x6 needs a 3x3 conv, cin %% 16 == 0");
-        LRPX_REQUIRE(d->blocked == 0 && (!d->pool_am || d->epi == EPI_REL_MUL), "conv_mfma: bf16x6 takes NHWC tensors; pool_am needs the REL_MUL epilogue");
+        LRPX_REQUIRE(d->blocked == 0 && (!d->pool_am || d->epi == EPI_REL_MUL || d->epi == EPI_GUIDED),
+                     "conv_mfma: bf16x6 takes NHWC tensors; pool_am needs the REL_MUL or GUIDED epilogue");
+        a.ksplit = (d->epi == EPI_PLAIN && f16_ksplit > 1 && (d->cin / 16) % f16_ksplit == 0) ? f16_ksplit : 1;
+        if (d->epi == EPI_GUIDED && d->pool_am) {
+            LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
+                         "conv_mfma: too many (image, pooled pixel, channel) elements for the pooled-input kernel");
+            if (d->hw == 224 && d->n_oc <= 64) return launch_b6_224_pool_guided(a, s);
+            if (d->hw == 112 && d->n_oc > 64) return launch_b6_112_pool_guided(a, s);
+            if (d->hw == 56) return launch_b6_56_pool_guided(a, s);
+            if (d->hw == 28) return launch_b6_28_pool_guided(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no pooled-input bf16x6 GUIDED kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
+        if (d->epi == EPI_GUIDED) {
+            if (d->hw == 112 && d->n_oc <= 64) return launch_b6_112n_guided(a, s);
+            if (d->hw == 56) return launch_b6_56_guided(a, s);
+            if (d->hw == 28) return launch_b6_28_guided(a, s);
+            if (d->hw == 14) return launch_b6_14_guided(a, s);
+            LRPX_REQUIRE(false, "conv_mfma: no bf16x6 GUIDED kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
+        }
+        if (d->epi == EPI_PLAIN) {
+            LRPX_REQUIRE(d->hw == 14 && !d->relu && !d->bias, "conv_mfma: the bf16x6 PLAIN kernel is built for 14x14 maps, no bias / ReLU (the K-split forward)");
+            return launch_b6_14_plain(a, s);
+        }
         if (d->epi == EPI_REL_MUL && d->pool_am) {
             // the conv sits under a 2x2 max-pool: `in` at the pool's output resolution, unpooled while staged (conv_f16x3.h, POOL + B6)
             LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
@@ -231,6 +253,13 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
             if (d->hw == 56) return launch_x6_56_rel(a, s);
             if (d->hw == 28) return launch_x6_28_rel(a, s);
             if (d->hw == 14) return launch_x6_14_rel(a, s);
+        }
+        if (d->epi == EPI_FWD_DUAL && !switches().x6_legacy && (d->oc_split & 31) == 0) {
+            if (d->hw == 224) return launch_b6_224_fwd(a, s);
+            if (d->hw == 112) return launch_b6_112_fwd(a, s);
+            if (d->hw == 56) return launch_b6_56_fwd(a, s);
+            if (d->hw == 28) return launch_b6_28_fwd(a, s);
+            if (d->hw == 14) return launch_b6_14_fwd(a, s);
         }
         if (d->epi == EPI_FWD_DUAL) {
             if (d->hw == 112) return launch_x6_112_fwd(a, s);
@@ -347,7 +376,7 @@ static thread_local int tl_timing = 0;
 static thread_local float tl_ms[17];
 
 struct VggPacked {   // offsets in floats into the packed blob
-    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], fwdh0, first6, first6p, first16, first16p, total;
+    size_t fwd[17], bwd[17], bwdp[17], bwd6[17], bwdp6[17], bwdh[17], bwdph[17], bwd8[17], bwdp8[17], fwd6[17], fwdh[17], bias[17], fwdh0, first6, first6p, first16, first16p, total;
     size_t chs[17];      // per-output-channel balance factors rs_l[c] of conv l (powers of two, see lrpx_vgg16_pack)
     size_t spread;       // [17] per conv layer: largest ratio of row maxima max|W[c,:]| inside one 16-row K slice (lrpx_vgg16_row_spread)
     size_t scratch;      // scaled weight copies while packing: cout*cin*9 + 2*cout*2*cin*9 floats of the largest layer
@@ -356,7 +385,7 @@ static VggPacked vgg_packed_layout() {
     VggPacked p;
     size_t off = 0;
     for (int l = 0; l < kNL; ++l) {
-        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdh[l] = p.bwdph[l] = p.bwd8[l] = p.bwdp8[l] = p.fwd6[l] = p.fwdh[l] = p.bias[l] = 0;
+        p.fwd[l] = p.bwd[l] = p.bwdp[l] = p.bwd6[l] = p.bwdp6[l] = p.bwdh[l] = p.bwdph[l] = p.bwd8[l] = p.bwdp8[l] = p.fwd6[l] = p.fwdh[l] = p.bias[l] = 0;
         if (!kVgg[l].conv) continue;
         const VggLayer& L = kVgg[l];
         p.fwd[l] = off; off += lrpx_packed_floats(2 * L.cout, cin_pad(l), 9, lrpx_conv_kc(L.hw, 9, cin_pad(l)));
@@ -364,12 +393,13 @@ static VggPacked vgg_packed_layout() {
         p.bias[l] = off; off += (size_t)L.cout;
         if (l > 0) { p.bwdp[l] = off; off += lrpx_packed_floats(L.cin, L.cout, 9, lrpx_conv_kc(L.hw, 9, L.cout)); }
         if (l > 0) { p.bwd6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float); }
+        if (l > 0) { p.bwdp6[l] = off; off += lrpx_packed_bf16x3_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (l > 0) { p.bwdh[l] = off; off += lrpx_packed_f16x2_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (l > 0) { p.fwdh[l] = off; off += lrpx_packed_f16x2_bytes(2 * L.cout, L.cin, 9) / sizeof(float); }
         if (l > 0) { p.bwdph[l] = off; off += lrpx_packed_f16x2_bytes(L.cin, L.cout, 9) / sizeof(float); }
         if (l > 0) { p.bwd8[l] = off; off += lrpx_packed_f16f8_bytes(L.cin, L.cout) / sizeof(float); }
         if (l > 0) { p.bwdp8[l] = off; off += lrpx_packed_f16f8_bytes(L.cin, L.cout) / sizeof(float); }
-        if (L.hw <= 112) {
+        if (l > 0) {
             p.fwd6[l] = off; off += lrpx_packed_bf16x3_bytes(2 * L.cout, L.cin, 9) / sizeof(float);
         }
     }
@@ -619,9 +649,8 @@ int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, 
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16x2(w_plain, L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, base + p.bwdph[l], stream));
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16f8(wr, L.cout, L.cin, LRPX_PACK_BWD_POS, base + p.bwd8[l], stream));
         if (l > 0) LRPX_TRY(lrpx_pack_weights_f16f8(w_plain, L.cout, L.cin, LRPX_PACK_BWD_PLAIN, base + p.bwdp8[l], stream));
-        if (L.hw <= 112) {
-            LRPX_TRY(lrpx_pack_weights_bf16x3(wd, 2 * L.cout, L.cin, 9, LRPX_PACK_FWD, base + p.fwd6[l], stream));
-        }
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_bf16x3(wd, 2 * L.cout, L.cin, 9, LRPX_PACK_FWD, base + p.fwd6[l], stream));
+        if (l > 0) LRPX_TRY(lrpx_pack_weights_bf16x3(w_plain, L.cout, L.cin, 9, LRPX_PACK_BWD_PLAIN, base + p.bwdp6[l], stream));
         ++ci;
     }
     return LRPX_OK;
@@ -740,7 +769,22 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
                                              (long)L.hw * L.hw, L.cout, fam + (size_t)(l + 1) * n_img, (hipStream_t)stream));
                     continue;
                 }
-            } else if (use_bf16x6 && L.hw <= 112) { d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l]; }
+            } else if (use_bf16x6 && (L.hw <= 112 || (l > 0 && !switches().x6_legacy))) {
+                // mode 1: exact bf16 splits (round 6: conv1_2 too, and the 14 x 14 layers K-split as in the f16x3 forward - the decision
+                // depends on the layer only, never on the batch)
+                d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l];
+                const int fwd_ks = (L.hw == 14 && !switches().x6_legacy) ? switches().fwd_ksplit14 : 1;
+                if (fwd_ks > 1 && (fwd_ks & (fwd_ks - 1)) == 0 && fwd_ks <= 16 && (L.cin / 16) % fwd_ks == 0 &&
+                    (size_t)fwd_ks * L.hw * L.hw * 2 * L.cout <= (size_t)224 * 224 * 64) {
+                    float* part = tr + t.xz[1];
+                    d.epi = EPI_PLAIN; d.bias = nullptr; d.oc_split = 2 * L.cout;
+                    d.out0 = part; d.out1 = nullptr;
+                    LRPX_TRY(conv_dispatch(&d, (hipStream_t)stream, fwd_ks));
+                    LRPX_TRY(fwd_dual_finish(part, fwd_ks, pk + p.bias[l], tr + t.act[l + 1], tr + t.zpos[l], n_img,
+                                             (long)L.hw * L.hw, L.cout, nullptr, (hipStream_t)stream));
+                    continue;
+                }
+            }
             if (fwd_f16 && mode >= 2 && l == 0) {
                 unsigned* fam = reinterpret_cast<unsigned*>(tr + t.famax);
                 d.out0_amax = fam + (size_t)1 * n_img;       // per-image maximum of the activations: conv1_2's fp16 scale
@@ -985,6 +1029,8 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
     // tensor conv layer l consumes - recorded by whoever writes that tensor (the GUIDED epilogue of the conv above, the
     // pool backward kernel); only the first tensor costs a streaming read of its own
     const bool h3 = mode >= 2;
+    // mode 1 (round 6): exact bf16 splits on the conv_f16x3.h tiling (B6), GUIDED hooks fused, pools folded into the staging as in mode 3
+    const bool b6 = mode == 1 && !switches().x6_legacy && !switches().guided_poolbwd;
     unsigned* gam = reinterpret_cast<unsigned*>(R + (size_t)112 * 112 * 64 * n_maps);
     if (h3) {
         if (hipMemsetAsync(gam, 0, (size_t)kNL * n_maps * sizeof(unsigned), st) != hipSuccess) {
@@ -1012,23 +1058,26 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
             d.f16x3 = 1; d.wpacked = pk + p.bwdph[l]; d.in_amax = gam + (size_t)l * n_maps;
             d.tile_group = (n_maps % n_img == 0) ? n_maps / n_img : 0;        // (tile-order hint, as in the relevance chain)
             if (mode == 3) { d.f16x3 = 2; d.wpacked = pk + p.bwdp8[l]; }      // cross products on the fp8 matrix cores
+        } else if (b6) {
+            d.bf16x6 = 1; d.wpacked = pk + p.bwdp6[l];
+            d.tile_group = (n_maps % n_img == 0) ? n_maps / n_img : 0;
         }
         // mode 3: a conv under a pool receives the gradient at the pool's OUTPUT resolution and routes it to the windows'
         // arg-max while staging (the winner bytes of the trace, as the relevance chain): no pool-backward kernel, no 4x tensor
         const int gpool = switches().guided_poolbwd ? 0 : 1;
-        const bool lowres_in = gpool && mode == 3 && l + 1 < kNL && !kVgg[l + 1].conv && l + 2 < kNL;
+        const bool lowres_in = gpool && (mode == 3 || b6) && l + 1 < kNL && !kVgg[l + 1].conv && l + 2 < kNL;
         if (lowres_in) d.pool_am = (const uint8_t*)(tr + t.am[l + 1]);
         if (kVgg[l - 1].conv) {
             d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];      // ReLU hook of conv l-1 fused
             d.relu = plain ? 2 : 0;
             if (h3) d.out0_amax = gam + (size_t)(l - 1) * n_maps;
             LRPX_TRY(conv_dispatch(&d, st));
-        } else if (gpool && mode == 3 && l >= 2) {
+        } else if (gpool && (mode == 3 || b6) && l >= 2) {
             // a pool lies below: the pool backward's gate [max > 0] (and the guided clamp) is the GUIDED hook on the pool's
             // OUTPUT (= this conv's input, act[l]); the conv under the pool unpools while staging
             d.epi = EPI_GUIDED; d.x = tr + t.act[l]; d.out0 = G[cur ^ 1];
             d.relu = plain ? 2 : 0;
-            d.out0_amax = gam + (size_t)(l - 2) * n_maps;
+            if (h3) d.out0_amax = gam + (size_t)(l - 2) * n_maps;
             LRPX_TRY(conv_dispatch(&d, st));
         } else {
             d.epi = EPI_PLAIN; d.out0 = R;

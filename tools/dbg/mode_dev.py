@@ -13,6 +13,15 @@ sd = weights.make_gridtd_state(seed=0, vocab_size=64)
 names = [k for k in sd if k.startswith("img_encoder.encoder.") and k.endswith(".weight")]
 vgg = ops.Vgg16([torch.from_numpy(sd[k]).cuda() for k in names], [torch.from_numpy(sd[k.replace(".weight", ".bias")]).cuda() for k in names])
 img = torch.from_numpy(weights.make_images(0, images)).cuda()
+f0 = vgg.forward(img).clone()
+lib.lrpx_set_conv_mode(mode)
+import time
+f1 = vgg.forward(img).clone()
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(3): vgg.forward(img)
+torch.cuda.synchronize(); t_f = (time.time() - t0) / 3
+print(f"forward features mode {mode} vs mode 0: max diff {((f1 - f0).abs().max() / f0.abs().max()).item():.3e} of the maximum; forward {t_f * 1e3:.2f} ms for {images} images", flush=True)
+lib.lrpx_set_conv_mode(0)
 vgg.forward(img)
 torch.manual_seed(0)
 r_feat = torch.randn(maps, 196, 512, device="cuda")
