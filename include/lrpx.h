@@ -216,8 +216,13 @@ int lrpx_set_bf16x6(int enable);
  * contract on every tested input).  LRPX_CONV_MODE in the environment sets the initial default (read once at load).
  * Negative: query only.  Returns the previous mode. */
 int lrpx_set_conv_mode(int mode);
-/* 1: the forward trace of conv1_2..conv5_3 also runs on the fp16 split-product kernels (operand scale = per-image maximum of
- * the layer input); 0: bf16x6 / fp32 as selected by the conv mode.  Negative: query.  Returns the previous value. */
+/* 1 (conv modes 2 / 3 only): the forward trace of conv1_1..conv5_3 also runs on the fp16 split-product kernels (operand scale =
+ * per-image maximum of the layer input).  RANGE CONTRACT of that switch: inputs more than ~2^29 below their image's maximum
+ * flush to zero; a receptive field made only of such inputs gets Z+ = 0 and the relevance arriving there is dropped, where the
+ * reference (LRPtools/utils.py:16-18 stabilises exact zeros only) redistributes it (tests/test_gpu_range.py).
+ * 0 (THE DEFAULT since round 6, every conv mode): exact kernels - fp32 MFMA for conv1_1, exact bf16 splits (fp32's exponent
+ * range) above; conv mode 0: fp32 MFMA throughout.  LRPX_FORWARD_F16 in the environment sets the initial default.
+ * Negative: query.  Returns the previous value. */
 int lrpx_set_forward_f16(int enable);
 
 /* ---- device-side consumers of the relevance maps (evaluation.py) -------------------------- */
