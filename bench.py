@@ -602,8 +602,6 @@ def run_config(a, dist, rank, world):
         shape = {"maps": (B * T, 3, 224, 224), "heatmap": (B * T, 224, 224), "stats": (B * T, 4)}[a.gather]
         og = shard.OverlappedGather(shape, device="cpu" if gloo else "cuda", depth=n_pipe + 1,
                                     mode="gather" if a.gather == "maps" else "all_gather")
-        if gloo:
-            og.stage = [t_.pin_memory() for t_ in og.stage]
 
     def gather_maps(m):
         """the terminal collective of north_star: every rank's (reduced) maps travel from a side stream (RCCL over xGMI; device tensors

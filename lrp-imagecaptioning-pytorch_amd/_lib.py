@@ -242,6 +242,25 @@ def check(rc):
     raise LrpxError(f"lrpx error {rc}: {msg}")
 
 
+_get_dev = None
+
+
+def _same_device(t):
+    """a tensor of another GPU than the thread's current one would meet a stream (stream_ptr: the CURRENT device's) and kernels of the
+    wrong device - the same class of wrong-address fault as a host pointer; the C ABI checks it again (check_dev_ptrs)"""
+    global _get_dev
+    if _get_dev is None:
+        import torch
+        # one visible GPU (one process per GPU behind HIP_VISIBLE_DEVICES): nothing to confuse, and the check costs ~0.25 us on each of
+        # the ~10 pointers of a 5-us decoder launch
+        _get_dev = (getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device) if torch.cuda.device_count() > 1 else False
+    if _get_dev is False:
+        return
+    cur = _get_dev()
+    if t.device.index is not None and t.device.index != cur:
+        raise ValueError("lrpx: tensor on cuda:%d, the current device is cuda:%d (torch.cuda.set_device / a device context first)" % (t.device.index, cur))
+
+
 def ptr(t):
     """Device pointer of a contiguous torch tensor (or None)."""
     if t is None:
@@ -250,6 +269,7 @@ def ptr(t):
     # mapped (round 5: a test that passed CPU images aborted the process in two of three sessions): refuse it here, loudly
     if not t.is_cuda:
         raise TypeError("lrpx kernels take CUDA tensors (got a %s tensor): there is no CPU path" % t.device.type)
+    _same_device(t)
     assert t.is_contiguous(), "lrpx needs contiguous tensors"
     return C.c_void_p(t.data_ptr())
 
@@ -258,6 +278,9 @@ def ptr_at(t, offset_elems=0):
     """Device pointer of t's storage start + offset (for strided row views)."""
     if not t.is_cuda:
         raise TypeError("lrpx kernels take CUDA tensors (got a %s tensor): there is no CPU path" % t.device.type)
+    _same_device(t)
+    if t.element_size() != 4:
+        raise TypeError("ptr_at counts 4-byte elements (got %s)" % t.dtype)
     return C.c_void_p(t.data_ptr() + 4 * offset_elems)
 
 

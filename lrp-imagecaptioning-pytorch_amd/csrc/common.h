@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <initializer_list>
 #include <mutex>
 
 #include "../../include/lrpx.h"
@@ -35,6 +36,22 @@ inline int check_launch(const char* what) {
     do {                             \
         int rc__ = (expr);           \
         if (rc__ != LRPX_OK) return rc__; \
+    } while (0)
+
+// ---- caller pointers ------------------------------------------------------------------------------------------
+// The C ABI takes raw device pointers; a pageable host pointer (a CPU tensor's data_ptr) handed to a kernel is a GPU page fault, not
+// an error code.  check_dev_ptrs asks the runtime what each non-null pointer is (hipPointerGetAttributes, ~1 us each): device /
+// managed memory of the CURRENT device or pinned host memory pass; anything else returns LRPX_EINVAL with the entry point and the
+// argument's name in lrpx_last_error_string().  The heavy entry points (milliseconds of work: the VGG16 chains, the packers, the
+// layout converters, the rule classes' kernels) validate on every call; the microsecond-scale decoder steps only when
+// LRPX_CHECK_PTRS=1 is in the environment (latched at first use).
+struct PtrArg { const void* p; const char* name; };
+int check_dev_ptrs(const char* fn, std::initializer_list<PtrArg> args);     // (lrpx_core.hip)
+bool ptr_checks_all();
+#define LRPX_CHECK_PTRS(fn, ...) LRPX_TRY(lrpx::check_dev_ptrs(fn, {__VA_ARGS__}))
+#define LRPX_CHECK_PTRS_OPT(fn, ...)                                                   \
+    do {                                                                               \
+        if (lrpx::ptr_checks_all()) LRPX_TRY(lrpx::check_dev_ptrs(fn, {__VA_ARGS__})); \
     } while (0)
 
 // elementwise producers of S that also record max|S| per map for an f16x3 consumer (lrpx_core.hip)
@@ -96,6 +113,8 @@ struct Switches {
     int dense_rt;        // LRPX_DENSE_RT (default 0 = by the grid): row tiles per wave of that kernel, 4 (128-row tiles) or 3 (96-row tiles)
     int dense_1wave;     // LRPX_DENSE_1WAVE: PLAIN few-row GEMMs without the 4-wave K split
     int linear_valu;     // LRPX_LINEAR_VALU: the VALU skinny linear instead of the fp32-MFMA one
+    int b6_fwd_ksplit28; // LRPX_B6_FWD_KSPLIT28 (default 4): K ranges per tile of the 28x28 layers of the exact-split (conv mode 1) forward trace
+    int b6_fwd_ksplit56; // LRPX_B6_FWD_KSPLIT56 (default 2): ... of the 56x56 layers
     int x6_legacy;       // LRPX_X6_LEGACY: conv mode 1 on round 1's flow (conv_bf16x6.h with EPI_REL + pool kernels) instead of the fused B6 kernels
 };
 const Switches& switches();      // (lrpx_core.hip)

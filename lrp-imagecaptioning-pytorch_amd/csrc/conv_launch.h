@@ -85,6 +85,8 @@ int launch_b6_56_fwd(const ConvArgs& a, hipStream_t s);
 int launch_b6_28_fwd(const ConvArgs& a, hipStream_t s);
 int launch_b6_14_fwd(const ConvArgs& a, hipStream_t s);
 int launch_b6_14_plain(const ConvArgs& a, hipStream_t s);
+int launch_b6_28_plain(const ConvArgs& a, hipStream_t s);
+int launch_b6_56_plain(const ConvArgs& a, hipStream_t s);
 
 int launch_h3_224_rel(const ConvArgs& a, hipStream_t s);
 int launch_h3_112_rel(const ConvArgs& a, hipStream_t s);

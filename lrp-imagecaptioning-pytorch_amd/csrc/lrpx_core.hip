@@ -22,6 +22,38 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+bool ptr_checks_all() {
+    static const bool on = [] { const char* v = getenv("LRPX_CHECK_PTRS"); return v && *v && atoi(v) != 0; }();
+    return on;
+}
+
+int check_dev_ptrs(const char* fn, std::initializer_list<PtrArg> args) {
+    int dev = -1;
+    for (const PtrArg& a : args) {
+        if (!a.p) continue;                      // (null is the entry point's own business: optional arguments exist)
+        hipPointerAttribute_t at;
+        const hipError_t e = hipPointerGetAttributes(&at, a.p);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();             // (the failed query must not surface as the next launch's error)
+            set_error("%s: argument `%s` = %p is not memory the GPU can address (a pageable host pointer?): %s", fn, a.name, a.p, hipGetErrorString(e));
+            return LRPX_EINVAL;
+        }
+        if (at.type == hipMemoryTypeHost) continue;          // pinned host memory: device-accessible
+        if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged && at.type != hipMemoryTypeUnified) {
+            set_error("%s: argument `%s` = %p is not device memory (hipPointerGetAttributes: type %d - a pageable host pointer?)", fn, a.name, a.p, (int)at.type);
+            return LRPX_EINVAL;
+        }
+        if (at.type == hipMemoryTypeDevice) {
+            if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;
+            if (dev >= 0 && at.device != dev) {
+                set_error("%s: argument `%s` = %p lives on device %d, the calling thread's current device is %d", fn, a.name, a.p, at.device, dev);
+                return LRPX_EINVAL;
+            }
+        }
+    }
+    return LRPX_OK;
+}
+
 const Switches& switches() {
     static const Switches sw = [] {
         auto num = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
@@ -41,6 +73,8 @@ const Switches& switches() {
         w.dense_1wave = set("LRPX_DENSE_1WAVE");
         w.linear_valu = set("LRPX_LINEAR_VALU");
         w.x6_legacy = set("LRPX_X6_LEGACY");
+        w.b6_fwd_ksplit28 = num("LRPX_B6_FWD_KSPLIT28", 4);
+        w.b6_fwd_ksplit56 = num("LRPX_B6_FWD_KSPLIT56", 2);
         return w;
     }();
     return sw;
@@ -905,6 +939,7 @@ size_t lrpx_packed_floats(int n_oc, int k, int taps, int kc) {
 }
 
 int lrpx_pack_weights(const float* w, int cout, int cin, int taps, int mode, int kc, float* packed, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_pack_weights", {w, "w"}, {packed, "packed"});
     LRPX_REQUIRE(w && packed, "pack_weights: null pointer");
     LRPX_REQUIRE(taps == 9 || taps == 1, "pack_weights: taps must be 1 or 9");
     LRPX_REQUIRE(kc == 8 || kc == 16 || kc == 32, "pack_weights: kc must be 8, 16 or 32");
@@ -922,6 +957,7 @@ size_t lrpx_packed_bf16x3_bytes(int n_oc, int k, int taps) {
 }
 
 int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_pack_weights_bf16x3", {w, "w"}, {packed, "packed"});
     LRPX_REQUIRE(w && packed && taps == 9, "pack_weights_bf16x3: bad arguments (3x3 kernels only)");
     LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN || mode == LRPX_PACK_FWD ||
                      mode == LRPX_PACK_FWD_DUAL, "pack_weights_bf16x3: mode %d not supported", mode);
@@ -934,6 +970,7 @@ int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mo
 }
 
 int lrpx_nchw_to_nhwc(const float* src, float* dst, int n, int c, int hw_pix, int c_pad, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_nchw_to_nhwc", {src, "src"}, {dst, "dst"});
     LRPX_REQUIRE(src && dst && c <= c_pad, "nchw_to_nhwc: bad arguments");
     long total = (long)n * hw_pix * c_pad;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, c,
@@ -942,6 +979,7 @@ int lrpx_nchw_to_nhwc(const float* src, float* dst, int n, int c, int hw_pix, in
 }
 
 int lrpx_nchw_to_nhwc_posneg(const float* src, float* dst, int n, int c, int hw_pix, int c_pad, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_nchw_to_nhwc_posneg", {src, "src"}, {dst, "dst"});
     LRPX_REQUIRE(src && dst && 2 * c <= c_pad, "nchw_to_nhwc_posneg: bad arguments");
     long total = (long)n * hw_pix * c_pad;
     hipLaunchKernelGGL(nchw_to_nhwc_posneg_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst,
@@ -950,6 +988,7 @@ int lrpx_nchw_to_nhwc_posneg(const float* src, float* dst, int n, int c, int hw_
 }
 
 int lrpx_nhwc_to_nchw(const float* src, float* dst, int n, int c, int hw_pix, int c_src, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_nhwc_to_nchw", {src, "src"}, {dst, "dst"});
     LRPX_REQUIRE(src && dst && c <= c_src, "nhwc_to_nchw: bad arguments");
     long total = (long)n * hw_pix * c;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, c,
@@ -958,6 +997,7 @@ int lrpx_nhwc_to_nchw(const float* src, float* dst, int n, int c, int hw_pix, in
 }
 
 int lrpx_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_maxpool2x2_fwd", {x, "x"}, {y, "y"});
     LRPX_REQUIRE(x && y && (h % 2 == 0) && (w % 2 == 0) && (c % 4 == 0), "maxpool2x2_fwd: need even h,w and c%%4==0");
     long total = (long)n * (h / 2) * (w / 2) * (c / 4);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, h / 2,
@@ -1031,6 +1071,7 @@ extern "C" {
 int lrpx_maxpool2x2_relevance(const float* x, const float* r_out, const float* zdiv, const int32_t* map2img,
                               float* r_in, float* s_out, int n_maps, int h_out, int w_out, int c, int s_chunk,
                               void* stream) {
+    LRPX_CHECK_PTRS("lrpx_maxpool2x2_relevance", {x, "x"}, {r_out, "r_out"}, {zdiv, "zdiv"}, {map2img, "map2img"}, {r_in, "r_in"}, {s_out, "s_out"});
     return maxpool_relevance_amax(x, r_out, zdiv, map2img, r_in, s_out, n_maps, h_out, w_out, c, s_chunk, nullptr,
                                   (hipStream_t)stream);
 }
@@ -1045,14 +1086,17 @@ static int blocked_convert(const float* src, float* dst, long n_groups, int pix_
     return check_launch("blocked_convert");
 }
 int lrpx_nhwc_to_blocked(const float* src, float* dst, long n_groups, int pix_per_group, int c, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_nhwc_to_blocked", {src, "src"}, {dst, "dst"});
     return blocked_convert(src, dst, n_groups, pix_per_group, c, 1, stream);
 }
 int lrpx_blocked_to_nhwc(const float* src, float* dst, long n_groups, int pix_per_group, int c, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_blocked_to_nhwc", {src, "src"}, {dst, "dst"});
     return blocked_convert(src, dst, n_groups, pix_per_group, c, 0, stream);
 }
 
 int lrpx_pool_winner(const float* x, const float* z, float* xzw, uint8_t* am, int n, int h_out, int w_out, int c,
                      void* stream) {
+    LRPX_CHECK_PTRS("lrpx_pool_winner", {x, "x"}, {z, "z"}, {xzw, "xzw"}, {am, "am"});
     LRPX_REQUIRE(x && z && xzw && am && n > 0 && h_out > 0 && w_out > 0 && c % 4 == 0, "pool_winner: bad arguments");
     const long total = (long)n * h_out * w_out * (c / 4);
     hipLaunchKernelGGL(pool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, z, xzw, am,
@@ -1062,6 +1106,7 @@ int lrpx_pool_winner(const float* x, const float* z, float* xzw, uint8_t* am, in
 
 int lrpx_unpool_winner(const float* s_lo, const uint8_t* am, const int32_t* map2img, float* s_hi, int n_maps, int h_out,
                        int w_out, int c, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_unpool_winner", {s_lo, "s_lo"}, {am, "am"}, {map2img, "map2img"}, {s_hi, "s_hi"});
     LRPX_REQUIRE(s_lo && am && s_hi && n_maps > 0 && h_out > 0 && w_out > 0 && c % 4 == 0, "unpool_winner: bad arguments");
     const long total = (long)n_maps * h_out * w_out * (c / 4);
     hipLaunchKernelGGL(unpool_winner_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s_lo, am, map2img,
@@ -1070,6 +1115,7 @@ int lrpx_unpool_winner(const float* s_lo, const uint8_t* am, const int32_t* map2
 }
 
 int lrpx_amax_maps(const float* s, int n_maps, long per, uint32_t* amax, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_amax_maps", {s, "s"}, {amax, "amax"});
     LRPX_REQUIRE(s && amax && n_maps > 0 && per > 0 && per % 4 == 0, "amax_maps: bad arguments (per %% 4)");
     if (hipMemsetAsync(amax, 0, (size_t)n_maps * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
         set_error("amax_maps: memset failed");
@@ -1102,6 +1148,7 @@ size_t lrpx_packed_f16f8_bytes(int n_oc, int k) {
 }
 
 int lrpx_pack_weights_f16f8(const float* w, int cout, int cin, int mode, void* packed, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_pack_weights_f16f8", {w, "w"}, {packed, "packed"});
     LRPX_REQUIRE(w && packed, "pack_weights_f16f8: bad arguments");
     LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN, "pack_weights_f16f8: mode %d not supported", mode);
     int n_oc_pad, k_pad;
@@ -1119,6 +1166,7 @@ int lrpx_pack_weights_f16f8(const float* w, int cout, int cin, int mode, void* p
 }
 
 int lrpx_pack_weights_f16x2(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_pack_weights_f16x2", {w, "w"}, {packed, "packed"});
     LRPX_REQUIRE(w && packed && (taps == 9 || taps == 1), "pack_weights_f16x2: bad arguments (3x3 kernels or dense matrices)");
     LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN || mode == LRPX_PACK_FWD ||
                      mode == LRPX_PACK_FWD_DUAL || mode == LRPX_PACK_FWD_DUAL_FIRST, "pack_weights_f16x2: mode %d not supported", mode);
@@ -1140,11 +1188,13 @@ int lrpx_pack_weights_f16x2(const float* w, int cout, int cin, int taps, int mod
 
 int lrpx_divide_stab(const float* r, const float* z, const int32_t* map2img, float* s, int n_maps, long pix_c,
                      int stab, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_divide_stab", {r, "r"}, {z, "z"}, {map2img, "map2img"}, {s, "s"});
     LRPX_REQUIRE(stab >= LRPX_STAB_NONE && stab <= LRPX_STAB_EPS, "divide_stab: unknown stabiliser %d", stab);
     return divide_stab_amax(r, z, map2img, s, n_maps, pix_c, stab, nullptr, (hipStream_t)stream);
 }
 
 int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long per, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_cumsum_maps", {in, "in"}, {out, "out"});
     LRPX_REQUIRE(in && out && (per % 4 == 0) && t_per_img > 0, "cumsum_maps: bad arguments");
     long total = (long)n_img * (per / 4);
     hipLaunchKernelGGL(cumsum_maps_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out,
@@ -1154,6 +1204,7 @@ int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long
 
 int lrpx_scatter_maps(const float* in, float* out, int n_img, int t_per_img, const int32_t* lens, const int32_t* offs,
                       long per, int accumulate, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_scatter_maps", {in, "in"}, {out, "out"}, {lens, "lens"}, {offs, "offs"});
     LRPX_REQUIRE(in && out && lens && offs && (per % 4 == 0) && t_per_img > 0 && n_img > 0, "scatter_maps: bad arguments");
     long total = (long)n_img * (per / 4);
     hipLaunchKernelGGL(scatter_maps_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, t_per_img,
@@ -1162,6 +1213,7 @@ int lrpx_scatter_maps(const float* in, float* out, int n_img, int t_per_img, con
 }
 
 int lrpx_gather_rows(const void* src, const int32_t* rows, void* dst, int n_rows, int width, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gather_rows", {src, "src"}, {rows, "rows"}, {dst, "dst"});
     LRPX_REQUIRE(src && rows && dst && n_rows > 0 && width > 0, "gather_rows: bad arguments");
     long total = (long)n_rows * width;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src,
@@ -1207,6 +1259,7 @@ int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, f
 
 int lrpx_gradcam(const float* feats, const float* grads, const int32_t* map2img, float* cam, int rows, int P, int C,
                  void* stream) {
+    LRPX_CHECK_PTRS("lrpx_gradcam", {feats, "feats"}, {grads, "grads"}, {map2img, "map2img"}, {cam, "cam"});
     LRPX_REQUIRE(feats && grads && cam && rows > 0 && P > 0 && P <= 256 && C > 0, "gradcam: bad arguments (P <= 256)");
     hipLaunchKernelGGL(gradcam_kernel, dim3(rows), dim3(256), (C + 4) * sizeof(float), (hipStream_t)stream, feats, grads,
                        map2img, cam, P, C);
@@ -1214,12 +1267,14 @@ int lrpx_gradcam(const float* feats, const float* grads, const int32_t* map2img,
 }
 
 int lrpx_accumulate(float* dst, const float* src, long n, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_accumulate", {dst, "dst"}, {src, "src"});
     LRPX_REQUIRE(dst && src && n > 0 && n % 4 == 0, "accumulate: bad arguments");
     hipLaunchKernelGGL(accumulate_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dst, src, n / 4);
     return check_launch("accumulate");
 }
 
 int lrpx_fold_halves(const float* in, float* out, long rows, int half, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_fold_halves", {in, "in"}, {out, "out"});
     LRPX_REQUIRE(in && out && rows > 0 && half > 0, "fold_halves: bad arguments");
     hipLaunchKernelGGL(fold_halves_kernel, dim3(grid_for(rows * half)), dim3(256), 0, (hipStream_t)stream, in, out, half,
                        rows * half);
@@ -1227,6 +1282,7 @@ int lrpx_fold_halves(const float* in, float* out, long rows, int half, void* str
 }
 
 int lrpx_check(const float* buf, long n, int flags, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_check", {buf, "buf"});
     LRPX_REQUIRE(buf && n > 0, "check: bad arguments");
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);

@@ -1604,6 +1604,7 @@ extern "C" {
 
 int lrpx_linear_small(const float* x, long ldx, const float* w, const float* bias, float* out, long ldo, int B, int K,
                       int N, int act, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_linear_small", {x, "x"}, {w, "w"}, {bias, "bias"}, {out, "out"});
     LRPX_REQUIRE(x && w && out && B > 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0, "linear_small: bad arguments");
     const int lin_valu = switches().linear_valu;     // (A/B switch)
     if (K % 16 == 0 && B <= 64 && !lin_valu) {
@@ -1621,6 +1622,7 @@ int lrpx_linear_small(const float* x, long ldx, const float* w, const float* bia
 }
 
 int lrpx_mean_pixels(const float* f, float* avg, int B, int P, int C, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_mean_pixels", {f, "f"}, {avg, "avg"});
     LRPX_REQUIRE(f && avg && B > 0, "mean_pixels: bad arguments");
     hipLaunchKernelGGL(mean_pixels_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, f, avg, P, C,
                        1.0f / (float)P);
@@ -1628,12 +1630,14 @@ int lrpx_mean_pixels(const float* f, float* avg, int B, int P, int C, void* stre
 }
 
 int lrpx_relu(const float* x, float* y, long n, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_relu", {x, "x"}, {y, "y"});
     LRPX_REQUIRE(x && y && n > 0, "relu: bad arguments");
     hipLaunchKernelGGL(relu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
     return check_launch("relu");
 }
 
 int lrpx_argmax_rows(const float* x, long ld, int rows, int n, long long* out, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_argmax_rows", {x, "x"}, {out, "out"});
     LRPX_REQUIRE(x && out && rows > 0 && n > 0, "argmax_rows: bad arguments");
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, out);
     return check_launch("argmax_rows");
@@ -1660,6 +1664,7 @@ static int check_trace(const lrpx_gridtd_trace* t) {
 
 int lrpx_gridtd_fwd_pre(const lrpx_gridtd_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
                         int tok_ld, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_fwd_pre", {glob, "glob"}, {emb, "emb"}, {tok, "tok"});
     LRPX_TRY(check_trace(tr));
     LRPX_REQUIRE(glob && emb && tok && t >= 0 && t < tr->T, "gridtd_fwd_pre: bad arguments");
     hipLaunchKernelGGL(gridtd_fwd_pre_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, glob, emb,
@@ -1668,6 +1673,7 @@ int lrpx_gridtd_fwd_pre(const lrpx_gridtd_trace* tr, int t, const float* glob, c
 }
 
 int lrpx_gridtd_fwd_gate_input(const lrpx_gridtd_trace* tr, int t, float* xg, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_fwd_gate_input", {xg, "xg"});
     LRPX_TRY(check_trace(tr));
     LRPX_REQUIRE(xg && t >= 0 && t < tr->T, "gridtd_fwd_gate_input: bad arguments");
     hipLaunchKernelGGL(gridtd_gate_input_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, xg);
@@ -1675,6 +1681,7 @@ int lrpx_gridtd_fwd_gate_input(const lrpx_gridtd_trace* tr, int t, float* xg, vo
 }
 
 int lrpx_gridtd_fwd_sentinel(const lrpx_gridtd_trace* tr, int t, const float* zg, int ldz, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_fwd_sentinel", {zg, "zg"});
     LRPX_TRY(check_trace(tr));
     LRPX_REQUIRE(zg && ldz >= tr->H && t >= 0 && t < tr->T, "gridtd_fwd_sentinel: bad arguments");
     hipLaunchKernelGGL(gridtd_sentinel_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, zg, ldz);
@@ -1683,6 +1690,7 @@ int lrpx_gridtd_fwd_sentinel(const lrpx_gridtd_trace* tr, int t, const float* zg
 
 int lrpx_gridtd_lrp_reweight(const lrpx_gridtd_trace* tr, int t, const float* pred, long ld, int V, const float* fc_w,
                              const unsigned char* skip, float* hcw, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_lrp_reweight", {pred, "pred"}, {fc_w, "fc_w"}, {skip, "skip"}, {hcw, "hcw"});
     LRPX_TRY(check_trace(tr));
     LRPX_REQUIRE(pred && fc_w && skip && hcw && V > 0 && ld >= V && t >= 0 && t < tr->T,
                  "gridtd_lrp_reweight: bad arguments");
@@ -1695,6 +1703,7 @@ int lrpx_gridtd_lrp_reweight(const lrpx_gridtd_trace* tr, int t, const float* pr
 int lrpx_lrp_reweight_rows(const float* pred, long ld, int V, const float* h, long ldh, const float* ctx, long ldc,
                            const float* fc_w, const unsigned char* skip, float* hcw, int rows, int H, int log_softmax,
                            void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_lrp_reweight_rows", {pred, "pred"}, {h, "h"}, {ctx, "ctx"}, {fc_w, "fc_w"}, {skip, "skip"}, {hcw, "hcw"});
     LRPX_REQUIRE(pred && h && ctx && fc_w && skip && hcw && rows > 0 && V > 0 && ld >= V && H == 512 && ldh >= H &&
                      ldc >= H, "lrp_reweight_rows: bad arguments (H must be 512)");
     hipLaunchKernelGGL(lrp_reweight_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, ld, V, h, ldh, ctx, ldc,
@@ -1703,6 +1712,7 @@ int lrpx_lrp_reweight_rows(const float* pred, long ld, int V, const float* h, lo
 }
 
 int lrpx_argmax_logprob_rows(const float* x, long ld, int rows, int n, long long* out, float* logprob, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_argmax_logprob_rows", {x, "x"}, {out, "out"}, {logprob, "logprob"});
     LRPX_REQUIRE(x && out && logprob && rows > 0 && n > 0, "argmax_logprob_rows: bad arguments");
     hipLaunchKernelGGL(argmax_logprob_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, out,
                        logprob);
@@ -1711,6 +1721,7 @@ int lrpx_argmax_logprob_rows(const float* x, long ld, int rows, int n, long long
 
 int lrpx_beam_topk(const float* x, long ld, int n_rows, int n, const float* cum, int k, long long* out_idx, float* out_val,
                    void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_beam_topk", {x, "x"}, {cum, "cum"}, {out_idx, "out_idx"}, {out_val, "out_val"});
     LRPX_REQUIRE(x && out_idx && out_val && n_rows > 0 && n_rows <= 8 && n > 0 && k > 0 && k <= 4 && (long)n_rows * n < 0x7fffffffL,
                  "beam_topk: bad arguments (at most 8 live beams, k <= 4)");
     hipLaunchKernelGGL((beam_topk_kernel<4>), dim3(1), dim3(1024), 0, (hipStream_t)stream, x, ld, n_rows, n, cum, k, out_idx,
@@ -1719,6 +1730,7 @@ int lrpx_beam_topk(const float* x, long ld, int n_rows, int n, const float* cum,
 }
 
 int lrpx_gridtd_fwd_lstm(const lrpx_gridtd_trace* tr, int t, const float* zz, int ldz, int which, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_fwd_lstm", {zz, "zz"});
     LRPX_TRY(check_trace(tr));
     LRPX_REQUIRE(zz && (which == 1 || which == 2) && t >= 0 && t < tr->T, "gridtd_fwd_lstm: bad arguments");
     hipLaunchKernelGGL(gridtd_fwd_lstm_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_fwd(tr), t, zz, ldz,
@@ -1734,6 +1746,7 @@ extern "C" {
 int lrpx_gridtd_fwd_attention(const lrpx_gridtd_trace* tr, int t, const float* Vp, const float* att_img,
                               const float* Wg, const float* Ws, const float* bs, const float* wh, float* scratch,
                               void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_fwd_attention", {Vp, "Vp"}, {att_img, "att_img"}, {Wg, "Wg"}, {Ws, "Ws"}, {bs, "bs"}, {wh, "wh"}, {scratch, "scratch"});
     return gridtd_attention(tr, t, Vp, att_img, Wg, Ws, bs, wh, scratch, nullptr, stream);
 }
 }  // extern "C"
@@ -1754,6 +1767,7 @@ extern "C" {
 
 int lrpx_target_logit(const float* hc, const float* fcw, const float* fcb, const long long* tok, int tok_ld,
                       float* logit, int B, int T, int H, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_target_logit", {hc, "hc"}, {fcw, "fcw"}, {fcb, "fcb"}, {tok, "tok"}, {logit, "logit"});
     LRPX_REQUIRE(hc && fcw && fcb && tok && logit, "target_logit: null pointer");
     hipLaunchKernelGGL(target_logit_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, hc, fcw, fcb, tok,
                        tok_ld, logit, B, T, H);
@@ -1780,6 +1794,7 @@ static int check_rel(const lrpx_gridtd_trace* t, const lrpx_gridtd_relstate* r) 
 
 int lrpx_gridtd_rel_init(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* fcw,
                          const float* logit, const long long* tok, int tok_ld, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_rel_init", {fcw, "fcw"}, {logit, "logit"}, {tok, "tok"});
     LRPX_TRY(check_rel(tr, rs));
     LRPX_REQUIRE(fcw && logit && tok, "gridtd_rel_init: null pointer");
     hipLaunchKernelGGL(gridtd_rel_init_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_rel(tr, rs),
@@ -1801,6 +1816,7 @@ int lrpx_gridtd_rel_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate
 
 int lrpx_gridtd_rel_glob(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* glob_pre,
                          float* a_glob, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_rel_glob", {glob_pre, "glob_pre"}, {a_glob, "a_glob"});
     LRPX_TRY(check_rel(tr, rs));
     LRPX_REQUIRE(glob_pre && a_glob, "gridtd_rel_glob: null pointer");
     hipLaunchKernelGGL(gridtd_rel_glob_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_rel(tr, rs),
@@ -1809,6 +1825,7 @@ int lrpx_gridtd_rel_glob(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate
 }
 
 int lrpx_rel_avg_u(const float* r_avg, const float* avg, float* u, int rows, int T, int C, int P, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_rel_avg_u", {r_avg, "r_avg"}, {avg, "avg"}, {u, "u"});
     LRPX_REQUIRE(r_avg && avg && u && rows > 0, "rel_avg_u: bad arguments");
     hipLaunchKernelGGL(gridtd_rel_u_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, r_avg, avg, u, T, C, P);
     return check_launch("rel_avg_u");
@@ -1816,6 +1833,7 @@ int lrpx_rel_avg_u(const float* r_avg, const float* avg, float* u, int rows, int
 
 int lrpx_gridtd_rel_pix_rows(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* Vp,
                              const float* proj_pre, float* a_proj, const int32_t* rows, int n_rows, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_rel_pix_rows", {Vp, "Vp"}, {proj_pre, "proj_pre"}, {a_proj, "a_proj"}, {rows, "rows"});
     LRPX_TRY(check_rel(tr, rs));
     LRPX_REQUIRE(Vp && proj_pre && a_proj, "gridtd_rel_pix: null pointer");
     LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= tr->B * tr->T) : n_rows == tr->B * tr->T, "gridtd_rel_pix: bad row list");
@@ -1828,11 +1846,13 @@ int lrpx_gridtd_rel_pix_rows(const lrpx_gridtd_trace* tr, const lrpx_gridtd_rels
 
 int lrpx_gridtd_rel_pix(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, const float* Vp,
                         const float* proj_pre, float* a_proj, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_rel_pix", {Vp, "Vp"}, {proj_pre, "proj_pre"}, {a_proj, "a_proj"});
     LRPX_REQUIRE(tr, "gridtd_rel_pix: null trace");
     return lrpx_gridtd_rel_pix_rows(tr, rs, Vp, proj_pre, a_proj, nullptr, tr->B * tr->T, stream);
 }
 
 int lrpx_rel_words_norm(float* r_words, int rows, int T, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_rel_words_norm", {r_words, "r_words"});
     LRPX_REQUIRE(r_words && rows > 0 && T > 0, "rel_words_norm: bad arguments");
     hipLaunchKernelGGL(rel_words_norm_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, r_words, rows, T);
     return check_launch("rel_words_norm");
@@ -1860,6 +1880,7 @@ static int check_grad(const lrpx_gridtd_trace* t, const lrpx_gridtd_gradstate* r
 
 int lrpx_gridtd_grad_init(const lrpx_gridtd_trace* tr, const lrpx_gridtd_gradstate* gs, const float* fcw,
                           const long long* tok, int tok_ld, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_grad_init", {fcw, "fcw"}, {tok, "tok"});
     LRPX_TRY(check_grad(tr, gs));
     LRPX_REQUIRE(fcw && tok, "gridtd_grad_init: null pointer");
     hipLaunchKernelGGL(gridtd_grad_init_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_grad(tr, gs),
@@ -1880,6 +1901,7 @@ int lrpx_gridtd_grad_step(const lrpx_gridtd_trace* tr, const lrpx_gridtd_gradsta
 
 int lrpx_spread_pixels_rows(const float* wacc, const float* alpha, const int32_t* lens, float* a_proj, int B, int T, int H,
                             int P, const int32_t* rows, int n_rows, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_spread_pixels_rows", {wacc, "wacc"}, {alpha, "alpha"}, {lens, "lens"}, {a_proj, "a_proj"}, {rows, "rows"});
     LRPX_REQUIRE(wacc && alpha && a_proj && B > 0 && T > 0, "spread_pixels: bad arguments");
     LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= B * T) : n_rows == B * T, "spread_pixels: bad row list");
     const int kchunk = 28;
@@ -1890,16 +1912,19 @@ int lrpx_spread_pixels_rows(const float* wacc, const float* alpha, const int32_t
 
 int lrpx_spread_pixels(const float* wacc, const float* alpha, const int32_t* lens, float* a_proj, int B, int T, int H,
                        int P, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_spread_pixels", {wacc, "wacc"}, {alpha, "alpha"}, {lens, "lens"}, {a_proj, "a_proj"});
     return lrpx_spread_pixels_rows(wacc, alpha, lens, a_proj, B, T, H, P, nullptr, B * T, stream);
 }
 
 int lrpx_scale(const float* x, float* y, long n, float alpha, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_scale", {x, "x"}, {y, "y"});
     LRPX_REQUIRE(x && y && n > 0, "scale: bad arguments");
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, alpha);
     return check_launch("scale");
 }
 
 int lrpx_positive_mask(const float* x, float* y, long n, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_positive_mask", {x, "x"}, {y, "y"});
     LRPX_REQUIRE(x && y && n > 0, "positive_mask: bad arguments");
     hipLaunchKernelGGL(positive_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
     return check_launch("positive_mask");
@@ -1924,6 +1949,7 @@ static int check_atrace(const lrpx_aoa_trace* t) {
 
 int lrpx_aoa_fwd_pre(const lrpx_aoa_trace* tr, int t, const float* glob, const float* emb, const long long* tok,
                      int tok_ld, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_pre", {glob, "glob"}, {emb, "emb"}, {tok, "tok"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(glob && emb && tok && t >= 0 && t < tr->T, "aoa_fwd_pre: bad arguments");
     hipLaunchKernelGGL(aoa_fwd_pre_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), t, glob, emb, tok,
@@ -1932,6 +1958,7 @@ int lrpx_aoa_fwd_pre(const lrpx_aoa_trace* tr, int t, const float* glob, const f
 }
 
 int lrpx_aoa_fwd_lstm(const lrpx_aoa_trace* tr, int t, const float* zz, int ldz, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_lstm", {zz, "zz"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(zz && t >= 0 && t < tr->T, "aoa_fwd_lstm: bad arguments");
     hipLaunchKernelGGL(aoa_fwd_lstm_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), t, zz, ldz);
@@ -1940,6 +1967,7 @@ int lrpx_aoa_fwd_lstm(const lrpx_aoa_trace* tr, int t, const float* zz, int ldz,
 
 int lrpx_aoa_fwd_attention(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* key,
                            const float* value, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_attention", {qg, "qg"}, {key, "key"}, {value, "value"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(qg && key && value && t >= 0 && t < tr->T, "aoa_fwd_attention: bad arguments");
     const size_t lds = (size_t)(tr->H / tr->NH + tr->P + 8) * sizeof(float);
@@ -1949,6 +1977,7 @@ int lrpx_aoa_fwd_attention(const lrpx_aoa_trace* tr, int t, const float* qg, int
 }
 
 int lrpx_aoa_fwd_post(const lrpx_aoa_trace* tr, int t, const float* qg, int ldq, const float* lin, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_post", {qg, "qg"}, {lin, "lin"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(qg && lin && t >= 0 && t < tr->T, "aoa_fwd_post: bad arguments");
     hipLaunchKernelGGL(aoa_fwd_post_kernel, dim3(tr->B), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), t, qg, ldq, lin);
@@ -1971,6 +2000,7 @@ static int to_agrad(const lrpx_aoa_trace* t, const lrpx_aoa_gradstate* r, AoaGra
 
 int lrpx_aoa_grad_init(const lrpx_aoa_trace* tr, const lrpx_aoa_gradstate* gs, const float* fcw, const long long* tok,
                        int tok_ld, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_grad_init", {fcw, "fcw"}, {tok, "tok"});
     AoaGrad g;
     LRPX_TRY(to_agrad(tr, gs, &g));
     LRPX_REQUIRE(fcw && tok, "aoa_grad_init: null pointer");
@@ -1989,6 +2019,7 @@ int lrpx_aoa_grad_step(const lrpx_aoa_trace* tr, const lrpx_aoa_gradstate* gs, i
 
 int lrpx_aoa_grad_pix_rows(const lrpx_aoa_trace* tr, int head, const float* v1, const float* v2, float* d_feat, int C,
                            const int32_t* rows, int n_rows, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_grad_pix_rows", {v1, "v1"}, {v2, "v2"}, {d_feat, "d_feat"}, {rows, "rows"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(v1 && v2 && d_feat && head >= 0 && head < tr->NH && C > 0 && C % 4 == 0, "aoa_grad_pix: bad arguments");
     LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= tr->B * tr->T) : n_rows == tr->B * tr->T, "aoa_grad_pix: bad row list");
@@ -2000,11 +2031,13 @@ int lrpx_aoa_grad_pix_rows(const lrpx_aoa_trace* tr, int head, const float* v1, 
 
 int lrpx_aoa_grad_pix(const lrpx_aoa_trace* tr, int head, const float* v1, const float* v2, float* d_feat, int C,
                       void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_grad_pix", {v1, "v1"}, {v2, "v2"}, {d_feat, "d_feat"});
     LRPX_REQUIRE(tr, "aoa_grad_pix: null trace");
     return lrpx_aoa_grad_pix_rows(tr, head, v1, v2, d_feat, C, nullptr, tr->B * tr->T, stream);
 }
 
 int lrpx_keep_cols(float* x, long rows, int ncol, int lo, int hi, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_keep_cols", {x, "x"});
     LRPX_REQUIRE(x && rows > 0 && ncol > 0 && lo >= 0 && hi <= ncol && lo < hi, "keep_cols: bad arguments");
     const long total = rows * ncol;
     hipLaunchKernelGGL(keep_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ncol,
@@ -2029,6 +2062,7 @@ static int check_arel(const lrpx_aoa_trace* t, const lrpx_aoa_relstate* r) {
 
 int lrpx_aoa_rel_init(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* fcw, const float* logit,
                       const long long* tok, int tok_ld, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_rel_init", {fcw, "fcw"}, {logit, "logit"}, {tok, "tok"});
     LRPX_TRY(check_arel(tr, rs));
     LRPX_REQUIRE(fcw && logit && tok, "aoa_rel_init: null pointer");
     hipLaunchKernelGGL(aoa_rel_init_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_arel(tr, rs), fcw,
@@ -2038,6 +2072,7 @@ int lrpx_aoa_rel_init(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, con
 
 int lrpx_aoa_rel_value_rows(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
                             int head, float* a_val, const int32_t* rows, int n_rows, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_rel_value_rows", {r_ctx, "r_ctx"}, {value, "value"}, {a_val, "a_val"}, {rows, "rows"});
     LRPX_TRY(check_arel(tr, rs));
     LRPX_REQUIRE(r_ctx && value && a_val && head >= 0 && head < tr->NH, "aoa_rel_value: bad arguments");
     LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= tr->B * tr->T) : n_rows == tr->B * tr->T, "aoa_rel_value: bad row list");
@@ -2048,6 +2083,7 @@ int lrpx_aoa_rel_value_rows(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* r
 
 int lrpx_aoa_rel_value_head(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
                             int head, float* a_val_head, const int32_t* rows, int n_rows, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_rel_value_head", {r_ctx, "r_ctx"}, {value, "value"}, {a_val_head, "a_val_head"}, {rows, "rows"});
     LRPX_TRY(check_arel(tr, rs));
     LRPX_REQUIRE(r_ctx && value && a_val_head && head >= 0 && head < tr->NH && tr->H % tr->NH == 0, "aoa_rel_value_head: bad arguments");
     LRPX_REQUIRE(rows ? (n_rows > 0 && n_rows <= tr->B * tr->T) : n_rows == tr->B * tr->T, "aoa_rel_value_head: bad row list");
@@ -2058,6 +2094,7 @@ int lrpx_aoa_rel_value_head(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* r
 
 int lrpx_aoa_rel_value(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const float* r_ctx, const float* value,
                        int head, float* a_val, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_rel_value", {r_ctx, "r_ctx"}, {value, "value"}, {a_val, "a_val"});
     LRPX_REQUIRE(tr, "aoa_rel_value: null trace");
     return lrpx_aoa_rel_value_rows(tr, rs, r_ctx, value, head, a_val, nullptr, tr->B * tr->T, stream);
 }
@@ -2120,6 +2157,7 @@ int lrpx_aoa_fwd_steps(const lrpx_aoa_trace* tr, int t0, int t1, const lrpx_aoa_
 
 int lrpx_aoa_fwd_inputs(const lrpx_aoa_trace* tr, const float* glob, const float* emb, const long long* tok, int tok_ld,
                         float* xin, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_inputs", {glob, "glob"}, {emb, "emb"}, {tok, "tok"}, {xin, "xin"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(glob && emb && tok, "aoa_fwd_inputs: null pointer");
     hipLaunchKernelGGL(aoa_fwd_inputs_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), glob, emb, tok,
@@ -2142,6 +2180,7 @@ static int aoa_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const 
 }
 
 int lrpx_aoa_fwd_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* zin, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_recurrence", {w_hh_il, "w_hh_il"}, {zin, "zin"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(w_hh_il && zin && tr->B <= 64 && tr->H % 16 == 0, "aoa_fwd_recurrence: bad arguments (<= 64 images, H %% 16)");
     return aoa_recurrence(tr, w_hh_il, zin, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
@@ -2149,6 +2188,7 @@ int lrpx_aoa_fwd_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, cons
 
 int lrpx_aoa_fwd_recurrence_tab(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* tab, const float* gimg,
                                 const long long* tok, int tok_ld, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_recurrence_tab", {w_hh_il, "w_hh_il"}, {tab, "tab"}, {gimg, "gimg"}, {tok, "tok"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(w_hh_il && tab && gimg && tok && tok_ld >= tr->T && tr->B <= 64 && tr->H % 16 == 0,
                  "aoa_fwd_recurrence_tab: bad arguments (<= 64 images, H %% 16)");
@@ -2156,6 +2196,7 @@ int lrpx_aoa_fwd_recurrence_tab(const lrpx_aoa_trace* tr, const float* w_hh_il, 
 }
 
 int lrpx_aoa_fwd_gather_h(const lrpx_aoa_trace* tr, float* hn, uint32_t* hn_amax, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_gather_h", {hn, "hn"}, {hn_amax, "hn_amax"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(hn, "aoa_fwd_gather_h: null pointer");
     hipLaunchKernelGGL(aoa_fwd_gather_h_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), hn, hn_amax);
@@ -2164,6 +2205,7 @@ int lrpx_aoa_fwd_gather_h(const lrpx_aoa_trace* tr, float* hn, uint32_t* hn_amax
 
 int lrpx_aoa_fwd_attention_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* key, const float* value,
                                uint32_t* ctx_amax, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_attention_all", {qg, "qg"}, {key, "key"}, {value, "value"}, {ctx_amax, "ctx_amax"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(qg && key && value && tr->H % tr->NH == 0, "aoa_fwd_attention_all: bad arguments");
     const size_t lds = (size_t)(tr->H / tr->NH + tr->P) * sizeof(float);
@@ -2173,6 +2215,7 @@ int lrpx_aoa_fwd_attention_all(const lrpx_aoa_trace* tr, const float* qg, int ld
 }
 
 int lrpx_aoa_fwd_post_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, const float* lin, uint32_t* hc_amax, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_post_all", {qg, "qg"}, {lin, "lin"}, {hc_amax, "hc_amax"});
     LRPX_TRY(check_atrace(tr));
     LRPX_REQUIRE(qg && lin, "aoa_fwd_post_all: null pointer");
     hipLaunchKernelGGL(aoa_fwd_post_all_kernel, dim3(tr->B * tr->T), dim3(256), 0, (hipStream_t)stream, to_afwd(tr), qg, ldq, lin, hc_amax);
@@ -2181,6 +2224,7 @@ int lrpx_aoa_fwd_post_all(const lrpx_aoa_trace* tr, const float* qg, int ldq, co
 
 int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int n_steps, const lrpx_conv_desc* dense,
                        const int32_t* idx, int idx_ld, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_rel_steps", {idx, "idx"});
     LRPX_TRY(check_arel(tr, rs));
     LRPX_REQUIRE(dense && idx && n_steps >= 0 && n_steps <= tr->T && idx_ld >= tr->B * tr->T, "aoa_rel_steps: bad arguments");
     lrpx_conv_desc d = *dense;
@@ -2247,6 +2291,7 @@ int lrpx_gridtd_fwd_steps(const lrpx_gridtd_trace* tr, int t0, int t1, const lrp
 
 int lrpx_gridtd_rel_steps(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstate* rs, int n_steps, const lrpx_conv_desc* dense2,
                           const lrpx_conv_desc* dense1, const int32_t* idx, int idx_ld, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_gridtd_rel_steps", {idx, "idx"});
     LRPX_TRY(check_rel(tr, rs));
     LRPX_REQUIRE(dense1 && dense2 && idx && n_steps >= 0 && n_steps <= tr->T && idx_ld >= tr->B * tr->T, "gridtd_rel_steps: bad arguments");
     lrpx_conv_desc d2 = *dense2, d1 = *dense1;
@@ -2264,6 +2309,7 @@ int lrpx_gridtd_rel_steps(const lrpx_gridtd_trace* tr, const lrpx_gridtd_relstat
 
 int lrpx_aoa_rel_steps_fused(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, const lrpx_conv_desc* dense, const int32_t* idx,
                              int idx_ld, float* a_alt, float* wpart, float* coef, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_aoa_rel_steps_fused", {idx, "idx"}, {a_alt, "a_alt"}, {wpart, "wpart"}, {coef, "coef"});
     LRPX_TRY(check_arel(tr, rs));
     const int T = tr->T, rows = tr->B * tr->T, H = tr->H;
     LRPX_REQUIRE(dense && idx && a_alt && wpart && coef && idx_ld >= rows, "aoa_rel_steps_fused: bad arguments");

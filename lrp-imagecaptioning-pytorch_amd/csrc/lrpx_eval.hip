@@ -230,6 +230,7 @@ using namespace lrpx;
 extern "C" {
 
 int lrpx_spatial_reduce(const float* maps, int n, int c, long hw, int mode, float* out, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_spatial_reduce", {maps, "maps"}, {out, "out"});
     LRPX_REQUIRE(maps && out && n > 0 && c > 0 && hw > 0 && mode >= 0 && mode <= 2, "spatial_reduce: bad arguments");
     const long total = (long)n * hw;
     hipLaunchKernelGGL(spatial_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, maps,
@@ -238,12 +239,14 @@ int lrpx_spatial_reduce(const float* maps, int n, int c, long hw, int mode, floa
 }
 
 int lrpx_project_maxabs(float* x, int n, long per, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_project_maxabs", {x, "x"});
     LRPX_REQUIRE(x && n > 0 && per > 0, "project_maxabs: bad arguments");
     hipLaunchKernelGGL(project_maxabs_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, per);
     return check_launch("project_maxabs");
 }
 
 int lrpx_patch_mask(const float* spatial, int n, int h, int w, int patch, int k, float* mask, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_patch_mask", {spatial, "spatial"}, {mask, "mask"});
     LRPX_REQUIRE(spatial && mask && n > 0 && patch > 0 && h % patch == 0 && w % patch == 0, "patch_mask: bad arguments");
     const int np_ = (h / patch) * (w / patch);
     LRPX_REQUIRE(k >= 0 && k <= np_ && np_ <= 8192, "patch_mask: k must not exceed the number of patches (<= 8192)");
@@ -254,6 +257,7 @@ int lrpx_patch_mask(const float* spatial, int n, int h, int w, int patch, int k,
 
 int lrpx_bbox_ratio(const float* spatial, int n, int h, int w, const int32_t* boxes, const float* thresholds, int nthr,
                     float* out, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_bbox_ratio", {spatial, "spatial"}, {boxes, "boxes"}, {thresholds, "thresholds"}, {out, "out"});
     LRPX_REQUIRE(spatial && boxes && thresholds && out && n > 0 && h > 0 && w > 0 && nthr > 0, "bbox_ratio: bad arguments");
     hipLaunchKernelGGL(bbox_ratio_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, spatial, h, w, boxes, thresholds, nthr,
                        out);
@@ -261,6 +265,7 @@ int lrpx_bbox_ratio(const float* spatial, int n, int h, int w, const int32_t* bo
 }
 
 int lrpx_map_stats(const float* spatial, int n, long per, float* out4, void* stream) {
+    LRPX_CHECK_PTRS_OPT("lrpx_map_stats", {spatial, "spatial"}, {out4, "out4"});
     LRPX_REQUIRE(spatial && out4 && n > 0 && per > 0, "map_stats: bad arguments");
     hipLaunchKernelGGL(map_stats_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, spatial, per, out4);
     return check_launch("map_stats");
@@ -280,6 +285,7 @@ size_t lrpx_map_quantiles_workspace(int n, long per) {
 
 int lrpx_map_quantiles(const float* spatial, int n, long per, const double* q, int nq, float* out, void* workspace,
                        size_t workspace_bytes, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_map_quantiles", {spatial, "spatial"}, {out, "out"}, {workspace, "workspace"});
     LRPX_REQUIRE(spatial && q && out && workspace && n > 0 && per > 0 && nq > 0, "map_quantiles: bad arguments");
     LRPX_REQUIRE((long)n * per < 0x7fffffffL, "map_quantiles: more than 2^31 values in one call");
     const size_t need = lrpx_map_quantiles_workspace(n, per);
@@ -302,6 +308,7 @@ int lrpx_map_quantiles(const float* spatial, int n, long per, const double* q, i
 
 int lrpx_heatmap(const float* maps, int n, int c, long hw, float gamma, const float* lut, int nlut, float* tmp, float* out,
                  void* stream) {
+    LRPX_CHECK_PTRS("lrpx_heatmap", {maps, "maps"}, {lut, "lut"}, {tmp, "tmp"}, {out, "out"});
     LRPX_REQUIRE(maps && lut && tmp && out && n > 0 && c > 0 && hw > 0 && nlut > 0 && gamma > 0.f, "heatmap: bad arguments");
     hipLaunchKernelGGL(heatmap_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, maps, c, hw, gamma, lut, nlut, tmp, out);
     return check_launch("heatmap");

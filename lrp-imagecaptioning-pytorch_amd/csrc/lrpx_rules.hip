@@ -219,6 +219,7 @@ extern "C" {
 
 int lrpx_linear_eps_rule(float* x, const float* w, const float* bias, const float* r_out, float* s_ws, float* r_in,
                          int n_rows, int n_in, int n_out, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_linear_eps_rule", {x, "x"}, {w, "w"}, {bias, "bias"}, {r_out, "r_out"}, {s_ws, "s_ws"}, {r_in, "r_in"});
     LRPX_REQUIRE(x && w && r_out && s_ws && r_in && n_rows > 0 && n_in > 0 && n_out > 0, "linear_eps_rule: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const long nx = (long)n_rows * n_in;
@@ -233,6 +234,7 @@ int lrpx_linear_eps_rule(float* x, const float* w, const float* bias, const floa
 int lrpx_batchnorm_rule(const float* x, const float* r_out, const float* gamma, const float* beta, const float* mean,
                         const float* var, float eps, float* r_in, long n_outer, int channels, long inner, int broadcast_x,
                         void* stream) {
+    LRPX_CHECK_PTRS("lrpx_batchnorm_rule", {x, "x"}, {r_out, "r_out"}, {gamma, "gamma"}, {beta, "beta"}, {mean, "mean"}, {var, "var"}, {r_in, "r_in"});
     LRPX_REQUIRE(x && r_out && gamma && beta && mean && var && r_in && n_outer > 0 && channels > 0 && inner > 0,
                  "batchnorm_rule: bad arguments");
     LRPX_REQUIRE(!broadcast_x || n_outer == 1, "batchnorm_rule: a broadcast input has no outer dimension");
@@ -243,6 +245,7 @@ int lrpx_batchnorm_rule(const float* x, const float* r_out, const float* gamma, 
 }
 
 int lrpx_add_rule(const float* x1, const float* x2, const float* r_out, float* r1, float* r2, long n, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_add_rule", {x1, "x1"}, {x2, "x2"}, {r_out, "r_out"}, {r1, "r1"}, {r2, "r2"});
     LRPX_REQUIRE(x1 && x2 && r_out && r1 && r2 && n > 0, "add_rule: bad arguments");
     hipLaunchKernelGGL(add_rule_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x1, x2, r_out,
                        r1, r2, n);
@@ -251,6 +254,7 @@ int lrpx_add_rule(const float* x1, const float* x2, const float* r_out, float* r
 
 int lrpx_avgpool_rule(const float* x, const float* r_out, float* s_ws, float* r_in, long planes, int h, int w, int oh, int ow,
                       int kh, int kw, int sh, int sw, int ph, int pw, int count_include_pad, int divisor_override, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_avgpool_rule", {x, "x"}, {r_out, "r_out"}, {s_ws, "s_ws"}, {r_in, "r_in"});
     LRPX_REQUIRE(x && r_out && s_ws && r_in && planes > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "avgpool_rule: bad arguments");
     LRPX_REQUIRE(kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && 2 * ph <= kh && 2 * pw <= kw && divisor_override >= 0,
                  "avgpool_rule: bad window (kernel %dx%d stride %dx%d padding %dx%d)", kh, kw, sh, sw, ph, pw);

@@ -226,7 +226,9 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
             LRPX_REQUIRE(false, "conv_mfma: no bf16x6 GUIDED kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
         }
         if (d->epi == EPI_PLAIN) {
-            LRPX_REQUIRE(d->hw == 14 && !d->relu && !d->bias, "conv_mfma: the bf16x6 PLAIN kernel is built for 14x14 maps, no bias / ReLU (the K-split forward)");
+            LRPX_REQUIRE(d->hw <= 56 && !d->relu && !d->bias, "conv_mfma: the bf16x6 PLAIN kernels are built for 56 / 28 / 14-pixel maps, no bias / ReLU (the K-split forward)");
+            if (d->hw == 56) return launch_b6_56_plain(a, s);
+            if (d->hw == 28) return launch_b6_28_plain(a, s);
             return launch_b6_14_plain(a, s);
         }
         if (d->epi == EPI_REL_MUL && d->pool_am) {
@@ -575,7 +577,13 @@ int lrpx_conv_kc(int hw, int taps, int cin) {
     return 16;
 }
 
-int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream) { return conv_dispatch(d, (hipStream_t)stream); }
+int lrpx_conv_mfma(const lrpx_conv_desc* d, void* stream) {
+    LRPX_REQUIRE(d, "conv_mfma: null descriptor");
+    LRPX_CHECK_PTRS("lrpx_conv_mfma", {d->in, "in"}, {d->wpacked, "wpacked"}, {d->bias, "bias"}, {d->x, "x"}, {d->u, "u"}, {d->zdiv, "zdiv"},
+                    {d->map2img, "map2img"}, {d->out0, "out0"}, {d->out1, "out1"}, {d->in_amax, "in_amax"}, {d->out1_amax, "out1_amax"},
+                    {d->out0_amax, "out0_amax"}, {d->pool_am, "pool_am"});
+    return conv_dispatch(d, (hipStream_t)stream);
+}
 
 int lrpx_set_bf16x6(int enable) {
     if (enable >= 0) return g_default_mode.exchange(enable ? 1 : 0) >= 1;
@@ -609,6 +617,8 @@ size_t lrpx_vgg16_workspace_bytes(int n_maps) {
 
 int lrpx_vgg16_pack(const float* const* w, const float* const* b, void* packed, void* stream) {
     LRPX_REQUIRE(w && b && packed, "vgg16_pack: null pointer");
+    LRPX_CHECK_PTRS("lrpx_vgg16_pack", {packed, "packed"});
+    for (int i = 0; i < 13; ++i) LRPX_CHECK_PTRS("lrpx_vgg16_pack", {w[i], "w[i]"}, {b[i], "b[i]"});
     VggPacked p = vgg_packed_layout();
     float* base = (float*)packed;
     int ci = 0;
@@ -692,7 +702,10 @@ static int trace_derive_impl(void* trace, int n_img, void* stream, bool pools_do
     return LRPX_OK;
 }
 
-int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream) { return trace_derive_impl(trace, n_img, stream, false); }
+int lrpx_vgg16_trace_derive(void* trace, int n_img, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_vgg16_trace_derive", {trace, "trace"});
+    return trace_derive_impl(trace, n_img, stream, false);
+}
 
 int lrpx_vgg16_trace_layout(int n_img, size_t* act_off, size_t* zpos_off) {
     LRPX_REQUIRE(n_img > 0 && act_off && zpos_off, "vgg16_trace_layout: bad arguments");
@@ -723,6 +736,7 @@ int lrpx_vgg16_forward(const void* packed, const float* img_nchw, int n_img, voi
 
 int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, void* trace, float* feat_nhwc,
                           const lrpx_vgg16_opts* opts, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_vgg16_forward_ex", {packed, "packed"}, {img_nchw, "img_nchw"}, {trace, "trace"}, {feat_nhwc, "feat_nhwc"});
     LRPX_REQUIRE(packed && img_nchw && trace && n_img > 0, "vgg16_forward: bad arguments");
     const VggCtx cx = resolve_ctx(opts);
     const int mode = cx.mode, fwd_f16 = cx.fwd_f16;      // this call's values
@@ -781,7 +795,12 @@ int lrpx_vgg16_forward_ex(const void* packed, const float* img_nchw, int n_img, 
                 // mode 1: exact bf16 splits (round 6: conv1_2 too, and the 14 x 14 layers K-split as in the f16x3 forward - the decision
                 // depends on the layer only, never on the batch)
                 d.bf16x6 = 1; d.wpacked = pk + p.fwd6[l];
-                const int fwd_ks = (L.hw == 14 && !switches().x6_legacy) ? switches().fwd_ksplit14 : 1;
+                // K ranges per tile (a property of the LAYER, never of the batch).  An accumulator of this kernel is rounded six times per
+                // k-step (six MFMAs), against three on the fp16 split products: unsplit, the exact-split forward sits 2.7e-6 of the feature
+                // maximum from an fp64 evaluation where the fp16 forward sits at 2.1e-6 and oneDNN at 7.6e-7 (tools/dbg/fwd_f64_probe.py), and one
+                // well-conditioned r_words row of the T = 20 fixture left the 1e-5 bound (1.6e-5).  Partial sums over <= 72 k-steps, added
+                // pairwise by lrpx fwd_dual_finish: LRPX_B6_FWD_KSPLIT28 (4) / 56 (2); +0.5 ms per 16 images.
+                const int fwd_ks = switches().x6_legacy ? 1 : (L.hw == 14 ? switches().fwd_ksplit14 : (L.hw == 28 ? switches().b6_fwd_ksplit28 : (L.hw == 56 ? switches().b6_fwd_ksplit56 : 1)));
                 if (fwd_ks > 1 && (fwd_ks & (fwd_ks - 1)) == 0 && fwd_ks <= 16 && (L.cin / 16) % fwd_ks == 0 &&
                     (size_t)fwd_ks * L.hw * L.hw * 2 * L.cout <= (size_t)224 * 224 * 64) {
                     float* part = tr + t.xz[1];
@@ -872,6 +891,7 @@ struct LayerTimer {
 int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, const float* r_feat_nhwc,
                             const int32_t* map2img, int n_maps, void* workspace, float* out_nchw,
                             const lrpx_vgg16_opts* opts, void* stream) {
+    LRPX_CHECK_PTRS("lrpx_vgg16_relevance_ex", {packed, "packed"}, {trace, "trace"}, {r_feat_nhwc, "r_feat_nhwc"}, {map2img, "map2img"}, {workspace, "workspace"}, {out_nchw, "out_nchw"});
     LRPX_REQUIRE(packed && trace && r_feat_nhwc && workspace && out_nchw && n_maps > 0 && n_img > 0,
                  "vgg16_relevance: bad arguments");
     const VggCtx cx = resolve_ctx(opts);
@@ -1019,6 +1039,8 @@ static int vgg16_backprop(const void* packed, const void* trace, int n_img, cons
                           const lrpx_vgg16_opts* opts, void* stream) {
     LRPX_REQUIRE(packed && trace && d_feat_nhwc && workspace && out_nchw && n_maps > 0 && n_img > 0,
                  "vgg16_guided_backprop: bad arguments");
+    LRPX_CHECK_PTRS(plain ? "lrpx_vgg16_gradient" : "lrpx_vgg16_guided_backprop", {packed, "packed"}, {trace, "trace"}, {d_feat_nhwc, "d_feat_nhwc"},
+                    {map2img, "map2img"}, {workspace, "workspace"}, {out_nchw, "out_nchw"});
     const int mode = resolve_ctx(opts).mode;
     LRPX_REQUIRE(map2img || n_maps == n_img, "vgg16_guided_backprop: map2img is required when n_maps != n_img");
     const VggPacked p = vgg_packed_layout();

@@ -666,7 +666,7 @@ class ExplainAOAAttention(object):
             return AOAEngine(state, self.num_head)
         self.model = model
         # one device engine per weight set (explainers/engine_cache.py); weights shared, trace / workspace buffers this explainer's own
-        self.engine = engine_cache.get(key, build).replica()
+        self.engine = engine_cache.get(key, build, hold=engine_cache.source_tensors(model)).replica()
         self.rev_word_map = {v: k for k, v in word_map.items()}
         self.mean = list(IMAGENET_MEAN)
         self.std = list(IMAGENET_STD)

@@ -689,7 +689,7 @@ class ExplainGridTDAttention(object):
             return GridTDEngine(state)
         self.model = model
         # the weights are shared, the trace / workspace buffers are this explainer's own: two live explainers never see each other's image
-        self.engine = engine_cache.get(key, build).replica()
+        self.engine = engine_cache.get(key, build, hold=engine_cache.source_tensors(model)).replica()
         self.mean = list(IMAGENET_MEAN)
         self.std = list(IMAGENET_STD)
         self.rev_word_map = {v: k for k, v in word_map.items()}

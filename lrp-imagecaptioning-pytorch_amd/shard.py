@@ -115,13 +115,20 @@ class OverlappedGather:
     mode "gather": rank 0 receives (world, *shape); "all_gather": every rank does (`all_gather_into_tensor` on a preallocated
     tensor - for the small reduced results).  CPU tensors (gloo in the tests) take the same calls without streams."""
 
-    def __init__(self, shape, dtype=torch.float32, device="cuda", group=None, depth=2, mode="gather"):
+    def __init__(self, shape, dtype=torch.float32, device="cuda", group=None, depth=2, mode="gather", host_staged=False):
         import torch.distributed as dist
         self.dist, self.group, self.mode, self.depth = dist, group, mode, max(1, int(depth))
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.cuda = torch.device(device).type == "cuda"
         shape = tuple(shape)
-        self.stage = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.depth)]
+        # host slots (the gloo rehearsal of a GPU run): PINNED here, so that the non_blocking device -> host copy really is asynchronous
+        # (into pageable memory it blocks the host: no overlap; ADVICE r5)
+        pin = (not self.cuda) and torch.cuda.is_available()
+        self.stage = [torch.empty(shape, dtype=dtype, device=device, pin_memory=pin) for _ in range(self.depth)]
+        # host-staged collectives are ISSUED by one worker thread in submit order (see _HostStaged); host_staged=True forces that path
+        # for CPU inputs too (tests)
+        self.force_host_staged = bool(host_staged) and not self.cuda
+        self._q, self._worker = None, None
         need_out = mode == "all_gather" or self.rank == 0
         self.out = [torch.empty((self.world,) + shape, dtype=dtype, device=device) if need_out else None for _ in range(self.depth)]
         self.work = [None] * self.depth
@@ -135,23 +142,51 @@ class OverlappedGather:
         return self.dist.gather(self.stage[k], bufs, dst=0, group=self.group, async_op=True)
 
     class _HostStaged:
-        """handle of a collective whose device -> pinned-host copy is still in flight: a helper thread waits for the copy and
-        starts the collective (the rehearsal backend, gloo, moves host tensors only); wait() joins both"""
+        """handle of a collective whose device -> pinned-host copy is still in flight (the rehearsal backend, gloo, moves host tensors
+        only).  ONE worker thread per OverlappedGather takes the handles from a FIFO queue, waits for each copy and starts its
+        collective: gloo pairs collectives across ranks by ISSUE ORDER and all the buffers have one shape, so with a thread per
+        submit (round 5) and `depth` >= 2 two ranks could issue steps i and i + 1 in different orders and gather one step's data
+        against another's without any error.  wait() blocks until the collective has been issued, then until it is done."""
 
         def __init__(self, og, k, ev):
             import threading
-            self.work = None
+            self.work, self.error = None, None
+            self.issued = threading.Event()
+            self.og, self.k, self.ev = og, k, ev
 
-            def run():
-                ev.synchronize()
-                self.work = og._collective(k)
-            self.th = threading.Thread(target=run)
-            self.th.start()
+        def issue(self):                    # (worker thread)
+            try:
+                if self.ev is not None:
+                    self.ev.synchronize()
+                self.work = self.og._collective(self.k)
+            except BaseException as e:      # surfaced by wait() on the caller's thread
+                self.error = e
+            finally:
+                self.issued.set()
 
         def wait(self):
-            self.th.join()
+            self.issued.wait()
+            if self.error is not None:
+                raise self.error
             if self.work is not None:
                 self.work.wait()
+
+    def _enqueue(self, handle):
+        import queue
+        import threading
+        if self._worker is None:
+            self._q = queue.Queue()
+
+            def loop():
+                while True:
+                    h = self._q.get()
+                    if h is None:
+                        return
+                    h.issue()
+            self._worker = threading.Thread(target=loop, daemon=True)
+            self._worker.start()
+        self._q.put(handle)
+        return handle
 
     def submit(self, local):
         k = self.k
@@ -169,7 +204,11 @@ class OverlappedGather:
                 local.record_stream(self.stream)
                 ev = torch.cuda.Event()
                 ev.record()
-            self.work[k] = OverlappedGather._HostStaged(self, k, ev)
+            self.work[k] = self._enqueue(OverlappedGather._HostStaged(self, k, ev))
+            return k
+        if self.force_host_staged:
+            self.stage[k].copy_(local)
+            self.work[k] = self._enqueue(OverlappedGather._HostStaged(self, k, None))
             return k
         if not self.cuda:
             self.stage[k].copy_(local)
@@ -197,6 +236,14 @@ class OverlappedGather:
             torch.cuda.current_stream().wait_stream(self.stream)
         elif self.stream is not None:
             self.stream.synchronize()
+
+    def close(self):
+        """stop the worker thread of the host-staged path (idempotent; the thread is a daemon, so forgetting this leaks nothing)"""
+        self.finish()
+        if self._worker is not None:
+            self._q.put(None)
+            self._worker.join()
+            self._worker = None
 
 
 def explain_sharded(explain_fn, images, captions=None, gather=True, group=None, lens=None, n_items=None, reduce="maps"):

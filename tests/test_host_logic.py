@@ -201,6 +201,39 @@ def test_engine_cache_keys(tmp_path):
     ec.clear()
 
 
+def test_engine_cache_two_checkpoints_loaded_one_after_the_other(tmp_path):
+    """two DIFFERENT checkpoints `torch.load`ed in sequence, the first state dict freed before the second is read - the
+    allocator hands the second one the same addresses and `_version` is 0 after every load.  The entry holds its source tensors
+    (addresses cannot be reused while it lives) and the key carries a content digest: two different engines come back."""
+    import gc
+    from lrp_amd.explainers import engine_cache as ec
+    ec.clear()
+    g = torch.Generator().manual_seed(0)
+    for i in range(2):
+        torch.save({"state_dict": {"w": torch.randn(256, 256, generator=g), "b": torch.randn(256, generator=g)}}, tmp_path / f"c{i}.pth")
+    engines, keys = [], []
+    for hold in (False, True):          # the digest alone, then as the explainers call it (entry holds the tensors)
+        ec.clear()
+        engines.clear(); keys.clear()
+        for i in range(2):
+            sd = torch.load(tmp_path / f"c{i}.pth")["state_dict"]
+            k = ec.fingerprint("gridtd", sd)
+            keys.append(k)
+            engines.append(ec.get(k, lambda i=i: ("engine", i), hold=ec.source_tensors(sd) if hold else None))
+            del sd
+            gc.collect()
+        assert keys[0] != keys[1] and engines[0] != engines[1], hold
+    # the same state dict again: a hit
+    sd = torch.load(tmp_path / "c1.pth")["state_dict"]
+    built = []
+    e1 = ec.get(ec.fingerprint("gridtd", sd), lambda: built.append(1) or "x", hold=ec.source_tensors(sd))
+    assert ec.get(ec.fingerprint("gridtd", sd), lambda: built.append(1) or "y", hold=ec.source_tensors(sd)) is e1 and len(built) == 1
+    # an edit through .data bumps no version counter: the digest sees it (element 0 is always sampled)
+    sd["w"].data[0, 0] += 1.0
+    assert ec.get(ec.fingerprint("gridtd", sd), lambda: built.append(1) or "z") == "z"
+    ec.clear()
+
+
 def test_bench_pmc_traffic_parser_and_precedence(tmp_path):
     """bench.py's roofline.traffic: the counters of its own `rocprofv3 --pmc` child passes (one *_counter_collection.csv per pass, a row
     per dispatch and counter, FETCH_SIZE / WRITE_SIZE in kilobytes) -> bytes per launch = (2 x FETCH + WRITE) x 1024 / launches, scaled to

@@ -1,6 +1,7 @@
 """The reference-equivalent CPU mode (the cpu_baseline of bench.py) must give the oracle's numbers:
 it replays the reference's op sequence (hooks + autograd, materialised epsilon rules, per-pixel loops)."""
 import numpy as np
+import pytest
 import torch
 
 import lrp_amd  # noqa: F401
@@ -25,7 +26,7 @@ def test_ref_equiv_matches_oracle_and_accumulates():
 def test_ref_equiv_against_the_imported_reference_when_it_is_here():
     """the CPU baseline that travels (oracle/ref_equiv.py) is a stand-in for the reference.  Where the reference is
     present (the build container) it is RE-RUN against the imported `ExplainGridTDAttention.explain_caption` on a 3-word caption
-    (tools/ref_timing.py --words 3: the same maps incl. the running-sum quirk, wall time within a factor of 1.5 at this size - the
+    (tools/ref_timing.py --words 3: the same maps and r_words to 1e-5 incl. the running-sum quirk, wall time within a factor of 1.5 at this size - the
     20-word figure, 1.04x, is the evidence file profiles/r04_ref_equiv_vs_reference.json, written by the same tool).  Elsewhere
     (the GPU box has no /root/reference) the test is skipped: nothing is asserted on a committed file."""
     import json
@@ -45,5 +46,9 @@ def test_ref_equiv_against_the_imported_reference_when_it_is_here():
         if os.path.exists(path):
             os.remove(path)
     assert rec["words"] == 3 and rec["vocab"] == 9586
-    assert rec["max_rel_map_difference"] < 2e-3 and rec["max_r_words_difference"] < 1e-4, rec
+    # ref_equiv replays the reference's fp32 op sequence: the same bounds as the 20-word record (measured here at 3 words:
+    # maps 4.2e-7 of their maximum, r_words 5.7e-7)
+    assert rec["max_rel_map_difference"] < 1e-5 and rec["max_r_words_difference"] < 1e-5, rec
+    # wall time: only this window is wider than the record's +-10 % - a 3-word run is 5 s of which the one-off trace is a third, and the
+    # container's 8 shared cores move it by +-20 % between repetitions (measured 0.93; the 20-word record: 1.04)
     assert 0.5 <= rec["ratio_ref_equiv_over_reference_time"] <= 1.5, rec

@@ -193,6 +193,27 @@ def _gather_worker(rank, world, port, out):
                 ok &= res is None
         og.finish()
         ok &= slots == [0, 1, 0, 1, 0]
+    # the host-staged path (gloo rehearsal of a GPU run) with SEVERAL submits outstanding before any result is asked for:
+    # one worker issues the collectives in submit order on every rank, however the ranks' timing differs; rank 1 is slowed down
+    # between its submits so that a per-submit thread of rank 0 would run ahead
+    import time
+    for mode in ("gather", "all_gather"):
+        og = shard.OverlappedGather((4, 3), device="cpu", depth=4, mode=mode, host_staged=True)
+        ks = []
+        for step in range(3):
+            ks.append(og.submit(torch.full((4, 3), float(10 * step + rank))))
+            if rank == 1:
+                time.sleep(0.05)
+        for step, k in enumerate(ks):
+            res = og.result(k)
+            if mode == "all_gather" or rank == 0:
+                ok &= torch.equal(res, torch.stack([torch.full((4, 3), float(10 * step + r)) for r in range(world)]))
+        # a second round re-uses the slots in order
+        k = og.submit(torch.full((4, 3), float(77 + rank)))
+        res = og.result(k)
+        if mode == "all_gather" or rank == 0:
+            ok &= torch.equal(res, torch.stack([torch.full((4, 3), float(77 + r)) for r in range(world)]))
+        og.close()
     out.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -214,3 +235,56 @@ def test_two_ranks_gloo_gather_paths():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == {0: True, 1: True}
+
+
+def _config4_worker(rank, world, port, out):
+    """BASELINE config 4's block map at world size 8: B = 256 images, LRP + Guided-Backprop side by side; every rank explains its 32
+    images only, rank 0 receives both families' (reduced) maps in input order through the known-size gather (no size exchange)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, T = 256, 3
+    g = torch.Generator().manual_seed(1)
+    images = torch.randn(B, 3, 4, 4, generator=g)
+    caps = torch.randint(1, 50, (B, T + 1), generator=g)
+    asked = []
+
+    def load(lo, hi):
+        asked.append((lo, hi))
+        return images[lo:hi].clone(), caps[lo:hi].clone()
+
+    def explain_both(im, cp):          # (LRP maps | guided maps) side by side on the map axis, as bench.py --config 4 produces them
+        m, rw = _fake_explain(im, cp)
+        return torch.cat([m, -2.0 * m], dim=1), rw
+    maps, rw = shard.explain_sharded(explain_both, load, gather=True, n_items=B)
+    ok = asked == [shard.shard_bounds(B, world, rank)] and asked[0] == (32 * rank, 32 * rank + 32)
+    if rank == 0:
+        m, w = _fake_explain(images, caps)
+        ok &= torch.equal(maps, torch.cat([m, -2.0 * m], dim=1)) and torch.equal(rw, w) and maps.shape[0] == B
+    else:
+        ok &= maps is None and rw is None
+    # the reduced gather of the same batch (heat map = channel mean: a third of the bytes)
+    hm, _ = shard.explain_sharded(_fake_explain, images, caps, gather=True, reduce=lambda m: m.mean(dim=1))
+    if rank == 0:
+        ok &= tuple(hm.shape) == (B, 4, 4) and torch.allclose(hm, _fake_explain(images, caps)[0].mean(dim=1))
+    out.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_gloo_config4_block_map():
+    """the first real 8-GPU run must not fail on bookkeeping - world size 8 on gloo (CPU), config 4's B = 256:
+    bounds, order, per-rank loader, full and reduced gather"""
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_config4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == {r: True for r in range(world)}
