@@ -305,6 +305,16 @@ class Vgg16:
         self.conv_mode = None
         self.forward_f16 = None
 
+    # Where the 64 comes from.  The mode-3 gradient kernels carry the two cross products (2^-11 of a product each)
+    # as fp6 e2m3 fields behind ONE block scale per 16-row weight slice: a row whose maximum is s times below its slice's has its fields
+    # rounded with a half-step of up to s / 60 of their own size (e2m3: half-step 2^-4 at field 1, slice maximum at >= 3.75).  A product
+    # of such a row is therefore off by <= 2 x 2^-11 x s / 60 = s x 1.6e-5 of ITSELF, random sign.  An output element sums >= 9 x 16 =
+    # 144 products of a slice and the chain has 12 such layers: if it were carried by the smallest rows alone its error would be about
+    # s x 1.6e-5 x sqrt(12 / 144) = s x 4.7e-6, i.e. 1e-4 at s ~ 21; elements that large rows feed as well (all of them, with random
+    # weights and gradients) dilute that by the rows' own ratio.  Measured on the oracle's activations: 7.6e-6 at s = 63
+    # (tests/test_gpu_guided.py::test_gradient_chain_at_the_row_spread_boundary), 8.4e-5 at a slice spread of 2^13 and 1.1e-4 at 2^25
+    # (log-normal rows, tests/test_gpu_vgg.py::test_chain_hostile_weights_all_modes): 64 keeps a 4x margin to the contract where the
+    # model above would allow ~21 in the worst case and the data allow ~2^13.  Conv mode 1 (the default) has no such rule: exact splits.
     GRAD_SPREAD_MAX = 64.0
 
     def _opts(self, layer_ms=None, grad=False):

@@ -184,3 +184,40 @@ def test_image_gradient_chain_agrees_across_conv_modes(case, plain):
     for mode in (2, 3):
         for i in range(5):
             assert rel_err(outs[mode][i], outs[1][i]) < 1e-4, (mode, i, rel_err(outs[mode][i], outs[1][i]))
+
+
+@pytest.mark.parametrize("target", [63.0, 65.0])
+def test_gradient_chain_at_the_row_spread_boundary(target):
+    """the opt-in mode-3 image-gradient chains share one fp6 block scale over a 16-row weight slice; `ops.Vgg16`
+    moves them to mode 2 when the rows of a slice differ by more than GRAD_SPREAD_MAX (64).  Both sides of the boundary against the
+    CPU oracle (`O.vgg_guided_backprop`, models/gridTDmodel.py:1677-1723) on the oracle's own activations: one row of every slice is
+    scaled so that the largest in-slice ratio of row maxima is 63 (mode 3 runs, must hold 1e-4) or 65 (falls back to mode 2)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import test_gpu_vgg as TV
+    from lrp_amd import ops, weights
+    from oracle import lrp_oracle as O
+    sd = weights.make_gridtd_state(seed=9, vocab_size=64)
+    for k in [k for k in sd if k.startswith("img_encoder.encoder.") and k.endswith(".weight")][1:]:
+        w = sd[k]
+        rmax = np.abs(w).reshape(w.shape[0], -1).max(1)
+        for s0 in range(0, w.shape[0], 16):
+            sl = slice(s0, s0 + 16)
+            # row s0 becomes the slice's smallest: slice maximum / target (the other rows of a kaiming slice lie within 2x of it)
+            w[s0] *= (rmax[sl].max() / target) / rmax[s0]
+    img = torch.from_numpy(weights.make_images(10, 1))
+    vgg = TV._vgg(ops, sd)
+    assert abs(vgg.row_spread / target - 1.0) < 1e-3 and vgg.grad_mode2 == (target > vgg.GRAD_SPREAD_MAX), (vgg.row_spread, target)
+    vgg.conv_mode = 3
+    vgg.forward(img.cuda())
+    TV._inject_oracle_trace(vgg, sd, img)
+    sdt = O.state_to_torch(sd)
+    _, _, saved = O.vgg_forward(sdt, img)
+    gen = torch.Generator().manual_seed(11)
+    d = (torch.randn(2, 512, 14, 14, generator=gen) * torch.exp(torch.randn(2, 512, 14, 14, generator=gen))).contiguous()
+    got = vgg.guided_backprop(TV.to_nhwc(d).cuda(), torch.zeros(2, dtype=torch.int32, device="cuda")).cpu()
+    for i in range(2):
+        want = O.vgg_guided_backprop(sdt, saved, d[i:i + 1])
+        e = rel_err(got[i:i + 1], want)
+        print(f"in-slice row spread {target:.0f} ({'mode 2 fallback' if vgg.grad_mode2 else 'mode 3'}): guided-backprop map {i} vs the oracle {e:.2e}")
+        assert e < 1e-4, (target, i, e)

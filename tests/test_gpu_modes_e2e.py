@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import lrp_amd  # noqa: F401
-from conftest import GOLDEN, rel_err, cosine, assert_close_modulo_pool_ties
+from conftest import GOLDEN, rel_err, cosine, assert_close_modulo_pool_ties, forward_flips
 
 pytestmark = pytest.mark.gpu
 MODES = [1, 0, 2, 3]          # the headline mode first
@@ -25,7 +25,7 @@ def gridtd():
     from lrp_amd.explainers.gridtd import GridTDEngine
     g = np.load(os.path.join(GOLDEN, "gridtd_T3.npz"))
     sd = weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=int(g["V"]))
-    return g, GridTDEngine(sd), torch.from_numpy(weights.make_images(int(g["seed"]), 1)), torch.from_numpy(g["caption"]).view(1, -1)
+    return g, GridTDEngine(sd), torch.from_numpy(weights.make_images(int(g["seed"]), 1)), torch.from_numpy(g["caption"]).view(1, -1), sd
 
 
 @pytest.fixture(scope="module")
@@ -48,14 +48,23 @@ def test_process_default_is_the_exact_split_mode():
 
 @pytest.mark.parametrize("mode", MODES)
 def test_gridtd_explain_vs_reference_in_every_mode(gridtd, mode):
-    g, eng, img, cap = gridtd
+    g, eng, img, cap, sd = gridtd
     keep = eng.vgg.conv_mode
     eng.vgg.conv_mode = mode
     try:
         maps, r_words, r_feat, tr, enc = eng.explain_batch(img, cap, accumulate=True, return_features=True)
         torch.cuda.synchronize()
+        # the discrete decisions of THIS forward trace that differ from the reference's (oneDNN) forward: what the end-to-end deviation of
+        # the pixel maps is made of; printed per run so that the caveat stays quantified
+        flips = forward_flips(eng.vgg, sd, img)
     finally:
         eng.vgg.conv_mode = keep
+    n_relu = sum(f for _, kind, _, f in flips if kind == "conv")
+    n_pool = sum(f for _, kind, _, f in flips if kind == "pool")
+    d_full = (maps[0, 2].cpu() - torch.from_numpy(g["map_full_2"][0])).abs() / np.abs(g["map_full_2"][0]).max()
+    print(f"conv mode {mode}, golden image: {n_relu} ReLU sign flips, {n_pool} live pool-winner flips against the oneDNN forward "
+          f"(per pool: {[f for _, kind, _, f in flips if kind == 'pool']}); full map: worst pixel {d_full.max().item():.2e}, "
+          f"{(d_full > 1e-4).float().mean().item():.2e} of the pixels above 1e-4 of max|R|")
     maps, r_words, r_feat = maps.cpu(), r_words.cpu(), r_feat.cpu()
     for t in range(3):
         want = torch.from_numpy(g[f"r_feat_{t}"])[0].reshape(512, 196).t()
