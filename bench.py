@@ -307,6 +307,9 @@ def parse(argv=None):
     ap.add_argument("--all-heads", action="store_true", help="config 3: explain all 8 heads of every word in the step (8 x B x T maps)")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained sub-measurement (0 = off)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph per batch in flight (config 2 LRP, config 5); measured slower than eager launches with batches in flight in both (DESIGN.md)")
+    ap.add_argument("--replay", type=int, default=None, choices=[0, 1],
+                    help="config 5: issue the step from its recorded call list (AOAEngine.explain_batch_replay: inputs copied into static buffers, then the "
+                         "same launches without the interpreter's per-call cost); default 1 for config 5 (the step is host-bound eagerly), 0 elsewhere")
     ap.add_argument("--pipeline", type=int, default=None,
                     help="independent batches in flight on separate HIP streams (1 = serial steps; default 3, 2 for the "
                          "large configs 3 / 4); every step is still one full pass over one batch, the decoder's "
@@ -329,6 +332,8 @@ def parse(argv=None):
         a.vocab = 9586 if a.config in (2, 4) else 11027
     if a.pipeline is None:
         a.pipeline = 3 if a.config in (2, 5) else 2
+    if a.replay is None:
+        a.replay = 1 if (a.config == 5 and not a.graph) else 0
     return a
 
 
@@ -586,6 +591,8 @@ def run_config(a, dist, rank, world):
         def one_step(e, k):
             if a.graph:          # the step replayed from a HIP graph per batch in flight (the path is host-launch-bound eagerly)
                 return e.explain_batch_graph(caps, a.head, features=feats, predictions=True)
+            if a.replay:         # the step as a recorded call list (explain_batch_replay): same kernels as ordinary launches, ~1.5 us of host time each
+                return e.explain_batch_replay(caps, a.head, features=feats, predictions=True)
             enc = e.encode(features=feats)
             tr = e.trace(enc, caps, predictions=True)
             r_feat, r_words, _ = e.relevance(enc, tr, a.head)
@@ -756,7 +763,7 @@ def run_config(a, dist, rank, world):
                           "unit_of_work": "trace (VGG16 forward + decoder, predictions kept) + decoder relevance + CNN relevance + "
                                           "running sums of the maps" if has_vgg else "decoder trace (predictions kept) + decoder relevance",
                           "sharding": f"images x{world}, no data-path collective" + (f" + terminal gather of the {a.gather} (side stream, double-buffered)" if a.gather else ""),
-                          "batches_in_flight": n_pipe, "launch": ("HIP graph replay per batch in flight" if a.graph else "eager") + (", one host thread per batch in flight" if host_threads else "")},
+                          "batches_in_flight": n_pipe, "launch": ("HIP graph replay per batch in flight" if a.graph else ("recorded call list replayed as ordinary launches (explain_batch_replay)" if (a.replay and a.config == 5) else "eager")) + (", one host thread per batch in flight" if host_threads else "")},
                "median_ms": round(median_ms, 3), "hip_event_ms_per_step": round(ends[-1] / a.steps, 3), "sustained": sustained,
                "build_flags": build_flags, "value_valid": not build_flags}
         if build_flags:

@@ -177,6 +177,11 @@ int lrpx_cumsum_maps(const float* in, float* out, int n_img, int t_per_img, long
  * an image's last word. */
 int lrpx_scatter_maps(const float* in, float* out, int n_img, int t_per_img, const int32_t* lens, const int32_t* offs,
                       long per, int accumulate, void* stream);
+/* dst[0 .. bytes) = 0 on `stream` (hipMemsetAsync).  The host layer clears its scratch through the library, not through the
+ * framework, so that a recorded step (lrp_amd._lib.Recording: the calls of one eager run, replayed without the interpreter's
+ * per-launch cost) contains EVERY device operation of the step. */
+int lrpx_zero(void* dst, size_t bytes, void* stream);
+
 /* dst[r][0..width) = src[rows[r]][0..width) for 4-byte items (per-row operands of the compacted (word, pixel) rules) */
 int lrpx_gather_rows(const void* src, const int32_t* rows, void* dst, int n_rows, int width, void* stream);
 /* dst += src  (the `.grad` accumulation of autograd that compute_lrp relies on, lrp_wrapper.py:80-82) */

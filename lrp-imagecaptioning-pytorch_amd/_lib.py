@@ -4,6 +4,7 @@ There is no CPU fallback: if the shared library is missing or a call fails, an e
 raised.  Error codes map to the exceptions the reference raises at the same places
 (AssertionError for NaN/Inf/zero relevance, ValueError for unsupported layers/shapes)."""
 import ctypes as C
+import threading
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -118,6 +119,7 @@ SIGNATURES = {
     "lrpx_heatmap": (_i, [_f, _i, _i, _l, C.c_float, _f, _i, _f, _f, _f]),
     "lrpx_amax_maps": (_i, [_f, _i, _l, _f, _f]),
     "lrpx_cumsum_maps": (_i, [_f, _f, _i, _i, _l, _f]),
+    "lrpx_zero": (_i, [_f, _sz, _f]),
     "lrpx_scatter_maps": (_i, [_f, _f, _i, _i, _f, _f, _l, _i, _f]),
     "lrpx_gather_rows": (_i, [_f, _f, _f, _i, _i, _f]),
     "lrpx_gridtd_rel_pix_rows": (_i, [C.POINTER(GridTrace), C.POINTER(GridRelState), _f, _f, _f, _f, _i, _f]),
@@ -221,13 +223,70 @@ def load():
     # streams).  Loaded the other way round the process holds two HIP runtimes and ours sees no device.
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    ns = _Namespace()
+    ns._cdll = lib
     for name, (res, args) in SIGNATURES.items():
         if not hasattr(lib, name) and os.environ.get("LRPX_LIB_PATH"):
             continue          # (A/B against an OLDER build of the ABI through LRPX_LIB_PATH: entry points it predates stay unbound)
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    _lib = lib
-    return lib
+        setattr(ns, name, _recordable(fn))
+    _lib = ns
+    return ns
+
+
+class _Namespace(object):
+    """the bound entry points of liblrpx.so (attributes by name; `_cdll`: the ctypes library itself)"""
+
+
+# ---- recorded steps ------------------------------------------------------------------------------------------------------------
+# A step of the decoders is 50 - 330 launches of 5 - 20 us; issuing one from Python costs ~9 us (pointer objects, argument
+# conversion, the status check), so the bottom-up step (config 5) and the one-image drop-in are bound by the INTERPRETER, not by
+# the GPU (DESIGN.md 5.5b).  A `Recording` keeps the (function, arguments) pairs of one eager run of a step together with every
+# tensor / descriptor the arguments point at; `replay()` issues the same calls again - the same kernels in the same order on the
+# same buffers, ~1.5 us of host time each - as ordinary launches on the current stream (no HIP graph: graphs were measured to
+# overlap worse with the other batches in flight).  Like a graph, a recording works on static buffers: the caller copies new
+# inputs into the recorded input tensors first (explainers: explain_batch_replay).
+_TLS = threading.local()
+
+
+class Recording(object):
+    def __init__(self):
+        self.calls, self.keep, self.stream, self.result = [], [], None, None
+
+    def __enter__(self):
+        if getattr(_TLS, "rec", None) is not None:
+            raise LrpxError("a recording is already active on this thread")
+        self.stream = stream_ptr().value
+        _TLS.rec = self
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.rec = None
+        return False
+
+    def replay(self):
+        """issue the recorded calls again on the current stream (which must be the stream of the recording)"""
+        if stream_ptr().value != self.stream:
+            raise LrpxError("a recorded step must be replayed on the stream it was recorded on")
+        for fn, args in self.calls:
+            rc = fn(*args)
+            if rc:
+                check(rc)
+        return self.result
+
+
+def _recordable(fn):
+    status = fn.restype is _i
+
+    def call(*args):
+        rec = getattr(_TLS, "rec", None)
+        if rec is not None and status:
+            rec.calls.append((fn, args))
+        return fn(*args)
+    call.raw = fn
+    call.__name__ = getattr(fn, "__name__", "lrpx")
+    return call
 
 
 def check(rc):
@@ -271,6 +330,9 @@ def ptr(t):
         raise TypeError("lrpx kernels take CUDA tensors (got a %s tensor): there is no CPU path" % t.device.type)
     _same_device(t)
     assert t.is_contiguous(), "lrpx needs contiguous tensors"
+    rec = getattr(_TLS, "rec", None)
+    if rec is not None:
+        rec.keep.append(t)          # the recorded arguments hold this address: the tensor lives as long as the recording
     return C.c_void_p(t.data_ptr())
 
 
@@ -281,6 +343,9 @@ def ptr_at(t, offset_elems=0):
     _same_device(t)
     if t.element_size() != 4:
         raise TypeError("ptr_at counts 4-byte elements (got %s)" % t.dtype)
+    rec = getattr(_TLS, "rec", None)
+    if rec is not None:
+        rec.keep.append(t)
     return C.c_void_p(t.data_ptr() + 4 * offset_elems)
 
 

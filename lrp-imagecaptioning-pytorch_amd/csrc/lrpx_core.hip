@@ -1212,6 +1212,16 @@ int lrpx_scatter_maps(const float* in, float* out, int n_img, int t_per_img, con
     return check_launch("scatter_maps");
 }
 
+int lrpx_zero(void* dst, size_t bytes, void* stream) {
+    LRPX_REQUIRE(dst || bytes == 0, "zero: null pointer");
+    LRPX_CHECK_PTRS_OPT("lrpx_zero", {dst, "dst"});
+    if (bytes && hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream) != hipSuccess) {
+        set_error("zero: hipMemsetAsync failed");
+        return LRPX_ELAUNCH;
+    }
+    return LRPX_OK;
+}
+
 int lrpx_gather_rows(const void* src, const int32_t* rows, void* dst, int n_rows, int width, void* stream) {
     LRPX_CHECK_PTRS_OPT("lrpx_gather_rows", {src, "src"}, {rows, "rows"}, {dst, "dst"});
     LRPX_REQUIRE(src && rows && dst && n_rows > 0 && width > 0, "gather_rows: bad arguments");

@@ -512,7 +512,7 @@ class AOAEngine:
             a_val = e(n, P, H)
             check(lib.lrpx_aoa_rel_value_rows(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), ptr(rowlist), n, st))
         if self.p_v_rel_h is not None and P >= 32:
-            amax2 = torch.zeros(n, dtype=torch.int32, device=self.device)         # max|a_proj| per row: recorded by the first GEMM
+            amax2 = ops.zeros(n, dtype=torch.int32, device=self.device)           # max|a_proj| per row: recorded by the first GEMM
             ops.conv_mfma(a_val, self.p_v_rel_head[int(head_idx)] if head_only else self.p_v_rel_h, n, 0, dk if head_only else H, H, 1,
                           EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
                           zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img, out1=a_proj, f16x3=1,
@@ -590,6 +590,37 @@ class AOAEngine:
         graph.replay()
         return out
 
+    def explain_batch_replay(self, captions, head_idx, images=None, features=None, accumulate=False, predictions=False):
+        """`explain_batch` as a RECORDED step (lrp_amd._lib.Recording): the first call with a given input shape runs the step eagerly
+        on static copies of the inputs and keeps its library calls - functions, arguments, and every buffer they point at; later calls
+        copy the inputs into those static buffers and issue the same calls again: the same kernels in the same order on the same
+        stream, as ordinary launches (they overlap with other streams' kernels like any launch; a HIP graph replay did not), without the
+        interpreter's ~9 us per launch.  Bit-identical to `explain_batch` by construction.  Like a graph's, the returned tensors are
+        the recording's static outputs: overwritten by the next call of the same shape on this engine (take `replica()`s for batches
+        in flight).  Captions of equal length only (`lens` makes the launch sequence data-dependent)."""
+        src = features if features is not None else images
+        src = src.to(self.device, torch.float32)
+        captions = captions.to(self.device, torch.int64)
+        key = (tuple(src.shape), tuple(captions.shape), bool(accumulate), bool(predictions), _lib.stream_ptr().value,
+               self.vgg.conv_mode if self.vgg is not None else None, int(head_idx), features is not None)
+        if not hasattr(self, "_recordings"):
+            self._recordings = {}
+        rec = self._recordings.get(key)
+        if rec is None:
+            st_src, st_cap = src.clone(), captions.clone()
+            # warm-up outside the recording: one-time work (kernel attributes, index caches, workspace allocations) must not be replayed
+            self.explain_batch(st_cap, head_idx, accumulate=accumulate, predictions=predictions, **({"features": st_src} if features is not None else {"images": st_src}))
+            rec = _lib.Recording()
+            with rec:
+                rec.result = self.explain_batch(st_cap, head_idx, accumulate=accumulate, predictions=predictions, **({"features": st_src} if features is not None else {"images": st_src}))
+            rec.inputs = (st_src, st_cap)
+            self._recordings[key] = rec
+            return rec.result
+        st_src, st_cap = rec.inputs
+        st_src.copy_(src)
+        st_cap.copy_(captions)
+        return rec.replay()
+
     def replica(self):
         """A second execution context over the SAME weights: own VGG16 trace / workspace buffers, so that several
         batches can be in flight on separate HIP streams (as GridTDEngine.replica)."""
@@ -598,7 +629,7 @@ class AOAEngine:
         if self.vgg is not None:
             r.vgg = self.vgg.replica()
         r._idx_cache = {}
-        for k in ("_graphs", "_replicas", "_streams"):
+        for k in ("_graphs", "_replicas", "_streams", "_recordings"):
             r.__dict__.pop(k, None)
         return r
 

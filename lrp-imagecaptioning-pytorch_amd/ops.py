@@ -79,8 +79,19 @@ def zeros_arena(device, shapes):
             n *= int(d)
         offs[k] = (total, n)
         total += -(-n // 64) * 64
-    flat = torch.zeros(total, device=device, dtype=torch.float32)
+    flat = zeros(total, device=device)
     return {k: flat[o:o + n].view(*shapes[k]) for k, (o, n) in offs.items()}
+
+
+def zeros(*shape, dtype=torch.float32, device="cuda"):
+    """a zero tensor cleared THROUGH THE LIBRARY (lrpx_zero) on the current stream: a recorded step (_lib.Recording) then holds the
+    clear like any other launch of the step (a `torch.zeros` would run once, at recording time, and never again)"""
+    if torch.device(device).type != "cuda":          # (host-logic tests: layout checks of the arena without a GPU)
+        return torch.zeros(*shape, dtype=dtype, device=device)
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if t.numel():
+        check(_lib.load().lrpx_zero(ptr(t), t.numel() * t.element_size(), stream_ptr()))
+    return t
 
 
 def amax_maps(s, n_maps):
