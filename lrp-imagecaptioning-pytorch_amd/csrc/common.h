@@ -115,6 +115,7 @@ struct Switches {
     int linear_valu;     // LRPX_LINEAR_VALU: the VALU skinny linear instead of the fp32-MFMA one
     int b6_fwd_ksplit28; // LRPX_B6_FWD_KSPLIT28 (default 4): K ranges per tile of the 28x28 layers of the exact-split (conv mode 1) forward trace
     int b6_fwd_ksplit56; // LRPX_B6_FWD_KSPLIT56 (default 2): ... of the 56x56 layers
+    int b6_wide;         // LRPX_B6_WIDE (bit mask): 8-wave conv-mode-1 relevance kernels for 56/28 (1), 14 (2), pooled-input 56/28 (4)
     int x6_legacy;       // LRPX_X6_LEGACY: conv mode 1 on round 1's flow (conv_bf16x6.h with EPI_REL + pool kernels) instead of the fused B6 kernels
 };
 const Switches& switches();      // (lrpx_core.hip)

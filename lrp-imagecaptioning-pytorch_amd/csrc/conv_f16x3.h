@@ -1228,8 +1228,10 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     // map-straddling tiles (28/14) spill beyond 7
     constexpr int NBQ_H3 = !AL ? 7 : (HW == 224 ? (POOL ? 10 : 5) : (((HW == 112 && NWN == 2) || (HOIST && !POOL)) ? 8 : 9));
     // B6: three planes per entry (12 registers)
+    // (measured, same-box A/B of builds: the map-aligned pooled-input kernels have the registers for a deeper queue - their staging items
+    // are a quarter as many - conv1_2 5.16 -> 5.04 ms, conv2_2 4.41 -> 4.25; one entry more spills in every other instantiation)
 #ifndef LRPXB6_NBQ
-#define LRPXB6_NBQ ((HW <= 56) ? 5 : 4)
+#define LRPXB6_NBQ ((POOL && AL) ? (HW == 112 ? 7 : 6) : ((HW <= 56) ? 5 : 4))
 #endif
     constexpr int NBQ = B6 ? LRPXB6_NBQ : NBQ_H3;
 #endif

@@ -71,6 +71,11 @@ int launch_b6_224_pool(const ConvArgs& a, hipStream_t s);
 int launch_b6_112_pool(const ConvArgs& a, hipStream_t s);
 int launch_b6_56_pool(const ConvArgs& a, hipStream_t s);
 int launch_b6_28_pool(const ConvArgs& a, hipStream_t s);
+int launch_b6_56w_rel(const ConvArgs& a, hipStream_t s);       // ... 8-wave workgroups (LRPX_B6_WIDE)
+int launch_b6_28w_rel(const ConvArgs& a, hipStream_t s);
+int launch_b6_14w_rel(const ConvArgs& a, hipStream_t s);
+int launch_b6_56w_pool(const ConvArgs& a, hipStream_t s);
+int launch_b6_28w_pool(const ConvArgs& a, hipStream_t s);
 int launch_b6_112n_guided(const ConvArgs& a, hipStream_t s);   // ... image-gradient chains (GUIDED: guided backprop / plain gradient)
 int launch_b6_56_guided(const ConvArgs& a, hipStream_t s);
 int launch_b6_28_guided(const ConvArgs& a, hipStream_t s);

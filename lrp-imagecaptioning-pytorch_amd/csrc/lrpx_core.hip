@@ -73,6 +73,7 @@ const Switches& switches() {
         w.dense_1wave = set("LRPX_DENSE_1WAVE");
         w.linear_valu = set("LRPX_LINEAR_VALU");
         w.x6_legacy = set("LRPX_X6_LEGACY");
+        w.b6_wide = num("LRPX_B6_WIDE", 0);
         w.b6_fwd_ksplit28 = num("LRPX_B6_FWD_KSPLIT28", 4);
         w.b6_fwd_ksplit56 = num("LRPX_B6_FWD_KSPLIT56", 2);
         return w;

@@ -235,6 +235,9 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
             // the conv sits under a 2x2 max-pool: `in` at the pool's output resolution, unpooled while staged (conv_f16x3.h, POOL + B6)
             LRPX_REQUIRE((long)d->n_maps * (d->hw / 2) * (d->hw / 2) * d->cin < 0x7fffffffL,
                          "conv_mfma: too many (image, pooled pixel, channel) elements for the pooled-input kernel");
+            const int b6w = switches().b6_wide;
+            if ((b6w & 4) && d->hw == 56 && d->n_oc >= 256) return launch_b6_56w_pool(a, s);
+            if ((b6w & 4) && d->hw == 28 && d->n_oc >= 256) return launch_b6_28w_pool(a, s);
             if (d->hw == 224 && d->n_oc <= 64) return launch_b6_224_pool(a, s);
             if (d->hw == 112 && d->n_oc > 64) return launch_b6_112_pool(a, s);
             if (d->hw == 56) return launch_b6_56_pool(a, s);
@@ -242,6 +245,10 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
             LRPX_REQUIRE(false, "conv_mfma: no pooled-input bf16x6 kernel built for hw=%d n_oc=%d", d->hw, d->n_oc);
         }
         if (d->epi == EPI_REL_MUL) {
+            const int b6w = switches().b6_wide;
+            if ((b6w & 1) && d->n_oc >= 256 && d->hw == 56) return launch_b6_56w_rel(a, s);
+            if ((b6w & 1) && d->n_oc >= 256 && d->hw == 28) return launch_b6_28w_rel(a, s);
+            if ((b6w & 2) && d->n_oc >= 256 && d->hw == 14) return launch_b6_14w_rel(a, s);
             if (d->hw == 224 && d->n_oc <= 64) return launch_b6_224_rel(a, s);
             if (d->hw == 112) return d->n_oc <= 64 ? launch_b6_112n_rel(a, s) : launch_b6_112_rel(a, s);
             if (d->hw == 56) return launch_b6_56_rel(a, s);

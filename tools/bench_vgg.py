@@ -17,11 +17,12 @@ ap.add_argument("--maps", type=int, default=80)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--fp32", action="store_true", help="same as --mode 0")
-ap.add_argument("--mode", type=int, default=3, help="0 fp32 MFMA, 1 bf16x6, 2 f16x3, 3 f16x3 with fp6 cross products in the relevance pass (default)")
+ap.add_argument("--mode", type=int, default=None, help="0 fp32 MFMA, 1 bf16x6 exact splits, 2 f16x3, 3 f16x3 with fp6 cross products in the relevance pass (default: the library's process default = 1)")
 a = ap.parse_args()
 
 from lrp_amd import _lib
-_lib.load().lrpx_set_conv_mode(0 if a.fp32 else a.mode)
+if a.fp32 or a.mode is not None:
+    _lib.load().lrpx_set_conv_mode(0 if a.fp32 else a.mode)
 sd = weights.make_gridtd_state(seed=0, vocab_size=64)
 names = [k for k in sd if k.startswith("img_encoder.encoder.") and k.endswith(".weight")]
 vgg = ops.Vgg16([torch.from_numpy(sd[k]).cuda() for k in names],

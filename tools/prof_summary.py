@@ -78,14 +78,14 @@ def pipe(dirs):
     """matrix-pipe utilisation per kernel from the counters: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / 1024 against
     GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs), per-launch means; MFMA operations by type; LDS bank-conflict share"""
     data = counters(dirs)
-    print(f"{'kernel':64s} {'launches':>8s} {'Mcycles':>9s} {'pipe busy':>10s} {'MOPS f16':>10s} {'MOPS f8':>10s} {'MOPS f6f4':>10s} {'MOPS f32':>10s} {'LDS confl':>10s}")
+    print(f"{'kernel':64s} {'launches':>8s} {'Mcycles':>9s} {'pipe busy':>10s} {'MOPS f16':>10s} {'MOPS bf16':>10s} {'MOPS f8':>10s} {'MOPS f6f4':>10s} {'MOPS f32':>10s} {'LDS confl':>10s}")
     for k, c in sorted(data.items()):
         if "GRBM_GUI_ACTIVE" not in c or "SQ_VALU_MFMA_BUSY_CYCLES" not in c:
             continue
         m = lambda n: sum(c[n]) / len(c[n]) if n in c else 0.0
         gui = m("GRBM_GUI_ACTIVE") / 8
         print(f"{k[:64]:64s} {len(c['SQ_VALU_MFMA_BUSY_CYCLES']):8d} {gui/1e6:9.3f} {m('SQ_VALU_MFMA_BUSY_CYCLES')/1024/max(gui,1):10.3f} "
-              f"{m('SQ_INSTS_VALU_MFMA_MOPS_F16')/1e9:10.2f} {m('SQ_INSTS_VALU_MFMA_MOPS_F8')/1e9:10.2f} {m('SQ_INSTS_VALU_MFMA_MOPS_F6F4')/1e9:10.2f} {m('SQ_INSTS_VALU_MFMA_MOPS_F32')/1e9:10.2f} "
+              f"{m('SQ_INSTS_VALU_MFMA_MOPS_F16')/1e9:10.2f} {m('SQ_INSTS_VALU_MFMA_MOPS_BF16')/1e9:10.2f} {m('SQ_INSTS_VALU_MFMA_MOPS_F8')/1e9:10.2f} {m('SQ_INSTS_VALU_MFMA_MOPS_F6F4')/1e9:10.2f} {m('SQ_INSTS_VALU_MFMA_MOPS_F32')/1e9:10.2f} "
               f"{m('SQ_LDS_BANK_CONFLICT')/max(m('SQ_LDS_IDX_ACTIVE'),1):10.3f}")
 
 
