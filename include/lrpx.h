@@ -217,8 +217,11 @@ int lrpx_set_bf16x6(int enable);
  * accumulate: 24 significand bits and fp32's exponent range per operand - THE DEFAULT since round 6, arithmetic no narrower than the
  * reference's fp32 convolutions, LRPtools/lrp_modules.py:124-150), 2 f16x3 (fp16 split products behind per-map power-of-two
  * scales: 22 operand bits, fp16's exponent range below the map maximum), 3 = 2 with the cross products of the relevance pass on the fp6
- * matrix cores (lrpx_conv_desc.f16x3 = 2).  Modes 2 / 3 are opt-in speed modes (1.8x / 2.4x the maps/s of mode 1, inside the 1e-4
- * contract on every tested input).  LRPX_CONV_MODE in the environment sets the initial default (read once at load).
+ * matrix cores (lrpx_conv_desc.f16x3 = 2).  Modes 2 / 3 are opt-in speed modes (1.6x / 2.0 - 2.2x the maps/s of mode 1, inside the 1e-4
+ * contract on every tested input of natural range).  RANGE CONTRACT of modes 2 / 3: the relevance operand S = R / Z+ of a layer is scaled by
+ * ONE power of two per map into the fp16 range; entries more than ~2^29 below the map's maximum flush to zero and entries below ~2^-15 of it
+ * lose bits, so a map whose layer activations differ by more than ~2^16 BETWEEN REGIONS of one image (S = R / Z+ then spans that range the
+ * other way) is rounded against its largest region: tests/test_gpu_range.py pins 1e-2-grade maps on a 2^33 range, where modes 0 / 1 keep 1e-4.  LRPX_CONV_MODE in the environment sets the initial default (read once at load).
  * Negative: query only.  Returns the previous mode. */
 int lrpx_set_conv_mode(int mode);
 /* 1 (conv modes 2 / 3 only): the forward trace of conv1_1..conv5_3 also runs on the fp16 split-product kernels (operand scale =

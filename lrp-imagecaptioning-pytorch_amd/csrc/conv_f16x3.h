@@ -642,6 +642,15 @@ __global__ __launch_bounds__(64 * MT * NWN, (MT * NWN >= 8) ? 1 : 2) void conv_f
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
+#ifdef LRPXB6_PRIO
+    // (experiment, round 6) the two workgroups of a CU tend to phase-lock - the one that is alone in its matrix phase runs at twice the
+    // speed and catches up with the other's barrier - so that both stage at the same time and the matrix pipe idles (busy 0.79).  A STATIC
+    // asymmetry per SIMD: the wave in an odd hardware slot issues with priority, the other fills the gaps.
+    if constexpr (B6) {
+        const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));      // HW_REG_HW_ID, WAVE_ID[3:0]
+        if (hwid & 1u) __builtin_amdgcn_s_setprio(LRPXB6_PRIO); else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     // (the body stays in the __global__ function: as an inlined device function taking the argument struct by value it spilled 12 - 25
     // registers in every instantiation - the struct no longer lived in the kernel-argument segment - and ran 6 - 8 % slower)
     const int bid = blockIdx.x;

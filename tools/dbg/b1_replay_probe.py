@@ -30,5 +30,9 @@ for mode in (1, 3):
     torch.cuda.synchronize(); t0 = time.perf_counter(); eng.explain_batch(img, cap, accumulate=True, predictions=True); h_e = (time.perf_counter() - t0) * 1e3
     torch.cuda.synchronize(); t0 = time.perf_counter(); eng.explain_batch_replay(img, cap, accumulate=True, predictions=True); h_r = (time.perf_counter() - t0) * 1e3
     torch.cuda.synchronize()
+    for _ in range(3):
+        eng.explain_batch_graph(img, cap, accumulate=True, predictions=True)
+    g = timed(lambda: eng.explain_batch_graph(img, cap, accumulate=True, predictions=True))
+    print(f"mode {mode}: HIP graph replay {g:.2f} ms", flush=True)
     n = len(next(iter(eng._recordings.values())).calls)
     print(f"mode {mode}: eager {e:.2f} ms (host issue {h_e:.2f} ms), replay {r:.2f} ms (host issue {h_r:.2f} ms), {n} recorded calls", flush=True)
