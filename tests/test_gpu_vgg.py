@@ -37,7 +37,7 @@ def from_nhwc(x, c, h, w):
     return x[:, :, :c].reshape(x.shape[0], h, w, c).permute(0, 3, 1, 2).contiguous()
 
 
-def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False, f16x3=False, zdiv_next=None):
+def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False, f16x3=False, zdiv_next=None, b6=False):
     """alpha1beta0 rule for one conv layer with non-negative input x (n_img,cin,hw,hw); r_out per map."""
     from lrp_amd import _lib
     n_img, cin, hw, _ = x.shape
@@ -64,7 +64,7 @@ def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False, f16x3
     kc_b = ops.conv_kc(hw, 9, cout_p)
     if f16x3:
         wb = (ops.pack_weights_f16f8 if int(f16x3) == 2 else ops.pack_weights_f16x2)(wg, cout_p, cin_p, _lib.PACK_BWD_POS)
-    elif bf16x6:
+    elif bf16x6 or b6:
         wb = ops.pack_weights_bf16x3(wg, cout_p, cin_p, _lib.PACK_BWD_POS)
     else:
         wb = ops.pack_weights(wg, cout_p, cin_p, 9, _lib.PACK_BWD_POS, kc_b)
@@ -84,6 +84,9 @@ def gpu_conv_rule(ops, x, w, r_out, map2img=None, bias=None, bf16x6=False, f16x3
                           out1=out1, f16x3=int(f16x3), in_amax=amax_in, out1_amax=out1_amax)
             torch.cuda.synchronize()
             gpu_conv_rule.last_out1 = (out1.cpu(), out1_amax.cpu())
+    elif b6:
+        # conv mode 1's kernels (round 6; conv_f16x3.h with B6): REL_MUL on the exact bf16 splits - no operand scale, no amax
+        ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xg, map2img=m2i, out0=r_in, bf16x6=1)
     else:
         ops.conv_mfma(s, wb, n_maps, hw, cout_p, cin_p, 9, _lib.EPI_REL, oc_split=cin_p, x=xg, map2img=m2i, out0=r_in,
                       bf16x6=int(bf16x6))
@@ -109,6 +112,32 @@ def test_conv_rule_vs_oracle(ops, hw, cin, cout, n_img, n_maps):
     assert rel_err(zpos, F.conv2d(x, w.clamp(min=0), padding=1)) < 1e-5
     assert rel_err(got, want) < TOL
     assert cosine(got, want) > 0.99999
+
+
+@pytest.mark.parametrize("hw,cin,cout,n_img,n_maps", [(14, 64, 96, 3, 5), (28, 32, 64, 2, 3), (56, 64, 128, 1, 2), (112, 64, 128, 1, 2),
+                                                      (112, 128, 128, 1, 1), (224, 64, 64, 1, 1), (14, 512, 32, 2, 3)])
+def test_conv_rule_b6_rel_mul_is_fp32_accurate(ops, hw, cin, cout, n_img, n_maps):
+    """round 6: the exact-split kernels of conv mode 1 on the conv_f16x3.h tiling (REL_MUL, every map size incl. both 112 tiles and the
+    8-wave 224 tile) against the oracle (1e-4), against the fp32-MFMA kernel (1e-5) and BIT FOR BIT against... nothing: the summation
+    order differs from round 1's kernel - so the bound against that kernel is 2e-6.  Relevance spread over e^+-4 with NO per-map scale:
+    bf16 parts carry fp32's exponent range"""
+    from oracle import lrp_oracle as O
+    g = torch.Generator().manual_seed(hw * 71 + cin)
+    x = torch.relu(torch.randn(n_img, cin, hw, hw, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    r = torch.randn(n_maps, cout, hw, hw, generator=g) * torch.exp(4 * torch.randn(n_maps, cout, hw, hw, generator=g))
+    r[0] *= 1e-20          # a map 2^66 below its neighbours: nothing is scaled, nothing flushes
+    m2i = [i % n_img for i in range(n_maps)]
+    got, _, _ = gpu_conv_rule(ops, x, w, r, m2i, b6=True)
+    got32, _, _ = gpu_conv_rule(ops, x, w, r, m2i)
+    want = torch.cat([O.conv_alpha1beta0(x[m2i[i]:m2i[i] + 1], w, r[i:i + 1]) for i in range(n_maps)])
+    for i in range(n_maps):
+        assert rel_err(got[i], want[i]) < TOL, i
+        assert rel_err(got[i], got32[i]) < 1e-5, i
+        assert cosine(got[i], want[i]) > 0.99999
+    if hw <= 56:
+        got6, _, _ = gpu_conv_rule(ops, x, w, r, m2i, bf16x6=True)          # round 1's kernel (EPI_REL): the same products, another order
+        assert max(rel_err(got[i], got6[i]) for i in range(n_maps)) < 2e-6
 
 
 @pytest.mark.parametrize("hw,cin,cout,n_img,n_maps", [(14, 64, 96, 3, 5), (28, 32, 64, 2, 3), (56, 64, 128, 1, 2)])
@@ -204,7 +233,7 @@ def test_conv_rule_f16f8(ops, hw, cin, cout, n_img, n_maps):
     print("f16f8 single-layer error vs fp32 MFMA per map:", ["%.2e" % e for e in errs])
 
 
-@pytest.mark.parametrize("f8", [False, True])
+@pytest.mark.parametrize("f8", [False, True, "b6"])
 @pytest.mark.parametrize("hw,cpool,cin,n_img,n_maps", [(28, 64, 32, 2, 3), (56, 32, 64, 1, 2), (112, 32, 128, 1, 2),
                                                         (224, 16, 64, 1, 1),
                                                         # 8-wave pooled-input kernels (conv3_3 / conv4_3 of the chain)
@@ -253,12 +282,17 @@ def test_pooled_input_conv_rule(ops, hw, cpool, cin, n_img, n_maps, f8):
     s_lo = to_nhwc(r_pool_out, cp).to(dev) / (to_nhwc(pooled, cp).to(dev)[m2i] + 1e-7 * (to_nhwc(pooled, cp).to(dev)[m2i] == 0))
     s_lo = (s_lo * xzw[m2i]).contiguous()
     wpad = torch.zeros(cp, cin_p, 3, 3); wpad[:cpool, :cin] = w
-    wb = (ops.pack_weights_f16f8 if f8 else ops.pack_weights_f16x2)(wpad.to(dev), cp, cin_p, _lib.PACK_BWD_POS)
     xg = to_nhwc(xin, cin_p).to(dev)
     r_in = torch.empty(n_maps, hw * hw, cin_p, device=dev)
-    ops.conv_mfma(s_lo, wb, n_maps, hw, cp, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xg,
-                  map2img=torch.tensor(m2i, dtype=torch.int32, device=dev), out0=r_in, f16x3=2 if f8 else 1,
-                  in_amax=ops.amax_maps(s_lo, n_maps), pool_am=am)
+    if f8 == "b6":      # conv mode 1's kernels (round 6): exact bf16 splits, no operand scales (bf16x6 = 1 with REL_MUL + pool_am)
+        wb = ops.pack_weights_bf16x3(wpad.to(dev), cp, cin_p, _lib.PACK_BWD_POS)
+        ops.conv_mfma(s_lo, wb, n_maps, hw, cp, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xg,
+                      map2img=torch.tensor(m2i, dtype=torch.int32, device=dev), out0=r_in, bf16x6=1, pool_am=am)
+    else:
+        wb = (ops.pack_weights_f16f8 if f8 else ops.pack_weights_f16x2)(wpad.to(dev), cp, cin_p, _lib.PACK_BWD_POS)
+        ops.conv_mfma(s_lo, wb, n_maps, hw, cp, cin_p, 9, _lib.EPI_REL_MUL, oc_split=cin_p, x=xg,
+                      map2img=torch.tensor(m2i, dtype=torch.int32, device=dev), out0=r_in, f16x3=2 if f8 else 1,
+                      in_amax=ops.amax_maps(s_lo, n_maps), pool_am=am)
     torch.cuda.synchronize()
     got = from_nhwc(r_in.cpu(), cin, hw, hw)
     for i in range(n_maps):

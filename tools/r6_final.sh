@@ -6,7 +6,7 @@ TAG=${1:-r06}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-WHAT=${2:-tests bench prof pmc sq b1}
+WHAT=${2:-tests bench prof pmc sq b1 smoke gloo}
 if [[ $WHAT == *tests* ]]; then
   LRPX_TIE_STATS=1 timeout -k 10 1100 python -m pytest tests -q -m gpu -s > $OUT/tests.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed" $OUT/tests.log | tail -2
 fi
@@ -49,6 +49,13 @@ if [[ $WHAT == *sq* ]]; then
   cd $ROOT
   python tools/prof_summary.py sq $OUT/pmc/A $OUT/pmc/E $OUT/pmc/F $OUT/pmc/G > $OUT/pmc_sq.txt 2>&1
   python tools/prof_summary.py pipe $OUT/pmc/A $OUT/pmc/E $OUT/pmc/F $OUT/pmc/G > $OUT/pmc_pipe.txt 2>&1; cat $OUT/pmc_pipe.txt
+fi
+if [[ $WHAT == *smoke* ]]; then
+  timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
+fi
+if [[ $WHAT == *gloo* ]]; then
+  LRPX_BENCH_BACKEND=gloo LRPX_BENCH_ONE_GPU=1 timeout -k 10 400 python bench.py --gpus 2 --gather --steps 6 --warmup 2 --no-cpu-baseline --no-modes --no-configs --sustain 0 --pipeline 2 > $OUT/bench_2rank_gloo_gather.json 2> $OUT/bench_2rank_gloo_gather.err; echo "gloo gather rc=$?"; cat $OUT/bench_2rank_gloo_gather.json | head -c 400; echo
+  LRPX_BENCH_BACKEND=gloo LRPX_BENCH_ONE_GPU=1 timeout -k 10 400 python bench.py --gpus 2 --gather heatmap --steps 6 --warmup 2 --no-cpu-baseline --no-modes --no-configs --sustain 0 --pipeline 2 > $OUT/bench_2rank_gloo_heatmap.json 2> $OUT/bench_2rank_gloo_heatmap.err; echo "gloo heatmap rc=$?"; cat $OUT/bench_2rank_gloo_heatmap.json | head -c 300; echo
 fi
 rm -rf $OUT/pmc/*/*/*.db
 exit 0
