@@ -740,6 +740,42 @@ def test_rel_mul_rejects_two_outputs_and_never_writes_past_the_last_map(ops):
             assert oamax[i:i + 1].view(torch.float32).item() == out[i].abs().max().item()
 
 
+@pytest.mark.parametrize("epi", ["rel_mul", "guided", "pool"])
+@pytest.mark.parametrize("hw,n_maps", [(14, 5), (28, 3), (14, 1), (56, 1)])
+def test_b6_kernels_never_write_past_the_last_map(ops, hw, n_maps, epi):
+    """the same guard-band check for conv mode 1's kernels (round 6: conv_f16x3.h with B6 - 112-byte LDS pixels, three planes, no
+    amax), REL_MUL / GUIDED and the pooled-input staging: a partial last workgroup tile must neither store behind the tensor nor read
+    outside its inputs (the input tensors sit at the END of their allocations), and every element of the output is written"""
+    from lrp_amd import _lib
+    if epi == "pool" and hw == 14:
+        pytest.skip("no pooled-input kernel for 14 x 14 maps (conv5_x never sits under a pool)")
+    g = torch.Generator().manual_seed(19)
+    cin = cout = 64
+    ho = hw // 2
+    n_in = n_maps * (ho * ho if epi == "pool" else hw * hw) * cout
+    pad = 4096
+    sbuf = torch.zeros(pad + n_in, device="cuda")
+    sbuf[pad:] = torch.randn(n_in, generator=g).cuda()
+    s = sbuf[pad:].view(n_maps, -1, cout)
+    x = torch.rand(n_maps, hw * hw, cin, generator=g).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+    wb = ops.pack_weights_bf16x3(w, cout, cin, _lib.PACK_BWD_POS)
+    n_out = n_maps * hw * hw * cin
+    guard = 448 * cin
+    buf = torch.full((n_out + guard,), 12345.0, device="cuda")
+    out = buf[:n_out].view(n_maps, hw * hw, cin)
+    kw = {}
+    if epi == "pool":
+        kw["pool_am"] = torch.randint(0, 4, (n_maps, ho * ho, cout), generator=g).to(torch.uint8).cuda()
+    e = _lib.EPI_GUIDED if epi == "guided" else _lib.EPI_REL_MUL
+    ops.conv_mfma(s, wb, n_maps, hw, cout, cin, 9, e, oc_split=cin, x=x, bf16x6=1, **({"out0": out} if epi == "guided" else {"out1": out}), **kw)
+    torch.cuda.synchronize()
+    assert (buf[n_out:] == 12345.0).all(), (hw, epi)
+    assert torch.isfinite(out).all() and (out != 12345.0).all()
+    with pytest.raises(ValueError):          # REL_MUL takes exactly one output in this family too
+        ops.conv_mfma(s, wb, n_maps, hw, cout, cin, 9, _lib.EPI_REL_MUL, oc_split=cin, x=x, out0=out, out1=out, bf16x6=1, **kw)
+
+
 def test_per_context_conv_mode_in_flight_on_two_streams(ops, gridtd_case):
     """the conv mode travels per call (lrpx_vgg16_opts): two contexts over the same weights with DIFFERENT modes run
     interleaved on two streams and each reproduces, bit for bit, what a process-wide setter run of its mode gives - while
