@@ -18,6 +18,12 @@ Other BASELINE configs as optional lines (the headline stays config 2):
                                (= --explainer lrp+guided --batch 32; 2 x 640 maps / step)
     --config 5                 AoA bottom-up, 36x2048 region features, B=32 per GPU, relevance back to the features
 
+Arithmetic of the line (round 6): `value`, `dtype`, `ms_per_step` and `roofline` are measured in CONV MODE 1 - every fp32 operand of the VGG16
+contractions split exactly into three bf16 parts (24 significand bits, fp32's exponent range), six matrix-core products, fp32 accumulate: no
+narrower than the reference's fp32 convolutions (LRPtools/lrp_modules.py:124-150, utils.py:21-31); it is also the library's process default.
+The opt-in speed modes are reported beside it as top-level scalars: `value_f16x3`, `value_f16f6` (and `value_fp32_mfma`), each with
+`dev_chain_<mode>` / `dev_step_<mode>` = its worst-map deviation from the fp32-MFMA chain measured in this run on the step's own 320 maps.
+
 Rank 0 prints ONE JSON line.  At N=1 it also carries
   roofline     : MFMA roofline of the dominant kernel = the relevance conv kernel NAME with the largest total time over the
                  12 conv launches of one pass (30.69 GFLOP per map), picked from this run's own per-launch HIP-event times
@@ -25,7 +31,7 @@ Rank 0 prints ONE JSON line.  At N=1 it also carries
                  `traffic` = HBM bytes per launch from the PMC counters: measured in this run by two `rocprofv3 --pmc` child passes
                  over the chain alone before the timed region (`traffic_source` says so; --no-live-traffic or any failure: the PMC
                  summary committed under profiles/, separate --pmc passes of tools/pmc_passes.sh);
-                 `modes`: the same step and chain in every matrix-core mode (0 fp32 MFMA ... 3 fp16+fp6), same process
+                 `modes`: the same step and chain in every matrix-core mode (0 fp32 MFMA ... 3 fp16+fp6), same process, with `dev_vs_fp32`
   sustained    : the same step repeated for >= --sustain seconds (power-limited clocks show here, not in 20 steps)
   median_ms    : median interval between step completions (HIP events) inside the timed region
   cpu_baseline : the reference-equivalent CPU mode (oracle/ref_equiv.py, kind "port") on a bounded sample.

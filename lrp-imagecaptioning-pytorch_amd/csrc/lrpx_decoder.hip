@@ -2167,6 +2167,25 @@ int lrpx_aoa_fwd_inputs(const lrpx_aoa_trace* tr, const float* glob, const float
 
 static int aoa_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* zin, const float* tab, const float* gimg,
                           const long long* tok, int tok_ld, hipStream_t st) {
+    if (tr->B > 64) {
+        // more than 64 images: slices of at most 64 through the SAME kernels (the recurrence is independent per image), so that an image's
+        // trace does not depend on the batch it sits in (B = 65 used to leave the decoupled path altogether)
+        const long T = tr->T, H = tr->H, W = tr->E + 2L * tr->H;
+        for (int b0 = 0; b0 < tr->B; b0 += 64) {
+            lrpx_aoa_trace sub = *tr;
+            sub.B = tr->B - b0 < 64 ? tr->B - b0 : 64;
+            sub.xh += b0 * T * W;
+            sub.h += b0 * (T + 1) * H; sub.c += b0 * (T + 1) * H;
+            sub.g += b0 * T * H; sub.i += b0 * T * H; sub.f += b0 * T * H;
+            sub.ctx += b0 * T * H; sub.lin += b0 * T * H; sub.c_aoa += b0 * T * H; sub.hc += b0 * T * H;
+            sub.alpha += b0 * T * tr->NH * (long)tr->P;
+            if (sub.o) sub.o += b0 * T * H;
+            if (sub.sg) sub.sg += b0 * T * H;
+            LRPX_TRY(aoa_recurrence(&sub, w_hh_il, zin ? zin + b0 * T * 4 * H : nullptr, tab, gimg ? gimg + b0 * 4L * H : nullptr,
+                                    tok ? tok + (long)b0 * tok_ld : nullptr, tok_ld, st));
+        }
+        return LRPX_OK;
+    }
     const AoaFwd g = to_afwd(tr);
     const int H = tr->H, B = tr->B;
     for (int t = 0; t < tr->T; ++t) {
@@ -2182,7 +2201,7 @@ static int aoa_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const 
 int lrpx_aoa_fwd_recurrence(const lrpx_aoa_trace* tr, const float* w_hh_il, const float* zin, void* stream) {
     LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_recurrence", {w_hh_il, "w_hh_il"}, {zin, "zin"});
     LRPX_TRY(check_atrace(tr));
-    LRPX_REQUIRE(w_hh_il && zin && tr->B <= 64 && tr->H % 16 == 0, "aoa_fwd_recurrence: bad arguments (<= 64 images, H %% 16)");
+    LRPX_REQUIRE(w_hh_il && zin && tr->H % 16 == 0, "aoa_fwd_recurrence: bad arguments (H %% 16)");
     return aoa_recurrence(tr, w_hh_il, zin, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -2190,8 +2209,8 @@ int lrpx_aoa_fwd_recurrence_tab(const lrpx_aoa_trace* tr, const float* w_hh_il, 
                                 const long long* tok, int tok_ld, void* stream) {
     LRPX_CHECK_PTRS_OPT("lrpx_aoa_fwd_recurrence_tab", {w_hh_il, "w_hh_il"}, {tab, "tab"}, {gimg, "gimg"}, {tok, "tok"});
     LRPX_TRY(check_atrace(tr));
-    LRPX_REQUIRE(w_hh_il && tab && gimg && tok && tok_ld >= tr->T && tr->B <= 64 && tr->H % 16 == 0,
-                 "aoa_fwd_recurrence_tab: bad arguments (<= 64 images, H %% 16)");
+    LRPX_REQUIRE(w_hh_il && tab && gimg && tok && tok_ld >= tr->T && tr->H % 16 == 0,
+                 "aoa_fwd_recurrence_tab: bad arguments (H %% 16)");
     return aoa_recurrence(tr, w_hh_il, nullptr, tab, gimg, tok, tok_ld, (hipStream_t)stream);
 }
 

@@ -268,7 +268,9 @@ class AOAEngine:
     def _plain_rows(self, x, name, bias, amax=None):
         """x (R, K) @ W^T + bias -> (R, N) for one of the trace's plain linears over all (image, word) rows: split products on the
         fp16 matrix cores (as `logits(fast=True)`: <= 2e-7 of a row's maximum; operand scale per ROW), the fp32 MFMA kernel where K is
-        no multiple of 64.  The kernel never depends on the number of rows: an image's trace is the same in every batch."""
+        no multiple of 64.  The kernel never depends on the number of rows: an image's TRACE is the same in every batch (the recurrence in
+        slices of <= 64 images; `tests/test_gpu_aoa.py::test_trace_is_the_same_in_every_batch`: B = 1 / 64 / 65 bit for bit).  The (T,V)
+        `pred` block is the exception: `logits(fast=True)` takes the fp32 kernel below 128 rows (scores equal to rounding)."""
         p_h, p_f, n, k = self._plain[name]
         R = x.shape[0]
         out = torch.empty(R, n, device=self.device)
@@ -315,7 +317,7 @@ class AOAEngine:
         W = E + 2 * H
         bias = self.bcat_model if model_bias else self.bcat_explainer
         sd = self.sd
-        if self.decoupled and B <= 64 and T > 0:
+        if self.decoupled and T > 0:          # (any B: the recurrence runs in slices of <= 64 images inside the library)
             self._trace_decoupled(tr, enc, captions, model_bias)
             tr["captions"] = captions
             tr["logit"] = torch.empty(B * T, device=self.device)

@@ -257,3 +257,37 @@ def test_aoa_head_slice_of_the_v_proj_rule_is_bit_identical(bu):
         finally:
             eng.head_only = True
         assert torch.equal(a_feat, b_feat) and torch.equal(a_words, b_words), (head, (a_feat - b_feat).abs().max().item())
+
+
+def test_trace_is_the_same_in_every_batch():
+    """an image's trace must not depend on the batch it sits in.  The decoupled trace (one table lookup + T recurrence launches
+    + the attention half over all rows, models/aoamodel.py:1019-1052) now takes ANY batch size - the recurrence in slices of at most 64
+    images inside the library - where B = 65 used to fall back to the stepwise kernels: images at B = 1, 64 and 65, bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.aoa import AOAEngine
+    V, T = 211, 4
+    eng = AOAEngine(weights.make_aoa_state(seed=4, vocab_size=V, feat_dim=2048, with_encoder=False))
+    feats = torch.from_numpy(weights.make_bu_features(31, 65)).cuda()
+    caps = torch.from_numpy(weights.make_captions(32, 65, T, V)).cuda()
+    keys = ("h", "c", "g", "i", "f", "ctx", "lin", "c_aoa", "hc", "alpha")
+
+    def run(sel):
+        enc = eng.encode(features=feats[sel].contiguous())
+        tr = eng.trace(enc, caps[sel].contiguous(), predictions=False)
+        torch.cuda.synchronize()
+        return {k: tr[k].clone() for k in keys}
+    t65 = run(slice(0, 65))
+    t64 = run(slice(0, 64))
+    for b in (0, 37, 63):
+        one = run(slice(b, b + 1))
+        for k in keys:
+            assert torch.equal(one[k][0], t64[k][b]) and torch.equal(one[k][0], t65[k][b]), (b, k)
+    one = run(slice(64, 65))
+    for k in keys:
+        assert torch.equal(one[k][0], t65[k][64]), k
+    # and the relevance of those rows: the same maps whatever the batch (rows are independent in every kernel behind `relevance`)
+    r65, w65 = eng.explain_batch(caps, 3, features=feats)
+    r1, w1 = eng.explain_batch(caps[64:65].contiguous(), 3, features=feats[64:65].contiguous())
+    assert torch.equal(w1[0], w65[64]) and torch.equal(r1[0], r65[64])
