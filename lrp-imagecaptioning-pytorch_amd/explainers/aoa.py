@@ -294,7 +294,9 @@ class AOAEngine:
         check(lib.lrpx_aoa_fwd_inputs(c, ptr(enc["glob"]), ptr(sd["embedding.weight"]), ptr(captions), captions.shape[1], None, st))
         bias_il = self.bcat_model_il if model_bias else self.bcat_explainer_il
         gimg = torch.empty(B, 4 * H, device=self.device)                     # glob W_ig^T + bias: the image part of every step's z
-        check(lib.lrpx_linear_small(ptr(enc["glob"]), H, ptr(self.W_ig_il), ptr(bias_il), ptr(gimg), 4 * H, B, H, 4 * H, 0, st))
+        for b0 in range(0, B, 64):          # slices of <= 64 rows: the same (MFMA) kernel whatever the batch size - an image's trace never depends on its batch
+            nb = min(64, B - b0)
+            check(lib.lrpx_linear_small(ptr_at(enc["glob"], b0 * H), H, ptr(self.W_ig_il), ptr(bias_il), ptr_at(gimg, b0 * 4 * H), 4 * H, nb, H, 4 * H, 0, st))
         check(lib.lrpx_aoa_fwd_recurrence_tab(c, ptr(self.W_hh_il), ptr(self.tok_table), ptr(gimg), ptr(captions), captions.shape[1], st))
         hn = torch.empty(R, H, device=self.device)
         am = tr["_amax"].view(torch.int32)                                    # [3][R] row maxima of hn / ctx / hc (ctx: zeroed with the trace)

@@ -283,7 +283,8 @@ def test_trace_is_the_same_in_every_batch():
     for b in (0, 37, 63):
         one = run(slice(b, b + 1))
         for k in keys:
-            assert torch.equal(one[k][0], t64[k][b]) and torch.equal(one[k][0], t65[k][b]), (b, k)
+            assert torch.equal(one[k][0], t64[k][b]), ("B = 1 vs B = 64", b, k, (one[k][0] - t64[k][b]).abs().max().item())
+            assert torch.equal(one[k][0], t65[k][b]), ("B = 1 vs B = 65", b, k, (one[k][0] - t65[k][b]).abs().max().item())
     one = run(slice(64, 65))
     for k in keys:
         assert torch.equal(one[k][0], t65[k][64]), k
