@@ -279,3 +279,29 @@ def test_fused_trace_steps_are_bit_identical_to_the_seven_launch_step(B):
             assert {"o1", "o2", "sgate"} <= set(keys), keys
         for k in keys:
             assert torch.equal(a[k], b[k]), (k, grad, B, (a[k] - b[k]).abs().max().item())
+
+
+def test_one_image_alone_equals_the_same_image_inside_a_batch_of_16():
+    """the drop-in's calling pattern is ONE image per call (evaluation.py:806-838); its results must be the bits the
+    batched engine gives the same image inside a B = 16 batch - every kernel decision on the path depends on the LAYER or on the row,
+    never on the batch: forward K splits per layer, decoder GEMMs with row-local operand scales, tile order hints that do not touch a
+    result.  Trace, decoder relevance, r_words and the pixel maps of two images, bit for bit, in the default conv mode."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lrp_amd import weights
+    from lrp_amd.explainers.gridtd import GridTDEngine
+    V, B, T = 401, 16, 5
+    eng = GridTDEngine(weights.make_gridtd_state(seed=6, vocab_size=V))
+    imgs = torch.from_numpy(weights.make_images(51, B)).cuda()
+    caps = torch.from_numpy(weights.make_captions(52, B, T, V)).cuda()
+    maps, r_words, r_feat, tr, enc = eng.explain_batch(imgs, caps, accumulate=True, return_features=True)
+    maps, r_words, r_feat = maps.clone(), r_words.clone(), r_feat.clone()
+    feats, hc = enc["feats"].clone(), tr["hc"].clone()
+    for b in (0, 11):
+        m1, w1, f1, tr1, enc1 = eng.explain_batch(imgs[b:b + 1].contiguous(), caps[b:b + 1].contiguous(), accumulate=True, return_features=True)
+        torch.cuda.synchronize()
+        assert torch.equal(enc1["feats"][0], feats[b]), ("encoder features", b)
+        assert torch.equal(tr1["hc"][0], hc[b]), ("decoder trace", b)
+        assert torch.equal(f1[0], r_feat[b]), ("decoder relevance", b, (f1[0] - r_feat[b]).abs().max().item())
+        assert torch.equal(w1[0], r_words[b]), ("r_words", b)
+        assert torch.equal(m1[0], maps[b]), ("pixel maps", b, (m1[0] - maps[b]).abs().max().item())
