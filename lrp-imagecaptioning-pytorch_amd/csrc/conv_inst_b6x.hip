@@ -4,4 +4,5 @@
 namespace lrpx {
 int launch_b6_56w_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<56, 1, 8, true, EPI_REL_MUL, true, false, true>(a, s); }
 int launch_b6_28w_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<28, 1, 8, true, EPI_REL_MUL, true, false, true>(a, s); }
+int launch_b6_112w_pool(const ConvArgs& a, hipStream_t s) { return launch_conv_f16x3<112, 2, 4, true, EPI_REL_MUL, true, false, true>(a, s); }
 }

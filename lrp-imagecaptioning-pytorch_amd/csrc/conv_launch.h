@@ -76,6 +76,7 @@ int launch_b6_28w_rel(const ConvArgs& a, hipStream_t s);
 int launch_b6_14w_rel(const ConvArgs& a, hipStream_t s);
 int launch_b6_56w_pool(const ConvArgs& a, hipStream_t s);
 int launch_b6_28w_pool(const ConvArgs& a, hipStream_t s);
+int launch_b6_112w_pool(const ConvArgs& a, hipStream_t s);
 int launch_b6_112n_guided(const ConvArgs& a, hipStream_t s);   // ... image-gradient chains (GUIDED: guided backprop / plain gradient)
 int launch_b6_56_guided(const ConvArgs& a, hipStream_t s);
 int launch_b6_28_guided(const ConvArgs& a, hipStream_t s);

@@ -238,6 +238,7 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
             const int b6w = switches().b6_wide;
             if ((b6w & 4) && d->hw == 56 && d->n_oc >= 256) return launch_b6_56w_pool(a, s);
             if ((b6w & 4) && d->hw == 28 && d->n_oc >= 256) return launch_b6_28w_pool(a, s);
+            if ((b6w & 8) && d->hw == 112 && d->n_oc > 64 && d->n_oc <= 128) return launch_b6_112w_pool(a, s);
             if (d->hw == 224 && d->n_oc <= 64) return launch_b6_224_pool(a, s);
             if (d->hw == 112 && d->n_oc > 64) return launch_b6_112_pool(a, s);
             if (d->hw == 56) return launch_b6_56_pool(a, s);
