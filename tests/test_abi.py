@@ -148,3 +148,23 @@ def test_per_call_context_is_not_affected_by_other_threads_setters():
     m, f = C.c_int(), C.c_int()
     lib.lrpx_vgg16_resolve_opts(C.byref(o), C.byref(m), C.byref(f))
     assert (m.value, f.value) == (prev_mode, 0)
+
+
+def test_process_defaults_and_their_environment_overrides():
+    """Round 6: the library's process default is conv mode 1 (exact bf16 splits: arithmetic no narrower than the reference's fp32,
+    LRPtools/lrp_modules.py:124-150) with the exact forward trace; LRPX_CONV_MODE / LRPX_FORWARD_F16 move the INITIAL defaults (read once
+    at load), out-of-range values are clamped.  Host logic only: one child process per environment."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import lrp_amd; from lrp_amd import _lib; lib = _lib.load(); "
+            "print('DEFAULTS', lib.lrpx_set_conv_mode(-1), lib.lrpx_set_forward_f16(-1))" % root)
+    for env, want in (({}, (1, 0)), ({"LRPX_CONV_MODE": "3"}, (3, 0)), ({"LRPX_CONV_MODE": "2", "LRPX_FORWARD_F16": "1"}, (2, 1)),
+                      ({"LRPX_CONV_MODE": "9"}, (3, 0)), ({"LRPX_CONV_MODE": "0"}, (0, 0)), ({"LRPX_CONV_MODE": ""}, (1, 0))):
+        e = {k: v for k, v in os.environ.items() if k not in ("LRPX_CONV_MODE", "LRPX_FORWARD_F16")}
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1500:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("DEFAULTS")][0].split()
+        assert (int(line[1]), int(line[2])) == want, (env, line)
