@@ -903,7 +903,8 @@ def roofline(a, lib, eng, state, maps, B, T, mode):
                       "(power-limited clock): v_mfma_f32_32x32x16_bf16 from registers, six products per accumulator as in this kernel, runs at "
                       "2489 TFLOP/s on zeros and at 1830 - 1880 on the three planes of split random data (tools/micro/mfma_bf16_peak.hip, "
                       "profiles/r06_mfma_bf16_peak.txt): the power-limited roof of mode 1 is ~310 fp32-equivalent TFLOP/s = 0.74 of `peak`; "
-                      "v_mfma_f32_32x32x16_f16: 2484 / 1656 (profiles/r04_mfma_f16_peak.txt)"),
+                      "v_mfma_f32_32x32x16_f16: 2484 / 1656 (profiles/r04_mfma_f16_peak.txt).  rocm-smi under the mode-1 chain: 1280 - 1320 W of package "
+                      "power, shader clock 1.97 - 2.02 GHz of 2.4 (profiles/r06_clocks_under_load.txt): the chain runs at the part's power cap"),
         "accounting": ("executed matrix flop = algorithmic x products; mode 3 executes 1 fp16 + 2 fp6 products per fp32 "
                        "product and an fp6 flop counts 1/4 (fp6 dense peak = 4 x fp16 peak; the path's roof is 2500 / 1.5 = 1667 "
                        "algorithmic TFLOP/s, 1250 with the fp8 cross products of rounds 1-2), so achieved/peak = matrix "
