@@ -116,6 +116,7 @@ struct Switches {
     int b6_fwd_ksplit28; // LRPX_B6_FWD_KSPLIT28 (default 4): K ranges per tile of the 28x28 layers of the exact-split (conv mode 1) forward trace
     int b6_fwd_ksplit56; // LRPX_B6_FWD_KSPLIT56 (default 2): ... of the 56x56 layers
     int b6_wide;         // LRPX_B6_WIDE (bit mask): 8-wave conv-mode-1 relevance kernels for 56/28 (1), 14 (2), pooled-input 56/28 (4)
+    int b6_rel_ksplit14; // LRPX_B6_REL_KSPLIT14 (default 2; 1 = unsplit, 4 built): K ranges per tile of the 14x14 RELEVANCE layers of conv mode 1 (partial sums + rel_mul_finish)
     int x6_legacy;       // LRPX_X6_LEGACY: conv mode 1 on round 1's flow (conv_bf16x6.h with EPI_REL + pool kernels) instead of the fused B6 kernels
 };
 const Switches& switches();      // (lrpx_core.hip)

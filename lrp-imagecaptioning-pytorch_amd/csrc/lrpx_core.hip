@@ -74,6 +74,7 @@ const Switches& switches() {
         w.linear_valu = set("LRPX_LINEAR_VALU");
         w.x6_legacy = set("LRPX_X6_LEGACY");
         w.b6_wide = num("LRPX_B6_WIDE", 0);
+        w.b6_rel_ksplit14 = num("LRPX_B6_REL_KSPLIT14", 2);
         w.b6_fwd_ksplit28 = num("LRPX_B6_FWD_KSPLIT28", 4);
         w.b6_fwd_ksplit56 = num("LRPX_B6_FWD_KSPLIT56", 2);
         return w;
@@ -1249,6 +1250,32 @@ int fwd_dual_finish(const float* part, int nsplit, const float* bias, float* act
     hipLaunchKernelGGL(fwd_dual_finish_kernel, dim3((unsigned)(total4 / 256)), dim3(256), 0, s, part, nsplit,
                        (long)n_img * pix_per_img * 2 * cout, bias, act, zpos, cout, per_img4, amax);
     return check_launch("fwd_dual_finish");
+}
+// out[m][i] = x[img(m)][i] * (sum over the K splits of part[s][m][i]), pairwise in a fixed order (as fwd_dual_finish): the REL_MUL epilogue
+// of a K-split relevance conv (lrpx_vgg16_relevance_ex, LRPX_B6_REL_KSPLIT14)
+__global__ void rel_mul_finish_kernel(const float* __restrict__ part, int nsplit, long split_stride, const float* __restrict__ x,
+                                      const int* __restrict__ map2img, float* __restrict__ out, long per_map4, long total4) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    f32x4 lvl[5];
+    f32x4 v = reinterpret_cast<const f32x4*>(part)[idx];
+    for (int s = 0; s < nsplit; ++s) {
+        if (s) v = reinterpret_cast<const f32x4*>(part + s * split_stride)[idx];
+        int k = s, l = 0;
+        while (k & 1) { v = lvl[l] + v; k >>= 1; ++l; }
+        lvl[l] = v;
+    }
+    const long m = idx / per_map4, w = idx - m * per_map4;
+    const long img = map2img ? map2img[m] : m;
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[img * per_map4 + w];
+    reinterpret_cast<f32x4*>(out)[idx] = f32x4{xv[0] * v[0], xv[1] * v[1], xv[2] * v[2], xv[3] * v[3]};
+}
+int rel_mul_finish(const float* part, int nsplit, const float* x, const int* map2img, float* out, int n_maps, long per_map, hipStream_t s) {
+    LRPX_REQUIRE(per_map % 4 == 0 && nsplit >= 1 && nsplit <= 16 && (nsplit & (nsplit - 1)) == 0, "rel_mul_finish: bad arguments");
+    const long total4 = (long)n_maps * (per_map / 4);
+    hipLaunchKernelGGL(rel_mul_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, part, nsplit, (long)n_maps * per_map, x,
+                       map2img, out, per_map / 4, total4);
+    return check_launch("rel_mul_finish");
 }
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
                        int c, int plain, unsigned* amax, hipStream_t s) {

@@ -344,6 +344,7 @@ int first_layer_relevance_mfma(const float* S, const float* packed, const float*
 
 int guided_gate(const float* g, const float* y, const int* map2img, float* out, int n_maps, long per, int plain,
                 hipStream_t s);
+int rel_mul_finish(const float* part, int nsplit, const float* x, const int* map2img, float* out, int n_maps, long per_map, hipStream_t s);
 int maxpool_guided_bwd(const float* x, const float* g_out, const int* map2img, float* g_in, int n_maps, int ho, int wo,
                        int c, int plain, unsigned* amax, hipStream_t s);
 
@@ -988,6 +989,22 @@ int lrpx_vgg16_relevance_ex(const void* packed, const void* trace, int n_img, co
             if (blk) d.blocked = l == 1 ? 1 : 7;
         }
         else if (use_bf16x6) { d.bf16x6 = 1; d.wpacked = pk + p.bwd6[l]; }   // round 1's flow (LRPX_X6_LEGACY): EPI_REL, pool kernels
+        const int rel_ks = (b6 && L.hw == 14) ? switches().b6_rel_ksplit14 : 1;
+        if (rel_ks > 1 && (rel_ks & (rel_ks - 1)) == 0 && rel_ks <= 4 && (L.cout / 16) % rel_ks == 0) {
+            // the 14 x 14 relevance layers K-split in two (LRPX_B6_REL_KSPLIT14): partial sums into the R buffer (unused in the fused flow), then
+            // out = multiplicand * (pairwise sum) in rel_mul_finish.  At 320 maps the layers cost the same (1 120 -> 2 240 workgroups on 512 slots:
+            // the shorter tail pays for the extra pass: 3.67 -> 3.64 ms over the three layers); a chain of 20 maps - the drop-in's one image - ran
+            // them on 72 workgroups with 288-step K loops: 319 -> 190 us each, 4.24 -> 3.86 ms per chain.  A LAYER property, never the batch's:
+            // an image's maps are the same bits in every batch (tests/test_gpu_gridtd.py::test_one_image_alone_equals...).  Four ranges: +0.3 ms at 320 maps.
+            lrpx_conv_desc dk = d;
+            dk.epi = EPI_PLAIN; dk.x = nullptr; dk.out0 = R; dk.out1 = nullptr; dk.pool_am = nullptr; dk.map2img = nullptr; dk.tile_group = 0;
+            if (timing) (void)hipEventRecord(timer.ev[l][0], (hipStream_t)stream);
+            LRPX_TRY(conv_dispatch(&dk, (hipStream_t)stream, rel_ks));
+            LRPX_TRY(rel_mul_finish(R, rel_ks, tr + t.xz[l], map2img, S[cur ^ 1], n_maps, (long)196 * L.cin, (hipStream_t)stream));
+            if (timing) { (void)hipEventRecord(timer.ev[l][1], (hipStream_t)stream); timer.valid[l] = true; }
+            cur ^= 1;
+            continue;
+        }
         if (kVgg[l - 1].conv) {
             // ReLU passes relevance through (lrp_modules.py:42-46): fuse the next layer's S = R / safe(Z+)
             d.out1 = S[cur ^ 1];
