@@ -132,9 +132,23 @@ MODE_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
 # cores need at their peaks) / (measured time), as in the other modes.  (Rounds 1-2 ran the cross products in fp8: 2.0.)
 PRODUCTS = {0: 1, 1: 6, 2: 3, 3: 1.5}
 # arithmetic the contractions run in (tensors in HBM are fp32 in every mode; everything outside the convolutions is fp32 VALU)
-MODE_DTYPE = {0: "f32", 1: "f32 operands as exact 3 x bf16 splits (24 significand bits, f32 exponent range), 6 bf16 MFMA products, f32 accumulate",
-              2: "f16x3 split products, f32 accumulate", 3: "f16 + 2 x f6(e2m3, block-scaled) split products, f32 accumulate"}
+# (the decoders follow the conv mode - lrp_amd.ops.decoder_f16: in modes 0 / 1 their (word, pixel) rules run on the same exact bf16 splits
+# (csrc/dense_f16x3.hip, B6) and every other decoder GEMM on the fp32 MFMA / fp32 VALU; the fp16 split products only in modes 2 / 3)
+DEC_EXACT = "decoder GEMMs: exact 3 x bf16 splits ((word, pixel) rules) and f32 MFMA"
+DEC_F16 = "decoder GEMMs: f16x3 split products (22 operand bits, per-row scale)"
+MODE_DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32); " + DEC_EXACT,
+              1: "f32 operands as exact 3 x bf16 splits (24 significand bits, f32 exponent range), 6 bf16 MFMA products, f32 accumulate; " + DEC_EXACT,
+              2: "f16x3 split products, f32 accumulate; " + DEC_F16, 3: "f16 + 2 x f6(e2m3, block-scaled) split products, f32 accumulate; " + DEC_F16}
 MODE_KEY = {0: "fp32_mfma", 1: "bf16x6", 2: "f16x3", 3: "f16f6"}
+
+
+def dtype_of(mode, has_vgg=True):
+    """the line's `dtype`: the conv mode's arithmetic + what the decoders' GEMMs run on (LRPX_DECODER_F16 can override the rule: say so)"""
+    from lrp_amd import ops
+    d = MODE_DTYPE[mode] if has_vgg else "f32; " + (DEC_F16 if mode >= 2 else DEC_EXACT)
+    if ops.decoder_f16(mode) != (mode >= 2):
+        d = d.replace(DEC_F16, DEC_EXACT + " (LRPX_DECODER_F16=0)") if mode >= 2 else d.replace(DEC_EXACT, DEC_F16 + " (LRPX_DECODER_F16=1)")
+    return d
 # The headline mode: the fastest mode whose operands keep 24 significand bits and fp32's exponent range (VERDICT r5: a number at
 # arithmetic narrower than the reference's fp32 convolutions - LRPtools/lrp_modules.py:124-150, utils.py:21-31 - is not creditable).
 # Modes 2 / 3 are reported beside it (value_f16x3 / value_f16f6) with their same-run deviation from the fp32-MFMA chain.
@@ -398,7 +412,7 @@ def other_configs(a):
             ("4", ["--config", "4"], 6), ("5", ["--config", "5"], 80), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 6),
             ("varlen", ["--config", "2", "--lens", "uniform", "--batch", "23"], 12)]
     # the same lines in the opt-in speed mode 3 (fp16 + fp6 cross products): reported beside the headline-mode values, never instead
-    fast = [("3", ["--config", "3"], 4), ("4", ["--config", "4"], 4), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 4)]
+    fast = [("3", ["--config", "3"], 4), ("4", ["--config", "4"], 4), ("5", ["--config", "5"], 60), ("b64", ["--config", "2", "--batch", "64", "--pipeline", "2"], 4)]
     todo += [(k + "#f16f6", argv, n) for k, argv, n in fast] if a.conv_mode != 3 else []
     for key, argv, n in todo:
         gc.collect()
@@ -409,9 +423,14 @@ def other_configs(a):
         o = run_config(b, None, 0, 1)
         if fast_mode:
             k0 = key.split("#")[0]
-            res[k0]["value_f16f6"] = o["value"]
-            res[k0]["value_f16f6_note"] = f"conv mode 3 (fp16 + block-scaled fp6 cross products: narrower than fp32, opt-in), {n} timed steps, same process"
-            log(f"configs[{k0}] mode 3 (f16+f6): {o['value']:.0f} maps/s")
+            if k0 == "5":       # (no CNN stage: what mode 3 changes here is the decoder's GEMMs - fp16 split products instead of exact splits / fp32)
+                res[k0]["value_f16x3"] = o["value"]
+                res[k0]["value_f16x3_note"] = f"{DEC_F16}: narrower than fp32, opt-in (conv modes 2 / 3 or LRPX_DECODER_F16=1), {n} timed steps, same process"
+            else:
+                res[k0]["value_f16f6"] = o["value"]
+                res[k0]["value_f16f6_note"] = (f"conv mode 3 (fp16 + block-scaled fp6 cross products; {DEC_F16}: narrower than fp32, opt-in), "
+                                               f"{n} timed steps, same process")
+            log(f"configs[{k0}] mode 3 (f16+f6, f16x3 decoder): {o['value']:.0f} maps/s")
             continue
         r = o.get("roofline") or {}
         line = {"value": o["value"], "unit": o["unit"], "dtype": o["dtype"], "ms_per_step": o["ms_per_step"], "steps": n, "maps_per_step": o["config"]["maps_per_step"],
@@ -771,7 +790,7 @@ def run_config(a, dist, rank, world):
                   5: "LRP relevance maps/sec (AoA bottom-up 36x2048 features, 20-token caption)"}[a.config]
         out = {"metric": metric, "value": round(n_maps / dt, 2), "unit": "maps/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": MODE_DTYPE[mode] if has_vgg else "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": dtype_of(mode, has_vgg), "data": "synthetic",
                "config": {"workload": workload, "images_per_gpu": B, "words": T, "vocab": V,
                           "maps_per_step": world * maps_per_gpu,
                           "unit_of_work": "trace (VGG16 forward + decoder, predictions kept) + decoder relevance + CNN relevance + "

@@ -57,7 +57,8 @@ size_t lrpx_packed_floats(int n_oc, int k, int taps, int kc);
 /* w: conv (cout,cin,3,3) or dense matrix; kc = K-chunk the consuming kernel will use (lrpx_conv_kc) */
 int lrpx_pack_weights(const float* w, int cout, int cin, int taps, int mode, int kc, float* packed, void* stream);
 /* bf16x3 split of the same fragment layout for the fp32-accurate bf16 path (lrpx_conv_desc.bf16x6): every weight is
- * stored as three bf16 planes w = w0 + w1 + w2; modes BWD_POS / BWD_PLAIN / FWD, 3x3 kernels */
+ * stored as three bf16 planes w = w0 + w1 + w2; modes BWD_POS / BWD_PLAIN / FWD; 3x3 kernels (taps = 9) or - round 6 - a dense
+ * (cout, cin) matrix (taps = 1; BWD_PLAIN = the transposed product of the epsilon rules, as lrpx_pack_weights_f16x2) */
 size_t lrpx_packed_bf16x3_bytes(int n_oc, int k, int taps);
 int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream);
 /* f16x2 split for the fp16 matrix-core path (lrpx_conv_desc.f16x3): the layer's weights are scaled by a power of two
@@ -90,7 +91,11 @@ typedef struct lrpx_conv_desc {
                              partial products (fp32 accuracy, 2.67x less matrix-pipe time); wpacked must come from
                              lrpx_pack_weights_bf16x3; 3x3 convs, cin %% 16 == 0.  Epilogues: REL, FWD_DUAL (conv_bf16x6.h) and - round 6,
                              on the conv_f16x3.h tiling - REL_MUL (x = the precomputed multiplicand; with pool_am the input is the
-                             relevance at the pool's output and is unpooled while staged).  No operand scales: in_amax / out1_amax unused */
+                             relevance at the pool's output and is unpooled while staged).  No operand scales: in_amax / out1_amax unused.
+                             taps = 1 (round 6): the (word, pixel) epsilon rules of the decoders (gridTDmodel.py:1125-1128, aoamodel.py:1135-1148)
+                             in the same exact arithmetic - REL epilogue with x, map2img and ONE of out0 / out1 (+ zdiv), optional u;
+                             cin %% 32 == 0, oc_split %% 4 == 0, 16-byte aligned operands, any number of rows (one kernel: a row's sum
+                             never depends on the batch).  What the host layer uses while the conv mode is 0 / 1 */
     const float* bias;
     const float* x;
     const float* u;

@@ -276,8 +276,12 @@ class Recording(object):
         return self.result
 
 
+# int-valued entry points that are QUERIES / setters, not launches with a status: never part of a recorded step
+_QUERIES = {"lrpx_version", "lrpx_conv_kc", "lrpx_set_bf16x6", "lrpx_set_conv_mode", "lrpx_set_forward_f16"}
+
+
 def _recordable(fn):
-    status = fn.restype is _i
+    status = fn.restype is _i and getattr(fn, "__name__", "") not in _QUERIES
 
     def call(*args):
         rec = getattr(_TLS, "rec", None)

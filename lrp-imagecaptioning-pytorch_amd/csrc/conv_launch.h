@@ -160,6 +160,7 @@ int launch_h3_28_pool(const ConvArgs& a, hipStream_t s);
 
 // dense relevance GEMMs with many rows on the fp16 matrix cores (dense_f16x3.hip)
 int launch_dense_f16x3(const ConvArgs& a, hipStream_t s);
+int launch_dense_bf16x6(const ConvArgs& a, hipStream_t s);      // dense_f16x3.hip, B6: exact bf16 splits, REL epilogue
 int launch_dense_small_f16x3(const ConvArgs& a, hipStream_t s);     // few rows: whole K per workgroup, row scales found in-kernel
 // lock-step s of the AoA decoder relevance fused into that GEMM (dense_f16x3.hip, FUSE): rows are (image, word) pairs, row = image * T + word
 struct AoaStepFuse {

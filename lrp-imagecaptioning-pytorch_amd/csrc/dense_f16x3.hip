@@ -300,8 +300,12 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void dense_f16x3_kernel(
 #ifndef LRPXB_KC
 #define LRPXB_KC 32        // K chunk of the 128 x 256 kernel (one barrier and one commit per chunk)
 #endif
-constexpr int DN_BM = 128, DN_BN = 256, DN_KC = LRPXB_KC, DN_KS = DN_KC / 16, DN_ROWB = DN_KS * 64 + 16, DN_BUF = DN_BM * DN_ROWB;
-constexpr int DN_LDS = 2 * DN_BUF + DN_BM * 16;
+constexpr int DN_BM = 128, DN_BN = 256, DN_KC = LRPXB_KC, DN_KS = DN_KC / 16;
+// LDS row of the A chunk: per k-step [hi | lo] (f16x3) or [p0 | p1 | p2] (B6: exact bf16 split) x 2 lane groups x 16 B, + 16 B pad (9 / 13
+// 16-byte units per row: odd, conflict-free ds_read_b128)
+template <bool B6> struct DnCfg {
+    static constexpr int PL = B6 ? 3 : 2, ROWB = DN_KS * 32 * PL + 16, BUF = DN_BM * ROWB, LDS = 2 * BUF + DN_BM * 16;
+};
 #ifdef LRPX_STAMP
 static __device__ unsigned long long g_stamp_dn[16384 * 10];      // per wave: start, loop start, loop end, stores issued, stores drained, sum issue..MFMAs, sum commit, sum barrier, HW_ID, XCC_ID
 #endif
@@ -315,11 +319,16 @@ static __device__ unsigned long long g_stamp_dn[16384 * 10];      // per wave: s
 #ifndef LRPXB_NBQ
 #define LRPXB_NBQ 2        // B ring of the 128 x 256 kernel: k-steps in registers (2: one ahead; 3: two ahead - measured +-0, 16 registers more)
 #endif
-template <int EPI, bool HAS_U, bool HAS_O1, int RT>      // REL: with the addend U; writing out1 = r / stab(Zdiv) (+ its per-map maxima) instead of
+// B6 (round 6): the same tile on the bf16 matrix cores with EXACT operands - a = a0 + a1 + a2 (three bf16 parts, split while staged; weights
+// from lrpx_pack_weights_bf16x3, taps = 1), the six products with i + j <= 2 on v_mfma_f32_32x32x16_bf16, small terms first
+// (conv_bf16x6.h): no operand scales, no in_amax, fp32 range.  This is what the decoders' (word, pixel) rules run on in the default
+// conv mode 1 (nothing on the path narrower than fp32); per (row tile, k-step) one step of 12 MFMAs (3 A x 6 B fragments).
+template <int EPI, bool HAS_U, bool HAS_O1, int RT, bool B6 = false>      // REL: with the addend U; writing out1 = r / stab(Zdiv) (+ its per-map maxima) instead of
                                                          // out0 = r; RT row tiles per wave: 4 (128-row tiles) or 3 (96 rows: the launcher picks the
                                                          // tile height that fills the 512 resident slots in fewer (rounds x rows))
 __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    constexpr int DN_ROWB = DnCfg<B6>::ROWB, DN_BUF = DnCfg<B6>::BUF, PL = DnCfg<B6>::PL;
     unsigned* ri_n = reinterpret_cast<unsigned*>(ldsb + 2 * DN_BUF);        // [128] map of the row
     unsigned* ri_xb = ri_n + DN_BM;                                         // [128] offset of its multiplicand row
     float* ri_sc = reinterpret_cast<float*>(ri_n + 2 * DN_BM);              // [128] result scale 2^-kA 2^-kW
@@ -342,14 +351,15 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     const unsigned P = (unsigned)a.pix_per_map;
     const unsigned* __restrict__ in_amax = a.in_amax;
     const int ncol = a.oc_split;
-    const float inv_w = a.wp[0];
+    const float inv_w = B6 ? 1.f : a.wp[0];
 
     if (tid < BM) {
         const long r = row0 + tid;
         const unsigned rc = (unsigned)(r < M ? r : M - 1);
         const unsigned n = rc / P, p = rc - n * P;
         const unsigned img = EPI == EPI_PLAIN ? n : (unsigned)a.map2img[n];          // (REL: map2img is required)
-        const float sc = exp2i(-f16_scale_exp(in_amax[n])) * inv_w;
+        float sc = 1.f;
+        if constexpr (!B6) sc = exp2i(-f16_scale_exp(in_amax[n])) * inv_w;
         ri_n[tid] = n; ri_xb[tid] = (img * P + p) * (unsigned)ncol; ri_sc[tid] = sc;     // (< 2^31: host-checked)
     }
 
@@ -363,9 +373,10 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
         const long r = row0 + s_row + RP * u;
         const unsigned rc = (unsigned)(r < M ? r : M - 1);        // rows past the end re-read the last row (results dropped)
         soff[u] = rc * (unsigned)K + s_seg * 4;                    // (M * K < 2^31: host-checked)
-        ssc[u] = exp2i(f16_scale_exp(in_amax[rc / P]));
+        if constexpr (!B6) ssc[u] = exp2i(f16_scale_exp(in_amax[rc / P]));
+        else ssc[u] = 1.f;
     }
-    const int s_off = (s_seg >> 2) * 64 + ((s_seg >> 1) & 1) * 16 + (s_seg & 1) * 8;
+    const int s_off = (s_seg >> 2) * (32 * PL) + ((s_seg >> 1) & 1) * 16 + (s_seg & 1) * 8;
     constexpr bool SHADOW = LRPXB_SHADOW != 0;      // the next chunk's conversion + LDS writes between the MFMAs of this one (loads two chunks ahead)
     f32x4 sv[SHADOW ? 2 : 1][NU];
     const float* __restrict__ A = a.in;
@@ -375,6 +386,15 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
         for (int u = 0; u < NU; ++u) sv[set][u] = *reinterpret_cast<const f32x4*>(Ac + soff[u]);
     };
     auto commit_item = [&](const int bufi, const int set, const int u) {
+        if constexpr (B6) {
+            unsigned pa_[3], pb_[3];
+            split3_pk(f32x2_{sv[set][u][0], sv[set][u][1]}, pa_[0], pa_[1], pa_[2]);
+            split3_pk(f32x2_{sv[set][u][2], sv[set][u][3]}, pb_[0], pb_[1], pb_[2]);
+            char* d_ = ldsb + bufi * DN_BUF + (s_row + RP * u) * DN_ROWB + s_off;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2_*>(d_ + 32 * pl) = u32x2_{pa_[pl], pb_[pl]};
+            return;
+        }
         unsigned h0_, h1_, l0_, l1_;
         f32x2_ f0_, f1_;
         split2_pk(f32x2_{sv[set][u][0], sv[set][u][1]} * f32x2_{ssc[u], ssc[u]}, h0_, l0_, f0_);
@@ -393,15 +413,15 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     const int ocb0 = nblk * 8 + wave * 2;
     const int ocb_last = (a.n_oc - 1) / 32;
     const int nks = K / 16;
-    const u32x4_* wp0 = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) + (long)min(ocb0, ocb_last) * nks * 128 + lane;
-    const u32x4_* wp1 = reinterpret_cast<const u32x4_*>(a.wp + F16X3_HEADER_FLOATS) + (long)min(ocb0 + 1, ocb_last) * nks * 128 + lane;
+    const u32x4_* wp0 = reinterpret_cast<const u32x4_*>(a.wp + (B6 ? 0 : F16X3_HEADER_FLOATS)) + (long)min(ocb0, ocb_last) * nks * (64 * PL) + lane;
+    const u32x4_* wp1 = reinterpret_cast<const u32x4_*>(a.wp + (B6 ? 0 : F16X3_HEADER_FLOATS)) + (long)min(ocb0 + 1, ocb_last) * nks * (64 * PL) + lane;
     // B ring: k-step s + NBQ - 1 is loaded while k-step s multiplies (24 MFMAs = 768 matrix cycles per k-step)
     constexpr int NBQ = LRPXB_NBQ;
-    u32x4_ bq[NBQ][4];               // [tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo]
-    auto load_b = [&](const int ks, u32x4_ (&b)[4]) {
+    u32x4_ bq[NBQ][2 * PL];          // [tile 0 hi, lo, tile 1 hi, lo]; B6: [tile 0 p0, p1, p2, tile 1 p0, p1, p2]
+    auto load_b = [&](const int ks, u32x4_ (&b)[2 * PL]) {
         const int k = min(ks, nks - 1);
-        b[0] = wp0[(long)k * 128]; b[1] = wp0[(long)k * 128 + 64];
-        b[2] = wp1[(long)k * 128]; b[3] = wp1[(long)k * 128 + 64];
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) { b[pl] = wp0[(long)k * (64 * PL) + 64 * pl]; b[PL + pl] = wp1[(long)k * (64 * PL) + 64 * pl]; }
     };
 #pragma unroll
     for (int i = 0; i < NBQ - 1; ++i) load_b(i, bq[i]);
@@ -422,6 +442,58 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
     static_assert(!SHADOW || (NU <= 2 * DN_KS && NBQ == 2), "at most one staging item per (k-step, pair) step; two chunks per loop trip");
     static_assert(RT == 4 || RT == 3, "two pairs of row tiles, or a pair and a single one");
     // (NBQ chunks per loop iteration: the ring positions are compile-time constants - 2 NBQ k-steps, a multiple of the ring)
+    if constexpr (B6) {
+        static_assert(SHADOW && NBQ == 2 && NU <= RT * DN_KS, "B6: shadow commits, a two-deep B ring");
+        for (int c0 = 0; c0 < nchunk; c0 += 2) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int chunk = c0 + cc;
+                if (chunk >= nchunk) break;                      // (uniform)
+                issue(min(chunk + 2, nchunk - 1), cc & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const char* abuf = ldsb + (chunk & 1) * DN_BUF + a_off;
+                bf16x8 af[2][3];                                  // the three planes of ONE row tile, a step ahead of its 12 MFMAs
+                auto read_a = [&](const int t, bf16x8 (&f)[3]) {
+                    const char* q = abuf + (32 * (t % RT)) * DN_ROWB + (t / RT) * 96;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8*>(q + 32 * pl);
+                };
+                read_a(0, af[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < RT * DN_KS; ++t) {          // t = RT * k-step + row tile
+                    const int s = t / RT, i = t % RT;
+                    const int q = cc * DN_KS + s;
+                    if (i == 0) load_b(chunk * DN_KS + s + 1, bq[(q + 1) % 2]);
+                    if (t + 1 < RT * DN_KS) read_a(t + 1, af[(t + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t < NU) commit_item((chunk + 1) & 1, (cc + 1) & 1, t);      // (shadow commit of the next chunk, as in the f16x3 loop)
+                    const bf16x8 a0 = af[t & 1][0], a1 = af[t & 1][1], a2 = af[t & 1][2];
+                    const u32x4_(&b)[2 * PL] = bq[q % 2];
+                    f32x16 &c0_ = acc[i][0], &c1_ = acc[i][1];
+#define LRPXB6_MM(A_, PLB_)                                                                                              \
+    c0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, __builtin_bit_cast(bf16x8, b[PLB_]), c0_, 0, 0, 0);               \
+    c1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, __builtin_bit_cast(bf16x8, b[PL + PLB_]), c1_, 0, 0, 0)
+                    LRPXB6_MM(a2, 0); LRPXB6_MM(a1, 1); LRPXB6_MM(a0, 2);      // small terms first (conv_bf16x6.h)
+                    LRPXB6_MM(a1, 0); LRPXB6_MM(a0, 1);
+                    LRPXB6_MM(a0, 0);
+#undef LRPXB6_MM
+                    if (t < NU) {
+#pragma unroll
+                        for (int g = 0; g < 10; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // three vector instructions of the split
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);          // the LDS writes
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+            }
+        }
+    } else
     for (int c0 = 0; c0 < nchunk; c0 += NBQ) {
 #pragma unroll
         for (int cc = 0; cc < NBQ; ++cc) {
@@ -458,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void dense_f16x3_n256_kernel(ConvArgs a, in
                 // (no branch around it - the scheduler mixes within a basic block only: the last chunk writes a copy of itself into the idle buffer)
                 if constexpr (SHADOW) { if (t < NU) commit_item((chunk + 1) & 1, (cc + 1) & 1, t); }
                 const f16x8 a0h = af[t & 1][0], a0l = af[t & 1][1], a1h = af[t & 1][2], a1l = af[t & 1][3];
-                const u32x4_(&b)[4] = bq[q % NBQ];
+                const u32x4_(&b)[2 * PL] = bq[q % NBQ];
                 const f16x8 b0h = __builtin_bit_cast(f16x8, b[0]), b0l = __builtin_bit_cast(f16x8, b[1]);
                 const f16x8 b1h = __builtin_bit_cast(f16x8, b[2]), b1l = __builtin_bit_cast(f16x8, b[3]);
                 const bool two = RT == 4 || pr == 0;           // (compile-time per unrolled step)
@@ -957,8 +1029,8 @@ int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
              dense_f16x3_n256_kernel<EPI_REL, false, true, 3>, dense_f16x3_n256_kernel<EPI_REL, true, true, 3>,
              dense_f16x3_n256_kernel<EPI_PLAIN, false, false, 3>}};
         Kern kern = kerns[rt == 3][v];
-        LRPX_TRY(reserve_lds_once(once_n[(rt == 3 ? 5 : 0) + v], kern, DN_LDS, "dense_f16x3_n256"));
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), DN_LDS, stream, a, (int)m_tiles, n_blocks);
+        LRPX_TRY(reserve_lds_once(once_n[(rt == 3 ? 5 : 0) + v], kern, DnCfg<false>::LDS, "dense_f16x3_n256"));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), DnCfg<false>::LDS, stream, a, (int)m_tiles, n_blocks);
         return check_launch("dense_f16x3_n256");
     }
     const bool wide = switches().dense_wide && M >= 8192;      // 256-row tiles (8 waves) for many rows: measured slower, off (A/B)
@@ -979,6 +1051,39 @@ int launch_dense_f16x3(const ConvArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), DenseCfg<2>::LDS, stream, a, (int)m_tiles, n_blocks);
     }
     return check_launch("dense_f16x3");
+}
+
+// The (word, pixel) rules with EXACT operand splits on the bf16 matrix cores (B6 above): any number of rows - ONE kernel, so that a
+// row's sum does not depend on the batch it sits in; weights from lrpx_pack_weights_bf16x3 (taps = 1).
+int launch_dense_bf16x6(const ConvArgs& a, hipStream_t stream) {
+    const long M = (long)a.n_maps * a.pix_per_map;
+    LRPX_REQUIRE(a.epi == EPI_REL && a.X && a.map2img && (a.out0 || a.out1) && !(a.out0 && a.out1), "dense_bf16x6: the REL epilogue with x, map2img and ONE output");
+    LRPX_REQUIRE(!a.out1 || a.Zdiv, "dense_bf16x6: out1 needs zdiv");
+    LRPX_REQUIRE(a.cin % DN_KC == 0 && a.cin >= DN_KC, "dense_bf16x6: K = %d is not a multiple of %d", a.cin, DN_KC);
+    LRPX_REQUIRE(a.oc_split % 4 == 0 && a.oc_split >= 4 && a.n_oc >= a.oc_split, "dense_bf16x6: %d columns (a multiple of 4)", a.oc_split);
+    LRPX_REQUIRE(M > 0 && M * a.cin < 0x7fffffffL && M * a.oc_split < 0x7fffffffL && (long)a.n_maps * a.oc_split < 0x7fffffffL,
+                 "dense_bf16x6: %ld rows out of range for 32-bit offsets", M);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    LRPX_REQUIRE(al16(a.in) && al16(a.X) && al16(a.U) && al16(a.Zdiv) && al16(a.out0) && al16(a.out1), "dense_bf16x6: operands must be 16-byte aligned");
+    LRPX_REQUIRE(!a.out1_amax || a.pix_per_map >= 32, "dense_bf16x6: out1_amax needs at least 32 rows per map");
+    const int n_blocks = (int)ceil_div(a.n_oc, DN_BN);
+    auto cost = [&](int rows) { return ceil_div(ceil_div(M, rows) * n_blocks, 512) * rows; };
+    const int rt = switches().dense_rt == 3 || switches().dense_rt == 4 ? switches().dense_rt : (cost(96) < cost(128) ? 3 : 4);
+    const long m_tiles = ceil_div(M, 32 * rt);
+    const long grid = ceil_div(m_tiles * n_blocks, 8) * 8;
+    LRPX_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "dense_bf16x6: grid %ld out of range", grid);
+    static LdsOnce once_n[8];
+    const int v = (a.U ? 1 : 0) + (a.out1 ? 2 : 0);
+    using Kern = void (*)(ConvArgs, int, int);
+    static const Kern kerns[2][4] = {
+        {dense_f16x3_n256_kernel<EPI_REL, false, false, 4, true>, dense_f16x3_n256_kernel<EPI_REL, true, false, 4, true>,
+         dense_f16x3_n256_kernel<EPI_REL, false, true, 4, true>, dense_f16x3_n256_kernel<EPI_REL, true, true, 4, true>},
+        {dense_f16x3_n256_kernel<EPI_REL, false, false, 3, true>, dense_f16x3_n256_kernel<EPI_REL, true, false, 3, true>,
+         dense_f16x3_n256_kernel<EPI_REL, false, true, 3, true>, dense_f16x3_n256_kernel<EPI_REL, true, true, 3, true>}};
+    Kern kern = kerns[rt == 3][v];
+    LRPX_TRY(reserve_lds_once(once_n[(rt == 3 ? 4 : 0) + v], kern, DnCfg<true>::LDS, "dense_bf16x6"));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), DnCfg<true>::LDS, stream, a, (int)m_tiles, n_blocks);
+    return check_launch("dense_bf16x6");
 }
 
 }  // namespace lrpx

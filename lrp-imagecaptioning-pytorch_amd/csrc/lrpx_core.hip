@@ -960,7 +960,7 @@ size_t lrpx_packed_bf16x3_bytes(int n_oc, int k, int taps) {
 
 int lrpx_pack_weights_bf16x3(const float* w, int cout, int cin, int taps, int mode, void* packed, void* stream) {
     LRPX_CHECK_PTRS("lrpx_pack_weights_bf16x3", {w, "w"}, {packed, "packed"});
-    LRPX_REQUIRE(w && packed && taps == 9, "pack_weights_bf16x3: bad arguments (3x3 kernels only)");
+    LRPX_REQUIRE(w && packed && (taps == 9 || taps == 1), "pack_weights_bf16x3: bad arguments (3x3 kernels or dense matrices)");
     LRPX_REQUIRE(mode == LRPX_PACK_BWD_POS || mode == LRPX_PACK_BWD_PLAIN || mode == LRPX_PACK_FWD ||
                      mode == LRPX_PACK_FWD_DUAL, "pack_weights_bf16x3: mode %d not supported", mode);
     int n_oc_pad, k_pad;

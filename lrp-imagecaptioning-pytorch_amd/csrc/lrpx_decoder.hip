@@ -105,6 +105,64 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
     }
 }
 
+// The K loop of the skinny linears on the fp32 matrix cores (linear_mfma_kernel below and the fused step kernels further down share it:
+// the same dot products in the same order, bit-identical traces).  The 4 waves split K; a lane loads ONE float4 of its weight row and one
+// of its x row per 16 k (lane = (feature or row) lane & 15, k quad lane >> 4: component j of the two float4s is the operand pair of MFMA j).
+// Round 6: FOUR accumulators per row tile take the wave's k-steps in turn (k-step s -> accumulator s % 4): a sum of 2048 products is formed
+// from 16 partial sums of 128 instead of 4 of 512 - the gate pre-activations of a gridTD trace moved from 8e-7 to 3e-7 of their fp64 values
+// (what an fp32 CPU GEMM gives: tests/diag_t20_words.py), and with them the worst T = 20 r_words row of the goldens from 1.0e-5 to 1.4e-6 of
+// fp64.  No faster: the kernel is at the rate its weights stream in (11 us per gridTD gate linear, 5 us of them the launch floor).
+template <int RT>
+__device__ __forceinline__ void linear_mfma_core(const float* __restrict__ x, long ldx, const float* __restrict__ w, int B, int K,
+                                                 int N, float (&red)[4][RT][16][17], const int n0) {
+    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    const int nl = lane & 15, kq = lane >> 4;
+    const int kslice = ((K / 16 + 3) / 4) * 16;                        // K % 16 == 0 (host-checked)
+    const int k_lo = wv_ * kslice, k_hi = min(K, k_lo + kslice);
+    const float* __restrict__ wrow = w + (long)min(n0 + nl, N - 1) * K + kq * 4;
+    const float* __restrict__ xrow[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) xrow[r] = x + (long)min(r * 16 + nl, B - 1) * ldx + kq * 4;
+    constexpr int NA = 4;                                              // accumulators per row tile (k-step s -> accumulator s % NA)
+    constexpr int NW = RT <= 2 ? 8 : 4;                                // k-steps of weights in flight per wave (16 measured no faster: the
+                                                                       // kernel streams its 13 - 17 MB of fp32 weights at ~2.8 TB/s either way)
+    constexpr int NX = 4;                                              // k-steps of x rows in flight (L2 hits)
+    f32x4 acc[RT][NA];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int u = 0; u < NA; ++u) acc[r][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16 * NW) {
+        f32x4 wq[NW];
+#pragma unroll
+        for (int u = 0; u < NW; ++u) wq[u] = *reinterpret_cast<const f32x4*>(wrow + min(k0 + 16 * u, k_hi - 16));   // (past the slice: re-read, MFMAs skipped)
+#pragma unroll
+        for (int v = 0; v < NW; v += NX) {
+            f32x4 xq[RT][NX];
+#pragma unroll
+            for (int u = 0; u < NX; ++u)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) xq[r][u] = *reinterpret_cast<const f32x4*>(xrow[r] + min(k0 + 16 * (v + u), k_hi - 16));
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                if (k0 + 16 * (v + u) < k_hi) {                        // (wave-uniform)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[r][u % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[r][u][j], wq[v + u][j], acc[r][u % NA], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // result layout: column (feature) lane & 15, rows 4 * (lane >> 4) + i
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wv_][r][4 * kq + i][nl] = (acc[r][0][i] + acc[r][1][i]) + (acc[r][2][i] + acc[r][3][i]);
+    __syncthreads();
+}
+
 // The same skinny linear on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products): M = 16 rows b per row tile,
 // N = 16 output features per workgroup, the 4 waves split K.  A lane loads ONE float4 of its weight row and one of its x
 // row per 16 k (lane = (feature or row) lane & 15, k quad lane >> 4: component j of the two float4s is the operand pair of
@@ -115,34 +173,8 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
                                                           const float* __restrict__ bias, float* __restrict__ out, long ldo,
                                                           int B, int K, int N, int act) {
     __shared__ float red[4][RT][16][17];
-    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
-    const int nl = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int kslice = ((K / 16 + 3) / 4) * 16;                        // K % 16 == 0 (host-checked)
-    const int k_lo = wv_ * kslice, k_hi = min(K, k_lo + kslice);
-    const float* __restrict__ wrow = w + (long)min(n0 + nl, N - 1) * K + kq * 4;
-    const float* __restrict__ xrow[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) xrow[r] = x + (long)min(r * 16 + nl, B - 1) * ldx + kq * 4;
-    f32x4 acc[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // (four k-steps of loads ahead of their MFMAs by hand: 9.0 instead of 9.3 us at B = 16, 23 instead of 17 at B = 64)
-    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
-        const f32x4 wq = *reinterpret_cast<const f32x4*>(wrow + k0);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const f32x4 xq = *reinterpret_cast<const f32x4*>(xrow[r] + k0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[j], wq[j], acc[r], 0, 0, 0);
-        }
-    }
-    // result layout: column (feature) lane & 15, rows 4 * (lane >> 4) + i
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[wv_][r][4 * kq + i][nl] = acc[r][i];
-    __syncthreads();
+    linear_mfma_core<RT>(x, ldx, w, B, K, N, red, n0);
     for (int e = threadIdx.x; e < RT * 256; e += 256) {
         const int r = e >> 8, row = (e >> 4) & 15, col = e & 15;
         const int b = r * 16 + row, n = n0 + col;
@@ -1030,35 +1062,7 @@ __global__ void aoa_fwd_post_kernel(AoaFwd g, int t, const float* __restrict__ q
 // a unit meet in the workgroup's LDS reduction), decoder_aoa_linear applies the gated sum (fwd_post) and gathers the NEXT
 // step's LSTM input row (fwd_pre).  The dot products run in the same order as in linear_mfma_kernel and the point-wise code is
 // that of aoa_fwd_lstm / _post / _pre: results are bit-identical to the unfused step (token ids of the sampling goldens, traces).
-template <int RT>
-__device__ __forceinline__ void linear_mfma_core(const float* __restrict__ x, long ldx, const float* __restrict__ w, int B, int K,
-                                                 int N, float (&red)[4][RT][16][17], const int n0) {
-    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
-    const int nl = lane & 15, kq = lane >> 4;
-    const int kslice = ((K / 16 + 3) / 4) * 16;
-    const int k_lo = wv_ * kslice, k_hi = min(K, k_lo + kslice);
-    const float* __restrict__ wrow = w + (long)min(n0 + nl, N - 1) * K + kq * 4;
-    const float* __restrict__ xrow[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) xrow[r] = x + (long)min(r * 16 + nl, B - 1) * ldx + kq * 4;
-    f32x4 acc[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
-        const f32x4 wq = *reinterpret_cast<const f32x4*>(wrow + k0);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const f32x4 xq = *reinterpret_cast<const f32x4*>(xrow[r] + k0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[j], wq[j], acc[r], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[wv_][r][4 * kq + i][nl] = acc[r][i];
-    __syncthreads();
-}
+// (linear_mfma_core: next to linear_mfma_kernel above)
 
 // ---- gridTD: the two gate linears of a decoder step with their LSTM cells (gridtd_fwd_lstm_kernel) in the epilogue, and the next step's
 // input row (gridtd_fwd_pre_kernel) behind the second: 7 launches per time step -> 4.  Weight rows interleaved as above (w_il / b_il:

@@ -33,6 +33,12 @@ int conv_dispatch(const lrpx_conv_desc* d, hipStream_t s, int f16_ksplit) {
     a.ksplit = 1;
     // many rows (the (word, pixel) rules of the decoders): split products on the fp16 matrix cores (dense_f16x3.hip);
     // `wpacked` is then an lrpx_pack_weights_f16x2 blob (taps = 1) and `in_amax` holds max|in| per map
+    // ... or, with operands split EXACTLY into three bf16 parts (the default arithmetic of the path: nothing narrower than fp32), on the
+    // bf16 matrix cores: `wpacked` from lrpx_pack_weights_bf16x3 (taps = 1), no in_amax, any number of rows
+    if (d->taps == 1 && d->bf16x6) {
+        LRPX_REQUIRE(!d->f16x3 && d->epi == EPI_REL && d->x && d->pix_per_map > 0, "conv_mfma: the dense bf16x6 GEMM is built for the REL epilogue (x, pix_per_map)");
+        return launch_dense_bf16x6(a, s);
+    }
     if (d->taps == 1 && d->f16x3 && d->epi == EPI_PLAIN) {
         // out0 = in W^T + bias on the fp16 matrix cores (the (T,V) scores of a trace): weights from lrpx_pack_weights_f16x2(PACK_FWD,
         // taps = 1), in_amax = max|in| per map (rows of a map share one operand scale; pix_per_map = 1: per row)

@@ -60,6 +60,8 @@ class AOAEngine:
         self.p_k_fwd = ops.pack_weights(sd["decoder_k_proj.weight"], H, H, 1, PACK_DENSE, kc)
         self.p_v_fwd = ops.pack_weights(sd["decoder_v_proj.weight"], H, H, 1, PACK_DENSE, kc)
         self.p_fc_fwd = ops.pack_weights(sd["fc.weight"], self.V, H, 1, PACK_DENSE, kc)
+        # fp16 split-product packs (csrc/dense_f16x3.hip): built always, USED only while ops.decoder_f16() says so (`_f16()`: conv modes 2 / 3)
+        self.force_f16 = None            # True / False: this engine's decoder GEMMs on / off the fp16 split products whatever the conv mode (A/B and tests)
         self.p_fc_fwd_h = ops.pack_weights_f16x2(sd["fc.weight"], self.V, H, _lib.PACK_FWD, taps=1) if H % 64 == 0 else None
         # plain GEMMs over all (image, word) rows of the decoupled trace: (pack for the fp16 split-product kernel, fp32 pack)
         self._plain = {}
@@ -93,6 +95,17 @@ class AOAEngine:
             if dk % 64 == 0:      # `lrp_mha` passes one head: the v_proj rule contracts over that head's dk rows of W_v only
                 self.p_v_rel_head = [ops.pack_weights_f16x2(sd["decoder_v_proj.weight"][h * dk:(h + 1) * dk].contiguous(), dk, H,
                                                             _lib.PACK_BWD_PLAIN, taps=1) for h in range(self.NH)]
+        # ... in the default (exact) arithmetic: the same tiles on the bf16 matrix cores with operands split exactly into three bf16 parts
+        # (dense_f16x3.hip, B6: six products, fp32 range - what conv mode 1 is for the VGG16 chains); the fp32 MFMA where the sizes do not fit
+        self.p_v_rel_6 = self.p_proj_rel_6 = self.p_v_rel_head6 = None
+        if H % 32 == 0 and Cc % 4 == 0:
+            self.p_v_rel_6 = ops.pack_weights_bf16x3(sd["decoder_v_proj.weight"], H, H, _lib.PACK_BWD_PLAIN, taps=1)
+            self.p_proj_rel_6 = ops.pack_weights_bf16x3(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1)
+            dk = H // self.NH
+            if dk % 32 == 0:
+                self.p_v_rel_head6 = [ops.pack_weights_bf16x3(sd["decoder_v_proj.weight"][h * dk:(h + 1) * dk].contiguous(), dk, H,
+                                                              _lib.PACK_BWD_PLAIN, taps=1) for h in range(self.NH)]
+        self.dense_bf16x6 = True         # False: those rules on the fp32 MFMA kernel (A/B and tests)
         self.head_only = True            # (False: the v_proj rule over all H columns, 7/8 of them zero; A/B and tests)
         # ... and the lock-step gate rule / the aoa_linear rule (rows = images x words): the few-row kernel of the same file
         self.fused_steps = True          # decoder steps as 4 launches instead of 7 (False: the unfused kernels; A/B and tests)
@@ -272,6 +285,8 @@ class AOAEngine:
         slices of <= 64 images; `tests/test_gpu_aoa.py::test_trace_is_the_same_in_every_batch`: B = 1 / 64 / 65 bit for bit).  The (T,V)
         `pred` block is the exception: `logits(fast=True)` takes the fp32 kernel below 128 rows (scores equal to rounding)."""
         p_h, p_f, n, k = self._plain[name]
+        if not self._f16():
+            p_h = None
         R = x.shape[0]
         out = torch.empty(R, n, device=self.device)
         if p_h is not None:
@@ -438,7 +453,7 @@ class AOAEngine:
         products on the fp16 matrix cores (csrc/dense_f16x3.hip, fp32-grade: <= 2e-7 of a row's maximum)"""
         R = hc_rows.shape[0]
         out = torch.empty(R, self.V, device=self.device)
-        if fast and R >= 128 and self.p_fc_fwd_h is not None:
+        if fast and R >= 128 and self.p_fc_fwd_h is not None and self._f16():
             hc_rows = hc_rows.contiguous()
             ops.conv_mfma(hc_rows, self.p_fc_fwd_h, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=self.V,
                           bias=self.sd["fc.bias"], out0=out, f16x3=1, in_amax=amax if amax is not None else ops.amax_maps(hc_rows, R))
@@ -481,7 +496,7 @@ class AOAEngine:
         check(lib.lrpx_aoa_rel_init(ctr, crs, ptr(self.sd["fc.weight"]), ptr(tr["logit"]), ptr(tr["captions"]), T + 1, st))
         # decoder_aoa_linear dense rule (:1107-1110): r_ctx = ctx * (W^T (r_caoa / z~(lin)))
         r_ctx = e(rows, H)
-        f16 = 1 if self.lockstep_f16 else 0
+        f16 = 1 if (self.lockstep_f16 and self._f16()) else 0
         ops.conv_mfma(rs["A"], self.p_lin_rel_h if f16 else self.p_lin_rel, rows, 0, H, H, 1, EPI_REL, pix_per_map=1, oc_split=H,
                       x=tr["ctx"], map2img=rowid, out0=r_ctx, f16x3=f16)
         W = E + 2 * H
@@ -507,7 +522,9 @@ class AOAEngine:
             U = ops.gather_rows(U, rowlist)
         a_proj = e(n, P, H)
         r_feat = e(n, P, Cc)
-        head_only = self.head_only and self.p_v_rel_head is not None and P >= 32
+        f16_rules = self.p_v_rel_h is not None and P >= 32 and self._f16()
+        b6_rules = not f16_rules and self.p_v_rel_6 is not None and self.dense_bf16x6           # (any P: a row's kernel never depends on the batch)
+        head_only = self.head_only and ((f16_rules and self.p_v_rel_head is not None) or (b6_rules and self.p_v_rel_head6 is not None))
         if head_only:
             dk = H // self.NH
             a_val = e(n, P, dk)
@@ -515,7 +532,7 @@ class AOAEngine:
         else:
             a_val = e(n, P, H)
             check(lib.lrpx_aoa_rel_value_rows(ctr, crs, ptr(r_ctx), ptr(enc["value"]), int(head_idx), ptr(a_val), ptr(rowlist), n, st))
-        if self.p_v_rel_h is not None and P >= 32:
+        if f16_rules:
             amax2 = ops.zeros(n, dtype=torch.int32, device=self.device)           # max|a_proj| per row: recorded by the first GEMM
             ops.conv_mfma(a_val, self.p_v_rel_head[int(head_idx)] if head_only else self.p_v_rel_h, n, 0, dk if head_only else H, H, 1,
                           EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
@@ -523,6 +540,12 @@ class AOAEngine:
                           in_amax=ops.amax_maps(a_val, n), out1_amax=amax2)
             ops.conv_mfma(a_proj, self.p_proj_rel_h, n, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
                           x=enc["feats"], map2img=row2img, out0=r_feat, f16x3=1, in_amax=amax2)       # :1145-1148
+        elif b6_rules:
+            ops.conv_mfma(a_val, self.p_v_rel_head6[int(head_idx)] if head_only else self.p_v_rel_6, n, 0, dk if head_only else H, H, 1,
+                          EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U, zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img,
+                          out1=a_proj, bf16x6=1)
+            ops.conv_mfma(a_proj, self.p_proj_rel_6, n, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
+                          x=enc["feats"], map2img=row2img, out0=r_feat, bf16x6=1)                     # :1145-1148
         else:
             ops.conv_mfma(a_val, self.p_v_rel, n, 0, H, H, 1, EPI_REL, pix_per_map=P, oc_split=H, x=enc["Vp"], u=U,
                           zdiv=enc["proj_pre"], stab=STAB_EPS, map2img=row2img, out1=a_proj)
@@ -571,7 +594,7 @@ class AOAEngine:
         src = features if features is not None else images
         src = src.to(self.device, torch.float32)
         captions = captions.to(self.device, torch.int64)
-        key = (features is not None, tuple(src.shape), tuple(captions.shape), int(head_idx), bool(accumulate), bool(predictions))
+        key = (features is not None, tuple(src.shape), tuple(captions.shape), int(head_idx), bool(accumulate), bool(predictions), self._f16())
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         g = self._graphs.get(key)
@@ -606,7 +629,7 @@ class AOAEngine:
         src = src.to(self.device, torch.float32)
         captions = captions.to(self.device, torch.int64)
         key = (tuple(src.shape), tuple(captions.shape), bool(accumulate), bool(predictions), _lib.stream_ptr().value,
-               self.vgg.conv_mode if self.vgg is not None else None, int(head_idx), features is not None)
+               self.vgg.conv_mode if self.vgg is not None else None, int(head_idx), features is not None, self._f16())
         if not hasattr(self, "_recordings"):
             self._recordings = {}
         rec = self._recordings.get(key)
@@ -624,6 +647,13 @@ class AOAEngine:
         st_src.copy_(src)
         st_cap.copy_(captions)
         return rec.replay()
+
+    def _f16(self):
+        """the decoder GEMMs on the fp16 split products?  (ops.decoder_f16: with conv modes 2 / 3 only - the engine's own `vgg.conv_mode` or the
+        process default; `force_f16` overrides per engine)"""
+        if self.force_f16 is not None:
+            return bool(self.force_f16)
+        return ops.decoder_f16(self.vgg.conv_mode if self.vgg is not None else None)
 
     def replica(self):
         """A second execution context over the SAME weights: own VGG16 trace / workspace buffers, so that several

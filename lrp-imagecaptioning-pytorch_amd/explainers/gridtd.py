@@ -81,6 +81,8 @@ class GridTDEngine:
         self.p_proj_fwd = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE, kc)
         self.p_attv_fwd = ops.pack_weights(sd["AdaAttention.W_v_proj.weight"], self.P, H, 1, PACK_DENSE, kc)
         self.p_fc_fwd = ops.pack_weights(sd["fc.weight"], self.V, H, 1, PACK_DENSE, kc)
+        # fp16 split-product packs (csrc/dense_f16x3.hip): built always, USED only while ops.decoder_f16() says so (`_f16()`: conv modes 2 / 3)
+        self.force_f16 = None            # True / False: this engine's decoder GEMMs on / off the fp16 split products whatever the conv mode (A/B and tests)
         self.p_fc_fwd_h = ops.pack_weights_f16x2(sd["fc.weight"], self.V, H, _lib.PACK_FWD, taps=1) if H % 64 == 0 else None
         # --- guided-backprop weights: full gate matrices, contraction over the 4H gate rows (gridTDmodel.py:1637-1659)
         self.p_g2 = ops.pack_weights(self.Wcat2, 4 * H, 3 * H, 1, PACK_DENSE_T, kc)
@@ -95,6 +97,10 @@ class GridTDEngine:
         self.p_proj_rel = ops.pack_weights(self.w_proj2d, H, Cc, 1, PACK_DENSE_T, kc)
         # the projector rule runs over every (word, pixel) row: split products on the fp16 matrix cores (csrc/dense_f16x3.hip)
         self.p_proj_rel_h = ops.pack_weights_f16x2(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1) if H % 64 == 0 else None
+        # ... in the default (exact) arithmetic: the same tile on the bf16 matrix cores with operands split exactly into three bf16 parts
+        # (dense_f16x3.hip, B6: six products, fp32 range - what conv mode 1 is for the VGG16 chains); the fp32 MFMA where the sizes do not fit
+        self.p_proj_rel_6 = ops.pack_weights_bf16x3(self.w_proj2d, H, Cc, _lib.PACK_BWD_PLAIN, taps=1) if (H % 32 == 0 and Cc % 4 == 0) else None
+        self.dense_bf16x6 = True         # False: those rules on the fp32 MFMA kernel (A/B and tests)
         # ... and the lock-step gate rules (rows = images x words): the few-row kernel of the same file.  `lockstep_f16 = False`
         # puts them back on the fp32 MFMA (csrc/dense_small.hip; A/B: tools/phase_times.py --lockstep-fp32)
         self.lockstep_f16 = H % 16 == 0 and E % 16 == 0
@@ -220,7 +226,7 @@ class GridTDEngine:
         decisions of a decoding loop): split products on the fp16 matrix cores (csrc/dense_f16x3.hip, fp32-grade)"""
         R = hc_rows.shape[0]
         out = torch.empty(R, self.V, device=self.device)
-        if fast and R >= 128 and self.p_fc_fwd_h is not None:
+        if fast and R >= 128 and self.p_fc_fwd_h is not None and self._f16():
             hc_rows = hc_rows.contiguous()
             ops.conv_mfma(hc_rows, self.p_fc_fwd_h, R, 0, self.H, -(-self.V // 32) * 32, 1, EPI_PLAIN, pix_per_map=1, oc_split=self.V,
                           bias=self.sd["fc.bias"], out0=out, f16x3=1, in_amax=ops.amax_maps(hc_rows, R))
@@ -394,7 +400,7 @@ class GridTDEngine:
         check(lib.lrpx_gridtd_rel_init(ctr, crs, ptr(self.sd["fc.weight"]), ptr(tr["logit"]), ptr(tr["captions"]),
                                        T + 1, st))
         W1 = 2 * E + 2 * H
-        f16 = 1 if self.lockstep_f16 else 0
+        f16 = 1 if (self.lockstep_f16 and self._f16()) else 0
         # the T lock-steps in one native call (lrpx_gridtd_rel_steps): phase 0, LanguageLSTM dense rule, phase 1, AdaLSTM dense rule, phase 2
         d2 = ops.conv_desc(rs["A"], self.p_wg2_h if f16 else self.p_wg2, rows, 0, H, 3 * H, 1, EPI_REL, pix_per_map=1, oc_split=3 * H,
                            x=tr["xh2"], map2img=idx[0], out0=rs["rx"], f16x3=f16)
@@ -419,9 +425,12 @@ class GridTDEngine:
         a_proj = e(n, P, H)
         check(lib.lrpx_gridtd_rel_pix_rows(ctr, crs, ptr(enc["Vp"]), ptr(enc["proj_pre"]), ptr(a_proj), ptr(rowlist), n, st))
         r_feat = e(n, P, Cc)
-        if self.p_proj_rel_h is not None:
+        if self.p_proj_rel_h is not None and self._f16():
             ops.conv_mfma(a_proj, self.p_proj_rel_h, n, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
                           x=enc["feats"], u=U, map2img=row2img, out0=r_feat, f16x3=1, in_amax=ops.amax_maps(a_proj, n))
+        elif self.p_proj_rel_6 is not None and self.dense_bf16x6:
+            ops.conv_mfma(a_proj, self.p_proj_rel_6, n, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
+                          x=enc["feats"], u=U, map2img=row2img, out0=r_feat, bf16x6=1)
         else:
             ops.conv_mfma(a_proj, self.p_proj_rel, n, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc,
                           x=enc["feats"], u=U, map2img=row2img, out0=r_feat)
@@ -434,7 +443,7 @@ class GridTDEngine:
         static outputs (overwritten by the next call with the same shape)."""
         images = images.to(self.device, torch.float32)
         captions = captions.to(self.device, torch.int64)
-        key = (tuple(images.shape), tuple(captions.shape), bool(accumulate), bool(predictions))
+        key = (tuple(images.shape), tuple(captions.shape), bool(accumulate), bool(predictions), self._f16())
         g = self._graphs.get(key) if hasattr(self, "_graphs") else None
         if g is None:
             if not hasattr(self, "_graphs"):
@@ -468,7 +477,7 @@ class GridTDEngine:
         src = src.to(self.device, torch.float32)
         captions = captions.to(self.device, torch.int64)
         key = (tuple(src.shape), tuple(captions.shape), bool(accumulate), bool(predictions), _lib.stream_ptr().value,
-               self.vgg.conv_mode if self.vgg is not None else None)
+               self.vgg.conv_mode if self.vgg is not None else None, self._f16())
         if not hasattr(self, "_recordings"):
             self._recordings = {}
         rec = self._recordings.get(key)
@@ -536,9 +545,12 @@ class GridTDEngine:
         else:   # ExplainGridTDGradient.explain_caption_wordt (:1424-1505): same BPTT, no `features <= 0` gate
             mask = torch.ones(B, P, Cc, device=self.device, dtype=torch.float32)
         d_feat = e(rows, P, Cc)
-        if self.p_proj_rel_h is not None:      # the split-fp16 GEMM of the relevance path (fp32-grade, 4x the fp32 MFMA's rate)
+        if self.p_proj_rel_h is not None and self._f16():      # the split-fp16 GEMM of the relevance path (fp32-grade, 4x the fp32 MFMA's rate)
             ops.conv_mfma(a_proj, self.p_proj_rel_h, rows, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=mask,
                           u=U, map2img=row2img, out0=d_feat, f16x3=1, in_amax=ops.amax_maps(a_proj, rows))
+        elif self.p_proj_rel_6 is not None and self.dense_bf16x6:
+            ops.conv_mfma(a_proj, self.p_proj_rel_6, rows, 0, H, -(-Cc // 32) * 32, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=mask,
+                          u=U, map2img=row2img, out0=d_feat, bf16x6=1)
         else:
             ops.conv_mfma(a_proj, self.p_proj_rel, rows, 0, H, Cc, 1, EPI_REL, pix_per_map=P, oc_split=Cc, x=mask, u=U,
                           map2img=row2img, out0=d_feat)                                          # :1668, :1674
@@ -636,6 +648,13 @@ class GridTDEngine:
         if return_features:
             out = out + (r_feat.view(B, T, self.P, self.C), tr, enc)
         return out
+
+    def _f16(self):
+        """the decoder GEMMs on the fp16 split products?  (ops.decoder_f16: with conv modes 2 / 3 only - the engine's own `vgg.conv_mode` or the
+        process default; `force_f16` overrides per engine)"""
+        if self.force_f16 is not None:
+            return bool(self.force_f16)
+        return ops.decoder_f16(self.vgg.conv_mode if self.vgg is not None else None)
 
     def replica(self):
         """A second execution context over the SAME weights (device tensors and packed blobs are shared): own VGG16

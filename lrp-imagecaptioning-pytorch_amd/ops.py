@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the current HIP stream; ever
 hand-written HIP kernel inside csrc/liblrpx.so.  All tensors are CUDA(=HIP) float32 contiguous;
 activations are NHWC ([maps, H*W, C])."""
 import ctypes as C
+import os
 
 import torch
 
@@ -40,12 +41,13 @@ def pack_weights(w, cout, cin, taps, mode, kc):
     return out
 
 
-def pack_weights_bf16x3(w, cout, cin, mode):
-    """3x3 conv weights -> three bf16 planes in fragment layout (for conv_mfma(..., bf16x6=1))."""
+def pack_weights_bf16x3(w, cout, cin, mode, taps=9):
+    """3x3 conv weights (taps = 9) or a dense (cout, cin) matrix (taps = 1; PACK_BWD_PLAIN = the transposed product of the epsilon
+    rules, as pack_weights_f16x2) -> three bf16 planes, w == p0 + p1 + p2 exactly, in fragment layout (for conv_mfma(..., bf16x6=1))."""
     lib = _lib.load()
     n_oc, k = (cout, cin) if mode == _lib.PACK_FWD else (cin, cout)
-    out = torch.empty(lib.lrpx_packed_bf16x3_bytes(n_oc, k, 9) // 2, dtype=torch.int16, device=w.device)
-    check(lib.lrpx_pack_weights_bf16x3(ptr(w.contiguous()), cout, cin, 9, mode, ptr(out), stream_ptr()))
+    out = torch.empty(lib.lrpx_packed_bf16x3_bytes(n_oc, k, taps) // 2, dtype=torch.int16, device=w.device)
+    check(lib.lrpx_pack_weights_bf16x3(ptr(w.contiguous()), cout, cin, taps, mode, ptr(out), stream_ptr()))
     return out
 
 
@@ -81,6 +83,20 @@ def zeros_arena(device, shapes):
         total += -(-n // 64) * 64
     flat = zeros(total, device=device)
     return {k: flat[o:o + n].view(*shapes[k]) for k, (o, n) in offs.items()}
+
+
+def decoder_f16(mode=None):
+    """Do the decoders' GEMMs (the (word, pixel) rules, the lock-step gate rules, the plain linears of a trace, the (T,V) scores) run on
+    the fp16 split-product kernels (csrc/dense_f16x3.hip: two fp16 halves behind a power-of-two scale per ROW - 22 operand bits, 1.5 - 2.4x
+    the decoder throughput)?  They FOLLOW the process's conv mode: in the default, exact mode 1 (and mode 0) every contraction of the
+    path is fp32 arithmetic - the decoders on the fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2) and fp32 VALU kernels, as the reference's
+    `lrp_linear_eps` (models/gridTDmodel.py:744-765) and its nn.Linear forwards are - and only the opt-in speed modes 2 / 3 take the
+    split products.  LRPX_DECODER_F16=0 / 1 overrides (A/B).  Read at every call of an engine (the packs of both kinds are built
+    with the engine; `engine.force_f16 = True / False` pins one engine)."""
+    v = os.environ.get("LRPX_DECODER_F16", "")
+    if v != "":
+        return v != "0"
+    return (_lib.load().lrpx_set_conv_mode(-1) if mode is None else int(mode)) >= 2          # (mode: an engine's per-context conv mode)
 
 
 def zeros(*shape, dtype=torch.float32, device="cuda"):

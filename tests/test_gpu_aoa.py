@@ -216,6 +216,7 @@ def test_aoa_fused_lock_steps_match_the_two_launch_steps(bu):
         enc = eng.encode(torch.from_numpy(weights.make_images(36, B)))
     cap = torch.from_numpy(weights.make_captions(37, B, T, V)).cuda()
     tr = eng.trace(enc, cap, predictions=False)
+    eng.force_f16 = True          # (the fused lock-step is the fp16 split-product kernel's epilogue: speed modes / LRPX_DECODER_F16=1)
     assert eng.fused_rel
     for head, lens in ((0, None), (6, [9, 2, 5, 0, 9])):
         a_feat, a_words, _ = eng.relevance(enc, tr, head, lens, compact=False)
@@ -248,6 +249,7 @@ def test_aoa_head_slice_of_the_v_proj_rule_is_bit_identical(bu):
         enc = eng.encode(torch.from_numpy(weights.make_images(39, B)))
     cap = torch.from_numpy(weights.make_captions(40, B, T, V)).cuda()
     tr = eng.trace(enc, cap, predictions=False)
+    eng.force_f16 = True          # (the head slice is a pack of the fp16 split-product kernel)
     assert eng.head_only and eng.p_v_rel_head is not None
     for head, lens in ((0, None), (4, [5, 1, 0, 3, 5, 2]), (7, None)):
         a_feat, a_words, _ = eng.relevance(enc, tr, head, lens)

@@ -109,6 +109,85 @@ def test_dense_f16x3_rel_many_rows(ops, n_maps, P, k, n, n_img):
     print(f"dense f16x3 ({n_maps} maps x {P} rows, {k} -> {n}): worst map {worst:.2e} of its maximum")
 
 
+@pytest.mark.parametrize("n_maps,P,k,n,n_img", [(40, 196, 512, 512, 4), (23, 36, 512, 2048, 5), (3, 36, 64, 96, 2), (320, 196, 512, 512, 16),
+                                                 (1, 5, 32, 8, 1), (47, 100, 128, 1000, 5)])
+def test_dense_bf16x6_rel_many_rows(ops, n_maps, P, k, n, n_img):
+    """The same rules in the DEFAULT arithmetic of the path (conv mode 1: nothing narrower than fp32) - operands split exactly into
+    three bf16 parts, six products on v_mfma_f32_32x32x16_bf16 (csrc/dense_f16x3.hip, B6; weights from lrpx_pack_weights_bf16x3 with
+    taps = 1): no operand scale, no in_amax, fp32 range.  Against fp64, per map <= 2e-6 of max|r| with the maps' magnitudes spread over
+    1e-30 .. 1e30 (beyond fp16's range even behind a per-map scale: entries e^+-6 around it); out0 (with and without the addend U) and
+    out1 = r / z~ (epsilon stabiliser, z = 0 included); any number of rows (5 .. 62 720; off the 96 / 128-row tiles), 8 / 96 / 1000 /
+    2048 columns; nothing written behind the outputs; a map's result is the same bits whatever else is in the batch."""
+    from lrp_amd import _lib
+    g = torch.Generator().manual_seed(n_maps * 13 + P)
+    a = torch.randn(n_maps, P, k, generator=g) * torch.exp(1.5 * torch.randn(n_maps, P, k, generator=g))
+    a = a * torch.logspace(-30, 30, n_maps).view(-1, 1, 1) if n_maps > 1 else a
+    if n_maps > 2:
+        a[n_maps // 2] = 0.0
+    w = torch.randn(k, n, generator=g) * 0.05
+    x = torch.randn(n_img, P, n, generator=g)
+    u = torch.randn(n_maps, n, generator=g) * a.abs().amax(dim=(1, 2)).view(-1, 1) * 0.3
+    z = torch.randn(n_img, P, n, generator=g)
+    z[0, 0, :5] = 0.0
+    m2i = torch.randint(0, n_img, (n_maps,), generator=g).to(torch.int32)
+    n_pad = -(-n // 32) * 32
+    wp = ops.pack_weights_bf16x3(w.cuda(), k, n, _lib.PACK_BWD_PLAIN, taps=1)
+    rows = n_maps * P
+    guard = 128 * n
+    xs, zs = x[m2i.long()].double(), z[m2i.long()].double()
+    zt = zs + 0.01 * torch.sign(zs)
+    zt[zt == 0] = 0.01
+    ad, xd, ud, zd, md = a.cuda(), x.cuda(), u.cuda(), z.cuda(), m2i.cuda()
+    worst = 0.0
+    for with_u, with_o1 in ((True, False), (False, False), (True, True), (False, True)):
+        buf = torch.full((rows * n + guard,), 777.0, device="cuda")
+        kw = dict(out1=buf[:rows * n], zdiv=zd, stab=_lib.STAB_EPS) if with_o1 else dict(out0=buf[:rows * n])
+        ops.conv_mfma(ad, wp, n_maps, 0, k, n_pad, 1, _lib.EPI_REL, pix_per_map=P, oc_split=n, x=xd, u=ud if with_u else None,
+                      map2img=md, bf16x6=1, **kw)
+        torch.cuda.synchronize()
+        assert (buf[rows * n:] == 777.0).all()
+        got = buf[:rows * n].view(n_maps, P, n).cpu().double()
+        want = xs * (a.double() @ w.double() + (u.double().unsqueeze(1) if with_u else 0.0))
+        if with_o1:
+            want = want / zt
+        for m in range(n_maps):
+            s0 = want[m].abs().max().item()
+            if s0 == 0:
+                assert got[m].abs().max().item() == 0
+                continue
+            e = ((got[m] - want[m]).abs().max() / s0).item()
+            worst = max(worst, e)
+            assert e < (4e-6 if with_o1 else 2e-6), (with_u, with_o1, m, e)      # (fp32 accumulation over K = 512: the bounds of the f16x3 test above)
+        if n_maps >= 3 and not with_o1:          # the first maps alone (another grid, another tile height): the same bits
+            sub = max(1, n_maps // 3)
+            buf2 = torch.full((sub * P * n,), 777.0, device="cuda")
+            ops.conv_mfma(ad[:sub].contiguous(), wp, sub, 0, k, n_pad, 1, _lib.EPI_REL, pix_per_map=P, oc_split=n, x=xd,
+                          u=ud[:sub].contiguous() if with_u else None, map2img=md[:sub].contiguous(), bf16x6=1, out0=buf2)
+            torch.cuda.synchronize()
+            assert torch.equal(buf2, buf[:sub * P * n])
+    print(f"dense bf16x6 ({n_maps} maps x {P} rows, {k} -> {n}): worst map {worst:.2e} of its maximum")
+
+
+def test_dense_bf16x6_refuses_what_it_is_not_built_for(ops):
+    """K off the 32-chunk, two outputs at once, a PLAIN epilogue: EINVAL with a message, no launch"""
+    from lrp_amd import _lib
+    a = torch.randn(2, 40, 48, device="cuda")
+    w = torch.randn(48, 64, device="cuda")
+    x = torch.randn(1, 40, 64, device="cuda")
+    m2i = torch.zeros(2, dtype=torch.int32, device="cuda")
+    wp = ops.pack_weights_bf16x3(w, 48, 64, _lib.PACK_BWD_PLAIN, taps=1)
+    out = torch.empty(2, 40, 64, device="cuda")
+    with pytest.raises(ValueError, match="multiple of 32"):
+        ops.conv_mfma(a, wp, 2, 0, 48, 64, 1, _lib.EPI_REL, pix_per_map=40, oc_split=64, x=x, map2img=m2i, out0=out, bf16x6=1)
+    a2 = torch.randn(2, 40, 64, device="cuda")
+    wp2 = ops.pack_weights_bf16x3(torch.randn(64, 64, device="cuda"), 64, 64, _lib.PACK_BWD_PLAIN, taps=1)
+    with pytest.raises(ValueError, match="ONE output"):
+        ops.conv_mfma(a2, wp2, 2, 0, 64, 64, 1, _lib.EPI_REL, pix_per_map=40, oc_split=64, x=x, zdiv=x, stab=_lib.STAB_EPS, map2img=m2i,
+                      out0=out, out1=torch.empty_like(out), bf16x6=1)
+    with pytest.raises(ValueError, match="REL epilogue"):
+        ops.conv_mfma(a2, wp2, 2, 0, 64, 64, 1, _lib.EPI_PLAIN, pix_per_map=40, oc_split=64, out0=out, bf16x6=1)
+
+
 @pytest.mark.parametrize("per", [36 * 512, 196 * 512, 1024, 2048, 3072, 4096, 6144, 8192, 100, 4 * 1037])
 def test_amax_maps_exact_for_every_block_shape(ops, per):
     """lrpx_amax_maps: float bits of max|.| per map, exact, for every float4-per-thread instantiation (256 * ITER float4 dividing

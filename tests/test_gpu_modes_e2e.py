@@ -46,6 +46,40 @@ def test_process_default_is_the_exact_split_mode():
     assert _lib.load().lrpx_set_conv_mode(-1) == want
 
 
+def test_decoder_arithmetic_follows_the_conv_mode(gridtd, aoa):
+    """VERDICT r5 item 1 (nothing on the headline path narrower than fp32): in the exact modes 0 / 1 the decoders' GEMMs take the fp32
+    kernels, the fp16 split products (csrc/dense_f16x3.hip: 22 operand bits behind a per-row scale) only with the opt-in modes 2 / 3
+    (ops.decoder_f16); the two agree to ~1e-6 of a row's maximum on the golden caption."""
+    if "LRPX_DECODER_F16" in os.environ:
+        pytest.skip("LRPX_DECODER_F16 overrides the rule under test")
+    from lrp_amd import _lib
+    for eng in (gridtd[1], aoa[1]):
+        keep = eng.vgg.conv_mode
+        try:
+            for mode, want in ((0, False), (1, False), (2, True), (3, True)):
+                eng.vgg.conv_mode = mode
+                assert eng._f16() is want, (type(eng).__name__, mode)
+            eng.vgg.conv_mode = None
+            assert eng._f16() is (_lib.load().lrpx_set_conv_mode(-1) >= 2)
+        finally:
+            eng.vgg.conv_mode = keep
+    g, eng, img, cap, sd = gridtd
+    enc = eng.encode(img)
+    got = {}
+    for f16 in (False, True):
+        eng.force_f16 = f16
+        try:
+            tr = eng.trace(enc, cap.cuda(), predictions=False)
+            r_feat, r_words, _ = eng.relevance(enc, tr)
+            got[f16] = (r_feat.clone(), r_words.clone())
+        finally:
+            eng.force_f16 = None
+    d = (got[True][0] - got[False][0]).flatten(1).abs().amax(1) / got[False][0].flatten(1).abs().amax(1)
+    print(f"gridTD decoder fp32 vs f16x3 GEMMs: r_feat worst row {d.max().item():.2e} of max|R|, r_words {(got[True][1] - got[False][1]).abs().max().item():.2e}")
+    assert d.max().item() < 5e-6 and (got[True][1] - got[False][1]).abs().max().item() < 5e-6
+    assert d.max().item() > 0           # (they ARE different kernels)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_gridtd_explain_vs_reference_in_every_mode(gridtd, mode):
     g, eng, img, cap, sd = gridtd

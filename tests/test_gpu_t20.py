@@ -70,12 +70,15 @@ def words_bound(got, ref32, ref64, what):
     return e64, noise
 
 
-def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout, g64=None, pos=POS, lens=None):
+def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout, g64=None, pos=POS, lens=None, strict=1e-5):
     """r_feat (B,T,P,C) / r_words (B,T,T) of the engine vs the golden rows `prefix{k}_*`.
     layout 'chw': golden sub = (C/stride, 14, 14); 'pc': golden sub = (P, C/stride).
     tol_words: flat bound against the reference's fp32 rows, or None = the fp64-anchored bound (g64 = t20_f64.npz view).
     pos: batch positions of the golden images; lens: words of golden image k that the batch explains (a caption cut after
-    lens[k] words: word t depends on the steps 0..t only, so the fixture's first lens[k] rows are the reference's result)."""
+    lens[k] words: word t depends on the steps 0..t only, so the fixture's first lens[k] rows are the reference's result).
+    strict: the SURVEY 8(d) bound of a well-conditioned r_words row against the reference's fp32 row - 1e-5 in the default arithmetic (fp32
+    decoder GEMMs); the opt-in fp16 split products of the speed modes (22 operand bits) are held to 2e-5 there (gridTD image 1, word 1:
+    1.1e-5) and to the fp64 anchor like every row."""
     worst_f, worst_w, worst_ratio, worst_well, n_well = 0.0, 0.0, 0.0, 0.0, 0
     T_pad = T
     for k, p in enumerate(pos):
@@ -106,7 +109,7 @@ def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout, g64
                 if noise <= 3e-6:
                     n_well += 1
                     worst_well = max(worst_well, float(w))
-                    assert w <= 1e-5, (prefix, k, t, "vs the reference's fp32 row", float(w), "its own distance from fp64", noise)
+                    assert w <= strict, (prefix, k, t, "vs the reference's fp32 row", float(w), "its own distance from fp64", noise)
                 st64 = g64[f"{prefix}{k}_r_feat_stats64_{t}"]           # r_feat of the fp64 evaluation: L2 and max agree
                 assert abs(got.norm().item() - st64[2]) <= 1e-4 * st64[2] and abs(got.abs().max().item() - st64[1]) <= 1e-4 * st64[1]
             if t + 1 < T_pad:
@@ -123,16 +126,18 @@ def _check_rows(g, prefix, r_feat, r_words, T, C, stride, tol_words, layout, g64
              f"{n_well} well-conditioned rows: worst |GPU - ref32| = {worst_well:.2e} (bound 1e-5)"))
 
 
-def test_gridtd_t20_rows_inside_b16_batch(g20, g64):
+@pytest.mark.parametrize("f16", [False, True], ids=["decoder-fp32", "decoder-f16x3"])
+def test_gridtd_t20_rows_inside_b16_batch(g20, g64, f16):
     from lrp_amd import weights
     from lrp_amd.explainers.gridtd import GridTDEngine
     g = g20
     V, B = int(g["grid_V"]), 16
     T, caps = _batch(g, B, "grid_caption", V, 61)
     eng = GridTDEngine(weights.make_gridtd_state(seed=int(g["seed"]), vocab_size=V))
+    eng.force_f16 = f16          # the decoder GEMMs on the fp32 kernels (default mode) / on the fp16 split products (speed modes): same bounds
     maps, r_words, r_feat, tr, enc = eng.explain_batch(_images(g, B), caps, accumulate=True, return_features=True)
     torch.cuda.synchronize()
-    _check_rows(g, "grid", r_feat.cpu(), r_words.cpu(), T, 512, 32, None, "chw", g64=g64)
+    _check_rows(g, "grid", r_feat.cpu(), r_words.cpu(), T, 512, 32, None, "chw", g64=g64, strict=2e-5 if f16 else 1e-5)
     # pixel maps of golden image 0: the reference's running sums over all 20 words (lrp_wrapper.py:64-82 quirk), GPU forward
     # included -> modulo max-pool tie flips (conftest)
     m = maps[POS[0]].cpu()
@@ -142,21 +147,23 @@ def test_gridtd_t20_rows_inside_b16_batch(g20, g64):
         assert abs(m[t].double().norm().item() - st[2]) <= 2e-3 * st[2]
 
 
+@pytest.mark.parametrize("f16", [False, True], ids=["decoder-fp32", "decoder-f16x3"])
 @pytest.mark.parametrize("head", [0, 3])
-def test_aoa_t20_rows_inside_b16_batch(g20, g64, head):
+def test_aoa_t20_rows_inside_b16_batch(g20, g64, head, f16):
     from lrp_amd import weights
     from lrp_amd.explainers.aoa import AOAEngine
     g = g20
     V, B = int(g["aoa_V"]), 16
     T, caps = _batch(g, B, "aoa_caption", V, 62)
     eng = AOAEngine(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=V))
+    eng.force_f16 = f16
     enc = eng.encode(_images(g, B).cuda())
     tr = eng.trace(enc, caps.cuda(), predictions=False)
     r_feat, r_words, _ = eng.relevance(enc, tr, head)
     torch.cuda.synchronize()
     r_feat, r_words = r_feat.view(B, T, 196, 512).cpu(), r_words.view(B, T, T).cpu()
     if head == 0:
-        _check_rows(_Prefixed(g, "_h0"), "aoa", r_feat, r_words, T, 512, 32, None, "chw", g64=_Prefixed(g64, "_h0"))
+        _check_rows(_Prefixed(g, "_h0"), "aoa", r_feat, r_words, T, 512, 32, None, "chw", g64=_Prefixed(g64, "_h0"), strict=2e-5 if f16 else 1e-5)
     else:      # head 3 was generated for golden image 1 only
         gg, gg64 = _Prefixed(g, "_h3"), _Prefixed(g64, "_h3")
         k, p = 1, POS[1]
@@ -180,7 +187,8 @@ class _Prefixed:
         return self.g[f"{head}{self.tag}_{rest}"]
 
 
-def test_aoa_bottom_up_t20_rows_inside_b32_batch(g20, g64):
+@pytest.mark.parametrize("f16", [False, True], ids=["decoder-fp32", "decoder-f16x3"])
+def test_aoa_bottom_up_t20_rows_inside_b32_batch(g20, g64, f16):
     from lrp_amd import weights
     from lrp_amd.explainers.aoa import AOAEngine
     g = g20
@@ -191,9 +199,10 @@ def test_aoa_bottom_up_t20_rows_inside_b32_batch(g20, g64):
     for k, p in enumerate(POS):
         feats[p] = gold[k]
     eng = AOAEngine(weights.make_aoa_state(seed=int(g["seed"]), vocab_size=V, feat_dim=2048, with_encoder=False))
+    eng.force_f16 = f16
     r_feat, r_words = eng.explain_batch(caps, 0, features=torch.from_numpy(feats))
     torch.cuda.synchronize()
-    _check_rows(g, "bu", r_feat.cpu(), r_words.cpu(), T, 2048, 64, None, "pc", g64=g64)
+    _check_rows(g, "bu", r_feat.cpu(), r_words.cpu(), T, 2048, 64, None, "pc", g64=g64, strict=2e-5 if f16 else 1e-5)
 
 
 def test_forward_features_vs_fp64_and_batch_independence(g20, g64):
