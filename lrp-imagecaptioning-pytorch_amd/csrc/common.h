@@ -109,6 +109,7 @@ struct Switches {
     int s21_nhwc;        // LRPX_S21_NHWC: S between conv2_2 and conv2_1 as NHWC instead of 16-channel chunks
     int guided_poolbwd;  // LRPX_GUIDED_POOLBWD: image-gradient chain with pool-backward kernels
     int dense_wide;      // LRPX_DENSE_WIDE (default 0): 256-row 8-wave tiles for the many-row dense f16x3 GEMM (1), 128-row tiles (0)
+    int dense_ks_rel;    // LRPX_DENSE_KS_REL: the few-row epsilon rule (the decoders' lock-steps in the exact modes) with K split over four waves (dense_ks_kernel)
     int dense_n256;      // LRPX_DENSE_N256 (default 1): 128 x 256 tiles with the waves side by side for the many-row dense f16x3 GEMM
     int dense_rt;        // LRPX_DENSE_RT (default 0 = by the grid): row tiles per wave of that kernel, 4 (128-row tiles) or 3 (96-row tiles)
     int dense_1wave;     // LRPX_DENSE_1WAVE: PLAIN few-row GEMMs without the 4-wave K split

@@ -217,8 +217,11 @@ __global__ __launch_bounds__(256, 2) void dense_slab_kernel(ConvArgs a, int m_ti
 // The plain GEMM with the K loop of a tile split over four waves (the decoders' image-gradient BPTT: 640 rows x K = 2048:
 // 137 us as 80 x 4 waves with 1024 dependent fp32 MFMAs each).  Workgroup = 16 waves = 4 column blocks x 4 K quarters over
 // the same 32 x K slab of A; the four partial tiles of a column block meet in LDS and are summed in K order
-// (deterministic).  Not used for the epsilon rule: there another summation order moves ONE T = 20 word relevance of the
-// LRP goldens from below to above its 1e-5 bound (an ill-conditioned sum; measured).
+// (deterministic).  Round 6: also the epsilon rule of the decoders' lock-steps in the exact modes (REL epilogue; LRPX_DENSE_KS_REL=0:
+// the one-wave kernel above) - 20 -> 12 us per lock-step GEMM, the one-image drop-in's decoder relevance 1.14 -> 0.97 ms.  (Rounds 3 - 5
+// kept the rule on the one-wave kernel because this order moved ONE T = 20 word relevance of the LRP goldens above its 1e-5 bound; with
+// the round-6 K loop of the trace linears - lrpx_decoder.hip, linear_mfma_core - the worst row sits at 9.2e-6 in this order, 9.9e-6 in
+// the other: the row is carried by the encoder features' own 1.8e-6, tests/diag_t20_words.py.)
 template <int EPI>
 __global__ __launch_bounds__(1024, 1) void dense_ks_kernel(ConvArgs a, int m_tiles, int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -297,7 +300,8 @@ __global__ __launch_bounds__(1024, 1) void dense_ks_kernel(ConvArgs a, int m_til
     const int ncol = a.oc_split;
     if (oc >= ncol || oc >= a.n_oc) return;
     float bias = 0.f;
-    if (a.bias) bias = a.bias[oc];
+    if (EPI == EPI_PLAIN && a.bias) bias = a.bias[oc];
+    const long P = a.pix_per_map;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (tid >> 7) + 8 * i;
@@ -305,9 +309,16 @@ __global__ __launch_bounds__(1024, 1) void dense_ks_kernel(ConvArgs a, int m_til
         if (row >= rows) continue;
         float v = (red[((0 * 4 + cb) * 32 + r) * 33 + cl] + red[((1 * 4 + cb) * 32 + r) * 33 + cl]) +
                   (red[((2 * 4 + cb) * 32 + r) * 33 + cl] + red[((3 * 4 + cb) * 32 + r) * 33 + cl]);
-        v += bias;
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        a.out0[row * ncol + oc] = v;
+        if constexpr (EPI == EPI_REL) {               // (the epilogue of dense_small_kernel)
+            const long n = row / P, p = row - n * P;
+            const long img = a.map2img ? a.map2img[n] : n;
+            if (a.U) v += a.U[n * ncol + oc];
+            a.out0[row * ncol + oc] = a.X[(img * P + p) * ncol + oc] * v;
+        } else {
+            v += bias;
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            a.out0[row * ncol + oc] = v;
+        }
     }
 }
 
@@ -318,8 +329,8 @@ static int launch_dense_small_t(const ConvArgs& a, hipStream_t stream) {
     const int n_blocks = (int)ceil_div(a.n_oc, 128);
     const int lds = 32 * ((a.cin < 1024 ? a.cin : 1024) + 4) * (int)sizeof(float);
     const int dense_ks = switches().dense_1wave ? 0 : 1;      // (A/B switch)
-    if constexpr (EPI == EPI_PLAIN) {
-        if (dense_ks && a.cin >= 512) {
+    {
+        if (dense_ks && a.cin >= 512 && (EPI == EPI_PLAIN || switches().dense_ks_rel)) {
             // K split over four waves per column block (16-wave workgroups)
             constexpr int RED = 16 * 32 * 33 * (int)sizeof(float);
             const int lds_ks = lds > RED ? lds : RED;

@@ -68,6 +68,7 @@ const Switches& switches() {
         w.s21_nhwc = set("LRPX_S21_NHWC");
         w.guided_poolbwd = set("LRPX_GUIDED_POOLBWD");
         w.dense_wide = num("LRPX_DENSE_WIDE", 0);
+        w.dense_ks_rel = num("LRPX_DENSE_KS_REL", 1);
         w.dense_n256 = num("LRPX_DENSE_N256", 1);
         w.dense_rt = num("LRPX_DENSE_RT", 0);
         w.dense_1wave = set("LRPX_DENSE_1WAVE");
