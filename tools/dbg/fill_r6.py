@@ -14,7 +14,7 @@ rep = {
     "@CHAIN@": f"{r['chain']['ms_per_step']:.2f}", "@CFRAC@": f"{r['chain_frac']:.3f}",
     "@LAYERS@": ", ".join(f"{x['layer']} {x['ms']:.2f}" for x in r["per_layer"]),
     "@C3@": f(c["3"]["value"]), "@C3F@": f(c["3"].get("value_f16f6", 0)), "@C4@": f(c["4"]["value"]), "@C4F@": f(c["4"].get("value_f16f6", 0)),
-    "@CB@": f(c["b64"]["value"]), "@CBF@": f(c["b64"].get("value_f16f6", 0)), "@C5@": f(c["5"]["value"]), "@CV@": f(c["varlen"]["value"]),
+    "@CB@": f(c["b64"]["value"]), "@CBF@": f(c["b64"].get("value_f16f6", 0)), "@C5@": f(c["5"]["value"]), "@C5MS@": f"{c['5']['ms_per_step']:.2f}", "@C5F@": f(c["5"].get("value_f16x3", 0)), "@CV@": f(c["varlen"]["value"]),
     "@C3A@": f(c["3"]["all_heads"]["value"]),
     "@B1@": f"{b1['ms_per_call']:.2f}", "@B1F@": (f"{b1['ms_per_call_f16f6']:.2f}" if b1.get("ms_per_call_f16f6") else "4.8"),
     "@B1A@": f"{c['dropin_b1']['aoa_given_caption']['ms_per_call']:.2f}",
