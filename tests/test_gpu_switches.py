@@ -61,11 +61,15 @@ def default_run(tmp_path_factory):
     return get
 
 
-# (switch, value, conv mode of the child: "" = the default mode 3; LRPX_FIRST_VALU / LRPX_S21_NHWC choose kernels of the NHWC
+# (switch, value, conv mode of the child: "" = the process default (mode 1 since round 6; mode 3 before); LRPX_FIRST_VALU / LRPX_S21_NHWC choose kernels of the NHWC
 # chain of mode 2 - the mode-3 chain keeps its tensors in the blocked layout and has no such alternatives)
 SWITCHES = [("LRPX_FWD_WIDE", "15", ""), ("LRPX_CONV11_F16", "0", ""), ("LRPX_WIDE", "0", ""), ("LRPX_FWD_KSPLIT", "1", ""),
             ("LRPX_FWD_KSPLIT28", "4", ""), ("LRPX_FIRST_VALU", "1", "2"), ("LRPX_S21_NHWC", "1", "2"), ("LRPX_GUIDED_POOLBWD", "1", ""),
-            ("LRPX_DENSE_1WAVE", "1", ""), ("LRPX_LINEAR_VALU", "1", "")]
+            ("LRPX_DENSE_1WAVE", "1", ""), ("LRPX_LINEAR_VALU", "1", ""),
+            # round 6: the lock-step rule of the exact modes on the one-wave kernel; the decoders' GEMMs on / off the fp16 split products
+            # against the conv mode's rule (lrp_amd.ops.decoder_f16)
+            ("LRPX_DENSE_KS_REL", "0", ""), ("LRPX_DECODER_F16", "1", ""), ("LRPX_DECODER_F16", "0", "3"),
+            ("LRPX_B6_FWD_KSPLIT28", "1", ""), ("LRPX_B6_FWD_KSPLIT56", "1", ""), ("LRPX_B6_REL_KSPLIT14", "1", ""), ("LRPX_X6_LEGACY", "1", "")]
 
 
 @pytest.mark.parametrize("name,value,mode", SWITCHES)
@@ -73,7 +77,7 @@ def test_non_default_switch_gives_the_same_results(default_run, tmp_path, name, 
     from conftest import rel_err
     got = _run(tmp_path, name, {name: value, **({"LRPX_CHILD_MODE": mode} if mode else {})})
     ref = default_run(mode)
-    fwd = name.startswith("LRPX_FWD") or name == "LRPX_CONV11_F16"
+    fwd = name.startswith("LRPX_FWD") or name.startswith("LRPX_B6_FWD") or name in ("LRPX_CONV11_F16", "LRPX_X6_LEGACY")
     # forward switches change the summation order of the trace (features move at the 1e-6 level, a pool winner may flip);
     # everything else runs the same trace through another kernel of the same arithmetic
     assert rel_err(got["feats"], ref["feats"]) < (1e-5 if fwd else 1e-7), name

@@ -267,3 +267,26 @@ def test_bench_pmc_traffic_parser_and_precedence(tmp_path):
     finally:
         bench.LIVE_TRAFFIC.clear()
         bench.LIVE_TRAFFIC.update(saved)
+
+
+def test_decoder_arithmetic_rule_and_its_overrides(monkeypatch):
+    """lrp_amd.ops.decoder_f16: the decoders' GEMMs take the fp16 split products (22 operand bits) only with the opt-in conv modes 2 / 3 -
+    an engine's own mode, else the process default - so that nothing on the default path is narrower than the reference's fp32
+    (models/gridTDmodel.py:744-765 `lrp_linear_eps` is fp32 matmul); LRPX_DECODER_F16 = 0 / 1 overrides either way.  Host logic only."""
+    from lrp_amd import _lib, ops
+    lib = _lib.load()
+    monkeypatch.delenv("LRPX_DECODER_F16", raising=False)
+    keep = lib.lrpx_set_conv_mode(-1)
+    try:
+        for mode in (0, 1, 2, 3):
+            assert ops.decoder_f16(mode) is (mode >= 2)
+            lib.lrpx_set_conv_mode(mode)
+            assert ops.decoder_f16() is (mode >= 2)          # (None: the process default)
+        monkeypatch.setenv("LRPX_DECODER_F16", "1")
+        assert ops.decoder_f16(1) is True and ops.decoder_f16(0) is True
+        monkeypatch.setenv("LRPX_DECODER_F16", "0")
+        assert ops.decoder_f16(3) is False
+        monkeypatch.setenv("LRPX_DECODER_F16", "")
+        assert ops.decoder_f16(3) is True and ops.decoder_f16(1) is False
+    finally:
+        lib.lrpx_set_conv_mode(keep)
