@@ -95,6 +95,8 @@ def rel_launcher(l, mode):
     if mode == 1:      # conv_f16x3.h with B6 (exact bf16 splits): fused multiplicand, pooled-input staging
         if pooled:
             return f"launch_b6_{hw}_pool"
+        if hw == 14:      # K split in two as a property of the layer (csrc/lrpx_vgg.hip, b6_rel_ksplit14): PLAIN partials + rel_mul_finish
+            return "launch_b6_14_plain"
         return "launch_b6_112n_rel" if (hw == 112 and n_oc <= 64) else f"launch_b6_{hw}_rel"
     return {224: "launch_conv_224_8_2_2_9_rel", 112: "launch_conv_112_8_2_2_9_rel" if n_oc <= 64 else "launch_conv_112_8_1_4_9_rel",
             56: "launch_conv_56_16_1_4_9_rel", 28: "launch_conv_28_16_1_4_9_rel", 14: "launch_conv_14_16_1_4_9_rel"}[hw]

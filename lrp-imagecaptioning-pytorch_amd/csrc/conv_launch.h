@@ -172,6 +172,7 @@ struct AoaStepFuse {
     float* wpart = nullptr;                                      // [rows][T][4] partial sums of r_words
 };
 int launch_dense_small_f16x3_aoa_step(const ConvArgs& a, const AoaStepFuse& fz, hipStream_t s);
+int launch_dense_ks_aoa_step(const ConvArgs& a, const AoaStepFuse& fz, hipStream_t s);      // dense_small.hip: the same step on the fp32 MFMA (exact modes)
 
 // few-row dense GEMMs (dense_small.hip)
 bool dense_small_fits(const ConvArgs& a);

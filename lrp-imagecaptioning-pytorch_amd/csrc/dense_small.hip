@@ -222,9 +222,16 @@ __global__ __launch_bounds__(256, 2) void dense_slab_kernel(ConvArgs a, int m_ti
 // kept the rule on the one-wave kernel because this order moved ONE T = 20 word relevance of the LRP goldens above its 1e-5 bound; with
 // the round-6 K loop of the trace linears - lrpx_decoder.hip, linear_mfma_core - the worst row sits at 9.2e-6 in this order, 9.9e-6 in
 // the other: the row is carried by the encoder features' own 1.8e-6, tests/diag_t20_words.py.)
-template <int EPI>
-__global__ __launch_bounds__(1024, 1) void dense_ks_kernel(ConvArgs a, int m_tiles, int n_blocks) {
+// FUSE (round 6): lock-step s of the AoA decoder relevance (models/aoamodel.py:1114-1134) in this kernel's epilogue - what FUSE of
+// dense_small_f16x3_kernel (dense_f16x3.hip) is for the fp16 split products, here in the exact arithmetic of the default mode: the product
+// r_xh = xh * (W_g^T A) is consumed where it is formed, by column range [emb | glob | h] (E = H = K = 512, 128-column workgroups):
+// emb -> one partial sum of r_words per (row, workgroup) (wpart, added up in a fixed order afterwards), glob -> r_glob +=, h -> the next
+// lock-step's A = (q1 r_h) / dg from the per-trace tables (the expressions and their order as in aoa_rel_ca_kernel / aoa_rel_a_kernel:
+// r_feat bit-identical to the two-launch step).  One launch per lock-step instead of two.
+template <int EPI, bool FUSE = false>
+__global__ __launch_bounds__(1024, 1) void dense_ks_kernel(ConvArgs a, int m_tiles, int n_blocks, AoaStepFuse fz) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float wsum[16][4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,6 +305,59 @@ __global__ __launch_bounds__(1024, 1) void dense_ks_kernel(ConvArgs a, int m_til
     const int col = tid & 127, cb = col >> 5, cl = col & 31;
     const int oc = nblk * 128 + col;
     const int ncol = a.oc_split;
+    if constexpr (FUSE) {                                 // (EPI_REL, P = 1, no U, n_oc = oc_split = 3 H: host-checked - every column exists)
+        const int Hh = a.cin, T = fz.T, sNow = fz.s;
+        const int part = (nblk * 128) / Hh;               // 0 emb, 1 glob, 2 h (workgroup-uniform)
+        float rx[4];
+        int tm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 7) + 8 * i;
+            const long row = row0 + r;
+            tm[i] = row < rows ? fz.tmax[row] : -2;       // (-2: no such row; -1: the caption does not have the word)
+            rx[i] = 0.f;
+            if (row < rows) {
+                const float v = (red[((0 * 4 + cb) * 32 + r) * 33 + cl] + red[((1 * 4 + cb) * 32 + r) * 33 + cl]) +
+                                (red[((2 * 4 + cb) * 32 + r) * 33 + cl] + red[((3 * 4 + cb) * 32 + r) * 33 + cl]);
+                rx[i] = a.X[(long)a.map2img[row] * ncol + oc] * v;
+            }
+        }
+        if (part == 0) {
+            // per row the sum over the workgroup's 128 columns: the 64 lanes of a wave, then the two waves that hold the row
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = rx[i];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) wsum[wave][i] = v;
+            }
+            __syncthreads();
+            if (tid < 32) {
+                const long row = row0 + tid;
+                if (row < rows) {
+                    const int t = fz.tmax[row], gq = tid & 7, i = tid >> 3;
+                    if (sNow <= t) fz.wpart[(row * T + (t - sNow)) * 4 + (nblk & 3)] = wsum[2 * gq][i] + wsum[2 * gq + 1][i];
+                }
+            }
+        } else if (part == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long row = row0 + (tid >> 7) + 8 * i;
+                if (sNow <= tm[i]) fz.r_glob[row * Hh + (oc - Hh)] += rx[i];
+            }
+        } else if (sNow + 1 < T) {
+            const int ch = oc - 2 * Hh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long row = row0 + (tid >> 7) + 8 * i;
+                if (tm[i] == -2) continue;
+                float q1 = 0.f, dg = 1.f;                 // (a row that is not active at s + 1: A = 0)
+                if (sNow + 1 <= tm[i]) { const long ti = (row - sNow - 1) * Hh + ch; q1 = fz.q1[ti]; dg = fz.dg[ti]; }
+                fz.A_next[row * Hh + ch] = (q1 * rx[i]) / dg;
+            }
+        }
+        return;
+    }
     if (oc >= ncol || oc >= a.n_oc) return;
     float bias = 0.f;
     if (EPI == EPI_PLAIN && a.bias) bias = a.bias[oc];
@@ -338,7 +398,7 @@ static int launch_dense_small_t(const ConvArgs& a, hipStream_t stream) {
             static LdsOnce once_ks;
             LRPX_TRY(reserve_lds_once(once_ks, dense_ks_kernel<EPI>, LDS_KS_MAX, "dense_ks"));
             hipLaunchKernelGGL(dense_ks_kernel<EPI>, dim3((unsigned)(m_tiles * n_blocks)), dim3(1024), lds_ks, stream, a, m_tiles,
-                               n_blocks);
+                               n_blocks, AoaStepFuse{});
             return check_launch("dense_ks");
         }
     }
@@ -356,6 +416,25 @@ static int launch_dense_small_t(const ConvArgs& a, hipStream_t stream) {
 bool dense_small_fits(const ConvArgs& a) {
     return a.pix_per_map > 0 && (long)a.n_maps * a.pix_per_map <= 4096 && a.cin % 32 == 0 && a.cin <= 8192 && !a.out1 && a.out0 &&
            (a.epi == EPI_REL || a.epi == EPI_PLAIN);
+}
+
+// lock-step fz.s of the AoA relevance in the exact arithmetic: the gate rule's GEMM (K split over four waves) with the step's point-wise
+// code in its epilogue (FUSE above); weights from lrpx_pack_weights(PACK_DENSE_T, kc = 32)
+int launch_dense_ks_aoa_step(const ConvArgs& a, const AoaStepFuse& fz, hipStream_t stream) {
+    const long rows = (long)a.n_maps * a.pix_per_map;
+    LRPX_REQUIRE(a.cin == 512 && a.n_oc == 3 * a.cin && a.oc_split == a.n_oc && a.pix_per_map == 1 && !a.U && a.X && a.map2img,
+                 "dense_ks (AoA lock-step): built for E = H = K = 512, N = 1536, one row per map, x and map2img given");
+    LRPX_REQUIRE(rows > 0 && rows < 0x7fffffffL && fz.T > 0 && rows % fz.T == 0 && fz.s >= 0 && fz.s < fz.T && fz.q1 && fz.dg && fz.tmax &&
+                     fz.r_glob && fz.wpart && (fz.A_next || fz.s + 1 >= fz.T), "dense_ks (AoA lock-step): bad step arguments");
+    const int m_tiles = (int)ceil_div(rows, 32), n_blocks = a.n_oc / 128;
+    constexpr int RED = 16 * 32 * 33 * (int)sizeof(float);
+    const int lds = 32 * (a.cin + 4) * (int)sizeof(float);
+    constexpr int LDS_KS_MAX = 32 * (1024 + 4) * (int)sizeof(float);
+    auto kern = dense_ks_kernel<EPI_REL, true>;
+    static LdsOnce once;
+    LRPX_TRY(reserve_lds_once(once, kern, LDS_KS_MAX, "dense_ks (AoA lock-step)"));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_blocks)), dim3(1024), lds > RED ? lds : RED, stream, a, m_tiles, n_blocks, fz);
+    return check_launch("dense_ks (AoA lock-step)");
 }
 
 int launch_dense_small(const ConvArgs& a, hipStream_t stream) {

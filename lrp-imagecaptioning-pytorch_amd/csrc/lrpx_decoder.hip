@@ -2336,9 +2336,10 @@ int lrpx_aoa_rel_steps_fused(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* 
     LRPX_TRY(check_arel(tr, rs));
     const int T = tr->T, rows = tr->B * tr->T, H = tr->H;
     LRPX_REQUIRE(dense && idx && a_alt && wpart && coef && idx_ld >= rows, "aoa_rel_steps_fused: bad arguments");
-    LRPX_REQUIRE(dense->f16x3 == 1 && dense->taps == 1 && dense->epi == EPI_REL && dense->in == rs->A && dense->x && !dense->u &&
+    LRPX_REQUIRE((dense->f16x3 == 1 || (dense->f16x3 == 0 && !dense->bf16x6)) && dense->taps == 1 && dense->epi == EPI_REL && dense->in == rs->A && dense->x && !dense->u &&
                      dense->cin == H && tr->E == H && H == 512 && dense->n_oc == 3 * H && dense->oc_split == 3 * H && dense->n_maps == rows &&
-                     dense->pix_per_map == 1, "aoa_rel_steps_fused: the fused lock-step is built for E = H = 512 on the f16x3 gate rule");
+                     dense->pix_per_map == 1, "aoa_rel_steps_fused: the fused lock-step is built for E = H = 512 on the f16x3 gate rule or (f16x3 = 0: weights "
+                     "from lrpx_pack_weights, DENSE_T, kc = 32) on the fp32 MFMA");
     hipStream_t st = (hipStream_t)stream;
     LRPX_TRY(lrpx_aoa_rel_step(tr, rs, 0, 0, stream));                 // A of lock-step 0 (:1116-1120)
     ConvArgs a = {};
@@ -2355,7 +2356,8 @@ int lrpx_aoa_rel_steps_fused(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* 
         a.in = buf[s & 1];
         a.map2img = idx + (long)s * idx_ld;        // row -> source row of the multiplicand at lock-step s
         fz.s = s; fz.A_next = buf[(s + 1) & 1];
-        LRPX_TRY(launch_dense_small_f16x3_aoa_step(a, fz, st));
+        if (dense->f16x3) LRPX_TRY(launch_dense_small_f16x3_aoa_step(a, fz, st));
+        else LRPX_TRY(launch_dense_ks_aoa_step(a, fz, st));
     }
     hipLaunchKernelGGL(rel_words_norm_parts_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, rs->r_words, wpart, rs->lens, rows, T);
     return check_launch("rel_words_norm_parts");

@@ -110,6 +110,7 @@ class AOAEngine:
         # ... and the lock-step gate rule / the aoa_linear rule (rows = images x words): the few-row kernel of the same file
         self.fused_steps = True          # decoder steps as 4 launches instead of 7 (False: the unfused kernels; A/B and tests)
         self.fused_rel = True            # relevance lock-steps as ONE launch each (False: GEMM + point-wise kernel; A/B and tests)
+        self.fused_rel_exact = True      # ... also while the decoder GEMMs are exact (modes 0 / 1): dense_ks_kernel<REL, FUSE> (False: two launches; A/B and tests)
         self.lockstep_f16 = H % 16 == 0 and E % 16 == 0
         self.p_wg_h = ops.pack_weights_f16x2(wg, H, E + 2 * H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
         self.p_lin_rel_h = ops.pack_weights_f16x2(sd["decoder_aoa_linear.weight"], H, H, _lib.PACK_BWD_PLAIN, taps=1) if self.lockstep_f16 else None
@@ -503,7 +504,7 @@ class AOAEngine:
         # the lock-steps s = 0..T-1 (:1114-1134) in one native call: phase 0, the LSTM dense rule with map2img = idx[s], phase 1
         dense = ops.conv_desc(rs["A"], self.p_wg_h if f16 else self.p_wg, rows, 0, H, W, 1, EPI_REL, pix_per_map=1, oc_split=W,
                               x=tr["xh"], map2img=idx[0], out0=rs["rx"], f16x3=f16)
-        fused = self.fused_rel and f16 and E == H == 512
+        fused = self.fused_rel and E == H == 512 and (f16 or self.fused_rel_exact)     # (exact modes: the same fusion in the fp32 K-split kernel, csrc/dense_small.hip)
         if fused:      # one launch per lock-step: the step's point-wise code in the GEMM's epilogue (lrpx_aoa_rel_steps_fused)
             a_alt, wpart, coef = e(rows, H), e(rows, T, 4), e(2 * rows * H + rows)
             check(lib.lrpx_aoa_rel_steps_fused(ctr, crs, C.byref(dense), ptr(idx), idx.shape[1], ptr(a_alt), ptr(wpart), ptr(coef), st))

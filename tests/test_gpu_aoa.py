@@ -197,8 +197,9 @@ def test_aoa_decoupled_trace_matches_the_stepwise_trace(bu):
             assert e < 1e-5, (k, grad, e)
 
 
+@pytest.mark.parametrize("f16", [False, True], ids=["decoder-fp32", "decoder-f16x3"])
 @pytest.mark.parametrize("bu", [False, True])
-def test_aoa_fused_lock_steps_match_the_two_launch_steps(bu):
+def test_aoa_fused_lock_steps_match_the_two_launch_steps(bu, f16):
     """The relevance lock-steps with the step's point-wise code inside the gate rule's GEMM (lrpx_aoa_rel_steps_fused: one launch per
     step, r_xh never stored) against GEMM + point-wise kernel: the same expressions in the same order, so r_feat - everything behind
     r_h and r_glob - is bit-identical; r_words sums its 512 embedding columns in another order (four 128-column partial sums): equal
@@ -216,7 +217,7 @@ def test_aoa_fused_lock_steps_match_the_two_launch_steps(bu):
         enc = eng.encode(torch.from_numpy(weights.make_images(36, B)))
     cap = torch.from_numpy(weights.make_captions(37, B, T, V)).cuda()
     tr = eng.trace(enc, cap, predictions=False)
-    eng.force_f16 = True          # (the fused lock-step is the fp16 split-product kernel's epilogue: speed modes / LRPX_DECODER_F16=1)
+    eng.force_f16 = f16           # the fusion exists in both arithmetics: the fp16 split-product kernel (speed modes) and the fp32 K-split kernel (default)
     assert eng.fused_rel
     for head, lens in ((0, None), (6, [9, 2, 5, 0, 9])):
         a_feat, a_words, _ = eng.relevance(enc, tr, head, lens, compact=False)
