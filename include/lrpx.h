@@ -532,8 +532,9 @@ int lrpx_aoa_rel_step(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int
 int lrpx_aoa_rel_steps(const lrpx_aoa_trace* tr, const lrpx_aoa_relstate* rs, int n_steps, const lrpx_conv_desc* dense,
                        const int32_t* idx, int idx_ld, void* stream);
 /* All T lock-steps with ONE launch each: the step's point-wise code (:1116-1120 of the next step, :1129-1133 of this one) runs in the
- * epilogue of the gate rule's GEMM, r_xh is never stored (csrc/dense_f16x3.hip, FUSE).  `dense` as above and on the f16x3 kernel
- * (f16x3 = 1, in = rs->A, no addend; E = H = 512); a_alt: a second [B*T][H] buffer (the steps ping-pong between rs->A and it);
+ * epilogue of the gate rule's GEMM, r_xh is never stored.  `dense` as above (in = rs->A, no addend; E = H = 512) and either on the fp16
+ * split products (f16x3 = 1: csrc/dense_f16x3.hip, FUSE) or - round 6, the exact arithmetic of the default mode - on the fp32 MFMA with K split
+ * over four waves (f16x3 = 0, wpacked from lrpx_pack_weights(DENSE_T, kc = 32): csrc/dense_small.hip, dense_ks_kernel<REL, FUSE>); a_alt: a second [B*T][H] buffer (the steps ping-pong between rs->A and it);
  * wpart: [B*T][T][4] scratch for the partial sums of r_words; coef: [2 * B*T*H + B*T] floats of scratch (per-trace coefficient tables of
  * :1116-1120 and the rows' last active step).  rs->r_words comes out NORMALISED (lrpx_rel_words_norm included); rs->rx
  * and rs->r_hn are not used.  Values equal to the two-launch steps up to the summation order of r_words. */
