@@ -35,6 +35,14 @@ def test_dense_rel_few_rows(ops, rows, k, n, n_src):
     torch.cuda.synchronize()
     want = x[src.long()].double() * (a.double() @ w.double())
     assert rel_err(out.cpu(), want) < 2e-6
+    # ... with the addend U (one row per map here): x * (A W + U) - K >= 512 runs the four-wave K-split kernel (dense_ks_kernel<REL>, round 6)
+    u = torch.randn(rows, n, generator=g) * 3.0
+    out2 = torch.full((rows, n), float("nan"), device="cuda")
+    ops.conv_mfma(a.cuda(), wp, rows, 0, k, n_pad, 1, _lib.EPI_REL, pix_per_map=1, oc_split=n, x=x.cuda(), u=u.cuda(),
+                  map2img=src.cuda(), out0=out2)
+    torch.cuda.synchronize()
+    want2 = x[src.long()].double() * (a.double() @ w.double() + u.double())
+    assert rel_err(out2.cpu(), want2) < 2e-6
 
 
 @pytest.mark.parametrize("rows,k,n,relu", [(320, 512, 1536, 0), (16, 64, 96, 1), (320, 2048, 1536, 0), (100, 1056, 64, 0)])
